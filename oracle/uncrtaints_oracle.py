@@ -1,0 +1,404 @@
+"""CPU oracle for the UnCRtainTS `--model uncrtaints` hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain PyTorch-CPU fp32 restatement of the
+reference algorithm (forward of the network + the MGNLL loss; backward through
+torch.autograd).  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s
+`cpu_baseline` leg may import it -- never the product path in `uncrtaints_amd/`.
+
+Parity status: PINNED.  `tests/golden/make_golden.py` imports the reference from
+/root/reference in the build container and records inputs/outputs/gradients; the
+fixtures are committed under `tests/golden/` and `tests/test_oracle_golden.py` checks
+this restatement against them (the reference itself never travels to the GPU box).
+
+Every function cites the reference file:line (relative to /root/reference) it follows.
+Parameters are passed as a flat dict with the reference's `state_dict()` key names
+(SURVEY.md section 8(b)), so a reference checkpoint can be fed in unchanged.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+S2_BANDS = 13
+Tensor = torch.Tensor
+
+
+@dataclass
+class OracleConfig:
+    """Constructor arguments of UNCRTAINTS (model/src/backbones/uncrtaints.py:231-254)."""
+    input_dim: int = 15
+    encoder_widths: List[int] = field(default_factory=lambda: [128])
+    decoder_widths: List[int] = field(default_factory=lambda: [128] * 5)
+    out_conv: List[int] = field(default_factory=lambda: [26])
+    out_nonlin_mean: bool = True
+    out_nonlin_var: str = "softplus"
+    agg_mode: str = "att_group"
+    encoder_norm: str = "group"
+    decoder_norm: str = "batch"
+    n_head: int = 16
+    d_model: int = 256
+    d_k: int = 4
+    pad_value: float = 0.0
+    positional_encoding: bool = True
+    covmode: str = "diag"
+    scale_by: float = 1.0
+    T_period: int = 1000          # ltae.py:152
+    att_down: int = 32            # uncrtaints.py:403 (hard-coded)
+    attn_dropout: float = 0.1     # uncrtaints.py:154
+
+    @property
+    def covar_dim(self) -> int:   # uncrtaints.py:357-365
+        return {"uni": S2_BANDS, "iso": 1, "diag": S2_BANDS}.get(self.covmode, 0)
+
+    @property
+    def mean_idx(self) -> int:    # uncrtaints.py:367
+        return S2_BANDS
+
+    @property
+    def vars_idx(self) -> int:    # uncrtaints.py:368
+        return S2_BANDS + self.covar_dim
+
+    @property
+    def eps(self) -> float:       # uncrtaints.py:374
+        return 1e-9 if self.scale_by == 1.0 else 1e-3
+
+
+# --------------------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------------------
+
+def gelu_exact(x: Tensor) -> Tensor:
+    """nn.GELU() default = exact erf form (uncrtaints.py:128,133,88)."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def group_norm(x: Tensor, groups: int, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    """nn.GroupNorm over (C/groups channels x all trailing dims) per sample, biased variance.
+    Used at utae.py:470-473 (n_groups=4), uncrtaints.py:16-22, ltae.py:191-194."""
+    n, c = x.shape[:2]
+    xg = x.reshape(n, groups, -1)
+    mu = xg.mean(dim=-1, keepdim=True)
+    var = xg.var(dim=-1, unbiased=False, keepdim=True)
+    xn = ((xg - mu) * torch.rsqrt(var + eps)).reshape(x.shape)
+    shape = [1, c] + [1] * (x.dim() - 2)
+    return xn * w.view(shape) + b.view(shape)
+
+
+def batch_norm(x: Tensor, w: Tensor, b: Tensor, running_mean: Tensor, running_var: Tensor,
+               training: bool, momentum: float = 0.1, eps: float = 1e-5,
+               update_running: bool = True) -> Tensor:
+    """nn.BatchNorm2d (uncrtaints.py:17-18): batch statistics (biased var) in train mode, running
+    statistics in eval mode; running buffers are updated in place with the unbiased variance."""
+    c = x.shape[1]
+    if training:
+        mu = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        if update_running:
+            with torch.no_grad():
+                m = x.numel() / c
+                running_mean.mul_(1 - momentum).add_(momentum * mu.detach())
+                running_var.mul_(1 - momentum).add_(momentum * var.detach() * m / max(m - 1, 1))
+    else:
+        mu, var = running_mean, running_var
+    xn = (x - mu.view(1, c, 1, 1)) * torch.rsqrt(var.view(1, c, 1, 1) + eps)
+    return xn * w.view(1, c, 1, 1) + b.view(1, c, 1, 1)
+
+
+def conv1x1(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    """Conv2d(kernel 1) on [N,C,H,W]; w is [Cout,Cin,1,1] (utae.py:476-484, uncrtaints.py:126,136)."""
+    y = torch.einsum("oc,nchw->nohw", w.reshape(w.shape[0], w.shape[1]), x)
+    if b is not None:
+        y = y + b.view(1, -1, 1, 1)
+    return y
+
+
+def depthwise3x3_reflect(x: Tensor, w: Tensor) -> Tensor:
+    """Conv2d(C,C,3,padding=1,padding_mode='reflect',groups=C,bias=False) (uncrtaints.py:130-131).
+    w is [C,1,3,3]; cross-correlation (no kernel flip)."""
+    xp = F.pad(x, (1, 1, 1, 1), mode="reflect")
+    h, wd = x.shape[-2:]
+    out = torch.zeros_like(x)
+    for i in range(3):
+        for j in range(3):
+            out = out + xp[:, :, i:i + h, j:j + wd] * w[:, 0, i, j].view(1, -1, 1, 1)
+    return out
+
+
+def squeeze_excite(x: Tensor, w1: Tensor, w2: Tensor) -> Tensor:
+    """SE block (uncrtaints.py:82-97): global avg-pool -> Linear(no bias) -> GELU -> Linear(no bias)
+    -> sigmoid -> channel scale."""
+    y = x.mean(dim=(2, 3))
+    y = gelu_exact(y @ w1.t())
+    y = torch.sigmoid(y @ w2.t())
+    return x * y[:, :, None, None]
+
+
+class _NormCtx:
+    """Selects GroupNorm(4) (encoder) or BatchNorm2d (decoder) for one MBConv (uncrtaints.py:16-22)."""
+
+    def __init__(self, params: Dict[str, Tensor], kind: str, training: bool, update_running: bool):
+        self.p, self.kind, self.training, self.update = params, kind, training, update_running
+
+    def __call__(self, x: Tensor, prefix: str) -> Tensor:
+        w, b = self.p[prefix + ".weight"], self.p[prefix + ".bias"]
+        if self.kind == "group":
+            return group_norm(x, 4, w, b)
+        if self.kind == "batch":
+            return batch_norm(x, w, b, self.p[prefix + ".running_mean"], self.p[prefix + ".running_var"],
+                              self.training, update_running=self.update)
+        raise NotImplementedError(self.kind)
+
+
+def mbconv(x: Tensor, p: Dict[str, Tensor], prefix: str, norm: str, training: bool,
+           update_running: bool = True, taps: Optional[dict] = None) -> Tensor:
+    """MBConv(inp, oup, expansion=2) without down-sampling (uncrtaints.py:100-146):
+    x + Norm(pw2(SE(GELU(Norm(dw3x3(GELU(Norm(pw1(PreNorm(x)))))))))).  `prefix` e.g. 'in_block.0'."""
+    nrm = _NormCtx(p, norm, training, update_running)
+    a = nrm(x, prefix + ".conv.norm")                                   # PreNorm (uncrtaints.py:72-79,140)
+    h1 = conv1x1(a, p[prefix + ".conv.fn.0.weight"])                    # pw 128->256
+    g1 = gelu_exact(nrm(h1, prefix + ".conv.fn.1"))
+    h2 = depthwise3x3_reflect(g1, p[prefix + ".conv.fn.3.weight"])      # dw 3x3 reflect
+    g2 = gelu_exact(nrm(h2, prefix + ".conv.fn.4"))
+    z = squeeze_excite(g2, p[prefix + ".conv.fn.6.fc.0.weight"], p[prefix + ".conv.fn.6.fc.2.weight"])
+    h3 = conv1x1(z, p[prefix + ".conv.fn.7.weight"])                    # pw-linear 256->128
+    u3 = nrm(h3, prefix + ".conv.fn.8")
+    if taps is not None:
+        taps[prefix + ".h1"], taps[prefix + ".h2"], taps[prefix + ".h3"] = h1, h2, h3
+    return x + u3
+
+
+def positional_table(dates: Tensor, d: int, T: int, repeat: int) -> Tensor:
+    """PositionalEncoder (positional_encoding.py:5-31): [B,T] dates -> [B,T,d*repeat].
+    denom_i = T^(2*(i//2)/d); even i -> sin, odd i -> cos; tiled `repeat` times along channels."""
+    i = torch.arange(d, dtype=torch.float32)
+    denom = torch.pow(torch.tensor(float(T)), 2.0 * torch.div(i, 2, rounding_mode="floor") / d)
+    tab = dates[:, :, None] / denom[None, None, :]
+    even = (torch.arange(d) % 2 == 0)
+    tab = torch.where(even[None, None, :], torch.sin(tab), torch.cos(tab))
+    return tab.repeat(1, 1, repeat)
+
+
+def ltae_tiny_attention(down: Tensor, dates: Tensor, pad_mask: Tensor, p: Dict[str, Tensor],
+                        cfg: OracleConfig) -> Tensor:
+    """LTAE2dtiny.forward + MultiHeadAttentionSmall + ScaledDotProductAttentionSmall
+    (ltae.py:197-239, 341-385, 431-458).  down [B,T,C,h,w] -> attention [n_head,B,T,h,w]."""
+    B, T, C, h, w = down.shape
+    nh, dk = cfg.n_head, cfg.d_k
+    x = down.permute(0, 3, 4, 2, 1).reshape(B * h * w, C, T)            # per low-res pixel: [C,T]
+    x = group_norm(x, nh, p["temporal_encoder.in_norm.weight"], p["temporal_encoder.in_norm.bias"])
+    wi = p["temporal_encoder.inconv.weight"][:, :, 0]                   # Conv1d k=1: [d_model,C]
+    y = torch.einsum("oc,nct->nto", wi, x) + p["temporal_encoder.inconv.bias"]   # [n,T,d_model]
+    if cfg.positional_encoding:
+        pe = positional_table(dates, cfg.d_model // nh, cfg.T_period, nh)         # [B,T,d_model]
+        y = y + pe[:, None, :, :].expand(B, h * w, T, cfg.d_model).reshape(B * h * w, T, cfg.d_model)
+    k = y @ p["temporal_encoder.attention_heads.fc1_k.weight"].t() \
+        + p["temporal_encoder.attention_heads.fc1_k.bias"]              # [n,T,nh*dk]
+    k = k.view(B * h * w, T, nh, dk)
+    q = p["temporal_encoder.attention_heads.Q"]                          # [nh,dk]
+    score = torch.einsum("hd,nthd->hnt", q, k) / math.sqrt(dk)           # temperature = sqrt(d_k)
+    pm = pad_mask[:, None, :].expand(B, h * w, T).reshape(B * h * w, T)
+    score = score.masked_fill(pm[None], -1e3)                            # ltae.py:435
+    attn = torch.softmax(score, dim=2)                                   # over T
+    return attn.view(nh, B, h, w, T).permute(0, 1, 4, 2, 3)
+
+
+def temporal_aggregate(x: Tensor, pad_mask: Tensor, attn: Tensor, cfg: OracleConfig,
+                       training: bool, dropout_mask: Optional[Tensor] = None) -> Tensor:
+    """Compact_Temporal_Aggregator, mode 'att_group' (uncrtaints.py:156-221).
+    x [B,T,C,H,W], attn [nh,B,T,h,w] -> [B,C,H,W].  `dropout_mask` (if given, shape
+    [nh*B,T,H,W], values in {0, 1/(1-p)}) replaces the stochastic nn.Dropout in train mode."""
+    nh, B, T, h, w = attn.shape
+    H, W = x.shape[-2:]
+    a = attn.reshape(nh * B, T, h, w)
+    if H > w:
+        a = F.interpolate(a, size=(H, W), mode="bilinear", align_corners=False)
+        if training:
+            if dropout_mask is not None:
+                a = a * dropout_mask
+            elif cfg.attn_dropout > 0:
+                a = F.dropout(a, cfg.attn_dropout, training=True)
+    else:
+        a = F.avg_pool2d(a, kernel_size=w // H)
+    a = a.view(nh, B, T, H, W)
+    if bool(pad_mask.any()):
+        a = a * (~pad_mask).float()[None, :, :, None, None]
+    C = x.shape[2]
+    xg = x.view(B, T, nh, C // nh, H, W)                                  # channel c -> head c // (C/nh)
+    out = torch.einsum("hbtyx,bthcyx->bhcyx", a, xg)
+    return out.reshape(B, C, H, W)
+
+
+def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, training: bool = False,
+            dropout_mask: Optional[Tensor] = None, update_running: bool = True,
+            taps: Optional[dict] = None) -> Tensor:
+    """UNCRTAINTS.forward (uncrtaints.py:391-447).  x [B,T,Cin,H,W], dates [B,T] -> [B,1,13+covar,H,W]."""
+    B, T, Cin, H, W = x.shape
+    pad_mask = (x == cfg.pad_value).all(dim=-1).all(dim=-1).all(dim=-1)   # [B,T]
+    f = x.reshape(B * T, Cin, H, W)                                       # smart_forward, utae.py:422-450
+    c0 = conv1x1(f, p["in_conv.conv.conv.0.weight"], p["in_conv.conv.conv.0.bias"])
+    a0 = torch.relu(group_norm(c0, 4, p["in_conv.conv.conv.1.weight"], p["in_conv.conv.conv.1.bias"]))
+    e = mbconv(a0, p, "in_block.0", cfg.encoder_norm, training, update_running, taps)
+    C = e.shape[1]
+    down = F.adaptive_max_pool2d(e, (cfg.att_down, cfg.att_down)).view(B, T, C, cfg.att_down, cfg.att_down)
+    attn = ltae_tiny_attention(down, dates, pad_mask, p, cfg)
+    g = temporal_aggregate(e.view(B, T, C, H, W), pad_mask, attn, cfg, training, dropout_mask)
+    if taps is not None:
+        taps.update(c0=c0, a0=a0, e=e, down=down, attn=attn, agg=g)
+    out = g
+    for i in range(len(cfg.decoder_widths)):
+        out = mbconv(out, p, f"out_block.{i}", cfg.decoder_norm, training, update_running, taps)
+        if taps is not None:
+            taps[f"dec{i}"] = out
+    o = conv1x1(out, p["out_conv.conv.conv.0.weight"], p["out_conv.conv.conv.0.bias"]).unsqueeze(1)
+    if taps is not None:
+        taps["pre_head"] = o
+    mean = o[:, :, :cfg.mean_idx]
+    if cfg.out_nonlin_mean:
+        mean = cfg.scale_by * torch.sigmoid(mean)                          # uncrtaints.py:384
+    if not cfg.covmode:
+        return mean
+    var = F.softplus(o[:, :, cfg.mean_idx:cfg.vars_idx], beta=1, threshold=20) + cfg.eps   # :225
+    return torch.cat((mean, var), dim=2)
+
+
+# --------------------------------------------------------------------------------------
+# MGNLL (losses.py:131-218)
+# --------------------------------------------------------------------------------------
+
+def mgnll_per_pixel(pred: Tensor, target: Tensor, var: Tensor, mode: str = "diag",
+                    eps: float = 1e-8) -> Tensor:
+    """Un-reduced loss, laid out [W,H,B] like the reference's double vmap over the last two dims.
+
+    L[x,y,b] = k/2 ln(2 pi) + 1/2 sum_{b',c} ln v[b',c,y,x] + 1/2 max(nan_to_num(maha[b,y,x]), 1e-9)
+    with v = clamp(var, eps) applied without gradient effect (losses.py:203-205) and the log-det summed
+    over the batch AND channels (losses.py:138 -- `var.log().sum()` inside the per-pixel function)."""
+    if mode == "iso":
+        var = var.expand(-1, -1, S2_BANDS, -1, -1)                         # losses.py:190-192
+    if torch.any(var < 0):
+        raise ValueError("var has negative entry/entries")                 # losses.py:199-200
+    v = var + (var.detach().clamp(min=eps) - var.detach())                 # clamp, identity gradient
+    pred, target, v = pred[:, 0], target[:, 0], v[:, 0]                    # T==1
+    k = pred.shape[1]
+    logdet = v.log().sum(dim=(0, 1))                                       # [H,W], over B and C
+    maha = (((pred - target) ** 2) / v).sum(dim=1)                         # [B,H,W]
+    maha = torch.nan_to_num(maha).clamp(min=1e-9)
+    loss = 0.5 * k * math.log(2 * math.pi) + 0.5 * logdet[None] + 0.5 * maha
+    loss = loss.permute(2, 1, 0)                                           # [W,H,B]
+    return loss[..., 0] if loss.shape[-1] == 1 else loss                   # losses.py:141 .squeeze() drops B==1
+
+
+def mgnll(pred: Tensor, target: Tensor, var: Tensor, mode: str = "diag", eps: float = 1e-8,
+          reduction: str = "mean", want_covariance: bool = False):
+    """multi_gaussian_nll_loss (losses.py:149-218) -> (loss, variance).  The dense covariance
+    `diag_embed(v)` [B,1,13,13,H,W] is only materialised on request (it is used for logging only)."""
+    if reduction not in ("none", "mean", "sum"):
+        raise ValueError(reduction + " is not valid")
+    loss = mgnll_per_pixel(pred, target, var, mode, eps)
+    variance = None
+    if want_covariance:
+        v = var.expand(-1, -1, S2_BANDS, -1, -1) if mode == "iso" else var
+        v = v.detach().clamp(min=eps)[:, 0]                                 # [B,13,H,W]
+        variance = torch.diag_embed(v.permute(0, 2, 3, 1)).permute(0, 3, 4, 1, 2).unsqueeze(1)
+    if reduction == "mean":
+        return loss.mean(), variance
+    if reduction == "sum":
+        return loss.sum(), variance
+    return loss, variance
+
+
+def loss_from_output(out: Tensor, target: Tensor, cfg: OracleConfig):
+    """BaseModel.get_loss_G slicing (base_model.py:80-85)."""
+    return mgnll(out[:, :, :cfg.mean_idx], target, out[:, :, cfg.mean_idx:cfg.vars_idx], mode=cfg.covmode)[0]
+
+
+# --------------------------------------------------------------------------------------
+# ensemble combine (ensemble_reconstruct.py:116-133)
+# --------------------------------------------------------------------------------------
+
+def ensemble_combine(means: Tensor, variances: Tensor, mode: str = "both"):
+    """means [M,...], variances [M,...] -> (mean_ens, var_ens).
+    'both': var = mean_i(var_i + mu_i^2) - mu_ens^2; 'aleatoric': mean_i var_i;
+    'epistemic': mean_i mu_i^2 - mu_ens^2."""
+    mu = means.mean(dim=0)
+    if mode == "both":
+        var = (variances + means ** 2).mean(dim=0) - mu ** 2
+    elif mode == "aleatoric":
+        var = variances.mean(dim=0)
+    elif mode == "epistemic":
+        var = (means ** 2).mean(dim=0) - mu ** 2
+    else:
+        raise ValueError(mode)
+    return mu, var
+
+
+# --------------------------------------------------------------------------------------
+# parameter construction (reference-style init; weight_init.py:4-74, ltae.py:324-337)
+# --------------------------------------------------------------------------------------
+
+def init_params(cfg: OracleConfig, seed: int = 1) -> Dict[str, Tensor]:
+    """Build a parameter dict with the reference's state_dict key names and shapes, initialised in the
+    style of `netG.apply(weight_init)` (Conv2d/Linear xavier-normal + N(0,1) bias, Conv1d N(0,1),
+    BatchNorm weight N(0,1) bias 0, GroupNorm default 1/0, Q ~ N(0, sqrt(2/d_k))).  Not bit-identical to
+    the reference's RNG stream -- golden fixtures carry the actual reference weights."""
+    g = torch.Generator().manual_seed(seed)
+    p: Dict[str, Tensor] = {}
+
+    def xavier(*shape):
+        fan_out, fan_in = shape[0], shape[1]
+        rf = 1
+        for s in shape[2:]:
+            rf *= s
+        std = math.sqrt(2.0 / ((fan_in + fan_out) * rf))
+        return torch.randn(*shape, generator=g) * std
+
+    def randn(*shape):
+        return torch.randn(*shape, generator=g)
+
+    def norm_params(prefix, c, kind):
+        if kind == "batch":
+            p[prefix + ".weight"], p[prefix + ".bias"] = randn(c), torch.zeros(c)
+            p[prefix + ".running_mean"], p[prefix + ".running_var"] = torch.zeros(c), torch.ones(c)
+            p[prefix + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+        else:
+            p[prefix + ".weight"], p[prefix + ".bias"] = torch.ones(c), torch.zeros(c)
+
+    def mb(prefix, c, kind):
+        hd = 2 * c
+        norm_params(prefix + ".conv.norm", c, kind)
+        p[prefix + ".conv.fn.0.weight"] = xavier(hd, c, 1, 1)
+        norm_params(prefix + ".conv.fn.1", hd, kind)
+        p[prefix + ".conv.fn.3.weight"] = xavier(hd, 1, 3, 3)
+        norm_params(prefix + ".conv.fn.4", hd, kind)
+        p[prefix + ".conv.fn.6.fc.0.weight"] = xavier(int(c * 0.25), hd)
+        p[prefix + ".conv.fn.6.fc.2.weight"] = xavier(hd, int(c * 0.25))
+        p[prefix + ".conv.fn.7.weight"] = xavier(c, hd, 1, 1)
+        norm_params(prefix + ".conv.fn.8", c, kind)
+
+    c = cfg.encoder_widths[0]
+    p["in_conv.conv.conv.0.weight"], p["in_conv.conv.conv.0.bias"] = xavier(c, cfg.input_dim, 1, 1), randn(c)
+    norm_params("in_conv.conv.conv.1", c, cfg.encoder_norm)
+    mb("in_block.0", c, cfg.encoder_norm)
+    p["temporal_encoder.inconv.weight"], p["temporal_encoder.inconv.bias"] = randn(cfg.d_model, c, 1), randn(cfg.d_model)
+    p["temporal_encoder.attention_heads.Q"] = randn(cfg.n_head, cfg.d_k) * math.sqrt(2.0 / cfg.d_k)
+    p["temporal_encoder.attention_heads.fc1_k.weight"] = xavier(cfg.n_head * cfg.d_k, cfg.d_model)
+    p["temporal_encoder.attention_heads.fc1_k.bias"] = randn(cfg.n_head * cfg.d_k)
+    p["temporal_encoder.in_norm.weight"], p["temporal_encoder.in_norm.bias"] = torch.ones(c), torch.zeros(c)
+    for i, cw in enumerate(cfg.decoder_widths):
+        mb(f"out_block.{i}", cw, cfg.decoder_norm)
+    oc = cfg.out_conv[-1]
+    p["out_conv.conv.conv.0.weight"], p["out_conv.conv.conv.0.bias"] = xavier(oc, cfg.decoder_widths[0], 1, 1), randn(oc)
+    return p
+
+
+def synthetic_batch(B: int, T: int, H: int, W: int, seed: int = 1, input_dim: int = 15):
+    """Synthetic inputs of SURVEY.md section 8(d): x~U[0,1) [B,T,15,H,W], y~U[0,1) [B,1,13,H,W],
+    dates = sorted randint(1400,1800) as float (data/dataLoader.py:36-59 value ranges)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, T, input_dim, H, W, generator=g)
+    y = torch.rand(B, 1, S2_BANDS, H, W, generator=g)
+    dates = torch.sort(torch.randint(1400, 1800, (B, T), generator=g), dim=1).values.float()
+    return x, y, dates

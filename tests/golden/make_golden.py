@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""Generate golden fixtures by importing the UnCRtainTS reference (read-only) from /root/reference.
+
+Run ONLY in the build container (the reference does not exist on the GPU box):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden.py
+
+Writes `*.npz` next to this file.  The fixtures hold data only (inputs, weights, expected outputs,
+gradients, checksums); no reference source travels.  SURVEY.md section 8(c) lists the cases (G1..G7).
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path[:0] = [os.path.join(REF, "model"), REF]
+
+# `src.model_utils` / `base_model` import fvcore only for --profile; stub it.
+_fv = types.ModuleType("fvcore"); _fvnn = types.ModuleType("fvcore.nn")
+_fvnn.FlopCountAnalysis = object; _fvnn.flop_count_table = lambda *a, **k: ""
+_fv.nn = _fvnn
+sys.modules.setdefault("fvcore", _fv); sys.modules.setdefault("fvcore.nn", _fvnn)
+
+os.chdir("/tmp")  # model_utils.py:4-5 chdirs into ./model if it exists
+from src.backbones import uncrtaints  # noqa: E402
+from src.backbones.positional_encoding import PositionalEncoder  # noqa: E402
+from src import losses  # noqa: E402
+from src.learning.weight_init import weight_init  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def np_state(sd):
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+def proj_vec(n, seed=1234):
+    return np.random.default_rng(seed).standard_normal(n).astype(np.float64)
+
+
+def checksum(a):
+    """(sum, abs-sum, random projection) in float64 -- compact stand-in for a full tensor."""
+    a = np.asarray(a, dtype=np.float64).ravel()
+    return np.array([a.sum(), np.abs(a).sum(), float(a @ proj_vec(a.size))])
+
+
+def build(covmode, seed):
+    torch.manual_seed(seed)
+    out_c = 13 + (13 if covmode == "diag" else 1)
+    m = uncrtaints.UNCRTAINTS(input_dim=15, out_conv=[out_c], out_nonlin_mean=True, out_nonlin_var="softplus",
+                              covmode=covmode, scale_by=1.0)
+    m.apply(weight_init)
+    # non-trivial BatchNorm running statistics so eval mode is a real test
+    g = torch.Generator().manual_seed(seed + 100)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=g))
+            mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g))
+    # non-trivial GroupNorm affine (weight_init leaves them at 1/0)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.GroupNorm):
+            mod.weight.data.copy_(1.0 + 0.3 * torch.randn(mod.weight.shape, generator=g))
+            mod.bias.data.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+    m.temporal_aggregator.attn_dropout.p = 0.0     # deterministic train mode
+    return m
+
+
+def synth(B, T, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, T, 15, H, W, generator=g)
+    y = torch.rand(B, 1, 13, H, W, generator=g)
+    dates = torch.sort(torch.randint(1400, 1800, (B, T), generator=g), dim=1).values.float()
+    return x, y, dates
+
+
+def crit(covmode):
+    return losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode=covmode, chunk=None)
+
+
+def case_model(name, covmode, B, T, H, W, seed, full_grads, pad_last=False, save_state=True, taps=True):
+    m = build(covmode, seed)
+    x, y, dates = synth(B, T, H, W, seed)
+    if pad_last:
+        x[0, T - 1] = 0.0
+    state0 = np_state(m.state_dict())
+    out = {"x": x.numpy(), "y": y.numpy(), "dates": dates.numpy(),
+           "meta": json.dumps(dict(covmode=covmode, B=B, T=T, H=H, W=W, seed=seed, pad_last=pad_last))}
+    if save_state:
+        for k, v in state0.items():
+            out["state/" + k] = v
+
+    # ---- eval-mode forward (running stats) ----
+    m.eval()
+    feats = {}
+    hooks = []
+    if taps:
+        hooks.append(m.temporal_encoder.register_forward_hook(lambda mod, i, o: feats.__setitem__("attn", o.detach())))
+        hooks.append(m.temporal_aggregator.register_forward_hook(lambda mod, i, o: feats.__setitem__("agg", o.detach())))
+        # smart_forward (utae.py:422-450) calls .forward directly, so tap by wrapping the bound method
+        def tap(mod, key):
+            orig = mod.forward
+            def wrapped(inp):
+                o = orig(inp); feats[key] = o.detach(); return o
+            mod.forward = wrapped
+            class _H:
+                def remove(self_inner): del mod.forward
+            return _H()
+        hooks.append(tap(m.in_block[0], "e"))
+        hooks.append(tap(m.in_conv, "a0"))
+    with torch.no_grad():
+        o_eval = m(x, batch_positions=dates)
+        vi = m.vars_idx
+        l_eval, _ = crit(covmode)(o_eval[:, :, :13], y, o_eval[:, :, 13:vi])
+    for h in hooks:
+        h.remove()
+    out["eval/out"] = o_eval.numpy()
+    out["eval/loss"] = np.array(l_eval.item())
+    if taps:
+        out["eval/attn"] = feats["attn"].contiguous().numpy()          # [16,B,T,32,32]
+        e = feats["e"].reshape(B, T, 128, H, W)
+        out["eval/e_b0t0"] = e[0, 0, ::16].contiguous().numpy()        # 8 channels of one frame
+        out["eval/e_checksum"] = checksum(e.numpy())
+        out["eval/agg_b0"] = feats["agg"][0, ::16].contiguous().numpy()
+        out["eval/agg_checksum"] = checksum(feats["agg"].numpy())
+        out["eval/a0_checksum"] = checksum(feats["a0"].numpy())
+
+    # ---- train-mode forward + MGNLL + backward (dropout p=0, batch-stat BN) ----
+    m.train()
+    xg = x.clone().requires_grad_(True)
+    o_tr = m(xg, batch_positions=dates)
+    l_tr, _ = crit(covmode)(o_tr[:, :, :13], y, o_tr[:, :, 13:m.vars_idx])
+    l_tr.backward()
+    out["train/out"] = o_tr.detach().numpy()
+    out["train/loss"] = np.array(l_tr.item())
+    out["train/dx_checksum"] = checksum(xg.grad.numpy())
+    out["train/dx_b0t0"] = xg.grad[0, 0].numpy()
+    for k, v in m.named_parameters():
+        g = v.grad.numpy()
+        if full_grads:
+            out["grad/" + k] = g
+        out["gradsum/" + k] = checksum(g)
+    state1 = np_state(m.state_dict())
+    for k, v in state1.items():
+        if "running_" in k:
+            out["train/state/" + k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "eval loss", l_eval.item(), "train loss", l_tr.item())
+
+
+def case_mgnll():
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    idx = 0
+    for mode in ("diag", "iso"):
+        for B in (1, 2, 4):
+            H, W = 5, 7
+            pred = torch.rand(B, 1, 13, H, W, generator=g, requires_grad=True)
+            targ = torch.rand(B, 1, 13, H, W, generator=g)
+            vc = 13 if mode == "diag" else 1
+            var0 = torch.rand(B, 1, vc, H, W, generator=g) * 0.5 + 1e-3
+            var0[0, 0, 0, 0, 0] = 1e-10          # below the clamp (eps=1e-8)
+            var0[-1, 0, -1, 2, 3] = 0.0           # exactly zero
+            var = var0.clone().requires_grad_(True)
+            for red in ("none", "mean", "sum"):
+                c = losses.MultiGaussianNLLLoss(reduction=red, eps=1e-8, full=True, mode=mode, chunk=None)
+                l, v = c(pred, targ, var)
+                out[f"k{idx}/loss_{red}"] = l.detach().numpy()
+                if red == "mean":
+                    out[f"k{idx}/variance"] = v.detach().numpy()
+                    gp, gv = torch.autograd.grad(l, (pred, var))
+                    out[f"k{idx}/dpred"], out[f"k{idx}/dvar"] = gp.numpy(), gv.numpy()
+            out[f"k{idx}/pred"], out[f"k{idx}/target"], out[f"k{idx}/var"] = pred.detach().numpy(), targ.numpy(), var0.numpy()
+            out[f"k{idx}/meta"] = json.dumps(dict(mode=mode, B=B))
+            idx += 1
+    out["n"] = np.array(idx)
+    np.savez_compressed(os.path.join(HERE, "g3_mgnll.npz"), **out)
+    print("g3_mgnll", idx, "cases")
+
+
+def case_posenc():
+    pe = PositionalEncoder(256 // 16, T=1000, repeat=16)
+    dates = torch.tensor([[1400., 1433., 1799.], [0., 1., 1000.]])
+    tab = pe(dates)
+    np.savez_compressed(os.path.join(HERE, "g7_posenc.npz"), dates=dates.numpy(), table=tab.numpy())
+    print("g7_posenc", tuple(tab.shape))
+
+
+def case_ensemble():
+    # ensemble_reconstruct.py:116-133 has module-level side effects and cannot be imported; known-answer
+    # vectors are produced from the published mixture-moment formula on random inputs.
+    rng = np.random.default_rng(5)
+    mu = rng.random((5, 13, 6, 6)).astype(np.float32)
+    var = (rng.random((5, 13, 6, 6)) * 0.1 + 1e-3).astype(np.float32)
+    mu64, var64 = mu.astype(np.float64), var.astype(np.float64)
+    m = mu64.mean(0)
+    np.savez_compressed(os.path.join(HERE, "g8_ensemble.npz"), mu=mu, var=var, mean_ens=m,
+                        var_both=(var64 + mu64 ** 2).mean(0) - m ** 2, var_alea=var64.mean(0),
+                        var_epi=(mu64 ** 2).mean(0) - m ** 2)
+    print("g8_ensemble")
+
+
+def case_trainseq():
+    """G6: BaseModel.optimize_parameters x3 (base_model.py:115-131) with parser defaults + the
+    train_reconstruct.py:53-61 fix-ups for covmode=diag."""
+    from parse_args import create_parser
+    from src.model_utils import get_model
+    cfg = create_parser(mode="train").parse_args([])
+    cfg.model, cfg.use_sar, cfg.device, cfg.lr, cfg.input_t = "uncrtaints", True, "cpu", 1e-3, 3
+    from src.utils import str2list
+    cfg = str2list(cfg, ["encoder_widths", "decoder_widths", "out_conv"])
+    cfg.out_conv[-1] += 13                      # train_reconstruct.py:53-57 (diag)
+    cfg.var_nonLinearity = "softplus"
+    torch.manual_seed(1)
+    model = get_model(cfg)
+    model.netG.apply(weight_init)
+    model.netG.temporal_aggregator.attn_dropout.p = 0.0
+    model.train()
+    state0 = np_state(model.netG.state_dict())
+    x, y, dates = synth(2, 3, 64, 64, 11)
+    out = {"x": x.numpy(), "y": y.numpy(), "dates": dates.numpy(),
+           "meta": json.dumps(dict(lr=cfg.lr, steps=3, scale_by=cfg.scale_by))}
+    for k, v in state0.items():
+        out["state/" + k] = v
+    ls = []
+    for _ in range(3):
+        model.set_input({"A": x, "B": y, "dates": dates, "masks": torch.zeros(1)})
+        model.optimize_parameters()
+        ls.append(model.loss_G.item())
+    out["losses"] = np.array(ls)
+    for k, v in model.netG.state_dict().items():
+        if v.dtype.is_floating_point:
+            out["final_sum/" + k] = checksum(v.numpy())
+    np.savez_compressed(os.path.join(HERE, "g6_trainseq.npz"), **out)
+    print("g6_trainseq", ls)
+
+
+if __name__ == "__main__":
+  if "--skip-model" not in sys.argv:
+    case_model("g1_diag_t3", "diag", 2, 3, 64, 64, seed=1, full_grads=True)
+    case_model("g1_diag_t3_pad", "diag", 2, 3, 64, 64, seed=1, full_grads=False, pad_last=True, save_state=False, taps=False)
+    case_model("g1_iso_t6", "iso", 1, 6, 64, 64, seed=2, full_grads=False)
+  if "--only-trainseq" not in sys.argv:
+    case_mgnll()
+    case_posenc()
+    case_ensemble()
+  case_trainseq()

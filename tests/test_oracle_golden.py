@@ -1,0 +1,115 @@
+"""Pins oracle/uncrtaints_oracle.py (the CPU restatement) to fixtures captured from the reference
+(tests/golden/make_golden.py).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import checksum, compare_param_grads, load_golden, rel_err
+from oracle import uncrtaints_oracle as orc
+
+TOL = 2e-5   # fp32 re-association between two CPU formulations of the same graph
+
+
+def _state(g, prefix="state/"):
+    return {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+
+
+def _cfg(meta):
+    cov = meta["covmode"]
+    # fixtures were captured with the aggregator's dropout p set to 0 (deterministic train mode)
+    return orc.OracleConfig(covmode=cov, out_conv=[13 + (13 if cov == "diag" else 1)], attn_dropout=0.0)
+
+
+def _run_case(name, state_from=None):
+    g = load_golden(name)
+    meta = json.loads(str(g["meta"]))
+    cfg = _cfg(meta)
+    p = _state(load_golden(state_from) if state_from else g)
+    x, y, dates = (torch.from_numpy(g[k]) for k in ("x", "y", "dates"))
+
+    # eval mode
+    with torch.no_grad():
+        out = orc.forward(p, x, dates, cfg, training=False)
+        loss = orc.loss_from_output(out, y, cfg)
+    assert rel_err(out.numpy(), g["eval/out"]) < TOL
+    assert abs(loss.item() - float(g["eval/loss"])) < TOL * abs(float(g["eval/loss"]))
+
+    # train mode (dropout p=0) + backward
+    pt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+          for k, v in p.items()}
+    xg = x.clone().requires_grad_(True)
+    out = orc.forward(pt, xg, dates, cfg, training=True)
+    loss = orc.loss_from_output(out, y, cfg)
+    loss.backward()
+    assert rel_err(out.detach().numpy(), g["train/out"]) < TOL
+    assert abs(loss.item() - float(g["train/loss"])) < 5e-5 * abs(float(g["train/loss"]))
+    compare_param_grads({k: v.grad.numpy() for k, v in pt.items() if v.requires_grad}, g, tol=2e-4)
+    for k in g.files:
+        if k.startswith("train/state/"):
+            name_ = k[len("train/state/"):]
+            assert rel_err(pt[name_].numpy(), g[k]) < TOL, name_
+    assert rel_err(xg.grad[0, 0].numpy(), g["train/dx_b0t0"]) < 2e-4
+    return g, p, cfg, x, dates
+
+
+def test_g1_diag_t3_with_taps():
+    g, p, cfg, x, dates = _run_case("g1_diag_t3")
+    taps = {}
+    with torch.no_grad():
+        orc.forward(p, x, dates, cfg, training=False, taps=taps)
+    assert rel_err(taps["attn"].numpy(), g["eval/attn"]) < TOL
+    B, T = x.shape[:2]
+    e = taps["e"].reshape(B, T, 128, 64, 64)
+    assert rel_err(e[0, 0, ::16].numpy(), g["eval/e_b0t0"]) < TOL
+    assert rel_err(taps["agg"][0, ::16].numpy(), g["eval/agg_b0"]) < TOL
+
+
+def test_g1_diag_t3_pad():
+    _run_case("g1_diag_t3_pad", state_from="g1_diag_t3")
+
+
+def test_g1_iso_t6():
+    _run_case("g1_iso_t6")
+
+
+def test_g3_mgnll_kats():
+    g = load_golden("g3_mgnll")
+    for i in range(int(g["n"])):
+        meta = json.loads(str(g[f"k{i}/meta"]))
+        pred = torch.from_numpy(g[f"k{i}/pred"]).requires_grad_(True)
+        var = torch.from_numpy(g[f"k{i}/var"]).requires_grad_(True)
+        targ = torch.from_numpy(g[f"k{i}/target"])
+        for red in ("none", "mean", "sum"):
+            l, v = orc.mgnll(pred, targ, var, mode=meta["mode"], reduction=red, want_covariance=(red == "mean"))
+            assert l.shape == g[f"k{i}/loss_{red}"].shape
+            assert rel_err(l.detach().numpy(), g[f"k{i}/loss_{red}"]) < 1e-5
+            if red == "mean":
+                assert rel_err(v.numpy(), g[f"k{i}/variance"]) < 1e-6
+                gp, gv = torch.autograd.grad(l, (pred, var))
+                assert rel_err(gp.numpy(), g[f"k{i}/dpred"]) < 1e-5
+                assert rel_err(gv.numpy(), g[f"k{i}/dvar"]) < 1e-5
+
+
+def test_mgnll_rejects_negative_var_and_bad_reduction():
+    pred = torch.rand(1, 1, 13, 2, 2); var = torch.rand(1, 1, 13, 2, 2); var[0, 0, 0, 0, 0] = -1.0
+    with pytest.raises(ValueError):
+        orc.mgnll(pred, pred, var)
+    with pytest.raises(ValueError):
+        orc.mgnll(pred, pred, var.abs(), reduction="avg")
+
+
+def test_g7_positional_table():
+    g = load_golden("g7_posenc")
+    tab = orc.positional_table(torch.from_numpy(g["dates"]), 16, 1000, 16)
+    assert rel_err(tab.numpy(), g["table"]) < 1e-6
+
+
+def test_g8_ensemble_combine():
+    g = load_golden("g8_ensemble")
+    mu, var = torch.from_numpy(g["mu"]).double(), torch.from_numpy(g["var"]).double()
+    for mode, key in (("both", "var_both"), ("aleatoric", "var_alea"), ("epistemic", "var_epi")):
+        m, v = orc.ensemble_combine(mu, var, mode)
+        assert rel_err(m.numpy(), g["mean_ens"]) < 1e-12
+        assert rel_err(v.numpy(), g[key]) < 1e-10
