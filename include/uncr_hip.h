@@ -1,0 +1,149 @@
+/* libuncr_hip -- C ABI of the MI355X (gfx950) kernels behind the UnCRtainTS `--model uncrtaints`
+ * forward/backward hot path.
+ *
+ * The reference (PatrickTUM/UnCRtainTS) has no FFI: below `model/src/backbones/uncrtaints.py` everything is
+ * stock torch.nn / ATen.  This header therefore defines the seam a maintainer would bind (ctypes stub shown in
+ * INTEGRATION.md): one entry point per fused stage, forward and backward.  Each comment names the reference
+ * code (file:line under /root/reference) whose work the entry point replaces.
+ *
+ * Conventions
+ *   - all tensors are contiguous fp32, NCHW planes: [frames N][channels C][pixels P = H*W];
+ *   - the CALLER owns every buffer (incl. partial-statistics workspaces); nothing is allocated, freed or
+ *     retained here; kernels are enqueued on the passed stream and never synchronise;
+ *   - return 0 on success, negative = argument/shape error, positive = hipError_t of the launch;
+ *   - "part" buffers hold per-block partial sums float2[N*C][slots]; the *_slots()/tile helpers give the
+ *     slot count of each producer for a given size;
+ *   - a normalisation layer is never run on its own: producers emit partial (sum, sum^2), a finalize call
+ *     turns them into per-(frame,channel) coefficients A,B, and the CONSUMER applies u = A*h + B in its
+ *     prologue.  Backward likewise: dh = C1*du + C2*h + C3.
+ */
+#ifndef UNCR_HIP_H
+#define UNCR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+/* prologue kinds (pw_gemm / pw_wgrad) */
+#define UNCR_PRO_NONE 0
+#define UNCR_PRO_AFFINE 1        /* A*v + B                              */
+#define UNCR_PRO_AFFINE_GELU 2   /* S * gelu(A*v + B)                    */
+#define UNCR_PRO_NORMBWD 3       /* C1*v + C2*v2 + C3  (two operands)    */
+#define UNCR_PRO_AFFINE_RELU 4
+/* normalisation kinds */
+#define UNCR_NORM_GROUP 0
+#define UNCR_NORM_BATCH_TRAIN 1
+#define UNCR_NORM_BATCH_EVAL 2
+/* element-wise ops (uncr_ew) */
+#define UNCR_EW_STATS_SQ 0
+#define UNCR_EW_STATS_AUX 1
+#define UNCR_EW_AFFINE_RELU 2
+#define UNCR_EW_RESIDUAL 3
+#define UNCR_EW_PASSB 4
+#define UNCR_EW_PASSE 5
+#define UNCR_EW_RELU_BWD 6
+#define UNCR_EW_SE_POOL 7
+#define UNCR_EW_HEAD_FWD 8
+#define UNCR_EW_HEAD_BWD 9
+
+int uncr_version(void);
+
+/* ---- normalisation coefficients: nn.GroupNorm / nn.BatchNorm2d statistics
+ *      (uncrtaints.py:16-22 get_norm_layer, utae.py:470-473, uncrtaints.py:72-79 PreNorm) ---- */
+int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           float momentum, float eps, float* coefA, float* coefB, float* save_mean,
+                           float* save_rstd, hipStream_t stream);
+int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
+                           const float* gamma, const float* save_mean, const float* save_rstd, float* c1,
+                           float* c2, float* c3, float* dgamma, float* dbeta, hipStream_t stream);
+
+/* ---- element-wise family with fused coefficients + partial statistics
+ *      (norm-apply/ReLU utae.py:470-494; residual add uncrtaints.py:142-146; SE avg-pool uncrtaints.py:85,95;
+ *       output nonlinearities uncrtaints.py:384-388,441-445 and their autograd twins) ---- */
+int uncr_ew_slots(int P);
+int uncr_ew(int op, const float* a, const float* b, const float* c, const float* aux, float* out,
+            const float* k0, const float* k1, const float* k2, const float* k3, float* part, int planes, int P,
+            int C, int n_mean, float scale, float eps, hipStream_t stream);
+
+/* ---- 1x1 convolutions as fp32 MFMA GEMMs (nn.Conv2d k=1: utae.py:476-484 in_conv/out_conv,
+ *      uncrtaints.py:126 pw, :136 pw-linear; nn.Conv1d k=1 ltae.py:176,214; nn.Linear ltae.py:327,349) ---- */
+int uncr_pw_coutp(int Cout);      /* padded output-channel count of the kernel variant */
+int uncr_pw_kpad(int Cin);        /* padded reduction length */
+int uncr_pw_tile_px(int Cout);    /* pixels per block == pixels per statistics slot */
+int uncr_pack_wt(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out, hipStream_t stream);
+int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, float* out, const float* k0,
+                 const float* k1, const float* k2, const float* bias, int bias_stride_n, const float* aux,
+                 float* part, int N, int Cin, int Cout, int P, int pro, int epi, hipStream_t stream);
+int uncr_wgrad_shape(int Cd, int Cx, int* cop, int* cip);
+int uncr_pw_wgrad(const float* d, const float* d2, const float* x, const float* x2, const float* dk0,
+                  const float* dk1, const float* dk2, const float* xk0, const float* xk1, const float* xk2,
+                  float* part, float* rs_part, int N, int Cd, int Cx, int P, int PXB, int pro_d, int pro_x,
+                  hipStream_t stream);
+int uncr_wgrad_reduce(const float* part, int n_out, int nblk_per_out, int COP, int CIP, int Cout, int Cin,
+                      float* out, hipStream_t stream);
+
+/* ---- depthwise 3x3 reflect (nn.Conv2d groups=C, padding_mode='reflect', uncrtaints.py:130-131) ---- */
+int uncr_dw_slots_fwd(int H);
+int uncr_dw_slots_bwd(int H);
+int uncr_dw_fwd(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part,
+                int N, int C, int H, int W, hipStream_t stream);
+int uncr_dw_bwd(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2,
+                const float* k3, const float* cA1, const float* cB1, const float* w, float* du1, float* part,
+                float* dw_part, int N, int C, int H, int W, hipStream_t stream);
+int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw, hipStream_t stream);
+
+/* ---- squeeze-excite MLP (uncrtaints.py:82-97) ---- */
+int uncr_se_mlp_fwd(const float* pool_part, int NP, int N, int C, int R, int P, const float* W1,
+                    const float* W2, float* pooled, float* hid_pre, float* s, hipStream_t stream);
+int uncr_se_mlp_bwd(const float* G, const float* Wpw, int N, int Co, int C, int R, int P, const float* W1,
+                    const float* W2, const float* s, const float* pooled, const float* hid_pre, float* ds_pre,
+                    float* dhid_pre, float* dpool_px, float* dWpw, float* dW1, float* dW2, hipStream_t stream);
+
+/* ---- L-TAE low-resolution branch (uncrtaints.py:403-404 max-pool; ltae.py:197-239 LTAE2dtiny;
+ *      positional_encoding.py:5-31; ltae.py:341-385,431-458 attention) ---- */
+int uncr_pad_mask(const float* x, int NF, long long frame_elems, float pad_value, int* mask,
+                  hipStream_t stream);   /* pad-frame detection, uncrtaints.py:392-394 */
+int uncr_maxpool_fwd(const float* in, float* out, int* idx, int planes, int H, int W, int OH, int OW,
+                     hipStream_t stream);
+int uncr_maxpool_bwd(const float* dout, const int* idx, float* din, int planes, int H, int W, int OH, int OW,
+                     hipStream_t stream);
+int uncr_ltae_gn_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean,
+                     float* rstd, int B, int T, int C, int G, int S, hipStream_t stream);
+int uncr_ltae_gn_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                     float* dx, float* gb_part, int B, int T, int C, int G, int S, hipStream_t stream);
+int uncr_colsum(const float* part, int R, int K, float* out, hipStream_t stream);
+int uncr_ltae_posbias(const float* dates, const float* denom, int d, const float* bin, float* out, int NF, int D,
+                      int use_pe, hipStream_t stream);
+int uncr_ltae_softmax_fwd(const float* k, const float* Q, const int* pad, float* att, int B, int T, int NH,
+                          int DK, int S, hipStream_t stream);
+int uncr_ltae_softmax_bwd(const float* datt, const float* att, const float* k, const float* Q, const int* pad,
+                          float* dk, float* dq_part, int B, int T, int NH, int DK, int S, hipStream_t stream);
+
+/* ---- full-resolution temporal aggregation (Compact_Temporal_Aggregator 'att_group',
+ *      uncrtaints.py:156-221: bilinear up-sample + dropout + pad mask + V-aggregate) ---- */
+int uncr_agg_slots(int P);
+int uncr_aggregate_fwd(const float* e, const float* att, const int* pad, const float* dmask,
+                       unsigned long long seed, float p_drop, float* out, float* part, int B, int T, int C,
+                       int NH, int H, int W, int AH, int AW, hipStream_t stream);
+int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const int* pad, const float* dmask,
+                       unsigned long long seed, float p_drop, float* de, float* datt_up, float* datt, int B,
+                       int T, int C, int NH, int H, int W, int AH, int AW, hipStream_t stream);
+
+/* ---- MGNLL loss (losses.py:131-218) and ensemble combine (ensemble_reconstruct.py:116-133) ---- */
+int uncr_mgnll_blocks(int P);
+int uncr_mgnll_fwd(const float* pred, const float* targ, const float* var, float* loss_none, float* part,
+                   float* loss_out, int* neg_flag, int B, int K, int Kv, int H, int W, float eps, int reduction,
+                   hipStream_t stream);
+int uncr_mgnll_bwd(const float* pred, const float* targ, const float* var, const float* gscalar,
+                   const float* gnone, float* dpred, float* dvar, int B, int K, int Kv, int H, int W, float eps,
+                   int reduction, hipStream_t stream);
+int uncr_ensemble_combine(const float* mu, const float* var, int M, long long n, int mode, float* mu_out,
+                          float* var_out, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNCR_HIP_H */

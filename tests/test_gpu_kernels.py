@@ -1,0 +1,403 @@
+"""-m gpu: each HIP kernel family against the CPU oracle / plain torch fp32 on seeded inputs."""
+import json
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from gpu_util import DEV, TOL, close, dev, rand
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    from uncrtaints_amd import engine
+    return engine
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import uncrtaints_oracle
+    return uncrtaints_oracle
+
+
+# ------------------------------------------------------------------------------------------------
+def test_ew_stats_and_norm_finalize(E, orc):
+    N, C, H, W = 3, 128, 64, 64
+    P = H * W
+    x = rand(N, C, H, W, seed=1, scale=1.5, shift=0.3)
+    gam, bet = rand(C, seed=2), rand(C, seed=3)
+    xd = dev(x)
+    part = E.stats_sq(xd, N * C, P)
+    # GroupNorm(4)
+    nf = E.norm_fwd(part, N, C, P, E.NormSpec("group", 4), True, dev(gam), dev(bet))
+    y = nf.A.view(N, C, 1, 1) * xd + nf.B.view(N, C, 1, 1)
+    close("gn4_apply", y, orc.group_norm(x, 4, gam, bet))
+    # BatchNorm train (+ running stats)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    rmd, rvd = dev(rm.clone()), dev(rv.clone())
+    nf = E.norm_fwd(part, N, C, P, E.NormSpec("batch"), True, dev(gam), dev(bet), rmd, rvd)
+    y = nf.A.view(N, C, 1, 1) * xd + nf.B.view(N, C, 1, 1)
+    close("bn_train_apply", y, orc.batch_norm(x, gam, bet, rm, rv, True))
+    close("bn_running_mean", rmd, rm)
+    close("bn_running_var", rvd, rv)
+    # BatchNorm eval
+    nf = E.norm_fwd(None, N, C, P, E.NormSpec("batch"), False, dev(gam), dev(bet), rmd, rvd)
+    y = nf.A.view(N, C, 1, 1) * xd + nf.B.view(N, C, 1, 1)
+    close("bn_eval_apply", y, orc.batch_norm(x, gam, bet, rm, rv, False))
+
+
+@pytest.mark.parametrize("Cin,Cout,pro", [(15, 128, 0), (128, 256, 1), (256, 128, 2), (128, 26, 0), (64, 256, 0),
+                                           (256, 64, 0), (26, 128, 0), (128, 256, 3), (256, 128, 3), (128, 15, 3)])
+def test_pw_gemm(E, Cin, Cout, pro):
+    N, P = 2, 2048
+    x = rand(N, Cin, P, seed=Cin + Cout)
+    x2 = rand(N, Cin, P, seed=7)
+    W = rand(Cout, Cin, seed=5, scale=1.0 / math.sqrt(Cin))
+    bias = rand(Cout, seed=6)
+    k0, k1, k2 = rand(N * Cin, seed=8), rand(N * Cin, seed=9), rand(N * Cin, seed=10)
+    if pro == 0:
+        f = x
+    elif pro == 1:
+        f = k0.view(N, Cin, 1) * x + k1.view(N, Cin, 1)
+    elif pro == 2:
+        u = k0.view(N, Cin, 1) * x + k1.view(N, Cin, 1)
+        f = k2.view(N, Cin, 1) * (0.5 * u * (1 + torch.erf(u / math.sqrt(2))))
+    else:
+        f = k0.view(N, Cin, 1) * x + k1.view(N, Cin, 1) * x2 + k2.view(N, Cin, 1)
+    ref = torch.einsum("oc,ncp->nop", W.double(), f.double()) + bias.double().view(1, -1, 1)
+    aux = rand(N, Cout, P, seed=11)
+    Wt = E.pack_wt(dev(W), transpose=True)
+    for epi in (0, 1, 2):
+        out, part = E.pw_gemm(dev(x), Wt, N, Cin, Cout, P, pro=pro, k=(dev(k0), dev(k1), dev(k2)),
+                              x2=dev(x2) if pro == 3 else None, bias=dev(bias), epi=epi,
+                              aux=dev(aux) if epi == 2 else None)
+        close(f"pw_gemm[{Cin}->{Cout},pro{pro},epi{epi}]", out, ref.float())
+        if epi:
+            s = part.buf.double().sum(dim=1).cpu()
+            close(f"pw_gemm_stats0[{Cin}->{Cout},epi{epi}]", s[:, 0].float(), ref.sum(-1).reshape(-1).float())
+            second = (ref * ref).sum(-1) if epi == 1 else (ref * aux.double()).sum(-1)
+            close(f"pw_gemm_stats1[{Cin}->{Cout},epi{epi}]", s[:, 1].float(), second.reshape(-1).float(), tol=2e-4)
+    # per-frame bias
+    bn = rand(N, Cout, seed=12)
+    out, _ = E.pw_gemm(dev(x), Wt, N, Cin, Cout, P, pro=0, bias=dev(bn), bias_per_frame=True)
+    ref2 = torch.einsum("oc,ncp->nop", W.double(), x.double()) + bn.double().view(N, Cout, 1)
+    close(f"pw_gemm_framebias[{Cin}->{Cout}]", out, ref2.float())
+
+
+@pytest.mark.parametrize("Cd,Cx", [(128, 256), (256, 128), (128, 15), (26, 128), (14, 128), (64, 256)])
+def test_pw_wgrad(E, Cd, Cx):
+    N, P = 3, 2048
+    d, d2, x = rand(N, Cd, P, seed=1), rand(N, Cd, P, seed=2), rand(N, Cx, P, seed=3)
+    k = [rand(N * Cd, seed=10 + i) for i in range(3)]
+    xk = [rand(N * Cx, seed=20 + i) for i in range(2)]
+    fd = (k[0].view(N, Cd, 1) * d + k[1].view(N, Cd, 1) * d2 + k[2].view(N, Cd, 1)).double()
+    u = xk[0].view(N, Cx, 1) * x + xk[1].view(N, Cx, 1)
+    fx = (0.5 * u * (1 + torch.erf(u / math.sqrt(2)))).double()
+    G = torch.einsum("nop,ncp->noc", fd, fx)
+    dW, rs = E.pw_wgrad(dev(d), dev(x), N, Cd, Cx, P, pro_d=3, dk=tuple(dev(t) for t in k), d2=dev(d2), pro_x=2,
+                        xk=(dev(xk[0]), dev(xk[1]), None), rowsum=True)
+    close(f"wgrad[{Cd},{Cx}]", dW, G.sum(0).float())
+    close(f"wgrad_rowsum[{Cd},{Cx}]", rs, fd.sum(dim=(0, 2)).float())
+    Gf, _ = E.pw_wgrad(dev(d), dev(x), N, Cd, Cx, P, pro_d=3, dk=tuple(dev(t) for t in k), d2=dev(d2), pro_x=2,
+                       xk=(dev(xk[0]), dev(xk[1]), None), per_frame=True)
+    close(f"wgrad_per_frame[{Cd},{Cx}]", Gf, G.float())
+    # plain operands
+    dW0, _ = E.pw_wgrad(dev(d), dev(x), N, Cd, Cx, P)
+    close(f"wgrad_plain[{Cd},{Cx}]", dW0, torch.einsum("nop,ncp->oc", d.double(), x.double()).float())
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (96, 32)])
+def test_depthwise_fwd_bwd(E, orc, H, W):
+    N, C = 2, 64
+    h1 = rand(N, C, H, W, seed=1).requires_grad_(True)
+    w = rand(C, 1, 3, 3, seed=2, scale=0.4).requires_grad_(True)
+    A, B = rand(N * C, seed=3, scale=0.5, shift=1.0), rand(N * C, seed=4, scale=0.3)
+    g1 = orc.gelu_exact(A.view(N, C, 1, 1) * h1 + B.view(N, C, 1, 1))
+    h2 = orc.depthwise3x3_reflect(g1, w)
+    h2d = torch.empty(N, C, H, W, device=DEV)
+    from uncrtaints_amd import hip_backend as hb
+    slots = hb.query("uncr_dw_slots_fwd", H)
+    part = torch.empty(N * C, slots, 2, device=DEV)
+    hb.call("uncr_dw_fwd", dev(h1.detach()), dev(A), dev(B), dev(w.detach().reshape(C, 9)), h2d, part, N, C, H, W,
+            E._stream())
+    close(f"dw_fwd[{H}x{W}]", h2d, h2)
+    close("dw_fwd_stats0", part.sum(1)[:, 0], h2.detach().sum(dim=(2, 3)).reshape(-1))
+    close("dw_fwd_stats1", part.sum(1)[:, 1], (h2.detach() ** 2).sum(dim=(2, 3)).reshape(-1))
+    # backward: dh2 = C1*du2 + C2*h2 + C3 is the upstream gradient of h2
+    du2 = rand(N, C, H, W, seed=5)
+    c1, c2, c3 = rand(N * C, seed=6), rand(N * C, seed=7, scale=0.1), rand(N * C, seed=8, scale=0.1)
+    dh2 = c1.view(N, C, 1, 1) * du2 + c2.view(N, C, 1, 1) * h2.detach() + c3.view(N, C, 1, 1)
+    u1 = (A.view(N, C, 1, 1) * h1 + B.view(N, C, 1, 1))
+    u1.retain_grad()
+    h2b = orc.depthwise3x3_reflect(orc.gelu_exact(u1), w)
+    h2b.backward(dh2)
+    du1_ref = u1.grad
+    du1 = torch.empty(N, C, H, W, device=DEV)
+    sb = hb.query("uncr_dw_slots_bwd", H)
+    partb = torch.empty(N * C, sb, 2, device=DEV)
+    dwp = torch.empty(N * C, sb, 9, device=DEV)
+    hb.call("uncr_dw_bwd", dev(du2), h2d, dev(h1.detach()), dev(c1), dev(c2), dev(c3), dev(A), dev(B),
+            dev(w.detach().reshape(C, 9)), du1, partb, dwp, N, C, H, W, E._stream())
+    close(f"dw_bwd_du1[{H}x{W}]", du1, du1_ref)
+    close("dw_bwd_stats0", partb.sum(1)[:, 0], du1_ref.sum(dim=(2, 3)).reshape(-1))
+    close("dw_bwd_stats1", partb.sum(1)[:, 1], (du1_ref * h1.detach()).sum(dim=(2, 3)).reshape(-1))
+    dwd = torch.empty(C, 9, device=DEV)
+    hb.call("uncr_dw_wgrad_reduce", dwp, N, C, sb, dwd, E._stream())
+    close("dw_bwd_dw", dwd.view(C, 1, 3, 3), w.grad)
+
+
+def _mb_module(norm, seed):
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    from uncrtaints_amd.src.learning.weight_init import weight_init
+    torch.manual_seed(seed)
+    m = U.MBConv(128, 128, expansion=2, norm=norm)
+    m.apply(weight_init)
+    g = torch.Generator().manual_seed(seed + 1)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.GroupNorm):
+            mod.weight.data.copy_(1 + 0.3 * torch.randn(mod.weight.shape, generator=g))
+            mod.bias.data.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=g))
+            mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g))
+    return m
+
+
+@pytest.mark.parametrize("norm,training", [("group", True), ("batch", True), ("batch", False)])
+def test_mbconv_fwd_bwd(orc, norm, training):
+    from conftest import compare_param_grads  # noqa: F401
+    N, H, W = 3, 64, 64
+    m = _mb_module(norm, 3)
+    m.train(training)
+    sd = {("blk." + k): v.clone() for k, v in m.state_dict().items()}
+    x = rand(N, 128, H, W, seed=4, scale=1.2, shift=0.2)
+    gy = rand(N, 128, H, W, seed=5)
+    # oracle
+    pt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+          for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    yo = orc.mbconv(xo, pt, "blk", norm, training)
+    yo.backward(gy)
+    # HIP
+    md = m.to(DEV)
+    xd = dev(x).requires_grad_(True)
+    yd = md(xd)
+    close(f"mbconv_fwd[{norm},train={training}]", yd, yo)
+    yd.backward(dev(gy))
+    close("mbconv_dx", xd.grad, xo.grad)
+    for k, v in md.named_parameters():
+        ref = pt["blk." + k].grad
+        if ref.abs().max() < 1e-5 * max(pt["blk." + k.replace(".bias", ".weight")].grad.abs().max().item(), 1e-30) \
+                and k.endswith(".bias"):
+            assert v.grad.abs().max().item() < 1e-3 * pt["blk." + k.replace(".bias", ".weight")].grad.abs().max().item()
+            continue
+        close(f"mbconv_grad[{k}]", v.grad, ref, tol=2e-4)
+    if norm == "batch" and training:
+        for k, v in md.state_dict().items():
+            if "running" in k:
+                close(f"mbconv_buf[{k}]", v, pt["blk." + k])
+
+
+def test_inconv_fwd_bwd(orc):
+    from uncrtaints_amd.src.backbones.utae import ConvBlock
+    from uncrtaints_amd.src.learning.weight_init import weight_init
+    torch.manual_seed(0)
+    blk = ConvBlock(nkernels=[15, 128], k=1, s=1, p=0, norm="group")
+    blk.apply(weight_init)
+    B, T, H, W = 2, 3, 64, 64
+    x = torch.rand(B, T, 15, H, W)
+    gy = rand(B, T, 128, H, W, seed=2)
+    w, b = blk.conv.conv[0].weight, blk.conv.conv[0].bias
+    gw, gb = blk.conv.conv[1].weight, blk.conv.conv[1].bias
+    ps = [t.detach().clone().requires_grad_(True) for t in (w, b, gw, gb)]
+    xo = x.clone().requires_grad_(True)
+    c0 = orc.conv1x1(xo.view(B * T, 15, H, W), ps[0], ps[1])
+    a0 = torch.relu(orc.group_norm(c0, 4, ps[2], ps[3])).view(B, T, 128, H, W)
+    a0.backward(gy)
+    bd = blk.to(DEV)
+    xd = dev(x).requires_grad_(True)
+    yd = bd.smart_forward(xd)
+    close("inconv_fwd", yd, a0)
+    yd.backward(dev(gy))
+    close("inconv_dx", xd.grad, xo.grad)
+    for got, ref, name in zip((bd.conv.conv[0].weight, bd.conv.conv[0].bias, bd.conv.conv[1].weight,
+                               bd.conv.conv[1].bias), ps, ("w", "b", "gn_w", "gn_b")):
+        close(f"inconv_grad[{name}]", got.grad, ref.grad, tol=2e-4)
+
+
+@pytest.mark.parametrize("T,padded", [(3, False), (3, True), (6, False)])
+def test_ltae_attention_fwd_bwd(orc, T, padded):
+    from uncrtaints_amd.src.backbones.ltae import LTAE2dtiny
+    from uncrtaints_amd.src.learning.weight_init import weight_init
+    torch.manual_seed(1)
+    m = LTAE2dtiny(in_channels=128, n_head=16, d_k=4, d_model=256)
+    m.apply(weight_init)
+    B = 2
+    down = rand(B, T, 128, 32, 32, seed=3)
+    dates = torch.sort(torch.randint(1400, 1800, (B, T)), dim=1).values.float()
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    if padded:
+        pad[0, T - 1] = True
+    gatt = rand(16, B, T, 32, 32, seed=4)
+    cfg = orc.OracleConfig()
+    p = {"temporal_encoder." + k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    do = down.clone().requires_grad_(True)
+    att_o = orc.ltae_tiny_attention(do, dates, pad, p, cfg)
+    att_o.backward(gatt)
+    md = m.to(DEV)
+    dd = dev(down).requires_grad_(True)
+    att = md(dd, batch_positions=dev(dates), pad_mask=dev(pad))
+    close(f"ltae_att[T={T},pad={padded}]", att, att_o)
+    assert torch.allclose(att.sum(dim=2), torch.ones_like(att.sum(dim=2)), atol=1e-5)
+    att.backward(dev(gatt))
+    close("ltae_ddown", dd.grad, do.grad, tol=2e-4)
+    refw = {k: p["temporal_encoder." + k].grad for k, _ in md.named_parameters()}
+    for k, v in md.named_parameters():
+        ref = refw[k]
+        sib = refw.get(k.replace(".bias", ".weight"), ref)
+        if k.endswith(".bias") and ref.abs().max() < 1e-4 * sib.abs().max():
+            assert v.grad.abs().max().item() < 1e-3 * sib.abs().max().item(), k   # mathematically zero gradient
+            continue
+        close(f"ltae_grad[{k}]", v.grad, ref, tol=2e-4)
+
+
+@pytest.mark.parametrize("padded,masked", [(False, False), (True, False), (False, True)])
+def test_aggregate_fwd_bwd(E, orc, padded, masked):
+    B, T, C, H, W = 2, 3, 128, 64, 64
+    e = rand(B, T, C, H, W, seed=1)
+    att = torch.softmax(rand(16, B, T, 32, 32, seed=2), dim=2)
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    if padded:
+        pad[1, 0] = True
+    dm = None
+    if masked:
+        dm = (torch.rand(16 * B, T, H, W, generator=torch.Generator().manual_seed(5)) > 0.1).float() / 0.9
+    gg = rand(B, C, H, W, seed=3)
+    cfg = orc.OracleConfig()
+    eo, ao = e.clone().requires_grad_(True), att.clone().requires_grad_(True)
+    go = orc.temporal_aggregate(eo, pad, ao, cfg, training=masked, dropout_mask=dm)
+    go.backward(gg)
+    padd = dev(pad.to(torch.int32))
+    g, sv, part = E.aggregate_forward(dev(e), dev(att), padd, masked, 0.1, 1234, dev(dm) if masked else None)
+    close(f"agg_fwd[pad={padded},mask={masked}]", g, go)
+    close("agg_stats0", part.buf.sum(1)[:, 0], go.detach().sum(dim=(2, 3)).reshape(-1))
+    close("agg_stats1", part.buf.sum(1)[:, 1], (go.detach() ** 2).sum(dim=(2, 3)).reshape(-1))
+    de, datt = E.aggregate_backward(dev(gg), sv)
+    close("agg_de", de, eo.grad)
+    close("agg_datt", datt, ao.grad, tol=2e-4)
+
+
+def test_aggregate_hash_dropout_statistics(E):
+    """Train-mode dropout uses a counter-based hash stream: check keep-rate and scaling statistically."""
+    B, T, C, H, W = 1, 2, 128, 64, 64
+    e = torch.ones(B, T, C, H, W)
+    att = torch.full((16, B, T, 32, 32), 0.5)
+    g, sv, _ = E.aggregate_forward(dev(e), dev(att), None, True, 0.1, 99, None)
+    # each output = sum_t 0.5 * keep/(0.9): values in {0, .5/.9, 1/.9}; mean ~ 1
+    vals = g.cpu()
+    assert abs(vals.mean().item() - 1.0) < 5e-3
+    frac_zero = (vals == 0).float().mean().item()
+    assert abs(frac_zero - 0.01) < 5e-3
+    g2, _, _ = E.aggregate_forward(dev(e), dev(att), None, True, 0.1, 99, None)
+    assert torch.equal(g, g2)              # same seed -> same mask (needed to recompute it in backward)
+    g3, _, _ = E.aggregate_forward(dev(e), dev(att), None, True, 0.1, 100, None)
+    assert not torch.equal(g, g3)
+
+
+def test_maxpool(E):
+    x = rand(6, 16, 64, 96, seed=1)
+    down, idx = E.maxpool_forward(dev(x), 32, 32)
+    ref, ridx = F.adaptive_max_pool2d(x, (32, 32), return_indices=True)
+    close("maxpool", down, ref)
+    assert torch.equal(idx.cpu().long(), ridx)
+    de = torch.zeros(6, 16, 64, 96, device=DEV)
+    gd = rand(6, 16, 32, 32, seed=2)
+    E.maxpool_backward_into(dev(gd), idx, de, 64, 96, 32, 32)
+    xr = x.clone().requires_grad_(True)
+    F.adaptive_max_pool2d(xr, (32, 32)).backward(gd)
+    close("maxpool_bwd", de, xr.grad)
+
+
+def test_pad_mask(E):
+    x = torch.rand(2, 3, 15, 64, 64)
+    x[1, 2] = 0
+    x[0, 1, :, :, :] = 0
+    x[0, 1, 14, 63, 63] = 1e-3
+    m = E.pad_mask_of(dev(x), 0.0).cpu()
+    assert m.tolist() == [[0, 0, 0], [0, 0, 1]]
+
+
+@pytest.mark.parametrize("covmode", ["diag", "iso"])
+def test_head_fwd_bwd(E, covmode):
+    N, C, H, W = 2, 128, 64, 64
+    Co = 26 if covmode == "diag" else 14
+    y = rand(N, C, H, W, seed=1)
+    w, b = rand(Co, C, 1, 1, seed=2, scale=0.2), rand(Co, seed=3)
+    gy = rand(N, Co, H, W, seed=4)
+    yo, wo, bo = (t.clone().requires_grad_(True) for t in (y, w, b))
+    o = torch.einsum("oc,nchw->nohw", wo[:, :, 0, 0], yo) + bo.view(1, -1, 1, 1)
+    out = torch.cat((1.0 * torch.sigmoid(o[:, :13]), F.softplus(o[:, 13:]) + 1e-9), dim=1)
+    out.backward(gy)
+    got, sv = E.head_forward(dev(y), dev(w), dev(b), 13, True, 1.0, 1e-9)
+    close(f"head_fwd[{covmode}]", got, out)
+    dy, dW, db = E.head_backward(dev(gy), sv, dev(w))
+    close("head_dy", dy, yo.grad)
+    close("head_dW", dW, wo.grad)
+    close("head_db", db, bo.grad)
+
+
+def test_mgnll_known_answers():
+    from uncrtaints_amd.src import losses
+    g = load_golden("g3_mgnll")
+    for i in range(int(g["n"])):
+        meta = json.loads(str(g[f"k{i}/meta"]))
+        pred = dev(torch.from_numpy(g[f"k{i}/pred"])).requires_grad_(True)
+        var = dev(torch.from_numpy(g[f"k{i}/var"])).requires_grad_(True)
+        targ = dev(torch.from_numpy(g[f"k{i}/target"]))
+        for red in ("none", "mean", "sum"):
+            l, v = losses.multi_gaussian_nll_loss(pred, targ, var, full=True, reduction=red, mode=meta["mode"],
+                                                  want_covariance=(red == "mean"))
+            close(f"mgnll[{i},{red}]", l, torch.from_numpy(g[f"k{i}/loss_{red}"]), tol=1e-5)
+            if red == "mean":
+                close(f"mgnll_cov[{i}]", v, torch.from_numpy(g[f"k{i}/variance"]), tol=1e-6)
+                gp, gv = torch.autograd.grad(l, (pred, var))
+                close(f"mgnll_dpred[{i}]", gp, torch.from_numpy(g[f"k{i}/dpred"]), tol=1e-5)
+                close(f"mgnll_dvar[{i}]", gv, torch.from_numpy(g[f"k{i}/dvar"]), tol=1e-5)
+    with pytest.raises(ValueError):
+        bad = var.detach().clone()
+        bad[0, 0, 0, 0, 0] = -1.0
+        losses.multi_gaussian_nll_loss(pred.detach(), targ, bad, mode=meta["mode"], check_negative=True)
+    with pytest.raises(ValueError):
+        losses.multi_gaussian_nll_loss(pred.detach(), targ, var.detach(), reduction="avg")
+
+
+def test_mgnll_none_reduction_backward(orc):
+    from uncrtaints_amd.src import losses
+    B, H, W = 2, 8, 8
+    pred, targ = torch.rand(B, 1, 13, H, W), torch.rand(B, 1, 13, H, W)
+    var = torch.rand(B, 1, 13, H, W) * 0.5 + 0.01
+    go = torch.rand(W, H, B)
+    po, vo = pred.clone().requires_grad_(True), var.clone().requires_grad_(True)
+    orc.mgnll(po, targ, vo, reduction="none")[0].backward(go)
+    pd, vd = dev(pred).requires_grad_(True), dev(var).requires_grad_(True)
+    losses.multi_gaussian_nll_loss(pd, dev(targ), vd, reduction="none")[0].backward(dev(go))
+    close("mgnll_none_dpred", pd.grad, po.grad, tol=1e-5)
+    close("mgnll_none_dvar", vd.grad, vo.grad, tol=1e-5)
+
+
+def test_positional_table_and_ensemble(E):
+    from uncrtaints_amd.src.backbones.positional_encoding import PositionalEncoder
+    g = load_golden("g7_posenc")
+    pe = PositionalEncoder(16, T=1000, repeat=16)
+    close("posenc", pe(dev(torch.from_numpy(g["dates"]))), torch.from_numpy(g["table"]), tol=2e-6)
+    g8 = load_golden("g8_ensemble")
+    mu, var = dev(torch.from_numpy(g8["mu"])), dev(torch.from_numpy(g8["var"]))
+    for mode, key in (("both", "var_both"), ("aleatoric", "var_alea"), ("epistemic", "var_epi")):
+        m, v = E.ensemble_combine(mu, var, mode)
+        close(f"ens_mean[{mode}]", m, torch.from_numpy(g8["mean_ens"]).float(), tol=1e-6)
+        close(f"ens_var[{mode}]", v, torch.from_numpy(g8[key]).float(), tol=2e-5)

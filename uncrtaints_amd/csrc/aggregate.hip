@@ -1,0 +1,226 @@
+// Compact_Temporal_Aggregator, mode 'att_group' (uncrtaints.py:156-221): the only full-resolution piece
+// of the L-TAE stage.  The low-res attention [NH,B,T,32,32] is bilinearly up-sampled ON THE FLY
+// (align_corners=False, uncrtaints.py:197-200) -- the reference materialises a [NH*B,T,H,W] tensor --
+// multiplied by the (train-only) dropout mask and the pad mask, and contracted over T against the
+// encoder features:  g[b, c, p] = sum_t a[c / (C/NH), b, t, p] * e[b, t, c, p].
+//
+// Pure HBM streaming: fwd reads e once ((T) planes) and writes g (1 plane) per channel; every access is
+// 16 B per lane, 1 KiB contiguous per wave.  The epilogue emits (sum g, sum g^2) partials for the first
+// decoder BatchNorm.  Algorithmic bytes: (T+1)*C*P*4 forward, (2T+1)*C*P*4 backward.
+#include "common.h"
+
+#define AGG_PX 1024   // pixels per block
+
+struct AggArgs {
+    const float* e;        // [B][T][C][P]
+    const float* att;      // [NH][B][T][AH][AW]
+    const int* pad;        // [B][T] or null
+    const float* dmask;    // explicit dropout mask [NH*B][T][P] (values 0 or 1/(1-p)) or null
+    float* out;            // fwd: g [B][C][P]
+    const float* dg;       // bwd: [B][C][P]
+    float* de;             // bwd: [B][T][C][P]
+    float* datt_up;        // bwd: [NH][B][T][P]
+    float2* part;          // fwd: [B*C][NP] or null
+    unsigned long long seed;
+    float p_drop;          // > 0 with dmask == null: hash dropout
+    int B, T, C, NH, H, W, AH, AW;
+};
+
+struct Bilin {
+    int i0, i1;
+    float l0, l1;
+};
+__device__ __forceinline__ Bilin bilin_src(int dst, float scale, int in_size) {
+    // area_pixel_compute_source_index, align_corners=False, clamped at 0 (bilinear)
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    Bilin r;
+    r.i0 = (int)src;
+    if (r.i0 > in_size - 1) r.i0 = in_size - 1;
+    r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+
+__device__ __forceinline__ float agg_keep(const AggArgs& g, int h, int b, int t, size_t p) {
+    float m = 1.f;
+    const size_t P = (size_t)g.H * g.W;
+    if (g.dmask) m = g.dmask[(((size_t)h * g.B + b) * g.T + t) * P + p];
+    else if (g.p_drop > 0.f) {
+        const float u = hash_uniform(g.seed, (((size_t)h * g.B + b) * g.T + t) * P + p);
+        m = u < g.p_drop ? 0.f : 1.f / (1.f - g.p_drop);
+    }
+    if (g.pad && g.pad[b * g.T + t]) m = 0.f;   // attn * (~pad_mask), uncrtaints.py:172
+    return m;
+}
+
+template <bool BWD, int CH>
+__global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g) {
+    const int b = blockIdx.y;
+    const int P = g.H * g.W;
+    const int p0 = blockIdx.x * AGG_PX + threadIdx.x * 4;
+    const int y = p0 / g.W, x0 = p0 % g.W;
+    const float sy = (float)g.AH / (float)g.H, sx = (float)g.AW / (float)g.W;
+    const Bilin by = bilin_src(y, sy, g.AH);
+    Bilin bx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bx[j] = bilin_src(x0 + j, sx, g.AW);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+
+    __shared__ float wred[4][256][2];   // per-wave statistics partials (forward), C <= 256
+    for (int h = 0; h < g.NH; ++h) {
+        float4 acc[CH];                 // fwd: output accumulators; bwd: dg of the head's channels
+#pragma unroll
+        for (int jc = 0; jc < CH; ++jc) {
+            if constexpr (BWD) acc[jc] = *(const float4*)(g.dg + ((size_t)b * g.C + h * CH + jc) * P + p0);
+            else acc[jc] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int t = 0; t < g.T; ++t) {
+            // up-sampled attention (x dropout x pad) for this thread's 4 pixels
+            const float* ap = g.att + (((size_t)h * g.B + b) * g.T + t) * g.AH * g.AW;
+            float a[4], keep[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float top = bx[j].l0 * ap[by.i0 * g.AW + bx[j].i0] + bx[j].l1 * ap[by.i0 * g.AW + bx[j].i1];
+                const float bot = bx[j].l0 * ap[by.i1 * g.AW + bx[j].i0] + bx[j].l1 * ap[by.i1 * g.AW + bx[j].i1];
+                keep[j] = agg_keep(g, h, b, t, (size_t)p0 + j);
+                a[j] = (by.l0 * top + by.l1 * bot) * keep[j];
+            }
+            float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jc = 0; jc < CH; ++jc) {
+                const size_t eo = (((size_t)b * g.T + t) * g.C + h * CH + jc) * P + p0;
+                const float4 ev = *(const float4*)(g.e + eo);
+                if constexpr (!BWD) {
+                    acc[jc].x = fmaf(a[0], ev.x, acc[jc].x);
+                    acc[jc].y = fmaf(a[1], ev.y, acc[jc].y);
+                    acc[jc].z = fmaf(a[2], ev.z, acc[jc].z);
+                    acc[jc].w = fmaf(a[3], ev.w, acc[jc].w);
+                } else {
+                    const float4 dgv = acc[jc];
+                    *(float4*)(g.de + eo) = make_float4(a[0] * dgv.x, a[1] * dgv.y, a[2] * dgv.z, a[3] * dgv.w);
+                    d[0] = fmaf(dgv.x, ev.x, d[0]);
+                    d[1] = fmaf(dgv.y, ev.y, d[1]);
+                    d[2] = fmaf(dgv.z, ev.z, d[2]);
+                    d[3] = fmaf(dgv.w, ev.w, d[3]);
+                }
+            }
+            if constexpr (BWD) {
+                // gradient w.r.t. the up-sampled attention: keep * sum_j dg * e
+                *(float4*)(g.datt_up + (((size_t)h * g.B + b) * g.T + t) * P + p0) =
+                    make_float4(d[0] * keep[0], d[1] * keep[1], d[2] * keep[2], d[3] * keep[3]);
+            }
+        }
+        if constexpr (!BWD) {
+#pragma unroll
+            for (int jc = 0; jc < CH; ++jc) {
+                const int c = h * CH + jc;
+                const float4 o = acc[jc];
+                *(float4*)(g.out + ((size_t)b * g.C + c) * P + p0) = o;
+                if (g.part) {
+                    const float s0 = wave_sum(o.x + o.y + o.z + o.w);
+                    const float s1 = wave_sum(o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w);
+                    if (lane == 0) { wred[wv][c][0] = s0; wred[wv][c][1] = s1; }
+                }
+            }
+        }
+    }
+    if constexpr (!BWD) {
+        if (g.part) {
+            __syncthreads();
+            for (int c = threadIdx.x; c < g.C; c += 256)
+                g.part[((size_t)b * g.C + c) * gridDim.x + blockIdx.x] =
+                    make_float2(wred[0][c][0] + wred[1][c][0] + wred[2][c][0] + wred[3][c][0],
+                                wred[0][c][1] + wred[1][c][1] + wred[2][c][1] + wred[3][c][1]);
+        }
+    }
+}
+
+// adjoint of the bilinear up-sampling: datt[q, ay, ax] = sum_{y,x} wy(y,ay) wx(x,ax) dup[q, y, x]
+// grid = (AH, planes q = NH*B*T), block = 256 = 8 row lanes x 32 ax
+__global__ __launch_bounds__(256) void bilinear_adjoint_kernel(const float* __restrict__ dup,
+                                                               float* __restrict__ datt, int H, int W, int AH,
+                                                               int AW) {
+    const int ay = blockIdx.x, q = blockIdx.y;
+    const int axl = threadIdx.x & 31, yl = threadIdx.x >> 5;
+    const float sy = (float)AH / (float)H, sx = (float)AW / (float)W;
+    const int ry = (H + AH - 1) / AH, rx = (W + AW - 1) / AW;
+    const int ylo = max(0, (ay - 1) * ry - ry), yhi = min(H, (ay + 2) * ry + ry);
+    const float* src = dup + (size_t)q * H * W;
+    __shared__ float red[8][33];
+    for (int ax0 = 0; ax0 < AW; ax0 += 32) {
+        const int ax = ax0 + axl;
+        float acc = 0.f;
+        if (ax < AW) {
+            const int xlo = max(0, (ax - 1) * rx - rx), xhi = min(W, (ax + 2) * rx + rx);
+            for (int yy = ylo + yl; yy < yhi; yy += 8) {
+                const Bilin by = bilin_src(yy, sy, AH);
+                const float wy = (by.i0 == ay ? by.l0 : 0.f) + (by.i1 == ay ? by.l1 : 0.f);
+                if (wy == 0.f) continue;
+                float rowacc = 0.f;
+                for (int xx = xlo; xx < xhi; ++xx) {
+                    const Bilin bx = bilin_src(xx, sx, AW);
+                    const float wx = (bx.i0 == ax ? bx.l0 : 0.f) + (bx.i1 == ax ? bx.l1 : 0.f);
+                    if (wx != 0.f) rowacc = fmaf(wx, src[(size_t)yy * W + xx], rowacc);
+                }
+                acc = fmaf(wy, rowacc, acc);
+            }
+        }
+        red[yl][axl] = acc;
+        __syncthreads();
+        if (yl == 0 && ax < AW) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += red[i][axl];
+            datt[((size_t)q * AH + ay) * AW + ax] = s;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int uncr_agg_slots(int P) { return P / AGG_PX; }
+
+static int agg_check(int B, int T, int C, int NH, int H, int W, int AH, int AW) {
+    if (B <= 0 || T <= 0 || C % NH || C > 256) return UNCR_ESHAPE;
+    if (C / NH != 4 && C / NH != 8 && C / NH != 16) return UNCR_ESHAPE;
+    if ((W & 3) || ((H * W) % AGG_PX)) return UNCR_ESHAPE;
+    if (H <= AH || W <= AW) return UNCR_ESHAPE;   // avg-pool branch (uncrtaints.py:204) not built
+    return UNCR_OK;
+}
+
+extern "C" int uncr_aggregate_fwd(const float* e, const float* att, const int* pad, const float* dmask,
+                                  unsigned long long seed, float p_drop, float* out, float* part, int B, int T,
+                                  int C, int NH, int H, int W, int AH, int AW, hipStream_t stream) {
+    const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
+    if (rc) return rc;
+    AggArgs g{e, att, pad, dmask, out, nullptr, nullptr, nullptr, (float2*)part, seed, p_drop, B, T, C, NH, H, W, AH, AW};
+    const dim3 grid(H * W / AGG_PX, B);
+    switch (C / NH) {
+        case 4: hipLaunchKernelGGL((aggregate_kernel<false, 4>), grid, dim3(256), 0, stream, g); break;
+        case 8: hipLaunchKernelGGL((aggregate_kernel<false, 8>), grid, dim3(256), 0, stream, g); break;
+        default: hipLaunchKernelGGL((aggregate_kernel<false, 16>), grid, dim3(256), 0, stream, g); break;
+    }
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const int* pad,
+                                  const float* dmask, unsigned long long seed, float p_drop, float* de,
+                                  float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int AH,
+                                  int AW, hipStream_t stream) {
+    const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
+    if (rc) return rc;
+    AggArgs g{e, att, pad, dmask, nullptr, dg, de, datt_up, nullptr, seed, p_drop, B, T, C, NH, H, W, AH, AW};
+    const dim3 grid(H * W / AGG_PX, B);
+    switch (C / NH) {
+        case 4: hipLaunchKernelGGL((aggregate_kernel<true, 4>), grid, dim3(256), 0, stream, g); break;
+        case 8: hipLaunchKernelGGL((aggregate_kernel<true, 8>), grid, dim3(256), 0, stream, g); break;
+        default: hipLaunchKernelGGL((aggregate_kernel<true, 16>), grid, dim3(256), 0, stream, g); break;
+    }
+    UNCR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(AH, NH * B * T), dim3(256), 0, stream, datt_up, datt, H, W, AH,
+                       AW);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}

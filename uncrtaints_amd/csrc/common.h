@@ -1,0 +1,88 @@
+// Shared device helpers for libuncr_hip (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define UNCR_OK 0
+#define UNCR_EINVAL (-1)
+#define UNCR_ESHAPE (-2)
+
+#define UNCR_LAUNCH_CHECK()                       \
+    do {                                          \
+        hipError_t e__ = hipGetLastError();       \
+        if (e__ != hipSuccess) return (int)e__;   \
+    } while (0)
+
+// prologue kinds shared by the pointwise GEMM, the weight-gradient GEMM and the element-wise family
+enum : int {
+    PRO_NONE = 0,        // v
+    PRO_AFFINE = 1,      // A*v + B
+    PRO_AFFINE_GELU = 2, // S * gelu(A*v + B)        (S == 1 when no scale array is given)
+    PRO_NORMBWD = 3,     // C1*v + C2*v2 + C3        (norm backward: v = d(norm out), v2 = raw norm input)
+    PRO_AFFINE_RELU = 4  // max(A*v + B, 0)
+};
+
+enum : int { NORM_GROUP = 0, NORM_BATCH_TRAIN = 1, NORM_BATCH_EVAL = 2 };
+
+__device__ __forceinline__ float gelu_f(float u) {
+    // exact (erf) GELU, as nn.GELU() default
+    return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float u) {
+    // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
+    const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+    return cdf + u * pdf;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// sum over the 64 lanes of a wave (all lanes get the result)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+// sum over each 32-lane half of a wave (lanes 0-31 and 32-63 separately)
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Block-wide sum of two floats; result valid in thread 0.  `red` must hold >= 2*nwaves floats.
+template <int NTHREADS>
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+    constexpr int NW = NTHREADS / 64;
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { sa += red[2 * i]; sb += red[2 * i + 1]; }
+        a = sa; b = sb;
+    }
+    __syncthreads();
+}
+
+// reflect index for padding 1 (PyTorch 'reflect': -1 -> 1, n -> n-2)
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// counter-based RNG for the attention dropout: 32-bit mix of (seed, index); uniform in [0,1)
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
+    uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)((uint32_t)(z >> 40)) * (1.0f / 16777216.0f);
+}
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;

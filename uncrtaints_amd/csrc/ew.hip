@@ -1,0 +1,182 @@
+// Element-wise family over NCHW planes with fused per-(n,c) coefficient application and
+// per-block (sum, sum*) partial statistics.  All of these are HBM-streaming kernels: one block =
+// one (n,c) plane chunk of EW_CHUNK pixels, 16-byte loads/stores, stats reduced with wave shuffles.
+//
+// grid = (P / EW_CHUNK, N*C); partials are written to part[(n*C+c)*NP + blockIdx.x], NP = P/EW_CHUNK.
+#include "common.h"
+
+#define EW_CHUNK 1024   // pixels per block (256 threads x float4)
+
+enum : int {
+    EW_STATS_SQ = 0,     // stats only: (sum a, sum a^2)
+    EW_STATS_AUX = 1,    // stats only: (sum a, sum a*b)
+    EW_AFFINE_RELU = 2,  // out = relu(A*a + B);              stats (sum out, sum out^2)
+    EW_RESIDUAL = 3,     // out = a + A*b + B;                stats (sum out, sum out^2)   a=x, b=h3
+    EW_PASSB = 4,        // out = gelu'(A*b + B) * (S*a + D); stats (sum out, sum out*b)   a=dz, b=h2
+    EW_PASSE = 5,        // out = a + C1*b + C2*c + C3;       stats (sum out, sum out*aux) a=dy, b=da, c=x
+    EW_RELU_BWD = 6,     // out = a * [A*b + B > 0];          stats (sum out, sum out*b)   a=d(a0), b=c0
+    EW_SE_POOL = 7,      // stats only: (sum gelu(A*a + B), 0)
+    EW_HEAD_FWD = 8,     // out = c < n_mean ? scale*sigmoid(a) : softplus(a)+eps   (per-plane channel test)
+    EW_HEAD_BWD = 9      // out = a * f'(b)   a = d(out), b = pre-activation
+};
+
+struct EwArgs {
+    const float* a;
+    const float* b;
+    const float* c;
+    const float* aux;    // optional second stats operand for PASSE
+    float* out;
+    const float* k0;     // per-plane coefficient arrays [N*C] (meaning depends on op)
+    const float* k1;
+    const float* k2;
+    const float* k3;
+    float2* part;        // optional [N*C][NP]
+    int P;
+    int C;               // channels per frame (HEAD ops)
+    int n_mean;          // HEAD: number of mean channels
+    float scale;         // HEAD: scale_by
+    float eps;           // HEAD: variance epsilon
+};
+
+template <int OP>
+__global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
+    const int plane = blockIdx.y;
+    const size_t off = (size_t)plane * g.P + (size_t)blockIdx.x * EW_CHUNK + threadIdx.x * 4;
+    float s0 = 0.f, s1 = 0.f;
+    float4 va = *(const float4*)(g.a + off);
+    float4 vo;
+    float* o = (float*)&vo;
+    const float* pa = (const float*)&va;
+    if constexpr (OP == EW_STATS_SQ) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s0 += pa[i]; s1 += pa[i] * pa[i]; }
+    } else if constexpr (OP == EW_STATS_AUX) {
+        const float4 vb = *(const float4*)(g.b + off);
+        const float* pb = (const float*)&vb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s0 += pa[i]; s1 += pa[i] * pb[i]; }
+    } else if constexpr (OP == EW_AFFINE_RELU) {
+        const float A = g.k0[plane], B = g.k1[plane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = fmaxf(fmaf(A, pa[i], B), 0.f);
+            s0 += o[i]; s1 += o[i] * o[i];
+        }
+    } else if constexpr (OP == EW_RESIDUAL) {
+        const float A = g.k0[plane], B = g.k1[plane];
+        const float4 vb = *(const float4*)(g.b + off);
+        const float* pb = (const float*)&vb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = pa[i] + fmaf(A, pb[i], B);
+            s0 += o[i]; s1 += o[i] * o[i];
+        }
+    } else if constexpr (OP == EW_PASSB) {
+        const float A = g.k0[plane], B = g.k1[plane], S = g.k2[plane], D = g.k3[plane];
+        const float4 vb = *(const float4*)(g.b + off);
+        const float* pb = (const float*)&vb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float u = fmaf(A, pb[i], B);
+            o[i] = gelu_grad_f(u) * fmaf(S, pa[i], D);
+            s0 += o[i]; s1 += o[i] * pb[i];
+        }
+    } else if constexpr (OP == EW_PASSE) {
+        const float C1 = g.k0[plane], C2 = g.k1[plane], C3 = g.k2[plane];
+        const float4 vb = *(const float4*)(g.b + off);
+        const float4 vc = *(const float4*)(g.c + off);
+        const float* pb = (const float*)&vb;
+        const float* pc = (const float*)&vc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = pa[i] + fmaf(C1, pb[i], fmaf(C2, pc[i], C3));
+        if (g.part) {
+            const float4 vx = *(const float4*)(g.aux + off);
+            const float* px = (const float*)&vx;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s0 += o[i]; s1 += o[i] * px[i]; }
+        }
+    } else if constexpr (OP == EW_RELU_BWD) {
+        const float A = g.k0[plane], B = g.k1[plane];
+        const float4 vb = *(const float4*)(g.b + off);
+        const float* pb = (const float*)&vb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = fmaf(A, pb[i], B) > 0.f ? pa[i] : 0.f;
+            s0 += o[i]; s1 += o[i] * pb[i];
+        }
+    } else if constexpr (OP == EW_SE_POOL) {
+        const float A = g.k0[plane], B = g.k1[plane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s0 += gelu_f(fmaf(A, pa[i], B));
+    } else if constexpr (OP == EW_HEAD_FWD) {
+        // n_mean > 0: first n_mean channels get scale*sigmoid; n_mean < 0: first |n_mean| channels identity
+        const int ch = plane % g.C;
+        const int nm = g.n_mean < 0 ? -g.n_mean : g.n_mean;
+        if (ch < nm) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = g.n_mean > 0 ? g.scale * sigmoid_f(pa[i]) : pa[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // nn.Softplus(beta=1, threshold=20): identity above the threshold
+                const float x = pa[i];
+                o[i] = (x > 20.f ? x : log1pf(__expf(x))) + g.eps;
+            }
+        }
+    } else if constexpr (OP == EW_HEAD_BWD) {
+        const int ch = plane % g.C;
+        const float4 vb = *(const float4*)(g.b + off);
+        const float* pb = (const float*)&vb;
+        const int nm = g.n_mean < 0 ? -g.n_mean : g.n_mean;
+        if (ch < nm) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float sg = sigmoid_f(pb[i]);
+                o[i] = g.n_mean > 0 ? pa[i] * g.scale * sg * (1.f - sg) : pa[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = pa[i] * (pb[i] > 20.f ? 1.f : sigmoid_f(pb[i]));
+        }
+    }
+    if constexpr (OP != EW_STATS_SQ && OP != EW_STATS_AUX && OP != EW_SE_POOL) *(float4*)(g.out + off) = vo;
+    if constexpr (OP != EW_HEAD_FWD && OP != EW_HEAD_BWD) {
+        if (g.part) {
+            __shared__ float red[8];
+            block_sum2<256>(s0, s1, red);
+            if (threadIdx.x == 0) g.part[(size_t)plane * gridDim.x + blockIdx.x] = make_float2(s0, s1);
+        }
+    }
+}
+
+extern "C" int uncr_ew_slots(int P) { return P / EW_CHUNK; }
+
+extern "C" int uncr_ew(int op, const float* a, const float* b, const float* c, const float* aux, float* out,
+                       const float* k0, const float* k1, const float* k2, const float* k3, float* part, int planes,
+                       int P, int C, int n_mean, float scale, float eps, hipStream_t stream) {
+    if (planes <= 0 || P <= 0 || (P % EW_CHUNK) != 0) return UNCR_ESHAPE;
+    if (!a) return UNCR_EINVAL;
+    EwArgs g{a, b, c, aux, out, k0, k1, k2, k3, (float2*)part, P, C, n_mean, scale, eps};
+    dim3 grid(P / EW_CHUNK, planes), blk(256);
+#define EW_CASE(OPV)                                                  \
+    case OPV:                                                         \
+        hipLaunchKernelGGL(ew_kernel<OPV>, grid, blk, 0, stream, g);  \
+        break;
+    switch (op) {
+        EW_CASE(EW_STATS_SQ)
+        EW_CASE(EW_STATS_AUX)
+        EW_CASE(EW_AFFINE_RELU)
+        EW_CASE(EW_RESIDUAL)
+        EW_CASE(EW_PASSB)
+        EW_CASE(EW_PASSE)
+        EW_CASE(EW_RELU_BWD)
+        EW_CASE(EW_SE_POOL)
+        EW_CASE(EW_HEAD_FWD)
+        EW_CASE(EW_HEAD_BWD)
+        default:
+            return UNCR_EINVAL;
+    }
+#undef EW_CASE
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}

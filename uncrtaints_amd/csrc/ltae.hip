@@ -1,0 +1,357 @@
+// L-TAE (LTAE2dtiny, ltae.py:145-239) low-resolution branch.  Runs at 32x32 (uncrtaints.py:403), <1 % of
+// the bytes of the path; kernels are simple, coalesced along the pixel axis.  The two linear maps
+// (Conv1d 128->256, Linear 256->64) reuse the MFMA pointwise GEMM on [frames, C, 1024] planes.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// adaptive max-pool [planes][H][W] -> [planes][OH][OW] (+ argmax as flat in-plane index)
+// (nn.AdaptiveMaxPool2d window: start = floor(i*H/OH), end = ceil((i+1)*H/OH); first max wins)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          int* __restrict__ idx, int H, int W, int OH, int OW) {
+    const int plane = blockIdx.y;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= OH * OW) return;
+    const int oy = o / OW, ox = o % OW;
+    const int ys = (oy * H) / OH, ye = ((oy + 1) * H + OH - 1) / OH;
+    const int xs = (ox * W) / OW, xe = ((ox + 1) * W + OW - 1) / OW;
+    const float* p = in + (size_t)plane * H * W;
+    float best = -INFINITY;
+    int bi = ys * W + xs;
+    for (int y = ys; y < ye; ++y)
+        for (int x = xs; x < xe; ++x) {
+            const float v = p[y * W + x];
+            if (v > best || v != v) { best = v; bi = y * W + x; }   // NaN propagates like ATen
+        }
+    out[(size_t)plane * OH * OW + o] = best;
+    idx[(size_t)plane * OH * OW + o] = bi;
+}
+
+// de[plane][idx] += dpooled   (windows are disjoint when H % OH == 0; otherwise atomics)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx,
+                                                          float* __restrict__ din, int HW, int OHW, int disjoint) {
+    const int plane = blockIdx.y;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= OHW) return;
+    const size_t q = (size_t)plane * OHW + o;
+    float* dst = din + (size_t)plane * HW + idx[q];
+    if (disjoint) *dst += dout[q];
+    else atomicAdd(dst, dout[q]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-pixel GroupNorm over (Cg channels x T dates)  (ltae.py:191-194,211; n_head groups)
+// x [B][T][C][S] (S = low-res pixels), thread = (b, g, s)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ltae_gn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ y, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, int T, int C, int G, int S) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y, b = blockIdx.z;
+    if (s >= S) return;
+    const int Cg = C / G;
+    float sum = 0.f, sq = 0.f;
+    for (int t = 0; t < T; ++t)
+        for (int j = 0; j < Cg; ++j) {
+            const float v = x[(((size_t)b * T + t) * C + g * Cg + j) * S + s];
+            sum += v;
+            sq = fmaf(v, v, sq);
+        }
+    const float M = (float)(T * Cg);
+    const float mu = sum / M;
+    // second pass for the variance (numerically safer than E[x^2]-mu^2 at 24 samples)
+    float var = 0.f;
+    for (int t = 0; t < T; ++t)
+        for (int j = 0; j < Cg; ++j) {
+            const float d = x[(((size_t)b * T + t) * C + g * Cg + j) * S + s] - mu;
+            var = fmaf(d, d, var);
+        }
+    var /= M;
+    const float r = 1.0f / sqrtf(var + eps);
+    mean[((size_t)b * G + g) * S + s] = mu;
+    rstd[((size_t)b * G + g) * S + s] = r;
+    for (int t = 0; t < T; ++t)
+        for (int j = 0; j < Cg; ++j) {
+            const int c = g * Cg + j;
+            const size_t o = (((size_t)b * T + t) * C + c) * S + s;
+            y[o] = (x[o] - mu) * r * gamma[c] + beta[c];
+        }
+    (void)sq;
+}
+
+// backward; gb_part[(b*nchunk+chunk)][C][2] = per-block (d gamma, d beta) partials.  Cg <= 16.
+__global__ __launch_bounds__(256) void ltae_gn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, float* __restrict__ dx,
+                                                          float* __restrict__ gb_part, int T, int C, int G, int S) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y, b = blockIdx.z;
+    const int Cg = C / G;
+    const bool act = s < S;
+    float mu = 0.f, r = 0.f, m1 = 0.f, m2 = 0.f;
+    float dgam[16], dbet[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { dgam[j] = 0.f; dbet[j] = 0.f; }
+    if (act) {
+        mu = mean[((size_t)b * G + g) * S + s];
+        r = rstd[((size_t)b * G + g) * S + s];
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < Cg) {
+                    const int c = g * Cg + j;
+                    const size_t o = (((size_t)b * T + t) * C + c) * S + s;
+                    const float d = dy[o], xh = (x[o] - mu) * r;
+                    m1 = fmaf(gamma[c], d, m1);
+                    m2 = fmaf(gamma[c] * d, xh, m2);
+                    dgam[j] = fmaf(d, xh, dgam[j]);
+                    dbet[j] += d;
+                }
+        const float M = (float)(T * Cg);
+        m1 /= M;
+        m2 /= M;
+        for (int t = 0; t < T; ++t)
+            for (int j = 0; j < Cg; ++j) {
+                const int c = g * Cg + j;
+                const size_t o = (((size_t)b * T + t) * C + c) * S + s;
+                const float xh = (x[o] - mu) * r;
+                dx[o] = r * (gamma[c] * dy[o] - m1 - xh * m2);
+            }
+    }
+    __shared__ float red[4][32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float a = wave_sum(dgam[j]), bb = wave_sum(dbet[j]);
+        if (lane == 0) { red[wv][2 * j] = a; red[wv][2 * j + 1] = bb; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * Cg) {
+        const int j = threadIdx.x >> 1, which = threadIdx.x & 1;
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
+        gb_part[(blk * C + g * Cg + j) * 2 + which] = v;
+    }
+}
+
+// out[r][k] summed over r (fp64, fixed order): generic column sum for small partial arrays
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int R, int K,
+                                                     float* __restrict__ out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) s += (double)part[(size_t)r * K + k];
+    out[k] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-frame bias of the first linear map:  bias[n][c] = b_in[c] + PE(date[n], c)
+// PositionalEncoder (positional_encoding.py:5-31): channel c uses sinusoid i = c mod d, even -> sin,
+// odd -> cos, argument date / denom[i].  denom is computed on the host exactly like the reference
+// __init__ does (torch.pow), so the only device transcendental is sinf/cosf with full range reduction.
+// ---------------------------------------------------------------------------------------------
+__global__ void ltae_posbias_kernel(const float* __restrict__ dates, const float* __restrict__ denom, int d,
+                                    const float* __restrict__ bin, float* __restrict__ out, int NF, int D,
+                                    int use_pe) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= NF * D) return;
+    const int n = idx / D, c = idx % D;
+    float v = bin ? bin[c] : 0.f;
+    if (use_pe) {
+        const int i = c % d;
+        const float a = dates[n] / denom[i];
+        v += (i & 1) ? cosf(a) : sinf(a);
+    }
+    out[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// temporal softmax (ltae.py:341-385, 431-458): k [B][T][NH*DK][S], Q [NH][DK] -> att [NH][B][T][S]
+//   score = (Q[h] . k[b,t,h*DK:(h+1)*DK, s]) / sqrt(DK); pad -> -1e3; softmax over t.
+// thread = (b, h, s)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ltae_score(const float* __restrict__ k, const float* q, int DK, size_t base,
+                                            int S, float inv_temp) {
+    float a = 0.f;
+    for (int d = 0; d < DK; ++d) a = fmaf(q[d], k[base + (size_t)d * S], a);
+    return a * inv_temp;
+}
+
+__global__ __launch_bounds__(256) void ltae_softmax_fwd_kernel(const float* __restrict__ k,
+                                                               const float* __restrict__ Q,
+                                                               const int* __restrict__ pad, float* __restrict__ att,
+                                                               int B, int T, int NH, int DK, int S, float inv_temp) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z;
+    if (s >= S) return;
+    float q[8];
+    for (int d = 0; d < DK; ++d) q[d] = Q[h * DK + d];
+    float mx = -INFINITY;
+    for (int t = 0; t < T; ++t) {
+        float sc = ltae_score(k, q, DK, (((size_t)b * T + t) * NH * DK + h * DK) * S + s, S, inv_temp);
+        if (pad && pad[b * T + t]) sc = -1e3f;
+        mx = fmaxf(mx, sc);
+    }
+    float den = 0.f;
+    for (int t = 0; t < T; ++t) {
+        float sc = ltae_score(k, q, DK, (((size_t)b * T + t) * NH * DK + h * DK) * S + s, S, inv_temp);
+        if (pad && pad[b * T + t]) sc = -1e3f;
+        den += expf(sc - mx);
+    }
+    const float inv = 1.0f / den;
+    for (int t = 0; t < T; ++t) {
+        float sc = ltae_score(k, q, DK, (((size_t)b * T + t) * NH * DK + h * DK) * S + s, S, inv_temp);
+        if (pad && pad[b * T + t]) sc = -1e3f;
+        att[(((size_t)h * B + b) * T + t) * S + s] = expf(sc - mx) * inv;
+    }
+}
+
+// backward: datt, att -> dk [B][T][NH*DK][S]; dq_part[(b*nchunk+chunk)][NH*DK]
+__global__ __launch_bounds__(256) void ltae_softmax_bwd_kernel(const float* __restrict__ datt,
+                                                               const float* __restrict__ att,
+                                                               const float* __restrict__ k,
+                                                               const float* __restrict__ Q,
+                                                               const int* __restrict__ pad, float* __restrict__ dk,
+                                                               float* __restrict__ dq_part, int B, int T, int NH,
+                                                               int DK, int S, float inv_temp) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const bool act = s < S;
+    float dq[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) dq[d] = 0.f;
+    if (act) {
+        float dot = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const size_t o = (((size_t)h * B + b) * T + t) * S + s;
+            dot = fmaf(att[o], datt[o], dot);
+        }
+        for (int t = 0; t < T; ++t) {
+            const size_t o = (((size_t)h * B + b) * T + t) * S + s;
+            float ds = att[o] * (datt[o] - dot);
+            if (pad && pad[b * T + t]) ds = 0.f;      // masked_fill: no gradient to the replaced score
+            ds *= inv_temp;
+            const size_t kb = (((size_t)b * T + t) * NH * DK + h * DK) * S + s;
+#pragma unroll
+            for (int d = 0; d < 8; ++d)
+                if (d < DK) {
+                    dk[kb + (size_t)d * S] = ds * Q[h * DK + d];
+                    dq[d] = fmaf(ds, k[kb + (size_t)d * S], dq[d]);
+                }
+        }
+    }
+    __shared__ float red[4][8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const float a = wave_sum(dq[d]);
+        if (lane == 0) red[wv][d] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < DK) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
+        dq_part[blk * NH * DK + h * DK + threadIdx.x] = v;
+    }
+}
+
+// pad_mask[n] = 1 iff every element of frame n equals pad_value (uncrtaints.py:392-394).  One block per
+// frame with a block-wide early exit: a real frame is rejected after its first chunk.
+__global__ __launch_bounds__(256) void pad_mask_kernel(const float* __restrict__ x, long long frame_elems,
+                                                       float pad_value, int* __restrict__ mask) {
+    const float* src = x + (size_t)blockIdx.x * frame_elems;
+    int found = 0;
+    for (long long base = 0; base < frame_elems; base += 256 * 4) {
+        int local = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long i = base + j * 256 + threadIdx.x;
+            if (i < frame_elems && src[i] != pad_value) local = 1;
+        }
+        if (__syncthreads_or(local)) { found = 1; break; }
+    }
+    if (threadIdx.x == 0) mask[blockIdx.x] = found ? 0 : 1;
+}
+
+extern "C" int uncr_pad_mask(const float* x, int NF, long long frame_elems, float pad_value, int* mask,
+                             hipStream_t stream) {
+    if (NF <= 0 || frame_elems <= 0) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(pad_mask_kernel, dim3(NF), dim3(256), 0, stream, x, frame_elems, pad_value, mask);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_maxpool_fwd(const float* in, float* out, int* idx, int planes, int H, int W, int OH, int OW,
+                                hipStream_t stream) {
+    if (planes <= 0 || H < OH || W < OW) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((OH * OW + 255) / 256, planes), dim3(256), 0, stream, in, out, idx, H,
+                       W, OH, OW);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_maxpool_bwd(const float* dout, const int* idx, float* din, int planes, int H, int W, int OH,
+                                int OW, hipStream_t stream) {
+    if (planes <= 0) return UNCR_ESHAPE;
+    const int disjoint = (H % OH == 0) && (W % OW == 0);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((OH * OW + 255) / 256, planes), dim3(256), 0, stream, dout, idx, din,
+                       H * W, OH * OW, disjoint);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_ltae_gn_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y,
+                                float* mean, float* rstd, int B, int T, int C, int G, int S, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || C % G) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(ltae_gn_fwd_kernel, dim3((S + 255) / 256, G, B), dim3(256), 0, stream, x, gamma, beta, eps, y,
+                       mean, rstd, T, C, G, S);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_ltae_gn_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                const float* rstd, float* dx, float* gb_part, int B, int T, int C, int G, int S,
+                                hipStream_t stream) {
+    if (B <= 0 || T <= 0 || C % G || C / G > 16) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(ltae_gn_bwd_kernel, dim3((S + 255) / 256, G, B), dim3(256), 0, stream, dy, x, gamma, mean,
+                       rstd, dx, gb_part, T, C, G, S);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_colsum(const float* part, int R, int K, float* out, hipStream_t stream) {
+    if (R <= 0 || K <= 0) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(colsum_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, part, R, K, out);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_ltae_posbias(const float* dates, const float* denom, int d, const float* bin, float* out,
+                                 int NF, int D, int use_pe, hipStream_t stream) {
+    if (NF <= 0 || D <= 0 || (use_pe && (!dates || !denom || d <= 0))) return UNCR_EINVAL;
+    hipLaunchKernelGGL(ltae_posbias_kernel, dim3((NF * D + 255) / 256), dim3(256), 0, stream, dates, denom, d, bin,
+                       out, NF, D, use_pe);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_ltae_softmax_fwd(const float* k, const float* Q, const int* pad, float* att, int B, int T,
+                                     int NH, int DK, int S, hipStream_t stream) {
+    if (DK > 8 || B <= 0) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(ltae_softmax_fwd_kernel, dim3((S + 255) / 256, NH, B), dim3(256), 0, stream, k, Q, pad, att, B,
+                       T, NH, DK, S, 1.0f / sqrtf((float)DK));
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_ltae_softmax_bwd(const float* datt, const float* att, const float* k, const float* Q,
+                                     const int* pad, float* dk, float* dq_part, int B, int T, int NH, int DK, int S,
+                                     hipStream_t stream) {
+    if (DK > 8 || B <= 0) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(ltae_softmax_bwd_kernel, dim3((S + 255) / 256, NH, B), dim3(256), 0, stream, datt, att, k, Q,
+                       pad, dk, dq_part, B, T, NH, DK, S, 1.0f / sqrtf((float)DK));
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}

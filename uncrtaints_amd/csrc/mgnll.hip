@@ -1,0 +1,174 @@
+// Multivariate (diagonal / isotropic) Gaussian NLL, losses.py:131-218, as ONE streaming pass per direction
+// (the reference runs a double vmap of tiny bmm's and moves a dense [B,1,13,13,H,W] covariance to the host).
+//
+//   L[b,p] = k/2 ln(2 pi) + 1/2 sum_{b',c} ln v[b',c,p] + 1/2 max(nan_to_num(sum_c (mu-t)^2 / v), 1e-9)
+//   v = max(var, eps) with identity gradient (losses.py:203-205); the log-det is summed over the batch
+//   AND channels inside the per-pixel function (losses.py:138) -- reproduced on purpose.
+//
+// Layouts: pred/target [B][K][P], var [B][Kv][P] with Kv = K (diag) or 1 (iso, broadcast).
+// loss_none (optional) is laid out [W][H][B] like the reference's reduction='none' result.
+#include "common.h"
+
+#define MG_PX 256   // pixels per block (1 per thread; B*K*3 planes streamed per thread)
+
+__global__ __launch_bounds__(256) void mgnll_fwd_kernel(const float* __restrict__ pred,
+                                                        const float* __restrict__ targ,
+                                                        const float* __restrict__ var, float* __restrict__ loss_none,
+                                                        float* __restrict__ part, int* __restrict__ neg_flag, int B,
+                                                        int K, int Kv, int H, int W, float eps) {
+    const int P = H * W;
+    const int p = blockIdx.x * MG_PX + threadIdx.x;
+    float total = 0.f;
+    if (p < P) {
+        float logdet = 0.f;
+        bool neg = false;
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < Kv; ++c) {
+                const float vr = var[((size_t)b * Kv + c) * P + p];
+                neg |= vr < 0.f;
+                logdet += logf(fmaxf(vr, eps)) * (Kv == 1 ? (float)K : 1.f);
+            }
+        if (neg && neg_flag) atomicOr(neg_flag, 1);
+        const float cst = 0.5f * (float)K * 1.8378770664093453f;   // k/2 * ln(2 pi)
+        const int y = p / W, x = p % W;
+        for (int b = 0; b < B; ++b) {
+            float maha = 0.f;
+            for (int c = 0; c < K; ++c) {
+                const float v = fmaxf(var[((size_t)b * Kv + (Kv == 1 ? 0 : c)) * P + p], eps);
+                const float e = pred[((size_t)b * K + c) * P + p] - targ[((size_t)b * K + c) * P + p];
+                maha += e * e / v;
+            }
+            if (maha != maha) maha = 0.f;                       // nan_to_num
+            else if (maha > 3.4028234664e38f) maha = 3.4028234664e38f;
+            maha = fmaxf(maha, 1e-9f);
+            const float l = cst + 0.5f * logdet + 0.5f * maha;
+            if (loss_none) loss_none[((size_t)x * H + y) * B + b] = l;
+            total += l;
+        }
+    }
+    __shared__ float red[8];
+    float dummy = 0.f;
+    block_sum2<256>(total, dummy, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = total;
+}
+
+// backward.  gscalar: device scalar upstream gradient times `scale` (1/(P*B) for 'mean', 1 for 'sum'); or
+// gnone: upstream gradient for reduction='none' in [W][H][B] layout.
+__global__ __launch_bounds__(256) void mgnll_bwd_kernel(const float* __restrict__ pred,
+                                                        const float* __restrict__ targ,
+                                                        const float* __restrict__ var,
+                                                        const float* __restrict__ gscalar, float scale,
+                                                        const float* __restrict__ gnone, float* __restrict__ dpred,
+                                                        float* __restrict__ dvar, int B, int K, int Kv, int H, int W,
+                                                        float eps) {
+    const int P = H * W;
+    const int p = blockIdx.x * MG_PX + threadIdx.x;
+    if (p >= P) return;
+    const int y = p / W, x = p % W;
+    const float gs = gscalar ? gscalar[0] * scale : 0.f;
+    float gsum = 0.f;   // sum_b upstream weight (log-det couples every sample of the batch)
+    for (int b = 0; b < B; ++b) gsum += gnone ? gnone[((size_t)x * H + y) * B + b] : gs;
+    for (int b = 0; b < B; ++b) {
+        const float gb = gnone ? gnone[((size_t)x * H + y) * B + b] : gs;
+        float maha = 0.f;
+        for (int c = 0; c < K; ++c) {
+            const float v = fmaxf(var[((size_t)b * Kv + (Kv == 1 ? 0 : c)) * P + p], eps);
+            const float e = pred[((size_t)b * K + c) * P + p] - targ[((size_t)b * K + c) * P + p];
+            maha += e * e / v;
+        }
+        // gradient flows through nan_to_num/clamp only for finite values above the clamp
+        const float ind = (maha == maha && maha <= 3.4028234664e38f && maha > 1e-9f) ? 1.f : 0.f;
+        float dv_iso = 0.f;
+        for (int c = 0; c < K; ++c) {
+            const float v = fmaxf(var[((size_t)b * Kv + (Kv == 1 ? 0 : c)) * P + p], eps);
+            const float e = pred[((size_t)b * K + c) * P + p] - targ[((size_t)b * K + c) * P + p];
+            const float iv = 1.f / v;
+            if (dpred) dpred[((size_t)b * K + c) * P + p] = gb * ind * e * iv;
+            const float dv = 0.5f * gsum * iv - 0.5f * gb * ind * e * e * iv * iv;
+            if (Kv == 1) dv_iso += dv;
+            else if (dvar) dvar[((size_t)b * Kv + c) * P + p] = dv;
+        }
+        if (Kv == 1 && dvar) dvar[(size_t)b * P + p] = dv_iso;
+    }
+}
+
+// sum `n` floats (fp64, single block, fixed order) times `scale` -> out[0]
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ part, int n, double scale,
+                                                        float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)part[i];
+    __shared__ double red[4];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) * scale);
+}
+
+// ensemble combine (ensemble_reconstruct.py:116-133): means/vars [M][n] -> mean_ens, var_ens [n]
+// mode 0 'both': mean_i(var_i + mu_i^2) - mu_ens^2; 1 'aleatoric': mean_i var_i; 2 'epistemic': mean_i mu_i^2 - mu_ens^2
+__global__ __launch_bounds__(256) void ensemble_kernel(const float* __restrict__ mu, const float* __restrict__ var,
+                                                       int M, size_t n, int mode, float* __restrict__ mu_out,
+                                                       float* __restrict__ var_out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float sm = 0.f, sv = 0.f, sq = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float a = mu[(size_t)m * n + i];
+        sm += a;
+        sq = fmaf(a, a, sq);
+        if (var) sv += var[(size_t)m * n + i];
+    }
+    const float inv = 1.f / (float)M;
+    const float me = sm * inv;
+    mu_out[i] = me;
+    float v;
+    if (mode == 0) v = (sv + sq) * inv - me * me;
+    else if (mode == 1) v = sv * inv;
+    else v = sq * inv - me * me;
+    var_out[i] = v;
+}
+
+extern "C" int uncr_mgnll_blocks(int P) { return (P + MG_PX - 1) / MG_PX; }
+
+extern "C" int uncr_mgnll_fwd(const float* pred, const float* targ, const float* var, float* loss_none, float* part,
+                              float* loss_out, int* neg_flag, int B, int K, int Kv, int H, int W, float eps,
+                              int reduction /*0 none, 1 mean, 2 sum*/, hipStream_t stream) {
+    if (B <= 0 || K <= 0 || (Kv != K && Kv != 1)) return UNCR_ESHAPE;
+    if (!pred || !targ || !var || !part) return UNCR_EINVAL;
+    const int P = H * W, nb = uncr_mgnll_blocks(P);
+    hipLaunchKernelGGL(mgnll_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred, targ, var, loss_none, part, neg_flag, B,
+                       K, Kv, H, W, eps);
+    UNCR_LAUNCH_CHECK();
+    if (reduction != 0) {
+        if (!loss_out) return UNCR_EINVAL;
+        const double sc = reduction == 1 ? 1.0 / ((double)P * (double)B) : 1.0;
+        hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, stream, part, nb, sc, loss_out);
+        UNCR_LAUNCH_CHECK();
+    }
+    return UNCR_OK;
+}
+
+extern "C" int uncr_mgnll_bwd(const float* pred, const float* targ, const float* var, const float* gscalar,
+                              const float* gnone, float* dpred, float* dvar, int B, int K, int Kv, int H, int W,
+                              float eps, int reduction, hipStream_t stream) {
+    if (B <= 0 || K <= 0 || (Kv != K && Kv != 1)) return UNCR_ESHAPE;
+    if ((reduction == 0 && !gnone) || (reduction != 0 && !gscalar)) return UNCR_EINVAL;
+    const int P = H * W;
+    const float sc = reduction == 1 ? (float)(1.0 / ((double)P * (double)B)) : 1.f;
+    hipLaunchKernelGGL(mgnll_bwd_kernel, dim3(uncr_mgnll_blocks(P)), dim3(256), 0, stream, pred, targ, var,
+                       reduction ? gscalar : nullptr, sc, reduction ? nullptr : gnone, dpred, dvar, B, K, Kv, H, W, eps);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_ensemble_combine(const float* mu, const float* var, int M, long long n, int mode, float* mu_out,
+                                     float* var_out, hipStream_t stream) {
+    if (M <= 0 || n <= 0 || mode < 0 || mode > 2) return UNCR_ESHAPE;
+    if (mode != 2 && !var) return UNCR_EINVAL;
+    hipLaunchKernelGGL(ensemble_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mu, var, M, (size_t)n,
+                       mode, mu_out, var_out);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_version() { return 1; }

@@ -1,0 +1,258 @@
+// Normalisation statistics -> per-(frame,channel) affine coefficients.
+//
+// Every GroupNorm / BatchNorm on the path (uncrtaints.py:16-22, utae.py:470-473) is applied by the
+// CONSUMING kernel as  u = A[n,c]*h + B[n,c]; the producers only emit per-block partial sums
+// (sum h, sum h^2) per (n,c).  These kernels turn the partials into A/B (forward) and into the three
+// backward coefficients  dh = C1*du + C2*h + C3  (+ d gamma, d beta).  Final combines run in fp64 in a
+// fixed order, so results are deterministic.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// forward: GroupNorm.  grid = N*G blocks; block reduces the contiguous range of Cg*NP partials.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(
+    const float2* __restrict__ part, int NP, int C, int G, int P, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float* __restrict__ coefA, float* __restrict__ coefB,
+    float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+    const int n = blockIdx.x / G, g = blockIdx.x % G;
+    const int Cg = C / G;
+    const float2* src = part + ((size_t)n * C + (size_t)g * Cg) * NP;
+    const int cnt = Cg * NP;
+    double s = 0.0, ss = 0.0;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const float2 v = src[i];
+        s += (double)v.x;
+        ss += (double)v.y;
+    }
+    __shared__ double red[8];
+    __shared__ float sh_mean, sh_rstd;
+    s = wave_sum_d(s);
+    ss = wave_sum_d(ss);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[2 * w] = s; red[2 * w + 1] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = 0, SS = 0;
+        for (int i = 0; i < 4; ++i) { S += red[2 * i]; SS += red[2 * i + 1]; }
+        const double M = (double)Cg * (double)P;
+        const double mean = S / M;
+        double var = SS / M - mean * mean;
+        if (var < 0) var = 0;
+        sh_mean = (float)mean;
+        sh_rstd = (float)(1.0 / sqrt(var + (double)eps));
+        save_mean[n * G + g] = sh_mean;
+        save_rstd[n * G + g] = sh_rstd;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cg; c += 256) {
+        const int ch = g * Cg + c;
+        const float a = gamma[ch] * sh_rstd;
+        coefA[n * C + ch] = a;
+        coefB[n * C + ch] = beta[ch] - sh_mean * a;
+    }
+}
+
+// forward: BatchNorm (train: batch statistics + running update; eval: running statistics). grid = C.
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(
+    const float2* __restrict__ part, int NP, int N, int C, int P, int train, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+    float momentum, float eps, float* __restrict__ coefA, float* __restrict__ coefB,
+    float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+    const int c = blockIdx.x;
+    __shared__ double red[8];
+    __shared__ float sh_mean, sh_rstd;
+    if (train) {
+        double s = 0.0, ss = 0.0;
+        const int cnt = N * NP;
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            const int n = i / NP, j = i - n * NP;
+            const float2 v = part[((size_t)n * C + c) * NP + j];
+            s += (double)v.x;
+            ss += (double)v.y;
+        }
+        s = wave_sum_d(s);
+        ss = wave_sum_d(ss);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) { red[2 * w] = s; red[2 * w + 1] = ss; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double S = 0, SS = 0;
+            for (int i = 0; i < 4; ++i) { S += red[2 * i]; SS += red[2 * i + 1]; }
+            const double M = (double)N * (double)P;
+            const double mean = S / M;
+            double var = SS / M - mean * mean;
+            if (var < 0) var = 0;
+            sh_mean = (float)mean;
+            sh_rstd = (float)(1.0 / sqrt(var + (double)eps));
+            if (running_mean) {
+                const double unb = var * (M / (M > 1 ? M - 1 : 1));
+                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+            }
+        }
+    } else if (threadIdx.x == 0) {
+        sh_mean = running_mean[c];
+        sh_rstd = 1.0f / sqrtf(running_var[c] + eps);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { save_mean[c] = sh_mean; save_rstd[c] = sh_rstd; }
+    const float a = gamma[c] * sh_rstd;
+    const float b = beta[c] - sh_mean * a;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        coefA[n * C + c] = a;
+        coefB[n * C + c] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward.  part holds (S1, S2) = (sum_p du, sum_p du*h) per (n,c).
+//   GN  : grid = G blocks (loop over n so d gamma / d beta come out in a fixed order)
+//   BN  : grid = C blocks
+// dh = C1*du + C2*h + C3 with  C1 = r*gamma, C2 = -r^2*m2, C3 = r*(-m1 + r*mu*m2),
+//   m1 = mean_group(gamma*du), m2 = mean_group(gamma*du*hhat).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(
+    const float2* __restrict__ part, int NP, int N, int C, int G, int P, const float* __restrict__ gamma,
+    const float* __restrict__ save_mean, const float* __restrict__ save_rstd, float* __restrict__ c1,
+    float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int g = blockIdx.x;
+    const int Cg = C / G;   // <= 256
+    __shared__ double s1[256], s2[256];
+    __shared__ double sm1, sm2;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double dg_acc = 0.0, db_acc = 0.0;   // thread c (< Cg) owns channel g*Cg + c
+    for (int n = 0; n < N; ++n) {
+        // per-channel sums over the NP partials: one wave per channel, round-robin
+        for (int c = w; c < Cg; c += 4) {
+            const float2* src = part + ((size_t)n * C + g * Cg + c) * NP;
+            double a = 0.0, b = 0.0;
+            for (int j = lane; j < NP; j += 64) {
+                const float2 v = src[j];
+                a += (double)v.x;
+                b += (double)v.y;
+            }
+            a = wave_sum_d(a);
+            b = wave_sum_d(b);
+            if (lane == 0) { s1[c] = a; s2[c] = b; }
+        }
+        __syncthreads();
+        const double mu = (double)save_mean[n * G + g], r = (double)save_rstd[n * G + g];
+        if (w == 0) {
+            double a = 0.0, b = 0.0;
+            for (int c = lane; c < Cg; c += 64) {
+                const double gm = (double)gamma[g * Cg + c];
+                a += gm * s1[c];
+                b += gm * r * (s2[c] - mu * s1[c]);
+            }
+            a = wave_sum_d(a);
+            b = wave_sum_d(b);
+            if (lane == 0) {
+                const double M = (double)Cg * (double)P;
+                sm1 = a / M;
+                sm2 = b / M;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < Cg) {
+            const int c = threadIdx.x, ch = g * Cg + c;
+            const double gm = (double)gamma[ch];
+            c1[n * C + ch] = (float)(r * gm);
+            c2[n * C + ch] = (float)(-r * r * sm2);
+            c3[n * C + ch] = (float)(r * (-sm1 + r * mu * sm2));
+            dg_acc += r * (s2[c] - mu * s1[c]);
+            db_acc += s1[c];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < Cg) {
+        dgamma[g * Cg + threadIdx.x] = (float)dg_acc;
+        dbeta[g * Cg + threadIdx.x] = (float)db_acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(
+    const float2* __restrict__ part, int NP, int N, int C, int P, int train, const float* __restrict__ gamma,
+    const float* __restrict__ save_mean, const float* __restrict__ save_rstd, float* __restrict__ c1,
+    float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x;
+    __shared__ double red[8];
+    __shared__ float k1, k2, k3;
+    double a = 0.0, b = 0.0;
+    const int cnt = N * NP;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int n = i / NP, j = i - n * NP;
+        const float2 v = part[((size_t)n * C + c) * NP + j];
+        a += (double)v.x;
+        b += (double)v.y;
+    }
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S1 = 0, S2 = 0;
+        for (int i = 0; i < 4; ++i) { S1 += red[2 * i]; S2 += red[2 * i + 1]; }
+        const double mu = (double)save_mean[c], r = (double)save_rstd[c], gm = (double)gamma[c];
+        const double dg = r * (S2 - mu * S1);
+        dgamma[c] = (float)dg;
+        dbeta[c] = (float)S1;
+        k1 = (float)(r * gm);
+        if (train) {
+            const double M = (double)N * (double)P;
+            const double m1 = gm * S1 / M, m2 = gm * dg / M;
+            k2 = (float)(-r * r * m2);
+            k3 = (float)(r * (-m1 + r * mu * m2));
+        } else {
+            k2 = 0.f;
+            k3 = 0.f;
+        }
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) {
+        c1[n * C + c] = k1;
+        c2[n * C + c] = k2;
+        c3[n * C + c] = k3;
+    }
+}
+
+extern "C" int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
+                                      const float* gamma, const float* beta, float* running_mean,
+                                      float* running_var, float momentum, float eps, float* coefA, float* coefB,
+                                      float* save_mean, float* save_rstd, hipStream_t stream) {
+    if (N <= 0 || C <= 0 || P <= 0) return UNCR_ESHAPE;
+    if (kind == NORM_GROUP) {
+        if (groups <= 0 || C % groups || !part) return UNCR_EINVAL;
+        hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(N * groups), dim3(256), 0, stream, (const float2*)part, NP, C,
+                           groups, P, gamma, beta, eps, coefA, coefB, save_mean, save_rstd);
+    } else if (kind == NORM_BATCH_TRAIN || kind == NORM_BATCH_EVAL) {
+        const int train = kind == NORM_BATCH_TRAIN;
+        if (train && !part) return UNCR_EINVAL;
+        if (!train && (!running_mean || !running_var)) return UNCR_EINVAL;
+        hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(256), 0, stream, (const float2*)part, NP, N, C, P,
+                           train, gamma, beta, running_mean, running_var, momentum, eps, coefA, coefB, save_mean,
+                           save_rstd);
+    } else {
+        return UNCR_EINVAL;
+    }
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
+                                      const float* gamma, const float* save_mean, const float* save_rstd, float* c1,
+                                      float* c2, float* c3, float* dgamma, float* dbeta, hipStream_t stream) {
+    if (N <= 0 || C <= 0 || P <= 0 || !part) return UNCR_ESHAPE;
+    if (kind == NORM_GROUP) {
+        if (groups <= 0 || C % groups || C / groups > 256) return UNCR_EINVAL;
+        hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(groups), dim3(256), 0, stream, (const float2*)part, NP, N, C,
+                           groups, P, gamma, save_mean, save_rstd, c1, c2, c3, dgamma, dbeta);
+    } else if (kind == NORM_BATCH_TRAIN || kind == NORM_BATCH_EVAL) {
+        hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(256), 0, stream, (const float2*)part, NP, N, C, P,
+                           kind == NORM_BATCH_TRAIN, gamma, save_mean, save_rstd, c1, c2, c3, dgamma, dbeta);
+    } else {
+        return UNCR_EINVAL;
+    }
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}

@@ -1,0 +1,462 @@
+// 1x1 ("pointwise") convolutions over NCHW planes as fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32: exact
+// fp32 fma chain, 157 TF peak on gfx950).
+//
+//   out[n, co, p] = sum_ci Wt[ci, co] * f(in[n, ci, p])  (+ bias)
+//
+// where f is the fused prologue (norm-apply / GELU / SE scale / norm-backward affine) and the epilogue
+// optionally emits per-(n,co) partial statistics for the NEXT normalisation (sum, sum^2) or for a
+// norm backward (sum out, sum out*aux).  Layout decisions (MI355X):
+//   * pixels are the contiguous axis (NCHW), so a wave's MFMA B operand (k x 32 px) is a 128-B row
+//     segment; each lane carries FOUR consecutive pixels (float4) = four interleaved 32-px MFMA
+//     column tiles, so every global/LDS access on the activation stream is 16 B per lane and the
+//     accumulator epilogue stores float4 rows (no LDS transpose anywhere).
+//   * the activation chunk [32 k][TP px] is staged ONCE per block in LDS with the prologue applied
+//     (GELU/erf is evaluated once per element, not once per consuming wave); the next chunk is
+//     prefetched into registers while the current one feeds the MFMAs.
+//   * weights are tiny (<=128 KB, L2 resident): each wave reads its A fragments (Wt[k][co], co
+//     contiguous => 128-B coalesced) straight from global.
+#include "common.h"
+
+struct PwArgs {
+    const float* in;
+    const float* in2;    // PRO_NORMBWD second operand
+    const float* Wt;     // [nk*32][COUTP], zero padded
+    float* out;          // [N][Cout][P]
+    const float* k0;     // prologue coefficients, [N*Cin] each
+    const float* k1;
+    const float* k2;
+    const float* bias;   // [Cout] or [N][Cout] (bias_stride_n = Cout) or null
+    const float* aux;    // EPI_AUX operand [N][Cout][P]
+    float2* part;        // [N*Cout][NP] or null
+    int bias_stride_n;
+    int Cin, Cout, P;
+    int pro;             // PRO_*
+    int epi;             // 0 none, 1 (sum, sum^2), 2 (sum, sum*aux)
+};
+
+// PRE2 = false drops the second prefetch register set (PRO_NORMBWD unavailable): keeps the 32-wide
+// variant (16 prefetch float4 per lane) free of spills.
+template <int CT, int WN, int WM, bool PRE2>
+__global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
+    constexpr int NT = 64 * WN * WM;
+    constexpr int TP = 128 * WM;
+    constexpr int COUTP = 32 * CT * WN;
+    constexpr int KC = 32;
+    constexpr int NL = (KC * TP / 4) / NT;        // float4 loads per thread per chunk
+    constexpr int ROWS_PER_I = NT / (TP / 4);     // rows covered per load index
+
+    __shared__ __attribute__((aligned(16))) float xs[KC][TP];
+    __shared__ float cf[3][256];
+    __shared__ float red[WM][COUTP][2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int n = blockIdx.y;
+    const int px0 = blockIdx.x * TP;
+    const int Cin = g.Cin, Cout = g.Cout, P = g.P;
+    const int nk = (Cin + KC - 1) / KC;
+    const int pro = g.pro;
+
+    // prologue coefficients for this frame -> LDS
+    for (int i = tid; i < Cin; i += NT) {
+        cf[0][i] = g.k0 ? g.k0[n * Cin + i] : 1.f;
+        cf[1][i] = g.k1 ? g.k1[n * Cin + i] : 0.f;
+        cf[2][i] = g.k2 ? g.k2[n * Cin + i] : (pro == PRO_AFFINE_GELU ? 1.f : 0.f);
+    }
+
+    const int lrow = tid / (TP / 4), lc4 = tid % (TP / 4);
+    const float* inb = g.in + (size_t)n * Cin * P + px0 + 4 * lc4;
+    const float* in2b = g.in2 ? g.in2 + (size_t)n * Cin * P + px0 + 4 * lc4 : nullptr;
+
+    float4 pre[NL], pre2[PRE2 ? NL : 1];
+    auto issue_loads = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int k = kc * KC + lrow + i * ROWS_PER_I;
+            if (k < Cin) {
+                pre[i] = *(const float4*)(inb + (size_t)k * P);
+                if constexpr (PRE2) {
+                    if (pro == PRO_NORMBWD) pre2[i] = *(const float4*)(in2b + (size_t)k * P);
+                }
+            } else {
+                pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    f32x16 acc[4][CT];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][ct][r] = 0.f;
+
+    issue_loads(0);
+    __syncthreads();   // cf visible
+
+    const float* wbase = g.Wt + (size_t)(lane >> 5) * COUTP + wn * (CT * 32) + (lane & 31);
+
+    for (int kc = 0; kc < nk; ++kc) {
+        // A fragments of this chunk (L2-resident weights), issued ahead of the LDS staging
+        float afr[16][CT];
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) afr[s][ct] = wbase[(size_t)(kc * KC + 2 * s) * COUTP + ct * 32];
+
+        // transform + stage the prefetched activation chunk
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int r = lrow + i * ROWS_PER_I;
+            const int k = kc * KC + r;
+            float4 v = pre[i];
+            if (k < Cin) {
+                const float c0 = cf[0][k], c1 = cf[1][k], c2 = cf[2][k];
+                float* pv = (float*)&v;
+                if (pro == PRO_AFFINE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], c1);
+                } else if (pro == PRO_AFFINE_GELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pv[j] = c2 * gelu_f(fmaf(c0, pv[j], c1));
+                } else if (pro == PRO_NORMBWD) {
+                    if constexpr (PRE2) {
+                        const float* p2 = (const float*)&pre2[i];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], fmaf(c1, p2[j], c2));
+                    }
+                } else if (pro == PRO_AFFINE_RELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pv[j] = fmaxf(fmaf(c0, pv[j], c1), 0.f);
+                }
+            }
+            *(float4*)&xs[r][4 * lc4] = v;
+        }
+        __syncthreads();
+        if (kc + 1 < nk) issue_loads(kc + 1);
+
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float4 b = *(const float4*)&xs[2 * s + (lane >> 5)][wm * 128 + 4 * (lane & 31)];
+            const float* pb = (const float*)&b;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[e][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s][ct], pb[e], acc[e][ct], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, store (float4 along pixels), statistics ----
+    const int epi = g.epi;
+    const int pxw = px0 + wm * 128 + 4 * (lane & 31);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int col = wn * (CT * 32) + ct * 32 + row;   // local output channel
+            float4 v = make_float4(acc[0][ct][r], acc[1][ct][r], acc[2][ct][r], acc[3][ct][r]);
+            float s0 = 0.f, s1 = 0.f;
+            if (col < Cout) {
+                if (g.bias) {
+                    const float bb = g.bias[(size_t)n * g.bias_stride_n + col];
+                    v.x += bb; v.y += bb; v.z += bb; v.w += bb;
+                }
+                const size_t o = ((size_t)n * Cout + col) * P + pxw;
+                *(float4*)(g.out + o) = v;
+                if (epi == 1) {
+                    s0 = v.x + v.y + v.z + v.w;
+                    s1 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                } else if (epi == 2) {
+                    const float4 x = *(const float4*)(g.aux + o);
+                    s0 = v.x + v.y + v.z + v.w;
+                    s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
+                }
+            }
+            if (epi) {   // block-uniform
+                s0 = half_wave_sum(s0);
+                s1 = half_wave_sum(s1);
+                if ((lane & 31) == 0) { red[wm][col][0] = s0; red[wm][col][1] = s1; }
+            }
+        }
+    }
+    if (epi) {
+        __syncthreads();
+        for (int c = tid; c < COUTP; c += NT) {
+            if (c < Cout) {
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int m = 0; m < WM; ++m) { s0 += red[m][c][0]; s1 += red[m][c][1]; }
+                g.part[((size_t)n * Cout + c) * gridDim.x + blockIdx.x] = make_float2(s0, s1);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient:  dW[co, ci] = sum_p fD(d[n,co,p]) * fX(x[n,ci,p])   (reduction over pixels)
+// One block reduces PXB pixels of one frame into a full [COP][CIP] partial (accumulators live in
+// the MFMA result registers across the whole pixel loop); a second kernel reduces the partials in
+// fp64 in a fixed order.  Both operands are staged through LDS with their prologues applied.
+// The reduction axis (pixels) is the contiguous one for BOTH operands, so a lane's float4 feeds
+// four k-steps.
+// ---------------------------------------------------------------------------------------------
+struct WgArgs {
+    const float* d;
+    const float* d2;
+    const float* x;
+    const float* x2;
+    const float* dk0; const float* dk1; const float* dk2;   // [N*Cd]
+    const float* xk0; const float* xk1; const float* xk2;   // [N*Cx]
+    float* part;       // [N*NBX][COP][CIP]
+    float* rs_part;    // [N*NBX][COP] row sums of fD(d) (bias gradient) or null
+    int Cd, Cx, P, PXB;
+    int pro_d, pro_x;
+};
+
+__device__ __forceinline__ float4 apply_pro(int pro, float4 v, const float4& v2, float c0, float c1, float c2) {
+    float* pv = (float*)&v;
+    const float* p2 = (const float*)&v2;
+    if (pro == PRO_AFFINE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], c1);
+    } else if (pro == PRO_AFFINE_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = c2 * gelu_f(fmaf(c0, pv[j], c1));
+    } else if (pro == PRO_NORMBWD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], fmaf(c1, p2[j], c2));
+    } else if (pro == PRO_AFFINE_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = fmaxf(fmaf(c0, pv[j], c1), 0.f);
+    }
+    return v;
+}
+
+template <int MT, int NTL, int WCO, int WCI>
+__global__ __launch_bounds__(64 * WCO * WCI) void pw_wgrad_kernel(WgArgs g) {
+    constexpr int NT = 64 * WCO * WCI;
+    constexpr int COP = 32 * MT * WCO;
+    constexpr int CIP = 32 * NTL * WCI;
+    constexpr int KP = 32, PITCH = 36;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ds = smem;                   // [COP][PITCH]
+    float* xs = smem + COP * PITCH;     // [CIP][PITCH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wco = wv / WCI, wci = wv % WCI;
+    const int n = blockIdx.y;
+    const int P = g.P, Cd = g.Cd, Cx = g.Cx;
+    const int pbeg = blockIdx.x * g.PXB;
+    const int nchunks = g.PXB / KP;
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NTL; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float rowsum = 0.f;
+
+    const float* dbase = g.d + (size_t)n * Cd * P;
+    const float* d2base = g.d2 ? g.d2 + (size_t)n * Cd * P : nullptr;
+    const float* xbase = g.x + (size_t)n * Cx * P;
+    const float* x2base = g.x2 ? g.x2 + (size_t)n * Cx * P : nullptr;
+    const int pro_d = g.pro_d, pro_x = g.pro_x;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int p0 = pbeg + ch * KP;
+        // stage D: COP rows x 8 float4
+        for (int f = tid; f < COP * 8; f += NT) {
+            const int row = f >> 3, c4 = f & 7;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < Cd) {
+                const size_t o = (size_t)row * P + p0 + 4 * c4;
+                v = *(const float4*)(dbase + o);
+                float4 v2 = v;
+                if (pro_d == PRO_NORMBWD) v2 = *(const float4*)(d2base + o);
+                const int ci = n * Cd + row;
+                v = apply_pro(pro_d, v, v2, g.dk0 ? g.dk0[ci] : 1.f, g.dk1 ? g.dk1[ci] : 0.f,
+                              g.dk2 ? g.dk2[ci] : (pro_d == PRO_AFFINE_GELU ? 1.f : 0.f));
+            }
+            *(float4*)&ds[row * PITCH + 4 * c4] = v;
+        }
+        for (int f = tid; f < CIP * 8; f += NT) {
+            const int row = f >> 3, c4 = f & 7;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < Cx) {
+                const size_t o = (size_t)row * P + p0 + 4 * c4;
+                v = *(const float4*)(xbase + o);
+                float4 v2 = v;
+                if (pro_x == PRO_NORMBWD) v2 = *(const float4*)(x2base + o);
+                const int ci = n * Cx + row;
+                v = apply_pro(pro_x, v, v2, g.xk0 ? g.xk0[ci] : 1.f, g.xk1 ? g.xk1[ci] : 0.f,
+                              g.xk2 ? g.xk2[ci] : (pro_x == PRO_AFFINE_GELU ? 1.f : 0.f));
+            }
+            *(float4*)&xs[row * PITCH + 4 * c4] = v;
+        }
+        __syncthreads();
+        if (g.rs_part && tid < COP) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < KP; ++j) s += ds[tid * PITCH + j];
+            rowsum += s;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 a4[MT], b4[NTL];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+                a4[a] = *(const float4*)&ds[((wco * MT + a) * 32 + (lane & 31)) * PITCH + 8 * s + 4 * (lane >> 5)];
+#pragma unroll
+            for (int b = 0; b < NTL; ++b)
+                b4[b] = *(const float4*)&xs[((wci * NTL + b) * 32 + (lane & 31)) * PITCH + 8 * s + 4 * (lane >> 5)];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NTL; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(((const float*)&a4[a])[e],
+                                                                          ((const float*)&b4[b])[e], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const size_t blk = (size_t)n * gridDim.x + blockIdx.x;
+    float* po = g.part + blk * COP * CIP;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NTL; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int co = (wco * MT + a) * 32 + row;
+                const int ci = (wci * NTL + b) * 32 + (lane & 31);
+                po[co * CIP + ci] = acc[a][b][r];
+            }
+    if (g.rs_part && tid < COP) g.rs_part[blk * COP + tid] = rowsum;
+}
+
+// Reduce partials: out[f][co][ci] = sum over the blocks of frame-group f.  frames_per_out = N gives the
+// total gradient, 1 gives per-frame products (needed for the SE gradient).  fp64, fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nblk_per_out,
+                                                           int COP, int CIP, int Cout, int Cin,
+                                                           float* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= COP * CIP) return;
+    const int co = idx / CIP, ci = idx % CIP;
+    if (co >= Cout || ci >= Cin) return;
+    const float* src = part + (size_t)blockIdx.y * nblk_per_out * COP * CIP + idx;
+    double s = 0.0;
+    for (int b = 0; b < nblk_per_out; ++b) s += (double)src[(size_t)b * COP * CIP];
+    out[((size_t)blockIdx.y * Cout + co) * Cin + ci] = (float)s;
+}
+
+// Wt[k][co] (zero padded [Kp][COUTP]) from W[co][k] (transpose=1) or W[k][co] (transpose=0), W row stride = ld
+__global__ void pack_wt_kernel(const float* __restrict__ W, int rows_k, int cols_co, int ld, int transpose,
+                               int Kp, int COUTP, float* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Kp * COUTP) return;
+    const int k = idx / COUTP, co = idx % COUTP;
+    float v = 0.f;
+    if (k < rows_k && co < cols_co) v = transpose ? W[(size_t)co * ld + k] : W[(size_t)k * ld + co];
+    out[idx] = v;
+}
+
+static int pw_coutp(int Cout) { return Cout > 128 ? 256 : (Cout > 64 ? 128 : (Cout > 32 ? 64 : 32)); }
+
+extern "C" int uncr_pw_coutp(int Cout) { return Cout <= 256 ? pw_coutp(Cout) : -1; }
+extern "C" int uncr_pw_kpad(int Cin) { return ((Cin + 31) / 32) * 32; }
+extern "C" int uncr_pw_tile_px(int Cout) {
+    const int cp = pw_coutp(Cout);
+    return (cp >= 128) ? 128 : 256;
+}
+
+extern "C" int uncr_pack_wt(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out,
+                            hipStream_t stream) {
+    if (cols_co > 256 || rows_k > 256) return UNCR_ESHAPE;
+    const int Kp = uncr_pw_kpad(rows_k), CP = pw_coutp(cols_co);
+    hipLaunchKernelGGL(pack_wt_kernel, dim3((Kp * CP + 255) / 256), dim3(256), 0, stream, W, rows_k, cols_co, ld,
+                       transpose, Kp, CP, out);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, float* out, const float* k0,
+                            const float* k1, const float* k2, const float* bias, int bias_stride_n, const float* aux,
+                            float* part, int N, int Cin, int Cout, int P, int pro, int epi, hipStream_t stream) {
+    if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
+    if (!in || !Wt || !out) return UNCR_EINVAL;
+    if (pro == PRO_NORMBWD && !in2) return UNCR_EINVAL;
+    if (epi && !part) return UNCR_EINVAL;
+    if (epi == 2 && !aux) return UNCR_EINVAL;
+    const int tp = uncr_pw_tile_px(Cout);
+    if (P % tp) return UNCR_ESHAPE;
+    PwArgs g{in, in2, Wt, out, k0, k1, k2, bias, aux, (float2*)part, bias_stride_n, Cin, Cout, P, pro, epi};
+    dim3 grid(P / tp, N);
+    const int cp = pw_coutp(Cout);
+    if (cp == 256)
+        hipLaunchKernelGGL((pw_gemm_kernel<2, 4, 1, true>), grid, dim3(256), 0, stream, g);
+    else if (cp == 128)
+        hipLaunchKernelGGL((pw_gemm_kernel<1, 4, 1, true>), grid, dim3(256), 0, stream, g);
+    else if (cp == 64)
+        hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true>), grid, dim3(256), 0, stream, g);
+    else if (pro == PRO_NORMBWD)
+        hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, true>), grid, dim3(128), 0, stream, g);
+    else
+        hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false>), grid, dim3(128), 0, stream, g);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+// weight-gradient shapes: (COP, CIP) in {(128,256), (256,128), (128,32), (32,128), (64,256)}
+static int wg_shape(int Cd, int Cx, int* cop, int* cip) {
+    if (Cd > 128 && Cd <= 256 && Cx > 32 && Cx <= 128) { *cop = 256; *cip = 128; return 0; }
+    if (Cd > 64 && Cd <= 128 && Cx > 128 && Cx <= 256) { *cop = 128; *cip = 256; return 1; }
+    if (Cd > 32 && Cd <= 128 && Cx <= 32) { *cop = 128; *cip = 32; return 2; }
+    if (Cd <= 32 && Cx > 32 && Cx <= 128) { *cop = 32; *cip = 128; return 3; }
+    if (Cd > 32 && Cd <= 64 && Cx > 128 && Cx <= 256) { *cop = 64; *cip = 256; return 4; }
+    return -1;
+}
+
+extern "C" int uncr_wgrad_shape(int Cd, int Cx, int* cop, int* cip) { return wg_shape(Cd, Cx, cop, cip); }
+
+extern "C" int uncr_pw_wgrad(const float* d, const float* d2, const float* x, const float* x2, const float* dk0,
+                             const float* dk1, const float* dk2, const float* xk0, const float* xk1,
+                             const float* xk2, float* part, float* rs_part, int N, int Cd, int Cx, int P, int PXB,
+                             int pro_d, int pro_x, hipStream_t stream) {
+    int cop, cip;
+    const int shp = wg_shape(Cd, Cx, &cop, &cip);
+    if (shp < 0 || N <= 0) return UNCR_ESHAPE;
+    if (PXB <= 0 || PXB % 32 || P % PXB) return UNCR_ESHAPE;
+    if (!d || !x || !part) return UNCR_EINVAL;
+    if ((pro_d == PRO_NORMBWD && !d2) || (pro_x == PRO_NORMBWD && !x2)) return UNCR_EINVAL;
+    WgArgs g{d, d2, x, x2, dk0, dk1, dk2, xk0, xk1, xk2, part, rs_part, Cd, Cx, P, PXB, pro_d, pro_x};
+    dim3 grid(P / PXB, N);
+    const size_t lds = (size_t)(cop + cip) * 36 * sizeof(float);
+    switch (shp) {
+        case 0: hipLaunchKernelGGL((pw_wgrad_kernel<2, 4, 4, 1>), grid, dim3(256), lds, stream, g); break;
+        case 1: hipLaunchKernelGGL((pw_wgrad_kernel<2, 4, 2, 2>), grid, dim3(256), lds, stream, g); break;
+        case 2: hipLaunchKernelGGL((pw_wgrad_kernel<1, 1, 4, 1>), grid, dim3(256), lds, stream, g); break;
+        case 3: hipLaunchKernelGGL((pw_wgrad_kernel<1, 1, 1, 4>), grid, dim3(256), lds, stream, g); break;
+        case 4: hipLaunchKernelGGL((pw_wgrad_kernel<2, 4, 1, 2>), grid, dim3(128), lds, stream, g); break;
+    }
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_wgrad_reduce(const float* part, int n_out, int nblk_per_out, int COP, int CIP, int Cout, int Cin,
+                                 float* out, hipStream_t stream) {
+    if (n_out <= 0 || nblk_per_out <= 0) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((COP * CIP + 255) / 256, n_out), dim3(256), 0, stream, part,
+                       nblk_per_out, COP, CIP, Cout, Cin, out);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}

@@ -1,0 +1,129 @@
+// Squeeze-and-excitation MLP (uncrtaints.py:82-97) on the pooled [N,C] vectors: tiny, latency-bound.
+//   fwd : pooled = mean_p gelu(norm(h2));  s = sigmoid(W2 * gelu(W1 * pooled))
+//   bwd : from the per-frame products G[n] = sum_p dh3[n,:,p] (x) g2[n,:,p]  (weight-gradient GEMM,
+//         un-scaled operand) both  ds[n,c] = sum_co Wpw[co,c] G[n,co,c]  and
+//         dWpw[co,c] = sum_n s[n,c] G[n,co,c]  follow without another pass over the activations.
+#include "common.h"
+
+// grid = N, block = 256.  C <= 256, R <= 64.
+__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float2* __restrict__ pool_part, int NP, int C, int R,
+                                                         int P, const float* __restrict__ W1,
+                                                         const float* __restrict__ W2, float* __restrict__ pooled,
+                                                         float* __restrict__ hid_pre, float* __restrict__ s) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    __shared__ float sp[256], sh[64];
+    if (tid < C) {
+        double a = 0.0;
+        const float2* src = pool_part + ((size_t)n * C + tid) * NP;
+        for (int j = 0; j < NP; ++j) a += (double)src[j].x;
+        const float m = (float)(a / (double)P);
+        sp[tid] = m;
+        pooled[n * C + tid] = m;
+    }
+    __syncthreads();
+    // hidden: one wave handles rows round-robin
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int j = wv; j < R; j += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a = fmaf(W1[j * C + c], sp[c], a);
+        a = wave_sum(a);
+        if (lane == 0) {
+            hid_pre[n * R + j] = a;
+            sh[j] = gelu_f(a);
+        }
+    }
+    __syncthreads();
+    if (tid < C) {
+        float a = 0.f;
+        for (int j = 0; j < R; ++j) a = fmaf(W2[tid * R + j], sh[j], a);
+        s[n * C + tid] = sigmoid_f(a);
+    }
+}
+
+// grid = N.  Produces per-frame ds_pre[n,c], dhid_pre[n,j] and the pass-B coefficient dpool_px[n,c].
+__global__ __launch_bounds__(256) void se_mlp_bwd_frame_kernel(
+    const float* __restrict__ G, const float* __restrict__ Wpw, int Co, int C, int R, int P,
+    const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ s,
+    const float* __restrict__ hid_pre, float* __restrict__ ds_pre, float* __restrict__ dhid_pre,
+    float* __restrict__ dpool_px) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    __shared__ float sds[256], sdh[64];
+    if (tid < C) {
+        const float* g = G + (size_t)n * Co * C + tid;
+        double a = 0.0;
+        for (int co = 0; co < Co; ++co) a += (double)Wpw[co * C + tid] * (double)g[(size_t)co * C];
+        const float sv = s[n * C + tid];
+        const float d = (float)a * sv * (1.f - sv);
+        sds[tid] = d;
+        ds_pre[n * C + tid] = d;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int j = wv; j < R; j += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a = fmaf(W2[c * R + j], sds[c], a);
+        a = wave_sum(a);
+        if (lane == 0) {
+            const float d = a * gelu_grad_f(hid_pre[n * R + j]);
+            sdh[j] = d;
+            dhid_pre[n * R + j] = d;
+        }
+    }
+    __syncthreads();
+    if (tid < C) {
+        float a = 0.f;
+        for (int j = 0; j < R; ++j) a = fmaf(W1[j * C + tid], sdh[j], a);
+        dpool_px[n * C + tid] = a / (float)P;
+    }
+}
+
+// grid = Co + R blocks, block = 256 (thread = channel c).
+//   blocks [0,Co)   : dWpw[co][c] = sum_n s[n,c] G[n,co,c]
+//   blocks [Co,Co+R): j = b-Co:  dW1[j][c] = sum_n dhid_pre[n,j] pooled[n,c];  dW2[c][j] = sum_n ds_pre[n,c] gelu(hid_pre[n,j])
+__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ G, int N, int Co, int C, int R,
+                                                       const float* __restrict__ s, const float* __restrict__ pooled,
+                                                       const float* __restrict__ hid_pre,
+                                                       const float* __restrict__ ds_pre,
+                                                       const float* __restrict__ dhid_pre, float* __restrict__ dWpw,
+                                                       float* __restrict__ dW1, float* __restrict__ dW2) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    if ((int)blockIdx.x < Co) {
+        const int co = blockIdx.x;
+        double a = 0.0;
+        for (int n = 0; n < N; ++n) a += (double)s[n * C + c] * (double)G[((size_t)n * Co + co) * C + c];
+        dWpw[co * C + c] = (float)a;
+    } else {
+        const int j = blockIdx.x - Co;
+        double a = 0.0, b = 0.0;
+        for (int n = 0; n < N; ++n) {
+            a += (double)dhid_pre[n * R + j] * (double)pooled[n * C + c];
+            b += (double)ds_pre[n * C + c] * (double)gelu_f(hid_pre[n * R + j]);
+        }
+        dW1[j * C + c] = (float)a;
+        dW2[c * R + j] = (float)b;
+    }
+}
+
+extern "C" int uncr_se_mlp_fwd(const float* pool_part, int NP, int N, int C, int R, int P, const float* W1,
+                               const float* W2, float* pooled, float* hid_pre, float* s, hipStream_t stream) {
+    if (C > 256 || R > 64 || N <= 0) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(N), dim3(256), 0, stream, (const float2*)pool_part, NP, C, R, P, W1,
+                       W2, pooled, hid_pre, s);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_se_mlp_bwd(const float* G, const float* Wpw, int N, int Co, int C, int R, int P,
+                               const float* W1, const float* W2, const float* s, const float* pooled,
+                               const float* hid_pre, float* ds_pre, float* dhid_pre, float* dpool_px, float* dWpw,
+                               float* dW1, float* dW2, hipStream_t stream) {
+    if (C > 256 || R > 64 || N <= 0) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(se_mlp_bwd_frame_kernel, dim3(N), dim3(256), 0, stream, G, Wpw, Co, C, R, P, W1, W2, s,
+                       hid_pre, ds_pre, dhid_pre, dpool_px);
+    UNCR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(se_wgrad_kernel, dim3(Co + R), dim3(256), 0, stream, G, N, Co, C, R, s, pooled, hid_pre,
+                       ds_pre, dhid_pre, dWpw, dW1, dW2);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}

@@ -1,0 +1,572 @@
+"""Kernel orchestration for the UnCRtainTS hot path on MI355X.
+
+Every function here only allocates device buffers through torch and enqueues hand-written HIP kernels
+(libuncr_hip.so, include/uncr_hip.h) on torch's current stream.  No torch compute ops are used on the
+path; there is no CPU fallback.  Stages mirror SURVEY.md section 8(a):
+
+    in_conv (a4) -> MBConv encoder (a5) -> max-pool (a6) + L-TAE attention (a7-a9) + temporal
+    aggregation (a10) -> 5 x MBConv decoder (a5) -> out_conv + head (a2) ; MGNLL (a12)
+
+Normalisation layers never run on their own: producers emit partial statistics, `norm_fwd` turns them
+into per-(frame,channel) coefficients and the consuming kernel applies them in its prologue.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import hip_backend as hb
+
+PRO_NONE, PRO_AFFINE, PRO_AFFINE_GELU, PRO_NORMBWD, PRO_AFFINE_RELU = 0, 1, 2, 3, 4
+NORM_GROUP, NORM_BATCH_TRAIN, NORM_BATCH_EVAL = 0, 1, 2
+EW_STATS_SQ, EW_STATS_AUX, EW_AFFINE_RELU, EW_RESIDUAL, EW_PASSB, EW_PASSE, EW_RELU_BWD, EW_SE_POOL, \
+    EW_HEAD_FWD, EW_HEAD_BWD = range(10)
+
+Tensor = torch.Tensor
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(shape, dev) -> Tensor:
+    return torch.empty(shape, device=dev, dtype=torch.float32)
+
+
+def _check4(x: Tensor):
+    if x.dim() != 4 or x.dtype != torch.float32 or not x.is_cuda:
+        raise RuntimeError("expected a 4-D fp32 CUDA tensor [frames, C, H, W]")
+    N, C, H, W = x.shape
+    if (H * W) % 1024 or W % 4:
+        raise RuntimeError(f"unsupported spatial size {H}x{W}: H*W must be a multiple of 1024 and W of 4")
+    return N, C, H, W
+
+
+@dataclass
+class Part:
+    """Per-block partial statistics float2[N*C][slots] emitted by a producer kernel."""
+    buf: Tensor
+    slots: int
+
+
+@dataclass
+class NormSpec:
+    kind: str        # 'group' | 'batch'
+    groups: int = 4
+
+    def code(self, training: bool) -> int:
+        if self.kind == "group":
+            return NORM_GROUP
+        if self.kind == "batch":
+            return NORM_BATCH_TRAIN if training else NORM_BATCH_EVAL
+        raise NotImplementedError(f"norm '{self.kind}' is not built (group | batch)")
+
+    def needs_stats(self, training: bool) -> bool:
+        return self.code(training) != NORM_BATCH_EVAL
+
+
+# ------------------------------------------------------------------------------------------------
+# thin wrappers over the C ABI
+# ------------------------------------------------------------------------------------------------
+
+def ew(op: int, a: Tensor, *, b=None, c=None, aux=None, out: Optional[Tensor] = None, k=(None, None, None, None),
+       want_part: bool = False, planes: int, P: int, C: int = 1, n_mean: int = 0, scale: float = 1.0,
+       eps: float = 0.0) -> Tuple[Optional[Tensor], Optional[Part]]:
+    part = None
+    if want_part:
+        slots = hb.query("uncr_ew_slots", P)
+        part = Part(_f32((planes, slots, 2), a.device), slots)
+    hb.call("uncr_ew", op, a, b, c, aux, out, k[0], k[1], k[2], k[3], part.buf if part else None, planes, P, C,
+            n_mean, float(scale), float(eps), _stream())
+    return out, part
+
+
+def stats_sq(x: Tensor, planes: int, P: int) -> Part:
+    return ew(EW_STATS_SQ, x, want_part=True, planes=planes, P=P)[1]
+
+
+def stats_aux(a: Tensor, b: Tensor, planes: int, P: int) -> Part:
+    return ew(EW_STATS_AUX, a, b=b, want_part=True, planes=planes, P=P)[1]
+
+
+@dataclass
+class NormFwd:
+    A: Tensor
+    B: Tensor
+    mean: Tensor
+    rstd: Tensor
+    kind: int
+    groups: int
+
+
+def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, training: bool, gamma: Tensor,
+             beta: Tensor, running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None,
+             momentum: float = 0.1, eps: float = 1e-5) -> NormFwd:
+    kind = spec.code(training)
+    dev = gamma.device
+    A, B = _f32((N * C,), dev), _f32((N * C,), dev)
+    nstat = N * spec.groups if kind == NORM_GROUP else C
+    mean, rstd = _f32((nstat,), dev), _f32((nstat,), dev)
+    hb.call("uncr_norm_finalize_fwd", part.buf if part else None, part.slots if part else 0, N, C, spec.groups, P,
+            kind, gamma, beta, running_mean, running_var, float(momentum), float(eps), A, B, mean, rstd, _stream())
+    return NormFwd(A, B, mean, rstd, kind, spec.groups)
+
+
+@dataclass
+class NormBwd:
+    c1: Tensor
+    c2: Tensor
+    c3: Tensor
+    dgamma: Tensor
+    dbeta: Tensor
+
+
+def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor) -> NormBwd:
+    dev = gamma.device
+    c1, c2, c3 = _f32((N * C,), dev), _f32((N * C,), dev), _f32((N * C,), dev)
+    dg, db = _f32((C,), dev), _f32((C,), dev)
+    hb.call("uncr_norm_finalize_bwd", part.buf, part.slots, N, C, nf.groups, P, nf.kind, gamma, nf.mean, nf.rstd,
+            c1, c2, c3, dg, db, _stream())
+    return NormBwd(c1, c2, c3, dg, db)
+
+
+def pack_wt(W2d: Tensor, transpose: bool) -> Tensor:
+    """W2d [R][Ccols] -> zero-padded Wt[Kpad][COUTP] with Wt[k][co] = W[co][k] (transpose) or W[k][co]."""
+    W2d = W2d.contiguous()
+    R, Cc = W2d.shape
+    rows_k, cols_co = (Cc, R) if transpose else (R, Cc)
+    out = _f32((hb.query("uncr_pw_kpad", rows_k), hb.query("uncr_pw_coutp", cols_co)), W2d.device)
+    hb.call("uncr_pack_wt", W2d, rows_k, cols_co, Cc, 1 if transpose else 0, out, _stream())
+    return out
+
+
+def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: int = PRO_NONE, k=(None, None, None),
+            x2: Optional[Tensor] = None, bias: Optional[Tensor] = None, bias_per_frame: bool = False, epi: int = 0,
+            aux: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Part]]:
+    if out is None:
+        out = _f32((N, Cout, P), x.device)
+    part = None
+    if epi:
+        slots = P // hb.query("uncr_pw_tile_px", Cout)
+        part = Part(_f32((N * Cout, slots, 2), x.device), slots)
+    hb.call("uncr_pw_gemm", x, x2, Wt, out, k[0], k[1], k[2], bias, Cout if bias_per_frame else 0, aux,
+            part.buf if part else None, N, Cin, Cout, P, pro, epi, _stream())
+    return out, part
+
+
+def _pick_pxb(N: int, P: int) -> int:
+    """Pixels per weight-gradient block: aim for ~512-1024 blocks on the 256 CUs."""
+    for cand in (4096, 2048, 1024, 512, 256):
+        if P % cand == 0 and N * (P // cand) >= 512:
+            return cand
+    return 256 if P % 256 == 0 else 32
+
+
+def pw_wgrad(d: Tensor, x: Tensor, N: int, Cd: int, Cx: int, P: int, *, pro_d: int = PRO_NONE, dk=(None, None, None),
+             d2: Optional[Tensor] = None, pro_x: int = PRO_NONE, xk=(None, None, None), x2: Optional[Tensor] = None,
+             per_frame: bool = False, rowsum: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """dW[co,ci] = sum_{n,p} fD(d)[n,co,p] * fX(x)[n,ci,p]  (-> [Cd,Cx], or [N,Cd,Cx] if per_frame);
+    optionally also rowsum[co] = sum_{n,p} fD(d)."""
+    import ctypes
+    cop, cip = ctypes.c_int(), ctypes.c_int()
+    if hb.lib().cdll.uncr_wgrad_shape(Cd, Cx, ctypes.byref(cop), ctypes.byref(cip)) < 0:
+        raise RuntimeError(f"weight-gradient shape ({Cd},{Cx}) not built")
+    cop, cip = cop.value, cip.value
+    pxb = _pick_pxb(N, P)
+    nbx = P // pxb
+    dev = d.device
+    part = _f32((N * nbx, cop, cip), dev)
+    rs_part = _f32((N * nbx, cop), dev) if rowsum else None
+    hb.call("uncr_pw_wgrad", d, d2, x, x2, dk[0], dk[1], dk[2], xk[0], xk[1], xk[2], part, rs_part, N, Cd, Cx, P, pxb,
+            pro_d, pro_x, _stream())
+    n_out = N if per_frame else 1
+    dW = _f32((n_out, Cd, Cx), dev)
+    hb.call("uncr_wgrad_reduce", part, n_out, (N * nbx) // n_out, cop, cip, Cd, Cx, dW, _stream())
+    rs = None
+    if rowsum:
+        rs = _f32((Cd,), dev)
+        hb.call("uncr_wgrad_reduce", rs_part, 1, N * nbx, cop, 1, Cd, 1, rs, _stream())
+    return (dW if per_frame else dW[0]), rs
+
+
+# ------------------------------------------------------------------------------------------------
+# MBConv (uncrtaints.py:100-146)
+# ------------------------------------------------------------------------------------------------
+MB_KEYS = ("n0w", "n0b", "w1", "n1w", "n1b", "wdw", "n2w", "n2b", "se1", "se2", "w2", "n3w", "n3b")
+
+
+def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bool,
+                   x_part: Optional[Part] = None, buffers: Optional[Dict[str, Tensor]] = None,
+                   want_out_stats: bool = True):
+    """x [N,C,H,W] -> y, saved-for-backward dict, partial stats of y (for the next PreNorm).
+    `buffers` holds BatchNorm running_mean/var tensors keyed n{0..3}rm / n{0..3}rv (updated in place)."""
+    N, C, H, W = _check4(x)
+    P = H * W
+    Ch = p["w1"].shape[0]
+    R = p["se1"].shape[0]
+    need = spec.needs_stats(training)
+    buffers = buffers or {}
+
+    def rm(i):
+        return buffers.get(f"n{i}rm"), buffers.get(f"n{i}rv")
+
+    if need and x_part is None:
+        x_part = stats_sq(x, N * C, P)
+    n0 = norm_fwd(x_part if need else None, N, C, P, spec, training, p["n0w"], p["n0b"], *rm(0))
+    W1t = pack_wt(p["w1"].reshape(Ch, C), transpose=True)
+    h1, part1 = pw_gemm(x, W1t, N, C, Ch, P, pro=PRO_AFFINE, k=(n0.A, n0.B, None), epi=1 if need else 0)
+    n1 = norm_fwd(part1, N, Ch, P, spec, training, p["n1w"], p["n1b"], *rm(1))
+
+    h2 = _f32((N, Ch, H, W), x.device)
+    slots = hb.query("uncr_dw_slots_fwd", H)
+    part2 = Part(_f32((N * Ch, slots, 2), x.device), slots) if need else None
+    hb.call("uncr_dw_fwd", h1, n1.A, n1.B, p["wdw"].reshape(Ch, 9).contiguous(), h2, part2.buf if need else None, N, Ch,
+            H, W, _stream())
+    n2 = norm_fwd(part2, N, Ch, P, spec, training, p["n2w"], p["n2b"], *rm(2))
+
+    _, ppool = ew(EW_SE_POOL, h2, k=(n2.A, n2.B, None, None), want_part=True, planes=N * Ch, P=P)
+    pooled, hid_pre, s = _f32((N, Ch), x.device), _f32((N, R), x.device), _f32((N * Ch,), x.device)
+    hb.call("uncr_se_mlp_fwd", ppool.buf, ppool.slots, N, Ch, R, P, p["se1"].contiguous(), p["se2"].contiguous(),
+            pooled, hid_pre, s, _stream())
+
+    W2t = pack_wt(p["w2"].reshape(C, Ch), transpose=True)
+    h3, part3 = pw_gemm(h2, W2t, N, Ch, C, P, pro=PRO_AFFINE_GELU, k=(n2.A, n2.B, s), epi=1 if need else 0)
+    n3 = norm_fwd(part3, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))
+
+    y = _f32((N, C, H, W), x.device)
+    _, party = ew(EW_RESIDUAL, x, b=h3, out=y, k=(n3.A, n3.B, None, None), want_part=want_out_stats, planes=N * C,
+                  P=P)
+    saved = dict(x=x, h1=h1, h2=h2, h3=h3, n0=n0, n1=n1, n2=n2, n3=n3, pooled=pooled, hid_pre=hid_pre, s=s,
+                 dims=(N, C, Ch, R, H, W))
+    return y, saved, party
+
+
+def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = True):
+    """-> dx, {param key: grad}"""
+    N, C, Ch, R, H, W = sv["dims"]
+    P = H * W
+    dev = dy.device
+    x, h1, h2, h3 = sv["x"], sv["h1"], sv["h2"], sv["h3"]
+    n0, n1, n2, n3 = sv["n0"], sv["n1"], sv["n2"], sv["n3"]
+    dy = dy.contiguous()
+    g: Dict[str, Tensor] = {}
+
+    # norm 3 backward coefficients: needs (sum dy, sum dy*h3)
+    part3 = stats_aux(dy, h3, N * C, P)
+    b3 = norm_bwd(part3, N, C, P, n3, p["n3w"])
+    g["n3w"], g["n3b"] = b3.dgamma, b3.dbeta
+    k3 = (b3.c1, b3.c2, b3.c3)
+
+    # pw2: per-frame products G[n] = dh3 (x) g2  -> dW2 and the SE gradient
+    G, _ = pw_wgrad(dy, h2, N, C, Ch, P, pro_d=PRO_NORMBWD, dk=k3, d2=h3, pro_x=PRO_AFFINE_GELU,
+                    xk=(n2.A, n2.B, None), per_frame=True)
+    ds_pre, dhid_pre, dpool = _f32((N, Ch), dev), _f32((N, R), dev), _f32((N * Ch,), dev)
+    dW2, dse1, dse2 = _f32((C, Ch), dev), _f32((R, Ch), dev), _f32((Ch, R), dev)
+    w2 = p["w2"].reshape(C, Ch).contiguous()
+    hb.call("uncr_se_mlp_bwd", G, w2, N, C, Ch, R, P, p["se1"].contiguous(), p["se2"].contiguous(), sv["s"],
+            sv["pooled"], sv["hid_pre"], ds_pre, dhid_pre, dpool, dW2, dse1, dse2, _stream())
+    g["w2"], g["se1"], g["se2"] = dW2.view_as(p["w2"]), dse1, dse2
+
+    # dz = W2^T dh3 ; du2 = gelu'(u2) * (s*dz + dpool) (in place) with stats (sum du2, sum du2*h2)
+    W2k = pack_wt(w2, transpose=False)                     # [k=co 128][out=c 256]
+    dz, _ = pw_gemm(dy, W2k, N, C, Ch, P, pro=PRO_NORMBWD, k=k3, x2=h3)
+    _, part2 = ew(EW_PASSB, dz, b=h2, out=dz, k=(n2.A, n2.B, sv["s"], dpool), want_part=True, planes=N * Ch, P=P)
+    du2 = dz
+    b2 = norm_bwd(part2, N, Ch, P, n2, p["n2w"])
+    g["n2w"], g["n2b"] = b2.dgamma, b2.dbeta
+
+    # depthwise backward
+    du1 = _f32((N, Ch, H, W), dev)
+    slots = hb.query("uncr_dw_slots_bwd", H)
+    part1 = Part(_f32((N * Ch, slots, 2), dev), slots)
+    dw_part = _f32((N * Ch, slots, 9), dev)
+    wdw = p["wdw"].reshape(Ch, 9).contiguous()
+    hb.call("uncr_dw_bwd", du2, h2, h1, b2.c1, b2.c2, b2.c3, n1.A, n1.B, wdw, du1, part1.buf, dw_part, N, Ch, H, W,
+            _stream())
+    dwdw = _f32((Ch, 9), dev)
+    hb.call("uncr_dw_wgrad_reduce", dw_part, N, Ch, slots, dwdw, _stream())
+    g["wdw"] = dwdw.view_as(p["wdw"])
+    b1 = norm_bwd(part1, N, Ch, P, n1, p["n1w"])
+    g["n1w"], g["n1b"] = b1.dgamma, b1.dbeta
+    k1 = (b1.c1, b1.c2, b1.c3)
+
+    # pw1: weight gradient and data gradient
+    dW1, _ = pw_wgrad(du1, x, N, Ch, C, P, pro_d=PRO_NORMBWD, dk=k1, d2=h1, pro_x=PRO_AFFINE, xk=(n0.A, n0.B, None))
+    g["w1"] = dW1.view_as(p["w1"])
+    W1k = pack_wt(p["w1"].reshape(Ch, C), transpose=False)  # [k=co 256][out=ci 128]
+    da, part0 = pw_gemm(du1, W1k, N, Ch, C, P, pro=PRO_NORMBWD, k=k1, x2=h1, epi=2, aux=x)
+    b0 = norm_bwd(part0, N, C, P, n0, p["n0w"])
+    g["n0w"], g["n0b"] = b0.dgamma, b0.dbeta
+
+    dx = None
+    if need_dx:
+        dx = _f32((N, C, H, W), dev)
+        ew(EW_PASSE, dy, b=da, c=x, out=dx, k=(b0.c1, b0.c2, b0.c3, None), planes=N * C, P=P)
+    return dx, g
+
+
+# ------------------------------------------------------------------------------------------------
+# in_conv: Conv2d(15->128,k1,bias) + GroupNorm(4) + ReLU   (utae.py:453-520, uncrtaints.py:310-314)
+# ------------------------------------------------------------------------------------------------
+
+def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec: NormSpec, training: bool,
+                   buffers: Optional[Dict[str, Tensor]] = None):
+    N, Cin, H, W = _check4(x)
+    P = H * W
+    Cout = w.shape[0]
+    buffers = buffers or {}
+    need = spec.needs_stats(training)
+    Wt = pack_wt(w.reshape(Cout, Cin), transpose=True)
+    c0, part = pw_gemm(x, Wt, N, Cin, Cout, P, bias=b.contiguous(), epi=1 if need else 0)
+    nf = norm_fwd(part, N, Cout, P, spec, training, gw, gb, buffers.get("rm"), buffers.get("rv"))
+    a0 = _f32((N, Cout, H, W), x.device)
+    _, parta = ew(EW_AFFINE_RELU, c0, out=a0, k=(nf.A, nf.B, None, None), want_part=True, planes=N * Cout, P=P)
+    return a0, dict(x=x, c0=c0, nf=nf, dims=(N, Cin, Cout, H, W)), parta
+
+
+def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool):
+    N, Cin, Cout, H, W = sv["dims"]
+    P = H * W
+    nf, c0, x = sv["nf"], sv["c0"], sv["x"]
+    da0 = da0.contiguous()
+    du0 = _f32((N, Cout, H, W), da0.device)
+    _, part = ew(EW_RELU_BWD, da0, b=c0, out=du0, k=(nf.A, nf.B, None, None), want_part=True, planes=N * Cout, P=P)
+    nb = norm_bwd(part, N, Cout, P, nf, gw)
+    kk = (nb.c1, nb.c2, nb.c3)
+    dW, db = pw_wgrad(du0, x, N, Cout, Cin, P, pro_d=PRO_NORMBWD, dk=kk, d2=c0, rowsum=True)
+    dx = None
+    if need_dx:
+        Wk = pack_wt(w.reshape(Cout, Cin), transpose=False)   # [k=128][out=15]
+        dx, _ = pw_gemm(du0, Wk, N, Cout, Cin, P, pro=PRO_NORMBWD, k=kk, x2=c0)
+        dx = dx.view(N, Cin, H, W)
+    return dx, dW.view_as(w), db, nb.dgamma, nb.dbeta
+
+
+# ------------------------------------------------------------------------------------------------
+# L-TAE stage: max-pool + LTAE2dtiny attention + temporal aggregation (uncrtaints.py:402-412)
+# ------------------------------------------------------------------------------------------------
+
+def pad_mask_of(x: Tensor, pad_value: float) -> Tensor:
+    """[B,T,...] -> int32 [B,T]: 1 where the whole frame equals pad_value (uncrtaints.py:392-394)."""
+    B, T = x.shape[:2]
+    mask = torch.empty((B, T), device=x.device, dtype=torch.int32)
+    hb.call("uncr_pad_mask", x, B * T, x[0, 0].numel(), float(pad_value), mask, _stream())
+    return mask
+
+
+def maxpool_forward(e: Tensor, OH: int, OW: int):
+    """e [..., H, W] (planes = product of leading dims) -> pooled [..., OH, OW], argmax int32."""
+    H, W = e.shape[-2:]
+    planes = e.numel() // (H * W)
+    lead = tuple(e.shape[:-2])
+    down = _f32(lead + (OH, OW), e.device)
+    idx = torch.empty(lead + (OH, OW), device=e.device, dtype=torch.int32)
+    hb.call("uncr_maxpool_fwd", e, down, idx, planes, H, W, OH, OW, _stream())
+    return down, idx
+
+
+def maxpool_backward_into(ddown: Tensor, idx: Tensor, de: Tensor, H: int, W: int, OH: int, OW: int):
+    """de[plane][argmax] += ddown (in place on `de`)."""
+    planes = ddown.numel() // (OH * OW)
+    hb.call("uncr_maxpool_bwd", ddown.contiguous(), idx, de, planes, H, W, OH, OW, _stream())
+
+
+def ltae_attention_forward(down: Tensor, dates: Optional[Tensor], pad: Optional[Tensor], p: Dict[str, Tensor],
+                           denom: Optional[Tensor], n_head: int, d_k: int):
+    """LTAE2dtiny (ltae.py:197-239): down [B,T,C,h,w] -> att [n_head,B,T,h,w].
+    p: in_norm_w/b [C], inconv_w [D,C,1], inconv_b [D], fc_w [nh*dk,D], fc_b, Q [nh,dk]."""
+    B, T, C, ah, aw = down.shape
+    S = ah * aw
+    if S % 256:
+        raise RuntimeError("L-TAE resolution must be a multiple of 256 pixels")
+    D = p["inconv_w"].shape[0]
+    HK = n_head * d_k
+    dev = down.device
+    NF = B * T
+    use_pe = denom is not None
+    xn, mean, rstd = _f32((NF, C, S), dev), _f32((B, n_head, S), dev), _f32((B, n_head, S), dev)
+    hb.call("uncr_ltae_gn_fwd", down, p["in_norm_w"], p["in_norm_b"], 1e-5, xn, mean, rstd, B, T, C, n_head, S,
+            _stream())
+    bias1 = _f32((NF, D), dev)
+    hb.call("uncr_ltae_posbias", dates.reshape(-1).contiguous().float() if use_pe else None,
+            denom if use_pe else None, denom.numel() if use_pe else 0, p["inconv_b"], bias1, NF, D,
+            1 if use_pe else 0, _stream())
+    Wit = pack_wt(p["inconv_w"].reshape(D, C), transpose=True)
+    y1, _ = pw_gemm(xn, Wit, NF, C, D, S, bias=bias1, bias_per_frame=True)
+    Wkt = pack_wt(p["fc_w"], transpose=True)
+    k, _ = pw_gemm(y1, Wkt, NF, D, HK, S, bias=p["fc_b"].contiguous())
+    att = _f32((n_head, B, T, ah, aw), dev)
+    hb.call("uncr_ltae_softmax_fwd", k, p["Q"].contiguous(), pad, att, B, T, n_head, d_k, S, _stream())
+    saved = dict(down=down, xn=xn, mean=mean, rstd=rstd, y1=y1, k=k, att=att, pad=pad, dims=(B, T, C, S, D, HK))
+    return att, saved
+
+
+def ltae_attention_backward(datt: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int, d_k: int):
+    """-> d(down) [B*T,C,S], {param grads}"""
+    B, T, C, S, D, HK = sv["dims"]
+    NF = B * T
+    dev = datt.device
+    g: Dict[str, Tensor] = {}
+    nchunk = (S + 255) // 256
+    dk = _f32((NF, HK, S), dev)
+    dq_part = _f32((B * nchunk, HK), dev)
+    hb.call("uncr_ltae_softmax_bwd", datt.contiguous(), sv["att"], sv["k"], p["Q"].contiguous(), sv["pad"], dk,
+            dq_part, B, T, n_head, d_k, S, _stream())
+    dQ = _f32((HK,), dev)
+    hb.call("uncr_colsum", dq_part, B * nchunk, HK, dQ, _stream())
+    g["Q"] = dQ.view(n_head, d_k)
+    dWk, dbk = pw_wgrad(dk, sv["y1"], NF, HK, D, S, rowsum=True)
+    g["fc_w"], g["fc_b"] = dWk, dbk
+    Wkk = pack_wt(p["fc_w"], transpose=False)                     # [k=64][out=256]
+    dy1, _ = pw_gemm(dk, Wkk, NF, HK, D, S)
+    dWi, dbi = pw_wgrad(dy1, sv["xn"], NF, D, C, S, rowsum=True)
+    g["inconv_w"], g["inconv_b"] = dWi.view_as(p["inconv_w"]), dbi
+    Wik = pack_wt(p["inconv_w"].reshape(D, C), transpose=False)   # [k=256][out=128]
+    dxn, _ = pw_gemm(dy1, Wik, NF, D, C, S)
+    ddown = _f32((NF, C, S), dev)
+    gb_part = _f32((B * nchunk, C, 2), dev)
+    hb.call("uncr_ltae_gn_bwd", dxn, sv["down"], p["in_norm_w"], sv["mean"], sv["rstd"], ddown, gb_part, B, T, C,
+            n_head, S, _stream())
+    gb = _f32((C * 2,), dev)
+    hb.call("uncr_colsum", gb_part, B * nchunk, C * 2, gb, _stream())
+    gb = gb.view(C, 2)
+    g["in_norm_w"], g["in_norm_b"] = gb[:, 0].contiguous(), gb[:, 1].contiguous()
+    return ddown, g
+
+
+def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: bool, p_drop: float, seed: int,
+                      dmask: Optional[Tensor] = None, want_stats: bool = True):
+    """Compact_Temporal_Aggregator 'att_group' (uncrtaints.py:156-221): e [B,T,C,H,W], att [nh,B,T,ah,aw]."""
+    B, T, C, H, W = e.shape
+    n_head, _, _, ah, aw = att.shape
+    if (H * W) % 1024 or W % 4:
+        raise RuntimeError(f"unsupported spatial size {H}x{W}")
+    if H <= ah or W <= aw:
+        raise NotImplementedError("feature map not larger than the attention map (AvgPool branch, "
+                                  "uncrtaints.py:204) is not built")
+    dev = e.device
+    g = _f32((B, C, H, W), dev)
+    gpart = None
+    if want_stats:
+        slots = hb.query("uncr_agg_slots", H * W)
+        gpart = Part(_f32((B * C, slots, 2), dev), slots)
+    use_mask = dmask if training else None
+    pd = float(p_drop) if (training and dmask is None) else 0.0
+    hb.call("uncr_aggregate_fwd", e, att, pad, use_mask, seed, pd, g, gpart.buf if gpart else None, B, T, C, n_head,
+            H, W, ah, aw, _stream())
+    saved = dict(e=e, att=att, pad=pad, dmask=use_mask, pd=pd, seed=seed, dims=(B, T, C, H, W, n_head, ah, aw))
+    return g, saved, gpart
+
+
+def aggregate_backward(dg: Tensor, sv: dict):
+    """-> de [B,T,C,H,W] (freshly written), datt [nh,B,T,ah,aw]"""
+    B, T, C, H, W, n_head, ah, aw = sv["dims"]
+    dev = dg.device
+    de = _f32((B, T, C, H, W), dev)
+    datt_up = _f32((n_head, B, T, H * W), dev)
+    datt = _f32((n_head, B, T, ah, aw), dev)
+    hb.call("uncr_aggregate_bwd", dg.contiguous(), sv["e"], sv["att"], sv["pad"], sv["dmask"], sv["seed"], sv["pd"],
+            de, datt_up, datt, B, T, C, n_head, H, W, ah, aw, _stream())
+    return de, datt
+
+
+def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor], p: Dict[str, Tensor],
+                       denom: Optional[Tensor], n_head: int, d_k: int, att_down: int, training: bool, p_drop: float,
+                       seed: int, dmask: Optional[Tensor] = None, want_stats: bool = True):
+    """Fused stage used by UNCRTAINTS.forward: e [B,T,C,H,W] -> g [B,C,H,W] (+ stats partials of g)."""
+    down, idx = maxpool_forward(e, att_down, att_down)
+    att, sv_att = ltae_attention_forward(down, dates, pad, p, denom, n_head, d_k)
+    g, sv_agg, gpart = aggregate_forward(e, att, pad, training, p_drop, seed, dmask, want_stats)
+    return g, dict(att=sv_att, agg=sv_agg, idx=idx, att_down=att_down), gpart, att
+
+
+def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int, d_k: int):
+    de, datt = aggregate_backward(dg, sv["agg"])
+    ddown, g = ltae_attention_backward(datt, sv["att"], p, n_head, d_k)
+    H, W = de.shape[-2:]
+    maxpool_backward_into(ddown, sv["idx"], de, H, W, sv["att_down"], sv["att_down"])
+    return de, g
+
+
+# ------------------------------------------------------------------------------------------------
+# out_conv + output nonlinearities (uncrtaints.py:381,432-445)
+# ------------------------------------------------------------------------------------------------
+
+def head_forward(y: Tensor, w: Tensor, b: Tensor, n_mean: int, mean_sigmoid: bool, scale: float, eps: float):
+    N, C, H, W = _check4(y)
+    P = H * W
+    Co = w.shape[0]
+    Wt = pack_wt(w.reshape(Co, C), transpose=True)
+    o, _ = pw_gemm(y, Wt, N, C, Co, P, bias=b.contiguous())
+    out = _f32((N, Co, H, W), y.device)
+    nm = n_mean if mean_sigmoid else -n_mean
+    ew(EW_HEAD_FWD, o, out=out, planes=N * Co, P=P, C=Co, n_mean=nm, scale=scale, eps=eps)
+    return out, dict(y=y, o=o, nm=nm, scale=scale, dims=(N, C, Co, H, W))
+
+
+def head_backward(dout: Tensor, sv: dict, w: Tensor, need_dy: bool = True):
+    N, C, Co, H, W = sv["dims"]
+    P = H * W
+    dout = dout.contiguous()
+    do = _f32((N, Co, H, W), dout.device)
+    ew(EW_HEAD_BWD, dout, b=sv["o"], out=do, planes=N * Co, P=P, C=Co, n_mean=sv["nm"], scale=sv["scale"])
+    dW, db = pw_wgrad(do, sv["y"], N, Co, C, P, rowsum=True)
+    dy = None
+    if need_dy:
+        Wk = pack_wt(w.reshape(Co, C), transpose=False)        # [k=26][out=128]
+        dy, _ = pw_gemm(do, Wk, N, Co, C, P)
+        dy = dy.view(N, C, H, W)
+    return dy, dW.view_as(w), db
+
+
+# ------------------------------------------------------------------------------------------------
+# MGNLL (losses.py:149-218)
+# ------------------------------------------------------------------------------------------------
+_RED = {"none": 0, "mean": 1, "sum": 2}
+
+
+def mgnll_forward(pred: Tensor, target: Tensor, var: Tensor, eps: float, reduction: str, check_negative: bool):
+    B, T1, K, H, W = pred.shape
+    Kv = var.shape[2]
+    dev = pred.device
+    P = H * W
+    nb = hb.query("uncr_mgnll_blocks", P)
+    part = _f32((nb,), dev)
+    red = _RED[reduction]
+    loss_none = _f32((W, H, B), dev) if red == 0 else None
+    loss = _f32((), dev) if red else None
+    flag = torch.zeros((1,), device=dev, dtype=torch.int32) if check_negative else None
+    hb.call("uncr_mgnll_fwd", pred, target, var, loss_none, part, loss, flag, B, K, Kv, H, W, float(eps), red, _stream())
+    if check_negative and int(flag.item()):      # opt-in host sync (losses.py:199-200)
+        raise ValueError("var has negative entry/entries")
+    if red == 0:
+        return loss_none[..., 0] if B == 1 else loss_none      # reference .squeeze() drops B == 1
+    return loss
+
+
+def mgnll_backward(gout: Tensor, pred: Tensor, target: Tensor, var: Tensor, eps: float, reduction: str,
+                   need_dpred: bool = True, need_dvar: bool = True):
+    B, T1, K, H, W = pred.shape
+    Kv = var.shape[2]
+    red = _RED[reduction]
+    dpred = torch.empty_like(pred) if need_dpred else None
+    dvar = torch.empty_like(var) if need_dvar else None
+    gout = gout.contiguous().to(torch.float32)
+    if red == 0 and B == 1:
+        gout = gout.reshape(W, H, 1)
+    hb.call("uncr_mgnll_bwd", pred, target, var, gout if red else None, gout if red == 0 else None, dpred, dvar, B, K,
+            Kv, H, W, float(eps), red, _stream())
+    return dpred, dvar
+
+
+def ensemble_combine(means: Tensor, variances: Optional[Tensor], mode: str = "both"):
+    """means/variances [M, ...] -> (mean_ens, var_ens) (ensemble_reconstruct.py:116-133)."""
+    M = means.shape[0]
+    n = means[0].numel()
+    mu, v = torch.empty_like(means[0]), torch.empty_like(means[0])
+    code = {"both": 0, "aleatoric": 1, "epistemic": 2}[mode]
+    hb.call("uncr_ensemble_combine", means.contiguous(), variances.contiguous() if variances is not None else None, M,
+            n, code, mu, v, _stream())
+    return mu, v

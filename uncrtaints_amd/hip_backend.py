@@ -1,0 +1,116 @@
+"""ctypes binding of libuncr_hip.so (the C ABI declared in include/uncr_hip.h).
+
+Prototypes are parsed from the header, so the loader, the ABI test and INTEGRATION.md share one source
+of truth.  There is NO fallback: if the library is missing or a symbol does not resolve, importing the
+product path raises -- the GPU path is never silently replaced by PyTorch ops."""
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HEADER = os.path.join(ROOT, "include", "uncr_hip.h")
+LIB_PATH = os.path.join(HERE, "lib", "libuncr_hip.so")
+
+_CTYPES = {
+    "int": ctypes.c_int,
+    "float": ctypes.c_float,
+    "unsigned long long": ctypes.c_ulonglong,
+    "long long": ctypes.c_longlong,
+    "hipStream_t": ctypes.c_void_p,
+}
+
+
+def parse_header(path: str = HEADER) -> Dict[str, List[Tuple[str, str]]]:
+    """-> {function name: [(ctype string, arg name), ...]} for every `int uncr_*(...)` declaration."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint\s+(uncr_\w+)\s*\(([^)]*)\)\s*;", text):
+        name, args = m.group(1), m.group(2).strip()
+        lst = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.+?)\s*(\w+)$", a)
+                typ, an = mm.group(1).strip(), mm.group(2)
+                lst.append((typ, an))
+        protos[name] = lst
+    return protos
+
+
+def _ctype_of(typ: str):
+    if "*" in typ:
+        return ctypes.c_void_p
+    return _CTYPES[typ.replace("const ", "").strip()]
+
+
+class HipLib:
+    def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} not found: build it with `python -m uncrtaints_amd.build` (hipcc --offload-arch=gfx950). "
+                "uncrtaints_amd has no CPU / PyTorch fallback for its kernels.")
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        self.protos = parse_header()
+        self.fn = {}
+        for name, args in self.protos.items():
+            f = getattr(self.cdll, name)   # AttributeError if the header and the library disagree
+            f.restype = ctypes.c_int
+            f.argtypes = [_ctype_of(t) for t, _ in args]
+            self.fn[name] = f
+
+
+_LIB = None
+
+
+def lib() -> HipLib:
+    global _LIB
+    if _LIB is None:
+        _LIB = HipLib()
+    return _LIB
+
+
+def _ptr(x):
+    """torch tensor -> device pointer (checked), None -> NULL, int -> as is."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    import torch
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"expected tensor/None, got {type(x)}")
+    if not x.is_cuda:
+        raise RuntimeError("uncrtaints_amd kernels need tensors on the GPU (cuda device); there is no CPU path")
+    if not x.is_contiguous():
+        raise RuntimeError("uncrtaints_amd kernels need contiguous tensors")
+    if x.dtype not in (torch.float32, torch.int32):
+        raise RuntimeError(f"unsupported dtype {x.dtype}")
+    return x.data_ptr()
+
+
+def call(name: str, *args):
+    """Call an entry point; tensors are converted to pointers; raises RuntimeError on a non-zero code."""
+    L = lib()
+    f = L.fn[name]
+    proto = L.protos[name]
+    if len(args) != len(proto):
+        raise TypeError(f"{name}: expected {len(proto)} args, got {len(args)}")
+    conv = []
+    for a, (typ, _) in zip(args, proto):
+        if "*" in typ or typ == "hipStream_t":
+            conv.append(_ptr(a) if typ != "hipStream_t" else a)
+        else:
+            conv.append(a)
+    rc = f(*conv)
+    if rc != 0:
+        kind = "argument/shape error" if rc < 0 else "hipError_t"
+        raise RuntimeError(f"{name} failed with code {rc} ({kind})")
+    return rc
+
+
+def query(name: str, *args) -> int:
+    """Call a pure size-query entry point (returns its int result, no error convention)."""
+    return lib().fn[name](*args)

@@ -1,0 +1,366 @@
+"""UnCRtainTS network with the reference's class surface (model/src/backbones/uncrtaints.py), computed by
+hand-written HIP kernels for MI355X.
+
+Same constructor arguments, tensor shapes, attributes (`mean_idx`, `vars_idx`, `variance`) and `state_dict()`
+key names as the reference, so it drops into a train_reconstruct.py / test_reconstruct.py style driver and
+loads reference checkpoints.  Modules hold parameters in stock `nn.*` layers (weight_init / freeze_layers
+dispatch on those types); `forward` routes through autograd Functions over `uncrtaints_amd.engine`.
+There is no PyTorch-op fallback: on a machine without the HIP library or a GPU tensor, forward raises.
+
+Built: block_type='mbconv', agg_mode='att_group', encoder_norm/decoder_norm in {group, batch},
+use_v=False, separate_out=False, out_nonlin_var='softplus', covmode in {diag, iso, uni, None}.
+Not built yet (raise NotImplementedError): block_type='residual', use_v, separate_out, att_mean/mean
+aggregation, is_mono, instance norm."""
+import torch
+import torch.nn as nn
+
+from ... import engine as E
+from .ltae import LTAE2dtiny, _LTAE_KEYS, _ltae_params
+from .utae import ConvBlock, ConvLayer, TemporallySharedBlock
+
+S2_BANDS = 13
+
+
+def get_norm_layer(out_channels, num_feats, n_groups=4, layer_type='batch'):
+    if layer_type == 'batch':
+        return nn.BatchNorm2d(out_channels)
+    elif layer_type == 'instance':
+        return nn.InstanceNorm2d(out_channels)
+    elif layer_type == 'group':
+        return nn.GroupNorm(num_channels=num_feats, num_groups=n_groups)
+
+
+class PreNorm(nn.Module):
+    """Parameter holder: `norm` then `fn` (uncrtaints.py:72-79); applied fused inside MBConv."""
+
+    def __init__(self, dim, fn, norm, n_groups=4):
+        super().__init__()
+        self.norm = get_norm_layer(dim, dim, n_groups, norm)
+        self.fn = fn
+
+    def forward(self, x, **kwargs):
+        raise NotImplementedError("PreNorm is fused into MBConv on the HIP path; call MBConv")
+
+
+class SE(nn.Module):
+    """Parameter holder of the squeeze-excite MLP (uncrtaints.py:82-97); fused inside MBConv."""
+
+    def __init__(self, inp, oup, expansion=0.25):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Sequential(
+            nn.Linear(oup, int(inp * expansion), bias=False),
+            nn.GELU(),
+            nn.Linear(int(inp * expansion), oup, bias=False),
+            nn.Sigmoid()
+        )
+
+    def forward(self, x):
+        raise NotImplementedError("SE is fused into MBConv on the HIP path; call MBConv")
+
+
+class _MBConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, *params):
+        p = dict(zip(E.MB_KEYS, params))
+        x = x.contiguous()
+        y, sv, party = E.mbconv_forward(x, p, module._spec, module.training, getattr(x, "_uncr_part", None),
+                                        module._bn_buffers(), want_out_stats=True)
+        ctx.sv, ctx.p = sv, p
+        y._uncr_part = party
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, g = E.mbconv_backward(dy, ctx.sv, ctx.p, need_dx=ctx.needs_input_grad[0])
+        return (dx, None) + tuple(g[k] for k in E.MB_KEYS)
+
+
+class MBConv(TemporallySharedBlock):
+    def __init__(self, inp, oup, downsample=False, expansion=4, norm='batch', n_groups=4):
+        super().__init__()
+        if downsample or expansion == 1 or inp != oup:
+            raise NotImplementedError("HIP MBConv is built for the UNCRTAINTS configuration: no down-sampling, "
+                                      "expansion > 1, inp == oup")
+        if norm not in ("group", "batch"):
+            raise NotImplementedError(f"MBConv norm '{norm}' is not built (group | batch)")
+        self.downsample = downsample
+        hidden_dim = int(inp * expansion)
+        self.conv = nn.Sequential(
+            nn.Conv2d(inp, hidden_dim, 1, stride=1, padding=0, bias=False),
+            get_norm_layer(hidden_dim, hidden_dim, n_groups, norm),
+            nn.GELU(),
+            nn.Conv2d(hidden_dim, hidden_dim, 3, stride=1, padding=1, padding_mode='reflect',
+                      groups=hidden_dim, bias=False),
+            get_norm_layer(hidden_dim, hidden_dim, n_groups, norm),
+            nn.GELU(),
+            SE(inp, hidden_dim),
+            nn.Conv2d(hidden_dim, oup, 1, stride=1, padding=0, bias=False),
+            get_norm_layer(oup, oup, n_groups, norm),
+        )
+        self.conv = PreNorm(inp, self.conv, norm, n_groups=4)
+        self._spec = E.NormSpec(norm, n_groups)
+
+    def _norms(self):
+        f = self.conv.fn
+        return (self.conv.norm, f[1], f[4], f[8])
+
+    def _bn_buffers(self):
+        out = {}
+        for i, m in enumerate(self._norms()):
+            if isinstance(m, nn.BatchNorm2d):
+                out[f"n{i}rm"], out[f"n{i}rv"] = m.running_mean, m.running_var
+        return out
+
+    def _params(self):
+        f = self.conv.fn
+        n0, n1, n2, n3 = self._norms()
+        return (n0.weight, n0.bias, f[0].weight, n1.weight, n1.bias, f[3].weight, n2.weight, n2.bias,
+                f[6].fc[0].weight, f[6].fc[2].weight, f[7].weight, n3.weight, n3.bias)
+
+    def forward(self, x):
+        y = _MBConvFn.apply(x, self, *self._params())
+        if self.training:
+            for m in self._norms():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.num_batches_tracked += 1
+        return y
+
+
+class _AggregateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, att, pad, module, dmask):
+        seed = module._next_seed()
+        g, sv, gpart = E.aggregate_forward(x.contiguous(), att.contiguous(), pad, module.training,
+                                           module.attn_dropout.p, seed, dmask)
+        ctx.sv = sv
+        g._uncr_part = gpart
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        de, datt = E.aggregate_backward(dg, ctx.sv)
+        return de, datt, None, None, None
+
+
+class Compact_Temporal_Aggregator(nn.Module):
+    def __init__(self, mode="mean"):
+        super().__init__()
+        self.mode = mode
+        self.attn_dropout = nn.Dropout(0.1)   # applied after up-sampling, inside the HIP kernel (train only)
+        self._seed_base = 0x5EED
+        self._calls = 0
+        self.dropout_mask = None              # optional explicit mask [n_head*B,T,H,W] (testing / parity)
+
+    def _next_seed(self):
+        self._calls += 1
+        return (self._seed_base * 1000003 + self._calls) & 0xFFFFFFFFFFFF
+
+    def set_seed(self, seed: int):
+        """Seed of the counter-based dropout stream (use seed + rank under data parallelism)."""
+        self._seed_base, self._calls = int(seed), 0
+
+    def forward(self, x, pad_mask=None, attn_mask=None):
+        if self.mode != "att_group":
+            raise NotImplementedError(f"agg_mode '{self.mode}' is not built (att_group only; SURVEY 8(f))")
+        pad = None
+        if pad_mask is not None:
+            pad = pad_mask if pad_mask.dtype == torch.int32 else pad_mask.to(torch.int32)
+            pad = pad.contiguous()
+        return _AggregateFn.apply(x, attn_mask, pad, self, self.dropout_mask)
+
+
+def get_nonlinearity(mode, eps):
+    if mode == 'softplus':
+        fct = lambda vars: nn.Softplus(beta=1, threshold=20)(vars) + eps
+    elif mode == 'elu':
+        fct = lambda vars: nn.ELU()(vars) + 1 + eps
+    elif mode == 'relu':
+        raise TypeError("out_nonlin_var='relu' is broken in the reference too (uncrtaints.py:224: nn.ReLU() + eps)")
+    else:
+        fct = nn.Identity()
+    return fct
+
+
+class _StageFn(torch.autograd.Function):
+    """max-pool + L-TAE attention + aggregation as one autograd node (uncrtaints.py:402-412)."""
+
+    @staticmethod
+    def forward(ctx, e, dates, pad, net, dmask, *params):
+        p = dict(zip(_LTAE_KEYS, params))
+        te, agg = net.temporal_encoder, net.temporal_aggregator
+        denom = te.positional_encoder.denom_on(e.device) if te.positional_encoder is not None else None
+        want_stats = net.out_block[0]._spec.needs_stats(net.training)
+        g, sv, gpart, att = E.ltae_stage_forward(e.contiguous(), dates, pad, p, denom, te.n_head,
+                                                 te.attention_heads.d_k, 32, net.training, agg.attn_dropout.p,
+                                                 agg._next_seed(), dmask, want_stats)
+        ctx.sv, ctx.p, ctx.te = sv, p, te
+        net._last_attention = att
+        g._uncr_part = gpart
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        de, g = E.ltae_stage_backward(dg, ctx.sv, ctx.p, ctx.te.n_head, ctx.te.attention_heads.d_k)
+        return (de, None, None, None, None) + tuple(g[k] for k in _LTAE_KEYS)
+
+
+class _HeadFn(torch.autograd.Function):
+    """out_conv (1x1 + bias) + mean/variance nonlinearities (uncrtaints.py:432-445)."""
+
+    @staticmethod
+    def forward(ctx, y, w, b, net):
+        out, sv = E.head_forward(y.contiguous(), w, b, net.mean_idx, net._mean_sigmoid, float(net.scale_by), net._eps)
+        ctx.sv, ctx.w = sv, w
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dy, dW, db = E.head_backward(dout, ctx.sv, ctx.w, ctx.needs_input_grad[0])
+        return dy, dW, db, None
+
+
+class UNCRTAINTS(nn.Module):
+    def __init__(
+        self,
+        input_dim,
+        encoder_widths=[128],
+        decoder_widths=[128, 128, 128, 128, 128],
+        out_conv=[S2_BANDS],
+        out_nonlin_mean=False,
+        out_nonlin_var='relu',
+        agg_mode="att_group",
+        encoder_norm="group",
+        decoder_norm="batch",
+        n_head=16,
+        d_model=256,
+        d_k=4,
+        pad_value=0,
+        padding_mode="reflect",
+        positional_encoding=True,
+        covmode='diag',
+        scale_by=1,
+        separate_out=False,
+        use_v=False,
+        block_type='mbconv',
+        is_mono=False
+    ):
+        super().__init__()
+        self.n_stages = len(encoder_widths)
+        self.encoder_widths = encoder_widths
+        self.decoder_widths = decoder_widths
+        self.out_widths = out_conv
+        self.is_mono = is_mono
+        self.use_v = use_v
+        self.block_type = block_type
+        self.enc_dim = decoder_widths[0] if decoder_widths is not None else encoder_widths[0]
+        self.stack_dim = sum(decoder_widths) if decoder_widths is not None else sum(encoder_widths)
+        self.pad_value = pad_value
+        self.padding_mode = padding_mode
+        self.scale_by = scale_by
+        self.separate_out = separate_out
+
+        if decoder_widths is not None:
+            assert encoder_widths[-1] == decoder_widths[-1]
+        else:
+            decoder_widths = encoder_widths
+        if block_type != 'mbconv':
+            raise NotImplementedError("block_type='residual' is not built (SURVEY 8(f) rank 2)")
+        if use_v or separate_out or is_mono:
+            raise NotImplementedError("use_v / separate_out / is_mono variants are not built (SURVEY 8(f) rank 2)")
+        if padding_mode != "reflect":
+            raise NotImplementedError("only padding_mode='reflect' is built")
+        if len(encoder_widths) != 1:
+            raise NotImplementedError("UNCRTAINTS uses a single encoder stage (encoder_widths=[C])")
+
+        self.in_conv = ConvBlock(nkernels=[input_dim] + [encoder_widths[0]], k=1, s=1, p=0, norm=encoder_norm)
+        self.in_block = nn.ModuleList([MBConv(layer, layer, downsample=False, expansion=2, norm=encoder_norm)
+                                       for layer in encoder_widths])
+        self.temporal_encoder = LTAE2dtiny(in_channels=encoder_widths[0], d_model=d_model, n_head=n_head, d_k=d_k,
+                                           positional_encoding=positional_encoding)
+        self.temporal_aggregator = Compact_Temporal_Aggregator(mode=agg_mode)
+        self.out_block = nn.ModuleList([MBConv(layer, layer, downsample=False, expansion=2, norm=decoder_norm)
+                                        for layer in decoder_widths])
+
+        self.covmode = covmode
+        if covmode == 'uni':
+            covar_dim = S2_BANDS
+        elif covmode == 'iso':
+            covar_dim = 1
+        elif covmode == 'diag':
+            covar_dim = S2_BANDS
+        else:
+            covar_dim = 0
+        self.mean_idx = S2_BANDS
+        self.vars_idx = self.mean_idx + covar_dim
+        self.out_dims = out_conv[-1]
+        eps = 1e-9 if self.scale_by == 1.0 else 1e-3
+        self._eps = eps
+        self._mean_sigmoid = bool(out_nonlin_mean)
+        self.out_conv = ConvBlock(nkernels=[decoder_widths[0]] + out_conv, k=1, s=1, p=0, norm='none', last_relu=False)
+
+        if out_nonlin_mean:
+            self.out_mean = lambda vars: self.scale_by * nn.Sigmoid()(vars)
+        else:
+            self.out_mean = nn.Identity()
+        if self.covmode in ['uni', 'iso', 'diag']:
+            if out_nonlin_var != 'softplus':
+                raise NotImplementedError(f"out_nonlin_var='{out_nonlin_var}' is not built on the HIP path (the "
+                                          "reference's diag/iso/uni fix-up always selects 'softplus', "
+                                          "train_reconstruct.py:53-61)")
+            self.diag_var = get_nonlinearity(out_nonlin_var, eps)
+            if self.out_dims < self.vars_idx:
+                raise ValueError(f"out_conv[-1]={self.out_dims} < 13 + covar_dim={self.vars_idx}")
+        self.variance = None
+        self._last_attention = None
+
+    def forward(self, input, batch_positions=None):
+        if not input.is_cuda:
+            raise RuntimeError("uncrtaints_amd.UNCRTAINTS runs on the GPU only (HIP kernels); move the model and "
+                               "the inputs to the cuda device")
+        input = input.contiguous().float()
+        if self.temporal_aggregator.mode != "att_group":
+            raise NotImplementedError("only agg_mode='att_group' is built")
+        pad = E.pad_mask_of(input, float(self.pad_value))                  # [B,T] int32, uncrtaints.py:392-394
+        out = self.in_conv.smart_forward(input)                            # [B,T,C,H,W]
+        part = None
+        for layer in self.in_block:
+            b, t, c, h, w = out.shape
+            x4 = out.view(b * t, c, h, w)
+            if part is not None:
+                x4._uncr_part = part
+            elif hasattr(out, "_uncr_part"):
+                x4._uncr_part = out._uncr_part
+            y4 = layer(x4)
+            part = getattr(y4, "_uncr_part", None)
+            out = y4.view(b, t, c, h, w)
+        if self.temporal_encoder.positional_encoder is not None and batch_positions is None:
+            raise ValueError("batch_positions (dates) are required when positional_encoding=True")
+        p = _ltae_params(self.temporal_encoder)
+        out = _StageFn.apply(out, batch_positions, pad, self, self.temporal_aggregator.dropout_mask,
+                             *[p[k] for k in _LTAE_KEYS])
+        for layer in self.out_block:
+            out = layer.smart_forward(out)
+        conv = self.out_conv.conv.conv[0]
+        if not self.covmode:
+            # mean only: plain conv + mean nonlinearity on all out_dims channels
+            o = _HeadFnMeanOnly.apply(out, conv.weight, conv.bias, self)
+            return o.unsqueeze(1)[:, :, :self.mean_idx, ...]
+        o = _HeadFn.apply(out, conv.weight, conv.bias, self)               # [B, out_dims, H, W]
+        o = o.unsqueeze(1)
+        if self.out_dims != self.vars_idx:
+            o = o[:, :, :self.vars_idx, ...]
+        return o
+
+
+class _HeadFnMeanOnly(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, w, b, net):
+        out, sv = E.head_forward(y.contiguous(), w, b, w.shape[0], net._mean_sigmoid, float(net.scale_by), 0.0)
+        ctx.sv, ctx.w = sv, w
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dy, dW, db = E.head_backward(dout, ctx.sv, ctx.w, ctx.needs_input_grad[0])
+        return dy, dW, db, None

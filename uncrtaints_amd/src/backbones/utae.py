@@ -1,0 +1,149 @@
+"""The three utae.py classes that sit on the `--model uncrtaints` path
+(model/src/backbones/utae.py:409-520): TemporallySharedBlock, ConvLayer, ConvBlock.
+
+They keep stock nn.Conv2d / nn.GroupNorm / nn.BatchNorm2d modules as PARAMETER HOLDERS (so `weight_init`,
+`state_dict()` keys and `freeze_layers` behave as in the reference) and route compute to the HIP engine.
+Only the configurations UNCRTAINTS builds are supported: 1x1 convolutions, one conv per block, norm in
+{group, batch, none}; anything else raises NotImplementedError (no silent PyTorch fallback)."""
+import torch
+import torch.nn as nn
+
+from ... import engine as E
+
+
+class TemporallySharedBlock(nn.Module):
+    """smart_forward folds T into the batch for 5-D inputs (utae.py:422-450)."""
+
+    def __init__(self, pad_value=None):
+        super().__init__()
+        self.out_shape = None
+        self.pad_value = pad_value
+
+    def smart_forward(self, input):
+        if len(input.shape) == 4:
+            return self.forward(input)
+        if self.pad_value is not None:
+            raise NotImplementedError("pad-aware smart_forward (utae.py:433-446) is unused by UNCRTAINTS blocks")
+        b, t, c, h, w = input.shape
+        out4 = self.forward(input.reshape(b * t, c, h, w))
+        _, c, h, w = out4.shape
+        out = out4.view(b, t, c, h, w)
+        part = getattr(out4, "_uncr_part", None)      # partial statistics ride along for the next PreNorm
+        if part is not None:
+            out._uncr_part = part
+        return out
+
+
+class _ConvNormActFn(torch.autograd.Function):
+    """Conv2d(k=1,bias) [+ GroupNorm/BatchNorm] [+ ReLU] through the HIP engine."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gw, gb, layer):
+        x = x.contiguous()
+        spec = layer._spec
+        if spec is None:
+            raise NotImplementedError
+        buffers = layer._bn_buffers()
+        a0, sv, part = E.inconv_forward(x, w, b, gw, gb, spec, layer.training, buffers)
+        ctx.sv, ctx.layer = sv, layer
+        ctx.params = (w, gw)
+        a0._uncr_part = part
+        return a0
+
+    @staticmethod
+    def backward(ctx, da):
+        w, gw = ctx.params
+        dx, dW, db, dgw, dgb = E.inconv_backward(da, ctx.sv, w, gw, ctx.needs_input_grad[0])
+        return dx, dW, db, dgw, dgb, None
+
+
+class _ConvBiasFn(torch.autograd.Function):
+    """Plain Conv2d(k=1,bias), no norm / activation (out_conv without the output nonlinearities)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        N, C, H, W = E._check4(x)
+        Co = w.shape[0]
+        Wt = E.pack_wt(w.reshape(Co, C), transpose=True)
+        o, _ = E.pw_gemm(x, Wt, N, C, Co, H * W, bias=b.contiguous())
+        ctx.save_for_backward(x, w)
+        return o.view(N, Co, H, W)
+
+    @staticmethod
+    def backward(ctx, do):
+        x, w = ctx.saved_tensors
+        N, C, H, W = x.shape
+        Co = w.shape[0]
+        do = do.contiguous()
+        dW, db = E.pw_wgrad(do, x, N, Co, C, H * W, rowsum=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            Wk = E.pack_wt(w.reshape(Co, C), transpose=False)
+            dx, _ = E.pw_gemm(do, Wk, N, Co, C, H * W)
+            dx = dx.view(N, C, H, W)
+        return dx, dW.view_as(w), db
+
+
+class ConvLayer(nn.Module):
+    def __init__(self, nkernels, norm="batch", k=3, s=1, p=1, n_groups=4, last_relu=True, padding_mode="reflect"):
+        super().__init__()
+        layers = []
+        if norm == "batch":
+            nl = nn.BatchNorm2d
+        elif norm == "instance":
+            nl = nn.InstanceNorm2d
+        elif norm == "group":
+            nl = lambda num_feats: nn.GroupNorm(num_channels=num_feats, num_groups=n_groups)
+        else:
+            nl = None
+        for i in range(len(nkernels) - 1):
+            layers.append(nn.Conv2d(in_channels=nkernels[i], out_channels=nkernels[i + 1], kernel_size=k, padding=p,
+                                    stride=s, padding_mode=padding_mode))
+            if nl is not None:
+                layers.append(nl(nkernels[i + 1]))
+            if last_relu:
+                layers.append(nn.ReLU())
+            elif i < len(nkernels) - 2:
+                layers.append(nn.ReLU())
+        self.conv = nn.Sequential(*layers)
+        self._k, self._s, self._p = k, s, p
+        self._norm, self._n_groups, self._last_relu = norm, n_groups, last_relu
+        self._nconv = len(nkernels) - 1
+        if norm == "group":
+            self._spec = E.NormSpec("group", n_groups)
+        elif norm == "batch":
+            self._spec = E.NormSpec("batch")
+        else:
+            self._spec = None
+
+    def _bn_buffers(self):
+        m = self.conv[1] if len(self.conv) > 1 else None
+        if isinstance(m, nn.BatchNorm2d):
+            return dict(rm=m.running_mean, rv=m.running_var)
+        return {}
+
+    def forward(self, input):
+        if self._k != 1 or self._s != 1 or self._p != 0 or self._nconv != 1:
+            raise NotImplementedError("HIP ConvLayer is built for single 1x1 convolutions (the UNCRTAINTS in_conv / "
+                                      "out_conv configuration)")
+        conv = self.conv[0]
+        if self._norm in ("group", "batch") and self._last_relu:
+            nrm = self.conv[1]
+            out = _ConvNormActFn.apply(input, conv.weight, conv.bias, nrm.weight, nrm.bias, self)
+            if isinstance(nrm, nn.BatchNorm2d) and self.training:
+                nrm.num_batches_tracked += 1
+            return out
+        if self._norm in (None, "none") and not self._last_relu:
+            return _ConvBiasFn.apply(input, conv.weight, conv.bias)
+        raise NotImplementedError(f"ConvLayer(norm={self._norm}, last_relu={self._last_relu}) is not built")
+
+
+class ConvBlock(TemporallySharedBlock):
+    def __init__(self, nkernels, pad_value=None, norm="batch", last_relu=True, k=3, s=1, p=1, padding_mode="reflect"):
+        super().__init__(pad_value=pad_value)
+        self.conv = ConvLayer(nkernels=nkernels, norm=norm, last_relu=last_relu, k=k, s=s, p=p,
+                              padding_mode=padding_mode)
+
+    def forward(self, input):
+        return self.conv(input)

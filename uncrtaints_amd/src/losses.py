@@ -1,0 +1,88 @@
+"""Losses with the reference's surface (model/src/losses.py): get_loss, calc_loss, MultiGaussianNLLLoss,
+multi_gaussian_nll_loss -- MGNLL (diag / iso) as one HIP streaming kernel per direction (csrc/mgnll.hip).
+
+Differences from the reference, all opt-in / documented:
+  * the dense covariance `diag_embed(var)` [B,1,13,13,H,W] (moved to the host inside the reference loss,
+    losses.py:145,211; logging only) is produced only with `want_covariance=True`, on the device;
+  * `torch.any(var < 0)` (a host sync, losses.py:199) is checked only with `check_negative=True`.
+GNLL / l1 / l2 are outside the hot path and raise NotImplementedError."""
+import torch
+import torch.nn as nn
+from torch.nn.modules.loss import _Loss
+
+from .. import engine as E
+
+S2_BANDS = 13
+Tensor = torch.Tensor
+
+
+class _MGNLLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, var, eps, reduction, check_negative):
+        pred, target, var = pred.contiguous().float(), target.contiguous().float(), var.contiguous().float()
+        loss = E.mgnll_forward(pred, target, var, eps, reduction, check_negative)
+        ctx.save_for_backward(pred, target, var)
+        ctx.eps, ctx.reduction = eps, reduction
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target, var = ctx.saved_tensors
+        dpred, dvar = E.mgnll_backward(gout, pred, target, var, ctx.eps, ctx.reduction,
+                                       ctx.needs_input_grad[0], ctx.needs_input_grad[2])
+        return dpred, None, dvar, None, None, None
+
+
+def multi_gaussian_nll_loss(input: Tensor, target: Tensor, var: Tensor, full: bool = False, eps: float = 1e-8,
+                            reduction: str = "mean", mode: str = "diag", chunk=None, want_covariance: bool = False,
+                            check_negative: bool = False):
+    """(loss, variance) like losses.py:149-218.  input/target [B,1,13,H,W], var [B,1,13|1,H,W]."""
+    if reduction != 'none' and reduction != 'mean' and reduction != 'sum':
+        raise ValueError(reduction + " is not valid")
+    if mode not in ("diag", "iso"):
+        raise NotImplementedError(f"MGNLL mode '{mode}' is not built (diag | iso)")
+    if input.dim() != 5 or input.shape[1] != 1:
+        raise ValueError("expected [B,1,C,H,W] tensors")
+    if mode == "iso" and var.shape[2] != 1:
+        var = var[:, :, :1]
+    loss = _MGNLLFn.apply(input, target, var, float(eps), reduction, bool(check_negative))
+    variance = None
+    if want_covariance:   # logging-only export, losses.py:145,211 (layout [B,1,13,13,H,W])
+        v = var.detach().expand(-1, -1, S2_BANDS, -1, -1) if mode == "iso" else var.detach()
+        v = v.clamp(min=eps)[:, 0]
+        variance = torch.diag_embed(v.permute(0, 2, 3, 1)).permute(0, 3, 4, 1, 2).unsqueeze(1)
+    return loss, variance
+
+
+class MultiGaussianNLLLoss(_Loss):
+    __constants__ = ['full', 'eps', 'reduction']
+
+    def __init__(self, *, full: bool = False, eps: float = 1e-8, reduction: str = 'mean', mode: str = 'diag',
+                 chunk=None, want_covariance: bool = False, check_negative: bool = False) -> None:
+        super().__init__(None, None, reduction)
+        self.full, self.eps, self.mode, self.chunk = full, eps, mode, chunk
+        self.want_covariance, self.check_negative = want_covariance, check_negative
+
+    def forward(self, input: Tensor, target: Tensor, var: Tensor):
+        return multi_gaussian_nll_loss(input, target, var, full=self.full, eps=self.eps, reduction=self.reduction,
+                                       mode=self.mode, chunk=self.chunk, want_covariance=self.want_covariance,
+                                       check_negative=self.check_negative)
+
+
+def get_loss(config):
+    """losses.py:14-32"""
+    if config.loss == "MGNLL":
+        criterion1 = MultiGaussianNLLLoss(reduction='mean', eps=1e-8, full=True, mode=config.covmode,
+                                          chunk=getattr(config, "chunk_size", None),
+                                          want_covariance=getattr(config, "want_covariance", False))
+        return lambda pred, targ, var: criterion1(pred, targ, var)
+    raise NotImplementedError(f"loss '{config.loss}' is outside the MI355X hot path (MGNLL only)")
+
+
+def calc_loss(criterion, config, out, y, var=None):
+    """losses.py:35-43"""
+    if config.loss in ['GNLL', 'MGNLL']:
+        loss, variance = criterion(out, y, var)
+    else:
+        loss, variance = criterion(out, y), None
+    return loss, variance
