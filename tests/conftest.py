@@ -61,6 +61,7 @@ def compare_param_grads(got, golden, tol=2e-4, zero_ratio=1e-5):
             err = rel_err(gv, ref)
         else:
             err = abs(checksum(gv)[1] - ref[1]) / max(abs(ref[1]), 1e-30)
+        print(f"[parity] grad {kind} {name}: {err:.3e}")
         assert err < tol, (name, kind, err)
         report.append((name, err))
     return report

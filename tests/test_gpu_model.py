@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import checksum, compare_param_grads, load_golden, rel_err
-from gpu_util import DEV, TOL, close, dev
+from gpu_util import DEV, TOL, close, close_vs_truth, dev, is_zero_grad, oracle_run
 
 pytestmark = pytest.mark.gpu
 
@@ -27,12 +27,15 @@ def _state(g, prefix="state/"):
 
 
 def _golden_case(name, state_from=None):
+    from oracle import uncrtaints_oracle as orc
     from uncrtaints_amd.src import losses
     g = load_golden(name)
     meta = json.loads(str(g["meta"]))
     cov = meta["covmode"]
-    m = _build(cov, _state(load_golden(state_from) if state_from else g))
-    x, y, dates = (dev(torch.from_numpy(g[k])) for k in ("x", "y", "dates"))
+    state = _state(load_golden(state_from) if state_from else g)
+    m = _build(cov, state)
+    xc, yc, dc = (torch.from_numpy(g[k]) for k in ("x", "y", "dates"))
+    x, y, dates = dev(xc), dev(yc), dev(dc)
     crit = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode=cov)
     # eval
     m.eval()
@@ -51,13 +54,25 @@ def _golden_case(name, state_from=None):
     l.backward()
     close(f"{name}/train_out", out, torch.from_numpy(g["train/out"]))
     assert abs(l.item() - float(g["train/loss"])) < 1e-4 * abs(float(g["train/loss"])), (l.item(), g["train/loss"])
-    rep = compare_param_grads({k: v.grad.detach().cpu().numpy() for k, v in m.named_parameters()}, g, tol=3e-4)
-    worst = max(rep, key=lambda t: t[1])
-    print(f"[parity] {name}: worst param-grad error {worst}")
-    close(f"{name}/dx_b0t0", xg.grad[0, 0], torch.from_numpy(g["train/dx_b0t0"]), tol=3e-4)
     for k in g.files:
         if k.startswith("train/state/"):
             close(f"{name}/{k}", m.state_dict()[k[len("train/state/"):]], torch.from_numpy(g[k]))
+    # gradients: fp32 reference values from the fixture, fp64 oracle as the tie-breaker for ill-conditioned ones
+    cfg = orc.OracleConfig(covmode=cov, out_conv=[13 + (13 if cov == "diag" else 1)], attn_dropout=0.0)
+    _, _, dx64, g64, _ = oracle_run(state, xc, yc, dc, cfg, torch.float64)
+    _, _, dx32, g32, _ = oracle_run(state, xc, yc, dc, cfg, torch.float32)
+    close_vs_truth(f"{name}/dx_b0t0", xg.grad[0, 0], torch.from_numpy(g["train/dx_b0t0"]), dx64[0, 0],
+                   alt32=dx32[0, 0])
+    for k, v in m.named_parameters():
+        if is_zero_grad(k, g64):
+            sib = g64[k.replace(".bias", ".weight")].abs().max().item()
+            assert v.grad.abs().max().item() < 1e-3 * sib, k
+            continue
+        ref32 = torch.from_numpy(g["grad/" + k]) if ("grad/" + k) in g.files else g32[k]
+        close_vs_truth(f"{name}/grad[{k}]", v.grad, ref32, g64[k], alt32=g32[k])
+        if ("gradsum/" + k) in g.files and ("grad/" + k) not in g.files:
+            # the oracle-fp32 stand-in must itself agree with the reference's checksum
+            assert abs(checksum(g32[k].numpy())[1] - g[("gradsum/" + k)][1]) < 2e-3 * abs(g["gradsum/" + k][1])
     return m
 
 
@@ -112,32 +127,26 @@ def test_vs_oracle_fresh_inputs(B, T, H, W):
     state = _state(g)
     cfg = orc.OracleConfig(attn_dropout=0.0)
     x, y, dates = orc.synthetic_batch(B, T, H, W, seed=3)
-    pt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
-          for k, v in state.items()}
-    out_o = orc.forward(pt, x, dates, cfg, training=True)
-    loss_o = orc.loss_from_output(out_o, y, cfg)
-    loss_o.backward()
+    out_o, loss_o, dx32, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32)
+    _, _, dx64, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64)
     m = _build("diag", state)
     m.train()
-    out = m(dev(x), batch_positions=dev(dates))
+    xg = dev(x).requires_grad_(True)
+    out = m(xg, batch_positions=dev(dates))
     crit = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode="diag")
     l, _ = crit(out[:, :, :13], dev(y), out[:, :, 13:26])
     l.backward()
     close(f"fresh[{B},{T},{H}x{W}]/out", out, out_o)
     assert abs(l.item() - loss_o.item()) < 1e-4 * abs(loss_o.item())
-    worst = 0.0
+    close_vs_truth(f"fresh[{B},{T},{H}x{W}]/dx", xg.grad, dx32, dx64)
     for k, v in m.named_parameters():
-        ref = pt[k].grad
-        sib = pt.get(k.replace(".bias", ".weight"), pt[k]).grad
-        if k.endswith(".bias") and ref.abs().max() < 1e-5 * sib.abs().max():
+        if is_zero_grad(k, g64):
             continue
-        worst = max(worst, rel_err(v.grad.cpu().numpy(), ref.numpy()))
-    print(f"[parity] fresh[{B},{T},{H}x{W}] worst param-grad rel_err {worst:.3e}")
-    assert worst < 3e-4
-    # size-independent properties: attention is a distribution over T; variances positive; mean in (0,1)
+        close_vs_truth(f"fresh[{B},{T},{H}x{W}]/grad[{k}]", v.grad, g32[k], g64[k])
+    # size-independent properties: attention is a distribution over T; variances positive; mean in [0,1]
     att = m._last_attention
     assert torch.allclose(att.sum(dim=2), torch.ones_like(att.sum(dim=2)), atol=1e-5)
-    assert (out[:, :, 13:] > 0).all() and (out[:, :, :13] > 0).all() and (out[:, :, :13] < 1).all()
+    assert (out[:, :, 13:] > 0).all() and (out[:, :, :13] >= 0).all() and (out[:, :, :13] <= 1).all()
 
 
 def test_eval_is_deterministic_and_train_dropout_is_stochastic():
