@@ -1,0 +1,243 @@
+#!/usr/bin/env python
+"""Benchmark of the UnCRtainTS hot path on MI355X: one step = forward + MGNLL + backward (+ gradient
+all-reduce for N > 1) + Adam step on one batch of synthetic SAR+optical stacks.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Rank 0 prints ONE JSON line: BASELINE.json's metric (samples/s fwd+bwd at B x T x 15 x 256 x 256, T=3, B=4 per
+GPU, fp32), plus `roofline` for the dominant kernel (HIP-event timed inside the timed region) and
+`cpu_baseline` (the CPU oracle timed on the host cores; N=1 only)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+
+PRO_NORMBWD = 3
+
+
+def kernel_model(name, key):
+    """-> (label, algorithmic bytes, flops) of one launch from its int arguments."""
+    if name == "uncr_pw_gemm":
+        bias_stride, N, Cin, Cout, P, pro, epi = key
+        rd = Cin * (2 if pro == PRO_NORMBWD else 1) + (Cout if epi == 2 else 0)
+        return (f"pw_gemm[{Cin}->{Cout},pro{pro},epi{epi},N{N},P{P}]", 4.0 * N * P * (rd + Cout), 2.0 * N * P * Cin * Cout)
+    if name == "uncr_pw_wgrad":
+        N, Cd, Cx, P, PXB, pro_d, pro_x = key
+        rd = Cd * (2 if pro_d == PRO_NORMBWD else 1) + Cx * (2 if pro_x == PRO_NORMBWD else 1)
+        return (f"pw_wgrad[{Cd}x{Cx},N{N},P{P}]", 4.0 * N * P * rd, 2.0 * N * P * Cd * Cx)
+    if name == "uncr_dw_fwd":
+        N, C, H, W = key
+        return (f"dw_fwd[N{N},C{C},{H}x{W}]", 4.0 * N * C * H * W * 2, 18.0 * N * C * H * W)
+    if name == "uncr_dw_bwd":
+        N, C, H, W = key
+        return (f"dw_bwd[N{N},C{C},{H}x{W}]", 4.0 * N * C * H * W * 4, 36.0 * N * C * H * W)
+    if name == "uncr_ew":
+        op, planes, P, C, n_mean = key
+        tensors = {0: 1, 1: 2, 2: 2, 3: 3, 4: 3, 5: 4, 6: 3, 7: 1, 8: 2, 9: 3}[op]
+        return (f"ew[op{op},planes{planes},P{P}]", 4.0 * planes * P * tensors, 0.0)
+    if name == "uncr_aggregate_fwd":
+        B, T, C, NH, H, W, AH, AW = key
+        return (f"aggregate_fwd[B{B},T{T}]", 4.0 * B * C * H * W * (T + 1), 2.0 * B * T * C * H * W)
+    if name == "uncr_aggregate_bwd":
+        B, T, C, NH, H, W, AH, AW = key
+        return (f"aggregate_bwd[B{B},T{T}]", 4.0 * B * H * W * (C * (2 * T + 1) + NH * T), 4.0 * B * T * C * H * W)
+    return (name, 0.0, 0.0)
+
+
+PROFILED = ("uncr_pw_gemm", "uncr_pw_wgrad", "uncr_dw_fwd", "uncr_dw_bwd", "uncr_ew", "uncr_aggregate_fwd",
+            "uncr_aggregate_bwd")
+
+
+def a_step_bytes(T, P=65536):
+    """SURVEY 8(d) contract figure: algorithmic HBM bytes of one fwd+bwd step per sample, fp32."""
+    return 2.5 * 4.0 * P * (2206 * T + 9921)
+
+
+def build_model(device, seed):
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    from uncrtaints_amd.src.learning.weight_init import weight_init
+    torch.manual_seed(seed)
+    m = U.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag",
+                     scale_by=1.0)
+    m.apply(weight_init)
+    return m.to(device).train()
+
+
+def synthetic(B, T, H, W, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, T, 15, H, W, generator=g)
+    y = torch.rand(B, 1, 13, H, W, generator=g)
+    dates = torch.sort(torch.randint(1400, 1800, (B, T), generator=g), dim=1).values.float()
+    return x.to(device), y.to(device), dates.to(device)
+
+
+def cpu_baseline(T, H, W, budget_s=25.0):
+    """The CPU oracle (a port, not the reference itself) on the host cores: fwd + MGNLL + bwd, train mode, B=1."""
+    from oracle import uncrtaints_oracle as orc
+    cores = torch.get_num_threads()
+    cfg = orc.OracleConfig()
+    p = orc.init_params(cfg, seed=1)
+    pt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+          for k, v in p.items()}
+    x, y, dates = orc.synthetic_batch(1, T, H, W, seed=1)
+
+    def step():
+        for v in pt.values():
+            if getattr(v, "grad", None) is not None:
+                v.grad = None
+        out = orc.forward(pt, x, dates, cfg, training=True)
+        orc.loss_from_output(out, y, cfg).backward()
+
+    t0 = time.perf_counter()
+    step()                                      # warm-up (also sizes the sample)
+    warm = time.perf_counter() - t0
+    n = max(1, min(5, int(budget_s / max(warm, 1e-3)) - 1))
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle (torch fp32), B=1 T={T} {H}x{W}, fwd+MGNLL+bwd train mode, 1 warm-up + {n} timed, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=4)
+    ap.add_argument("--T", type=int, default=3)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from uncrtaints_amd import hip_backend as hb
+    from uncrtaints_amd.src import losses
+    hb.lib()
+    B, T, H = args.batch_per_gpu, args.T, args.size
+    model = build_model(device, seed=1)
+    crit = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode="diag")
+    dp = None
+    if world > 1:
+        from uncrtaints_amd.parallel import BucketedDataParallel
+        dp = BucketedDataParallel(model, seed=1)
+    else:
+        model.temporal_aggregator.set_seed(1)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    x, y, dates = synthetic(B, T, H, H, seed=1 + rank, device=device)
+
+    def step():
+        if dp is not None:
+            dp.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        out = model(x, batch_positions=dates)
+        loss, _ = crit(out[:, :, :13], y, out[:, :, 13:26])
+        loss.backward()
+        if dp is not None:
+            dp.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = None
+    if rank == 0 and not args.no_kernel_events:
+        prof = hb.EventProfiler(PROFILED)
+        hb.set_profiler(prof)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    hb.set_profiler(None)
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        res = {
+            "metric": "samples/sec fwd+bwd (BxTx15x256x256, T=3)", "value": round(value, 3), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"uncrtaints --input_t {T} --n_head 16 --block_type mbconv --covmode diag, "
+                                   f"B={B}/GPU, {H}x{H}, fwd+MGNLL+bwd+Adam, train mode (dropout on), fp32",
+                       "global_batch": world * B, "T": T, "parallelism": f"dp{world}"},
+            "final_loss": final_loss,
+            "step_hbm_roofline_frac": round(value / world * a_step_bytes(T, H * H) / 1e9 / HBM_PEAK_GBS, 4),
+        }
+        if prof is not None:
+            summ = prof.summarize()
+            rows = []
+            for (name, key), (n, mean_ms) in summ.items():
+                label, nbytes, flops = kernel_model(name, key)
+                rows.append(dict(kernel=label, launches=n, mean_ms=mean_ms, total_ms=n * mean_ms,
+                                 gbs=nbytes / mean_ms / 1e6 if mean_ms > 0 else 0.0,
+                                 tflops=flops / mean_ms / 1e9 if mean_ms > 0 else 0.0, bytes=nbytes, flops=flops))
+            rows.sort(key=lambda r: -r["total_ms"])
+            tot = sum(r["total_ms"] for r in rows)
+            top = rows[0]
+            # the bound of a kernel = whichever roof it is closer to
+            hbm_frac, mfma_frac = top["gbs"] / HBM_PEAK_GBS, top["tflops"] / FP32_MFMA_PEAK_TF
+            if mfma_frac > hbm_frac:
+                res["roofline"] = {"bound": "mfma", "achieved": round(top["tflops"], 2), "peak": FP32_MFMA_PEAK_TF,
+                                   "unit": "TFLOP/s", "frac": round(mfma_frac, 4), "traffic": None,
+                                   "kernel": top["kernel"]}
+            else:
+                res["roofline"] = {"bound": "hbm", "achieved": round(top["gbs"], 1), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": None, "kernel": top["kernel"]}
+            res["roofline"]["mean_launch_ms"] = round(top["mean_ms"], 4)
+            res["roofline"]["share_of_profiled_time"] = round(top["total_ms"] / max(tot, 1e-9), 4)
+            res["kernel_breakdown"] = [
+                dict(kernel=r["kernel"], launches_per_step=r["launches"] / args.steps, mean_ms=round(r["mean_ms"], 4),
+                     share=round(r["total_ms"] / max(tot, 1e-9), 4), gbs=round(r["gbs"], 1), tflops=round(r["tflops"], 2))
+                for r in rows[:12]]
+            res["profiled_ms_per_step"] = round(tot / args.steps, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(T, H, H)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,33 @@ def _ptr(x):
     return x.data_ptr()
 
 
+class EventProfiler:
+    """Optional per-launch timing with HIP events on torch's current stream (the stream every kernel of this
+    library is enqueued on).  Used by bench.py for the live roofline numbers; off by default."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []          # (entry point, int-arg tuple, start event, end event)
+
+    def summarize(self):
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for name, key, e0, e1 in self.records:
+            d = out.setdefault((name, key), [0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+        return {k: (n, ms / n) for k, (n, ms) in out.items()}   # launches, mean ms
+
+
+_PROF = None
+
+
+def set_profiler(p):
+    global _PROF
+    _PROF = p
+
+
 def call(name: str, *args):
     """Call an entry point; tensors are converted to pointers; raises RuntimeError on a non-zero code."""
     L = lib()
@@ -104,7 +131,16 @@ def call(name: str, *args):
             conv.append(_ptr(a) if typ != "hipStream_t" else a)
         else:
             conv.append(a)
-    rc = f(*conv)
+    if _PROF is not None and name in _PROF.names:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = f(*conv)
+        e1.record()
+        key = tuple(a for a, (typ, _) in zip(args, proto) if typ == "int")
+        _PROF.records.append((name, key, e0, e1))
+    else:
+        rc = f(*conv)
     if rc != 0:
         kind = "argument/shape error" if rc < 0 else "hipError_t"
         raise RuntimeError(f"{name} failed with code {rc} ({kind})")
