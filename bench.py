@@ -182,6 +182,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_dt = time.perf_counter() - t0      # host time to ENQUEUE the steps (no sync inside step())
     fence()
     dt = time.perf_counter() - t0
     hb.set_profiler(None)
@@ -201,7 +202,7 @@ def main():
             "config": {"workload": f"uncrtaints --input_t {T} --n_head 16 --block_type mbconv --covmode diag, "
                                    f"B={B}/GPU, {H}x{H}, fwd+MGNLL+bwd+Adam, train mode (dropout on), fp32",
                        "global_batch": world * B, "T": T, "parallelism": f"dp{world}"},
-            "final_loss": final_loss,
+            "final_loss": final_loss, "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
             "step_hbm_roofline_frac": round(value / world * a_step_bytes(T, H * H) / 1e9 / HBM_PEAK_GBS, 4),
         }
         if prof is not None:

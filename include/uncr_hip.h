@@ -58,7 +58,8 @@ int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, int groups, 
                            float* save_rstd, hipStream_t stream);
 int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                            const float* gamma, const float* save_mean, const float* save_rstd, float* c1,
-                           float* c2, float* c3, float* dgamma, float* dbeta, hipStream_t stream);
+                           float* c2, float* c3, float* dgamma, float* dbeta, float* scratch /* [2*N*C], GroupNorm */,
+                           hipStream_t stream);
 
 /* ---- element-wise family with fused coefficients + partial statistics
  *      (norm-apply/ReLU utae.py:470-494; residual add uncrtaints.py:142-146; SE avg-pool uncrtaints.py:85,95;

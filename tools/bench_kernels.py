@@ -1,0 +1,54 @@
+"""Microbenchmarks of single kernels at workload shapes (run on the GPU box).  Usage:
+   python tools/bench_kernels.py [gemm|wgrad|dw|ew|agg] [--iters K]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from uncrtaints_amd import engine as E
+
+def timeit(fn, iters):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
+    iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20
+    dev = "cuda"
+    N, P = 4, 65536
+    if what == "gemm":
+        for (Cin, Cout, pro, epi) in [(128, 256, 0, 0), (128, 256, 1, 1), (128, 256, 3, 0), (256, 128, 0, 0), (256, 128, 2, 1), (256, 128, 3, 2)]:
+            x = torch.randn(N, Cin, P, device=dev); x2 = torch.randn(N, Cin, P, device=dev)
+            W = torch.randn(Cout, Cin, device=dev) * 0.05
+            Wt = E.pack_wt(W, transpose=True)
+            k = tuple(torch.randn(N * Cin, device=dev) for _ in range(3))
+            aux = torch.randn(N, Cout, P, device=dev) if epi == 2 else None
+            out = torch.empty(N, Cout, P, device=dev)
+            fn = lambda: E.pw_gemm(x, Wt, N, Cin, Cout, P, pro=pro, k=k, x2=x2 if pro == 3 else None, epi=epi, aux=aux, out=out)
+            ms = timeit(fn, iters)
+            fl = 2.0 * N * P * Cin * Cout
+            by = 4.0 * N * P * (Cin * (2 if pro == 3 else 1) + Cout * (2 if epi == 2 else 1))
+            print(f"pw_gemm {Cin}->{Cout} pro{pro} epi{epi}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF  {by/ms/1e6:.0f} GB/s")
+    elif what == "wgrad":
+        for (Cd, Cx, pro_d, pro_x) in [(256, 128, 3, 1), (128, 256, 3, 2), (256, 128, 0, 0)]:
+            d = torch.randn(N, Cd, P, device=dev); d2 = torch.randn(N, Cd, P, device=dev); x = torch.randn(N, Cx, P, device=dev)
+            dk = tuple(torch.randn(N * Cd, device=dev) for _ in range(3)); xk = (torch.randn(N * Cx, device=dev), torch.randn(N * Cx, device=dev), None)
+            fn = lambda: E.pw_wgrad(d, x, N, Cd, Cx, P, pro_d=pro_d, dk=dk, d2=d2 if pro_d == 3 else None, pro_x=pro_x, xk=xk)
+            ms = timeit(fn, iters)
+            print(f"pw_wgrad {Cd}x{Cx} pro_d{pro_d} pro_x{pro_x}: {ms*1e3:.1f} us  {2.0*N*P*Cd*Cx/ms/1e9:.1f} TF (incl. reduce)")
+    elif what == "copy":
+        a = torch.randn(256 * 1024 * 1024 // 4, device=dev); b = torch.empty_like(a)
+        ms = timeit(lambda: b.copy_(a), iters)
+        print(f"torch copy 256MB: {ms*1e3:.1f} us  {2*a.numel()*4/ms/1e6:.0f} GB/s")
+        planes, PP = 1024, 65536
+        x = torch.randn(planes, PP, device=dev); h = torch.randn(planes, PP, device=dev); y = torch.empty_like(x)
+        kA = torch.randn(planes, device=dev); kB = torch.randn(planes, device=dev)
+        ms = timeit(lambda: E.ew(E.EW_RESIDUAL, x, b=h, out=y, k=(kA, kB, None, None), want_part=True, planes=planes, P=PP), iters)
+        print(f"ew residual 3x256MB: {ms*1e3:.1f} us  {3*x.numel()*4/ms/1e6:.0f} GB/s")
+
+if __name__ == "__main__":
+    main()

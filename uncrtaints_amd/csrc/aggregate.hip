@@ -119,9 +119,9 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g) {
                 const float4 o = acc[jc];
                 *(float4*)(g.out + ((size_t)b * g.C + c) * P + p0) = o;
                 if (g.part) {
-                    const float s0 = wave_sum(o.x + o.y + o.z + o.w);
-                    const float s1 = wave_sum(o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w);
-                    if (lane == 0) { wred[wv][c][0] = s0; wred[wv][c][1] = s1; }
+                    const float s0 = wave_sum_dpp(o.x + o.y + o.z + o.w);
+                    const float s1 = wave_sum_dpp(o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w);
+                    if (lane == 63) { wred[wv][c][0] = s0; wred[wv][c][1] = s1; }
                 }
             }
         }

@@ -54,14 +54,39 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     return v;
 }
 
+// DPP (data-parallel primitive) adds: full-rate VALU cross-lane moves inside a row of 16 lanes, no LDS
+// crossbar (ds_bpermute) round trip.  dpp_ctrl: quad_perm 0x00-0xFF, row_ror:n = 0x120+n, row_bcast15 = 0x142,
+// row_bcast31 = 0x143.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND = true>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK,
+                                                                 BANK_MASK, BOUND));
+}
+// sum over each 32-lane half; the result is valid in lane 31 (lanes 0-31) and lane 63 (lanes 32-63) ONLY
+__device__ __forceinline__ float half_wave_sum_dpp(float v) {
+    v += dpp_mov<0xB1>(v);                 // quad_perm [1,0,3,2]  (xor 1)
+    v += dpp_mov<0x4E>(v);                 // quad_perm [2,3,0,1]  (xor 2)
+    v += dpp_mov<0x124>(v);                // row_ror:4
+    v += dpp_mov<0x128>(v);                // row_ror:8  -> every lane of a row holds the row sum
+    v += dpp_mov<0x142, 0xA, 0xF, false>(v);   // row_bcast15 into rows 1 and 3: lane 31 / 63 = half sums
+    return v;
+}
+
+// sum over the whole wave; the result is valid in lane 63 ONLY
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = half_wave_sum_dpp(v);
+    v += dpp_mov<0x143, 0xC, 0xF, false>(v);   // row_bcast31 into rows 2 and 3: lane 63 = wave sum
+    return v;
+}
+
 // Block-wide sum of two floats; result valid in thread 0.  `red` must hold >= 2*nwaves floats.
 template <int NTHREADS>
 __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
     constexpr int NW = NTHREADS / 64;
-    a = wave_sum(a);
-    b = wave_sum(b);
+    a = wave_sum_dpp(a);
+    b = wave_sum_dpp(b);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+    if (lane == 63) { red[2 * w] = a; red[2 * w + 1] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
         float sa = 0.f, sb = 0.f;

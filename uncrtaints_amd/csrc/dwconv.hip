@@ -180,12 +180,12 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
         *(float4*)(du1 + o) = make_float4(res[0], res[1], res[2], res[3]);
     }
     __shared__ float red[4][12];
-    s0 = wave_sum(s0);
-    s1 = wave_sum(s1);
+    s0 = wave_sum_dpp(s0);
+    s1 = wave_sum_dpp(s1);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) gw[i] = wave_sum(gw[i]);
+    for (int i = 0; i < 9; ++i) gw[i] = wave_sum_dpp(gw[i]);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) {
+    if (lane == 63) {
         red[wv][0] = s0; red[wv][1] = s1;
 #pragma unroll
         for (int i = 0; i < 9; ++i) red[wv][2 + i] = gw[i];

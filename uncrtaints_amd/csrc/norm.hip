@@ -111,63 +111,70 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(
 // dh = C1*du + C2*h + C3 with  C1 = r*gamma, C2 = -r^2*m2, C3 = r*(-m1 + r*mu*m2),
 //   m1 = mean_group(gamma*du), m2 = mean_group(gamma*du*hhat).
 // ---------------------------------------------------------------------------------------------
+// grid = N*G blocks; per-(n,c) d gamma / d beta contributions go to scratch[2][N][C], reduced over n by
+// gn_dgb_reduce_kernel in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(
     const float2* __restrict__ part, int NP, int N, int C, int G, int P, const float* __restrict__ gamma,
     const float* __restrict__ save_mean, const float* __restrict__ save_rstd, float* __restrict__ c1,
-    float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int g = blockIdx.x;
+    float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ scratch) {
+    const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int Cg = C / G;   // <= 256
     __shared__ double s1[256], s2[256];
     __shared__ double sm1, sm2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double dg_acc = 0.0, db_acc = 0.0;   // thread c (< Cg) owns channel g*Cg + c
-    for (int n = 0; n < N; ++n) {
-        // per-channel sums over the NP partials: one wave per channel, round-robin
-        for (int c = w; c < Cg; c += 4) {
-            const float2* src = part + ((size_t)n * C + g * Cg + c) * NP;
-            double a = 0.0, b = 0.0;
-            for (int j = lane; j < NP; j += 64) {
-                const float2 v = src[j];
-                a += (double)v.x;
-                b += (double)v.y;
-            }
-            a = wave_sum_d(a);
-            b = wave_sum_d(b);
-            if (lane == 0) { s1[c] = a; s2[c] = b; }
+    // per-channel sums over the NP partials: one wave per channel, round-robin
+    for (int c = w; c < Cg; c += 4) {
+        const float2* src = part + ((size_t)n * C + g * Cg + c) * NP;
+        double a = 0.0, b = 0.0;
+        for (int j = lane; j < NP; j += 64) {
+            const float2 v = src[j];
+            a += (double)v.x;
+            b += (double)v.y;
         }
-        __syncthreads();
-        const double mu = (double)save_mean[n * G + g], r = (double)save_rstd[n * G + g];
-        if (w == 0) {
-            double a = 0.0, b = 0.0;
-            for (int c = lane; c < Cg; c += 64) {
-                const double gm = (double)gamma[g * Cg + c];
-                a += gm * s1[c];
-                b += gm * r * (s2[c] - mu * s1[c]);
-            }
-            a = wave_sum_d(a);
-            b = wave_sum_d(b);
-            if (lane == 0) {
-                const double M = (double)Cg * (double)P;
-                sm1 = a / M;
-                sm2 = b / M;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < Cg) {
-            const int c = threadIdx.x, ch = g * Cg + c;
-            const double gm = (double)gamma[ch];
-            c1[n * C + ch] = (float)(r * gm);
-            c2[n * C + ch] = (float)(-r * r * sm2);
-            c3[n * C + ch] = (float)(r * (-sm1 + r * mu * sm2));
-            dg_acc += r * (s2[c] - mu * s1[c]);
-            db_acc += s1[c];
-        }
-        __syncthreads();
+        a = wave_sum_d(a);
+        b = wave_sum_d(b);
+        if (lane == 0) { s1[c] = a; s2[c] = b; }
     }
+    __syncthreads();
+    const double mu = (double)save_mean[n * G + g], r = (double)save_rstd[n * G + g];
+    if (w == 0) {
+        double a = 0.0, b = 0.0;
+        for (int c = lane; c < Cg; c += 64) {
+            const double gm = (double)gamma[g * Cg + c];
+            a += gm * s1[c];
+            b += gm * r * (s2[c] - mu * s1[c]);
+        }
+        a = wave_sum_d(a);
+        b = wave_sum_d(b);
+        if (lane == 0) {
+            const double M = (double)Cg * (double)P;
+            sm1 = a / M;
+            sm2 = b / M;
+        }
+    }
+    __syncthreads();
     if (threadIdx.x < Cg) {
-        dgamma[g * Cg + threadIdx.x] = (float)dg_acc;
-        dbeta[g * Cg + threadIdx.x] = (float)db_acc;
+        const int c = threadIdx.x, ch = g * Cg + c;
+        const double gm = (double)gamma[ch];
+        c1[n * C + ch] = (float)(r * gm);
+        c2[n * C + ch] = (float)(-r * r * sm2);
+        c3[n * C + ch] = (float)(r * (-sm1 + r * mu * sm2));
+        scratch[(size_t)n * C + ch] = (float)(r * (s2[c] - mu * s1[c]));
+        scratch[(size_t)N * C + (size_t)n * C + ch] = (float)s1[c];
     }
+}
+
+__global__ __launch_bounds__(256) void gn_dgb_reduce_kernel(const float* __restrict__ scratch, int N, int C,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int n = 0; n < N; ++n) {
+        a += (double)scratch[(size_t)n * C + c];
+        b += (double)scratch[(size_t)N * C + (size_t)n * C + c];
+    }
+    dgamma[c] = (float)a;
+    dbeta[c] = (float)b;
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(
@@ -241,12 +248,16 @@ extern "C" int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, i
 
 extern "C" int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                                       const float* gamma, const float* save_mean, const float* save_rstd, float* c1,
-                                      float* c2, float* c3, float* dgamma, float* dbeta, hipStream_t stream) {
+                                      float* c2, float* c3, float* dgamma, float* dbeta, float* scratch,
+                                      hipStream_t stream) {
     if (N <= 0 || C <= 0 || P <= 0 || !part) return UNCR_ESHAPE;
     if (kind == NORM_GROUP) {
-        if (groups <= 0 || C % groups || C / groups > 256) return UNCR_EINVAL;
-        hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(groups), dim3(256), 0, stream, (const float2*)part, NP, N, C,
-                           groups, P, gamma, save_mean, save_rstd, c1, c2, c3, dgamma, dbeta);
+        if (groups <= 0 || C % groups || C / groups > 256 || !scratch) return UNCR_EINVAL;
+        hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(N * groups), dim3(256), 0, stream, (const float2*)part, NP, N,
+                           C, groups, P, gamma, save_mean, save_rstd, c1, c2, c3, scratch);
+        UNCR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gn_dgb_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, N, C, dgamma,
+                           dbeta);
     } else if (kind == NORM_BATCH_TRAIN || kind == NORM_BATCH_EVAL) {
         hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(256), 0, stream, (const float2*)part, NP, N, C, P,
                            kind == NORM_BATCH_TRAIN, gamma, save_mean, save_rstd, c1, c2, c3, dgamma, dbeta);

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
     constexpr int NL = (KC * TP / 4) / NT;        // float4 loads per thread per chunk
     constexpr int ROWS_PER_I = NT / (TP / 4);     // rows covered per load index
 
-    __shared__ __attribute__((aligned(16))) float xs[KC][TP];
+    __shared__ __attribute__((aligned(16))) float xs[2][KC][TP];   // double-buffered activation chunk
     __shared__ float cf[3][256];
     __shared__ float red[WM][COUTP][2];
 
@@ -68,20 +68,47 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
     const float* inb = g.in + (size_t)n * Cin * P + px0 + 4 * lc4;
     const float* in2b = g.in2 ? g.in2 + (size_t)n * Cin * P + px0 + 4 * lc4 : nullptr;
 
+    // Software pipeline: while the MFMAs of chunk kc run from xs[kc&1], the register-prefetched chunk kc+1 is
+    // transformed and written to xs[(kc+1)&1], chunk kc+2 is fetched into the registers just freed, and the
+    // A fragments of chunk kc+1 are re-loaded into the registers the MFMAs have just consumed.  One barrier
+    // per chunk; no global latency is exposed inside the loop.
     float4 pre[NL], pre2[PRE2 ? NL : 1];
-    auto issue_loads = [&](int kc) {
+    auto load_piece = [&](int i, int kc) {
+        const int k = kc * KC + lrow + i * ROWS_PER_I;
+        if (k < Cin) {
+            pre[i] = *(const float4*)(inb + (size_t)k * P);
+            if constexpr (PRE2) {
+                if (pro == PRO_NORMBWD) pre2[i] = *(const float4*)(in2b + (size_t)k * P);
+            }
+        } else {
+            pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage_piece = [&](int i, int kc, int buf) {
+        const int r = lrow + i * ROWS_PER_I;
+        const int k = kc * KC + r;
+        float4 v = pre[i];
+        if (k < Cin) {
+            const float c0 = cf[0][k], c1 = cf[1][k], c2 = cf[2][k];
+            float* pv = (float*)&v;
+            if (pro == PRO_AFFINE) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int k = kc * KC + lrow + i * ROWS_PER_I;
-            if (k < Cin) {
-                pre[i] = *(const float4*)(inb + (size_t)k * P);
+                for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], c1);
+            } else if (pro == PRO_AFFINE_GELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pv[j] = c2 * gelu_f(fmaf(c0, pv[j], c1));
+            } else if (pro == PRO_NORMBWD) {
                 if constexpr (PRE2) {
-                    if (pro == PRO_NORMBWD) pre2[i] = *(const float4*)(in2b + (size_t)k * P);
+                    const float* p2 = (const float*)&pre2[i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], fmaf(c1, p2[j], c2));
                 }
-            } else {
-                pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (pro == PRO_AFFINE_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pv[j] = fmaxf(fmaf(c0, pv[j], c1), 0.f);
             }
         }
+        *(float4*)&xs[buf][r][4 * lc4] = v;
     };
 
     f32x16 acc[4][CT];
@@ -92,59 +119,50 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][ct][r] = 0.f;
 
-    issue_loads(0);
-    __syncthreads();   // cf visible
-
     const float* wbase = g.Wt + (size_t)(lane >> 5) * COUTP + wn * (CT * 32) + (lane & 31);
+    float afr[16][CT];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) load_piece(i, 0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) afr[s][ct] = wbase[(size_t)(2 * s) * COUTP + ct * 32];
+    __syncthreads();   // cf visible
+#pragma unroll
+    for (int i = 0; i < NL; ++i) stage_piece(i, 0, 0);
+    if (nk > 1) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) load_piece(i, 1);
+    }
+    __syncthreads();
 
+    constexpr int SLOT = 16 / NL >= 1 ? 16 / NL : 1;   // MFMA k-steps between two staging pieces
     for (int kc = 0; kc < nk; ++kc) {
-        // A fragments of this chunk (L2-resident weights), issued ahead of the LDS staging
-        float afr[16][CT];
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) afr[s][ct] = wbase[(size_t)(kc * KC + 2 * s) * COUTP + ct * 32];
-
-        // transform + stage the prefetched activation chunk
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int r = lrow + i * ROWS_PER_I;
-            const int k = kc * KC + r;
-            float4 v = pre[i];
-            if (k < Cin) {
-                const float c0 = cf[0][k], c1 = cf[1][k], c2 = cf[2][k];
-                float* pv = (float*)&v;
-                if (pro == PRO_AFFINE) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], c1);
-                } else if (pro == PRO_AFFINE_GELU) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) pv[j] = c2 * gelu_f(fmaf(c0, pv[j], c1));
-                } else if (pro == PRO_NORMBWD) {
-                    if constexpr (PRE2) {
-                        const float* p2 = (const float*)&pre2[i];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], fmaf(c1, p2[j], c2));
-                    }
-                } else if (pro == PRO_AFFINE_RELU) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) pv[j] = fmaxf(fmaf(c0, pv[j], c1), 0.f);
-                }
-            }
-            *(float4*)&xs[r][4 * lc4] = v;
-        }
-        __syncthreads();
-        if (kc + 1 < nk) issue_loads(kc + 1);
-
+        const int cur = kc & 1;
+        const bool has1 = kc + 1 < nk, has2 = kc + 2 < nk;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const float4 b = *(const float4*)&xs[2 * s + (lane >> 5)][wm * 128 + 4 * (lane & 31)];
+            const float4 b = *(const float4*)&xs[cur][2 * s + (lane >> 5)][wm * 128 + 4 * (lane & 31)];
             const float* pb = (const float*)&b;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     acc[e][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s][ct], pb[e], acc[e][ct], 0, 0, 0);
+            if (has1) {
+                // rolling A prefetch into the registers this k-step has just consumed
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    afr[s][ct] = wbase[(size_t)((kc + 1) * KC + 2 * s) * COUTP + ct * 32];
+                // one staging piece of the next chunk every SLOT k-steps (NL pieces per chunk)
+                if constexpr (NL <= 16) {
+                    if (s % SLOT == SLOT - 1 && s / SLOT < NL) {
+                        const int i = s / SLOT;
+                        stage_piece(i, kc + 1, cur ^ 1);
+                        if (has2) load_piece(i, kc + 2);
+                    }
+                }
+            }
         }
         __syncthreads();
     }
@@ -177,9 +195,9 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
                 }
             }
             if (epi) {   // block-uniform
-                s0 = half_wave_sum(s0);
-                s1 = half_wave_sum(s1);
-                if ((lane & 31) == 0) { red[wm][col][0] = s0; red[wm][col][1] = s1; }
+                s0 = half_wave_sum_dpp(s0);
+                s1 = half_wave_sum_dpp(s1);
+                if ((lane & 31) == 31) { red[wm][col][0] = s0; red[wm][col][1] = s1; }
             }
         }
     }
@@ -236,12 +254,16 @@ __device__ __forceinline__ float4 apply_pro(int pro, float4 v, const float4& v2,
     return v;
 }
 
-template <int MT, int NTL, int WCO, int WCI>
-__global__ __launch_bounds__(64 * WCO * WCI) void pw_wgrad_kernel(WgArgs g) {
+// D2 = true keeps a second register set for the PRO_NORMBWD operand of D.
+template <int MT, int NTL, int WCO, int WCI, bool D2>
+__global__ __launch_bounds__(64 * WCO * WCI, 2) void pw_wgrad_kernel(WgArgs g) {
     constexpr int NT = 64 * WCO * WCI;
     constexpr int COP = 32 * MT * WCO;
     constexpr int CIP = 32 * NTL * WCI;
     constexpr int KP = 32, PITCH = 36;
+    constexpr int ND = COP * 8 / NT;   // float4 per thread per chunk, D operand
+    constexpr int NX = CIP * 8 / NT;   // X operand
+    static_assert(COP * 8 % NT == 0 && CIP * 8 % NT == 0, "loader mapping");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ds = smem;                   // [COP][PITCH]
@@ -253,6 +275,7 @@ __global__ __launch_bounds__(64 * WCO * WCI) void pw_wgrad_kernel(WgArgs g) {
     const int P = g.P, Cd = g.Cd, Cx = g.Cx;
     const int pbeg = blockIdx.x * g.PXB;
     const int nchunks = g.PXB / KP;
+    const int pro_d = g.pro_d, pro_x = g.pro_x;
 
     f32x16 acc[MT][NTL];
 #pragma unroll
@@ -263,42 +286,77 @@ __global__ __launch_bounds__(64 * WCO * WCI) void pw_wgrad_kernel(WgArgs g) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float rowsum = 0.f;
 
-    const float* dbase = g.d + (size_t)n * Cd * P;
-    const float* d2base = g.d2 ? g.d2 + (size_t)n * Cd * P : nullptr;
-    const float* xbase = g.x + (size_t)n * Cx * P;
-    const float* x2base = g.x2 ? g.x2 + (size_t)n * Cx * P : nullptr;
-    const int pro_d = g.pro_d, pro_x = g.pro_x;
+    // loader mapping: float4 index f = tid + i*NT -> (row = f >> 3, c4 = f & 7); rows advance by NT/8 per i
+    const int lrow = tid >> 3, lc4 = tid & 7;
+    constexpr int RSTEP = NT / 8;
+    const float* dbase = g.d + (size_t)n * Cd * P + 4 * lc4;
+    const float* d2base = g.d2 ? g.d2 + (size_t)n * Cd * P + 4 * lc4 : nullptr;
+    const float* xbase = g.x + (size_t)n * Cx * P + 4 * lc4;
+
+    // per-row prologue coefficients of this frame -> LDS (chunk-invariant)
+    float* cfd = smem + (COP + CIP) * PITCH;    // [3][COP]
+    float* cfx = cfd + 3 * COP;                 // [3][CIP]
+    for (int i = tid; i < COP; i += NT) {
+        const int ci = n * Cd + (i < Cd ? i : 0);
+        cfd[i] = g.dk0 ? g.dk0[ci] : 1.f;
+        cfd[COP + i] = g.dk1 ? g.dk1[ci] : 0.f;
+        cfd[2 * COP + i] = g.dk2 ? g.dk2[ci] : (pro_d == PRO_AFFINE_GELU ? 1.f : 0.f);
+    }
+    for (int i = tid; i < CIP; i += NT) {
+        const int ci = n * Cx + (i < Cx ? i : 0);
+        cfx[i] = g.xk0 ? g.xk0[ci] : 1.f;
+        cfx[CIP + i] = g.xk1 ? g.xk1[ci] : 0.f;
+        cfx[2 * CIP + i] = g.xk2 ? g.xk2[ci] : (pro_x == PRO_AFFINE_GELU ? 1.f : 0.f);
+    }
+    __syncthreads();
+
+    // staging registers: with both operands in flight at once the big shapes spill, so the X loads are issued
+    // after the D tile has been staged whenever the total exceeds 12 float4 per lane
+    constexpr bool SPLIT = (ND * (D2 ? 2 : 1) + NX) > 12;
+    float4 dv[ND], dv2[D2 ? ND : 1], xv[NX];
+    auto issue_d = [&](int ch) {
+        const size_t p0 = (size_t)pbeg + (size_t)ch * KP;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int row = lrow + i * RSTEP;
+            if (row < Cd) {
+                dv[i] = *(const float4*)(dbase + (size_t)row * P + p0);
+                if constexpr (D2) {
+                    if (pro_d == PRO_NORMBWD) dv2[i] = *(const float4*)(d2base + (size_t)row * P + p0);
+                }
+            } else {
+                dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto issue_x = [&](int ch) {
+        const size_t p0 = (size_t)pbeg + (size_t)ch * KP;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int row = lrow + i * RSTEP;
+            xv[i] = row < Cx ? *(const float4*)(xbase + (size_t)row * P + p0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
 
     for (int ch = 0; ch < nchunks; ++ch) {
-        const int p0 = pbeg + ch * KP;
-        // stage D: COP rows x 8 float4
-        for (int f = tid; f < COP * 8; f += NT) {
-            const int row = f >> 3, c4 = f & 7;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < Cd) {
-                const size_t o = (size_t)row * P + p0 + 4 * c4;
-                v = *(const float4*)(dbase + o);
-                float4 v2 = v;
-                if (pro_d == PRO_NORMBWD) v2 = *(const float4*)(d2base + o);
-                const int ci = n * Cd + row;
-                v = apply_pro(pro_d, v, v2, g.dk0 ? g.dk0[ci] : 1.f, g.dk1 ? g.dk1[ci] : 0.f,
-                              g.dk2 ? g.dk2[ci] : (pro_d == PRO_AFFINE_GELU ? 1.f : 0.f));
-            }
-            *(float4*)&ds[row * PITCH + 4 * c4] = v;
+        // all global loads of an operand tile are issued back-to-back (one or two latency exposures per chunk;
+        // the other resident block's MFMA phase covers them), then transformed and staged
+        issue_d(ch);
+        if constexpr (!SPLIT) issue_x(ch);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int row = lrow + i * RSTEP;
+            float4 v = dv[i];
+            if (row < Cd) v = apply_pro(pro_d, v, D2 ? dv2[D2 ? i : 0] : v, cfd[row], cfd[COP + row], cfd[2 * COP + row]);
+            *(float4*)&ds[row * PITCH + 4 * lc4] = v;
         }
-        for (int f = tid; f < CIP * 8; f += NT) {
-            const int row = f >> 3, c4 = f & 7;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < Cx) {
-                const size_t o = (size_t)row * P + p0 + 4 * c4;
-                v = *(const float4*)(xbase + o);
-                float4 v2 = v;
-                if (pro_x == PRO_NORMBWD) v2 = *(const float4*)(x2base + o);
-                const int ci = n * Cx + row;
-                v = apply_pro(pro_x, v, v2, g.xk0 ? g.xk0[ci] : 1.f, g.xk1 ? g.xk1[ci] : 0.f,
-                              g.xk2 ? g.xk2[ci] : (pro_x == PRO_AFFINE_GELU ? 1.f : 0.f));
-            }
-            *(float4*)&xs[row * PITCH + 4 * c4] = v;
+        if constexpr (SPLIT) issue_x(ch);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int row = lrow + i * RSTEP;
+            float4 v = xv[i];
+            if (row < Cx) v = apply_pro(pro_x, v, v, cfx[row], cfx[CIP + row], cfx[2 * CIP + row]);
+            *(float4*)&xs[row * PITCH + 4 * lc4] = v;
         }
         __syncthreads();
         if (g.rs_part && tid < COP) {
@@ -353,9 +411,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (idx >= COP * CIP) return;
     const int co = idx / CIP, ci = idx % CIP;
     if (co >= Cout || ci >= Cin) return;
-    const float* src = part + (size_t)blockIdx.y * nblk_per_out * COP * CIP + idx;
+    const size_t S = (size_t)COP * CIP;
+    const float* src = part + (size_t)blockIdx.y * nblk_per_out * S + idx;
     double s = 0.0;
-    for (int b = 0; b < nblk_per_out; ++b) s += (double)src[(size_t)b * COP * CIP];
+    int b = 0;
+    for (; b + 8 <= nblk_per_out; b += 8) {   // 8 independent loads in flight, summed in a fixed order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(b + j) * S];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (double)v[j];
+    }
+    for (; b < nblk_per_out; ++b) s += (double)src[(size_t)b * S];
     out[((size_t)blockIdx.y * Cout + co) * Cin + ci] = (float)s;
 }
 
@@ -437,16 +504,24 @@ extern "C" int uncr_pw_wgrad(const float* d, const float* d2, const float* x, co
     if (shp < 0 || N <= 0) return UNCR_ESHAPE;
     if (PXB <= 0 || PXB % 32 || P % PXB) return UNCR_ESHAPE;
     if (!d || !x || !part) return UNCR_EINVAL;
-    if ((pro_d == PRO_NORMBWD && !d2) || (pro_x == PRO_NORMBWD && !x2)) return UNCR_EINVAL;
+    if (pro_d == PRO_NORMBWD && !d2) return UNCR_EINVAL;
+    if (pro_x == PRO_NORMBWD) return UNCR_EINVAL;   // norm-backward form is only built for the D operand
     WgArgs g{d, d2, x, x2, dk0, dk1, dk2, xk0, xk1, xk2, part, rs_part, Cd, Cx, P, PXB, pro_d, pro_x};
     dim3 grid(P / PXB, N);
-    const size_t lds = (size_t)(cop + cip) * 36 * sizeof(float);
+    const size_t lds = (size_t)((cop + cip) * 36 + 3 * (cop + cip)) * sizeof(float);
     switch (shp) {
-        case 0: hipLaunchKernelGGL((pw_wgrad_kernel<2, 4, 4, 1>), grid, dim3(256), lds, stream, g); break;
-        case 1: hipLaunchKernelGGL((pw_wgrad_kernel<2, 4, 2, 2>), grid, dim3(256), lds, stream, g); break;
-        case 2: hipLaunchKernelGGL((pw_wgrad_kernel<1, 1, 4, 1>), grid, dim3(256), lds, stream, g); break;
-        case 3: hipLaunchKernelGGL((pw_wgrad_kernel<1, 1, 1, 4>), grid, dim3(256), lds, stream, g); break;
-        case 4: hipLaunchKernelGGL((pw_wgrad_kernel<2, 4, 1, 2>), grid, dim3(128), lds, stream, g); break;
+#define WG_LAUNCH(MT_, NT_, WCO_, WCI_, THREADS)                                                                   \
+    if (pro_d == PRO_NORMBWD)                                                                                      \
+        hipLaunchKernelGGL((pw_wgrad_kernel<MT_, NT_, WCO_, WCI_, true>), grid, dim3(THREADS), lds, stream, g);    \
+    else                                                                                                           \
+        hipLaunchKernelGGL((pw_wgrad_kernel<MT_, NT_, WCO_, WCI_, false>), grid, dim3(THREADS), lds, stream, g);   \
+    break;
+        case 0: WG_LAUNCH(2, 4, 4, 1, 256)
+        case 1: WG_LAUNCH(2, 4, 2, 2, 256)
+        case 2: WG_LAUNCH(1, 1, 4, 1, 256)
+        case 3: WG_LAUNCH(1, 1, 1, 4, 256)
+        case 4: WG_LAUNCH(2, 4, 1, 2, 128)
+#undef WG_LAUNCH
     }
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;

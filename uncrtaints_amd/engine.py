@@ -127,8 +127,9 @@ def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor) -> 
     dev = gamma.device
     c1, c2, c3 = _f32((N * C,), dev), _f32((N * C,), dev), _f32((N * C,), dev)
     dg, db = _f32((C,), dev), _f32((C,), dev)
+    scratch = _f32((2 * N * C,), dev) if nf.kind == NORM_GROUP else None
     hb.call("uncr_norm_finalize_bwd", part.buf, part.slots, N, C, nf.groups, P, nf.kind, gamma, nf.mean, nf.rstd,
-            c1, c2, c3, dg, db, _stream())
+            c1, c2, c3, dg, db, scratch, _stream())
     return NormBwd(c1, c2, c3, dg, db)
 
 
