@@ -49,6 +49,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define UNCR_EW_HEAD_BWD 9
 
 int uncr_version(void);
+int uncr_debug_mfma_probe(float* out, int blocks, int iters, hipStream_t stream);   /* fp32-MFMA peak probe */
 
 /* ---- normalisation coefficients: nn.GroupNorm / nn.BatchNorm2d statistics
  *      (uncrtaints.py:16-22 get_norm_layer, utae.py:470-473, uncrtaints.py:72-79 PreNorm) ---- */

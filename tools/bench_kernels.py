@@ -40,6 +40,24 @@ def main():
             fn = lambda: E.pw_wgrad(d, x, N, Cd, Cx, P, pro_d=pro_d, dk=dk, d2=d2 if pro_d == 3 else None, pro_x=pro_x, xk=xk)
             ms = timeit(fn, iters)
             print(f"pw_wgrad {Cd}x{Cx} pro_d{pro_d} pro_x{pro_x}: {ms*1e3:.1f} us  {2.0*N*P*Cd*Cx/ms/1e9:.1f} TF (incl. reduce)")
+    elif what == "ablate":
+        Cin, Cout = 128, 256
+        x = torch.randn(N, Cin, P, device=dev); W = torch.randn(Cout, Cin, device=dev) * 0.05
+        Wt = E.pack_wt(W, transpose=True); out = torch.empty(N, Cout, P, device=dev)
+        from uncrtaints_amd import hip_backend as hb
+        for flags, name in [(0, "full")]:
+            fn = lambda: hb.call("uncr_pw_gemm", x, None, Wt, out, None, None, None, None, 0, None, None, N, Cin, Cout, P, 0, flags, E._stream())
+            ms = timeit(fn, iters)
+            print(f"{name:28s}: {ms*1e3:.1f} us  {2.0*N*P*Cin*Cout/ms/1e9:.1f} TF")
+    elif what == "mfma":
+        from uncrtaints_amd import hip_backend as hb
+        out = torch.zeros(4, device=dev)
+        for blocks in (256, 512, 1024):
+            its = 4000
+            fn = lambda: hb.call("uncr_debug_mfma_probe", out, blocks, its, E._stream())
+            ms = timeit(fn, 5)
+            fl = blocks * 4 * its * 8 * (2.0 * 32 * 32 * 2)
+            print(f"mfma probe blocks={blocks}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF")
     elif what == "copy":
         a = torch.randn(256 * 1024 * 1024 // 4, device=dev); b = torch.empty_like(a)
         ms = timeit(lambda: b.copy_(a), iters)

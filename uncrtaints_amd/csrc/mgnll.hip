@@ -171,4 +171,27 @@ extern "C" int uncr_ensemble_combine(const float* mu, const float* var, int M, l
     return UNCR_OK;
 }
 
+// ---- debug: pure fp32-MFMA throughput probe (no memory traffic), used by tools/bench_kernels.py ----
+__global__ __launch_bounds__(256, 2) void mfma_probe_kernel(float* out, int iters, float a0, float b0) {
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = a0 + threadIdx.x * 1e-6f, b = b0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][15];
+    if (s == 12345.678f) out[0] = s;   // keep the chain alive
+}
+extern "C" int uncr_debug_mfma_probe(float* out, int blocks, int iters, hipStream_t stream) {
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, stream, out, iters, 1.0f, 0.5f);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
 extern "C" int uncr_version() { return 1; }
