@@ -24,14 +24,36 @@ enum : int {
 
 enum : int { NORM_GROUP = 0, NORM_BATCH_TRAIN = 1, NORM_BATCH_EVAL = 2 };
 
+// erf for the exact (erf-form) GELU of nn.GELU().  ocml's erff is a two-branch ~40-instruction routine and made
+// every GELU-carrying streaming kernel VALU-bound (3.3 TB/s vs 5.7 TB/s without it).  This is a branch-free
+// fit  erf(t) = 1 - 2^(-t*Q(t)),  t = min(|x|, 4),  Q of degree 7 (weighted least squares + Lawson iterations
+// against scipy's fp64 erf): max abs error 1.1e-7 over the whole real line in fp32 arithmetic -- the fp32
+// rounding floor of values near 1 -- for 7 FMAs + one v_exp_f32.  -DUNCR_EXACT_ERF restores erff.
+__device__ __forceinline__ float erf_f(float x) {
+#ifdef UNCR_EXACT_ERF
+    return erff(x);
+#else
+    const float t = fminf(fabsf(x), 4.0f);
+    float q = 4.536090636975132e-05f;
+    q = fmaf(q, t, -0.00044552396866492927f);
+    q = fmaf(q, t, 0.001489486894570291f);
+    q = fmaf(q, t, 0.0007745671318843961f);
+    q = fmaf(q, t, -0.02825363539159298f);
+    q = fmaf(q, t, 0.1484815925359726f);
+    q = fmaf(q, t, 0.9184163808822632f);
+    q = fmaf(q, t, 1.6279085874557495f);
+    const float e = 1.0f - __builtin_amdgcn_exp2f(-t * q);
+    return copysignf(e, x);
+#endif
+}
 __device__ __forceinline__ float gelu_f(float u) {
     // exact (erf) GELU, as nn.GELU() default
-    return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));
+    return 0.5f * u * (1.0f + erf_f(u * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float gelu_grad_f(float u) {
-    // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
-    const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+    // d/du [u * Phi(u)] = Phi(u) + u * phi(u);  phi(u) = exp(-u^2/2)/sqrt(2 pi) = 2^(-u^2 * log2(e)/2)/sqrt(2 pi)
+    const float cdf = 0.5f * (1.0f + erf_f(u * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * u * u);
     return cdf + u * pdf;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }

@@ -13,30 +13,37 @@
 #define DW_TR_FWD 32
 #define DW_TR_BWD 16
 
+// LDS tile layout: row pitch = W + 8 floats; image column x lives at offset 4 + x, so the interior is 16-byte
+// aligned (one ds_write_b128 per staged float4, one ds_read_b128 + two ds_read_b32 per stencil row); the
+// reflect / zero halo columns sit at offsets 3 and 4 + W.
+// Tile loops are division-free: thread -> (row r0 = tid / W4, column quad c4 = tid % W4) once, then r += 256 / W4.
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ in, const float* __restrict__ cA,
                                                      const float* __restrict__ cB, const float* __restrict__ w,
                                                      float* __restrict__ out, float2* __restrict__ part, int C,
                                                      int H, int W) {
-    extern __shared__ __attribute__((aligned(16))) float t[];   // [(TR+2)][W+2]
+    extern __shared__ __attribute__((aligned(16))) float t[];   // [(TR+2)][W+8]
     constexpr int TR = DW_TR_FWD;
     const int plane = blockIdx.y, c = plane % C;
     const int y0 = blockIdx.x * TR;
-    const int W4 = W >> 2, pitch = W + 2;
+    const int W4 = W >> 2, pitch = W + 8;
+    const int rpp = 256 / W4;                       // rows per pass
+    const int r0 = threadIdx.x / W4, c4 = threadIdx.x - r0 * W4;
+    const bool active = r0 < rpp;
     const float A = cA[plane], B = cB[plane];
     const float* src = in + (size_t)plane * H * W;
     const int rows = min(TR, H - y0) + 2;
-    for (int idx = threadIdx.x; idx < rows * W4; idx += 256) {
-        const int r = idx / W4, c4 = idx - r * W4;
-        const int gy = reflect1(y0 - 1 + r, H);
-        float4 v = *(const float4*)(src + (size_t)gy * W + 4 * c4);
-        v.x = gelu_f(fmaf(A, v.x, B));
-        v.y = gelu_f(fmaf(A, v.y, B));
-        v.z = gelu_f(fmaf(A, v.z, B));
-        v.w = gelu_f(fmaf(A, v.w, B));
-        float* row = t + r * pitch + 1 + 4 * c4;
-        row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
-        if (c4 == 0) t[r * pitch] = v.y;                    // col -1 -> col 1
-        if (c4 == W4 - 1) t[r * pitch + W + 1] = v.z;       // col W  -> col W-2
+    if (active) {
+        for (int r = r0; r < rows; r += rpp) {
+            const int gy = reflect1(y0 - 1 + r, H);
+            float4 v = *(const float4*)(src + (size_t)gy * W + 4 * c4);
+            v.x = gelu_f(fmaf(A, v.x, B));
+            v.y = gelu_f(fmaf(A, v.y, B));
+            v.z = gelu_f(fmaf(A, v.z, B));
+            v.w = gelu_f(fmaf(A, v.w, B));
+            *(float4*)(t + r * pitch + 4 + 4 * c4) = v;
+            if (c4 == 0) t[r * pitch + 3] = v.y;                    // col -1 -> col 1
+            if (c4 == W4 - 1) t[r * pitch + 4 + W] = v.z;           // col W  -> col W-2
+        }
     }
     float wk[9];
 #pragma unroll
@@ -45,22 +52,22 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ i
     float s0 = 0.f, s1 = 0.f;
     float* dst = out + (size_t)plane * H * W;
     const int orows = rows - 2;
-    for (int idx = threadIdx.x; idx < orows * W4; idx += 256) {
-        const int r = idx / W4, c4 = idx - r * W4;
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        for (int r = r0; r < orows; r += rpp) {
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const float* row = t + (r + dy) * pitch + 4 * c4;
-            float v[6];
+            for (int dy = 0; dy < 3; ++dy) {
+                const float* row = t + (r + dy) * pitch + 4 + 4 * c4;
+                const float4 m = *(const float4*)row;
+                const float v[6] = {row[-1], m.x, m.y, m.z, m.w, row[4]};
 #pragma unroll
-            for (int j = 0; j < 6; ++j) v[j] = row[j];
+                for (int j = 0; j < 4; ++j)
+                    o[j] = fmaf(wk[dy * 3 + 0], v[j], fmaf(wk[dy * 3 + 1], v[j + 1], fmaf(wk[dy * 3 + 2], v[j + 2], o[j])));
+            }
+            *(float4*)(dst + (size_t)(y0 + r) * W + 4 * c4) = make_float4(o[0], o[1], o[2], o[3]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                o[j] = fmaf(wk[dy * 3 + 0], v[j], fmaf(wk[dy * 3 + 1], v[j + 1], fmaf(wk[dy * 3 + 2], v[j + 2], o[j])));
+            for (int j = 0; j < 4; ++j) { s0 += o[j]; s1 += o[j] * o[j]; }
         }
-        *(float4*)(dst + (size_t)(y0 + r) * W + 4 * c4) = make_float4(o[0], o[1], o[2], o[3]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s0 += o[j]; s1 += o[j] * o[j]; }
     }
     if (part) {
         __shared__ float red[8];
@@ -78,41 +85,43 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
     constexpr int TR = DW_TR_BWD;
     const int plane = blockIdx.y, c = plane % C;
     const int y0 = blockIdx.x * TR;
-    const int W4 = W >> 2, pitch = W + 2;
-    float* Dt = sm;                          // zero-padded dh2 tile
+    const int W4 = W >> 2, pitch = W + 8;
+    const int rpp = 256 / W4;
+    const int r0 = threadIdx.x / W4, c4 = threadIdx.x - r0 * W4;
+    const bool active = r0 < rpp;
+    float* Dt = sm;                          // zero-padded dh2 tile   (image col x at offset 4 + x)
     float* Gt = sm + (TR + 2) * pitch;       // reflect-padded g1 tile
     const float C1 = k1[plane], C2 = k2[plane], C3 = k3[plane];
     const float A1 = cA1[plane], B1 = cB1[plane];
     const size_t pbase = (size_t)plane * H * W;
     const int rows = min(TR, H - y0) + 2;
-    for (int idx = threadIdx.x; idx < rows * W4; idx += 256) {
-        const int r = idx / W4, c4 = idx - r * W4;
-        const int y = y0 - 1 + r;
-        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= 0 && y < H) {
-            const size_t o = pbase + (size_t)y * W + 4 * c4;
-            const float4 a = *(const float4*)(du2 + o);
-            const float4 b = *(const float4*)(h2 + o);
-            d.x = fmaf(C1, a.x, fmaf(C2, b.x, C3));
-            d.y = fmaf(C1, a.y, fmaf(C2, b.y, C3));
-            d.z = fmaf(C1, a.z, fmaf(C2, b.z, C3));
-            d.w = fmaf(C1, a.w, fmaf(C2, b.w, C3));
-        }
-        float* drow = Dt + r * pitch + 1 + 4 * c4;
-        drow[0] = d.x; drow[1] = d.y; drow[2] = d.z; drow[3] = d.w;
-        if (c4 == 0) Dt[r * pitch] = 0.f;
-        if (c4 == W4 - 1) Dt[r * pitch + W + 1] = 0.f;
+    if (active) {
+        for (int r = r0; r < rows; r += rpp) {
+            const int y = y0 - 1 + r;
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < H) {
+                const size_t o = pbase + (size_t)y * W + 4 * c4;
+                const float4 a = *(const float4*)(du2 + o);
+                const float4 b = *(const float4*)(h2 + o);
+                d.x = fmaf(C1, a.x, fmaf(C2, b.x, C3));
+                d.y = fmaf(C1, a.y, fmaf(C2, b.y, C3));
+                d.z = fmaf(C1, a.z, fmaf(C2, b.z, C3));
+                d.w = fmaf(C1, a.w, fmaf(C2, b.w, C3));
+            }
+            *(float4*)(Dt + r * pitch + 4 + 4 * c4) = d;
+            if (c4 == 0) Dt[r * pitch + 3] = 0.f;
+            if (c4 == W4 - 1) Dt[r * pitch + 4 + W] = 0.f;
 
-        const int gy = reflect1(y, H);
-        float4 v = *(const float4*)(h1 + pbase + (size_t)gy * W + 4 * c4);
-        v.x = gelu_f(fmaf(A1, v.x, B1));
-        v.y = gelu_f(fmaf(A1, v.y, B1));
-        v.z = gelu_f(fmaf(A1, v.z, B1));
-        v.w = gelu_f(fmaf(A1, v.w, B1));
-        float* grow = Gt + r * pitch + 1 + 4 * c4;
-        grow[0] = v.x; grow[1] = v.y; grow[2] = v.z; grow[3] = v.w;
-        if (c4 == 0) Gt[r * pitch] = v.y;
-        if (c4 == W4 - 1) Gt[r * pitch + W + 1] = v.z;
+            const int gy = reflect1(y, H);
+            float4 v = *(const float4*)(h1 + pbase + (size_t)gy * W + 4 * c4);
+            v.x = gelu_f(fmaf(A1, v.x, B1));
+            v.y = gelu_f(fmaf(A1, v.y, B1));
+            v.z = gelu_f(fmaf(A1, v.z, B1));
+            v.w = gelu_f(fmaf(A1, v.w, B1));
+            *(float4*)(Gt + r * pitch + 4 + 4 * c4) = v;
+            if (c4 == 0) Gt[r * pitch + 3] = v.y;
+            if (c4 == W4 - 1) Gt[r * pitch + 4 + W] = v.z;
+        }
     }
     float wk[9];
 #pragma unroll
@@ -124,60 +133,75 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < 9; ++i) gw[i] = 0.f;
     const int orows = rows - 2;
-    for (int idx = threadIdx.x; idx < orows * W4; idx += 256) {
-        const int r = idx / W4, c4 = idx - r * W4;
-        const int y = y0 + r;
-        // adjoint of reflect padding: the plain transposed stencil on the zero-padded tile, plus the
-        // contributions that forward reflection folded back onto rows/cols 1 and H-2 / W-2.
-        const bool ry0 = (y == 1), ry1 = (y == H - 2);
-        const int er0 = 0 - (y0 - 1), er1 = (H - 1) - (y0 - 1);   // tile rows of image rows 0 and H-1
-        const size_t o = pbase + (size_t)y * W + 4 * c4;
-        const float4 hv = *(const float4*)(h1 + o);
-        const float* ph = (const float*)&hv;
-        float res[4];
+    // tile rows of image rows 0 and H-1 (only meaningful when the block holds them)
+    const int er0 = 0 - (y0 - 1), er1 = (H - 1) - (y0 - 1);
+    if (active) {
+        for (int r = r0; r < orows; r += rpp) {
+            const int y = y0 + r;
+            // adjoint of reflect padding: the plain transposed stencil on the zero-padded tile, plus the
+            // contributions that forward reflection folded back onto rows/cols 1 and H-2 / W-2.
+            const bool ry0 = (y == 1), ry1 = (y == H - 2);
+            const size_t o = pbase + (size_t)y * W + 4 * c4;
+            const float4 hv = *(const float4*)(h1 + o);
+            const float* ph = (const float*)&hv;
+            // rows r..r+2 of both tiles, columns x-1 .. x+4 (tile offsets 3+4c4 .. 8+4c4)
+            float dt[3][6], gt[3][6];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int x = 4 * c4 + j;
-            float acc = 0.f;
-#pragma unroll
-            for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-                for (int tx = 0; tx < 3; ++tx)
-                    acc = fmaf(wk[ty * 3 + tx], Dt[(r + 2 - ty) * pitch + x + 2 - tx], acc);
-            const bool cx0 = (x == 1), cx1 = (x == W - 2);
-            if (ry0) {
-#pragma unroll
-                for (int tx = 0; tx < 3; ++tx) acc = fmaf(wk[tx], Dt[er0 * pitch + x + 2 - tx], acc);
+            for (int dy = 0; dy < 3; ++dy) {
+                const float* drow = Dt + (r + dy) * pitch + 4 + 4 * c4;
+                const float4 dm = *(const float4*)drow;
+                dt[dy][0] = drow[-1]; dt[dy][1] = dm.x; dt[dy][2] = dm.y; dt[dy][3] = dm.z; dt[dy][4] = dm.w; dt[dy][5] = drow[4];
+                const float* grow = Gt + (r + dy) * pitch + 4 + 4 * c4;
+                const float4 gm = *(const float4*)grow;
+                gt[dy][0] = grow[-1]; gt[dy][1] = gm.x; gt[dy][2] = gm.y; gt[dy][3] = gm.z; gt[dy][4] = gm.w; gt[dy][5] = grow[4];
             }
-            if (ry1) {
+            float res[4];
 #pragma unroll
-                for (int tx = 0; tx < 3; ++tx) acc = fmaf(wk[6 + tx], Dt[er1 * pitch + x + 2 - tx], acc);
+            for (int j = 0; j < 4; ++j) {
+                const int x = 4 * c4 + j;
+                float acc = 0.f;
+                // transposed stencil: image (y - ty + 1, x - tx + 1) = tile row r + 2 - ty, local column j + 2 - tx
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) acc = fmaf(wk[ty * 3 + tx], dt[2 - ty][j + 2 - tx], acc);
+                const bool cx0 = (x == 1), cx1 = (x == W - 2);
+                if (ry0 || ry1 || cx0 || cx1) {     // rare: image border fix-ups straight from LDS
+                    if (ry0) {
+#pragma unroll
+                        for (int tx = 0; tx < 3; ++tx) acc = fmaf(wk[tx], Dt[er0 * pitch + 4 + x + 1 - tx], acc);
+                    }
+                    if (ry1) {
+#pragma unroll
+                        for (int tx = 0; tx < 3; ++tx) acc = fmaf(wk[6 + tx], Dt[er1 * pitch + 4 + x + 1 - tx], acc);
+                    }
+                    if (cx0) {
+#pragma unroll
+                        for (int ty = 0; ty < 3; ++ty) acc = fmaf(wk[ty * 3], Dt[(r + 2 - ty) * pitch + 4], acc);
+                        if (ry0) acc = fmaf(wk[0], Dt[er0 * pitch + 4], acc);
+                        if (ry1) acc = fmaf(wk[6], Dt[er1 * pitch + 4], acc);
+                    }
+                    if (cx1) {
+#pragma unroll
+                        for (int ty = 0; ty < 3; ++ty) acc = fmaf(wk[ty * 3 + 2], Dt[(r + 2 - ty) * pitch + 4 + W - 1], acc);
+                        if (ry0) acc = fmaf(wk[2], Dt[er0 * pitch + 4 + W - 1], acc);
+                        if (ry1) acc = fmaf(wk[8], Dt[er1 * pitch + 4 + W - 1], acc);
+                    }
+                }
+                const float u = fmaf(A1, ph[j], B1);
+                const float dv = gelu_grad_f(u) * acc;
+                res[j] = dv;
+                s0 += dv;
+                s1 += dv * ph[j];
+                // depthwise weight gradient: dh2 at (y,x) times g1 at the reflect-padded neighbours
+                const float dc = dt[1][j + 1];
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) gw[ty * 3 + tx] = fmaf(dc, gt[ty][j + tx], gw[ty * 3 + tx]);
             }
-            if (cx0) {
-#pragma unroll
-                for (int ty = 0; ty < 3; ++ty) acc = fmaf(wk[ty * 3], Dt[(r + 2 - ty) * pitch + 1], acc);
-                if (ry0) acc = fmaf(wk[0], Dt[er0 * pitch + 1], acc);
-                if (ry1) acc = fmaf(wk[6], Dt[er1 * pitch + 1], acc);
-            }
-            if (cx1) {
-#pragma unroll
-                for (int ty = 0; ty < 3; ++ty) acc = fmaf(wk[ty * 3 + 2], Dt[(r + 2 - ty) * pitch + W], acc);
-                if (ry0) acc = fmaf(wk[2], Dt[er0 * pitch + W], acc);
-                if (ry1) acc = fmaf(wk[8], Dt[er1 * pitch + W], acc);
-            }
-            const float u = fmaf(A1, ph[j], B1);
-            const float dv = gelu_grad_f(u) * acc;
-            res[j] = dv;
-            s0 += dv;
-            s1 += dv * ph[j];
-            // depthwise weight gradient: dh2 at (y,x) times g1 at the reflect-padded neighbours
-            const float dc = Dt[(r + 1) * pitch + x + 1];
-#pragma unroll
-            for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-                for (int tx = 0; tx < 3; ++tx) gw[ty * 3 + tx] = fmaf(dc, Gt[(r + ty) * pitch + x + tx], gw[ty * 3 + tx]);
+            *(float4*)(du1 + o) = make_float4(res[0], res[1], res[2], res[3]);
         }
-        *(float4*)(du1 + o) = make_float4(res[0], res[1], res[2], res[3]);
     }
     __shared__ float red[4][12];
     s0 = wave_sum_dpp(s0);
@@ -217,8 +241,8 @@ extern "C" int uncr_dw_slots_bwd(int H) { return (H + DW_TR_BWD - 1) / DW_TR_BWD
 
 extern "C" int uncr_dw_fwd(const float* in, const float* cA, const float* cB, const float* w, float* out,
                            float* part, int N, int C, int H, int W, hipStream_t stream) {
-    if (N <= 0 || C <= 0 || H < 2 || W < 4 || (W & 3)) return UNCR_ESHAPE;
-    const size_t lds = (size_t)(DW_TR_FWD + 2) * (W + 2) * sizeof(float);
+    if (N <= 0 || C <= 0 || H < 2 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
+    const size_t lds = (size_t)(DW_TR_FWD + 2) * (W + 8) * sizeof(float);
     if (lds > 60 * 1024) return UNCR_ESHAPE;
     hipLaunchKernelGGL(dw_fwd_kernel, dim3(uncr_dw_slots_fwd(H), N * C), dim3(256), lds, stream, in, cA, cB, w, out,
                        (float2*)part, C, H, W);
@@ -229,8 +253,8 @@ extern "C" int uncr_dw_fwd(const float* in, const float* cA, const float* cB, co
 extern "C" int uncr_dw_bwd(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2,
                            const float* k3, const float* cA1, const float* cB1, const float* w, float* du1,
                            float* part, float* dw_part, int N, int C, int H, int W, hipStream_t stream) {
-    if (N <= 0 || C <= 0 || H < 4 || W < 4 || (W & 3)) return UNCR_ESHAPE;
-    const size_t lds = (size_t)2 * (DW_TR_BWD + 2) * (W + 2) * sizeof(float);
+    if (N <= 0 || C <= 0 || H < 4 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
+    const size_t lds = (size_t)2 * (DW_TR_BWD + 2) * (W + 8) * sizeof(float);
     if (lds > 60 * 1024) return UNCR_ESHAPE;
     hipLaunchKernelGGL(dw_bwd_kernel, dim3(uncr_dw_slots_bwd(H), N * C), dim3(256), lds, stream, du2, h2, h1, k1, k2,
                        k3, cA1, cB1, w, du1, (float2*)part, dw_part, C, H, W);

@@ -51,7 +51,15 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_frame_kernel(
     if (tid < C) {
         const float* g = G + (size_t)n * Co * C + tid;
         double a = 0.0;
-        for (int co = 0; co < Co; ++co) a += (double)Wpw[co * C + tid] * (double)g[(size_t)co * C];
+        int co = 0;
+        for (; co + 8 <= Co; co += 8) {       // 16 independent loads in flight, fixed summation order
+            float wv[8], gv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { wv[j] = Wpw[(co + j) * C + tid]; gv[j] = g[(size_t)(co + j) * C]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += (double)wv[j] * (double)gv[j];
+        }
+        for (; co < Co; ++co) a += (double)Wpw[co * C + tid] * (double)g[(size_t)co * C];
         const float sv = s[n * C + tid];
         const float d = (float)a * sv * (1.f - sv);
         sds[tid] = d;
