@@ -84,7 +84,11 @@ def synthetic(B, T, H, W, seed, device):
 def cpu_baseline(T, H, W, budget_s=25.0):
     """The CPU oracle (a port, not the reference itself) on the host cores: fwd + MGNLL + bwd, train mode, B=1."""
     from oracle import uncrtaints_oracle as orc
-    cores = torch.get_num_threads()
+    # 16 threads was the fastest setting measured on the GPU box's 256-thread host (8: 15.3 s, 16: 12.1 s,
+    # 32: 13.5 s, 64: 20.5 s per step before the oracle moved to ATen convolutions; torch's default of 128 is 3x
+    # slower still).  `cores` in the JSON is the thread count actually used.
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
     cfg = orc.OracleConfig()
     p = orc.init_params(cfg, seed=1)
     pt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())

@@ -113,3 +113,20 @@ def test_g8_ensemble_combine():
         m, v = orc.ensemble_combine(mu, var, mode)
         assert rel_err(m.numpy(), g["mean_ens"]) < 1e-12
         assert rel_err(v.numpy(), g[key]) < 1e-10
+
+
+def test_explicit_formulas_agree_with_aten_ops():
+    """The oracle's spelled-out formulas (USE_ATEN = False) and the ATen ops the reference modules call agree."""
+    g = load_golden("g1_diag_t3")
+    p = _state(g)
+    cfg = orc.OracleConfig(attn_dropout=0.0)
+    x, dates = torch.from_numpy(g["x"]), torch.from_numpy(g["dates"])
+    outs = {}
+    for flag in (True, False):
+        orc.USE_ATEN = flag
+        try:
+            with torch.no_grad():
+                outs[flag] = orc.forward({k: v.clone() for k, v in p.items()}, x, dates, cfg, training=True)
+        finally:
+            orc.USE_ATEN = True
+    assert rel_err(outs[False].numpy(), outs[True].numpy()) < TOL
