@@ -345,7 +345,7 @@ def test_head_fwd_bwd(E, covmode):
     out.backward(gy)
     got, sv = E.head_forward(dev(y), dev(w), dev(b), 13, True, 1.0, 1e-9)
     close(f"head_fwd[{covmode}]", got, out)
-    dy, dW, db = E.head_backward(dev(gy), sv, dev(w))
+    dy, dW, db, _ = E.head_backward(dev(gy), sv, dev(w))
     close("head_dy", dy, yo.grad)
     close("head_dW", dW, wo.grad)
     close("head_db", db, bo.grad)

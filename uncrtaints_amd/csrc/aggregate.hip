@@ -69,7 +69,10 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
     __shared__ float wred[4][256][2];   // per-wave statistics partials (forward), C <= 256
-    for (int h = 0; h < g.NH; ++h) {
+    // heads are split over blockIdx.z (more blocks in flight: the kernel is pure latency/bandwidth bound)
+    const int hpb = (g.NH + gridDim.z - 1) / gridDim.z;
+    const int h_beg = blockIdx.z * hpb, h_end = min(g.NH, h_beg + hpb);
+    for (int h = h_beg; h < h_end; ++h) {
         float4 acc[CH];                 // fwd: output accumulators; bwd: dg of the head's channels
 #pragma unroll
         for (int jc = 0; jc < CH; ++jc) {
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g) {
     if constexpr (!BWD) {
         if (g.part) {
             __syncthreads();
-            for (int c = threadIdx.x; c < g.C; c += 256)
+            for (int c = h_beg * CH + threadIdx.x; c < h_end * CH; c += 256)
                 g.part[((size_t)b * g.C + c) * gridDim.x + blockIdx.x] =
                     make_float2(wred[0][c][0] + wred[1][c][0] + wred[2][c][0] + wred[3][c][0],
                                 wred[0][c][1] + wred[1][c][1] + wred[2][c][1] + wred[3][c][1]);
@@ -195,7 +198,7 @@ extern "C" int uncr_aggregate_fwd(const float* e, const float* att, const int* p
     const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
     if (rc) return rc;
     AggArgs g{e, att, pad, dmask, out, nullptr, nullptr, nullptr, (float2*)part, seed, p_drop, B, T, C, NH, H, W, AH, AW};
-    const dim3 grid(H * W / AGG_PX, B);
+    const dim3 grid(H * W / AGG_PX, B, NH % 4 == 0 ? 4 : 1);
     switch (C / NH) {
         case 4: hipLaunchKernelGGL((aggregate_kernel<false, 4>), grid, dim3(256), 0, stream, g); break;
         case 8: hipLaunchKernelGGL((aggregate_kernel<false, 8>), grid, dim3(256), 0, stream, g); break;
@@ -212,7 +215,7 @@ extern "C" int uncr_aggregate_bwd(const float* dg, const float* e, const float* 
     const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
     if (rc) return rc;
     AggArgs g{e, att, pad, dmask, nullptr, dg, de, datt_up, nullptr, seed, p_drop, B, T, C, NH, H, W, AH, AW};
-    const dim3 grid(H * W / AGG_PX, B);
+    const dim3 grid(H * W / AGG_PX, B, NH % 4 == 0 ? 4 : 1);
     switch (C / NH) {
         case 4: hipLaunchKernelGGL((aggregate_kernel<true, 4>), grid, dim3(256), 0, stream, g); break;
         case 8: hipLaunchKernelGGL((aggregate_kernel<true, 8>), grid, dim3(256), 0, stream, g); break;

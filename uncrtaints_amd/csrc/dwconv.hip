@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
             // contributions that forward reflection folded back onto rows/cols 1 and H-2 / W-2.
             const bool ry0 = (y == 1), ry1 = (y == H - 2);
             const size_t o = pbase + (size_t)y * W + 4 * c4;
-            const float4 hv = *(const float4*)(h1 + o);
+            const float4 hv = *(const float4*)(h1 + o);     // L2-resident re-read (an LDS copy costs occupancy)
             const float* ph = (const float*)&hv;
             // rows r..r+2 of both tiles, columns x-1 .. x+4 (tile offsets 3+4c4 .. 8+4c4)
             float dt[3][6], gt[3][6];

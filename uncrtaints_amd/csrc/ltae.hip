@@ -18,11 +18,23 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const float* p = in + (size_t)plane * H * W;
     float best = -INFINITY;
     int bi = ys * W + xs;
-    for (int y = ys; y < ye; ++y)
-        for (int x = xs; x < xe; ++x) {
-            const float v = p[y * W + x];
-            if (v > best || v != v) { best = v; bi = y * W + x; }   // NaN propagates like ATen
-        }
+    if (((xe - xs) & 3) == 0 && (xs & 3) == 0 && (W & 3) == 0) {
+        // 16-byte loads along the window rows (the 256->32 case: two float4 per row); same scan order
+        for (int y = ys; y < ye; ++y)
+            for (int x = xs; x < xe; x += 4) {
+                const float4 q = *(const float4*)(p + y * W + x);
+                const float vv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (vv[j] > best || vv[j] != vv[j]) { best = vv[j]; bi = y * W + x + j; }
+            }
+    } else {
+        for (int y = ys; y < ye; ++y)
+            for (int x = xs; x < xe; ++x) {
+                const float v = p[y * W + x];
+                if (v > best || v != v) { best = v; bi = y * W + x; }   // NaN propagates like ATen
+            }
+    }
     out[(size_t)plane * OH * OW + o] = best;
     idx[(size_t)plane * OH * OW + o] = bi;
 }

@@ -200,7 +200,7 @@ MB_KEYS = ("n0w", "n0b", "w1", "n1w", "n1b", "wdw", "n2w", "n2b", "se1", "se2", 
 
 def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bool,
                    x_part: Optional[Part] = None, buffers: Optional[Dict[str, Tensor]] = None,
-                   want_out_stats: bool = True):
+                   want_out_stats: bool = True, x_h3: Optional[Tensor] = None):
     """x [N,C,H,W] -> y, saved-for-backward dict, partial stats of y (for the next PreNorm).
     `buffers` holds BatchNorm running_mean/var tensors keyed n{0..3}rm / n{0..3}rv (updated in place)."""
     N, C, H, W = _check4(x)
@@ -240,12 +240,14 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     _, party = ew(EW_RESIDUAL, x, b=h3, out=y, k=(n3.A, n3.B, None, None), want_part=want_out_stats, planes=N * C,
                   P=P)
     saved = dict(x=x, h1=h1, h2=h2, h3=h3, n0=n0, n1=n1, n2=n2, n3=n3, pooled=pooled, hid_pre=hid_pre, s=s,
-                 dims=(N, C, Ch, R, H, W))
+                 dims=(N, C, Ch, R, H, W), x_h3=x_h3)
     return y, saved, party
 
 
-def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = True):
-    """-> dx, {param key: grad}"""
+def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = True,
+                    dy_part: Optional[Part] = None):
+    """-> dx, {param key: grad}, partials (sum dx, sum dx*h3_prev) for the producing block (or None).
+    `dy_part` = (sum dy, sum dy*h3) partials if the kernel that produced dy already emitted them."""
     N, C, Ch, R, H, W = sv["dims"]
     P = H * W
     dev = dy.device
@@ -255,7 +257,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     g: Dict[str, Tensor] = {}
 
     # norm 3 backward coefficients: needs (sum dy, sum dy*h3)
-    part3 = stats_aux(dy, h3, N * C, P)
+    part3 = dy_part if dy_part is not None else stats_aux(dy, h3, N * C, P)
     b3 = norm_bwd(part3, N, C, P, n3, p["n3w"])
     g["n3w"], g["n3b"] = b3.dgamma, b3.dbeta
     k3 = (b3.c1, b3.c2, b3.c3)
@@ -301,11 +303,13 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     b0 = norm_bwd(part0, N, C, P, n0, p["n0w"])
     g["n0w"], g["n0b"] = b0.dgamma, b0.dbeta
 
-    dx = None
+    dx, dx_part = None, None
     if need_dx:
         dx = _f32((N, C, H, W), dev)
-        ew(EW_PASSE, dy, b=da, c=x, out=dx, k=(b0.c1, b0.c2, b0.c3, None), planes=N * C, P=P)
-    return dx, g
+        x_h3 = sv.get("x_h3")     # h3 of the block that produced x: emit its norm-3 backward statistics here
+        _, dx_part = ew(EW_PASSE, dy, b=da, c=x, aux=x_h3, out=dx, k=(b0.c1, b0.c2, b0.c3, None),
+                        want_part=x_h3 is not None, planes=N * C, P=P)
+    return dx, g, dx_part
 
 
 # ------------------------------------------------------------------------------------------------
@@ -504,7 +508,7 @@ def head_forward(y: Tensor, w: Tensor, b: Tensor, n_mean: int, mean_sigmoid: boo
     out = _f32((N, Co, H, W), y.device)
     nm = n_mean if mean_sigmoid else -n_mean
     ew(EW_HEAD_FWD, o, out=out, planes=N * Co, P=P, C=Co, n_mean=nm, scale=scale, eps=eps)
-    return out, dict(y=y, o=o, nm=nm, scale=scale, dims=(N, C, Co, H, W))
+    return out, dict(y=y, o=o, nm=nm, scale=scale, dims=(N, C, Co, H, W), y_h3=getattr(y, "_uncr_h3", None))
 
 
 def head_backward(dout: Tensor, sv: dict, w: Tensor, need_dy: bool = True):
@@ -514,12 +518,13 @@ def head_backward(dout: Tensor, sv: dict, w: Tensor, need_dy: bool = True):
     do = _f32((N, Co, H, W), dout.device)
     ew(EW_HEAD_BWD, dout, b=sv["o"], out=do, planes=N * Co, P=P, C=Co, n_mean=sv["nm"], scale=sv["scale"])
     dW, db = pw_wgrad(do, sv["y"], N, Co, C, P, rowsum=True)
-    dy = None
+    dy, dy_part = None, None
     if need_dy:
         Wk = pack_wt(w.reshape(Co, C), transpose=False)        # [k=26][out=128]
-        dy, _ = pw_gemm(do, Wk, N, Co, C, P)
+        y_h3 = sv.get("y_h3")       # last decoder block's h3: emit (sum dy, sum dy*h3) in the GEMM epilogue
+        dy, dy_part = pw_gemm(do, Wk, N, Co, C, P, epi=2 if y_h3 is not None else 0, aux=y_h3)
         dy = dy.view(N, C, H, W)
-    return dy, dW.view_as(w), db
+    return dy, dW.view_as(w), db, dy_part
 
 
 # ------------------------------------------------------------------------------------------------

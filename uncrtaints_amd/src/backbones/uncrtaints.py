@@ -65,14 +65,23 @@ class _MBConvFn(torch.autograd.Function):
         p = dict(zip(E.MB_KEYS, params))
         x = x.contiguous()
         y, sv, party = E.mbconv_forward(x, p, module._spec, module.training, getattr(x, "_uncr_part", None),
-                                        module._bn_buffers(), want_out_stats=True)
+                                        module._bn_buffers(), want_out_stats=True,
+                                        x_h3=getattr(x, "_uncr_h3", None))
         ctx.sv, ctx.p = sv, p
-        y._uncr_part = party
+        y._uncr_part = party        # (sum y, sum y^2) partials for the next PreNorm
+        y._uncr_h3 = sv["h3"]       # lets the consumer of y emit this block's norm-3 backward statistics
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        dx, g = E.mbconv_backward(dy, ctx.sv, ctx.p, need_dx=ctx.needs_input_grad[0])
+        # when dy comes straight from the consumer's backward kernel it carries (sum dy, sum dy*h3) partials
+        part = getattr(dy, "_uncr_bpart", None)
+        N, C, _, _, H, W = ctx.sv["dims"]
+        if part is not None and part.buf.shape[0] != N * C:
+            part = None
+        dx, g, dx_part = E.mbconv_backward(dy, ctx.sv, ctx.p, need_dx=ctx.needs_input_grad[0], dy_part=part)
+        if dx is not None and dx_part is not None:
+            dx._uncr_bpart = dx_part
         return (dx, None) + tuple(g[k] for k in E.MB_KEYS)
 
 
@@ -216,7 +225,9 @@ class _HeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        dy, dW, db = E.head_backward(dout, ctx.sv, ctx.w, ctx.needs_input_grad[0])
+        dy, dW, db, dy_part = E.head_backward(dout, ctx.sv, ctx.w, ctx.needs_input_grad[0])
+        if dy is not None and dy_part is not None:
+            dy._uncr_bpart = dy_part
         return dy, dW, db, None
 
 
@@ -362,5 +373,7 @@ class _HeadFnMeanOnly(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        dy, dW, db = E.head_backward(dout, ctx.sv, ctx.w, ctx.needs_input_grad[0])
+        dy, dW, db, dy_part = E.head_backward(dout, ctx.sv, ctx.w, ctx.needs_input_grad[0])
+        if dy is not None and dy_part is not None:
+            dy._uncr_bpart = dy_part
         return dy, dW, db, None
