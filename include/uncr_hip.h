@@ -117,6 +117,9 @@ int uncr_ltae_gn_fwd(const float* x, const float* gamma, const float* beta, floa
 int uncr_ltae_gn_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                      float* dx, float* gb_part, int B, int T, int C, int G, int S, hipStream_t stream);
 int uncr_colsum(const float* part, int R, int K, float* out, hipStream_t stream);
+/* agg_mode 'att_mean' (head-averaged attention, uncrtaints.py:179-188,211-219) and 'mean' (:189-192,220-221) helpers */
+int uncr_bcast_scale(const float* src, int R, long long n, float scale, float* dst, hipStream_t stream);
+int uncr_mean_weights(const int* pad, int NH, int B, int T, int S, float* out, hipStream_t stream);
 int uncr_ltae_posbias(const float* dates, const float* denom, int d, const float* bin, float* out, int NF, int D,
                       int use_pe, hipStream_t stream);
 int uncr_ltae_softmax_fwd(const float* k, const float* Q, const int* pad, float* att, int B, int T, int NH,
@@ -128,11 +131,12 @@ int uncr_ltae_softmax_bwd(const float* datt, const float* att, const float* k, c
  *      uncrtaints.py:156-221: bilinear up-sample + dropout + pad mask + V-aggregate) ---- */
 int uncr_agg_slots(int P);
 int uncr_aggregate_fwd(const float* e, const float* att, const int* pad, const float* dmask,
-                       unsigned long long seed, float p_drop, float* out, float* part, int B, int T, int C,
-                       int NH, int H, int W, int AH, int AW, hipStream_t stream);
-int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const int* pad, const float* dmask,
-                       unsigned long long seed, float p_drop, float* de, float* datt_up, float* datt, int B,
+                       unsigned long long seed, float p_drop, int shared_mask, float* out, float* part, int B,
                        int T, int C, int NH, int H, int W, int AH, int AW, hipStream_t stream);
+int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const int* pad, const float* dmask,
+                       unsigned long long seed, float p_drop, int shared_mask, float* de, float* datt_up,
+                       float* datt, int B, int T, int C, int NH, int H, int W, int AH, int AW,
+                       hipStream_t stream);
 
 /* ---- MGNLL loss (losses.py:131-218) and ensemble combine (ensemble_reconstruct.py:116-133) ---- */
 int uncr_mgnll_blocks(int P);

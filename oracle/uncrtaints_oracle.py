@@ -55,6 +55,8 @@ class OracleConfig:
     T_period: int = 1000          # ltae.py:152
     att_down: int = 32            # uncrtaints.py:403 (hard-coded)
     attn_dropout: float = 0.1     # uncrtaints.py:154
+    separate_out: bool = False    # uncrtaints.py:376-379
+    is_mono: bool = False         # uncrtaints.py:322,418
 
     @property
     def covar_dim(self) -> int:   # uncrtaints.py:357-365
@@ -228,6 +230,13 @@ def temporal_aggregate(x: Tensor, pad_mask: Tensor, attn: Tensor, cfg: OracleCon
     [nh*B,T,H,W], values in {0, 1/(1-p)}) replaces the stochastic nn.Dropout in train mode."""
     nh, B, T, h, w = attn.shape
     H, W = x.shape[-2:]
+    if cfg.agg_mode == "mean":              # uncrtaints.py:189-192, 220-221
+        keep = (~pad_mask).float()
+        out = (x * keep[:, :, None, None, None]).sum(dim=1)
+        return out / keep.sum(dim=1)[:, None, None, None]
+    if cfg.agg_mode == "att_mean":          # uncrtaints.py:179-188, 211-219: one head-averaged map for all channels
+        attn = attn.mean(dim=0, keepdim=True)
+        nh = 1
     a = attn.reshape(nh * B, T, h, w)
     if H > w:
         a = F.interpolate(a, size=(H, W), mode="bilinear", align_corners=False)
@@ -242,7 +251,7 @@ def temporal_aggregate(x: Tensor, pad_mask: Tensor, attn: Tensor, cfg: OracleCon
     if bool(pad_mask.any()):
         a = a * (~pad_mask).float()[None, :, :, None, None]
     C = x.shape[2]
-    xg = x.view(B, T, nh, C // nh, H, W)                                  # channel c -> head c // (C/nh)
+    xg = x.reshape(B, T, nh, C // nh, H, W)                               # channel c -> head c // (C/nh)
     out = torch.einsum("hbtyx,bthcyx->bhcyx", a, xg)
     return out.reshape(B, C, H, W)
 
@@ -258,9 +267,12 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
     a0 = torch.relu(group_norm(c0, 4, p["in_conv.conv.conv.1.weight"], p["in_conv.conv.conv.1.bias"]))
     e = mbconv(a0, p, "in_block.0", cfg.encoder_norm, training, update_running, taps)
     C = e.shape[1]
-    down = F.adaptive_max_pool2d(e, (cfg.att_down, cfg.att_down)).view(B, T, C, cfg.att_down, cfg.att_down)
-    attn = ltae_tiny_attention(down, dates, pad_mask, p, cfg)
-    g = temporal_aggregate(e.view(B, T, C, H, W), pad_mask, attn, cfg, training, dropout_mask)
+    if cfg.is_mono:
+        g, down, attn = e.view(B, T, C, H, W).squeeze(dim=1), None, None
+    else:
+        down = F.adaptive_max_pool2d(e, (cfg.att_down, cfg.att_down)).view(B, T, C, cfg.att_down, cfg.att_down)
+        attn = ltae_tiny_attention(down, dates, pad_mask, p, cfg)
+        g = temporal_aggregate(e.view(B, T, C, H, W), pad_mask, attn, cfg, training, dropout_mask)
     if taps is not None:
         taps.update(c0=c0, a0=a0, e=e, down=down, attn=attn, agg=g)
     out = g
@@ -268,7 +280,14 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
         out = mbconv(out, p, f"out_block.{i}", cfg.decoder_norm, training, update_running, taps)
         if taps is not None:
             taps[f"dec{i}"] = out
-    o = conv1x1(out, p["out_conv.conv.conv.0.weight"], p["out_conv.conv.conv.0.bias"]).unsqueeze(1)
+    if cfg.separate_out:
+        o = conv1x1(out, p["out_conv_mean_1.conv.conv.0.weight"], p["out_conv_mean_1.conv.conv.0.bias"])
+        if "out_conv_var_1.conv.conv.0.weight" in p:
+            o = torch.cat((o, conv1x1(out, p["out_conv_var_1.conv.conv.0.weight"],
+                                      p["out_conv_var_1.conv.conv.0.bias"])), dim=1)
+        o = o.unsqueeze(1)
+    else:
+        o = conv1x1(out, p["out_conv.conv.conv.0.weight"], p["out_conv.conv.conv.0.bias"]).unsqueeze(1)
     if taps is not None:
         taps["pre_head"] = o
     mean = o[:, :, :cfg.mean_idx]

@@ -240,12 +240,70 @@ def case_trainseq():
     print("g6_trainseq", ls)
 
 
+VARIANTS = {
+    "att_mean": dict(agg_mode="att_mean"),
+    "mean": dict(agg_mode="mean"),
+    "separate_out": dict(separate_out=True),
+    "is_mono": dict(is_mono=True, n_head=1),
+}
+
+
+def variant_state(state, name):
+    """Derive a variant's state_dict from the g1_diag_t3 weights (same rule in tests/test_variants.py)."""
+    st = dict(state)
+    if name == "separate_out":
+        w, b = st.pop("out_conv.conv.conv.0.weight"), st.pop("out_conv.conv.conv.0.bias")
+        st["out_conv_mean_1.conv.conv.0.weight"], st["out_conv_mean_1.conv.conv.0.bias"] = w[:13].clone(), b[:13].clone()
+        st["out_conv_var_1.conv.conv.0.weight"], st["out_conv_var_1.conv.conv.0.bias"] = w[13:].clone(), b[13:].clone()
+    if name == "is_mono":
+        st = {k: v for k, v in st.items() if not k.startswith("temporal_encoder")}
+    return st
+
+
+def case_variants():
+    """G2: secondary variants of the UNCRTAINTS class; weights come from g1_diag_t3."""
+    base = np.load(os.path.join(HERE, "g1_diag_t3.npz"))
+    state = {k[len("state/"):]: torch.from_numpy(base[k]) for k in base.files if k.startswith("state/")}
+    x, y, dates = (torch.from_numpy(base[k]) for k in ("x", "y", "dates"))
+    out = {}
+    for name, kw in VARIANTS.items():
+        torch.manual_seed(0)
+        m = uncrtaints.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus",
+                                  covmode="diag", scale_by=1.0, **kw)
+        m.load_state_dict(variant_state(state, name), strict=True)
+        if hasattr(m, "temporal_aggregator"):
+            m.temporal_aggregator.attn_dropout.p = 0.0
+        xin = x[:, :1] if name == "is_mono" else x
+        din = dates[:, :1] if name == "is_mono" else dates
+        if name == "mean":
+            xin = xin.clone(); xin[1, 0] = 0.0           # a padded date exercises the masked mean
+        m.eval()
+        with torch.no_grad():
+            oe = m(xin, batch_positions=din)
+        m.train()
+        ot = m(xin, batch_positions=din)
+        l, _ = crit("diag")(ot[:, :, :13], y, ot[:, :, 13:26])
+        l.backward()
+        out[f"{name}/eval_slice"] = oe[:, 0, :, ::8, ::8].numpy()
+        out[f"{name}/eval_checksum"] = checksum(oe.numpy())
+        out[f"{name}/train_slice"] = ot.detach()[:, 0, :, ::8, ::8].numpy()
+        out[f"{name}/train_loss"] = np.array(l.item())
+        for k, v in m.named_parameters():
+            if v.grad is not None:
+                out[f"{name}/gradsum/{k}"] = checksum(v.grad.numpy())
+        print("variant", name, "train loss", l.item())
+    np.savez_compressed(os.path.join(HERE, "g2_variants.npz"), **out)
+
+
 if __name__ == "__main__":
   if "--skip-model" not in sys.argv:
     case_model("g1_diag_t3", "diag", 2, 3, 64, 64, seed=1, full_grads=True)
     case_model("g1_diag_t3_pad", "diag", 2, 3, 64, 64, seed=1, full_grads=False, pad_last=True, save_state=False, taps=False)
     case_model("g1_iso_t6", "iso", 1, 6, 64, 64, seed=2, full_grads=False)
+  if "--only-variants" in sys.argv:
+    case_variants(); sys.exit(0)
   if "--only-trainseq" not in sys.argv:
+    case_variants()
     case_mgnll()
     case_posenc()
     case_ensemble()

@@ -23,6 +23,7 @@ struct AggArgs {
     float2* part;          // fwd: [B*C][NP] or null
     unsigned long long seed;
     float p_drop;          // > 0 with dmask == null: hash dropout
+    int shared_mask;       // 1: one dropout mask per (b,t,pixel) shared by all heads ('att_mean' mode)
     int B, T, C, NH, H, W, AH, AW;
 };
 
@@ -46,6 +47,7 @@ __device__ __forceinline__ Bilin bilin_src(int dst, float scale, int in_size) {
 __device__ __forceinline__ float agg_keep(const AggArgs& g, int h, int b, int t, size_t p) {
     float m = 1.f;
     const size_t P = (size_t)g.H * g.W;
+    if (g.shared_mask) h = 0;
     if (g.dmask) m = g.dmask[(((size_t)h * g.B + b) * g.T + t) * P + p];
     else if (g.p_drop > 0.f) {
         const float u = hash_uniform(g.seed, (((size_t)h * g.B + b) * g.T + t) * P + p);
@@ -193,11 +195,11 @@ static int agg_check(int B, int T, int C, int NH, int H, int W, int AH, int AW) 
 }
 
 extern "C" int uncr_aggregate_fwd(const float* e, const float* att, const int* pad, const float* dmask,
-                                  unsigned long long seed, float p_drop, float* out, float* part, int B, int T,
-                                  int C, int NH, int H, int W, int AH, int AW, hipStream_t stream) {
+                                  unsigned long long seed, float p_drop, int shared_mask, float* out, float* part,
+                                  int B, int T, int C, int NH, int H, int W, int AH, int AW, hipStream_t stream) {
     const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
     if (rc) return rc;
-    AggArgs g{e, att, pad, dmask, out, nullptr, nullptr, nullptr, (float2*)part, seed, p_drop, B, T, C, NH, H, W, AH, AW};
+    AggArgs g{e, att, pad, dmask, out, nullptr, nullptr, nullptr, (float2*)part, seed, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
     const dim3 grid(H * W / AGG_PX, B, NH % 4 == 0 ? 4 : 1);
     switch (C / NH) {
         case 4: hipLaunchKernelGGL((aggregate_kernel<false, 4>), grid, dim3(256), 0, stream, g); break;
@@ -209,12 +211,12 @@ extern "C" int uncr_aggregate_fwd(const float* e, const float* att, const int* p
 }
 
 extern "C" int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const int* pad,
-                                  const float* dmask, unsigned long long seed, float p_drop, float* de,
-                                  float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int AH,
-                                  int AW, hipStream_t stream) {
+                                  const float* dmask, unsigned long long seed, float p_drop, int shared_mask,
+                                  float* de, float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W,
+                                  int AH, int AW, hipStream_t stream) {
     const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
     if (rc) return rc;
-    AggArgs g{e, att, pad, dmask, nullptr, dg, de, datt_up, nullptr, seed, p_drop, B, T, C, NH, H, W, AH, AW};
+    AggArgs g{e, att, pad, dmask, nullptr, dg, de, datt_up, nullptr, seed, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
     const dim3 grid(H * W / AGG_PX, B, NH % 4 == 0 ? 4 : 1);
     switch (C / NH) {
         case 4: hipLaunchKernelGGL((aggregate_kernel<true, 4>), grid, dim3(256), 0, stream, g); break;

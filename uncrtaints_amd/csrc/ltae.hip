@@ -333,6 +333,45 @@ extern "C" int uncr_ltae_gn_bwd(const float* dy, const float* x, const float* ga
     return UNCR_OK;
 }
 
+// dst[r][i] = scale * src[i] for r < R   (head broadcast of the averaged attention / its gradient)
+__global__ __launch_bounds__(256) void bcast_scale_kernel(const float* __restrict__ src, int R, long long n,
+                                                          float scale, float* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = scale * src[i];
+    for (int r = 0; r < R; ++r) dst[(size_t)r * n + i] = v;
+}
+
+// 'mean' aggregation (uncrtaints.py:189-192,220-221): weight[h,b,t,s] = (1 - pad[b,t]) / #non-padded dates of b
+__global__ __launch_bounds__(256) void mean_weights_kernel(const int* __restrict__ pad, int NH, int B, int T, int S,
+                                                           float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)NH * B * T * S;
+    if (i >= n) return;
+    const int t = (int)((i / S) % T), b = (int)((i / ((long long)S * T)) % B);
+    int cnt = 0;
+    for (int tt = 0; tt < T; ++tt) cnt += (pad && pad[b * T + tt]) ? 0 : 1;
+    const bool p = pad && pad[b * T + t];
+    out[i] = (p || cnt == 0) ? 0.f : 1.f / (float)cnt;
+}
+
+extern "C" int uncr_bcast_scale(const float* src, int R, long long n, float scale, float* dst, hipStream_t stream) {
+    if (R <= 0 || n <= 0) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(bcast_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, R, n, scale,
+                       dst);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_mean_weights(const int* pad, int NH, int B, int T, int S, float* out, hipStream_t stream) {
+    if (NH <= 0 || B <= 0 || T <= 0 || S <= 0) return UNCR_ESHAPE;
+    const long long n = (long long)NH * B * T * S;
+    hipLaunchKernelGGL(mean_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pad, NH, B, T, S,
+                       out);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
 extern "C" int uncr_colsum(const float* part, int R, int K, float* out, hipStream_t stream) {
     if (R <= 0 || K <= 0) return UNCR_ESHAPE;
     hipLaunchKernelGGL(colsum_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, part, R, K, out);

@@ -442,7 +442,7 @@ def ltae_attention_backward(datt: Tensor, sv: dict, p: Dict[str, Tensor], n_head
 
 
 def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: bool, p_drop: float, seed: int,
-                      dmask: Optional[Tensor] = None, want_stats: bool = True):
+                      dmask: Optional[Tensor] = None, want_stats: bool = True, shared_mask: bool = False):
     """Compact_Temporal_Aggregator 'att_group' (uncrtaints.py:156-221): e [B,T,C,H,W], att [nh,B,T,ah,aw]."""
     B, T, C, H, W = e.shape
     n_head, _, _, ah, aw = att.shape
@@ -459,9 +459,10 @@ def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: b
         gpart = Part(_f32((B * C, slots, 2), dev), slots)
     use_mask = dmask if training else None
     pd = float(p_drop) if (training and dmask is None) else 0.0
-    hb.call("uncr_aggregate_fwd", e, att, pad, use_mask, seed, pd, g, gpart.buf if gpart else None, B, T, C, n_head,
-            H, W, ah, aw, _stream())
-    saved = dict(e=e, att=att, pad=pad, dmask=use_mask, pd=pd, seed=seed, dims=(B, T, C, H, W, n_head, ah, aw))
+    hb.call("uncr_aggregate_fwd", e, att, pad, use_mask, seed, pd, 1 if shared_mask else 0, g,
+            gpart.buf if gpart else None, B, T, C, n_head, H, W, ah, aw, _stream())
+    saved = dict(e=e, att=att, pad=pad, dmask=use_mask, pd=pd, seed=seed, shared=1 if shared_mask else 0,
+                 dims=(B, T, C, H, W, n_head, ah, aw))
     return g, saved, gpart
 
 
@@ -473,22 +474,69 @@ def aggregate_backward(dg: Tensor, sv: dict):
     datt_up = _f32((n_head, B, T, H * W), dev)
     datt = _f32((n_head, B, T, ah, aw), dev)
     hb.call("uncr_aggregate_bwd", dg.contiguous(), sv["e"], sv["att"], sv["pad"], sv["dmask"], sv["seed"], sv["pd"],
-            de, datt_up, datt, B, T, C, n_head, H, W, ah, aw, _stream())
+            sv["shared"], de, datt_up, datt, B, T, C, n_head, H, W, ah, aw, _stream())
     return de, datt
+
+
+def head_mean_attention(att: Tensor) -> Tensor:
+    """'att_mean' (uncrtaints.py:180,212): average the attention over heads, then give every head that average."""
+    NH = att.shape[0]
+    n = att[0].numel()
+    m = _f32(att.shape[1:], att.device)
+    scratch = _f32(att.shape[1:], att.device)
+    hb.call("uncr_ensemble_combine", att, None, NH, n, 2, m, scratch, _stream())      # mean over the leading axis
+    out = torch.empty_like(att)
+    hb.call("uncr_bcast_scale", m, NH, n, 1.0, out, _stream())
+    return out
+
+
+def head_mean_attention_backward(datt_e: Tensor) -> Tensor:
+    NH = datt_e.shape[0]
+    n = datt_e[0].numel()
+    s = _f32((n,), datt_e.device)
+    hb.call("uncr_colsum", datt_e.contiguous(), NH, n, s, _stream())
+    out = torch.empty_like(datt_e)
+    hb.call("uncr_bcast_scale", s, NH, n, 1.0 / NH, out, _stream())
+    return out
+
+
+def mean_mode_weights(pad: Optional[Tensor], n_head: int, B: int, T: int, ah: int, aw: int, dev) -> Tensor:
+    out = _f32((n_head, B, T, ah, aw), dev)
+    hb.call("uncr_mean_weights", pad, n_head, B, T, ah * aw, out, _stream())
+    return out
 
 
 def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor], p: Dict[str, Tensor],
                        denom: Optional[Tensor], n_head: int, d_k: int, att_down: int, training: bool, p_drop: float,
-                       seed: int, dmask: Optional[Tensor] = None, want_stats: bool = True):
-    """Fused stage used by UNCRTAINTS.forward: e [B,T,C,H,W] -> g [B,C,H,W] (+ stats partials of g)."""
+                       seed: int, dmask: Optional[Tensor] = None, want_stats: bool = True, mode: str = "att_group"):
+    """Fused stage used by UNCRTAINTS.forward: e [B,T,C,H,W] -> g [B,C,H,W] (+ stats partials of g).
+    mode: 'att_group' | 'att_mean' | 'mean' (uncrtaints.py:156-221)."""
     down, idx = maxpool_forward(e, att_down, att_down)
     att, sv_att = ltae_attention_forward(down, dates, pad, p, denom, n_head, d_k)
-    g, sv_agg, gpart = aggregate_forward(e, att, pad, training, p_drop, seed, dmask, want_stats)
-    return g, dict(att=sv_att, agg=sv_agg, idx=idx, att_down=att_down), gpart, att
+    B, T = e.shape[:2]
+    if mode == "att_group":
+        w_att, shared = att, False
+    elif mode == "att_mean":
+        w_att, shared = head_mean_attention(att), True
+    elif mode == "mean":
+        w_att, shared = mean_mode_weights(pad, n_head, B, T, att_down, att_down, e.device), False
+        p_drop = 0.0          # no dropout in this mode (uncrtaints.py:189-192)
+        dmask = None
+    else:
+        raise NotImplementedError(mode)
+    g, sv_agg, gpart = aggregate_forward(e, w_att, pad, training, p_drop, seed, dmask, want_stats, shared)
+    return g, dict(att=sv_att, agg=sv_agg, idx=idx, att_down=att_down, mode=mode), gpart, att
 
 
 def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int, d_k: int):
     de, datt = aggregate_backward(dg, sv["agg"])
+    mode = sv.get("mode", "att_group")
+    if mode == "mean":
+        # the attention does not reach the output: no gradient to the temporal encoder (returned as zeros)
+        g = {k: torch.zeros_like(v) for k, v in p.items()}
+        return de, g
+    if mode == "att_mean":
+        datt = head_mean_attention_backward(datt)
     ddown, g = ltae_attention_backward(datt, sv["att"], p, n_head, d_k)
     H, W = de.shape[-2:]
     maxpool_backward_into(ddown, sv["idx"], de, H, W, sv["att_down"], sv["att_down"])

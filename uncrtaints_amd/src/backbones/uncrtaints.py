@@ -140,15 +140,29 @@ class _AggregateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, att, pad, module, dmask):
         seed = module._next_seed()
-        g, sv, gpart = E.aggregate_forward(x.contiguous(), att.contiguous(), pad, module.training,
-                                           module.attn_dropout.p, seed, dmask)
-        ctx.sv = sv
+        mode = module.mode
+        x, att = x.contiguous(), att.contiguous()
+        B, T = x.shape[:2]
+        nh, ah, aw = att.shape[0], att.shape[-2], att.shape[-1]
+        p_drop, shared = module.attn_dropout.p, False
+        if mode == "att_mean":
+            w_att, shared = E.head_mean_attention(att), True
+        elif mode == "mean":
+            w_att, p_drop, dmask = E.mean_mode_weights(pad, nh, B, T, ah, aw, x.device), 0.0, None
+        else:
+            w_att = att
+        g, sv, gpart = E.aggregate_forward(x, w_att, pad, module.training, p_drop, seed, dmask, True, shared)
+        ctx.sv, ctx.mode = sv, mode
         g._uncr_part = gpart
         return g
 
     @staticmethod
     def backward(ctx, dg):
         de, datt = E.aggregate_backward(dg, ctx.sv)
+        if ctx.mode == "att_mean":
+            datt = E.head_mean_attention_backward(datt)
+        elif ctx.mode == "mean":
+            datt = None
         return de, datt, None, None, None
 
 
@@ -170,8 +184,8 @@ class Compact_Temporal_Aggregator(nn.Module):
         self._seed_base, self._calls = int(seed), 0
 
     def forward(self, x, pad_mask=None, attn_mask=None):
-        if self.mode != "att_group":
-            raise NotImplementedError(f"agg_mode '{self.mode}' is not built (att_group only; SURVEY 8(f))")
+        if self.mode not in ("att_group", "att_mean", "mean"):
+            raise NotImplementedError(f"agg_mode '{self.mode}'")
         pad = None
         if pad_mask is not None:
             pad = pad_mask if pad_mask.dtype == torch.int32 else pad_mask.to(torch.int32)
@@ -200,9 +214,10 @@ class _StageFn(torch.autograd.Function):
         te, agg = net.temporal_encoder, net.temporal_aggregator
         denom = te.positional_encoder.denom_on(e.device) if te.positional_encoder is not None else None
         want_stats = net.out_block[0]._spec.needs_stats(net.training)
+        net._last_pad = pad
         g, sv, gpart, att = E.ltae_stage_forward(e.contiguous(), dates, pad, p, denom, te.n_head,
                                                  te.attention_heads.d_k, 32, net.training, agg.attn_dropout.p,
-                                                 agg._next_seed(), dmask, want_stats)
+                                                 agg._next_seed(), dmask, want_stats, mode=agg.mode)
         ctx.sv, ctx.p, ctx.te = sv, p, te
         net._last_attention = att
         g._uncr_part = gpart
@@ -277,8 +292,10 @@ class UNCRTAINTS(nn.Module):
             decoder_widths = encoder_widths
         if block_type != 'mbconv':
             raise NotImplementedError("block_type='residual' is not built (SURVEY 8(f) rank 2)")
-        if use_v or separate_out or is_mono:
-            raise NotImplementedError("use_v / separate_out / is_mono variants are not built (SURVEY 8(f) rank 2)")
+        if use_v:
+            raise NotImplementedError("use_v (LTAE2d with values) is not built (SURVEY 8(f) rank 2)")
+        if agg_mode not in ("att_group", "att_mean", "mean"):
+            raise NotImplementedError(f"agg_mode '{agg_mode}'")
         if padding_mode != "reflect":
             raise NotImplementedError("only padding_mode='reflect' is built")
         if len(encoder_widths) != 1:
@@ -287,9 +304,10 @@ class UNCRTAINTS(nn.Module):
         self.in_conv = ConvBlock(nkernels=[input_dim] + [encoder_widths[0]], k=1, s=1, p=0, norm=encoder_norm)
         self.in_block = nn.ModuleList([MBConv(layer, layer, downsample=False, expansion=2, norm=encoder_norm)
                                        for layer in encoder_widths])
-        self.temporal_encoder = LTAE2dtiny(in_channels=encoder_widths[0], d_model=d_model, n_head=n_head, d_k=d_k,
-                                           positional_encoding=positional_encoding)
-        self.temporal_aggregator = Compact_Temporal_Aggregator(mode=agg_mode)
+        if not self.is_mono:     # uncrtaints.py:322-348
+            self.temporal_encoder = LTAE2dtiny(in_channels=encoder_widths[0], d_model=d_model, n_head=n_head, d_k=d_k,
+                                               positional_encoding=positional_encoding)
+            self.temporal_aggregator = Compact_Temporal_Aggregator(mode=agg_mode)
         self.out_block = nn.ModuleList([MBConv(layer, layer, downsample=False, expansion=2, norm=decoder_norm)
                                         for layer in decoder_widths])
 
@@ -308,7 +326,15 @@ class UNCRTAINTS(nn.Module):
         eps = 1e-9 if self.scale_by == 1.0 else 1e-3
         self._eps = eps
         self._mean_sigmoid = bool(out_nonlin_mean)
-        self.out_conv = ConvBlock(nkernels=[decoder_widths[0]] + out_conv, k=1, s=1, p=0, norm='none', last_relu=False)
+        if self.separate_out:    # two 1x1 streams for mean and variance (uncrtaints.py:376-379)
+            self.out_conv_mean_1 = ConvBlock(nkernels=[decoder_widths[0]] + [S2_BANDS], k=1, s=1, p=0, norm='none',
+                                             last_relu=False)
+            if self.out_dims - self.mean_idx > 0:
+                self.out_conv_var_1 = ConvBlock(nkernels=[decoder_widths[0]] + [self.out_dims - S2_BANDS], k=1, s=1,
+                                                p=0, norm='none', last_relu=False)
+        else:
+            self.out_conv = ConvBlock(nkernels=[decoder_widths[0]] + out_conv, k=1, s=1, p=0, norm='none',
+                                      last_relu=False)
 
         if out_nonlin_mean:
             self.out_mean = lambda vars: self.scale_by * nn.Sigmoid()(vars)
@@ -330,8 +356,6 @@ class UNCRTAINTS(nn.Module):
             raise RuntimeError("uncrtaints_amd.UNCRTAINTS runs on the GPU only (HIP kernels); move the model and "
                                "the inputs to the cuda device")
         input = input.contiguous().float()
-        if self.temporal_aggregator.mode != "att_group":
-            raise NotImplementedError("only agg_mode='att_group' is built")
         pad = E.pad_mask_of(input, float(self.pad_value))                  # [B,T] int32, uncrtaints.py:392-394
         out = self.in_conv.smart_forward(input)                            # [B,T,C,H,W]
         part = None
@@ -345,19 +369,37 @@ class UNCRTAINTS(nn.Module):
             y4 = layer(x4)
             part = getattr(y4, "_uncr_part", None)
             out = y4.view(b, t, c, h, w)
-        if self.temporal_encoder.positional_encoder is not None and batch_positions is None:
-            raise ValueError("batch_positions (dates) are required when positional_encoding=True")
-        p = _ltae_params(self.temporal_encoder)
-        out = _StageFn.apply(out, batch_positions, pad, self, self.temporal_aggregator.dropout_mask,
-                             *[p[k] for k in _LTAE_KEYS])
+        if not self.is_mono:
+            if self.temporal_encoder.positional_encoder is not None and batch_positions is None:
+                raise ValueError("batch_positions (dates) are required when positional_encoding=True")
+            p = _ltae_params(self.temporal_encoder)
+            out = _StageFn.apply(out, batch_positions, pad, self, self.temporal_aggregator.dropout_mask,
+                                 *[p[k] for k in _LTAE_KEYS])
+        else:                                                              # uncrtaints.py:418
+            if out.shape[1] != 1:
+                raise ValueError("is_mono expects a single input date (T == 1)")
+            part = getattr(out, "_uncr_part", None) or part
+            out = out.squeeze(dim=1)
+            if part is not None:
+                out._uncr_part = part
         for layer in self.out_block:
             out = layer.smart_forward(out)
-        conv = self.out_conv.conv.conv[0]
+        if self.separate_out:
+            # two 1x1 convolutions on the same input == one convolution with concatenated kernels
+            cm = self.out_conv_mean_1.conv.conv[0]
+            if self.out_dims - self.mean_idx > 0:
+                cv = self.out_conv_var_1.conv.conv[0]
+                w_all, b_all = torch.cat((cm.weight, cv.weight), dim=0), torch.cat((cm.bias, cv.bias), dim=0)
+            else:
+                w_all, b_all = cm.weight, cm.bias
+        else:
+            conv = self.out_conv.conv.conv[0]
+            w_all, b_all = conv.weight, conv.bias
         if not self.covmode:
             # mean only: plain conv + mean nonlinearity on all out_dims channels
-            o = _HeadFnMeanOnly.apply(out, conv.weight, conv.bias, self)
+            o = _HeadFnMeanOnly.apply(out, w_all, b_all, self)
             return o.unsqueeze(1)[:, :, :self.mean_idx, ...]
-        o = _HeadFn.apply(out, conv.weight, conv.bias, self)               # [B, out_dims, H, W]
+        o = _HeadFn.apply(out, w_all, b_all, self)                         # [B, out_dims, H, W]
         o = o.unsqueeze(1)
         if self.out_dims != self.vars_idx:
             o = o[:, :, :self.vars_idx, ...]
