@@ -108,3 +108,31 @@ def test_hip_variants(name):
         if is_zero_grad(k, g64):
             continue
         close_vs_truth(f"{name}/grad[{k}]", v.grad, g32[k], g64[k])
+
+
+@pytest.mark.gpu
+def test_iso_ensemble_inference_config5():
+    """BASELINE config 5: five iso members, inference only, mixture-moment combine
+    (ensemble_reconstruct.py:116-133) -- HIP members + HIP combine against the oracle."""
+    from gpu_util import close, dev
+    from uncrtaints_amd import engine as E
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    cfg = orc.OracleConfig(covmode="iso", out_conv=[14])
+    x, _, dates = orc.synthetic_batch(1, 3, 64, 64, seed=4)
+    mus, vs, mus_o, vs_o = [], [], [], []
+    for member in range(5):
+        p = orc.init_params(cfg, seed=10 + member)
+        with torch.no_grad():
+            o = orc.forward({k: v.clone() for k, v in p.items()}, x, dates, cfg, training=False)
+        mus_o.append(o[:, 0, :13]); vs_o.append(o[:, 0, 13:14].expand(-1, 13, -1, -1))
+        m = U.UNCRTAINTS(input_dim=15, out_conv=[14], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="iso")
+        m.load_state_dict(p, strict=True)
+        m = m.to("cuda").eval()
+        with torch.no_grad():
+            out = m(dev(x), batch_positions=dev(dates))
+        close(f"member{member}", out, o)
+        mus.append(out[:, 0, :13].contiguous()); vs.append(out[:, 0, 13:14].expand(-1, 13, -1, -1).contiguous())
+    mu_e, var_e = E.ensemble_combine(torch.stack(mus), torch.stack(vs), "both")
+    mu_o, var_o = orc.ensemble_combine(torch.stack(mus_o), torch.stack(vs_o), "both")
+    close("ensemble_mean", mu_e, mu_o)
+    close("ensemble_var", var_e, var_o, tol=2e-4)
