@@ -1,0 +1,93 @@
+"""-m gpu: the bucketed data-parallel wrapper around the REAL HIP model, two ranks on the one available GPU
+(gloo backend: RCCL rejects two ranks on one device).  Contract of SURVEY 8(e): every rank ends up with the
+rank-average of the per-shard gradients (BatchNorm statistics and the batch-summed log-det are per replica)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+B, T, H = 1, 3, 64
+
+
+def _model():
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    from uncrtaints_amd.src.learning.weight_init import weight_init
+    torch.manual_seed(3)
+    m = U.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag")
+    m.apply(weight_init)
+    m.temporal_aggregator.attn_dropout.p = 0.0
+    return m.to("cuda").train()
+
+
+def _shard(rank):
+    g = torch.Generator().manual_seed(50 + rank)
+    x = torch.rand(B, T, 15, H, H, generator=g).cuda()
+    y = torch.rand(B, 1, 13, H, H, generator=g).cuda()
+    d = torch.sort(torch.randint(1400, 1800, (B, T), generator=g), dim=1).values.float().cuda()
+    return x, y, d
+
+
+def _grads(m, rank):
+    from uncrtaints_amd.src import losses
+    x, y, d = _shard(rank)
+    out = m(x, batch_positions=d)
+    l, _ = losses.MultiGaussianNLLLoss(reduction="mean", full=True, mode="diag")(out[:, :, :13], y, out[:, :, 13:26])
+    l.backward()
+    return l
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uncrtaints_amd.parallel import BucketedDataParallel
+    m = _model()
+    dp = BucketedDataParallel(m, seed=1)
+    for _ in range(2):
+        dp.zero_grad()
+        _grads(m, rank)
+        dp.finish()
+    torch.cuda.synchronize()
+    q.put((rank, {n: p.grad.detach().cpu().numpy() for n, p in m.named_parameters()}))   # by value (numpy)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_two_ranks_average_shard_gradients():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    res = {r: {n: torch.from_numpy(a) for n, a in d.items()} for r, d in res.items()}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single-process reference: the two shards one after the other on identical initial weights
+    ref = None
+    for rank in range(world):
+        m = _model()
+        # BN running stats advance per step in the workers too, but gradients do not depend on them in train mode
+        _grads(m, rank)
+        g = {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
+        ref = g if ref is None else {n: ref[n] + g[n] for n in g}
+    ref = {n: v / world for n, v in ref.items()}
+    worst = 0.0
+    for n in ref:
+        assert torch.allclose(res[0][n], res[1][n], rtol=0, atol=0), n      # identical on every rank
+        scale = ref[n].abs().max().item()
+        if scale == 0:
+            continue
+        worst = max(worst, (res[0][n] - ref[n]).abs().max().item() / scale)
+    print(f"[parity] ddp 2 ranks vs sequential shards: worst rel err {worst:.3e}")
+    assert worst < 1e-4
