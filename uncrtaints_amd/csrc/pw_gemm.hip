@@ -75,39 +75,34 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
     float4 pre[NL], pre2[PRE2 ? NL : 1];
     auto load_piece = [&](int i, int kc) {
         const int k = kc * KC + lrow + i * ROWS_PER_I;
-        if (k < Cin) {
-            pre[i] = *(const float4*)(inb + (size_t)k * P);
-            if constexpr (PRE2) {
-                if (pro == PRO_NORMBWD) pre2[i] = *(const float4*)(in2b + (size_t)k * P);
-            }
-        } else {
-            pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const int kk = k < Cin ? k : 0;                   // out-of-range rows re-read row 0 and are zeroed at staging
+        pre[i] = *(const float4*)(inb + (size_t)kk * P);
+        if constexpr (PRE2) pre2[i] = *(const float4*)((pro == PRO_NORMBWD ? in2b : inb) + (size_t)kk * P);
     };
     auto stage_piece = [&](int i, int kc, int buf) {
         const int r = lrow + i * ROWS_PER_I;
         const int k = kc * KC + r;
+        const int kk = k < Cin ? k : 0;
         float4 v = pre[i];
-        if (k < Cin) {
-            const float c0 = cf[0][k], c1 = cf[1][k], c2 = cf[2][k];
-            float* pv = (float*)&v;
-            if (pro == PRO_AFFINE) {
+        const float c0 = cf[0][kk], c1 = cf[1][kk], c2 = cf[2][kk];
+        float* pv = (float*)&v;
+        if (pro == PRO_AFFINE) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], c1);
-            } else if (pro == PRO_AFFINE_GELU) {
+            for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], c1);
+        } else if (pro == PRO_AFFINE_GELU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pv[j] = c2 * gelu_f(fmaf(c0, pv[j], c1));
-            } else if (pro == PRO_NORMBWD) {
-                if constexpr (PRE2) {
-                    const float* p2 = (const float*)&pre2[i];
+            for (int j = 0; j < 4; ++j) pv[j] = c2 * gelu_f(fmaf(c0, pv[j], c1));
+        } else if (pro == PRO_NORMBWD) {
+            if constexpr (PRE2) {
+                const float* p2 = (const float*)&pre2[i];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], fmaf(c1, p2[j], c2));
-                }
-            } else if (pro == PRO_AFFINE_RELU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pv[j] = fmaxf(fmaf(c0, pv[j], c1), 0.f);
+                for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], fmaf(c1, p2[j], c2));
             }
+        } else if (pro == PRO_AFFINE_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pv[j] = fmaxf(fmaf(c0, pv[j], c1), 0.f);
         }
+        if (k >= Cin) v = make_float4(0.f, 0.f, 0.f, 0.f);
         *(float4*)&xs[buf][r][4 * lc4] = v;
     };
 
@@ -130,16 +125,17 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
     __syncthreads();   // cf visible
 #pragma unroll
     for (int i = 0; i < NL; ++i) stage_piece(i, 0, 0);
-    if (nk > 1) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) load_piece(i, 1);
-    }
+    for (int i = 0; i < NL; ++i) load_piece(i, nk > 1 ? 1 : 0);
     __syncthreads();
 
     constexpr int SLOT = 16 / NL >= 1 ? 16 / NL : 1;   // MFMA k-steps between two staging pieces
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
-        const bool has1 = kc + 1 < nk, has2 = kc + 2 < nk;
+        // successors are clamped instead of branched on: memory operations under (even uniform) branches make the
+        // compiler lose count of the outstanding loads and fall back to s_waitcnt vmcnt(0), which drains the
+        // just-issued HBM prefetch at every staging slot.  The redundant work at the tail is harmless.
+        const int k1 = kc + 1 < nk ? kc + 1 : nk - 1, k2 = kc + 2 < nk ? kc + 2 : nk - 1;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const float4 b = *(const float4*)&xs[cur][2 * s + (lane >> 5)][wm * 128 + 4 * (lane & 31)];
@@ -149,18 +145,15 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     acc[e][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s][ct], pb[e], acc[e][ct], 0, 0, 0);
-            if (has1) {
-                // rolling A prefetch into the registers this k-step has just consumed
+            // rolling A prefetch into the registers this k-step has just consumed
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    afr[s][ct] = wbase[(size_t)((kc + 1) * KC + 2 * s) * COUTP + ct * 32];
-                // one staging piece of the next chunk every SLOT k-steps (NL pieces per chunk)
-                if constexpr (NL <= 16) {
-                    if (s % SLOT == SLOT - 1 && s / SLOT < NL) {
-                        const int i = s / SLOT;
-                        stage_piece(i, kc + 1, cur ^ 1);
-                        if (has2) load_piece(i, kc + 2);
-                    }
+            for (int ct = 0; ct < CT; ++ct) afr[s][ct] = wbase[(size_t)(k1 * KC + 2 * s) * COUTP + ct * 32];
+            // one staging piece of the next chunk every SLOT k-steps (NL pieces per chunk)
+            if constexpr (NL <= 16) {
+                if (s % SLOT == SLOT - 1 && s / SLOT < NL) {
+                    const int i = s / SLOT;
+                    stage_piece(i, k1, cur ^ 1);
+                    load_piece(i, k2);
                 }
             }
         }
