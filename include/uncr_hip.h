@@ -131,12 +131,13 @@ int uncr_ltae_softmax_bwd(const float* datt, const float* att, const float* k, c
  *      uncrtaints.py:156-221: bilinear up-sample + dropout + pad mask + V-aggregate) ---- */
 int uncr_agg_slots(int P);
 int uncr_aggregate_fwd(const float* e, const float* att, const int* pad, const float* dmask,
-                       unsigned long long seed, float p_drop, int shared_mask, float* out, float* part, int B,
-                       int T, int C, int NH, int H, int W, int AH, int AW, hipStream_t stream);
-int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const int* pad, const float* dmask,
-                       unsigned long long seed, float p_drop, int shared_mask, float* de, float* datt_up,
-                       float* datt, int B, int T, int C, int NH, int H, int W, int AH, int AW,
+                       unsigned long long seed, const long long* seed_dev, float p_drop, int shared_mask,
+                       float* out, float* part, int B, int T, int C, int NH, int H, int W, int AH, int AW,
                        hipStream_t stream);
+int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const int* pad, const float* dmask,
+                       unsigned long long seed, const long long* seed_dev, float p_drop, int shared_mask,
+                       float* de, float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int AH,
+                       int AW, hipStream_t stream);
 
 /* ---- MGNLL loss (losses.py:131-218) and ensemble combine (ensemble_reconstruct.py:116-133) ---- */
 int uncr_mgnll_blocks(int P);

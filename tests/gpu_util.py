@@ -30,7 +30,13 @@ def rand(*shape, seed=0, scale=1.0, shift=0.0):
     return torch.randn(*shape, generator=g) * scale + shift
 
 
-def close_vs_truth(name, got, ref32, truth64, tol=TOL, slack=4.0, alt32=None):
+def close_vs_truth(name, got, ref32, truth64, tol=TOL, slack=4.0, alt32=None, kink_frac=0.0):
+    # kink_frac > 0: tensors downstream of the 8x8 max-pool (activation / input gradients).  A near-tie inside a
+    # pooling window can pick a different arg-max under a 1e-6 forward difference; the gradient then lands on the
+    # neighbouring pixel -- a kink of the function, not an arithmetic error (verified with tools/debug_argmax.py on
+    # g1_iso_t6: 2 of 786 432 cells have fp64 top-2 gaps of 3e-7 and flip on HIP and on CPU fp32 alike; one flipped
+    # cell perturbs ~1e-3 of a frame's input gradient through the 3x3 adjoint).  Those tensors pass if at most
+    # `kink_frac` of their elements deviate by more than `tol` (relative to the tensor's max).
     """fp32 parity with an fp64 tie-breaker: pass if `got` is within `tol` of the fp32 reference, or -- for
     ill-conditioned tensors where two fp32 evaluations legitimately differ by more than `tol` -- if it is no
     further from the fp64 ground truth than `slack` x the CPU fp32 reference's own distance from it."""
@@ -44,8 +50,13 @@ def close_vs_truth(name, got, ref32, truth64, tol=TOL, slack=4.0, alt32=None):
         alt32 = alt32.detach().double().cpu().numpy() if isinstance(alt32, torch.Tensor) else np.asarray(alt32)
         e_cpu = max(e_cpu, rel_err(alt32, truth64))
     print(f"[parity] {name}: vs fp32 ref {e_ref:.3e}; vs fp64 truth: hip {e_got:.3e}, cpu-fp32 {e_cpu:.3e}")
-    assert e_ref < tol or e_got <= slack * e_cpu + 1e-7, \
-        f"{name}: {e_ref:.3e} from the fp32 reference and {e_got:.3e} from fp64 truth (cpu fp32: {e_cpu:.3e})"
+    ok = e_ref < tol or e_got <= slack * e_cpu + 1e-7
+    if not ok and kink_frac > 0:
+        scale = max(float(np.abs(truth64).max()), 1e-30)
+        frac = float((np.abs(got - truth64) > tol * scale).mean())
+        print(f"[parity] {name}: fraction of elements beyond {tol:g}: {frac:.2e} (allowed {kink_frac:g})")
+        ok = frac <= kink_frac
+    assert ok, f"{name}: {e_ref:.3e} from the fp32 reference and {e_got:.3e} from fp64 truth (cpu fp32: {e_cpu:.3e})"
     return e_ref, e_got, e_cpu
 
 

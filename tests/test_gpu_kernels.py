@@ -307,6 +307,13 @@ def test_aggregate_hash_dropout_statistics(E):
     assert torch.equal(g, g2)              # same seed -> same mask (needed to recompute it in backward)
     g3, _, _ = E.aggregate_forward(dev(e), dev(att), None, True, 0.1, 100, None)
     assert not torch.equal(g, g3)
+    # device-resident step counter (HIP-graph replays): same host seed, different counter -> different mask
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    g4, sv4, _ = E.aggregate_forward(dev(e), dev(att), None, True, 0.1, (99, ctr), None)
+    assert torch.equal(g4, g)                                   # counter 0 == plain seed
+    ctr += 1
+    g5, _, _ = E.aggregate_forward(dev(e), dev(att), None, True, 0.1, (99, ctr), None)
+    assert not torch.equal(g5, g4) and abs(g5.mean().item() - 1.0) < 5e-3
 
 
 def test_maxpool(E):

@@ -62,14 +62,16 @@ def _golden_case(name, state_from=None):
     _, _, dx64, g64, _ = oracle_run(state, xc, yc, dc, cfg, torch.float64)
     _, _, dx32, g32, _ = oracle_run(state, xc, yc, dc, cfg, torch.float32)
     close_vs_truth(f"{name}/dx_b0t0", xg.grad[0, 0], torch.from_numpy(g["train/dx_b0t0"]), dx64[0, 0],
-                   alt32=dx32[0, 0])
+                   alt32=dx32[0, 0], kink_frac=3e-3)
     for k, v in m.named_parameters():
         if is_zero_grad(k, g64):
             sib = g64[k.replace(".bias", ".weight")].abs().max().item()
             assert v.grad.abs().max().item() < 1e-3 * sib, k
             continue
         ref32 = torch.from_numpy(g["grad/" + k]) if ("grad/" + k) in g.files else g32[k]
-        close_vs_truth(f"{name}/grad[{k}]", v.grad, ref32, g64[k], alt32=g32[k])
+        # parameters upstream of the 8x8 max-pool see the arg-max kink (see gpu_util.close_vs_truth): 5e-4 there
+        ktol = 5e-4 if k.startswith(("in_conv", "in_block")) else TOL
+        close_vs_truth(f"{name}/grad[{k}]", v.grad, ref32, g64[k], alt32=g32[k], tol=ktol)
         if ("gradsum/" + k) in g.files and ("grad/" + k) not in g.files:
             # the oracle-fp32 stand-in must itself agree with the reference's checksum
             assert abs(checksum(g32[k].numpy())[1] - g[("gradsum/" + k)][1]) < 2e-3 * abs(g["gradsum/" + k][1])
@@ -138,11 +140,12 @@ def test_vs_oracle_fresh_inputs(B, T, H, W):
     l.backward()
     close(f"fresh[{B},{T},{H}x{W}]/out", out, out_o)
     assert abs(l.item() - loss_o.item()) < 1e-4 * abs(loss_o.item())
-    close_vs_truth(f"fresh[{B},{T},{H}x{W}]/dx", xg.grad, dx32, dx64)
+    close_vs_truth(f"fresh[{B},{T},{H}x{W}]/dx", xg.grad, dx32, dx64, kink_frac=3e-3)
     for k, v in m.named_parameters():
         if is_zero_grad(k, g64):
             continue
-        close_vs_truth(f"fresh[{B},{T},{H}x{W}]/grad[{k}]", v.grad, g32[k], g64[k])
+        ktol = 5e-4 if k.startswith(("in_conv", "in_block")) else TOL
+        close_vs_truth(f"fresh[{B},{T},{H}x{W}]/grad[{k}]", v.grad, g32[k], g64[k], tol=ktol)
     # size-independent properties: attention is a distribution over T; variances positive; mean in [0,1]
     att = m._last_attention
     assert torch.allclose(att.sum(dim=2), torch.ones_like(att.sum(dim=2)), atol=1e-5)

@@ -22,6 +22,7 @@ struct AggArgs {
     float* datt_up;        // bwd: [NH][B][T][P]
     float2* part;          // fwd: [B*C][NP] or null
     unsigned long long seed;
+    const long long* seed_dev;   // optional device-resident step counter added to `seed` (HIP-graph replays)
     float p_drop;          // > 0 with dmask == null: hash dropout
     int shared_mask;       // 1: one dropout mask per (b,t,pixel) shared by all heads ('att_mean' mode)
     int B, T, C, NH, H, W, AH, AW;
@@ -50,7 +51,8 @@ __device__ __forceinline__ float agg_keep(const AggArgs& g, int h, int b, int t,
     if (g.shared_mask) h = 0;
     if (g.dmask) m = g.dmask[(((size_t)h * g.B + b) * g.T + t) * P + p];
     else if (g.p_drop > 0.f) {
-        const float u = hash_uniform(g.seed, (((size_t)h * g.B + b) * g.T + t) * P + p);
+        const unsigned long long sd = g.seed + (g.seed_dev ? (unsigned long long)g.seed_dev[0] * 0x9E3779B97F4A7C15ull : 0ull);
+        const float u = hash_uniform(sd, (((size_t)h * g.B + b) * g.T + t) * P + p);
         m = u < g.p_drop ? 0.f : 1.f / (1.f - g.p_drop);
     }
     if (g.pad && g.pad[b * g.T + t]) m = 0.f;   // attn * (~pad_mask), uncrtaints.py:172
@@ -195,11 +197,12 @@ static int agg_check(int B, int T, int C, int NH, int H, int W, int AH, int AW) 
 }
 
 extern "C" int uncr_aggregate_fwd(const float* e, const float* att, const int* pad, const float* dmask,
-                                  unsigned long long seed, float p_drop, int shared_mask, float* out, float* part,
-                                  int B, int T, int C, int NH, int H, int W, int AH, int AW, hipStream_t stream) {
+                                  unsigned long long seed, const long long* seed_dev, float p_drop, int shared_mask,
+                                  float* out, float* part, int B, int T, int C, int NH, int H, int W, int AH, int AW,
+                                  hipStream_t stream) {
     const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
     if (rc) return rc;
-    AggArgs g{e, att, pad, dmask, out, nullptr, nullptr, nullptr, (float2*)part, seed, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
+    AggArgs g{e, att, pad, dmask, out, nullptr, nullptr, nullptr, (float2*)part, seed, seed_dev, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
     const dim3 grid(H * W / AGG_PX, B, NH % 4 == 0 ? 4 : 1);
     switch (C / NH) {
         case 4: hipLaunchKernelGGL((aggregate_kernel<false, 4>), grid, dim3(256), 0, stream, g); break;
@@ -211,12 +214,12 @@ extern "C" int uncr_aggregate_fwd(const float* e, const float* att, const int* p
 }
 
 extern "C" int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const int* pad,
-                                  const float* dmask, unsigned long long seed, float p_drop, int shared_mask,
-                                  float* de, float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W,
-                                  int AH, int AW, hipStream_t stream) {
+                                  const float* dmask, unsigned long long seed, const long long* seed_dev,
+                                  float p_drop, int shared_mask, float* de, float* datt_up, float* datt, int B, int T,
+                                  int C, int NH, int H, int W, int AH, int AW, hipStream_t stream) {
     const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
     if (rc) return rc;
-    AggArgs g{e, att, pad, dmask, nullptr, dg, de, datt_up, nullptr, seed, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
+    AggArgs g{e, att, pad, dmask, nullptr, dg, de, datt_up, nullptr, seed, seed_dev, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
     const dim3 grid(H * W / AGG_PX, B, NH % 4 == 0 ? 4 : 1);
     switch (C / NH) {
         case 4: hipLaunchKernelGGL((aggregate_kernel<true, 4>), grid, dim3(256), 0, stream, g); break;

@@ -441,8 +441,10 @@ def ltae_attention_backward(datt: Tensor, sv: dict, p: Dict[str, Tensor], n_head
     return ddown, g
 
 
-def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: bool, p_drop: float, seed: int,
+def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: bool, p_drop: float, seed,
                       dmask: Optional[Tensor] = None, want_stats: bool = True, shared_mask: bool = False):
+    # `seed` is an int, or (int, device int64 tensor): the tensor is a step counter read by the kernel, so that a
+    # captured HIP graph draws a fresh dropout mask on every replay
     """Compact_Temporal_Aggregator 'att_group' (uncrtaints.py:156-221): e [B,T,C,H,W], att [nh,B,T,ah,aw]."""
     B, T, C, H, W = e.shape
     n_head, _, _, ah, aw = att.shape
@@ -459,10 +461,11 @@ def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: b
         gpart = Part(_f32((B * C, slots, 2), dev), slots)
     use_mask = dmask if training else None
     pd = float(p_drop) if (training and dmask is None) else 0.0
-    hb.call("uncr_aggregate_fwd", e, att, pad, use_mask, seed, pd, 1 if shared_mask else 0, g,
+    seed_val, seed_dev = seed if isinstance(seed, tuple) else (seed, None)
+    hb.call("uncr_aggregate_fwd", e, att, pad, use_mask, seed_val, seed_dev, pd, 1 if shared_mask else 0, g,
             gpart.buf if gpart else None, B, T, C, n_head, H, W, ah, aw, _stream())
-    saved = dict(e=e, att=att, pad=pad, dmask=use_mask, pd=pd, seed=seed, shared=1 if shared_mask else 0,
-                 dims=(B, T, C, H, W, n_head, ah, aw))
+    saved = dict(e=e, att=att, pad=pad, dmask=use_mask, pd=pd, seed=seed_val, seed_dev=seed_dev,
+                 shared=1 if shared_mask else 0, dims=(B, T, C, H, W, n_head, ah, aw))
     return g, saved, gpart
 
 
@@ -473,8 +476,8 @@ def aggregate_backward(dg: Tensor, sv: dict):
     de = _f32((B, T, C, H, W), dev)
     datt_up = _f32((n_head, B, T, H * W), dev)
     datt = _f32((n_head, B, T, ah, aw), dev)
-    hb.call("uncr_aggregate_bwd", dg.contiguous(), sv["e"], sv["att"], sv["pad"], sv["dmask"], sv["seed"], sv["pd"],
-            sv["shared"], de, datt_up, datt, B, T, C, n_head, H, W, ah, aw, _stream())
+    hb.call("uncr_aggregate_bwd", dg.contiguous(), sv["e"], sv["att"], sv["pad"], sv["dmask"], sv["seed"],
+            sv["seed_dev"], sv["pd"], sv["shared"], de, datt_up, datt, B, T, C, n_head, H, W, ah, aw, _stream())
     return de, datt
 
 

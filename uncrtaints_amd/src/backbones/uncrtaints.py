@@ -174,8 +174,14 @@ class Compact_Temporal_Aggregator(nn.Module):
         self._seed_base = 0x5EED
         self._calls = 0
         self.dropout_mask = None              # optional explicit mask [n_head*B,T,H,W] (testing / parity)
+        self.step_counter = None              # optional device int64[1] step counter (HIP-graph friendly seeding)
 
     def _next_seed(self):
+        """Seed of this call's dropout stream.  With `step_counter` set (a device int64 tensor the training loop
+        increments once per step, e.g. inside a captured HIP graph) the per-step variation comes from the device;
+        otherwise from a host-side call counter."""
+        if self.step_counter is not None:
+            return ((self._seed_base * 1000003) & 0xFFFFFFFFFFFF, self.step_counter)
         self._calls += 1
         return (self._seed_base * 1000003 + self._calls) & 0xFFFFFFFFFFFF
 
