@@ -29,7 +29,7 @@ def kernel_model(name, key):
     """-> (label, algorithmic bytes, flops) of one launch from its int arguments."""
     if name == "uncr_pw_gemm":
         bias_stride, N, Cin, Cout, P, pro, epi = key
-        rd = Cin * (2 if pro == PRO_NORMBWD else 1) + (Cout if epi == 2 else 0)
+        rd = Cin * (2 if pro == PRO_NORMBWD else 1) + (Cout if epi in (2, 3) else 0)
         return (f"pw_gemm[{Cin}->{Cout},pro{pro},epi{epi},N{N},P{P}]", 4.0 * N * P * (rd + Cout), 2.0 * N * P * Cin * Cout)
     if name == "uncr_pw_wgrad":
         N, Cd, Cx, P, PXB, pro_d, pro_x = key

@@ -78,6 +78,7 @@ int uncr_pw_tile_px(int Cout);    /* pixels per block == pixels per statistics s
 int uncr_pack_wt(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out, hipStream_t stream);
 int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, float* out, const float* k0,
                  const float* k1, const float* k2, const float* bias, int bias_stride_n, const float* aux,
+                 const float* e0, const float* e1, const float* e2, const float* e3 /* epi 3 coefficients */,
                  float* part, int N, int Cin, int Cout, int P, int pro, int epi, hipStream_t stream);
 int uncr_wgrad_shape(int Cd, int Cx, int* cop, int* cip);
 int uncr_pw_wgrad(const float* d, const float* d2, const float* x, const float* x2, const float* dk0,

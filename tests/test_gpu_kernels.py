@@ -82,6 +82,18 @@ def test_pw_gemm(E, Cin, Cout, pro):
             close(f"pw_gemm_stats0[{Cin}->{Cout},epi{epi}]", s[:, 0].float(), ref.sum(-1).reshape(-1).float())
             second = (ref * ref).sum(-1) if epi == 1 else (ref * aux.double()).sum(-1)
             close(f"pw_gemm_stats1[{Cin}->{Cout},epi{epi}]", s[:, 1].float(), second.reshape(-1).float(), tol=2e-4)
+    # fused pass-B epilogue: out = gelu'(A*aux+B) * (S*v + D), stats (sum out, sum out*aux)
+    ek = [rand(N * Cout, seed=30 + i, scale=0.5, shift=(1.0 if i in (0, 2) else 0.0)) for i in range(4)]
+    u = ek[0].view(N, Cout, 1) * aux + ek[1].view(N, Cout, 1)
+    gp = 0.5 * (1 + torch.erf(u.double() / math.sqrt(2))) + u.double() * torch.exp(-0.5 * u.double() ** 2) / math.sqrt(2 * math.pi)
+    ref3 = gp * (ek[2].view(N, Cout, 1).double() * ref + ek[3].view(N, Cout, 1).double())
+    out, part = E.pw_gemm(dev(x), Wt, N, Cin, Cout, P, pro=pro, k=(dev(k0), dev(k1), dev(k2)),
+                          x2=dev(x2) if pro == 3 else None, bias=dev(bias), epi=3, aux=dev(aux),
+                          ek=tuple(dev(t_) for t_ in ek))
+    close(f"pw_gemm_passB[{Cin}->{Cout},pro{pro}]", out, ref3.float())
+    sB = part.buf.double().sum(dim=1).cpu()
+    close(f"pw_gemm_passB_stats0[{Cin}->{Cout}]", sB[:, 0].float(), ref3.sum(-1).reshape(-1).float(), tol=2e-4)
+    close(f"pw_gemm_passB_stats1[{Cin}->{Cout}]", sB[:, 1].float(), (ref3 * aux.double()).sum(-1).reshape(-1).float(), tol=2e-4)
     # per-frame bias
     bn = rand(N, Cout, seed=12)
     out, _ = E.pw_gemm(dev(x), Wt, N, Cin, Cout, P, pro=0, bias=dev(bn), bias_per_frame=True)

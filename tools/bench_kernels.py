@@ -46,7 +46,7 @@ def main():
         Wt = E.pack_wt(W, transpose=True); out = torch.empty(N, Cout, P, device=dev)
         from uncrtaints_amd import hip_backend as hb
         for flags, name in [(0, "full")]:
-            fn = lambda: hb.call("uncr_pw_gemm", x, None, Wt, out, None, None, None, None, 0, None, None, N, Cin, Cout, P, 0, flags, E._stream())
+            fn = lambda: hb.call("uncr_pw_gemm", x, None, Wt, out, None, None, None, None, 0, None, None, None, None, None, None, N, Cin, Cout, P, 0, flags, E._stream())
             ms = timeit(fn, iters)
             print(f"{name:28s}: {ms*1e3:.1f} us  {2.0*N*P*Cin*Cout/ms/1e9:.1f} TF")
     elif what == "mfma":

@@ -27,11 +27,15 @@ struct PwArgs {
     const float* k2;
     const float* bias;   // [Cout] or [N][Cout] (bias_stride_n = Cout) or null
     const float* aux;    // EPI_AUX operand [N][Cout][P]
+    const float* e0;     // epi 3 (fused SE/GELU backward): per-(n,co) A, B, S, D  -> out = gelu'(A*aux+B)*(S*v+D)
+    const float* e1;
+    const float* e2;
+    const float* e3;
     float2* part;        // [N*Cout][NP] or null
     int bias_stride_n;
     int Cin, Cout, P;
     int pro;             // PRO_*
-    int epi;             // 0 none, 1 (sum, sum^2), 2 (sum, sum*aux)
+    int epi;             // 0 none, 1 (sum, sum^2), 2 (sum, sum*aux), 3 fused pass-B + (sum, sum*aux)
 };
 
 // PRE2 = false drops the second prefetch register set (PRO_NORMBWD unavailable): keeps the 32-wide
@@ -177,6 +181,18 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
                     v.x += bb; v.y += bb; v.z += bb; v.w += bb;
                 }
                 const size_t o = ((size_t)n * Cout + col) * P + pxw;
+                if (epi == 3) {
+                    // du2 = gelu'(A*h2 + B) * (S*dz + D): the SE / GELU backward applied to the fresh accumulator
+                    const float4 x = *(const float4*)(g.aux + o);
+                    const int ci = n * Cout + col;
+                    const float A = g.e0[ci], B = g.e1[ci], S = g.e2[ci], D = g.e3[ci];
+                    v.x = gelu_grad_f(fmaf(A, x.x, B)) * fmaf(S, v.x, D);
+                    v.y = gelu_grad_f(fmaf(A, x.y, B)) * fmaf(S, v.y, D);
+                    v.z = gelu_grad_f(fmaf(A, x.z, B)) * fmaf(S, v.z, D);
+                    v.w = gelu_grad_f(fmaf(A, x.w, B)) * fmaf(S, v.w, D);
+                    s0 = v.x + v.y + v.z + v.w;
+                    s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
+                }
                 *(float4*)(g.out + o) = v;
                 if (epi == 1) {
                     s0 = v.x + v.y + v.z + v.w;
@@ -451,15 +467,18 @@ extern "C" int uncr_pack_wt(const float* W, int rows_k, int cols_co, int ld, int
 
 extern "C" int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, float* out, const float* k0,
                             const float* k1, const float* k2, const float* bias, int bias_stride_n, const float* aux,
-                            float* part, int N, int Cin, int Cout, int P, int pro, int epi, hipStream_t stream) {
+                            const float* e0, const float* e1, const float* e2, const float* e3, float* part, int N,
+                            int Cin, int Cout, int P, int pro, int epi, hipStream_t stream) {
     if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
     if (!in || !Wt || !out) return UNCR_EINVAL;
     if (pro == PRO_NORMBWD && !in2) return UNCR_EINVAL;
     if (epi && !part) return UNCR_EINVAL;
-    if (epi == 2 && !aux) return UNCR_EINVAL;
+    if ((epi == 2 || epi == 3) && !aux) return UNCR_EINVAL;
+    if (epi == 3 && (!e0 || !e1 || !e2 || !e3)) return UNCR_EINVAL;
+    if (epi < 0 || epi > 3) return UNCR_EINVAL;
     const int tp = uncr_pw_tile_px(Cout);
     if (P % tp) return UNCR_ESHAPE;
-    PwArgs g{in, in2, Wt, out, k0, k1, k2, bias, aux, (float2*)part, bias_stride_n, Cin, Cout, P, pro, epi};
+    PwArgs g{in, in2, Wt, out, k0, k1, k2, bias, aux, e0, e1, e2, e3, (float2*)part, bias_stride_n, Cin, Cout, P, pro, epi};
     dim3 grid(P / tp, N);
     const int cp = pw_coutp(Cout);
     if (cp == 256)

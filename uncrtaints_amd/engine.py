@@ -145,7 +145,8 @@ def pack_wt(W2d: Tensor, transpose: bool) -> Tensor:
 
 def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: int = PRO_NONE, k=(None, None, None),
             x2: Optional[Tensor] = None, bias: Optional[Tensor] = None, bias_per_frame: bool = False, epi: int = 0,
-            aux: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Part]]:
+            aux: Optional[Tensor] = None, out: Optional[Tensor] = None,
+            ek=(None, None, None, None)) -> Tuple[Tensor, Optional[Part]]:
     if out is None:
         out = _f32((N, Cout, P), x.device)
     part = None
@@ -153,7 +154,7 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
         slots = P // hb.query("uncr_pw_tile_px", Cout)
         part = Part(_f32((N * Cout, slots, 2), x.device), slots)
     hb.call("uncr_pw_gemm", x, x2, Wt, out, k[0], k[1], k[2], bias, Cout if bias_per_frame else 0, aux,
-            part.buf if part else None, N, Cin, Cout, P, pro, epi, _stream())
+            ek[0], ek[1], ek[2], ek[3], part.buf if part else None, N, Cin, Cout, P, pro, epi, _stream())
     return out, part
 
 
@@ -274,9 +275,10 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
 
     # dz = W2^T dh3 ; du2 = gelu'(u2) * (s*dz + dpool) (in place) with stats (sum du2, sum du2*h2)
     W2k = pack_wt(w2, transpose=False)                     # [k=co 128][out=c 256]
-    dz, _ = pw_gemm(dy, W2k, N, C, Ch, P, pro=PRO_NORMBWD, k=k3, x2=h3)
-    _, part2 = ew(EW_PASSB, dz, b=h2, out=dz, k=(n2.A, n2.B, sv["s"], dpool), want_part=True, planes=N * Ch, P=P)
-    du2 = dz
+    # ... with the SE / GELU backward (du2 = gelu'(u2) * (s*dz + dpool)) and its statistics fused into the
+    # GEMM epilogue: dz itself is never written
+    du2, part2 = pw_gemm(dy, W2k, N, C, Ch, P, pro=PRO_NORMBWD, k=k3, x2=h3, epi=3, aux=h2,
+                         ek=(n2.A, n2.B, sv["s"], dpool))
     b2 = norm_bwd(part2, N, Ch, P, n2, p["n2w"])
     g["n2w"], g["n2b"] = b2.dgamma, b2.dbeta
 
