@@ -156,7 +156,11 @@ def main():
     else:
         model.temporal_aggregator.set_seed(1)
     use_graph = world == 1 and not args.no_graph
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph)
+    # fused multi-tensor Adam: one launch per step instead of ~180 per-tensor kernels (0.7 ms/step in the capture)
+    try:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph, fused=True)
+    except Exception:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph)
     x, y, dates = synthetic(B, T, H, H, seed=1 + rank, device=device)
     step_counter = torch.zeros(1, dtype=torch.int64, device=device)
     model.temporal_aggregator.step_counter = step_counter     # dropout stream advances on the device

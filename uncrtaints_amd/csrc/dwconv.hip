@@ -255,7 +255,14 @@ extern "C" int uncr_dw_bwd(const float* du2, const float* h2, const float* h1, c
                            float* part, float* dw_part, int N, int C, int H, int W, hipStream_t stream) {
     if (N <= 0 || C <= 0 || H < 4 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
     const size_t lds = (size_t)2 * (DW_TR_BWD + 2) * (W + 8) * sizeof(float);
-    if (lds > 60 * 1024) return UNCR_ESHAPE;
+    if (lds > 150 * 1024) return UNCR_ESHAPE;
+    static size_t lds_attr = 0;
+    if (lds > lds_attr) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU)
+        if (hipFuncSetAttribute((const void*)dw_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return UNCR_EINVAL;
+        lds_attr = lds;
+    }
     hipLaunchKernelGGL(dw_bwd_kernel, dim3(uncr_dw_slots_bwd(H), N * C), dim3(256), lds, stream, du2, h2, h1, k1, k2,
                        k3, cA1, cB1, w, du1, (float2*)part, dw_part, C, H, W);
     UNCR_LAUNCH_CHECK();
