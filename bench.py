@@ -286,6 +286,16 @@ def main():
             else:
                 res["roofline"] = {"bound": "hbm", "achieved": round(top["gbs"], 1), "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": None, "kernel": top["kernel"]}
+            # HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json; rocprofv3 cannot
+            # run inside this process): attached only when the dominant kernel is one that was measured
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                    tr = json.load(fh).get(top["kernel"])
+                if tr:
+                    res["roofline"]["traffic"] = tr["hbm_bytes"]
+                    res["roofline"]["algorithmic_bytes"] = int(top["bytes"])
+            except OSError:
+                pass
             res["roofline"]["mean_launch_ms"] = round(top["mean_ms"], 4)
             res["roofline"]["share_of_profiled_time"] = round(top["total_ms"] / max(tot, 1e-9), 4)
             res["kernel_breakdown"] = [

@@ -40,6 +40,20 @@ def main():
             fn = lambda: E.pw_wgrad(d, x, N, Cd, Cx, P, pro_d=pro_d, dk=dk, d2=d2 if pro_d == 3 else None, pro_x=pro_x, xk=xk)
             ms = timeit(fn, iters)
             print(f"pw_wgrad {Cd}x{Cx} pro_d{pro_d} pro_x{pro_x}: {ms*1e3:.1f} us  {2.0*N*P*Cd*Cx/ms/1e9:.1f} TF (incl. reduce)")
+    elif what == "traffic":
+        # one launch sequence of the step's dominant kernels at the bench shapes, for rocprofv3 --pmc passes
+        import json
+        seq = []
+        Cin, Cout = 128, 256
+        x = torch.randn(N, Cin, P, device=dev); x2 = torch.randn(N, Cin, P, device=dev)
+        h2 = torch.randn(N, Cout, P, device=dev)
+        Wt = E.pack_wt(torch.randn(Cout, Cin, device=dev) * 0.05, transpose=True)
+        k = tuple(torch.randn(N * Cin, device=dev) for _ in range(3)); ek = tuple(torch.rand(N * Cout, device=dev) for _ in range(4))
+        for _ in range(3):
+            E.pw_gemm(x, Wt, N, Cin, Cout, P, pro=3, k=k, x2=x2, epi=3, aux=h2, ek=ek)          # fused dz + pass-B
+            E.pw_gemm(x, Wt, N, Cin, Cout, P, pro=1, k=k, epi=1)                                # pw1 forward
+        torch.cuda.synchronize()
+        print("done")
     elif what == "ablate":
         Cin, Cout = 128, 256
         x = torch.randn(N, Cin, P, device=dev); W = torch.randn(Cout, Cin, device=dev) * 0.05
