@@ -50,6 +50,10 @@ typedef struct ihipStream_t* hipStream_t;
 
 int uncr_version(void);
 int uncr_debug_mfma_probe(float* out, int blocks, int iters, hipStream_t stream);   /* fp32-MFMA peak probe */
+int uncr_debug_mfma_probe_bf16(float* out, int blocks, int iters, hipStream_t stream);   /* bf16-MFMA peak probe */
+/* debug: out[32][32] = A[32][K] * B[K][32] through the 3-way bf16 split on v_mfma_f32_32x32x16_bf16
+ * (terms = 1, 3, 6 or 9 partial products); numerics probe, K % 16 == 0 */
+int uncr_debug_bf16split_probe(const float* A, const float* B, float* out, int K, int terms, hipStream_t stream);
 
 /* ---- normalisation coefficients: nn.GroupNorm / nn.BatchNorm2d statistics
  *      (uncrtaints.py:16-22 get_norm_layer, utae.py:470-473, uncrtaints.py:72-79 PreNorm) ---- */
@@ -70,8 +74,14 @@ int uncr_ew(int op, const float* a, const float* b, const float* c, const float*
             const float* k0, const float* k1, const float* k2, const float* k3, float* part, int planes, int P,
             int C, int n_mean, float scale, float eps, hipStream_t stream);
 
-/* ---- 1x1 convolutions as fp32 MFMA GEMMs (nn.Conv2d k=1: utae.py:476-484 in_conv/out_conv,
- *      uncrtaints.py:126 pw, :136 pw-linear; nn.Conv1d k=1 ltae.py:176,214; nn.Linear ltae.py:327,349) ---- */
+/* ---- 1x1 convolutions as MFMA GEMMs with fp32 results (nn.Conv2d k=1: utae.py:476-484 in_conv/out_conv,
+ *      uncrtaints.py:126 pw, :136 pw-linear; nn.Conv1d k=1 ltae.py:176,214; nn.Linear ltae.py:327,349).
+ *      Cout <= 64: v_mfma_f32_32x32x2_f32.  Cout > 64: exact 3-way bf16 split of both operands, six partial
+ *      products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (fp32-grade error, 2.7x fewer MFMA cycles);
+ *      uncr_pw_set_split(0) routes these to the fp32-MFMA kernels too (returns the previous setting; weights
+ *      must be packed under the setting they are used with). ---- */
+int uncr_pw_set_split(int on);
+int uncr_pw_wt_floats(int rows_k, int cols_co);   /* floats to allocate for uncr_pack_wt's output */
 int uncr_pw_coutp(int Cout);      /* padded output-channel count of the kernel variant */
 int uncr_pw_kpad(int Cin);        /* padded reduction length */
 int uncr_pw_tile_px(int Cout);    /* pixels per block == pixels per statistics slot */

@@ -21,17 +21,18 @@ def main():
     dev = "cuda"
     N, P = 4, 65536
     if what == "gemm":
-        for (Cin, Cout, pro, epi) in [(128, 256, 0, 0), (128, 256, 1, 1), (128, 256, 3, 0), (256, 128, 0, 0), (256, 128, 2, 1), (256, 128, 3, 2)]:
+        for (Cin, Cout, pro, epi) in [(128, 256, 0, 0), (128, 256, 1, 1), (128, 256, 3, 0), (256, 128, 0, 0), (256, 128, 2, 1), (256, 128, 3, 2), (128, 256, 3, 3)]:
             x = torch.randn(N, Cin, P, device=dev); x2 = torch.randn(N, Cin, P, device=dev)
             W = torch.randn(Cout, Cin, device=dev) * 0.05
             Wt = E.pack_wt(W, transpose=True)
             k = tuple(torch.randn(N * Cin, device=dev) for _ in range(3))
-            aux = torch.randn(N, Cout, P, device=dev) if epi == 2 else None
+            aux = torch.randn(N, Cout, P, device=dev) if epi >= 2 else None
+            ek = tuple(torch.rand(N * Cout, device=dev) for _ in range(4)) if epi == 3 else (None,) * 4
             out = torch.empty(N, Cout, P, device=dev)
-            fn = lambda: E.pw_gemm(x, Wt, N, Cin, Cout, P, pro=pro, k=k, x2=x2 if pro == 3 else None, epi=epi, aux=aux, out=out)
+            fn = lambda: E.pw_gemm(x, Wt, N, Cin, Cout, P, pro=pro, k=k, x2=x2 if pro == 3 else None, epi=epi, aux=aux, out=out, ek=ek)
             ms = timeit(fn, iters)
             fl = 2.0 * N * P * Cin * Cout
-            by = 4.0 * N * P * (Cin * (2 if pro == 3 else 1) + Cout * (2 if epi == 2 else 1))
+            by = 4.0 * N * P * (Cin * (2 if pro == 3 else 1) + Cout * (2 if epi >= 2 else 1))
             print(f"pw_gemm {Cin}->{Cout} pro{pro} epi{epi}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF  {by/ms/1e6:.0f} GB/s")
     elif what == "wgrad":
         for (Cd, Cx, pro_d, pro_x) in [(256, 128, 3, 1), (128, 256, 3, 2), (256, 128, 0, 0)]:
@@ -40,6 +41,28 @@ def main():
             fn = lambda: E.pw_wgrad(d, x, N, Cd, Cx, P, pro_d=pro_d, dk=dk, d2=d2 if pro_d == 3 else None, pro_x=pro_x, xk=xk)
             ms = timeit(fn, iters)
             print(f"pw_wgrad {Cd}x{Cx} pro_d{pro_d} pro_x{pro_x}: {ms*1e3:.1f} us  {2.0*N*P*Cd*Cx/ms/1e9:.1f} TF (incl. reduce)")
+    elif what == "gemmscale":
+        Cin, Cout = 128, 256
+        for nb in (128, 256, 512, 1024, 2048):
+            Pn = 128 * nb
+            x = torch.randn(1, Cin, Pn, device=dev)
+            Wt = E.pack_wt(torch.randn(Cout, Cin, device=dev) * 0.05, transpose=True)
+            out = torch.empty(1, Cout, Pn, device=dev)
+            fn = lambda: E.pw_gemm(x, Wt, 1, Cin, Cout, Pn, out=out)
+            ms = timeit(fn, iters)
+            print(f"blocks={nb}: {ms*1e3:.1f} us  {2.0*Pn*Cin*Cout/ms/1e9:.1f} TF")
+    elif what == "stamps":
+        Cin, Cout = 128, 256
+        for nb in (256, 2048):
+            Pn = 128 * nb
+            x = torch.randn(1, Cin, Pn, device=dev)
+            Wt = E.pack_wt(torch.randn(Cout, Cin, device=dev) * 0.05, transpose=True)
+            out = torch.empty(1, Cout, Pn, device=dev)
+            for _ in range(3): E.pw_gemm(x, Wt, 1, Cin, Cout, Pn, out=out)
+            torch.cuda.synchronize()
+            s = out.view(-1)[: nb * 4].view(nb, 4).cpu()
+            print(f"blocks={nb}: prologue {s[:,0].mean():.0f}  loop {s[:,1].mean():.0f}  epilogue {s[:,2].mean():.0f} cycles (readcyclecounter ticks); "
+                  f"loop min/max {s[:,1].min():.0f}/{s[:,1].max():.0f}")
     elif what == "traffic":
         # one launch sequence of the step's dominant kernels at the bench shapes, for rocprofv3 --pmc passes
         import json
@@ -72,6 +95,10 @@ def main():
             ms = timeit(fn, 5)
             fl = blocks * 4 * its * 8 * (2.0 * 32 * 32 * 2)
             print(f"mfma probe blocks={blocks}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF")
+            fn = lambda: hb.call("uncr_debug_mfma_probe_bf16", out, blocks, its, E._stream())
+            ms = timeit(fn, 5)
+            fl = blocks * 4 * its * 8 * (2.0 * 32 * 32 * 16)
+            print(f"bf16 mfma probe blocks={blocks}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF")
     elif what == "copy":
         a = torch.randn(256 * 1024 * 1024 // 4, device=dev); b = torch.empty_like(a)
         ms = timeit(lambda: b.copy_(a), iters)

@@ -11,7 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libuncr_hip.so")
-SOURCES = ["norm", "ew", "pw_gemm", "dwconv", "se", "ltae", "aggregate", "mgnll"]
+# (source stem, extra flags, object stem); the split GEMM is compiled once per prologue kind (compile-time PRO)
+SOURCES = [(s, [], s) for s in ["norm", "ew", "pw_gemm", "dwconv", "se", "ltae", "aggregate", "mgnll"]] + \
+          [("pw_gemm_split", [f"-DPWS_PRO={p}"], f"pw_gemm_split_p{p}") for p in range(5)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
@@ -24,12 +26,12 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    hdr = os.path.join(CSRC, "common.h")
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     jobs = []
-    for s in SOURCES:
-        src, obj = os.path.join(CSRC, s + ".hip"), os.path.join(objdir, s + ".o")
-        if force or _newer(src, obj) or _newer(hdr, obj):
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+    for s, extra, o in SOURCES:
+        src, obj = os.path.join(CSRC, s + ".hip"), os.path.join(objdir, o + ".o")
+        if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs):
+            jobs.append([hipcc, *FLAGS, *extra, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -39,9 +41,9 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(13, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    objs = [os.path.join(objdir, s + ".o") for s in SOURCES]
+    objs = [os.path.join(objdir, o + ".o") for _, _, o in SOURCES]
     if force or jobs or not os.path.exists(LIB):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
     return LIB

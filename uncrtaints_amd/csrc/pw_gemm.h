@@ -1,0 +1,52 @@
+// Shared between the two pointwise-GEMM translation units (pw_gemm.hip: fp32-MFMA kernels, weight gradient;
+// pw_gemm_split.hip: the bf16x3-split kernels for the wide shapes).
+#pragma once
+#include "common.h"
+
+struct PwArgs {
+    const float* in;
+    const float* in2;    // PRO_NORMBWD second operand
+    const float* Wt;     // packed weights (format depends on the kernel variant, see uncr_pack_wt)
+    float* out;          // [N][Cout][P]
+    const float* k0;     // prologue coefficients, [N*Cin] each
+    const float* k1;
+    const float* k2;
+    const float* bias;   // [Cout] or [N][Cout] (bias_stride_n = Cout) or null
+    const float* aux;    // EPI_AUX operand [N][Cout][P]
+    const float* e0;     // epi 3 (fused SE/GELU backward): per-(n,co) A, B, S, D  -> out = gelu'(A*aux+B)*(S*v+D)
+    const float* e1;
+    const float* e2;
+    const float* e3;
+    float2* part;        // [N*Cout][NP] or null
+    int bias_stride_n;
+    int Cin, Cout, P;
+    int pro;             // PRO_*
+    int epi;             // 0 none, 1 (sum, sum^2), 2 (sum, sum*aux), 3 fused pass-B + (sum, sum*aux)
+};
+
+// x = h + m + l exactly, each part a bf16 (kept in the upper half of a 32-bit word).  Truncation split: h takes
+// the leading 8 significant bits, m the next 8 starting at the residual's leading one, l the (<= 8) rest.
+__device__ __forceinline__ void split3_bf16(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));
+}
+// two upper-half bf16 -> one dword {lo16 = a, hi16 = b}
+__device__ __forceinline__ unsigned pack_bf16x2(unsigned a, unsigned b) {
+    return __builtin_amdgcn_perm(b, a, 0x07060302u);
+}
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+// pw_gemm_split.hip
+// one object per prologue kind (pw_gemm_split.hip compiled with -DPWS_PRO=0..4); cp in {128, 256}
+int pw_split_launch_p0(const PwArgs& g, int N, int cp, hipStream_t stream);
+int pw_split_launch_p1(const PwArgs& g, int N, int cp, hipStream_t stream);
+int pw_split_launch_p2(const PwArgs& g, int N, int cp, hipStream_t stream);
+int pw_split_launch_p3(const PwArgs& g, int N, int cp, hipStream_t stream);
+int pw_split_launch_p4(const PwArgs& g, int N, int cp, hipStream_t stream);
+int pw_split_pack(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out, hipStream_t stream);
+size_t pw_split_wt_floats(int rows_k, int cp);

@@ -15,28 +15,8 @@
 //     prefetched into registers while the current one feeds the MFMAs.
 //   * weights are tiny (<=128 KB, L2 resident): each wave reads its A fragments (Wt[k][co], co
 //     contiguous => 128-B coalesced) straight from global.
-#include "common.h"
+#include "pw_gemm.h"
 
-struct PwArgs {
-    const float* in;
-    const float* in2;    // PRO_NORMBWD second operand
-    const float* Wt;     // [nk*32][COUTP], zero padded
-    float* out;          // [N][Cout][P]
-    const float* k0;     // prologue coefficients, [N*Cin] each
-    const float* k1;
-    const float* k2;
-    const float* bias;   // [Cout] or [N][Cout] (bias_stride_n = Cout) or null
-    const float* aux;    // EPI_AUX operand [N][Cout][P]
-    const float* e0;     // epi 3 (fused SE/GELU backward): per-(n,co) A, B, S, D  -> out = gelu'(A*aux+B)*(S*v+D)
-    const float* e1;
-    const float* e2;
-    const float* e3;
-    float2* part;        // [N*Cout][NP] or null
-    int bias_stride_n;
-    int Cin, Cout, P;
-    int pro;             // PRO_*
-    int epi;             // 0 none, 1 (sum, sum^2), 2 (sum, sum*aux), 3 fused pass-B + (sum, sum*aux)
-};
 
 // PRE2 = false drops the second prefetch register set (PRO_NORMBWD unavailable): keeps the 32-wide
 // variant (16 prefetch float4 per lane) free of spills.
@@ -448,6 +428,12 @@ __global__ void pack_wt_kernel(const float* __restrict__ W, int rows_k, int cols
 
 static int pw_coutp(int Cout) { return Cout > 128 ? 256 : (Cout > 64 ? 128 : (Cout > 32 ? 64 : 32)); }
 
+// wide shapes (Cout > 64) run on the bf16x3-split kernels (pw_gemm_split.hip) unless switched off -- the switch
+// exists for A/B measurements and for testing both paths; weights must be packed under the same setting.
+static int g_split = 1;
+extern "C" int uncr_pw_set_split(int on) { const int old = g_split; g_split = on ? 1 : 0; return old; }
+static bool use_split(int Cout) { return g_split && pw_coutp(Cout) >= 128; }
+
 extern "C" int uncr_pw_coutp(int Cout) { return Cout <= 256 ? pw_coutp(Cout) : -1; }
 extern "C" int uncr_pw_kpad(int Cin) { return ((Cin + 31) / 32) * 32; }
 extern "C" int uncr_pw_tile_px(int Cout) {
@@ -455,9 +441,16 @@ extern "C" int uncr_pw_tile_px(int Cout) {
     return (cp >= 128) ? 128 : 256;
 }
 
+extern "C" int uncr_pw_wt_floats(int rows_k, int cols_co) {
+    if (cols_co > 256 || rows_k > 256 || cols_co <= 0 || rows_k <= 0) return -1;
+    if (use_split(cols_co)) return (int)pw_split_wt_floats(rows_k, pw_coutp(cols_co));
+    return uncr_pw_kpad(rows_k) * pw_coutp(cols_co);
+}
+
 extern "C" int uncr_pack_wt(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out,
                             hipStream_t stream) {
     if (cols_co > 256 || rows_k > 256) return UNCR_ESHAPE;
+    if (use_split(cols_co)) return pw_split_pack(W, rows_k, cols_co, ld, transpose, out, stream);
     const int Kp = uncr_pw_kpad(rows_k), CP = pw_coutp(cols_co);
     hipLaunchKernelGGL(pack_wt_kernel, dim3((Kp * CP + 255) / 256), dim3(256), 0, stream, W, rows_k, cols_co, ld,
                        transpose, Kp, CP, out);
@@ -479,8 +472,18 @@ extern "C" int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, 
     const int tp = uncr_pw_tile_px(Cout);
     if (P % tp) return UNCR_ESHAPE;
     PwArgs g{in, in2, Wt, out, k0, k1, k2, bias, aux, e0, e1, e2, e3, (float2*)part, bias_stride_n, Cin, Cout, P, pro, epi};
-    dim3 grid(P / tp, N);
     const int cp = pw_coutp(Cout);
+    if (use_split(Cout)) {
+        switch (pro) {
+            case PRO_NONE: return pw_split_launch_p0(g, N, cp, stream);
+            case PRO_AFFINE: return pw_split_launch_p1(g, N, cp, stream);
+            case PRO_AFFINE_GELU: return pw_split_launch_p2(g, N, cp, stream);
+            case PRO_NORMBWD: return pw_split_launch_p3(g, N, cp, stream);
+            case PRO_AFFINE_RELU: return pw_split_launch_p4(g, N, cp, stream);
+            default: return UNCR_EINVAL;
+        }
+    }
+    dim3 grid(P / tp, N);
     if (cp == 256)
         hipLaunchKernelGGL((pw_gemm_kernel<2, 4, 1, true>), grid, dim3(256), 0, stream, g);
     else if (cp == 128)

@@ -1,0 +1,352 @@
+// Pointwise (1x1) convolution GEMM for the wide shapes (Cout > 64) on the bf16 matrix pipe WITHOUT giving up
+// fp32 results: every fp32 operand is split exactly into three bf16 numbers, x = h + m + l (truncation split,
+// see pw_gemm.h), and the six partial products that can reach the fp32 result,
+//     a*b ~= ah*bl + ah*bm + ah*bh + am*bh + am*bm + al*bh          (dropped terms <= 3 * 2^-24 |a||b|)
+// are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Each bf16 x bf16 product is exact in fp32, so the
+// result carries the same rounding error as an fp32 FMA chain (measured on MI355X: 4e-7 relative to fp64 at
+// K = 128...256, fp32 chain 3...6e-7; tools/probe_bf16split.py) while one K=16 step costs 6 x 32 cycles on
+// the matrix pipe instead of 8 x 64 for v_mfma_f32_32x32x2_f32.  The MFMA phase drops below the HBM time of
+// these (fused, <= 43 FLOP/B) GEMMs, which is what makes them stream-bound.
+//
+// Data flow (block = 4 waves = 128 px x COUTP channels of one frame; wave = CT x 32 channels x 128 px):
+//   * activations: global (fp32 NCHW rows, float4 along px) -> registers (prologue: norm / GELU / SE scale /
+//     norm-backward, once per element) -> split -> LDS as bf16 in MFMA-operand order.  A thread owns 4
+//     consecutive ci x 4 consecutive px, so each LDS write is 8 B = 4 k-consecutive bf16 of one pixel; an MFMA
+//     lane reads its whole operand (8 k-values of one pixel) with ONE ds_read_b128 that lands in the register
+//     quad the MFMA consumes (no transposes, no sub-dword accesses, no register shuffles).  LDS bytes:
+//     (((part*2+ks)*2+kg)*4+e)*512 + j*16 + half*8, pixel px = 4*j + e -- a lane keeps four consecutive pixels
+//     in four accumulator tiles, so the epilogue stores float4 rows exactly like the fp32 kernel.
+//   * weights: pre-split and pre-swizzled by pack (Wp[ks][cotile][part][lane] = 16 B = the lane's 8 bf16 of
+//     A[co = lane&31][ci = 16 ks + 8 (lane>>5) + 0..7]); a wave's A load is one contiguous 1 KB read from L2.
+//     A parts are re-loaded for the next k-step right after their last use (no second register set).
+#include "pw_gemm.h"
+#include <type_traits>
+
+#ifndef PWS_ABL
+#define PWS_ABL 0   // development ablations (tools/ablate_split.sh): 1 no stores, 2 no staging, 4 no activation loads, 8 no A reloads, 16 no MFMA
+#endif
+#define PWS_TP 128
+#define PWS_KC 32
+#define PWS_BUF 24576   // bytes per LDS stage: 3 parts x 32 ci x 128 px x 2 B
+
+// DEPTH = chunks of raw activations in flight in registers (2 wherever the register budget allows: a chunk is
+// only ~1.3 us of MFMA work, one chunk of prefetch distance does not cover HBM latency under load).
+// PRO / EPI are compile-time: with run-time switches every staged element and every stored row carries a branch
+// tree, the kernel grows to ~60 KB of code (instruction-cache misses at every jump) and the per-row coefficient
+// loads each get their own vmcnt(0) -- measured: an 11k-cycle epilogue next to a 14k-cycle MFMA loop.
+template <int CT, int PRO, int EPI, int DEPTH>
+__global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
+    constexpr int NT = 256, WN = 4;
+    constexpr bool PRE2 = PRO == PRO_NORMBWD;
+    constexpr int COUTP = 32 * CT * WN;
+    constexpr int NCT = CT * WN;
+
+    __shared__ __attribute__((aligned(16))) unsigned char xs[2][PWS_BUF];
+    __shared__ float cf[3][256];
+    __shared__ float red[COUTP][2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int j = lane & 31, kg = lane >> 5;
+    const int n = blockIdx.y;
+    const int px0 = blockIdx.x * PWS_TP;
+#ifdef PWS_STAMP
+    const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+    const int Cin = g.Cin, Cout = g.Cout, P = g.P;
+    const int nk = (Cin + PWS_KC - 1) / PWS_KC;          // chunks that hold data
+    const int nkp = (nk + DEPTH - 1) / DEPTH * DEPTH;     // chunks computed (padding chunks are all-zero)
+    constexpr int pro = PRO;
+
+    if constexpr (PRO != PRO_NONE) {
+        for (int i = tid; i < Cin; i += NT) {
+            const float a = g.k0 ? g.k0[n * Cin + i] : 1.f;
+            const float b = g.k1 ? g.k1[n * Cin + i] : 0.f;
+            const float c = g.k2 ? g.k2[n * Cin + i] : (PRO == PRO_AFFINE_GELU ? 1.f : 0.f);
+            cf[0][i] = a; cf[1][i] = b; cf[2][i] = c;
+        }
+    }
+
+    // staging ownership: rows 4*cig .. 4*cig+3 of the chunk, pixels 4*sj .. 4*sj+3
+    const int sj = tid & 31, cig = tid >> 5;
+    const float* inb = g.in + (size_t)n * Cin * P + px0 + 4 * sj;
+    const float* in2b = g.in2 ? g.in2 + (size_t)n * Cin * P + px0 + 4 * sj : nullptr;
+    // LDS byte offset of this thread's 8-B half-slot for (part 0, e 0): ks = cig>>2, kg = (cig>>1)&1, half = cig&1
+    const int st_off = ((cig >> 2) * 2 + ((cig >> 1) & 1)) * 2048 + sj * 16 + (cig & 1) * 8;
+
+    float4 pre[DEPTH][4], pre2[PRE2 ? DEPTH : 1][4];
+    // rows past Cin re-read row 0 (branch-free; they are zeroed at staging)
+    auto load_chunk = [&](int kc, auto slot) {
+        constexpr int S = decltype(slot)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kc * PWS_KC + 4 * cig + r;
+            const int kk = k < Cin ? k : 0;
+            pre[S][r] = *(const float4*)(inb + (size_t)kk * P);
+            if constexpr (PRE2) pre2[S][r] = *(const float4*)(in2b + (size_t)kk * P);
+        }
+    };
+    auto stage_chunk = [&](int kc, int buf, auto slot) {
+        constexpr int S = decltype(slot)::value;
+        // pixel-major so that only one pixel's 4 rows x 3 parts are live at a time (register pressure)
+        float c0[4], c1[4], c2[4];
+        bool valid[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kc * PWS_KC + 4 * cig + r;
+            const int kk = k < Cin ? k : 0;
+            valid[r] = k < Cin;
+            if constexpr (PRO != PRO_NONE) { c0[r] = cf[0][kk]; c1[r] = cf[1][kk]; c2[r] = cf[2][kk]; }
+        }
+        unsigned char* b = &xs[buf][0] + st_off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = ((const float*)&pre[S][r])[e];
+                if constexpr (PRO == PRO_AFFINE) v = fmaf(c0[r], v, c1[r]);
+                else if constexpr (PRO == PRO_AFFINE_GELU) v = c2[r] * gelu_f(fmaf(c0[r], v, c1[r]));
+                else if constexpr (PRO == PRO_NORMBWD) v = fmaf(c0[r], v, fmaf(c1[r], ((const float*)&pre2[S][r])[e], c2[r]));
+                else if constexpr (PRO == PRO_AFFINE_RELU) v = fmaxf(fmaf(c0[r], v, c1[r]), 0.f);
+                if (!valid[r]) v = 0.f;
+                split3_bf16(v, hh[r], mm[r], ll[r]);
+            }
+            *(u32x2_t*)(b + e * 512) = u32x2_t{pack_bf16x2(hh[0], hh[1]), pack_bf16x2(hh[2], hh[3])};
+            *(u32x2_t*)(b + 8192 + e * 512) = u32x2_t{pack_bf16x2(mm[0], mm[1]), pack_bf16x2(mm[2], mm[3])};   // part stride 8192
+            *(u32x2_t*)(b + 16384 + e * 512) = u32x2_t{pack_bf16x2(ll[0], ll[1]), pack_bf16x2(ll[2], ll[3])};
+        }
+    };
+
+    f32x16 acc[4][CT];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][ct][r] = 0.f;
+
+    // A fragments: Wp[ks][cotile][part][lane] (16 B each)
+    const u32x4_t* wp = (const u32x4_t*)g.Wt + (size_t)(wn * CT) * 3 * 64 + lane;
+    auto lda = [&](int ks, int ct, int part) { return wp[((size_t)(ks * NCT + ct) * 3 + part) * 64]; };
+    u32x4_t ah[CT], am[CT], al[CT];
+    using S0 = std::integral_constant<int, 0>;
+    load_chunk(0, S0{});
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
+    __syncthreads();   // cf visible
+    stage_chunk(0, 0, S0{});
+    load_chunk(1 < nk ? 1 : nk - 1, S0{});
+    if constexpr (DEPTH == 2) load_chunk(2 < nk ? 2 : nk - 1, std::integral_constant<int, DEPTH - 1>{});
+    __syncthreads();
+
+    const int rd_off = kg * 2048 + j * 16;   // + (part*2+ks)*4096 + e*512
+    const int nks = 2 * nkp;
+    // B operand registers roll like the A registers: each part is re-read for the NEXT k-step right after its
+    // last use, so no MFMA waits on LDS latency (hipcc otherwise sinks the ds_reads next to their consumers).
+    u32x4_t bh[4], bm[4], bl[4];
+    auto ldb = [&](const unsigned char* p0, int part, u32x4_t (&b)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b[e] = *(const u32x4_t*)(p0 + part * 8192 + e * 512);   // one ds_read_b128 = the lane's 8 k-values
+        }
+    };
+    ldb(&xs[0][0] + rd_off, 1, bm);
+    ldb(&xs[0][0] + rd_off, 0, bh);
+
+#define PWS_MF(A, B)                                                                                          \
+    _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) _Pragma("unroll") for (int e = 0; e < 4; ++e)           \
+        if (!(PWS_ABL & 16)) acc[e][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A[ct]), \
+                                                             __builtin_bit_cast(bf16x8_t, B[e]), acc[e][ct], 0, 0, 0)
+    // one k-step: six (A part, B part) products, smallest terms first; nb = LDS address of the next k-step's B
+    auto kstep = [&](int ksn, const unsigned char* cb, const unsigned char* nb) {
+        // sched_barrier(0): hipcc must not move anything across -- left alone it batches the A re-loads right before
+        // their consumers and sinks the ds_reads to theirs, which serialises every latency behind the MFMAs.
+        // The low B part is needed by one product only: it is read at the top of its own k-step (one product of
+        // cover) so that only bm/bh stay live across the staging section between the k-steps.
+#define PWS_SB() __builtin_amdgcn_sched_barrier(0)
+        if (!(PWS_ABL & 32)) ldb(cb, 2, bl);
+        PWS_SB();
+        PWS_MF(ah, bm); PWS_SB();
+        PWS_MF(ah, bl); PWS_SB();
+        PWS_MF(ah, bh); PWS_SB();
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) if (!(PWS_ABL & 8)) ah[ct] = lda(ksn, ct, 0);
+        PWS_SB();
+        PWS_MF(am, bh); PWS_SB();
+        PWS_MF(am, bm); PWS_SB();
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) if (!(PWS_ABL & 8)) am[ct] = lda(ksn, ct, 1);
+        if (!(PWS_ABL & 32)) ldb(nb, 1, bm);
+        PWS_SB();
+        PWS_MF(al, bh); PWS_SB();
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) if (!(PWS_ABL & 8)) al[ct] = lda(ksn, ct, 2);
+        if (!(PWS_ABL & 32)) ldb(nb, 0, bh);
+        PWS_SB();
+#undef PWS_SB
+    };
+    auto compute_chunk = [&](int c, auto slot) {
+        // k-step 0 of chunk c | stage raw chunk c+1 (register slot) into the other buffer, refill the slot with
+        // chunk c+1+DEPTH | barrier | k-step 1 (its rolling B reads already come from the freshly staged buffer).
+        // One barrier per chunk: a buffer is re-written only after every wave has passed the barrier that follows
+        // the last reads from it.
+        const unsigned char* xb = &xs[c & 1][0] + rd_off;
+        const unsigned char* xn = &xs[(c & 1) ^ 1][0] + rd_off;
+        const int cl = c + 1 + DEPTH < nk ? c + 1 + DEPTH : nk - 1;
+        const int k0n = 2 * c + 1 < nks ? 2 * c + 1 : nks - 1, k1n = 2 * c + 2 < nks ? 2 * c + 2 : nks - 1;
+        kstep(k0n, xb, xb + 4096);
+        if (!(PWS_ABL & 2)) stage_chunk(c + 1, (c & 1) ^ 1, slot);
+        if (!(PWS_ABL & 4)) load_chunk(cl, slot);
+        __syncthreads();
+        kstep(k1n, xb + 4096, xn);
+    };
+#ifdef PWS_STAMP
+    const unsigned long long ts1 = __builtin_readcyclecounter();
+#endif
+    for (int kc = 0; kc < nkp; kc += DEPTH) {
+        compute_chunk(kc, S0{});
+        if constexpr (DEPTH == 2) compute_chunk(kc + 1, std::integral_constant<int, DEPTH - 1>{});
+    }
+#undef PWS_MF
+
+#ifdef PWS_STAMP
+    const unsigned long long ts2 = __builtin_readcyclecounter();
+#endif
+    // ---- epilogue (same accumulator layout as the fp32 kernel): bias, float4 stores, statistics ----
+    constexpr int epi = EPI;
+    const int pxw = px0 + 4 * j;
+    const bool has_bias = g.bias != nullptr;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            // per-row scalars of four rows first (one batch of loads, one wait), then the rows
+            float bb[4], eA[4], eB[4], eS[4], eD[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = (wn * CT + ct) * 32 + q + 8 * r4 + 4 * kg;
+                const int cc = col < Cout ? col : Cout - 1;
+                bb[q] = has_bias ? g.bias[(size_t)n * g.bias_stride_n + cc] : 0.f;
+                if constexpr (EPI == 3) {
+                    const int ci = n * Cout + cc;
+                    eA[q] = g.e0[ci]; eB[q] = g.e1[ci]; eS[q] = g.e2[ci]; eD[q] = g.e3[ci];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * r4 + q;
+                const int col = (wn * CT + ct) * 32 + q + 8 * r4 + 4 * kg;
+                const bool ok = col < Cout;
+                const size_t o = ((size_t)n * Cout + (ok ? col : Cout - 1)) * P + pxw;
+                float4 v = make_float4(acc[0][ct][r] + bb[q], acc[1][ct][r] + bb[q], acc[2][ct][r] + bb[q],
+                                       acc[3][ct][r] + bb[q]);
+                float s0 = 0.f, s1 = 0.f;
+                if constexpr (EPI == 3) {
+                    // du2 = gelu'(A*h2 + B) * (S*dz + D): the SE / GELU backward applied to the fresh accumulator
+                    const float4 x = *(const float4*)(g.aux + o);
+                    v.x = gelu_grad_f(fmaf(eA[q], x.x, eB[q])) * fmaf(eS[q], v.x, eD[q]);
+                    v.y = gelu_grad_f(fmaf(eA[q], x.y, eB[q])) * fmaf(eS[q], v.y, eD[q]);
+                    v.z = gelu_grad_f(fmaf(eA[q], x.z, eB[q])) * fmaf(eS[q], v.z, eD[q]);
+                    v.w = gelu_grad_f(fmaf(eA[q], x.w, eB[q])) * fmaf(eS[q], v.w, eD[q]);
+                    s0 = v.x + v.y + v.z + v.w;
+                    s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
+                } else if constexpr (EPI == 2) {
+                    const float4 x = *(const float4*)(g.aux + o);
+                    s0 = v.x + v.y + v.z + v.w;
+                    s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
+                } else if constexpr (EPI == 1) {
+                    s0 = v.x + v.y + v.z + v.w;
+                    s1 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                }
+                if (ok && (!(PWS_ABL & 1) || v.x == 1.2345e-30f)) *(float4*)(g.out + o) = v;
+                if constexpr (EPI != 0) {
+                    s0 = half_wave_sum_dpp(s0);
+                    s1 = half_wave_sum_dpp(s1);
+                    if (j == 31) { red[col][0] = s0; red[col][1] = s1; }
+                }
+            }
+        }
+    }
+    if constexpr (EPI != 0) {
+        __syncthreads();
+        for (int c = tid; c < COUTP; c += NT)
+            if (c < Cout) g.part[((size_t)n * Cout + c) * gridDim.x + blockIdx.x] = make_float2(red[c][0], red[c][1]);
+    }
+#ifdef PWS_STAMP
+    __syncthreads();
+    if (tid == 0) {   // development: per-block phase durations (cycles) overwrite the head of the output
+        const unsigned long long ts3 = __builtin_readcyclecounter();
+        float* o = g.out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        o[0] = (float)(ts1 - ts0); o[1] = (float)(ts2 - ts1); o[2] = (float)(ts3 - ts2); o[3] = (float)(ts0 & 0xFFFFFF);
+    }
+#endif
+}
+
+#ifndef PWS_PRO
+#error "compile with -DPWS_PRO=<0..4> (uncrtaints_amd/build.py builds one object per prologue kind)"
+#endif
+
+#if PWS_PRO == 0
+// Wp[ks][cotile][part][lane][8 bf16] from W[co][k] (transpose=1) or W[k][co] (transpose=0); zero padded to
+// Kp = 32*ceil(rows_k/32) and cp output channels.  One thread per (ks, cotile, lane): 3 x 16 B.
+__global__ __launch_bounds__(256) void pack_wt_split_kernel(const float* __restrict__ W, int rows_k, int cols_co,
+                                                            int ld, int transpose, int nks, int nct,
+                                                            u32x4_t* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nks * nct * 64) return;
+    const int lane = idx & 63, cot = (idx >> 6) % nct, ks = (idx >> 6) / nct;
+    const int co = cot * 32 + (lane & 31), kb = 16 * ks + 8 * (lane >> 5);
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = kb + q;
+        float v = 0.f;
+        if (k < rows_k && co < cols_co) v = transpose ? W[(size_t)co * ld + k] : W[(size_t)k * ld + co];
+        split3_bf16(v, h[q], m[q], l[q]);
+    }
+    u32x4_t* o = out + (size_t)(ks * nct + cot) * 3 * 64 + lane;
+    o[0] = u32x4_t{pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]), pack_bf16x2(h[4], h[5]), pack_bf16x2(h[6], h[7])};
+    o[64] = u32x4_t{pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7])};
+    o[128] = u32x4_t{pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]), pack_bf16x2(l[4], l[5]), pack_bf16x2(l[6], l[7])};
+}
+
+// k-steps in the packed weights: chunk count padded to even (the DEPTH = 2 kernels compute chunk pairs)
+static int pws_nks(int rows_k) { return 2 * (((rows_k + PWS_KC - 1) / PWS_KC + 1) / 2 * 2); }
+
+size_t pw_split_wt_floats(int rows_k, int cp) {
+    const int nks = pws_nks(rows_k), nct = cp / 32;
+    return (size_t)nks * nct * 3 * 64 * 4;   // 16 B = 4 floats per lane entry
+}
+
+int pw_split_pack(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out, hipStream_t stream) {
+    const int cp = cols_co > 128 ? 256 : 128;
+    const int nks = pws_nks(rows_k), nct = cp / 32;
+    hipLaunchKernelGGL(pack_wt_split_kernel, dim3((nks * nct * 64 + 255) / 256), dim3(256), 0, stream, W, rows_k,
+                       cols_co, ld, transpose, nks, nct, (u32x4_t*)out);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+#endif
+
+template <int EPI>
+static void pws_launch_epi(const PwArgs& g, dim3 grid, int cp, hipStream_t stream) {
+    // prefetch depth 2 where registers allow (CT = 1); the 256-channel tile keeps one chunk in flight
+    if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, 1>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 2>), grid, dim3(256), 0, stream, g);
+}
+
+#define PWS_CAT2(a, b) a##b
+#define PWS_CAT(a, b) PWS_CAT2(a, b)
+int PWS_CAT(pw_split_launch_p, PWS_PRO)(const PwArgs& g, int N, int cp, hipStream_t stream) {
+    if (g.P % PWS_TP) return UNCR_ESHAPE;
+    dim3 grid(g.P / PWS_TP, N);
+    switch (g.epi) {
+        case 0: pws_launch_epi<0>(g, grid, cp, stream); break;
+        case 1: pws_launch_epi<1>(g, grid, cp, stream); break;
+        case 2: pws_launch_epi<2>(g, grid, cp, stream); break;
+        case 3: pws_launch_epi<3>(g, grid, cp, stream); break;
+        default: return UNCR_EINVAL;
+    }
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}

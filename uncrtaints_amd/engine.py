@@ -134,11 +134,12 @@ def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor) -> 
 
 
 def pack_wt(W2d: Tensor, transpose: bool) -> Tensor:
-    """W2d [R][Ccols] -> zero-padded Wt[Kpad][COUTP] with Wt[k][co] = W[co][k] (transpose) or W[k][co]."""
+    """W2d [R][Ccols] -> the packed, zero-padded weight operand of pw_gemm for Wt[k][co] = W[co][k] (transpose) or
+    W[k][co] (opaque layout: fp32 [Kpad][COUTP] for Cout <= 64, pre-split bf16 MFMA fragments otherwise)."""
     W2d = W2d.contiguous()
     R, Cc = W2d.shape
     rows_k, cols_co = (Cc, R) if transpose else (R, Cc)
-    out = _f32((hb.query("uncr_pw_kpad", rows_k), hb.query("uncr_pw_coutp", cols_co)), W2d.device)
+    out = _f32((hb.query("uncr_pw_wt_floats", rows_k, cols_co),), W2d.device)
     hb.call("uncr_pack_wt", W2d, rows_k, cols_co, Cc, 1 if transpose else 0, out, _stream())
     return out
 

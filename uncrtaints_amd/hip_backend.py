@@ -11,7 +11,7 @@ from typing import Dict, List, Tuple
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "uncr_hip.h")
-LIB_PATH = os.path.join(HERE, "lib", "libuncr_hip.so")
+LIB_PATH = os.environ.get("UNCR_HIP_LIB") or os.path.join(HERE, "lib", "libuncr_hip.so")   # env: development builds only
 
 _CTYPES = {
     "int": ctypes.c_int,
