@@ -46,8 +46,9 @@ def _worker(rank, world, port, q):
         loss = ((dp(xs) - ys) ** 2).mean()
         loss.backward()
         dp.finish()
-    grads = {n: p.grad.clone() for n, p in m.named_parameters()}
-    weights = {n: p.detach().clone() for n, p in m.named_parameters()}
+    # numpy, not tensors: torch tensors travel through mp queues as shared-memory handles that die with the sender
+    grads = {n: p.grad.numpy().copy() for n, p in m.named_parameters()}
+    weights = {n: p.detach().numpy().copy() for n, p in m.named_parameters()}
     q.put((rank, grads, weights))
     dist.barrier()
     dist.destroy_process_group()
@@ -64,7 +65,8 @@ def test_bucketed_allreduce_matches_single_process():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, g0, w0), (_, g1, w1) = res
+    (_, g0, w0), (_, g1, w1) = [(r, {k: torch.from_numpy(v) for k, v in g.items()},
+                                 {k: torch.from_numpy(v) for k, v in w.items()}) for r, g, w in res]
     for n in g0:
         assert torch.allclose(g0[n], g1[n], atol=1e-7), n        # every rank holds the same averaged gradient
         assert torch.equal(w0[n], w1[n]), n                      # broadcast made the replicas identical
