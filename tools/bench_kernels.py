@@ -58,11 +58,14 @@ def main():
             x = torch.randn(1, Cin, Pn, device=dev)
             Wt = E.pack_wt(torch.randn(Cout, Cin, device=dev) * 0.05, transpose=True)
             out = torch.empty(1, Cout, Pn, device=dev)
-            for _ in range(3): E.pw_gemm(x, Wt, 1, Cin, Cout, Pn, out=out)
-            torch.cuda.synchronize()
-            s = out.view(-1)[: nb * 4].view(nb, 4).cpu()
-            print(f"blocks={nb}: prologue {s[:,0].mean():.0f}  loop {s[:,1].mean():.0f}  epilogue {s[:,2].mean():.0f} cycles (readcyclecounter ticks); "
-                  f"loop min/max {s[:,1].min():.0f}/{s[:,1].max():.0f}")
+            st = torch.zeros(4096 * 4, device=dev)
+            fn = lambda: E.pw_gemm(x, Wt, 1, Cin, Cout, Pn, out=out, ek=(None, None, None, st))
+            ms = timeit(fn, 10)
+            s = st.view(-1, 4).cpu(); s = s[s[:, 3] > 0]
+            tiles = s[:, 3].sum().item()
+            print(f"tiles={nb} blocks={len(s)} wall {ms*1e3:.1f} us: prologue {s[:,0].mean():.0f}  loop+epilogues {s[:,1].mean():.0f} "
+                  f"(per tile {(s[:,1] / s[:,3]).mean():.0f}, of which epilogue {(s[:,2] / s[:,3]).mean():.0f}) ticks; "
+                  f"-> {(s[:,:2].sum(1)).mean()/ms/1e3:.0f} ticks/us if blocks span the kernel")
     elif what == "traffic":
         # one launch sequence of the step's dominant kernels at the bench shapes, for rocprofv3 --pmc passes
         import json

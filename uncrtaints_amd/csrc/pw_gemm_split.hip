@@ -34,6 +34,12 @@
 // PRO / EPI are compile-time: with run-time switches every staged element and every stored row carries a branch
 // tree, the kernel grows to ~60 KB of code (instruction-cache misses at every jump) and the per-row coefficient
 // loads each get their own vmcnt(0) -- measured: an 11k-cycle epilogue next to a 14k-cycle MFMA loop.
+//
+// Persistent: grid = (blocks per frame, frames) with about two blocks per CU in total; block b of a frame walks the
+// pixel tiles b, b + G, b + 2G, ... and the chunk pipeline (raw chunk c+1+DEPTH in flight in registers, chunk c+1
+// staged in LDS, chunk c under the MFMAs, A/B operands of the next k-step rolling in) runs straight across tile
+// boundaries: when a tile's epilogue stores are issued, the next tile's first chunks and weights are already there.
+// A block's two HBM streams therefore never stop for a prologue, a block relaunch or a store acknowledgement.
 template <int CT, int PRO, int EPI, int DEPTH>
 __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     constexpr int NT = 256, WN = 4;
@@ -44,45 +50,73 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char xs[2][PWS_BUF];
     __shared__ float cf[3][256];
     __shared__ float red[COUTP][2];
+    __shared__ float ecf[EPI == 3 ? 5 : 1][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D
 
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar: row addresses stay in SGPRs
     const int j = lane & 31, kg = lane >> 5;
     const int n = blockIdx.y;
-    const int px0 = blockIdx.x * PWS_TP;
+    const int Cin = g.Cin, Cout = g.Cout, P = g.P;
+    const int ntile = P / PWS_TP;                                    // pixel tiles of the frame
+    const int G = gridDim.x, bx = blockIdx.x;
+    const int nt = (ntile - bx + G - 1) / G;                         // tiles of this block (>= 1: G <= ntile)
+    const int nk = (Cin + PWS_KC - 1) / PWS_KC;          // chunks that hold data
+    const int nkp = (nk + DEPTH - 1) / DEPTH * DEPTH;     // chunks computed per tile (padding chunks are all-zero)
 #ifdef PWS_STAMP
     const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
-    const int Cin = g.Cin, Cout = g.Cout, P = g.P;
-    const int nk = (Cin + PWS_KC - 1) / PWS_KC;          // chunks that hold data
-    const int nkp = (nk + DEPTH - 1) / DEPTH * DEPTH;     // chunks computed (padding chunks are all-zero)
-    constexpr int pro = PRO;
 
+    // Every optional pointer is read branch-free (a null pointer reads a dummy location and the value is replaced by
+    // a select): a load under a branch makes hipcc fall back to s_waitcnt vmcnt(0) at the join, and on gfx9 the
+    // stores share that counter -- in the epilogue that serialised every row group behind all earlier stores.
     if constexpr (PRO != PRO_NONE) {
+        const float* p0 = g.k0 ? g.k0 + (size_t)n * Cin : g.in;
+        const float* p1 = g.k1 ? g.k1 + (size_t)n * Cin : g.in;
+        const float* p2 = g.k2 ? g.k2 + (size_t)n * Cin : g.in;
         for (int i = tid; i < Cin; i += NT) {
-            const float a = g.k0 ? g.k0[n * Cin + i] : 1.f;
-            const float b = g.k1 ? g.k1[n * Cin + i] : 0.f;
-            const float c = g.k2 ? g.k2[n * Cin + i] : (PRO == PRO_AFFINE_GELU ? 1.f : 0.f);
-            cf[0][i] = a; cf[1][i] = b; cf[2][i] = c;
+            const float a = p0[i], b = p1[i], c = p2[i];
+            cf[0][i] = g.k0 ? a : 1.f;
+            cf[1][i] = g.k1 ? b : 0.f;
+            cf[2][i] = g.k2 ? c : (PRO == PRO_AFFINE_GELU ? 1.f : 0.f);
+        }
+    }
+    {
+        const float* pb = g.bias ? g.bias + (size_t)n * g.bias_stride_n : g.in;
+        for (int c = tid; c < COUTP; c += NT) {
+            const int cc = c < Cout ? c : Cout - 1;
+            const float b = pb[g.bias ? cc : 0];
+            ecf[0][c] = g.bias ? b : 0.f;
+            if constexpr (EPI == 3) {
+                const int ci = n * Cout + cc;
+                ecf[1][c] = g.e0[ci]; ecf[2][c] = g.e1[ci]; ecf[3][c] = g.e2[ci]; ecf[4][c] = g.e3[ci];
+            }
         }
     }
 
-    // staging ownership: rows 4*cig .. 4*cig+3 of the chunk, pixels 4*sj .. 4*sj+3
+    // staging ownership: rows 4*cig .. 4*cig+3 of the chunk, pixels 4*sj .. 4*sj+3 of the tile
     const int sj = tid & 31, cig = tid >> 5;
-    const float* inb = g.in + (size_t)n * Cin * P + px0 + 4 * sj;
-    const float* in2b = g.in2 ? g.in2 + (size_t)n * Cin * P + px0 + 4 * sj : nullptr;
+    const float* inb = g.in + (size_t)n * Cin * P + 4 * sj;
+    const float* in2b = g.in2 ? g.in2 + (size_t)n * Cin * P + 4 * sj : inb;
     // LDS byte offset of this thread's 8-B half-slot for (part 0, e 0): ks = cig>>2, kg = (cig>>1)&1, half = cig&1
     const int st_off = ((cig >> 2) * 2 + ((cig >> 1) & 1)) * 2048 + sj * 16 + (cig & 1) * 8;
 
+    // position in the block's chunk stream: chunk c of its ti-th tile.  Positions past the end are clamped to the
+    // last tile for the loads (re-reads, never consumed) -- no branches around memory operations.
+    struct Pos { int c, ti; };
+    auto advance = [&](Pos& p) { const bool wrap = p.c + 1 == nkp; p.c = wrap ? 0 : p.c + 1; p.ti += wrap ? 1 : 0; };
+    auto tile_px = [&](int ti) { return (bx + (ti < nt ? ti : nt - 1) * G) * PWS_TP; };
+
     float4 pre[DEPTH][4], pre2[PRE2 ? DEPTH : 1][4];
     // rows past Cin re-read row 0 (branch-free; they are zeroed at staging)
-    auto load_chunk = [&](int kc, auto slot) {
+    auto load_chunk = [&](const Pos& p, auto slot) {
         constexpr int S = decltype(slot)::value;
+        const int px = tile_px(p.ti);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int k = kc * PWS_KC + 4 * cig + r;
+            const int k = p.c * PWS_KC + 4 * cig + r;
             const int kk = k < Cin ? k : 0;
-            pre[S][r] = *(const float4*)(inb + (size_t)kk * P);
-            if constexpr (PRE2) pre2[S][r] = *(const float4*)(in2b + (size_t)kk * P);
+            pre[S][r] = *(const float4*)(inb + (size_t)kk * P + px);
+            if constexpr (PRE2) pre2[S][r] = *(const float4*)(in2b + (size_t)kk * P + px);
         }
     };
     auto stage_chunk = [&](int kc, int buf, auto slot) {
@@ -118,25 +152,30 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     };
 
     f32x16 acc[4][CT];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[e][ct][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[e][ct][r] = 0.f;
+    };
+    zero_acc();
 
     // A fragments: Wp[ks][cotile][part][lane] (16 B each)
     const u32x4_t* wp = (const u32x4_t*)g.Wt + (size_t)(wn * CT) * 3 * 64 + lane;
     auto lda = [&](int ks, int ct, int part) { return wp[((size_t)(ks * NCT + ct) * 3 + part) * 64]; };
     u32x4_t ah[CT], am[CT], al[CT];
     using S0 = std::integral_constant<int, 0>;
-    load_chunk(0, S0{});
+    using S1 = std::integral_constant<int, DEPTH - 1>;
+    Pos lp{0, 0};                       // next chunk to request from HBM
+    load_chunk(lp, S0{}); advance(lp);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
-    __syncthreads();   // cf visible
+    __syncthreads();   // cf / ecf visible
     stage_chunk(0, 0, S0{});
-    load_chunk(1 < nk ? 1 : nk - 1, S0{});
-    if constexpr (DEPTH == 2) load_chunk(2 < nk ? 2 : nk - 1, std::integral_constant<int, DEPTH - 1>{});
+    load_chunk(lp, S0{}); advance(lp);
+    if constexpr (DEPTH == 2) { load_chunk(lp, S1{}); advance(lp); }
     __syncthreads();
 
     const int rd_off = kg * 2048 + j * 16;   // + (part*2+ks)*4096 + e*512
@@ -146,9 +185,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     u32x4_t bh[4], bm[4], bl[4];
     auto ldb = [&](const unsigned char* p0, int part, u32x4_t (&b)[4]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            b[e] = *(const u32x4_t*)(p0 + part * 8192 + e * 512);   // one ds_read_b128 = the lane's 8 k-values
-        }
+        for (int e = 0; e < 4; ++e) b[e] = *(const u32x4_t*)(p0 + part * 8192 + e * 512);   // one ds_read_b128 = the lane's 8 k-values
     };
     ldb(&xs[0][0] + rd_off, 1, bm);
     ldb(&xs[0][0] + rd_off, 0, bh);
@@ -157,8 +194,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) _Pragma("unroll") for (int e = 0; e < 4; ++e)           \
         if (!(PWS_ABL & 16)) acc[e][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A[ct]), \
                                                              __builtin_bit_cast(bf16x8_t, B[e]), acc[e][ct], 0, 0, 0)
-    // one k-step: six (A part, B part) products, smallest terms first; nb = LDS address of the next k-step's B
-    auto kstep = [&](int ksn, const unsigned char* cb, const unsigned char* nb) {
+    // one k-step: six (A part, B part) products; cb / nb = LDS address of this / the next k-step's B operand
+    auto kstep = [&](int ksn, const unsigned char* cb, const unsigned char* nb, auto roll) {
+        constexpr bool ROLL = decltype(roll)::value;   // false on a tile's last k-step: operands are re-read after the epilogue
         // sched_barrier(0): hipcc must not move anything across -- left alone it batches the A re-loads right before
         // their consumers and sinks the ds_reads to theirs, which serialises every latency behind the MFMAs.
         // The low B part is needed by one product only: it is read at the top of its own k-step (one product of
@@ -170,114 +208,149 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         PWS_MF(ah, bl); PWS_SB();
         PWS_MF(ah, bh); PWS_SB();
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) if (!(PWS_ABL & 8)) ah[ct] = lda(ksn, ct, 0);
+        for (int ct = 0; ct < CT; ++ct) if (ROLL && !(PWS_ABL & 8)) ah[ct] = lda(ksn, ct, 0);
         PWS_SB();
         PWS_MF(am, bh); PWS_SB();
         PWS_MF(am, bm); PWS_SB();
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) if (!(PWS_ABL & 8)) am[ct] = lda(ksn, ct, 1);
-        if (!(PWS_ABL & 32)) ldb(nb, 1, bm);
+        for (int ct = 0; ct < CT; ++ct) if (ROLL && !(PWS_ABL & 8)) am[ct] = lda(ksn, ct, 1);
+        if (ROLL && !(PWS_ABL & 32)) ldb(nb, 1, bm);
         PWS_SB();
         PWS_MF(al, bh); PWS_SB();
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) if (!(PWS_ABL & 8)) al[ct] = lda(ksn, ct, 2);
-        if (!(PWS_ABL & 32)) ldb(nb, 0, bh);
+        for (int ct = 0; ct < CT; ++ct) if (ROLL && !(PWS_ABL & 8)) al[ct] = lda(ksn, ct, 2);
+        if (ROLL && !(PWS_ABL & 32)) ldb(nb, 0, bh);
         PWS_SB();
 #undef PWS_SB
     };
-    auto compute_chunk = [&](int c, auto slot) {
-        // k-step 0 of chunk c | stage raw chunk c+1 (register slot) into the other buffer, refill the slot with
-        // chunk c+1+DEPTH | barrier | k-step 1 (its rolling B reads already come from the freshly staged buffer).
-        // One barrier per chunk: a buffer is re-written only after every wave has passed the barrier that follows
-        // the last reads from it.
-        const unsigned char* xb = &xs[c & 1][0] + rd_off;
-        const unsigned char* xn = &xs[(c & 1) ^ 1][0] + rd_off;
-        const int cl = c + 1 + DEPTH < nk ? c + 1 + DEPTH : nk - 1;
-        const int k0n = 2 * c + 1 < nks ? 2 * c + 1 : nks - 1, k1n = 2 * c + 2 < nks ? 2 * c + 2 : nks - 1;
-        kstep(k0n, xb, xb + 4096);
-        if (!(PWS_ABL & 2)) stage_chunk(c + 1, (c & 1) ^ 1, slot);
-        if (!(PWS_ABL & 4)) load_chunk(cl, slot);
+    int par = 0;   // LDS buffer holding the chunk under the MFMAs
+    using Roll = std::true_type;
+    using NoRoll = std::false_type;
+    auto compute_chunk = [&](int c, auto slot, auto roll_last) {
+        // k-step 0 of chunk c | stage the raw chunk held in the register slot (the stream's next chunk) into the other
+        // buffer, refill the slot from HBM | barrier | k-step 1 (its rolling B reads already come from the freshly
+        // staged buffer).  One barrier per chunk: a buffer is re-written only after every wave has passed the barrier
+        // that follows the last reads from it.
+        const unsigned char* xb = &xs[par][0] + rd_off;
+        const unsigned char* xn = &xs[par ^ 1][0] + rd_off;
+        const int cn = c + 1 == nkp ? 0 : c + 1;                 // the next chunk of the stream (wraps into the next tile)
+        kstep(2 * c + 1, xb, xb + 4096, Roll{});
+        if (!(PWS_ABL & 2)) stage_chunk(cn, par ^ 1, slot);
+        if (!(PWS_ABL & 4)) { load_chunk(lp, slot); advance(lp); }
         __syncthreads();
-        kstep(k1n, xb + 4096, xn);
+        kstep(2 * c + 2 == nks ? 0 : 2 * c + 2, xb + 4096, xn, roll_last);
+        par ^= 1;
     };
-#ifdef PWS_STAMP
-    const unsigned long long ts1 = __builtin_readcyclecounter();
-#endif
-    for (int kc = 0; kc < nkp; kc += DEPTH) {
-        compute_chunk(kc, S0{});
-        if constexpr (DEPTH == 2) compute_chunk(kc + 1, std::integral_constant<int, DEPTH - 1>{});
-    }
-#undef PWS_MF
 
 #ifdef PWS_STAMP
-    const unsigned long long ts2 = __builtin_readcyclecounter();
+    const unsigned long long ts1 = __builtin_readcyclecounter();
+    unsigned long long tepi = 0;
 #endif
-    // ---- epilogue (same accumulator layout as the fp32 kernel): bias, float4 stores, statistics ----
-    constexpr int epi = EPI;
-    const int pxw = px0 + 4 * j;
-    const bool has_bias = g.bias != nullptr;
+    for (int ti = 0; ti < nt; ++ti) {
+        for (int kc = 0; kc + DEPTH < nkp; kc += DEPTH) {
+            compute_chunk(kc, S0{}, Roll{});
+            if constexpr (DEPTH == 2) compute_chunk(kc + 1, S1{}, Roll{});
+        }
+        // the tile's last chunk(s): no operand roll-over on the final k-step (frees 56 registers for the epilogue)
+        if constexpr (DEPTH == 2) { compute_chunk(nkp - 2, S0{}, Roll{}); compute_chunk(nkp - 1, S1{}, NoRoll{}); }
+        else compute_chunk(nkp - 1, S0{}, NoRoll{});
+
+#ifdef PWS_STAMP
+        const unsigned long long te0 = __builtin_readcyclecounter();
+#endif
+        // ---- tile epilogue (same accumulator layout as the fp32 kernel) ----
+        // pass 1: bias / fused backward transform in place in the accumulators + statistics (aux loads in batches)
+        // pass 2: float4 row stores, fire and forget; the next tile's chunks and weights were requested before them
+        const int tile = bx + ti * G;
+        // address of (row, lane) = uniform row base (SGPR arithmetic) + one per-lane element offset
+        const int loff = 4 * kg * P + tile * PWS_TP + 4 * j;
+        int nco = n * Cout;
+        asm volatile("" : "+s"(nco));   // keep the 2 x 32 row bases from being hoisted out of the tile loop (SGPR spills)
+        auto row_of = [&](int ct, int r) { return (wn * CT + ct) * 32 + (r & 3) + 8 * (r >> 2); };   // + 4*kg per lane
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            // per-row scalars of four rows first (one batch of loads, one wait), then the rows
-            float bb[4], eA[4], eB[4], eS[4], eD[4];
+            for (int rb = 0; rb < 16; rb += 8) {
+                float4 xa[(EPI == 2 || EPI == 3) ? 8 : 1];   // one request batch = 8 rows
+                if constexpr (EPI == 2 || EPI == 3) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = (wn * CT + ct) * 32 + q + 8 * r4 + 4 * kg;
-                const int cc = col < Cout ? col : Cout - 1;
-                bb[q] = has_bias ? g.bias[(size_t)n * g.bias_stride_n + cc] : 0.f;
-                if constexpr (EPI == 3) {
-                    const int ci = n * Cout + cc;
-                    eA[q] = g.e0[ci]; eB[q] = g.e1[ci]; eS[q] = g.e2[ci]; eD[q] = g.e3[ci];
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = rb + q;
+                        const int rw = row_of(ct, r);            // rows past Cout (padded tiles) re-read the last valid row
+                        const int rc = rw + 4 < Cout ? rw : (Cout > 8 ? Cout - 8 : 0);
+                        xa[q] = *(const float4*)(g.aux + (size_t)(nco + rc) * P + loff);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = 4 * r4 + q;
-                const int col = (wn * CT + ct) * 32 + q + 8 * r4 + 4 * kg;
-                const bool ok = col < Cout;
-                const size_t o = ((size_t)n * Cout + (ok ? col : Cout - 1)) * P + pxw;
-                float4 v = make_float4(acc[0][ct][r] + bb[q], acc[1][ct][r] + bb[q], acc[2][ct][r] + bb[q],
-                                       acc[3][ct][r] + bb[q]);
-                float s0 = 0.f, s1 = 0.f;
-                if constexpr (EPI == 3) {
-                    // du2 = gelu'(A*h2 + B) * (S*dz + D): the SE / GELU backward applied to the fresh accumulator
-                    const float4 x = *(const float4*)(g.aux + o);
-                    v.x = gelu_grad_f(fmaf(eA[q], x.x, eB[q])) * fmaf(eS[q], v.x, eD[q]);
-                    v.y = gelu_grad_f(fmaf(eA[q], x.y, eB[q])) * fmaf(eS[q], v.y, eD[q]);
-                    v.z = gelu_grad_f(fmaf(eA[q], x.z, eB[q])) * fmaf(eS[q], v.z, eD[q]);
-                    v.w = gelu_grad_f(fmaf(eA[q], x.w, eB[q])) * fmaf(eS[q], v.w, eD[q]);
-                    s0 = v.x + v.y + v.z + v.w;
-                    s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
-                } else if constexpr (EPI == 2) {
-                    const float4 x = *(const float4*)(g.aux + o);
-                    s0 = v.x + v.y + v.z + v.w;
-                    s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
-                } else if constexpr (EPI == 1) {
-                    s0 = v.x + v.y + v.z + v.w;
-                    s1 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-                }
-                if (ok && (!(PWS_ABL & 1) || v.x == 1.2345e-30f)) *(float4*)(g.out + o) = v;
-                if constexpr (EPI != 0) {
-                    s0 = half_wave_sum_dpp(s0);
-                    s1 = half_wave_sum_dpp(s1);
-                    if (j == 31) { red[col][0] = s0; red[col][1] = s1; }
+                for (int q = 0; q < 8; ++q) {
+                    const int r = rb + q;
+                    const int col = row_of(ct, r) + 4 * kg;
+                    const float bb = ecf[0][col];
+                    float4 v = make_float4(acc[0][ct][r] + bb, acc[1][ct][r] + bb, acc[2][ct][r] + bb, acc[3][ct][r] + bb);
+                    float s0 = 0.f, s1 = 0.f;
+                    if constexpr (EPI == 3) {
+                        // du2 = gelu'(A*h2 + B) * (S*dz + D): the SE / GELU backward applied to the fresh accumulator
+                        const float4 x = xa[q];
+                        const float eA = ecf[1][col], eB = ecf[2][col], eS = ecf[3][col], eD = ecf[4][col];
+                        v.x = gelu_grad_f(fmaf(eA, x.x, eB)) * fmaf(eS, v.x, eD);
+                        v.y = gelu_grad_f(fmaf(eA, x.y, eB)) * fmaf(eS, v.y, eD);
+                        v.z = gelu_grad_f(fmaf(eA, x.z, eB)) * fmaf(eS, v.z, eD);
+                        v.w = gelu_grad_f(fmaf(eA, x.w, eB)) * fmaf(eS, v.w, eD);
+                        s0 = v.x + v.y + v.z + v.w;
+                        s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
+                    } else if constexpr (EPI == 2) {
+                        const float4 x = xa[q];
+                        s0 = v.x + v.y + v.z + v.w;
+                        s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
+                    } else if constexpr (EPI == 1) {
+                        s0 = v.x + v.y + v.z + v.w;
+                        s1 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                    }
+                    acc[0][ct][r] = v.x; acc[1][ct][r] = v.y; acc[2][ct][r] = v.z; acc[3][ct][r] = v.w;
+                    if constexpr (EPI != 0) {
+                        s0 = half_wave_sum_dpp(s0);
+                        s1 = half_wave_sum_dpp(s1);
+                        if (j == 31) { red[col][0] = s0; red[col][1] = s1; }
+                    }
                 }
             }
         }
-    }
-    if constexpr (EPI != 0) {
-        __syncthreads();
-        for (int c = tid; c < COUTP; c += NT)
-            if (c < Cout) g.part[((size_t)n * Cout + c) * gridDim.x + blockIdx.x] = make_float2(red[c][0], red[c][1]);
-    }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rw = row_of(ct, r);
+                const float4 v = make_float4(acc[0][ct][r], acc[1][ct][r], acc[2][ct][r], acc[3][ct][r]);
+                if (rw + 4 * kg < Cout && (!(PWS_ABL & 1) || v.x == 1.2345e-30f))
+                    *(float4*)(g.out + (size_t)(nco + rw) * P + loff) = v;
+            }
+        }
+        zero_acc();
+        // operands of the next tile's first k-step (its chunk 0 is already staged in xs[par])
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
+        ldb(&xs[par][0] + rd_off, 1, bm);
+        ldb(&xs[par][0] + rd_off, 0, bh);
+        if constexpr (EPI != 0) {
+            // red is next written by the following tile's pass 1, at least one chunk barrier after these reads
+            __syncthreads();
+            for (int c = tid; c < COUTP; c += NT)
+                if (c < Cout) g.part[((size_t)n * Cout + c) * ntile + tile] = make_float2(red[c][0], red[c][1]);
+        }
 #ifdef PWS_STAMP
+        tepi += __builtin_readcyclecounter() - te0;
+#endif
+    }
+#undef PWS_MF
+#ifdef PWS_STAMP
+    const unsigned long long ts2 = __builtin_readcyclecounter();
+    __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
     __syncthreads();
-    if (tid == 0) {   // development: per-block phase durations (cycles) overwrite the head of the output
+    if (tid == 0 && g.e3 && EPI != 3) {   // development: per-block phase durations (cycles) -> e3
         const unsigned long long ts3 = __builtin_readcyclecounter();
-        float* o = g.out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
-        o[0] = (float)(ts1 - ts0); o[1] = (float)(ts2 - ts1); o[2] = (float)(ts3 - ts2); o[3] = (float)(ts0 & 0xFFFFFF);
+        float* o = const_cast<float*>(g.e3) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        o[0] = (float)(ts1 - ts0); o[1] = (float)(ts2 - ts1); o[2] = (float)tepi; o[3] = (float)nt;
     }
 #endif
 }
@@ -339,7 +412,20 @@ static void pws_launch_epi(const PwArgs& g, dim3 grid, int cp, hipStream_t strea
 #define PWS_CAT(a, b) PWS_CAT2(a, b)
 int PWS_CAT(pw_split_launch_p, PWS_PRO)(const PwArgs& g, int N, int cp, hipStream_t stream) {
     if (g.P % PWS_TP) return UNCR_ESHAPE;
-    dim3 grid(g.P / PWS_TP, N);
+    // persistent: about two resident blocks per CU in total, split evenly over the frames
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, ncu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+            ncu = 256;
+        slots = 2 * ncu;
+    }
+    const int ntile = g.P / PWS_TP;
+    int bpf = slots / N;
+    if (bpf < 1) bpf = 1;
+    if (bpf > ntile) bpf = ntile;
+    dim3 grid(bpf, N);
     switch (g.epi) {
         case 0: pws_launch_epi<0>(g, grid, cp, stream); break;
         case 1: pws_launch_epi<1>(g, grid, cp, stream); break;
