@@ -93,8 +93,10 @@ int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, float* out,
 int uncr_wgrad_shape(int Cd, int Cx, int* cop, int* cip);
 int uncr_pw_wgrad(const float* d, const float* d2, const float* x, const float* x2, const float* dk0,
                   const float* dk1, const float* dk2, const float* xk0, const float* xk1, const float* xk2,
-                  float* part, float* rs_part, int N, int Cd, int Cx, int P, int PXB, int pro_d, int pro_x,
+                  float* part /* [N*NBX][COP][CIP] */, float* rs_part, int N, int Cd, int Cx, int P,
+                  int NBX /* blocks (partials) per frame, from uncr_wgrad_nbx */, int pro_d, int pro_x,
                   hipStream_t stream);
+int uncr_wgrad_nbx(int N, int Cd, int Cx, int P, int pro_d, int pro_x, int rowsum);
 int uncr_wgrad_reduce(const float* part, int n_out, int nblk_per_out, int COP, int CIP, int Cout, int Cin,
                       float* out, hipStream_t stream);
 

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libuncr_hip.so")
 # (source stem, extra flags, object stem); the split GEMM is compiled once per prologue kind (compile-time PRO)
-SOURCES = [(s, [], s) for s in ["norm", "ew", "pw_gemm", "dwconv", "se", "ltae", "aggregate", "mgnll"]] + \
+SOURCES = [(s, [], s) for s in ["norm", "ew", "pw_gemm", "pw_wgrad_split", "dwconv", "se", "ltae", "aggregate", "mgnll"]] + \
           [("pw_gemm_split", [f"-DPWS_PRO={p}"], f"pw_gemm_split_p{p}") for p in range(5)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 

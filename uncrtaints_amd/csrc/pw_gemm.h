@@ -50,3 +50,10 @@ int pw_split_launch_p3(const PwArgs& g, int N, int cp, hipStream_t stream);
 int pw_split_launch_p4(const PwArgs& g, int N, int cp, hipStream_t stream);
 int pw_split_pack(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out, hipStream_t stream);
 size_t pw_split_wt_floats(int rows_k, int cp);
+
+// pw_wgrad_split.hip
+int pw_wgrad_split_nbx(int N, int P);
+bool pw_wgrad_split_supported(int Cd, int Cx, int pro_d, int pro_x, bool rowsum);
+int pw_wgrad_split_launch(const float* d, const float* d2, const float* x, const float* dk0, const float* dk1,
+                          const float* dk2, const float* xk0, const float* xk1, const float* xk2, float* part, int N,
+                          int Cd, int Cx, int P, int nbx, int pro_x, hipStream_t stream);

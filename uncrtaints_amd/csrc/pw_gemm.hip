@@ -510,17 +510,33 @@ static int wg_shape(int Cd, int Cx, int* cop, int* cip) {
 
 extern "C" int uncr_wgrad_shape(int Cd, int Cx, int* cop, int* cip) { return wg_shape(Cd, Cx, cop, cip); }
 
+// blocks (= partial products) per frame that uncr_pw_wgrad will use for this problem
+extern "C" int uncr_wgrad_nbx(int N, int Cd, int Cx, int P, int pro_d, int pro_x, int rowsum) {
+    if (N <= 0 || P <= 0 || P % 32) return -1;
+    if (g_split && pw_wgrad_split_supported(Cd, Cx, pro_d, pro_x, rowsum != 0)) return pw_wgrad_split_nbx(N, P);
+    // fp32-MFMA kernel: equal pixel ranges, aim for ~512-1024 blocks on the 256 CUs
+    for (int cand = 4096; cand >= 256; cand >>= 1)
+        if (P % cand == 0 && (long long)N * (P / cand) >= 512) return P / cand;
+    return P % 256 == 0 ? P / 256 : P / 32;
+}
+
 extern "C" int uncr_pw_wgrad(const float* d, const float* d2, const float* x, const float* x2, const float* dk0,
                              const float* dk1, const float* dk2, const float* xk0, const float* xk1,
-                             const float* xk2, float* part, float* rs_part, int N, int Cd, int Cx, int P, int PXB,
+                             const float* xk2, float* part, float* rs_part, int N, int Cd, int Cx, int P, int NBX,
                              int pro_d, int pro_x, hipStream_t stream) {
     int cop, cip;
     const int shp = wg_shape(Cd, Cx, &cop, &cip);
-    if (shp < 0 || N <= 0) return UNCR_ESHAPE;
-    if (PXB <= 0 || PXB % 32 || P % PXB) return UNCR_ESHAPE;
+    if (shp < 0 || N <= 0 || NBX <= 0) return UNCR_ESHAPE;
     if (!d || !x || !part) return UNCR_EINVAL;
     if (pro_d == PRO_NORMBWD && !d2) return UNCR_EINVAL;
     if (pro_x == PRO_NORMBWD) return UNCR_EINVAL;   // norm-backward form is only built for the D operand
+    if (g_split && pw_wgrad_split_supported(Cd, Cx, pro_d, pro_x, rs_part != nullptr)) {
+        if (!dk0 || !dk1 || !dk2 || !xk0 || !xk1) return UNCR_EINVAL;
+        return pw_wgrad_split_launch(d, d2, x, dk0, dk1, dk2, xk0, xk1, xk2, part, N, Cd, Cx, P, NBX, pro_x, stream);
+    }
+    if (P % NBX) return UNCR_ESHAPE;
+    const int PXB = P / NBX;
+    if (PXB % 32) return UNCR_ESHAPE;
     WgArgs g{d, d2, x, x2, dk0, dk1, dk2, xk0, xk1, xk2, part, rs_part, Cd, Cx, P, PXB, pro_d, pro_x};
     dim3 grid(P / PXB, N);
     const size_t lds = (size_t)((cop + cip) * 36 + 3 * (cop + cip)) * sizeof(float);

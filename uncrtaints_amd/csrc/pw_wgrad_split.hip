@@ -1,0 +1,269 @@
+// Weight gradient of the wide 1x1 convolutions on the bf16 matrix pipe with fp32 results (same exact 3-way
+// operand split and six products as pw_gemm_split.hip):
+//
+//     dW[co, ci] = sum_{p} fD(d[n, co, p]) * fX(x[n, ci, p])        (one partial [COP][CIP] per block)
+//
+// The contraction axis (pixels) is the contiguous one of BOTH operands, so after the prologue + split a thread's
+// float4 (4 pixels of one row) is 3 x 8 B of k-consecutive bf16 and an MFMA lane's operand (8 k-values of one
+// row) is one ds_read_b128 -- no transposes anywhere.
+//
+// Block = 8 waves (one block per CU, 256 VGPRs per wave), each wave owns a 64 x 64 corner of the [COP][CIP]
+// product (4 accumulator tiles), the block walks its share of the frame's 32-pixel chunks:
+//   raw chunk c+2 in flight (registers) | chunk c+1 being staged into the other LDS buffer, one float4 piece after
+//   each 4-MFMA group of k-step 0 | barrier | k-step 1, whose operand prefetches already read the new buffer.
+// The MFMA stream never waits on HBM: the only vm-counter traffic in the loop are those raw loads, each consumed a
+// full chunk after it was issued.  LDS bytes of one buffer: [part 3][plane 4 = ks*2+kg][row R][16 B], plane stride
+// padded by 32 B (bank spread of the 8-B staging writes).
+#include "pw_gemm.h"
+#include <type_traits>
+
+struct WgsArgs {
+    const float* d;
+    const float* d2;
+    const float* x;
+    const float* dk0; const float* dk1; const float* dk2;   // [N*Cd]
+    const float* xk0; const float* xk1; const float* xk2;   // [N*Cx]
+    float* part;       // [N*G][COP][CIP]
+    int Cd, Cx, P;
+};
+
+template <int PRO>
+__device__ __forceinline__ float wgs_pro(float v, float v2, float c0, float c1, float c2) {
+    if constexpr (PRO == PRO_AFFINE) return fmaf(c0, v, c1);
+    else if constexpr (PRO == PRO_AFFINE_GELU) return c2 * gelu_f(fmaf(c0, v, c1));
+    else if constexpr (PRO == PRO_NORMBWD) return fmaf(c0, v, fmaf(c1, v2, c2));
+    else if constexpr (PRO == PRO_AFFINE_RELU) return fmaxf(fmaf(c0, v, c1), 0.f);
+    else return v;
+}
+
+template <int WCO, int WCI, int PRO_D, int PRO_X>
+__global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
+    constexpr int NT = 512;
+    constexpr int COP = 64 * WCO, CIP = 64 * WCI, R = COP + CIP;
+    constexpr int PS = R * 16 + 32;          // plane stride (bytes)
+    constexpr int PART = 4 * PS, BUF = 3 * PART;
+    constexpr int ND = COP / 64, NX = CIP / 64;   // float4 pieces per thread per chunk (512 threads x 8 float4 per row)
+    constexpr bool D2 = PRO_D == PRO_NORMBWD;
+    static_assert(WCO * WCI == 8, "8 waves");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xs = smem;                           // [2][BUF]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wv / WCI, wci = wv % WCI;
+    const int n = blockIdx.y;
+    const int P = g.P;
+    const int nch = P / 32;
+    const int cbeg = (int)((long long)blockIdx.x * nch / gridDim.x), cend = (int)((long long)(blockIdx.x + 1) * nch / gridDim.x);
+    const int nc = cend - cbeg;
+
+    // loader mapping: piece i covers rows (tid>>3) + 64*i, float4 column c4 = tid & 7 of the 32-pixel chunk
+    const int lrow = tid >> 3, c4 = tid & 7;
+    const float* dbase = g.d + ((size_t)n * COP + lrow) * P + 4 * c4;
+    const float* d2base = D2 ? g.d2 + ((size_t)n * COP + lrow) * P + 4 * c4 : dbase;
+    const float* xbase = g.x + ((size_t)n * CIP + lrow) * P + 4 * c4;
+    const int st_off = (c4 >> 1) * PS + lrow * 16 + (c4 & 1) * 8;   // + part*PART + 64*i*16 (+ COP*16 for x rows)
+
+    // per-row prologue coefficients of this thread's six rows: chunk-invariant, kept in registers (optional pointers
+    // are read branch-free: a null pointer reads a dummy location and the value is replaced by a select)
+    float k0[ND + NX], k1[ND + NX], k2[ND + NX];
+#pragma unroll
+    for (int i = 0; i < ND + NX; ++i) {
+        const bool isd = i < ND;
+        const int idx = isd ? n * COP + lrow + 64 * i : n * CIP + lrow + 64 * (i - ND);
+        const float* q0 = isd ? g.dk0 : g.xk0;
+        const float* q1 = isd ? g.dk1 : g.xk1;
+        const float* q2 = isd ? g.dk2 : g.xk2;
+        const float a = (q0 ? q0 : g.d)[q0 ? idx : 0], b = (q1 ? q1 : g.d)[q1 ? idx : 0], c = (q2 ? q2 : g.d)[q2 ? idx : 0];
+        k0[i] = q0 ? a : 1.f;
+        k1[i] = q1 ? b : 0.f;
+        k2[i] = q2 ? c : ((isd ? PRO_D : PRO_X) == PRO_AFFINE_GELU ? 1.f : 0.f);
+    }
+
+    float4 dv[ND], dv2[D2 ? ND : 1], xv[NX];
+    auto load_piece = [&](int i, int ch) {   // i compile-time after unrolling; ch clamped by the caller
+        const size_t po = (size_t)(cbeg + ch) * 32;
+        if (i < ND) {
+            dv[i] = *(const float4*)(dbase + (size_t)(64 * i) * P + po);
+            if constexpr (D2) dv2[i] = *(const float4*)(d2base + (size_t)(64 * i) * P + po);
+        } else {
+            xv[i - ND] = *(const float4*)(xbase + (size_t)(64 * (i - ND)) * P + po);
+        }
+    };
+    auto stage_piece = [&](int i, int buf) {
+        const bool isd = i < ND;
+        const int row = isd ? lrow + 64 * i : COP + lrow + 64 * (i - ND);
+        const float c0 = k0[i], c1 = k1[i], c2 = k2[i];
+        const float4 v = isd ? dv[i] : xv[i - ND];
+        const float4 w = (isd && D2) ? dv2[D2 ? i : 0] : v;
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = ((const float*)&v)[q], b = ((const float*)&w)[q];
+            const float t = isd ? wgs_pro<PRO_D>(a, b, c0, c1, c2) : wgs_pro<PRO_X>(a, b, c0, c1, c2);
+            split3_bf16(t, h[q], m[q], l[q]);
+        }
+        unsigned char* b = xs + buf * BUF + st_off + (row - lrow) * 16;
+        *(u32x2_t*)(b) = u32x2_t{pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3])};
+        *(u32x2_t*)(b + PART) = u32x2_t{pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3])};
+        *(u32x2_t*)(b + 2 * PART) = u32x2_t{pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3])};
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // operand addresses: plane = ks*2 + (lane>>5); A rows of this wave's two co tiles, B rows of its two ci tiles
+    const int arow = (wco * 2) * 32 + (lane & 31), brow = COP + (wci * 2) * 32 + (lane & 31);
+    const int aoff = (lane >> 5) * PS + arow * 16, boff = (lane >> 5) * PS + brow * 16;
+    auto ldop = [&](int buf, int ks, int part, int off, u32x4_t (&o)[2]) {
+        const unsigned char* p = xs + buf * BUF + part * PART + ks * 2 * PS + off;
+        o[0] = *(const u32x4_t*)p;
+        o[1] = *(const u32x4_t*)(p + 32 * 16);
+    };
+
+    // prologue: chunk 0 -> buffer 0, chunk 1 raw in registers
+#pragma unroll
+    for (int i = 0; i < ND + NX; ++i) load_piece(i, 0);
+#pragma unroll
+    for (int i = 0; i < ND + NX; ++i) { stage_piece(i, 0); load_piece(i, nc > 1 ? 1 : 0); }
+    __syncthreads();
+
+    // rolling operands (ah, am, bh re-read in place after their last use) and double-buffered single-use ones
+    u32x4_t ah[2], am[2], bh[2], al[2][2], bl[2][2], bm[2][2];
+    ldop(0, 0, 0, aoff, ah); ldop(0, 0, 1, aoff, am); ldop(0, 0, 0, boff, bh);
+    ldop(0, 0, 2, aoff, al[0]); ldop(0, 0, 2, boff, bl[0]); ldop(0, 0, 1, boff, bm[0]);
+
+#define WGS_MF(A, B)                                                                                             \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)                  \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A[a]),                  \
+                                                            __builtin_bit_cast(bf16x8_t, B[b]), acc[a][b], 0, 0, 0)
+#define WGS_SB() __builtin_amdgcn_sched_barrier(0)
+    for (int c = 0; c < nc; ++c) {
+        const int cur = c & 1;
+        const int c2 = c + 2 < nc ? c + 2 : nc - 1;     // raw chunk to request (clamped, branch-free)
+        // ---- k-step 0 (operands of k-step 1 come from the same buffer); one staging piece after each product ----
+        {
+            constexpr int Q = 0;   // parity of the double-buffered operands
+            WGS_MF(ah, bl[Q]); WGS_SB();
+            ldop(cur, 1, 2, aoff, al[Q ^ 1]); ldop(cur, 1, 2, boff, bl[Q ^ 1]);
+            if (0 < ND + NX) { stage_piece(0, cur ^ 1); load_piece(0, c2); }
+            WGS_SB();
+            WGS_MF(ah, bm[Q]); WGS_SB();
+            ldop(cur, 1, 1, boff, bm[Q ^ 1]);
+            if (1 < ND + NX) { stage_piece(1, cur ^ 1); load_piece(1, c2); }
+            WGS_SB();
+            WGS_MF(ah, bh); WGS_SB();
+            ldop(cur, 1, 0, aoff, ah);
+            if (2 < ND + NX) { stage_piece(2, cur ^ 1); load_piece(2, c2); }
+            WGS_SB();
+            WGS_MF(am, bh); WGS_SB();
+            if (3 < ND + NX) { stage_piece(3, cur ^ 1); load_piece(3, c2); }
+            WGS_SB();
+            WGS_MF(al[Q], bh); WGS_SB();
+            ldop(cur, 1, 0, boff, bh);
+            if (4 < ND + NX) { stage_piece(4, cur ^ 1); load_piece(4, c2); }
+            WGS_SB();
+            WGS_MF(am, bm[Q]); WGS_SB();
+            ldop(cur, 1, 1, aoff, am);
+            if (5 < ND + NX) { stage_piece(5, cur ^ 1); load_piece(5, c2); }
+            WGS_SB();
+        }
+        __syncthreads();   // chunk c+1 staged by every wave; nobody still reads buffer cur^1's old contents
+        // ---- k-step 1 (operands of the next chunk's k-step 0 come from the freshly staged buffer) ----
+        {
+            constexpr int Q = 1;
+            WGS_MF(ah, bl[Q]); WGS_SB();
+            ldop(cur ^ 1, 0, 2, aoff, al[Q ^ 1]); ldop(cur ^ 1, 0, 2, boff, bl[Q ^ 1]);
+            WGS_SB();
+            WGS_MF(ah, bm[Q]); WGS_SB();
+            ldop(cur ^ 1, 0, 1, boff, bm[Q ^ 1]);
+            WGS_SB();
+            WGS_MF(ah, bh); WGS_SB();
+            ldop(cur ^ 1, 0, 0, aoff, ah);
+            WGS_SB();
+            WGS_MF(am, bh); WGS_SB();
+            WGS_MF(al[Q], bh); WGS_SB();
+            ldop(cur ^ 1, 0, 0, boff, bh);
+            WGS_SB();
+            WGS_MF(am, bm[Q]); WGS_SB();
+            ldop(cur ^ 1, 0, 1, aoff, am);
+            WGS_SB();
+        }
+    }
+#undef WGS_MF
+#undef WGS_SB
+
+    float* po = g.part + ((size_t)n * gridDim.x + blockIdx.x) * COP * CIP;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (wco * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int ci = (wci * 2 + b) * 32 + (lane & 31);
+                po[co * CIP + ci] = acc[a][b][r];
+            }
+}
+
+static int wgs_ncu() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+            ncu = 256;
+    }
+    return ncu;
+}
+
+// blocks per frame of the split kernel: one block per CU in total, never more than one block per 32-pixel chunk
+int pw_wgrad_split_nbx(int N, int P) {
+    int g = wgs_ncu() / N;
+    if (g < 1) g = 1;
+    if (g > P / 32) g = P / 32;
+    return g;
+}
+
+// shape 0: (Cd, Cx) = (256, 128), shape 1: (128, 256); (pro_d, pro_x) in {(NORMBWD, AFFINE), (NORMBWD, AFFINE_GELU)}
+bool pw_wgrad_split_supported(int Cd, int Cx, int pro_d, int pro_x, bool rowsum) {
+    if (rowsum || pro_d != PRO_NORMBWD) return false;
+    if (!((Cd == 256 && Cx == 128) || (Cd == 128 && Cx == 256))) return false;
+    return pro_x == PRO_AFFINE || pro_x == PRO_AFFINE_GELU;
+}
+
+template <int WCO, int WCI, int PRO_X>
+static int wgs_launch(const WgsArgs& g, dim3 grid, hipStream_t stream) {
+    constexpr int R = 64 * WCO + 64 * WCI;
+    constexpr size_t lds = 2 * 3 * 4 * (size_t)(R * 16 + 32);
+    auto kern = pw_wgrad_split_kernel<WCO, WCI, PRO_NORMBWD, PRO_X>;
+    static bool once = false;
+    if (!once) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return UNCR_EINVAL;
+        once = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, g);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+int pw_wgrad_split_launch(const float* d, const float* d2, const float* x, const float* dk0, const float* dk1,
+                          const float* dk2, const float* xk0, const float* xk1, const float* xk2, float* part, int N,
+                          int Cd, int Cx, int P, int nbx, int pro_x, hipStream_t stream) {
+    if (P % 32 || nbx < 1 || nbx > P / 32) return UNCR_ESHAPE;
+    WgsArgs g{d, d2, x, dk0, dk1, dk2, xk0, xk1, xk2, part, Cd, Cx, P};
+    dim3 grid(nbx, N);
+    if (Cd == 256) {
+        if (pro_x == PRO_AFFINE) return wgs_launch<4, 2, PRO_AFFINE>(g, grid, stream);
+        return wgs_launch<4, 2, PRO_AFFINE_GELU>(g, grid, stream);
+    }
+    if (pro_x == PRO_AFFINE) return wgs_launch<2, 4, PRO_AFFINE>(g, grid, stream);
+    return wgs_launch<2, 4, PRO_AFFINE_GELU>(g, grid, stream);
+}

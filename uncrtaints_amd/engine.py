@@ -159,14 +159,6 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
     return out, part
 
 
-def _pick_pxb(N: int, P: int) -> int:
-    """Pixels per weight-gradient block: aim for ~512-1024 blocks on the 256 CUs."""
-    for cand in (4096, 2048, 1024, 512, 256):
-        if P % cand == 0 and N * (P // cand) >= 512:
-            return cand
-    return 256 if P % 256 == 0 else 32
-
-
 def pw_wgrad(d: Tensor, x: Tensor, N: int, Cd: int, Cx: int, P: int, *, pro_d: int = PRO_NONE, dk=(None, None, None),
              d2: Optional[Tensor] = None, pro_x: int = PRO_NONE, xk=(None, None, None), x2: Optional[Tensor] = None,
              per_frame: bool = False, rowsum: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
@@ -177,12 +169,13 @@ def pw_wgrad(d: Tensor, x: Tensor, N: int, Cd: int, Cx: int, P: int, *, pro_d: i
     if hb.lib().cdll.uncr_wgrad_shape(Cd, Cx, ctypes.byref(cop), ctypes.byref(cip)) < 0:
         raise RuntimeError(f"weight-gradient shape ({Cd},{Cx}) not built")
     cop, cip = cop.value, cip.value
-    pxb = _pick_pxb(N, P)
-    nbx = P // pxb
+    nbx = hb.query("uncr_wgrad_nbx", N, Cd, Cx, P, pro_d, pro_x, 1 if rowsum else 0)
+    if nbx <= 0:
+        raise RuntimeError(f"weight-gradient problem (N={N}, P={P}) not supported")
     dev = d.device
     part = _f32((N * nbx, cop, cip), dev)
     rs_part = _f32((N * nbx, cop), dev) if rowsum else None
-    hb.call("uncr_pw_wgrad", d, d2, x, x2, dk[0], dk[1], dk[2], xk[0], xk[1], xk[2], part, rs_part, N, Cd, Cx, P, pxb,
+    hb.call("uncr_pw_wgrad", d, d2, x, x2, dk[0], dk[1], dk[2], xk[0], xk[1], xk[2], part, rs_part, N, Cd, Cx, P, nbx,
             pro_d, pro_x, _stream())
     n_out = N if per_frame else 1
     dW = _f32((n_out, Cd, Cx), dev)
