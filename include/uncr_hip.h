@@ -101,6 +101,7 @@ int uncr_wgrad_reduce(const float* part, int n_out, int nblk_per_out, int COP, i
                       float* out, hipStream_t stream);
 
 /* ---- depthwise 3x3 reflect (nn.Conv2d groups=C, padding_mode='reflect', uncrtaints.py:130-131) ---- */
+int uncr_dw_set_row(int on);   /* 1 (default): W == 256 uses the row-streaming kernels; 0: LDS-tiled kernels only */
 int uncr_dw_slots_fwd(int H);
 int uncr_dw_slots_bwd(int H);
 int uncr_dw_fwd(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part,

@@ -123,9 +123,21 @@ def test_pw_wgrad(E, Cd, Cx):
     close(f"wgrad_plain[{Cd},{Cx}]", dW0, torch.einsum("nop,ncp->oc", d.double(), x.double()).float())
 
 
-@pytest.mark.parametrize("H,W", [(64, 64), (96, 32)])
-def test_depthwise_fwd_bwd(E, orc, H, W):
-    N, C = 2, 64
+# W == 256 runs the row-streaming kernels (dwconv_row.hip): one / partial / several 64-row tiles, and once more on
+# the LDS-tiled kernels (row=False) so that both implementations stay covered
+@pytest.mark.parametrize("H,W,row", [(64, 64, True), (96, 32, True), (16, 256, True), (72, 256, True), (136, 256, True),
+                                     (72, 256, False)])
+def test_depthwise_fwd_bwd(E, orc, H, W, row):
+    from uncrtaints_amd import hip_backend as hb
+    old = hb.query("uncr_dw_set_row", 1 if row else 0)
+    try:
+        _depthwise_fwd_bwd(E, orc, H, W)
+    finally:
+        hb.query("uncr_dw_set_row", old)
+
+
+def _depthwise_fwd_bwd(E, orc, H, W):
+    N, C = (2, 64) if W < 256 else (2, 8)
     h1 = rand(N, C, H, W, seed=1).requires_grad_(True)
     w = rand(C, 1, 3, 3, seed=2, scale=0.4).requires_grad_(True)
     A, B = rand(N * C, seed=3, scale=0.5, shift=1.0), rand(N * C, seed=4, scale=0.3)

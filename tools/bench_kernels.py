@@ -41,6 +41,20 @@ def main():
             fn = lambda: E.pw_wgrad(d, x, N, Cd, Cx, P, pro_d=pro_d, dk=dk, d2=d2 if pro_d == 3 else None, pro_x=pro_x, xk=xk)
             ms = timeit(fn, iters)
             print(f"pw_wgrad {Cd}x{Cx} pro_d{pro_d} pro_x{pro_x}: {ms*1e3:.1f} us  {2.0*N*P*Cd*Cx/ms/1e9:.1f} TF (incl. reduce)")
+    elif what == "dw":
+        from uncrtaints_amd import hip_backend as hb
+        C, H, W = 256, 256, 256
+        for Nf in (4, 12):
+            t = lambda *s: torch.randn(*s, device=dev)
+            h1, h2, du2, out = t(Nf, C, H, W), t(Nf, C, H, W), t(Nf, C, H, W), torch.empty(Nf, C, H, W, device=dev)
+            cA, cB, k1, k2, k3 = (torch.randn(Nf * C, device=dev) for _ in range(5))
+            w = t(C, 9)
+            sf, sb = hb.query("uncr_dw_slots_fwd", H), hb.query("uncr_dw_slots_bwd", H)
+            partf, partb, dwp = torch.empty(Nf * C, sf, 2, device=dev), torch.empty(Nf * C, sb, 2, device=dev), torch.empty(Nf * C, sb, 9, device=dev)
+            ms = timeit(lambda: hb.call("uncr_dw_fwd", h1, cA, cB, w, out, partf, Nf, C, H, W, E._stream()), iters)
+            print(f"dw_fwd N={Nf}: {ms*1e3:.1f} us  {8.0*Nf*C*H*W/ms/1e6:.0f} GB/s")
+            ms = timeit(lambda: hb.call("uncr_dw_bwd", du2, h2, h1, k1, k2, k3, cA, cB, w, out, partb, dwp, Nf, C, H, W, E._stream()), iters)
+            print(f"dw_bwd N={Nf}: {ms*1e3:.1f} us  {16.0*Nf*C*H*W/ms/1e6:.0f} GB/s")
     elif what == "gemmscale":
         Cin, Cout = 128, 256
         for nb in (128, 256, 512, 1024, 2048):

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ i
     }
 }
 
+template <int NRMAX>   // row passes per thread: ceil((TR + 2) / (256 / (W/4)))
 __global__ __launch_bounds__(256) void dw_bwd_kernel(
     const float* __restrict__ du2, const float* __restrict__ h2, const float* __restrict__ h1,
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
@@ -95,29 +96,40 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
     const float A1 = cA1[plane], B1 = cB1[plane];
     const size_t pbase = (size_t)plane * H * W;
     const int rows = min(TR, H - y0) + 2;
-    if (active) {
-        for (int r = r0; r < rows; r += rpp) {
-            const int y = y0 - 1 + r;
-            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (y >= 0 && y < H) {
-                const size_t o = pbase + (size_t)y * W + 4 * c4;
-                const float4 a = *(const float4*)(du2 + o);
-                const float4 b = *(const float4*)(h2 + o);
-                d.x = fmaf(C1, a.x, fmaf(C2, b.x, C3));
-                d.y = fmaf(C1, a.y, fmaf(C2, b.y, C3));
-                d.z = fmaf(C1, a.z, fmaf(C2, b.z, C3));
-                d.w = fmaf(C1, a.w, fmaf(C2, b.w, C3));
-            }
+    // Staging: every load of the block is issued before the first use (one HBM round trip instead of one per row
+    // pass), branch-free: rows outside the tile / image re-read a clamped row and are masked afterwards.  A thread's
+    // rows are r0 + i*rpp; the raw h1 values stay in registers for the compute phase (same rows are its output rows).
+    float4 ra[NRMAX], rb[NRMAX], rh[NRMAX];
+#pragma unroll
+    for (int i = 0; i < NRMAX; ++i) {
+        const int r = r0 + i * rpp;
+        const int y = y0 - 1 + r;
+        const int yc = min(max(y, 0), H - 1);
+        const int gy = min(max(reflect1(y, H), 0), H - 1);
+        const int cc = active ? c4 : 0;
+        ra[i] = *(const float4*)(du2 + pbase + (size_t)yc * W + 4 * cc);
+        rb[i] = *(const float4*)(h2 + pbase + (size_t)yc * W + 4 * cc);
+        rh[i] = *(const float4*)(h1 + pbase + (size_t)gy * W + 4 * cc);
+    }
+#pragma unroll
+    for (int i = 0; i < NRMAX; ++i) {
+        const int r = r0 + i * rpp;
+        const int y = y0 - 1 + r;
+        if (active && r < rows) {                 // LDS writes only: no memory loads under this branch
+            const float m = (y >= 0 && y < H) ? 1.f : 0.f;
+            float4 d;
+            d.x = m * fmaf(C1, ra[i].x, fmaf(C2, rb[i].x, C3));
+            d.y = m * fmaf(C1, ra[i].y, fmaf(C2, rb[i].y, C3));
+            d.z = m * fmaf(C1, ra[i].z, fmaf(C2, rb[i].z, C3));
+            d.w = m * fmaf(C1, ra[i].w, fmaf(C2, rb[i].w, C3));
             *(float4*)(Dt + r * pitch + 4 + 4 * c4) = d;
             if (c4 == 0) Dt[r * pitch + 3] = 0.f;
             if (c4 == W4 - 1) Dt[r * pitch + 4 + W] = 0.f;
-
-            const int gy = reflect1(y, H);
-            float4 v = *(const float4*)(h1 + pbase + (size_t)gy * W + 4 * c4);
-            v.x = gelu_f(fmaf(A1, v.x, B1));
-            v.y = gelu_f(fmaf(A1, v.y, B1));
-            v.z = gelu_f(fmaf(A1, v.z, B1));
-            v.w = gelu_f(fmaf(A1, v.w, B1));
+            float4 v;
+            v.x = gelu_f(fmaf(A1, rh[i].x, B1));
+            v.y = gelu_f(fmaf(A1, rh[i].y, B1));
+            v.z = gelu_f(fmaf(A1, rh[i].z, B1));
+            v.w = gelu_f(fmaf(A1, rh[i].w, B1));
             *(float4*)(Gt + r * pitch + 4 + 4 * c4) = v;
             if (c4 == 0) Gt[r * pitch + 3] = v.y;
             if (c4 == W4 - 1) Gt[r * pitch + 4 + W] = v.z;
@@ -135,15 +147,16 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
     const int orows = rows - 2;
     // tile rows of image rows 0 and H-1 (only meaningful when the block holds them)
     const int er0 = 0 - (y0 - 1), er1 = (H - 1) - (y0 - 1);
-    if (active) {
-        for (int r = r0; r < orows; r += rpp) {
+#pragma unroll
+    for (int i = 0; i < NRMAX; ++i) {
+        const int r = r0 + i * rpp - 1;          // output row of the tile (staged tile row r + 1)
+        if (active && r >= 0 && r < orows) {     // LDS reads and global stores only under this branch
             const int y = y0 + r;
             // adjoint of reflect padding: the plain transposed stencil on the zero-padded tile, plus the
             // contributions that forward reflection folded back onto rows/cols 1 and H-2 / W-2.
             const bool ry0 = (y == 1), ry1 = (y == H - 2);
             const size_t o = pbase + (size_t)y * W + 4 * c4;
-            const float4 hv = *(const float4*)(h1 + o);     // L2-resident re-read (an LDS copy costs occupancy)
-            const float* ph = (const float*)&hv;
+            const float* ph = (const float*)&rh[i];          // raw h1 of this row, kept from the staging loads
             // rows r..r+2 of both tiles, columns x-1 .. x+4 (tile offsets 3+4c4 .. 8+4c4)
             float dt[3][6], gt[3][6];
 #pragma unroll
@@ -239,9 +252,19 @@ __global__ void dw_wgrad_reduce_kernel(const float* __restrict__ dw_part, int N,
 extern "C" int uncr_dw_slots_fwd(int H) { return (H + DW_TR_FWD - 1) / DW_TR_FWD; }
 extern "C" int uncr_dw_slots_bwd(int H) { return (H + DW_TR_BWD - 1) / DW_TR_BWD; }
 
+// dwconv_row.hip: streaming kernels for W == 256
+int dw_fwd_row_launch(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part, int N,
+                      int C, int H, int slots, hipStream_t stream);
+int dw_bwd_row_launch(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2,
+                      const float* k3, const float* cA1, const float* cB1, const float* w, float* du1, float* part,
+                      float* dw_part, int N, int C, int H, int slots, hipStream_t stream);
+static int g_dw_row = 1;   // A/B switch (tests exercise both implementations)
+extern "C" int uncr_dw_set_row(int on) { const int old = g_dw_row; g_dw_row = on ? 1 : 0; return old; }
+
 extern "C" int uncr_dw_fwd(const float* in, const float* cA, const float* cB, const float* w, float* out,
                            float* part, int N, int C, int H, int W, hipStream_t stream) {
     if (N <= 0 || C <= 0 || H < 2 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
+    if (g_dw_row && W == 256 && H >= 4 && (H & 3) == 0) return dw_fwd_row_launch(in, cA, cB, w, out, part, N, C, H, uncr_dw_slots_fwd(H), stream);
     const size_t lds = (size_t)(DW_TR_FWD + 2) * (W + 8) * sizeof(float);
     if (lds > 60 * 1024) return UNCR_ESHAPE;
     hipLaunchKernelGGL(dw_fwd_kernel, dim3(uncr_dw_slots_fwd(H), N * C), dim3(256), lds, stream, in, cA, cB, w, out,
@@ -254,17 +277,20 @@ extern "C" int uncr_dw_bwd(const float* du2, const float* h2, const float* h1, c
                            const float* k3, const float* cA1, const float* cB1, const float* w, float* du1,
                            float* part, float* dw_part, int N, int C, int H, int W, hipStream_t stream) {
     if (N <= 0 || C <= 0 || H < 4 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
+    if (g_dw_row && W == 256 && (H & 3) == 0)
+        return dw_bwd_row_launch(du2, h2, h1, k1, k2, k3, cA1, cB1, w, du1, part, dw_part, N, C, H, uncr_dw_slots_bwd(H), stream);
     const size_t lds = (size_t)2 * (DW_TR_BWD + 2) * (W + 8) * sizeof(float);
     if (lds > 150 * 1024) return UNCR_ESHAPE;
-    static size_t lds_attr = 0;
-    if (lds > lds_attr) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU)
-        if (hipFuncSetAttribute((const void*)dw_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
+    auto kern = W <= 256 ? dw_bwd_kernel<5> : (W <= 512 ? dw_bwd_kernel<9> : dw_bwd_kernel<18>);
+    static size_t lds_attr[3] = {0, 0, 0};
+    const int ki = W <= 256 ? 0 : (W <= 512 ? 1 : 2);
+    if (lds > lds_attr[ki]) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU)
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return UNCR_EINVAL;
-        lds_attr = lds;
+        lds_attr[ki] = lds;
     }
-    hipLaunchKernelGGL(dw_bwd_kernel, dim3(uncr_dw_slots_bwd(H), N * C), dim3(256), lds, stream, du2, h2, h1, k1, k2,
-                       k3, cA1, cB1, w, du1, (float2*)part, dw_part, C, H, W);
+    hipLaunchKernelGGL(kern, dim3(uncr_dw_slots_bwd(H), N * C), dim3(256), lds, stream, du2, h2, h1, k1, k2, k3, cA1,
+                       cB1, w, du1, (float2*)part, dw_part, C, H, W);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -1,0 +1,279 @@
+// Depthwise 3x3 reflect (uncrtaints.py:130-131), forward and backward, as pure streaming kernels for W == 256:
+// one image row is exactly one wave of float4 lanes, so a wave walks down DWR_TR rows of one (frame, channel) plane
+// with 3-row sliding windows in registers.  Horizontal neighbours come from DPP wave shifts (the shifted-in border
+// lane receives the reflect / zero-pad value directly through the DPP `old` operand), vertical neighbours are the
+// window rows.  No LDS, no barriers, two rows of loads in flight per wave, 2/64 halo rows instead of 2/16 -- the
+// same math as the LDS-tiled kernels in dwconv.hip (kept for other widths), restated per row.
+#include "common.h"
+
+#define DWR_TR 64
+
+__device__ __forceinline__ float wf_sr1(float v, float border) {   // lane i <- lane i-1; lane 0 <- border
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, border),
+                                                                 __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wf_sl1(float v, float border) {   // lane i <- lane i+1; lane 63 <- border
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, border),
+                                                                 __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+
+struct Row6 { float v[6]; };   // columns x0-1 .. x0+4 of one row for this lane's four pixels
+
+__device__ __forceinline__ Row6 row6_reflect(const float4& g) {   // col -1 -> col 1, col W -> col W-2
+    Row6 r;
+    r.v[0] = wf_sr1(g.w, g.y); r.v[1] = g.x; r.v[2] = g.y; r.v[3] = g.z; r.v[4] = g.w; r.v[5] = wf_sl1(g.x, g.z);
+    return r;
+}
+__device__ __forceinline__ Row6 row6_zero(const float4& d) {
+    Row6 r;
+    r.v[0] = wf_sr1(d.w, 0.f); r.v[1] = d.x; r.v[2] = d.y; r.v[3] = d.z; r.v[4] = d.w; r.v[5] = wf_sl1(d.x, 0.f);
+    return r;
+}
+// gelu(u) and gelu'(u) of u = A*h + B from ONE erf: Phi = (1 + erf(u/sqrt2))/2, gelu = u*Phi, gelu' = Phi + u*phi(u)
+__device__ __forceinline__ void gelu_both(float A, float B, float h, float& gv, float& gd) {
+    const float u = fmaf(A, h, B);
+    const float cdf = 0.5f * (1.0f + erf_f(u * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * u * u);
+    gv = u * cdf;
+    gd = fmaf(u, pdf, cdf);
+}
+__device__ __forceinline__ float4 gelu4(float A, float B, const float4& h) {
+    return make_float4(gelu_f(fmaf(A, h.x, B)), gelu_f(fmaf(A, h.y, B)), gelu_f(fmaf(A, h.z, B)), gelu_f(fmaf(A, h.w, B)));
+}
+
+// ---- forward: out = dw(reflectpad(gelu(A*in+B))), stats (sum, sum^2) per 32-row slot ----
+// grid = ceil(planes * tiles / 4) blocks of 4 independent waves; slots_per_plane = ceil(H / 32)
+__global__ __launch_bounds__(256) void dw_fwd_row_kernel(const float* __restrict__ in, const float* __restrict__ cA,
+                                                         const float* __restrict__ cB, const float* __restrict__ w,
+                                                         float* __restrict__ out, float2* __restrict__ part, int C,
+                                                         int H, int planes, int slots) {
+    constexpr int W = 256;
+    const int lane = threadIdx.x & 63;
+    const int tiles = (H + DWR_TR - 1) / DWR_TR;
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wid >= planes * tiles) return;
+    const int plane = wid / tiles, tile = wid - plane * tiles, c = plane % C;
+    const int y0 = tile * DWR_TR, y1 = min(H, y0 + DWR_TR);
+    const float A = cA[plane], B = cB[plane];
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
+    const float* src = in + (size_t)plane * H * W + 4 * lane;
+    float* dst = out + (size_t)plane * H * W + 4 * lane;
+    auto ld = [&](int yy) { return *(const float4*)(src + (size_t)min(max(yy, 0), H - 1) * W); };
+
+    // 4-slot ring of g rows (row y lives in slot (y - y0) & 3), the row loop unrolled x4 so that every slot index is
+    // static: no register rotation.  Raw prefetch registers alternate with the row parity.
+    Row6 gW[4];
+    float4 nx[2];
+    gW[3] = row6_reflect(gelu4(A, B, ld(reflect1(y0 - 1, H))));
+    gW[0] = row6_reflect(gelu4(A, B, ld(y0)));
+    nx[0] = ld(y0 + 1); nx[1] = ld(y0 + 2);
+    float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;   // (s) first 32-row slot of the tile, (t) second
+    for (int Y = y0; Y < y1; Y += 4) {               // (y1 - y0) % 4 == 0 (launcher: H % 4 == 0)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int y = Y + s;
+            constexpr int dummy = 0; (void)dummy;
+            const int im = (s + 3) & 3, ic = s, ip = (s + 1) & 3;
+            // row y+1 (reflect at the bottom edge: row H -> row H-2 = the ring's row y-1)
+            const Row6 gnew = row6_reflect(gelu4(A, B, nx[s & 1]));
+            const bool inside = y + 1 < H;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gW[ip].v[k] = inside ? gnew.v[k] : gW[im].v[k];
+            nx[s & 1] = ld(y + 3);
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = 0.f;
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    a = fmaf(wk[tx], gW[im].v[j + tx], a);
+                    a = fmaf(wk[3 + tx], gW[ic].v[j + tx], a);
+                    a = fmaf(wk[6 + tx], gW[ip].v[j + tx], a);
+                }
+                o[j] = a;
+            }
+            *(float4*)(dst + (size_t)y * W) = make_float4(o[0], o[1], o[2], o[3]);
+            const float q0 = (o[0] + o[1]) + (o[2] + o[3]);
+            const float q1 = fmaf(o[0], o[0], fmaf(o[1], o[1], fmaf(o[2], o[2], o[3] * o[3])));
+            if (Y - y0 < 32) { s0 += q0; s1 += q1; } else { t0 += q0; t1 += q1; }
+        }
+    }
+    if (part) {
+        s0 = wave_sum_dpp(s0); s1 = wave_sum_dpp(s1); t0 = wave_sum_dpp(t0); t1 = wave_sum_dpp(t1);
+        if (lane == 63) {
+            const int sl = tile * (DWR_TR / 32);
+            part[(size_t)plane * slots + sl] = make_float2(s0, s1);
+            if (sl + 1 < slots) part[(size_t)plane * slots + sl + 1] = make_float2(t0, t1);
+        }
+    }
+}
+
+// ---- backward (see dwconv.hip for the derivation of the reflect adjoint) ----
+// slots = ceil(H / 16) per plane (the ABI's statistics granularity); a 64-row tile fills its first slot, zeroes the rest
+__global__ __launch_bounds__(256) void dw_bwd_row_kernel(
+    const float* __restrict__ du2, const float* __restrict__ h2, const float* __restrict__ h1,
+    const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
+    const float* __restrict__ cA1, const float* __restrict__ cB1, const float* __restrict__ w,
+    float* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part, int C, int H, int planes,
+    int slots) {
+    constexpr int W = 256;
+    const int lane = threadIdx.x & 63;
+    const int tiles = (H + DWR_TR - 1) / DWR_TR;
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wid >= planes * tiles) return;
+    const int plane = wid / tiles, tile = wid - plane * tiles, c = plane % C;
+    const int y0 = tile * DWR_TR, y1 = min(H, y0 + DWR_TR);
+    const float C1 = k1[plane], C2 = k2[plane], C3 = k3[plane];
+    const float A1 = cA1[plane], B1 = cB1[plane];
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
+    const size_t pb = (size_t)plane * H * W + 4 * lane;
+    struct Raw { float4 a, b, h; };
+    auto ld = [&](int yy) {
+        const size_t o = pb + (size_t)min(max(yy, 0), H - 1) * W;
+        return Raw{*(const float4*)(du2 + o), *(const float4*)(h2 + o), *(const float4*)(h1 + o)};
+    };
+    auto dh2 = [&](const Raw& r, int yy) {   // zero outside the image
+        const float m = (yy >= 0 && yy < H) ? 1.f : 0.f;
+        return make_float4(m * fmaf(C1, r.a.x, fmaf(C2, r.b.x, C3)), m * fmaf(C1, r.a.y, fmaf(C2, r.b.y, C3)),
+                           m * fmaf(C1, r.a.z, fmaf(C2, r.b.z, C3)), m * fmaf(C1, r.a.w, fmaf(C2, r.b.w, C3)));
+    };
+
+    auto both4 = [&](const float4& h, float4& gv, float4& gd) {
+        gelu_both(A1, B1, h.x, gv.x, gd.x); gelu_both(A1, B1, h.y, gv.y, gd.y);
+        gelu_both(A1, B1, h.z, gv.z, gd.z); gelu_both(A1, B1, h.w, gv.w, gd.w);
+    };
+    // 4-slot rings (row y in slot (y - y0) & 3) of the zero-padded dh2 rows, the reflect-padded g1 rows, raw h1 and
+    // gelu'(u1); the row loop is unrolled x4 so that every slot index is static (no register rotation)
+    Row6 dW[4], gW[4];
+    float4 hW[4], qW[4];
+    Raw nx[2];
+    {
+        const Raw q = ld(y0 - 1);
+        dW[3] = row6_zero(dh2(q, y0 - 1));
+        gW[3] = row6_reflect(gelu4(A1, B1, q.h));          // g1(y0-1); for y0 == 0 replaced below by g1(1)
+        const Raw q0 = ld(y0);
+        dW[0] = row6_zero(dh2(q0, y0));
+        float4 gv;
+        both4(q0.h, gv, qW[0]);
+        gW[0] = row6_reflect(gv);
+        hW[0] = q0.h;
+    }
+    nx[0] = ld(y0 + 1); nx[1] = ld(y0 + 2);
+    const bool l0 = lane == 0, l63 = lane == 63;
+
+    float s0 = 0.f, s1 = 0.f, gw[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gw[i] = 0.f;
+    for (int Y = y0; Y < y1; Y += 4) {                     // (y1 - y0) % 4 == 0 (launcher: H % 4 == 0)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int y = Y + s;
+            const int im = (s + 3) & 3, ic = s, ip = (s + 1) & 3;
+            dW[ip] = row6_zero(dh2(nx[s & 1], y + 1));
+            float4 gvn;
+            both4(nx[s & 1].h, gvn, qW[ip]);
+            hW[ip] = nx[s & 1].h;
+            const Row6 gnew = row6_reflect(gvn);
+            const bool inside = y + 1 < H;                 // reflect: row H -> row H-2
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gW[ip].v[k] = inside ? gnew.v[k] : gW[im].v[k];
+            if (s == 0 && y == 0) gW[im] = gW[ip];         // reflect: row -1 -> row 1 (wave-uniform, registers only)
+            nx[s & 1] = ld(y + 3);
+            const Row6 &dm = dW[im], &dc = dW[ic], &dp = dW[ip], &gm = gW[im], &gc = gW[ic], &gp = gW[ip];
+
+            const bool ry0 = (y == 1), ry1 = (y == H - 2);  // rows that receive the folded-back padding rows
+            const float f0 = ry0 ? 1.f : 0.f, f1 = ry1 ? 1.f : 0.f;
+            float res[4];
+            const float* ph = (const float*)&hW[ic];
+            const float* pq = (const float*)&qW[ic];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // transposed stencil on the zero-padded dh2: image (y - ty + 1, x - tx + 1) = ring row (dp, dc, dm)[ty],
+                // column j + 2 - tx
+                float a = 0.f;
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    a = fmaf(wk[tx], dp.v[j + 2 - tx], a);
+                    a = fmaf(wk[3 + tx], dc.v[j + 2 - tx], a);
+                    a = fmaf(wk[6 + tx], dm.v[j + 2 - tx], a);
+                }
+                res[j] = a;
+            }
+            if (ry0 || ry1) {   // wave-uniform and rare; arithmetic only: the padding rows folded back onto rows 1 / H-2
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) {
+                        res[j] = fmaf(f0 * wk[tx], dm.v[j + 2 - tx], res[j]);
+                        res[j] = fmaf(f1 * wk[6 + tx], dp.v[j + 2 - tx], res[j]);
+                    }
+            }
+            // padding columns folded back onto columns 1 (lane 0, j = 1) and W-2 (lane 63, j = 2), corners included
+            {
+                float e0 = fmaf(wk[0], dp.v[1], fmaf(wk[3], dc.v[1], wk[6] * dm.v[1]));
+                e0 = fmaf(f0 * wk[0], dm.v[1], fmaf(f1 * wk[6], dp.v[1], e0));
+                float e1 = fmaf(wk[2], dp.v[4], fmaf(wk[5], dc.v[4], wk[8] * dm.v[4]));
+                e1 = fmaf(f0 * wk[2], dm.v[4], fmaf(f1 * wk[8], dp.v[4], e1));
+                res[1] += l0 ? e0 : 0.f;
+                res[2] += l63 ? e1 : 0.f;
+            }
+            float4 o;
+            float* po = (float*)&o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dv = pq[j] * res[j];
+                po[j] = dv;
+                s0 += dv;
+                s1 = fmaf(dv, ph[j], s1);
+                // depthwise weight gradient: dh2 at (y, x) times g1 at the reflect-padded neighbours
+                const float dcj = dc.v[j + 1];
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    gw[tx] = fmaf(dcj, gm.v[j + tx], gw[tx]);
+                    gw[3 + tx] = fmaf(dcj, gc.v[j + tx], gw[3 + tx]);
+                    gw[6 + tx] = fmaf(dcj, gp.v[j + tx], gw[6 + tx]);
+                }
+            }
+            *(float4*)(du1 + pb + (size_t)y * W) = o;
+        }
+    }
+    s0 = wave_sum_dpp(s0);
+    s1 = wave_sum_dpp(s1);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gw[i] = wave_sum_dpp(gw[i]);
+    if (lane == 63) {
+        const int sl = tile * (DWR_TR / 16);
+#pragma unroll
+        for (int k = 0; k < DWR_TR / 16; ++k) {
+            if (sl + k < slots) {
+                const size_t slot = (size_t)plane * slots + sl + k;
+                part[slot] = k == 0 ? make_float2(s0, s1) : make_float2(0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) dw_part[slot * 9 + i] = k == 0 ? gw[i] : 0.f;
+            }
+        }
+    }
+}
+
+int dw_fwd_row_launch(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part, int N,
+                      int C, int H, int slots, hipStream_t stream) {
+    const int planes = N * C, tiles = (H + DWR_TR - 1) / DWR_TR;
+    hipLaunchKernelGGL(dw_fwd_row_kernel, dim3((planes * tiles + 3) / 4), dim3(256), 0, stream, in, cA, cB, w, out,
+                       (float2*)part, C, H, planes, slots);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+int dw_bwd_row_launch(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2,
+                      const float* k3, const float* cA1, const float* cB1, const float* w, float* du1, float* part,
+                      float* dw_part, int N, int C, int H, int slots, hipStream_t stream) {
+    const int planes = N * C, tiles = (H + DWR_TR - 1) / DWR_TR;
+    hipLaunchKernelGGL(dw_bwd_row_kernel, dim3((planes * tiles + 3) / 4), dim3(256), 0, stream, du2, h2, h1, k1, k2,
+                       k3, cA1, cB1, w, du1, (float2*)part, dw_part, C, H, planes, slots);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
