@@ -12,12 +12,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libuncr_hip.so")
 # (source stem, extra flags, object stem); the split GEMM is compiled once per prologue kind (compile-time PRO)
-# dwconv_row: -fno-slp-vectorize -- the SLP vectoriser packs the stencil FMAs into v_pk_fma_f32 and pays for it with
-# ~70 register-pair moves per row (measured: 370 vs 282 VALU instructions per row)
-SOURCES = [(s, [], s) for s in ["norm", "ew", "pw_gemm", "pw_wgrad_split", "dwconv", "se", "ltae", "aggregate", "mgnll"]] + \
-          [("dwconv_row", ["-fno-slp-vectorize"], "dwconv_row")] + \
+SOURCES = [(s, [], s) for s in ["norm", "ew", "pw_gemm", "pw_wgrad_split", "dwconv", "dwconv_row", "se", "ltae", "aggregate", "mgnll"]] + \
           [("pw_gemm_split", [f"-DPWS_PRO={p}"], f"pw_gemm_split_p{p}") for p in range(5)]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# -fno-slp-vectorize: the SLP vectoriser packs neighbouring scalar FMAs into v_pk_fma_f32 and pays for it with
+# register-pair moves (depthwise row kernel: 370 vs 282 VALU instructions per row; whole step +1 %)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
 
 
 def _newer(src, dst):
