@@ -137,11 +137,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # UNCR_BENCH_BACKEND=gloo: development switch to exercise the N > 1 code path on a single-GPU box (all ranks on
+    # cuda:0, gradients reduced through the host); the real launch is one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get("UNCR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from uncrtaints_amd import hip_backend as hb
     from uncrtaints_amd.src import losses
@@ -152,20 +160,22 @@ def main():
     dp = None
     if world > 1:
         from uncrtaints_amd.parallel import BucketedDataParallel
-        dp = BucketedDataParallel(model, seed=1)
+        # with a captured forward/backward the collectives stay outside the graph: no launches from autograd hooks
+        dp = BucketedDataParallel(model, seed=1, overlap=args.no_graph)
     else:
         model.temporal_aggregator.set_seed(1)
-    use_graph = world == 1 and not args.no_graph
-    # fused multi-tensor Adam: one launch per step instead of ~180 per-tensor kernels (0.7 ms/step in the capture)
+    use_graph = not args.no_graph
+    # fused multi-tensor Adam: one launch per step instead of ~180 per-tensor kernels (0.7 ms/step in the capture);
+    # captured with the step at N = 1, launched eagerly after the gradient all-reduce at N > 1
     try:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph, fused=True)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph and world == 1, fused=True)
     except Exception:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph and world == 1)
     x, y, dates = synthetic(B, T, H, H, seed=1 + rank, device=device)
     step_counter = torch.zeros(1, dtype=torch.int64, device=device)
     model.temporal_aggregator.step_counter = step_counter     # dropout stream advances on the device
 
-    def eager_step():
+    def fwd_bwd():
         step_counter.add_(1)
         if dp is not None:
             dp.zero_grad()
@@ -174,6 +184,10 @@ def main():
         out = model(x, batch_positions=dates)
         loss, _ = crit(out[:, :, :13], y, out[:, :, 13:26])
         loss.backward()
+        return loss
+
+    def eager_step():
+        loss = fwd_bwd()
         if dp is not None:
             dp.finish()
         opt.step()
@@ -194,15 +208,29 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
-                static_loss = eager_step()
-            torch.cuda.synchronize()
+            if dp is None:
+                opt.zero_grad(set_to_none=True)
+                with torch.cuda.graph(graph):
+                    static_loss = eager_step()
+                torch.cuda.synchronize()
 
-            def step():
-                graph.replay()
-                return static_loss
-            graph_note = "HIP graph replay of the captured step"
+                def step():
+                    graph.replay()
+                    return static_loss
+                graph_note = "HIP graph replay of the captured step"
+            else:
+                # N > 1: forward + loss + backward replayed from a graph (gradients land in the flat buckets), then
+                # the three bucket all-reduces (RCCL) and the fused Adam step are launched eagerly
+                with torch.cuda.graph(graph):
+                    static_loss = fwd_bwd()
+                torch.cuda.synchronize()
+
+                def step():
+                    graph.replay()
+                    dp.finish()
+                    opt.step()
+                    return static_loss
+                graph_note = "HIP graph replay of forward+backward, eager bucket all-reduce + fused Adam"
         except Exception as exc:   # fall back loudly, never silently
             print(f"[bench] HIP-graph capture failed ({type(exc).__name__}: {exc}); timing eager launches",
                   file=sys.stderr)
@@ -230,13 +258,19 @@ def main():
     dt = time.perf_counter() - t0
     hb.set_profiler(None)
     eager_ms = None
-    if want_events and use_graph:
+    if world > 1:   # the max over ranks of the timed region, taken before anything else touches the stream
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if use_graph and not args.no_kernel_events:
         # kernels inside a graph replay cannot be bracketed one by one: re-run the SAME steps eagerly with a HIP
-        # event pair around every launch (same kernels, same shapes, same stream) for the roofline numbers
+        # event pair around every launch (same kernels, same shapes, same stream) for the roofline numbers.  Every
+        # rank runs the steps (they contain the gradient all-reduce); only rank 0 records events.
         n_ev = min(args.steps, 5)
         eager_step(); fence()
-        prof = hb.EventProfiler(PROFILED)
-        hb.set_profiler(prof)
+        if want_events:
+            prof = hb.EventProfiler(PROFILED)
+            hb.set_profiler(prof)
         t1 = time.perf_counter()
         for _ in range(n_ev):
             eager_step()
@@ -246,10 +280,6 @@ def main():
         prof_steps = n_ev
     else:
         prof_steps = args.steps
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
     final_loss = float(loss.item())
 
     if rank == 0:
@@ -303,6 +333,11 @@ def main():
                      share=round(r["total_ms"] / max(tot, 1e-9), 4), gbs=round(r["gbs"], 1), tflops=round(r["tflops"], 2))
                 for r in rows[:12]]
             res["profiled_ms_per_step"] = round(tot / prof_steps, 3)
+            # what the step would take if every profiled launch ran at its own roof (HBM 8 TB/s or fp32-MFMA peak,
+            # whichever is slower for that launch): the distance to "speed of light" of the whole launch list
+            sol = sum(r["launches"] * max(r["bytes"] / (HBM_PEAK_GBS * 1e6), r["flops"] / (FP32_MFMA_PEAK_TF * 1e9)) for r in rows)
+            res["profiled_roofline_ms_per_step"] = round(sol / prof_steps, 3)
+            res["profiled_gbytes_per_step"] = round(sum(r["launches"] * r["bytes"] for r in rows) / prof_steps / 1e9, 2)
             if eager_ms is not None:
                 res["eager_event_profiled_ms_per_step"] = round(eager_ms, 3)
                 res["roofline"]["source"] = ("eager re-run of the same steps with a HIP event pair around every launch "

@@ -32,7 +32,10 @@ def default_buckets(named_params) -> List[List[str]]:
 
 class BucketedDataParallel:
     def __init__(self, module: torch.nn.Module, buckets: Optional[Sequence[Sequence[str]]] = None,
-                 process_group=None, seed: int = 0):
+                 process_group=None, seed: int = 0, overlap: bool = True):
+        """overlap=True: all-reduces are launched from autograd hooks during backward.  overlap=False: nothing is
+        launched from hooks and `finish()` reduces all buckets -- for a forward/backward that is replayed from a
+        captured HIP graph (hooks do not run on replay, and collectives are kept out of the capture)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.module = module
@@ -48,6 +51,7 @@ class BucketedDataParallel:
         self.buckets = []
         self._pending = []
         self._use_avg = dist.get_backend(process_group) == "nccl"
+        self.overlap = overlap
         for bi, names in enumerate(buckets):
             params = [byname[n] for n in names]
             total = sum(p.numel() for p in params)
@@ -70,7 +74,7 @@ class BucketedDataParallel:
         def hook(param):
             b = self.buckets[bi]
             b["ready"] += 1
-            if b["ready"] == b["n"]:
+            if self.overlap and b["ready"] == b["n"]:
                 op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
                 b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
         return hook
@@ -83,6 +87,10 @@ class BucketedDataParallel:
 
     def finish(self):
         """Wait for the in-flight all-reduces (call after backward, before the optimizer step)."""
+        if not self.overlap:
+            op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
+            for b in self.buckets:
+                b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
         for b in self.buckets:
             if b["handle"] is None:
                 raise RuntimeError("a gradient bucket never became ready (parameter unused in this step?)")
