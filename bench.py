@@ -39,7 +39,7 @@ def kernel_model(name, key):
         N, C, H, W = key
         return (f"dw_fwd[N{N},C{C},{H}x{W}]", 4.0 * N * C * H * W * 2, 18.0 * N * C * H * W)
     if name == "uncr_dw_bwd":
-        N, C, H, W = key
+        N, C, H, W = key[-4:]
         return (f"dw_bwd[N{N},C{C},{H}x{W}]", 4.0 * N * C * H * W * 4, 36.0 * N * C * H * W)
     if name == "uncr_ew":
         op, planes, P, C, n_mean = key

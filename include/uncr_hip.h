@@ -50,6 +50,8 @@ typedef struct ihipStream_t* hipStream_t;
 
 int uncr_version(void);
 int uncr_debug_mfma_probe(float* out, int blocks, int iters, hipStream_t stream);   /* fp32-MFMA peak probe */
+/* debug: y = erf_f(x) (what 0), gelu_f (1), gelu_grad_f (2), raw v_exp_f32 2^x (3) -- accuracy probes */
+int uncr_debug_erf(const float* x, float* y, int n, int what, hipStream_t stream);
 int uncr_debug_mfma_probe_bf16(float* out, int blocks, int iters, hipStream_t stream);   /* bf16-MFMA peak probe */
 /* debug: out[32][32] = A[32][K] * B[K][32] through the 3-way bf16 split on v_mfma_f32_32x32x16_bf16
  * (terms = 1, 3, 6 or 9 partial products); numerics probe, K % 16 == 0 */
@@ -64,6 +66,7 @@ int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, int groups, 
 int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                            const float* gamma, const float* save_mean, const float* save_rstd, float* c1,
                            float* c2, float* c3, float* dgamma, float* dbeta, float* scratch /* [2*N*C], GroupNorm */,
+                           int centered /* 1: part.y = sum du*(h - mean) (uncr_dw_bwd with a mean array) */,
                            hipStream_t stream);
 
 /* ---- element-wise family with fused coefficients + partial statistics
@@ -86,6 +89,10 @@ int uncr_pw_coutp(int Cout);      /* padded output-channel count of the kernel v
 int uncr_pw_kpad(int Cin);        /* padded reduction length */
 int uncr_pw_tile_px(int Cout);    /* pixels per block == pixels per statistics slot */
 int uncr_pack_wt(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out, hipStream_t stream);
+/* the same for many weights in one launch: desc = n_items x 8 int64 in DEVICE memory {W, out, rows_k, cols_co, ld,
+ * transpose, 0, 0}; max_threads = max over items of uncr_pack_wt_threads */
+int uncr_pack_wt_threads(int rows_k, int cols_co);
+int uncr_pack_wt_batch(const long long* desc, int n_items, int max_threads, hipStream_t stream);
 int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, float* out, const float* k0,
                  const float* k1, const float* k2, const float* bias, int bias_stride_n, const float* aux,
                  const float* e0, const float* e1, const float* e2, const float* e3 /* epi 3 coefficients */,
@@ -108,7 +115,10 @@ int uncr_dw_fwd(const float* in, const float* cA, const float* cB, const float* 
                 int N, int C, int H, int W, hipStream_t stream);
 int uncr_dw_bwd(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2,
                 const float* k3, const float* cA1, const float* cB1, const float* w, float* du1, float* part,
-                float* dw_part, int N, int C, int H, int W, hipStream_t stream);
+                float* dw_part, const float* mean1 /* null: part.y = sum du1*h1; else sum du1*(h1 - mean), the
+                well-conditioned form for uncr_norm_finalize_bwd(centered = 1) */,
+                int mean_groups /* 0: mean1[c] (BatchNorm); G > 0: mean1[n*G + c/(C/G)] (GroupNorm) */,
+                int N, int C, int H, int W, hipStream_t stream);
 int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw, hipStream_t stream);
 
 /* ---- squeeze-excite MLP (uncrtaints.py:82-97) ---- */

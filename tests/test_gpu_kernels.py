@@ -166,13 +166,21 @@ def _depthwise_fwd_bwd(E, orc, H, W):
     partb = torch.empty(N * C, sb, 2, device=DEV)
     dwp = torch.empty(N * C, sb, 9, device=DEV)
     hb.call("uncr_dw_bwd", dev(du2), h2d, dev(h1.detach()), dev(c1), dev(c2), dev(c3), dev(A), dev(B),
-            dev(w.detach().reshape(C, 9)), du1, partb, dwp, N, C, H, W, E._stream())
+            dev(w.detach().reshape(C, 9)), du1, partb, dwp, None, 0, N, C, H, W, E._stream())
     close(f"dw_bwd_du1[{H}x{W}]", du1, du1_ref)
     close("dw_bwd_stats0", partb.sum(1)[:, 0], du1_ref.sum(dim=(2, 3)).reshape(-1))
     close("dw_bwd_stats1", partb.sum(1)[:, 1], (du1_ref * h1.detach()).sum(dim=(2, 3)).reshape(-1))
     dwd = torch.empty(C, 9, device=DEV)
     hb.call("uncr_dw_wgrad_reduce", dwp, N, C, sb, dwd, E._stream())
     close("dw_bwd_dw", dwd.view(C, 1, 3, 3), w.grad)
+    # centred second statistic: sum du1*(h1 - mean) with a per-channel (BatchNorm) and a per-(frame, group) mean
+    for groups in (0, 4):
+        mean = rand(C if groups == 0 else N * groups, seed=9, scale=2.0)
+        hb.call("uncr_dw_bwd", dev(du2), h2d, dev(h1.detach()), dev(c1), dev(c2), dev(c3), dev(A), dev(B),
+                dev(w.detach().reshape(C, 9)), du1, partb, dwp, dev(mean), groups, N, C, H, W, E._stream())
+        mfull = mean.view(1, C, 1, 1) if groups == 0 else mean.view(N, groups, 1, 1, 1).expand(N, groups, C // groups, 1, 1).reshape(N, C, 1, 1)
+        close(f"dw_bwd_stats1_centered[g{groups}]", partb.sum(1)[:, 1],
+              (du1_ref * (h1.detach() - mfull)).sum(dim=(2, 3)).reshape(-1))
 
 
 def _mb_module(norm, seed):

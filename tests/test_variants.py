@@ -107,7 +107,7 @@ def test_hip_variants(name):
             continue
         if is_zero_grad(k, g64):
             continue
-        close_vs_truth(f"{name}/grad[{k}]", v.grad, g32[k], g64[k])
+        close_vs_truth(f"{name}/grad[{k}]", v.grad, g32[k], g64[k], slack=10.0, cap=3e-4)   # see test_gpu_model.py
 
 
 @pytest.mark.gpu

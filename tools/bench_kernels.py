@@ -53,7 +53,7 @@ def main():
             partf, partb, dwp = torch.empty(Nf * C, sf, 2, device=dev), torch.empty(Nf * C, sb, 2, device=dev), torch.empty(Nf * C, sb, 9, device=dev)
             ms = timeit(lambda: hb.call("uncr_dw_fwd", h1, cA, cB, w, out, partf, Nf, C, H, W, E._stream()), iters)
             print(f"dw_fwd N={Nf}: {ms*1e3:.1f} us  {8.0*Nf*C*H*W/ms/1e6:.0f} GB/s")
-            ms = timeit(lambda: hb.call("uncr_dw_bwd", du2, h2, h1, k1, k2, k3, cA, cB, w, out, partb, dwp, Nf, C, H, W, E._stream()), iters)
+            ms = timeit(lambda: hb.call("uncr_dw_bwd", du2, h2, h1, k1, k2, k3, cA, cB, w, out, partb, dwp, None, 0, Nf, C, H, W, E._stream()), iters)
             print(f"dw_bwd N={Nf}: {ms*1e3:.1f} us  {16.0*Nf*C*H*W/ms/1e6:.0f} GB/s")
     elif what == "gemmscale":
         Cin, Cout = 128, 256

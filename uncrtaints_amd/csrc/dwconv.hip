@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
     const float* __restrict__ du2, const float* __restrict__ h2, const float* __restrict__ h1,
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
     const float* __restrict__ cA1, const float* __restrict__ cB1, const float* __restrict__ w,
-    float* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part, int C, int H, int W) {
+    float* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
+    const float* __restrict__ mean1, int mean_groups, int C, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int TR = DW_TR_BWD;
     const int plane = blockIdx.y, c = plane % C;
@@ -94,6 +95,8 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
     float* Gt = sm + (TR + 2) * pitch;       // reflect-padded g1 tile
     const float C1 = k1[plane], C2 = k2[plane], C3 = k3[plane];
     const float A1 = cA1[plane], B1 = cB1[plane];
+    // second statistic sum du1*(h1 - M1): with M1 = the norm's mean it is free of the |mean|/std cancellation
+    const float M1 = mean1 ? mean1[mean_groups > 0 ? (plane / C) * mean_groups + c / (C / mean_groups) : c] : 0.f;
     const size_t pbase = (size_t)plane * H * W;
     const int rows = min(TR, H - y0) + 2;
     // Staging: every load of the block is issued before the first use (one HBM round trip instead of one per row
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
                 const float dv = gelu_grad_f(u) * acc;
                 res[j] = dv;
                 s0 += dv;
-                s1 += dv * ph[j];
+                s1 += dv * (ph[j] - M1);
                 // depthwise weight gradient: dh2 at (y,x) times g1 at the reflect-padded neighbours
                 const float dc = dt[1][j + 1];
 #pragma unroll
@@ -257,7 +260,8 @@ int dw_fwd_row_launch(const float* in, const float* cA, const float* cB, const f
                       int C, int H, int slots, hipStream_t stream);
 int dw_bwd_row_launch(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2,
                       const float* k3, const float* cA1, const float* cB1, const float* w, float* du1, float* part,
-                      float* dw_part, int N, int C, int H, int slots, hipStream_t stream);
+                      float* dw_part, const float* mean1, int mean_groups, int N, int C, int H, int slots,
+                      hipStream_t stream);
 static int g_dw_row = 1;   // A/B switch (tests exercise both implementations)
 extern "C" int uncr_dw_set_row(int on) { const int old = g_dw_row; g_dw_row = on ? 1 : 0; return old; }
 
@@ -275,10 +279,13 @@ extern "C" int uncr_dw_fwd(const float* in, const float* cA, const float* cB, co
 
 extern "C" int uncr_dw_bwd(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2,
                            const float* k3, const float* cA1, const float* cB1, const float* w, float* du1,
-                           float* part, float* dw_part, int N, int C, int H, int W, hipStream_t stream) {
+                           float* part, float* dw_part, const float* mean1, int mean_groups, int N, int C, int H,
+                           int W, hipStream_t stream) {
+    if (mean1 && mean_groups > 0 && C % mean_groups) return UNCR_ESHAPE;
     if (N <= 0 || C <= 0 || H < 4 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
     if (g_dw_row && W == 256 && (H & 3) == 0)
-        return dw_bwd_row_launch(du2, h2, h1, k1, k2, k3, cA1, cB1, w, du1, part, dw_part, N, C, H, uncr_dw_slots_bwd(H), stream);
+        return dw_bwd_row_launch(du2, h2, h1, k1, k2, k3, cA1, cB1, w, du1, part, dw_part, mean1, mean_groups, N, C, H,
+                                 uncr_dw_slots_bwd(H), stream);
     const size_t lds = (size_t)2 * (DW_TR_BWD + 2) * (W + 8) * sizeof(float);
     if (lds > 150 * 1024) return UNCR_ESHAPE;
     auto kern = W <= 256 ? dw_bwd_kernel<5> : (W <= 512 ? dw_bwd_kernel<9> : dw_bwd_kernel<18>);
@@ -290,7 +297,7 @@ extern "C" int uncr_dw_bwd(const float* du2, const float* h2, const float* h1, c
         lds_attr[ki] = lds;
     }
     hipLaunchKernelGGL(kern, dim3(uncr_dw_slots_bwd(H), N * C), dim3(256), lds, stream, du2, h2, h1, k1, k2, k3, cA1,
-                       cB1, w, du1, (float2*)part, dw_part, C, H, W);
+                       cB1, w, du1, (float2*)part, dw_part, mean1, mean_groups, C, H, W);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -111,13 +111,13 @@ __global__ __launch_bounds__(256) void dw_fwd_row_kernel(const float* __restrict
 }
 
 // ---- backward (see dwconv.hip for the derivation of the reflect adjoint) ----
-// slots = ceil(H / 16) per plane (the ABI's statistics granularity); a 64-row tile fills its first slot, zeroes the rest
+// slots = ceil(H / 16) per plane (the ABI's statistics granularity)
 __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     const float* __restrict__ du2, const float* __restrict__ h2, const float* __restrict__ h1,
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
     const float* __restrict__ cA1, const float* __restrict__ cB1, const float* __restrict__ w,
-    float* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part, int C, int H, int planes,
-    int slots) {
+    float* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
+    const float* __restrict__ mean1, int mean_groups, int C, int H, int planes, int slots) {
     constexpr int W = 256;
     const int lane = threadIdx.x & 63;
     const int tiles = (H + DWR_TR - 1) / DWR_TR;
@@ -127,6 +127,8 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     const int y0 = tile * DWR_TR, y1 = min(H, y0 + DWR_TR);
     const float C1 = k1[plane], C2 = k2[plane], C3 = k3[plane];
     const float A1 = cA1[plane], B1 = cB1[plane];
+    // second statistic sum du1*(h1 - M1): with M1 = the norm's mean it is free of the |mean|/std cancellation
+    const float M1 = mean1 ? mean1[mean_groups > 0 ? (plane / C) * mean_groups + c / (C / mean_groups) : c] : 0.f;
     float wk[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
                 const float dv = pq[j] * res[j];
                 po[j] = dv;
                 s0 += dv;
-                s1 = fmaf(dv, ph[j], s1);
+                s1 = fmaf(dv, ph[j] - M1, s1);
                 // depthwise weight gradient: dh2 at (y, x) times g1 at the reflect-padded neighbours
                 const float dcj = dc.v[j + 1];
 #pragma unroll
@@ -240,20 +242,34 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
             }
             *(float4*)(du1 + pb + (size_t)y * W) = o;
         }
+        // one statistics slot per 16 rows (the ABI's granularity): short fp32 accumulation chains, the slots are
+        // combined in fp64 by the finalize / reduce kernels
+        if (((Y + 4 - y0) & 15) == 0 || Y + 4 >= y1) {
+            const float r0 = wave_sum_dpp(s0), r1 = wave_sum_dpp(s1);
+            float rg[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) rg[i] = wave_sum_dpp(gw[i]);
+            const int sl = tile * (DWR_TR / 16) + ((Y - y0) >> 4);
+            if (lane == 63 && sl < slots) {
+                const size_t slot = (size_t)plane * slots + sl;
+                part[slot] = make_float2(r0, r1);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) dw_part[slot * 9 + i] = rg[i];
+            }
+            s0 = 0.f; s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) gw[i] = 0.f;
+        }
     }
-    s0 = wave_sum_dpp(s0);
-    s1 = wave_sum_dpp(s1);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) gw[i] = wave_sum_dpp(gw[i]);
+    // slots of a partial last tile that received no rows
     if (lane == 63) {
-        const int sl = tile * (DWR_TR / 16);
-#pragma unroll
-        for (int k = 0; k < DWR_TR / 16; ++k) {
-            if (sl + k < slots) {
-                const size_t slot = (size_t)plane * slots + sl + k;
-                part[slot] = k == 0 ? make_float2(s0, s1) : make_float2(0.f, 0.f);
-#pragma unroll
-                for (int i = 0; i < 9; ++i) dw_part[slot * 9 + i] = k == 0 ? gw[i] : 0.f;
+        const int used = (y1 - y0 + 15) >> 4;
+        for (int k = used; k < DWR_TR / 16; ++k) {
+            const int sl = tile * (DWR_TR / 16) + k;
+            if (sl < slots) {
+                const size_t slot = (size_t)plane * slots + sl;
+                part[slot] = make_float2(0.f, 0.f);
+                for (int i = 0; i < 9; ++i) dw_part[slot * 9 + i] = 0.f;
             }
         }
     }
@@ -270,10 +286,11 @@ int dw_fwd_row_launch(const float* in, const float* cA, const float* cB, const f
 
 int dw_bwd_row_launch(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2,
                       const float* k3, const float* cA1, const float* cB1, const float* w, float* du1, float* part,
-                      float* dw_part, int N, int C, int H, int slots, hipStream_t stream) {
+                      float* dw_part, const float* mean1, int mean_groups, int N, int C, int H, int slots,
+                      hipStream_t stream) {
     const int planes = N * C, tiles = (H + DWR_TR - 1) / DWR_TR;
     hipLaunchKernelGGL(dw_bwd_row_kernel, dim3((planes * tiles + 3) / 4), dim3(256), 0, stream, du2, h2, h1, k1, k2,
-                       k3, cA1, cB1, w, du1, (float2*)part, dw_part, C, H, planes, slots);
+                       k3, cA1, cB1, w, du1, (float2*)part, dw_part, mean1, mean_groups, C, H, planes, slots);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

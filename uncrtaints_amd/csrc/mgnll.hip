@@ -263,4 +263,18 @@ extern "C" int uncr_debug_bf16split_probe(const float* A, const float* B, float*
     return UNCR_OK;
 }
 
+// ---- debug: the device erf_f / gelu_f / gelu_grad_f on an array (accuracy measurements, tools/probe_erf.py) ----
+__global__ __launch_bounds__(256) void erf_probe_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int what) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    y[i] = what == 0 ? erf_f(v) : (what == 1 ? gelu_f(v) : (what == 2 ? gelu_grad_f(v) : __builtin_amdgcn_exp2f(v)));
+}
+extern "C" int uncr_debug_erf(const float* x, float* y, int n, int what, hipStream_t stream) {
+    if (n <= 0) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(erf_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, y, n, what);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
 extern "C" int uncr_version() { return 1; }

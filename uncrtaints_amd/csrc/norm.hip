@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(
 __global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(
     const float2* __restrict__ part, int NP, int N, int C, int G, int P, const float* __restrict__ gamma,
     const float* __restrict__ save_mean, const float* __restrict__ save_rstd, float* __restrict__ c1,
-    float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ scratch) {
+    float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ scratch, int centered) {
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int Cg = C / G;   // <= 256
     __shared__ double s1[256], s2[256];
@@ -137,12 +137,13 @@ __global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(
     }
     __syncthreads();
     const double mu = (double)save_mean[n * G + g], r = (double)save_rstd[n * G + g];
+    const double mus = centered ? 0.0 : mu;   // centered partials already hold sum du*(h - mean)
     if (w == 0) {
         double a = 0.0, b = 0.0;
         for (int c = lane; c < Cg; c += 64) {
             const double gm = (double)gamma[g * Cg + c];
             a += gm * s1[c];
-            b += gm * r * (s2[c] - mu * s1[c]);
+            b += gm * r * (s2[c] - mus * s1[c]);
         }
         a = wave_sum_d(a);
         b = wave_sum_d(b);
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(
         c1[n * C + ch] = (float)(r * gm);
         c2[n * C + ch] = (float)(-r * r * sm2);
         c3[n * C + ch] = (float)(r * (-sm1 + r * mu * sm2));
-        scratch[(size_t)n * C + ch] = (float)(r * (s2[c] - mu * s1[c]));
+        scratch[(size_t)n * C + ch] = (float)(r * (s2[c] - mus * s1[c]));
         scratch[(size_t)N * C + (size_t)n * C + ch] = (float)s1[c];
     }
 }
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(256) void gn_dgb_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(
     const float2* __restrict__ part, int NP, int N, int C, int P, int train, const float* __restrict__ gamma,
     const float* __restrict__ save_mean, const float* __restrict__ save_rstd, float* __restrict__ c1,
-    float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    int centered) {
     const int c = blockIdx.x;
     __shared__ double red[8];
     __shared__ float k1, k2, k3;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(
         double S1 = 0, S2 = 0;
         for (int i = 0; i < 4; ++i) { S1 += red[2 * i]; S2 += red[2 * i + 1]; }
         const double mu = (double)save_mean[c], r = (double)save_rstd[c], gm = (double)gamma[c];
-        const double dg = r * (S2 - mu * S1);
+        const double dg = r * (centered ? S2 : S2 - mu * S1);   // centered: S2 = sum du*(h - mean)
         dgamma[c] = (float)dg;
         dbeta[c] = (float)S1;
         k1 = (float)(r * gm);
@@ -249,18 +251,18 @@ extern "C" int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, i
 extern "C" int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                                       const float* gamma, const float* save_mean, const float* save_rstd, float* c1,
                                       float* c2, float* c3, float* dgamma, float* dbeta, float* scratch,
-                                      hipStream_t stream) {
+                                      int centered, hipStream_t stream) {
     if (N <= 0 || C <= 0 || P <= 0 || !part) return UNCR_ESHAPE;
     if (kind == NORM_GROUP) {
         if (groups <= 0 || C % groups || C / groups > 256 || !scratch) return UNCR_EINVAL;
         hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(N * groups), dim3(256), 0, stream, (const float2*)part, NP, N,
-                           C, groups, P, gamma, save_mean, save_rstd, c1, c2, c3, scratch);
+                           C, groups, P, gamma, save_mean, save_rstd, c1, c2, c3, scratch, centered);
         UNCR_LAUNCH_CHECK();
         hipLaunchKernelGGL(gn_dgb_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, N, C, dgamma,
                            dbeta);
     } else if (kind == NORM_BATCH_TRAIN || kind == NORM_BATCH_EVAL) {
         hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(256), 0, stream, (const float2*)part, NP, N, C, P,
-                           kind == NORM_BATCH_TRAIN, gamma, save_mean, save_rstd, c1, c2, c3, dgamma, dbeta);
+                           kind == NORM_BATCH_TRAIN, gamma, save_mean, save_rstd, c1, c2, c3, dgamma, dbeta, centered);
     } else {
         return UNCR_EINVAL;
     }

@@ -458,6 +458,17 @@ extern "C" int uncr_pack_wt(const float* W, int rows_k, int cols_co, int ld, int
     return UNCR_OK;
 }
 
+// threads uncr_pack_wt needs for one weight (the batch launch is sized by the largest item)
+extern "C" int uncr_pack_wt_threads(int rows_k, int cols_co) {
+    if (cols_co > 256 || rows_k > 256 || cols_co <= 0 || rows_k <= 0) return -1;
+    if (use_split(cols_co)) return (int)(pw_split_wt_floats(rows_k, pw_coutp(cols_co)) / 12);   // 3 x 16 B per thread
+    return uncr_pw_kpad(rows_k) * pw_coutp(cols_co);
+}
+extern "C" int uncr_pack_wt_batch(const long long* desc, int n_items, int max_threads, hipStream_t stream) {
+    if (!desc || n_items <= 0 || max_threads <= 0) return UNCR_EINVAL;
+    return pw_pack_batch(desc, n_items, max_threads, g_split, stream);
+}
+
 extern "C" int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, float* out, const float* k0,
                             const float* k1, const float* k2, const float* bias, int bias_stride_n, const float* aux,
                             const float* e0, const float* e1, const float* e2, const float* e3, float* part, int N,

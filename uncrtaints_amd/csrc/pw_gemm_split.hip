@@ -362,10 +362,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
 #if PWS_PRO == 0
 // Wp[ks][cotile][part][lane][8 bf16] from W[co][k] (transpose=1) or W[k][co] (transpose=0); zero padded to
 // Kp = 32*ceil(rows_k/32) and cp output channels.  One thread per (ks, cotile, lane): 3 x 16 B.
-__global__ __launch_bounds__(256) void pack_wt_split_kernel(const float* __restrict__ W, int rows_k, int cols_co,
-                                                            int ld, int transpose, int nks, int nct,
-                                                            u32x4_t* __restrict__ out) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_wt_split_item(const float* __restrict__ W, int rows_k, int cols_co, int ld,
+                                                   int transpose, int nks, int nct, u32x4_t* __restrict__ out,
+                                                   int idx) {
     if (idx >= nks * nct * 64) return;
     const int lane = idx & 63, cot = (idx >> 6) % nct, ks = (idx >> 6) / nct;
     const int co = cot * 32 + (lane & 31), kb = 16 * ks + 8 * (lane >> 5);
@@ -381,6 +380,39 @@ __global__ __launch_bounds__(256) void pack_wt_split_kernel(const float* __restr
     o[0] = u32x4_t{pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]), pack_bf16x2(h[4], h[5]), pack_bf16x2(h[6], h[7])};
     o[64] = u32x4_t{pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7])};
     o[128] = u32x4_t{pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]), pack_bf16x2(l[4], l[5]), pack_bf16x2(l[6], l[7])};
+}
+__global__ __launch_bounds__(256) void pack_wt_split_kernel(const float* __restrict__ W, int rows_k, int cols_co,
+                                                            int ld, int transpose, int nks, int nct,
+                                                            u32x4_t* __restrict__ out) {
+    pack_wt_split_item(W, rows_k, cols_co, ld, transpose, nks, nct, out, blockIdx.x * 256 + threadIdx.x);
+}
+
+// all 1x1-conv weights of a model in ONE launch (33 pack launches per step otherwise): blockIdx.y = item,
+// descriptor = 8 x int64 {W, out, rows_k, cols_co, ld, transpose, -, -} in device memory (graph-replay safe)
+__global__ __launch_bounds__(256) void pack_wt_batch_kernel(const long long* __restrict__ desc, int split_on) {
+    const long long* d = desc + (size_t)blockIdx.y * 8;
+    const float* W = (const float*)d[0];
+    float* out = (float*)d[1];
+    const int rows_k = (int)d[2], cols_co = (int)d[3], ld = (int)d[4], transpose = (int)d[5];
+    const int cp = cols_co > 128 ? 256 : (cols_co > 64 ? 128 : (cols_co > 32 ? 64 : 32));
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (split_on && cp >= 128) {
+        const int nks = 2 * (((rows_k + PWS_KC - 1) / PWS_KC + 1) / 2 * 2);
+        pack_wt_split_item(W, rows_k, cols_co, ld, transpose, nks, cp / 32, (u32x4_t*)out, idx);
+    } else {
+        const int Kp = (rows_k + 31) / 32 * 32;
+        if (idx >= Kp * cp) return;
+        const int k = idx / cp, co = idx % cp;
+        float v = 0.f;
+        if (k < rows_k && co < cols_co) v = transpose ? W[(size_t)co * ld + k] : W[(size_t)k * ld + co];
+        out[idx] = v;
+    }
+}
+int pw_pack_batch(const long long* desc, int n_items, int max_threads, int split_on, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_wt_batch_kernel, dim3((max_threads + 255) / 256, n_items), dim3(256), 0, stream, desc,
+                       split_on);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
 }
 
 // k-steps in the packed weights: chunk count padded to even (the DEPTH = 2 kernels compute chunk pairs)

@@ -12,6 +12,8 @@ into per-(frame,channel) coefficients and the consuming kernel applies them in i
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -123,14 +125,55 @@ class NormBwd:
     dbeta: Tensor
 
 
-def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor) -> NormBwd:
+def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor, centered: bool = False) -> NormBwd:
+    """centered: the partials' second component is sum du*(h - mean) (producer was given nf.mean)."""
     dev = gamma.device
     c1, c2, c3 = _f32((N * C,), dev), _f32((N * C,), dev), _f32((N * C,), dev)
     dg, db = _f32((C,), dev), _f32((C,), dev)
     scratch = _f32((2 * N * C,), dev) if nf.kind == NORM_GROUP else None
     hb.call("uncr_norm_finalize_bwd", part.buf, part.slots, N, C, nf.groups, P, nf.kind, gamma, nf.mean, nf.rstd,
-            c1, c2, c3, dg, db, scratch, _stream())
+            c1, c2, c3, dg, db, scratch, 1 if centered else 0, _stream())
     return NormBwd(c1, c2, c3, dg, db)
+
+
+# ---- batched weight packing: every 1x1-conv weight of a model in ONE launch at the start of a forward ----
+_PACK_CACHE: Dict[tuple, tuple] = {}     # (data_ptr, transpose, R, Cc) -> (packed view, weight version)
+_PACK_PLANS: Dict[tuple, tuple] = {}     # plan key -> (descriptor tensor, flat output, views, max_threads)
+
+
+def prepack(weights) -> None:
+    """weights: iterable of (W2d [R][Ccols] contiguous view of a parameter, transpose).  Packs all of them with one
+    kernel launch into a per-plan static buffer and remembers the results for `pack_wt` until the next `prepack`
+    (entries are ignored when the parameter's version counter has moved, i.e. after an in-place update)."""
+    weights = [(w, bool(tr)) for w, tr in weights if w.is_contiguous()]
+    if not weights or os.environ.get("UNCR_NO_PREPACK"):      # env: development switch (bisecting)
+        return
+    key = tuple((w.data_ptr(), tr, w.shape[0], w.shape[1]) for w, tr in weights)
+    plan = _PACK_PLANS.get(key)
+    if plan is None:
+        dev = weights[0][0].device
+        sizes, thr, dims = [], [], []
+        for w, tr in weights:
+            R, Cc = w.shape
+            rows_k, cols_co = (Cc, R) if tr else (R, Cc)
+            sizes.append((hb.query("uncr_pw_wt_floats", rows_k, cols_co) + 3) // 4 * 4)     # keep 16-B alignment
+            thr.append(hb.query("uncr_pack_wt_threads", rows_k, cols_co))
+            dims.append((rows_k, cols_co, Cc))
+        flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        views, rows, off = [], [], 0
+        for (w, tr), n, (rows_k, cols_co, ld) in zip(weights, sizes, dims):
+            v = flat[off:off + n]
+            views.append(v)
+            rows.append([w.data_ptr(), v.data_ptr(), rows_k, cols_co, ld, 1 if tr else 0, 0, 0])
+            off += n
+        desc = torch.tensor(rows, dtype=torch.int64).to(dev)
+        plan = (desc, flat, views, max(thr))
+        _PACK_PLANS[key] = plan
+    desc, _, views, max_threads = plan
+    hb.call("uncr_pack_wt_batch", desc, len(weights), max_threads, _stream())
+    _PACK_CACHE.clear()
+    for (w, tr), v, k in zip(weights, views, key):
+        _PACK_CACHE[k] = (v, w._version)
 
 
 def pack_wt(W2d: Tensor, transpose: bool) -> Tensor:
@@ -138,6 +181,9 @@ def pack_wt(W2d: Tensor, transpose: bool) -> Tensor:
     W[k][co] (opaque layout: fp32 [Kpad][COUTP] for Cout <= 64, pre-split bf16 MFMA fragments otherwise)."""
     W2d = W2d.contiguous()
     R, Cc = W2d.shape
+    hit = _PACK_CACHE.get((W2d.data_ptr(), bool(transpose), R, Cc))
+    if hit is not None and hit[1] == W2d._version:
+        return hit[0]
     rows_k, cols_co = (Cc, R) if transpose else (R, Cc)
     out = _f32((hb.query("uncr_pw_wt_floats", rows_k, cols_co),), W2d.device)
     hb.call("uncr_pack_wt", W2d, rows_k, cols_co, Cc, 1 if transpose else 0, out, _stream())
@@ -282,12 +328,14 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     part1 = Part(_f32((N * Ch, slots, 2), dev), slots)
     dw_part = _f32((N * Ch, slots, 9), dev)
     wdw = p["wdw"].reshape(Ch, 9).contiguous()
-    hb.call("uncr_dw_bwd", du2, h2, h1, b2.c1, b2.c2, b2.c3, n1.A, n1.B, wdw, du1, part1.buf, dw_part, N, Ch, H, W,
-            _stream())
+    # statistics for the norm-1 backward in centred form (sum du1*(h1 - mean1)): h1 is the raw pw1 output, whose
+    # channel means can be many standard deviations from zero
+    hb.call("uncr_dw_bwd", du2, h2, h1, b2.c1, b2.c2, b2.c3, n1.A, n1.B, wdw, du1, part1.buf, dw_part, n1.mean,
+            n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, H, W, _stream())
     dwdw = _f32((Ch, 9), dev)
     hb.call("uncr_dw_wgrad_reduce", dw_part, N, Ch, slots, dwdw, _stream())
     g["wdw"] = dwdw.view_as(p["wdw"])
-    b1 = norm_bwd(part1, N, Ch, P, n1, p["n1w"])
+    b1 = norm_bwd(part1, N, Ch, P, n1, p["n1w"], centered=True)
     g["n1w"], g["n1b"] = b1.dgamma, b1.dbeta
     k1 = (b1.c1, b1.c2, b1.c3)
 

@@ -357,11 +357,36 @@ class UNCRTAINTS(nn.Module):
         self.variance = None
         self._last_attention = None
 
+    def _pack_list(self):
+        """(weight as [Cout][Cin], transpose) for every pointwise GEMM of forward and backward (engine.pack_wt calls)."""
+        out = []
+
+        def both(w):
+            w2 = w.reshape(w.shape[0], -1)
+            out.append((w2, True))
+            if self.training or torch.is_grad_enabled():
+                out.append((w2, False))
+        for mod in self.modules():
+            if isinstance(mod, MBConv):
+                f = mod.conv.fn
+                both(f[0].weight)
+                both(f[7].weight)
+        both(self.in_conv.conv.conv[0].weight)
+        if not self.is_mono:
+            te = self.temporal_encoder
+            p = _ltae_params(te)
+            both(p["inconv_w"])
+            both(p["fc_w"])
+        if not self.separate_out:
+            both(self.out_conv.conv.conv[0].weight)
+        return out
+
     def forward(self, input, batch_positions=None):
         if not input.is_cuda:
             raise RuntimeError("uncrtaints_amd.UNCRTAINTS runs on the GPU only (HIP kernels); move the model and "
                                "the inputs to the cuda device")
         input = input.contiguous().float()
+        E.prepack(self._pack_list())                                       # every 1x1-conv weight, one launch
         pad = E.pad_mask_of(input, float(self.pad_value))                  # [B,T] int32, uncrtaints.py:392-394
         out = self.in_conv.smart_forward(input)                            # [B,T,C,H,W]
         part = None
