@@ -92,6 +92,11 @@ def main():
         for _ in range(3):
             E.pw_gemm(x, Wt, N, Cin, Cout, P, pro=3, k=k, x2=x2, epi=3, aux=h2, ek=ek)          # fused dz + pass-B
             E.pw_gemm(x, Wt, N, Cin, Cout, P, pro=1, k=k, epi=1)                                # pw1 forward
+        # the two wide weight-gradient GEMMs of an MBConv backward
+        d = torch.randn(N, 256, P, device=dev); d2 = torch.randn(N, 256, P, device=dev); xx = torch.randn(N, 128, P, device=dev)
+        dk = tuple(torch.randn(N * 256, device=dev) for _ in range(3)); xk = (torch.randn(N * 128, device=dev), torch.randn(N * 128, device=dev), None)
+        for _ in range(3):
+            E.pw_wgrad(d, xx, N, 256, 128, P, pro_d=3, dk=dk, d2=d2, pro_x=1, xk=xk)
         torch.cuda.synchronize()
         print("done")
     elif what == "ablate":
