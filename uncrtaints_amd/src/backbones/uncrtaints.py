@@ -129,7 +129,7 @@ class MBConv(TemporallySharedBlock):
 
     def forward(self, x):
         y = _MBConvFn.apply(x, self, *self._params())
-        if self.training:
+        if self.training and not getattr(self, "_nbt_deferred", False):
             for m in self._norms():
                 if isinstance(m, nn.BatchNorm2d):
                     m.num_batches_tracked += 1
@@ -387,6 +387,15 @@ class UNCRTAINTS(nn.Module):
                                "the inputs to the cuda device")
         input = input.contiguous().float()
         E.prepack(self._pack_list())                                       # every 1x1-conv weight, one launch
+        if self.training:
+            # BatchNorm bookkeeping of all MBConv blocks in one multi-tensor launch (20 scalar-add kernels otherwise)
+            nbt = []       # rebuilt per call: buffers are re-created by .to() / load_state_dict(assign=True)
+            for mod in self.modules():
+                if isinstance(mod, MBConv):
+                    mod._nbt_deferred = True
+                    nbt += [n.num_batches_tracked for n in mod._norms() if isinstance(n, nn.BatchNorm2d)]
+            if nbt:
+                torch._foreach_add_(nbt, 1)
         pad = E.pad_mask_of(input, float(self.pad_value))                  # [B,T] int32, uncrtaints.py:392-394
         out = self.in_conv.smart_forward(input)                            # [B,T,C,H,W]
         part = None
