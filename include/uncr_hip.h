@@ -87,7 +87,8 @@ int uncr_pw_set_split(int on);
 int uncr_pw_wt_floats(int rows_k, int cols_co);   /* floats to allocate for uncr_pack_wt's output */
 int uncr_pw_coutp(int Cout);      /* padded output-channel count of the kernel variant */
 int uncr_pw_kpad(int Cin);        /* padded reduction length */
-int uncr_pw_tile_px(int Cout);    /* pixels per block == pixels per statistics slot */
+int uncr_pw_tile_px(int Cout);    /* pixels per tile of the kernel variant (P must be a multiple) */
+int uncr_pw_stat_slots(int N, int Cout, int P);   /* statistics slots per (frame, channel) written when epi != 0 */
 int uncr_pack_wt(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out, hipStream_t stream);
 /* the same for many weights in one launch: desc = n_items x 8 int64 in DEVICE memory {W, out, rows_k, cols_co, ld,
  * transpose, 0, 0}; max_threads = max over items of uncr_pack_wt_threads */

@@ -50,6 +50,7 @@ int pw_split_launch_p3(const PwArgs& g, int N, int cp, hipStream_t stream);
 int pw_split_launch_p4(const PwArgs& g, int N, int cp, hipStream_t stream);
 int pw_split_pack(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out, hipStream_t stream);
 size_t pw_split_wt_floats(int rows_k, int cp);
+int pw_split_blocks_per_frame(int N, int P);
 int pw_pack_batch(const long long* desc, int n_items, int max_threads, int split_on, hipStream_t stream);
 
 // pw_wgrad_split.hip

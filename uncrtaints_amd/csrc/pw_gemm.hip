@@ -436,6 +436,13 @@ static bool use_split(int Cout) { return g_split && pw_coutp(Cout) >= 128; }
 
 extern "C" int uncr_pw_coutp(int Cout) { return Cout <= 256 ? pw_coutp(Cout) : -1; }
 extern "C" int uncr_pw_kpad(int Cin) { return ((Cin + 31) / 32) * 32; }
+// statistics slots per (frame, channel) that uncr_pw_gemm(epi != 0) writes for this problem
+extern "C" int uncr_pw_stat_slots(int N, int Cout, int P) {
+    if (N <= 0 || Cout <= 0 || Cout > 256 || P <= 0) return -1;
+    if (use_split(Cout)) return P % 128 ? -1 : pw_split_blocks_per_frame(N, P);
+    const int tp = pw_coutp(Cout) >= 128 ? 128 : 256;
+    return P % tp ? -1 : P / tp;
+}
 extern "C" int uncr_pw_tile_px(int Cout) {
     const int cp = pw_coutp(Cout);
     return (cp >= 128) ? 128 : 256;

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         for (int c = tid; c < COUTP; c += NT) {
             const int cc = c < Cout ? c : Cout - 1;
             const float b = pb[g.bias ? cc : 0];
+            red[c][0] = 0.f; red[c][1] = 0.f;
             ecf[0][c] = g.bias ? b : 0.f;
             if constexpr (EPI == 3) {
                 const int ci = n * Cout + cc;
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                     if constexpr (EPI != 0) {
                         s0 = half_wave_sum_dpp(s0);
                         s1 = half_wave_sum_dpp(s1);
-                        if (j == 31) { red[col][0] = s0; red[col][1] = s1; }
+                        if (j == 31) { red[col][0] += s0; red[col][1] += s1; }   // this lane owns column col in the block
                     }
                 }
             }
@@ -332,15 +333,15 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
         ldb(&xs[par][0] + rd_off, 1, bm);
         ldb(&xs[par][0] + rd_off, 0, bh);
-        if constexpr (EPI != 0) {
-            // red is next written by the following tile's pass 1, at least one chunk barrier after these reads
-            __syncthreads();
-            for (int c = tid; c < COUTP; c += NT)
-                if (c < Cout) g.part[((size_t)n * Cout + c) * ntile + tile] = make_float2(red[c][0], red[c][1]);
-        }
 #ifdef PWS_STAMP
         tepi += __builtin_readcyclecounter() - te0;
 #endif
+    }
+    if constexpr (EPI != 0) {
+        // one statistics slot per block (its tiles were summed in a fixed order): G slots per frame instead of P/128
+        __syncthreads();
+        for (int c = tid; c < COUTP; c += NT)
+            if (c < Cout) g.part[((size_t)n * Cout + c) * G + bx] = make_float2(red[c][0], red[c][1]);
     }
 #undef PWS_MF
 #ifdef PWS_STAMP
@@ -442,9 +443,10 @@ static void pws_launch_epi(const PwArgs& g, dim3 grid, int cp, hipStream_t strea
 
 #define PWS_CAT2(a, b) a##b
 #define PWS_CAT(a, b) PWS_CAT2(a, b)
-int PWS_CAT(pw_split_launch_p, PWS_PRO)(const PwArgs& g, int N, int cp, hipStream_t stream) {
-    if (g.P % PWS_TP) return UNCR_ESHAPE;
-    // persistent: about two resident blocks per CU in total, split evenly over the frames
+#if PWS_PRO == 0
+// persistent grid: about two resident blocks per CU in total, split evenly over the frames; also the number of
+// statistics slots per (frame, channel) the kernels write
+int pw_split_blocks_per_frame(int N, int P) {
     static int slots = 0;
     if (!slots) {
         int dev = 0, ncu = 0;
@@ -453,11 +455,17 @@ int PWS_CAT(pw_split_launch_p, PWS_PRO)(const PwArgs& g, int N, int cp, hipStrea
             ncu = 256;
         slots = 2 * ncu;
     }
-    const int ntile = g.P / PWS_TP;
+    const int ntile = P / PWS_TP;
     int bpf = slots / N;
     if (bpf < 1) bpf = 1;
     if (bpf > ntile) bpf = ntile;
-    dim3 grid(bpf, N);
+    return bpf;
+}
+#endif
+
+int PWS_CAT(pw_split_launch_p, PWS_PRO)(const PwArgs& g, int N, int cp, hipStream_t stream) {
+    if (g.P % PWS_TP) return UNCR_ESHAPE;
+    dim3 grid(pw_split_blocks_per_frame(N, g.P), N);
     switch (g.epi) {
         case 0: pws_launch_epi<0>(g, grid, cp, stream); break;
         case 1: pws_launch_epi<1>(g, grid, cp, stream); break;

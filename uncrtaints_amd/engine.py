@@ -198,7 +198,9 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
         out = _f32((N, Cout, P), x.device)
     part = None
     if epi:
-        slots = P // hb.query("uncr_pw_tile_px", Cout)
+        slots = hb.query("uncr_pw_stat_slots", N, Cout, P)
+        if slots <= 0:
+            raise RuntimeError(f"pw_gemm: P={P} is not a multiple of the {hb.query('uncr_pw_tile_px', Cout)}-pixel tile")
         part = Part(_f32((N * Cout, slots, 2), x.device), slots)
     hb.call("uncr_pw_gemm", x, x2, Wt, out, k[0], k[1], k[2], bias, Cout if bias_per_frame else 0, aux,
             ek[0], ek[1], ek[2], ek[3], part.buf if part else None, N, Cin, Cout, P, pro, epi, _stream())
