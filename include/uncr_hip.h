@@ -164,6 +164,18 @@ int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const 
                        float* de, float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int AH,
                        int AW, hipStream_t stream);
 
+/* ---- element-wise criteria of get_loss (losses.py:14-32): kind 0 GaussianNLLLoss (losses.py:46-128: var clamped to
+ *      eps with identity gradient, optional 0.5*log(2 pi)), 1 nn.L1Loss, 2 nn.MSELoss.  The backward needs var of the
+ *      full shape (the host expands a broadcast one); `inner` > 1 in the forward = var broadcast over the innermost
+ *      `inner` elements. ---- */
+int uncr_eltloss_blocks(long long n);
+int uncr_eltloss_fwd(int kind, const float* pred, const float* targ, const float* var, float* loss_none,
+                     float* vclamp, float* part /* [uncr_eltloss_blocks(n)] */, float* loss_out, int* neg_flag,
+                     long long n, int inner, float eps, int full, int reduction, hipStream_t stream);
+int uncr_eltloss_bwd(int kind, const float* pred, const float* targ, const float* var, const float* gscalar,
+                     const float* gnone, float* dpred, float* dvar, long long n, float eps, int reduction,
+                     hipStream_t stream);
+
 /* ---- MGNLL loss (losses.py:131-218) and ensemble combine (ensemble_reconstruct.py:116-133) ---- */
 int uncr_mgnll_blocks(int P);
 int uncr_mgnll_fwd(const float* pred, const float* targ, const float* var, float* loss_none, float* part,

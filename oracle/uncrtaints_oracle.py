@@ -344,6 +344,39 @@ def mgnll(pred: Tensor, target: Tensor, var: Tensor, mode: str = "diag", eps: fl
     return loss, variance
 
 
+def gnll(pred: Tensor, target: Tensor, var: Tensor, eps: float = 1e-8, full: bool = True, reduction: str = "mean"):
+    """Element-wise Gaussian NLL (reference losses.py:46-128): var clamped to eps WITHOUT blocking its gradient
+    (clone + in-place clamp under no_grad, losses.py:114-116); returns (loss, clamped var)."""
+    if var.shape != pred.shape:
+        if pred.shape[:-1] == var.shape:
+            var = var.unsqueeze(-1)
+        elif not (pred.shape[:-1] == var.shape[:-1] and var.shape[-1] == 1):
+            raise ValueError("var is of incorrect size")
+    if reduction not in ("none", "mean", "sum"):
+        raise ValueError(reduction + " is not valid")
+    if bool((var < 0).any()):
+        raise ValueError("var has negative entry/entries")
+    v = var + (var.clamp(min=eps) - var).detach()            # value clamped, identity gradient
+    loss = 0.5 * (torch.log(v) + (pred - target) ** 2 / v)
+    if full:
+        loss = loss + 0.5 * math.log(2 * math.pi)
+    if reduction == "mean":
+        return loss.mean(), v
+    if reduction == "sum":
+        return loss.sum(), v
+    return loss, v
+
+
+def l1_loss(pred: Tensor, target: Tensor):
+    """nn.L1Loss() of get_loss 'l1' (losses.py:21-23)."""
+    return (pred - target).abs().mean()
+
+
+def l2_loss(pred: Tensor, target: Tensor):
+    """nn.MSELoss() of get_loss 'l2' (losses.py:24-26)."""
+    return ((pred - target) ** 2).mean()
+
+
 def loss_from_output(out: Tensor, target: Tensor, cfg: OracleConfig):
     """BaseModel.get_loss_G slicing (base_model.py:80-85)."""
     return mgnll(out[:, :, :cfg.mean_idx], target, out[:, :, cfg.mean_idx:cfg.vars_idx], mode=cfg.covmode)[0]

@@ -183,6 +183,38 @@ def case_mgnll():
     print("g3_mgnll", idx, "cases")
 
 
+def case_eltlosses():
+    """GaussianNLLLoss (losses.py:46-128, get_loss 'GNLL') and the l1 / l2 criteria (get_loss 'l1'/'l2')."""
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    idx = 0
+    for B in (1, 3):
+        H, W = 6, 5
+        pred = torch.rand(B, 1, 13, H, W, generator=g, requires_grad=True)
+        targ = torch.rand(B, 1, 13, H, W, generator=g)
+        var0 = torch.rand(B, 1, 13, H, W, generator=g) * 0.5 + 1e-3
+        var0[0, 0, 0, 0, 0] = 1e-10          # below the clamp (eps=1e-8)
+        var0[-1, 0, -1, 2, 3] = 0.0           # exactly zero
+        var = var0.clone().requires_grad_(True)
+        for red in ("none", "mean", "sum"):
+            c = losses.GaussianNLLLoss(reduction=red, eps=1e-8, full=True)
+            l, v = c(pred, targ, var)
+            out[f"k{idx}/gnll_{red}"] = l.detach().numpy()
+            if red == "mean":
+                out[f"k{idx}/gnll_variance"] = v.detach().numpy()
+                gp, gv = torch.autograd.grad(l, (pred, var))
+                out[f"k{idx}/gnll_dpred"], out[f"k{idx}/gnll_dvar"] = gp.numpy(), gv.numpy()
+        for name, crit in (("l1", torch.nn.L1Loss()), ("l2", torch.nn.MSELoss())):
+            l = crit(pred, targ)
+            out[f"k{idx}/{name}"] = l.detach().numpy()
+            out[f"k{idx}/{name}_dpred"] = torch.autograd.grad(l, pred)[0].numpy()
+        out[f"k{idx}/pred"], out[f"k{idx}/target"], out[f"k{idx}/var"] = pred.detach().numpy(), targ.numpy(), var0.numpy()
+        idx += 1
+    out["n"] = np.array(idx)
+    np.savez_compressed(os.path.join(HERE, "g9_eltlosses.npz"), **out)
+    print("g9_eltlosses", idx, "cases")
+
+
 def case_posenc():
     pe = PositionalEncoder(256 // 16, T=1000, repeat=16)
     dates = torch.tensor([[1400., 1433., 1799.], [0., 1., 1000.]])
@@ -302,9 +334,12 @@ if __name__ == "__main__":
     case_model("g1_iso_t6", "iso", 1, 6, 64, 64, seed=2, full_grads=False)
   if "--only-variants" in sys.argv:
     case_variants(); sys.exit(0)
+  if "--only-eltlosses" in sys.argv:
+    case_eltlosses(); sys.exit(0)
   if "--only-trainseq" not in sys.argv:
     case_variants()
     case_mgnll()
+    case_eltlosses()
     case_posenc()
     case_ensemble()
   case_trainseq()

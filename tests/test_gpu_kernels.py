@@ -440,3 +440,39 @@ def test_positional_table_and_ensemble(E):
         m, v = E.ensemble_combine(mu, var, mode)
         close(f"ens_mean[{mode}]", m, torch.from_numpy(g8["mean_ens"]).float(), tol=1e-6)
         close(f"ens_var[{mode}]", v, torch.from_numpy(g8[key]).float(), tol=2e-5)
+
+
+def test_eltlosses_gnll_l1_l2():
+    """get_loss 'GNLL' / 'l1' / 'l2' on the HIP path vs the reference-generated fixture (values and gradients)."""
+    from conftest import load_golden
+    from uncrtaints_amd.src import losses
+    g = load_golden("g9_eltlosses")
+    for i in range(int(g["n"])):
+        pred = torch.from_numpy(g[f"k{i}/pred"]).to(DEV).requires_grad_(True)
+        targ = torch.from_numpy(g[f"k{i}/target"]).to(DEV)
+        var = torch.from_numpy(g[f"k{i}/var"]).to(DEV).requires_grad_(True)
+        for red in ("none", "mean", "sum"):
+            l, v = losses.GaussianNLLLoss(reduction=red, eps=1e-8, full=True)(pred, targ, var)
+            close(f"gnll[{red}]", l, torch.from_numpy(np.asarray(g[f"k{i}/gnll_{red}"])), tol=5e-6)
+        l, v = losses.GaussianNLLLoss(reduction="mean", eps=1e-8, full=True)(pred, targ, var)
+        close("gnll_variance", v, torch.from_numpy(g[f"k{i}/gnll_variance"]), tol=1e-6)
+        gp, gv = torch.autograd.grad(l, (pred, var))
+        close("gnll_dpred", gp, torch.from_numpy(g[f"k{i}/gnll_dpred"]), tol=5e-6)
+        close("gnll_dvar", gv, torch.from_numpy(g[f"k{i}/gnll_dvar"]), tol=5e-6)
+        # element-wise upstream gradient (reduction='none')
+        ln, _ = losses.GaussianNLLLoss(reduction="none", eps=1e-8, full=True)(pred, targ, var)
+        gp2, = torch.autograd.grad(ln.sum() / ln.numel(), pred)
+        close("gnll_dpred_via_none", gp2, torch.from_numpy(g[f"k{i}/gnll_dpred"]), tol=5e-6)
+        for name, crit in (("l1", losses.L1Loss()), ("l2", losses.MSELoss())):
+            l = crit(pred, targ)
+            close(name, l, torch.from_numpy(np.asarray(g[f"k{i}/{name}"])), tol=5e-6)
+            close(name + "_dpred", torch.autograd.grad(l, pred)[0], torch.from_numpy(g[f"k{i}/{name}_dpred"]), tol=5e-6)
+
+    class Cfg:
+        loss, covmode = "GNLL", "diag"
+    crit = losses.get_loss(Cfg)
+    l, v = losses.calc_loss(crit, Cfg, pred, targ, var)
+    assert l.dim() == 0 and v.shape == var.shape
+    with pytest.raises(ValueError):
+        losses.GaussianNLLLoss(check_negative=True)(pred, targ, -var.detach().abs() - 1.0)
+

@@ -130,3 +130,23 @@ def test_explicit_formulas_agree_with_aten_ops():
         finally:
             orc.USE_ATEN = True
     assert rel_err(outs[False].numpy(), outs[True].numpy()) < TOL
+
+
+def test_eltlosses_match_reference():
+    """GaussianNLLLoss / l1 / l2 (get_loss 'GNLL', 'l1', 'l2') restated in the oracle vs the reference's values."""
+    g = load_golden("g9_eltlosses")
+    for i in range(int(g["n"])):
+        pred = torch.from_numpy(g[f"k{i}/pred"]).requires_grad_(True)
+        targ = torch.from_numpy(g[f"k{i}/target"])
+        var = torch.from_numpy(g[f"k{i}/var"]).requires_grad_(True)
+        for red in ("none", "mean", "sum"):
+            l, v = orc.gnll(pred, targ, var, eps=1e-8, full=True, reduction=red)
+            assert rel_err(l.detach().numpy(), g[f"k{i}/gnll_{red}"]) < 2e-6
+        l, v = orc.gnll(pred, targ, var, eps=1e-8, full=True, reduction="mean")
+        assert rel_err(v.detach().numpy(), g[f"k{i}/gnll_variance"]) < 1e-7
+        gp, gv = torch.autograd.grad(l, (pred, var))
+        assert rel_err(gp.numpy(), g[f"k{i}/gnll_dpred"]) < 2e-6 and rel_err(gv.numpy(), g[f"k{i}/gnll_dvar"]) < 2e-6
+        for name, fn in (("l1", orc.l1_loss), ("l2", orc.l2_loss)):
+            l = fn(pred, targ)
+            assert rel_err(l.detach().numpy(), g[f"k{i}/{name}"]) < 2e-6
+            assert rel_err(torch.autograd.grad(l, pred)[0].numpy(), g[f"k{i}/{name}_dpred"]) < 2e-6

@@ -105,6 +105,90 @@ __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict_
     if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) * scale);
 }
 
+// ---- element-wise criteria of get_loss (losses.py:14-32): GaussianNLLLoss (losses.py:46-128), nn.L1Loss, nn.MSELoss ----
+// kind 0: l = 0.5*(log v + e^2/v) [+ 0.5*log(2 pi)], v = max(var, eps) with identity gradient; 1: |e|; 2: e^2.
+// var_stride0 == 0: var has the full shape; else var is broadcast along the innermost `inner` elements (size-1 last dim).
+__global__ __launch_bounds__(256) void eltloss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ targ,
+                                                          const float* __restrict__ var, float* __restrict__ loss_none,
+                                                          float* __restrict__ vclamp, float* __restrict__ part,
+                                                          int* __restrict__ neg_flag, long long n, int inner, int kind,
+                                                          float eps, float cst) {
+    float total = 0.f;
+    bool neg = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float e = pred[i] - targ[i];
+        float l;
+        if (kind == 0) {
+            const float vr = var[inner > 1 ? i / inner : i];
+            neg |= vr < 0.f;
+            const float v = fmaxf(vr, eps);
+            if (vclamp && (inner <= 1 || i % inner == 0)) vclamp[inner > 1 ? i / inner : i] = v;
+            l = 0.5f * (logf(v) + e * e / v) + cst;
+        } else {
+            l = kind == 1 ? fabsf(e) : e * e;
+        }
+        if (loss_none) loss_none[i] = l;
+        total += l;
+    }
+    if (neg && neg_flag) atomicOr(neg_flag, 1);
+    __shared__ float red[8];
+    float dummy = 0.f;
+    block_sum2<256>(total, dummy, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = total;
+}
+// dpred / dvar for an upstream scalar gradient (gscalar[0]*scale) or an element-wise one (gnone)
+__global__ __launch_bounds__(256) void eltloss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ targ,
+                                                          const float* __restrict__ var,
+                                                          const float* __restrict__ gscalar, float scale,
+                                                          const float* __restrict__ gnone, float* __restrict__ dpred,
+                                                          float* __restrict__ dvar, long long n, int kind, float eps) {
+    const float gs = gscalar ? gscalar[0] * scale : 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = gnone ? gnone[i] : gs;
+        const float e = pred[i] - targ[i];
+        if (kind == 0) {
+            const float iv = 1.f / fmaxf(var[i], eps);
+            if (dpred) dpred[i] = gi * e * iv;
+            if (dvar) dvar[i] = gi * 0.5f * (iv - e * e * iv * iv);
+        } else if (dpred) {
+            dpred[i] = kind == 1 ? gi * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) : gi * 2.f * e;
+        }
+    }
+}
+extern "C" int uncr_eltloss_blocks(long long n) {
+    const long long b = (n + 1023) / 1024;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+extern "C" int uncr_eltloss_fwd(int kind, const float* pred, const float* targ, const float* var, float* loss_none,
+                                float* vclamp, float* part, float* loss_out, int* neg_flag, long long n, int inner,
+                                float eps, int full, int reduction /*0 none, 1 mean, 2 sum*/, hipStream_t stream) {
+    if (n <= 0 || kind < 0 || kind > 2 || inner < 1) return UNCR_ESHAPE;
+    if (!pred || !targ || !part || (kind == 0 && !var)) return UNCR_EINVAL;
+    const int nb = uncr_eltloss_blocks(n);
+    const float cst = (kind == 0 && full) ? 0.91893853320467274178f : 0.f;   // 0.5*log(2 pi)
+    hipLaunchKernelGGL(eltloss_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred, targ, var, loss_none, vclamp, part,
+                       neg_flag, n, inner, kind, eps, cst);
+    UNCR_LAUNCH_CHECK();
+    if (reduction != 0) {
+        if (!loss_out) return UNCR_EINVAL;
+        hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, stream, part, nb,
+                           reduction == 1 ? 1.0 / (double)n : 1.0, loss_out);
+        UNCR_LAUNCH_CHECK();
+    }
+    return UNCR_OK;
+}
+extern "C" int uncr_eltloss_bwd(int kind, const float* pred, const float* targ, const float* var, const float* gscalar,
+                                const float* gnone, float* dpred, float* dvar, long long n, float eps, int reduction,
+                                hipStream_t stream) {
+    if (n <= 0 || kind < 0 || kind > 2) return UNCR_ESHAPE;
+    if ((reduction == 0 && !gnone) || (reduction != 0 && !gscalar) || (kind == 0 && !var)) return UNCR_EINVAL;
+    const float sc = reduction == 1 ? (float)(1.0 / (double)n) : 1.f;
+    hipLaunchKernelGGL(eltloss_bwd_kernel, dim3(uncr_eltloss_blocks(n)), dim3(256), 0, stream, pred, targ, var,
+                       reduction ? gscalar : nullptr, sc, reduction ? nullptr : gnone, dpred, dvar, n, kind, eps);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
 // ensemble combine (ensemble_reconstruct.py:116-133): means/vars [M][n] -> mean_ens, var_ens [n]
 // mode 0 'both': mean_i(var_i + mu_i^2) - mu_ens^2; 1 'aleatoric': mean_i var_i; 2 'epistemic': mean_i mu_i^2 - mu_ens^2
 __global__ __launch_bounds__(256) void ensemble_kernel(const float* __restrict__ mu, const float* __restrict__ var,

@@ -630,6 +630,39 @@ def head_backward(dout: Tensor, sv: dict, w: Tensor, need_dy: bool = True):
 _RED = {"none": 0, "mean": 1, "sum": 2}
 
 
+ELT_GNLL, ELT_L1, ELT_L2 = 0, 1, 2
+
+
+def eltloss_forward(kind: int, pred: Tensor, target: Tensor, var: Optional[Tensor], eps: float, full: bool,
+                    reduction: str, check_negative: bool = False):
+    """Element-wise criteria of get_loss (losses.py:14-32).  -> (loss, clamped variance or None)."""
+    pred, target = pred.contiguous().float(), target.contiguous().float()
+    n, dev = pred.numel(), pred.device
+    red = _RED[reduction]
+    nb = hb.query("uncr_eltloss_blocks", n)
+    part = _f32((nb,), dev)
+    loss_none = torch.empty_like(pred) if red == 0 else None
+    loss = _f32((), dev) if red else None
+    vclamp = torch.empty_like(var) if var is not None else None
+    flag = torch.zeros((1,), device=dev, dtype=torch.int32) if (check_negative and var is not None) else None
+    hb.call("uncr_eltloss_fwd", kind, pred, target, var, loss_none, vclamp, part, loss, flag, n, 1, float(eps),
+            1 if full else 0, red, _stream())
+    if flag is not None and int(flag.item()):        # opt-in host sync (losses.py:110-111)
+        raise ValueError("var has negative entry/entries")
+    return (loss_none if red == 0 else loss), vclamp
+
+
+def eltloss_backward(kind: int, gout: Tensor, pred: Tensor, target: Tensor, var: Optional[Tensor], eps: float,
+                     reduction: str, need_dpred: bool = True, need_dvar: bool = True):
+    red = _RED[reduction]
+    dpred = torch.empty_like(pred) if need_dpred else None
+    dvar = torch.empty_like(var) if (need_dvar and var is not None) else None
+    gout = gout.contiguous().to(torch.float32)
+    hb.call("uncr_eltloss_bwd", kind, pred, target, var, gout if red else None, gout if red == 0 else None, dpred,
+            dvar, pred.numel(), float(eps), red, _stream())
+    return dpred, dvar
+
+
 def mgnll_forward(pred: Tensor, target: Tensor, var: Tensor, eps: float, reduction: str, check_negative: bool):
     B, T1, K, H, W = pred.shape
     Kv = var.shape[2]

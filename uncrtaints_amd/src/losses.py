@@ -1,11 +1,11 @@
 """Losses with the reference's surface (model/src/losses.py): get_loss, calc_loss, MultiGaussianNLLLoss,
-multi_gaussian_nll_loss -- MGNLL (diag / iso) as one HIP streaming kernel per direction (csrc/mgnll.hip).
+multi_gaussian_nll_loss, GaussianNLLLoss, gaussian_nll_loss and the l1 / l2 criteria -- each one HIP streaming kernel
+per direction (csrc/mgnll.hip).
 
 Differences from the reference, all opt-in / documented:
   * the dense covariance `diag_embed(var)` [B,1,13,13,H,W] (moved to the host inside the reference loss,
     losses.py:145,211; logging only) is produced only with `want_covariance=True`, on the device;
-  * `torch.any(var < 0)` (a host sync, losses.py:199) is checked only with `check_negative=True`.
-GNLL / l1 / l2 are outside the hot path and raise NotImplementedError."""
+  * `torch.any(var < 0)` (a host sync, losses.py:110,199) is checked only with `check_negative=True`."""
 import torch
 import torch.nn as nn
 from torch.nn.modules.loss import _Loss
@@ -69,14 +69,95 @@ class MultiGaussianNLLLoss(_Loss):
                                        check_negative=self.check_negative)
 
 
+class _EltLossFn(torch.autograd.Function):
+    """GaussianNLL / L1 / L2 as one streaming HIP pass per direction (engine.eltloss_forward/backward)."""
+
+    @staticmethod
+    def forward(ctx, kind, pred, target, var, eps, full, reduction, check_negative):
+        pred_c, targ_c = pred.contiguous().float(), target.contiguous().float()
+        var_c = var.contiguous().float() if var is not None else None
+        loss, vclamp = E.eltloss_forward(kind, pred_c, targ_c, var_c, eps, full, reduction, check_negative)
+        ctx.save_for_backward(pred_c, targ_c, var_c if var_c is not None else pred_c)
+        ctx.meta = (kind, eps, reduction, var is not None)
+        if vclamp is not None:
+            ctx.mark_non_differentiable(vclamp)
+            return loss, vclamp
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout, *_):
+        kind, eps, reduction, has_var = ctx.meta
+        pred, targ, var = ctx.saved_tensors
+        dpred, dvar = E.eltloss_backward(kind, gout, pred, targ, var if has_var else None, eps, reduction,
+                                         ctx.needs_input_grad[1], has_var and ctx.needs_input_grad[3])
+        return None, dpred, None, dvar, None, None, None, None
+
+
+def gaussian_nll_loss(input: Tensor, target: Tensor, var: Tensor, full: bool = False, eps: float = 1e-8,
+                      reduction: str = "mean", check_negative: bool = False):
+    """losses.py:46-128.  Returns (loss, clamped var).  The reference's `torch.any(var < 0)` host sync is opt-in
+    (`check_negative=True`), like MultiGaussianNLLLoss here."""
+    if var.size() != input.size():
+        if input.size()[:-1] == var.size():
+            var = torch.unsqueeze(var, dim=-1)
+        elif not (input.size()[:-1] == var.size()[:-1] and var.size(-1) == 1):
+            raise ValueError("var is of incorrect size")
+        var = var.expand_as(input)      # homoscedastic form: autograd sums the gradient back over the broadcast axis
+    if reduction not in ("none", "mean", "sum"):
+        raise ValueError(reduction + " is not valid")
+    loss, v = _EltLossFn.apply(E.ELT_GNLL, input, target, var, eps, full, reduction, check_negative)
+    return loss, v
+
+
+class GaussianNLLLoss(_Loss):
+    """losses.py:131-ish class surface: GaussianNLLLoss(full=, eps=, reduction=)(input, target, var) -> (loss, var)."""
+
+    def __init__(self, *, full: bool = False, eps: float = 1e-8, reduction: str = 'mean', check_negative: bool = False):
+        super().__init__(None, None, reduction)
+        self.full, self.eps, self.check_negative = full, eps, check_negative
+
+    def forward(self, input: Tensor, target: Tensor, var: Tensor):
+        return gaussian_nll_loss(input, target, var, full=self.full, eps=self.eps, reduction=self.reduction,
+                                 check_negative=self.check_negative)
+
+
+class L1Loss(_Loss):
+    """nn.L1Loss() stand-in of get_loss 'l1' (mean reduction)."""
+
+    def __init__(self, reduction: str = 'mean'):
+        super().__init__(None, None, reduction)
+
+    def forward(self, input: Tensor, target: Tensor):
+        return _EltLossFn.apply(E.ELT_L1, input, target, None, 0.0, False, self.reduction, False)
+
+
+class MSELoss(_Loss):
+    """nn.MSELoss() stand-in of get_loss 'l2' (mean reduction)."""
+
+    def __init__(self, reduction: str = 'mean'):
+        super().__init__(None, None, reduction)
+
+    def forward(self, input: Tensor, target: Tensor):
+        return _EltLossFn.apply(E.ELT_L2, input, target, None, 0.0, False, self.reduction, False)
+
+
 def get_loss(config):
     """losses.py:14-32"""
+    if config.loss == "GNLL":
+        criterion1 = GaussianNLLLoss(reduction='mean', eps=1e-8, full=True)
+        return lambda pred, targ, var: criterion1(pred, targ, var)
     if config.loss == "MGNLL":
         criterion1 = MultiGaussianNLLLoss(reduction='mean', eps=1e-8, full=True, mode=config.covmode,
                                           chunk=getattr(config, "chunk_size", None),
                                           want_covariance=getattr(config, "want_covariance", False))
         return lambda pred, targ, var: criterion1(pred, targ, var)
-    raise NotImplementedError(f"loss '{config.loss}' is outside the MI355X hot path (MGNLL only)")
+    if config.loss == "l1":
+        criterion1 = L1Loss()
+        return lambda pred, targ: criterion1(pred, targ)
+    if config.loss == "l2":
+        criterion1 = MSELoss()
+        return lambda pred, targ: criterion1(pred, targ)
+    raise NotImplementedError
 
 
 def calc_loss(criterion, config, out, y, var=None):
