@@ -164,6 +164,13 @@ int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const 
                        float* de, float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int AH,
                        int AW, hipStream_t stream);
 
+/* ---- input assembly in front of the path: prepare_data_multi (model/train_reconstruct.py:161-179) stacks the
+ *      per-date S1 [B,2,H,W] / S2 [B,13,H,W] tensors into x [B,T,C,H,W] (S1 channels first); with kind != 0 the
+ *      loader's process_MS / process_SAR (data/dataLoader.py:38-61: clip, rescale, nan_to_num) is applied on the way.
+ *      desc (DEVICE memory) = T*ngroups x 4 int64 {src pointer, channels, channel offset in x, kind}; kind: 0 copy,
+ *      1 MS 'default', 2 MS 'resnet', 3 SAR 'default', 4 SAR 'resnet'. ---- */
+int uncr_assemble_input(const long long* desc, float* x, int B, int T, int C, int P, int ngroups, hipStream_t stream);
+
 /* ---- element-wise criteria of get_loss (losses.py:14-32): kind 0 GaussianNLLLoss (losses.py:46-128: var clamped to
  *      eps with identity gradient, optional 0.5*log(2 pi)), 1 nn.L1Loss, 2 nn.MSELoss.  The backward needs var of the
  *      full shape (the host expands a broadcast one); `inner` > 1 in the forward = var broadcast over the innermost

@@ -469,3 +469,47 @@ def synthetic_batch(B: int, T: int, H: int, W: int, seed: int = 1, input_dim: in
     y = torch.rand(B, 1, S2_BANDS, H, W, generator=g)
     dates = torch.sort(torch.randint(1400, 1800, (B, T), generator=g), dim=1).values.float()
     return x, y, dates
+
+
+# ---- input assembly in front of the path ----
+def process_ms(img, method: str = "default"):
+    """data/dataLoader.py:38-48 (numpy): clip to [0, 10000]; 'default' -> /10000, 'resnet' -> /2000; nan_to_num."""
+    import numpy as np
+    img = np.asarray(img, dtype=np.float32).copy()
+    if method in ("default", "resnet"):
+        img = np.clip(img, 0, 10000)
+        img = img / (10000 if method == "default" else 2000)
+    return np.nan_to_num(img)
+
+
+def process_sar(img, method: str = "default"):
+    """data/dataLoader.py:50-61 (numpy): 'default' clip to [-25, 0] dB -> [0, 1]; 'resnet' per-channel ranges
+    [-25, 0] / [-32.5, 0] -> [0, 2]; nan_to_num."""
+    import numpy as np
+    img = np.asarray(img, dtype=np.float32).copy()
+    if method == "default":
+        img = (np.clip(img, -25, 0) + 25) / 25
+    elif method == "resnet":
+        lo = (-25.0, -32.5)
+        img = np.stack([2 * (np.clip(img[c], lo[c], 0) - lo[c]) / (0 - lo[c]) for c in range(2)], axis=0)
+    return np.nan_to_num(img)
+
+
+def prepare_data_multi(batch, use_sar: bool, batch_size: int):
+    """model/train_reconstruct.py:161-179: lists over dates of [B,C,H,W] -> x [B,T,(2+)13,H,W] (S1 channels first),
+    y [B,1,13,H,W], masks [B,T,H,W], dates [B,T] (mean of the S1 and S2 day offsets when SAR is used)."""
+    s2, s2_td = batch["input"]["S2"], batch["input"]["S2 TD"]
+    if batch_size > 1:
+        s2_td = torch.stack(list(s2_td)).T
+    m = torch.stack(list(batch["input"]["masks"])).swapaxes(0, 1)
+    y = torch.cat(list(batch["target"]["S2"]), dim=0).unsqueeze(1)
+    if use_sar:
+        s1, s1_td = batch["input"]["S1"], batch["input"]["S1 TD"]
+        if batch_size > 1:
+            s1_td = torch.stack(list(s1_td)).T
+        x = torch.cat((torch.stack(list(s1), dim=1), torch.stack(list(s2), dim=1)), dim=2)
+        dates = torch.stack((torch.as_tensor(s1_td), torch.as_tensor(s2_td))).float().mean(dim=0)
+    else:
+        x = torch.stack(list(s2), dim=1)
+        dates = torch.as_tensor(s2_td).float()
+    return x, y, m, dates

@@ -215,6 +215,58 @@ def case_eltlosses():
     print("g9_eltlosses", idx, "cases")
 
 
+def _reference_functions(path, names, namespace):
+    """Execute ONLY the named top-level functions of a reference file that cannot be imported as a module
+    (train_reconstruct.py parses argv at import, data/dataLoader.py needs rasterio): the function definitions are
+    taken from the parsed AST at generation time; nothing of the source is stored in the fixture."""
+    import ast
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in body) == sorted(names), [n.name for n in body]
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), namespace)
+    return namespace
+
+
+def case_prepare():
+    """Input assembly in front of the path: process_MS / process_SAR (data/dataLoader.py:31-59) and
+    prepare_data_multi (model/train_reconstruct.py:161-179)."""
+    import types
+    ns_d = _reference_functions(os.path.join(REF, "data", "dataLoader.py"), ["rescale", "process_MS", "process_SAR"],
+                                {"np": np})
+    ns_t = _reference_functions(os.path.join(REF, "model", "train_reconstruct.py"),
+                                ["prepare_data_multi", "recursive_todevice"], {"torch": torch, "np": np})
+    out = {}
+    rng = np.random.default_rng(5)
+    ms = (rng.random((13, 9, 8)).astype(np.float32) * 14000 - 1500)
+    ms[0, 0, 0], ms[1, 1, 1], ms[2, 2, 2] = np.nan, np.inf, -np.inf
+    sar = (rng.random((2, 9, 8)).astype(np.float32) * 40 - 36)
+    sar[0, 0, 1], sar[1, 3, 3] = np.nan, np.inf
+    out["ms_raw"], out["sar_raw"] = ms, sar
+    for method in ("default", "resnet"):
+        out[f"ms_{method}"] = ns_d["process_MS"](ms.copy(), method)
+        out[f"sar_{method}"] = ns_d["process_SAR"](sar.copy(), method)
+    # prepare_data_multi: batch as the loader collates it (lists over dates of [B, C, H, W] tensors)
+    g = torch.Generator().manual_seed(3)
+    B, T, H, W = 2, 3, 6, 5
+    batch = {"input": {"S1": [torch.rand(B, 2, H, W, generator=g) for _ in range(T)],
+                       "S2": [torch.rand(B, 13, H, W, generator=g) for _ in range(T)],
+                       "masks": [torch.rand(B, H, W, generator=g) for _ in range(T)],
+                       "S1 TD": [torch.randint(1400, 1800, (B,), generator=g) for _ in range(T)],
+                       "S2 TD": [torch.randint(1400, 1800, (B,), generator=g) for _ in range(T)]},
+             "target": {"S2": [torch.rand(B, 13, H, W, generator=g)]}}
+    for k in ("S1", "S2", "masks", "S1 TD", "S2 TD"):
+        for t in range(T):
+            out[f"batch/{k.replace(' ', '_')}/{t}"] = batch["input"][k][t].numpy()
+    out["batch/target"] = batch["target"]["S2"][0].numpy()
+    for use_sar in (True, False):
+        cfg = types.SimpleNamespace(batch_size=B, use_sar=use_sar)
+        x, y, m, dates = ns_t["prepare_data_multi"](batch, torch.device("cpu"), cfg)
+        tag = "sar" if use_sar else "nosar"
+        out[f"{tag}/x"], out[f"{tag}/y"], out[f"{tag}/m"], out[f"{tag}/dates"] = x.numpy(), y.numpy(), m.numpy(), dates.numpy()
+    np.savez_compressed(os.path.join(HERE, "g10_prepare.npz"), **out)
+    print("g10_prepare", {k: v.shape for k, v in out.items() if "/x" in k or "dates" in k})
+
+
 def case_posenc():
     pe = PositionalEncoder(256 // 16, T=1000, repeat=16)
     dates = torch.tensor([[1400., 1433., 1799.], [0., 1., 1000.]])
@@ -336,10 +388,13 @@ if __name__ == "__main__":
     case_variants(); sys.exit(0)
   if "--only-eltlosses" in sys.argv:
     case_eltlosses(); sys.exit(0)
+  if "--only-prepare" in sys.argv:
+    case_prepare(); sys.exit(0)
   if "--only-trainseq" not in sys.argv:
     case_variants()
     case_mgnll()
     case_eltlosses()
+    case_prepare()
     case_posenc()
     case_ensemble()
   case_trainseq()

@@ -476,3 +476,33 @@ def test_eltlosses_gnll_l1_l2():
     with pytest.raises(ValueError):
         losses.GaussianNLLLoss(check_negative=True)(pred, targ, -var.detach().abs() - 1.0)
 
+
+
+def test_prepare_input_assembly():
+    """uncr_assemble_input: prepare_data_multi and the fused process_MS / process_SAR vs the reference's outputs."""
+    import types
+    from conftest import load_golden
+    from uncrtaints_amd.src import prepare
+    g = load_golden("g10_prepare")
+    for method in ("default", "resnet"):
+        ms = prepare.process_MS(torch.from_numpy(g["ms_raw"]).to(DEV), method).cpu().numpy()
+        sar = prepare.process_SAR(torch.from_numpy(g["sar_raw"]).to(DEV), method).cpu().numpy()
+        assert np.abs(ms - g[f"ms_{method}"]).max() <= 1e-6 and np.abs(sar - g[f"sar_{method}"]).max() <= 1e-6
+    T = 3
+    kk = lambda name: [torch.from_numpy(g[f"batch/{name}/{t}"]) for t in range(T)]
+    batch = {"input": {"S1": kk("S1"), "S2": kk("S2"), "masks": kk("masks"), "S1 TD": kk("S1_TD"), "S2 TD": kk("S2_TD")},
+             "target": {"S2": [torch.from_numpy(g["batch/target"])]}}
+    for use_sar, tag in ((True, "sar"), (False, "nosar")):
+        cfg = types.SimpleNamespace(batch_size=2, use_sar=use_sar)
+        x, y, m, dates = prepare.prepare_data_multi(batch, torch.device(DEV), cfg)
+        for name, got in (("x", x), ("y", y), ("m", m), ("dates", dates)):
+            assert np.array_equal(got.cpu().numpy(), g[f"{tag}/{name}"]), (tag, name)     # pure data movement: bit-exact
+    # raw intensities processed inside the gather == processing first, assembling second
+    raw = {"input": dict(batch["input"]), "target": batch["target"]}
+    raw["input"]["S2"] = [t * 12000 - 500 for t in batch["input"]["S2"]]
+    raw["input"]["S1"] = [t * 30 - 28 for t in batch["input"]["S1"]]
+    cfg = types.SimpleNamespace(batch_size=2, use_sar=True)
+    x, _, _, _ = prepare.prepare_data_multi(raw, torch.device(DEV), cfg, process="default")
+    ref = torch.cat((torch.stack([(t.clamp(-25, 0) + 25) / 25 for t in raw["input"]["S1"]], dim=1),
+                     torch.stack([t.clamp(0, 10000) / 10000 for t in raw["input"]["S2"]], dim=1)), dim=2)
+    assert (x.cpu() - ref).abs().max().item() <= 1e-6

@@ -150,3 +150,22 @@ def test_eltlosses_match_reference():
             l = fn(pred, targ)
             assert rel_err(l.detach().numpy(), g[f"k{i}/{name}"]) < 2e-6
             assert rel_err(torch.autograd.grad(l, pred)[0].numpy(), g[f"k{i}/{name}_dpred"]) < 2e-6
+
+
+def _g10_batch(g, T=3):
+    k = lambda name: [torch.from_numpy(g[f"batch/{name}/{t}"]) for t in range(T)]
+    return {"input": {"S1": k("S1"), "S2": k("S2"), "masks": k("masks"), "S1 TD": k("S1_TD"), "S2 TD": k("S2_TD")},
+            "target": {"S2": [torch.from_numpy(g["batch/target"])]}}
+
+
+def test_prepare_matches_reference():
+    """process_MS / process_SAR and prepare_data_multi restated in the oracle vs the reference functions' outputs."""
+    g = load_golden("g10_prepare")
+    for method in ("default", "resnet"):
+        assert np.array_equal(orc.process_ms(g["ms_raw"], method), g[f"ms_{method}"])
+        assert np.allclose(orc.process_sar(g["sar_raw"], method), g[f"sar_{method}"], rtol=0, atol=1e-7)
+    batch = _g10_batch(g)
+    for use_sar, tag in ((True, "sar"), (False, "nosar")):
+        x, y, m, dates = orc.prepare_data_multi(batch, use_sar, batch_size=2)
+        assert np.array_equal(x.numpy(), g[f"{tag}/x"]) and np.array_equal(y.numpy(), g[f"{tag}/y"])
+        assert np.array_equal(m.numpy(), g[f"{tag}/m"]) and np.array_equal(dates.numpy(), g[f"{tag}/dates"])

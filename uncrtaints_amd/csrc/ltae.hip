@@ -406,3 +406,52 @@ extern "C" int uncr_ltae_softmax_bwd(const float* datt, const float* att, const 
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
+
+
+// ---- input assembly in front of the path (model/train_reconstruct.py:161-179 prepare_data_multi, fused with
+//      data/dataLoader.py:38-61 process_MS / process_SAR when raw intensities are given) ----
+// desc (device, int64): per (t, group) {src pointer [B][Cg][P], Cg, channel offset in x, kind}; kind 0 copy,
+// 1 MS 'default', 2 MS 'resnet', 3 SAR 'default', 4 SAR 'resnet'.  x is [B][T][C][P].  grid = (P/chunk, B*C, T*ngroups)
+__device__ __forceinline__ float prep_value(float v, int kind, int ch) {
+    if (kind == 0) return v;
+    float r;
+    if (kind == 1 || kind == 2) {
+        r = fminf(fmaxf(v, 0.f), 10000.f) * (kind == 1 ? 1e-4f : 5e-4f);
+    } else if (kind == 3) {
+        r = (fminf(fmaxf(v, -25.f), 0.f) + 25.f) * 0.04f;
+    } else {
+        const float lo = ch == 0 ? -25.f : -32.5f;
+        r = 2.f * (fminf(fmaxf(v, lo), 0.f) - lo) / (0.f - lo);
+    }
+    // np.clip propagates NaN, np.nan_to_num maps it to 0 (infinities were clipped to the range bounds)
+    return v != v ? 0.f : r;
+}
+__global__ __launch_bounds__(256) void assemble_input_kernel(const long long* __restrict__ desc, float* __restrict__ x,
+                                                             int B, int T, int C, int P, int ngroups) {
+    const int tg = blockIdx.z, t = tg / ngroups;
+    const long long* d = desc + (size_t)tg * 4;
+    const float* src = (const float*)d[0];
+    const int Cg = (int)d[1], c0 = (int)d[2], kind = (int)d[3];
+    const int b = blockIdx.y / C, cl = blockIdx.y % C;      // cl: channel inside the group (blocks beyond Cg exit)
+    if (cl >= Cg || !src) return;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= P) return;
+    const float* s = src + ((size_t)b * Cg + cl) * P + p;
+    float* o = x + (((size_t)b * T + t) * C + c0 + cl) * P + p;
+    if (p + 3 < P && (((size_t)s | (size_t)o) & 15) == 0) {
+        float4 v = *(const float4*)s;
+        v.x = prep_value(v.x, kind, cl); v.y = prep_value(v.y, kind, cl);
+        v.z = prep_value(v.z, kind, cl); v.w = prep_value(v.w, kind, cl);
+        *(float4*)o = v;
+    } else {
+        for (int q = 0; q < 4 && p + q < P; ++q) o[q] = prep_value(s[q], kind, cl);
+    }
+}
+extern "C" int uncr_assemble_input(const long long* desc, float* x, int B, int T, int C, int P, int ngroups,
+                                   hipStream_t stream) {
+    if (!desc || !x || B <= 0 || T <= 0 || C <= 0 || P <= 0 || ngroups <= 0) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(assemble_input_kernel, dim3((P + 1023) / 1024, B * C, T * ngroups), dim3(256), 0, stream, desc,
+                       x, B, T, C, P, ngroups);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
