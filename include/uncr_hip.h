@@ -171,6 +171,14 @@ int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const 
  *      1 MS 'default', 2 MS 'resnet', 3 SAR 'default', 4 SAR 'resnet'. ---- */
 int uncr_assemble_input(const long long* desc, float* x, int B, int T, int C, int P, int ngroups, hipStream_t stream);
 
+/* ---- evaluation metrics right behind the path: img_metrics (model/src/learning/metrics.py:20-63) with the SSIM of
+ *      util/pytorch_ssim/__init__.py:17-73.  target / pred / var [B][C][H][W]; win = the 11x11 window (121 floats, built
+ *      by the caller exactly like create_window); out[0..8] = RMSE, MAE, PSNR, SAM, SSIM, nanmean error / ae / se / var,
+ *      out[16 + b] = per-item SSIM; pixelwise (optional) [4][H*W] = x.nanmean(0).nanmean(0) of error, ae, se, var. ---- */
+int uncr_img_metrics_work(int B, int C, int H, int W);
+int uncr_img_metrics(const float* target, const float* pred, const float* var, const float* win, float* out,
+                     float* pixelwise, float* work, int B, int C, int H, int W, hipStream_t stream);
+
 /* ---- element-wise criteria of get_loss (losses.py:14-32): kind 0 GaussianNLLLoss (losses.py:46-128: var clamped to
  *      eps with identity gradient, optional 0.5*log(2 pi)), 1 nn.L1Loss, 2 nn.MSELoss.  The backward needs var of the
  *      full shape (the host expands a broadcast one); `inner` > 1 in the forward = var broadcast over the innermost

@@ -513,3 +513,45 @@ def prepare_data_multi(batch, use_sar: bool, batch_size: int):
         x = torch.stack(list(s2), dim=1)
         dates = torch.as_tensor(s2_td).float()
     return x, y, m, dates
+
+
+# ---- evaluation metrics behind the path ----
+def ssim_window(window_size: int = 11, sigma: float = 1.5) -> Tensor:
+    """util/pytorch_ssim/__init__.py:7-15: normalised 1-D Gaussian, outer product (fp32)."""
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    g = (g / g.sum()).unsqueeze(1)
+    return g.mm(g.t()).float()
+
+
+def ssim(img1: Tensor, img2: Tensor, window_size: int = 11, size_average: bool = True):
+    """util/pytorch_ssim/__init__.py:17-39,65-73: depthwise Gaussian filtering with zero padding."""
+    C = img1.shape[1]
+    w = ssim_window(window_size).to(img1.dtype).expand(C, 1, window_size, window_size).contiguous()
+    pad = window_size // 2
+    f = lambda x: F.conv2d(x, w, padding=pad, groups=C)
+    mu1, mu2 = f(img1), f(img2)
+    s11, s22, s12 = f(img1 * img1) - mu1 * mu1, f(img2 * img2) - mu2 * mu2, f(img1 * img2) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s11 + s22 + C2))
+    return m.mean() if size_average else m.mean(1).mean(1).mean(1)
+
+
+def img_metrics(target: Tensor, pred: Tensor, var: Optional[Tensor] = None, pixelwise: bool = True) -> dict:
+    """model/src/learning/metrics.py:20-63"""
+    rmse = torch.sqrt(torch.mean(torch.square(target - pred)))
+    out = {"RMSE": rmse.item(), "MAE": torch.mean(torch.abs(target - pred)).item(),
+           "PSNR": (20 * torch.log10(1 / rmse)).item()}
+    mat = torch.sum(target * pred, 1)
+    mat = mat / torch.sqrt(torch.sum(target * target, 1))
+    mat = mat / torch.sqrt(torch.sum(pred * pred, 1))
+    out["SAM"] = torch.mean(torch.acos(torch.clamp(mat, -1, 1)) * 180 / math.pi).item()
+    out["SSIM"] = ssim(target, pred).item()
+    if var is not None:
+        e = target - pred
+        se, ae = e * e, e.abs()
+        out.update({"error": e.nanmean().item(), "mean ae": ae.nanmean().item(), "mean se": se.nanmean().item(),
+                    "mean var": var.nanmean().item()})
+        if pixelwise:
+            pw = lambda x: x.nanmean(0).nanmean(0).flatten().numpy()
+            out.update({"pixelwise error": pw(e), "pixelwise ae": pw(ae), "pixelwise se": pw(se), "pixelwise var": pw(var)})
+    return out

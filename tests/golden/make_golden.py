@@ -267,6 +267,30 @@ def case_prepare():
     print("g10_prepare", {k: v.shape for k, v in out.items() if "/x" in k or "dates" in k})
 
 
+def case_metrics():
+    """img_metrics (model/src/learning/metrics.py:20-63) incl. SSIM (util/pytorch_ssim) and the nan-aware statistics."""
+    from src.learning import metrics as ref_metrics
+    out = {}
+    g = torch.Generator().manual_seed(13)
+    idx = 0
+    for (B, H, W, nan) in ((1, 24, 20, False), (3, 37, 33, True)):
+        targ = torch.rand(B, 13, H, W, generator=g)
+        pred = (targ + 0.1 * torch.randn(B, 13, H, W, generator=g)).clamp(0, 1)
+        var = torch.rand(B, 13, H, W, generator=g) * 0.1
+        if nan:
+            var[0, 2, 3, 4] = float("nan")
+            var[:, 5, 7, 7] = float("nan")            # NaN for every batch item of one (channel, pixel)
+        d = ref_metrics.img_metrics(targ, pred, var)
+        for k, v in d.items():
+            out[f"k{idx}/m/{k}"] = np.asarray(v)
+        out[f"k{idx}/ssim_items"] = ref_metrics.pytorch_ssim.ssim(targ, pred, size_average=False).numpy()
+        out[f"k{idx}/target"], out[f"k{idx}/pred"], out[f"k{idx}/var"] = targ.numpy(), pred.numpy(), var.numpy()
+        idx += 1
+    out["n"] = np.array(idx)
+    np.savez_compressed(os.path.join(HERE, "g11_metrics.npz"), **out)
+    print("g11_metrics", idx, "cases", {k: float(v) for k, v in d.items() if np.ndim(v) == 0})
+
+
 def case_posenc():
     pe = PositionalEncoder(256 // 16, T=1000, repeat=16)
     dates = torch.tensor([[1400., 1433., 1799.], [0., 1., 1000.]])
@@ -390,11 +414,14 @@ if __name__ == "__main__":
     case_eltlosses(); sys.exit(0)
   if "--only-prepare" in sys.argv:
     case_prepare(); sys.exit(0)
+  if "--only-metrics" in sys.argv:
+    case_metrics(); sys.exit(0)
   if "--only-trainseq" not in sys.argv:
     case_variants()
     case_mgnll()
     case_eltlosses()
     case_prepare()
+    case_metrics()
     case_posenc()
     case_ensemble()
   case_trainseq()

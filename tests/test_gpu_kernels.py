@@ -506,3 +506,23 @@ def test_prepare_input_assembly():
     ref = torch.cat((torch.stack([(t.clamp(-25, 0) + 25) / 25 for t in raw["input"]["S1"]], dim=1),
                      torch.stack([t.clamp(0, 10000) / 10000 for t in raw["input"]["S2"]], dim=1)), dim=2)
     assert (x.cpu() - ref).abs().max().item() <= 1e-6
+
+
+def test_img_metrics():
+    """uncr_img_metrics (RMSE / MAE / PSNR / SAM / SSIM / nan-aware statistics) vs the reference-generated fixture."""
+    from conftest import load_golden
+    from uncrtaints_amd.src.learning import metrics
+    g = load_golden("g11_metrics")
+    for i in range(int(g["n"])):
+        targ, pred, var = (torch.from_numpy(g[f"k{i}/{k}"]).to(DEV) for k in ("target", "pred", "var"))
+        d = metrics.img_metrics(targ, pred, var)
+        for k, v in d.items():
+            ref = g[f"k{i}/m/{k}"]
+            assert np.allclose(np.asarray(v), ref, rtol=5e-5, atol=2e-6, equal_nan=True), (k, v, ref)
+        items = metrics.ssim(targ, pred, size_average=False).cpu().numpy()
+        assert np.allclose(items, g[f"k{i}/ssim_items"], rtol=5e-5), (items, g[f"k{i}/ssim_items"])
+        d2 = metrics.img_metrics(targ, pred)
+        assert set(d2) == {"RMSE", "MAE", "PSNR", "SAM", "SSIM"} and abs(d2["SSIM"] - float(g[f"k{i}/m/SSIM"])) < 5e-5
+    avg = metrics.avg_img_metrics()
+    avg.add(d); avg.add(d)
+    assert abs(avg.value()["RMSE"] - d["RMSE"]) < 1e-9

@@ -169,3 +169,15 @@ def test_prepare_matches_reference():
         x, y, m, dates = orc.prepare_data_multi(batch, use_sar, batch_size=2)
         assert np.array_equal(x.numpy(), g[f"{tag}/x"]) and np.array_equal(y.numpy(), g[f"{tag}/y"])
         assert np.array_equal(m.numpy(), g[f"{tag}/m"]) and np.array_equal(dates.numpy(), g[f"{tag}/dates"])
+
+
+def test_img_metrics_match_reference():
+    """img_metrics + SSIM restated in the oracle vs the reference's values (incl. NaN-holed variances)."""
+    g = load_golden("g11_metrics")
+    for i in range(int(g["n"])):
+        targ, pred, var = (torch.from_numpy(g[f"k{i}/{k}"]) for k in ("target", "pred", "var"))
+        d = orc.img_metrics(targ, pred, var)
+        for k, v in d.items():
+            ref = g[f"k{i}/m/{k}"]
+            assert np.allclose(np.asarray(v), ref, rtol=2e-5, atol=1e-6, equal_nan=True), k
+        assert np.allclose(orc.ssim(targ, pred, size_average=False).numpy(), g[f"k{i}/ssim_items"], rtol=2e-5)
