@@ -171,3 +171,52 @@ def test_eval_is_deterministic_and_train_dropout_is_stochastic():
     with torch.no_grad():
         c, d = m(x, batch_positions=dates), m(x, batch_positions=dates)
     assert not torch.equal(c, d)
+
+
+def test_full_size_properties_at_the_bench_config():
+    """BASELINE config (B=4, T=3, 15x256x256; no CPU oracle at this size inside a test budget): size-independent
+    properties of the whole path.  (1) bit-reproducibility of a training step (forward, loss, every gradient);
+    (2) batch consistency: in eval mode (running statistics, no batch coupling) sample b of the B=4 batch equals
+    the same sample run alone -- this exercises the N=12 / N=4 kernel variants against the N=3 / N=1 ones;
+    (3) frame-permutation: feeding the dates in another order with the frames permuted alike gives the same output
+    (the temporal attention is a set function of (frame, date) pairs)."""
+    from oracle import uncrtaints_oracle as orc
+    from uncrtaints_amd.src import losses
+    cfg = orc.OracleConfig(attn_dropout=0.0)
+    state = orc.init_params(cfg, seed=3)
+    m = _build("diag", state)
+    m.temporal_aggregator.attn_dropout.p = 0.0
+    B, T, H, W = 4, 3, 256, 256
+    x, y, dates = orc.synthetic_batch(B, T, H, W, seed=5)
+    x, y, dates = dev(x), dev(y), dev(dates)
+    crit = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode="diag")
+
+    def step():
+        m.train()
+        m.zero_grad(set_to_none=True)
+        sd = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+        out = m(x, batch_positions=dates)
+        loss, _ = crit(out[:, :, :13], y, out[:, :, 13:26])
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+        m.load_state_dict({**m.state_dict(), **sd})       # undo the running-statistics update
+        return out.detach().clone(), loss.detach().clone(), grads
+    o1, l1, g1 = step()
+    o2, l2, g2 = step()
+    assert torch.equal(o1, o2) and torch.equal(l1, l2), "forward / loss not bit-reproducible"
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), f"gradient of {k} not bit-reproducible"
+    assert torch.isfinite(l1) and all(torch.isfinite(v).all() for v in g1.values())
+
+    m.eval()
+    with torch.no_grad():
+        full = m(x, batch_positions=dates)
+        for b in (0, 3):
+            alone = m(x[b:b + 1], batch_positions=dates[b:b + 1])
+            e = (full[b:b + 1] - alone).abs().max().item() / alone.abs().max().item()
+            print(f"[parity] bench-config batch consistency sample {b}: rel_err={e:.3e}")
+            assert e < 2e-5, e
+        perm = torch.tensor([2, 0, 1], device=x.device)
+        e = (m(x[:, perm], batch_positions=dates[:, perm]) - full).abs().max().item() / full.abs().max().item()
+        print(f"[parity] bench-config frame permutation: rel_err={e:.3e}")
+        assert e < 2e-5, e
