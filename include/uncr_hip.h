@@ -164,6 +164,16 @@ int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const 
                        float* de, float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int AH,
                        int AW, hipStream_t stream);
 
+/* ---- use_v variant (uncrtaints.py:324-338,414-417; LTAE2d ltae.py:10-141): pieces that are not already covered by the
+ *      entry points above.  include_v(cat(g, up(v))) = Wa*g + up(Wv*v + b), so only uncr_add_upsampled touches full
+ *      resolution; the attention-weighted values reuse uncr_aggregate_fwd/bwd at H == AH. ---- */
+int uncr_add_upsampled(const float* a, const float* z, float* out, float* part /* [planes][P/1024][2] or null */,
+                       int planes, int H, int W, int AH, int AW, hipStream_t stream);
+int uncr_bilinear_adjoint(const float* src, float* dst, int planes, int H, int W, int AH, int AW, hipStream_t stream);
+int uncr_add(const float* a, const float* b, float* out, long long n, hipStream_t stream);
+int uncr_dropout(const float* a, float* out, long long n, unsigned long long seed, const long long* seed_dev, float p,
+                 hipStream_t stream);
+
 /* ---- input assembly in front of the path: prepare_data_multi (model/train_reconstruct.py:161-179) stacks the
  *      per-date S1 [B,2,H,W] / S2 [B,13,H,W] tensors into x [B,T,C,H,W] (S1 channels first); with kind != 0 the
  *      loader's process_MS / process_SAR (data/dataLoader.py:38-61: clip, rescale, nan_to_num) is applied on the way.

@@ -57,6 +57,8 @@ class OracleConfig:
     attn_dropout: float = 0.1     # uncrtaints.py:154
     separate_out: bool = False    # uncrtaints.py:376-379
     is_mono: bool = False         # uncrtaints.py:322,418
+    use_v: bool = False           # uncrtaints.py:324-338,414-417 (LTAE2d values + include_v)
+    ltae_dropout: float = 0.2     # ltae.py:17,97 (dropout on the MLP-processed values; use_v only)
 
     @property
     def covar_dim(self) -> int:   # uncrtaints.py:357-365
@@ -223,6 +225,44 @@ def ltae_tiny_attention(down: Tensor, dates: Tensor, pad_mask: Tensor, p: Dict[s
     return attn.view(nh, B, h, w, T).permute(0, 1, 4, 2, 3)
 
 
+def ltae2d_values_attention(down: Tensor, dates: Tensor, pad_mask: Tensor, p: Dict[str, Tensor], cfg: OracleConfig,
+                            training: bool, update_running: bool = True,
+                            v_dropout_mask: Optional[Tensor] = None):
+    """LTAE2d.forward + MultiHeadAttention + ScaledDotProductAttention (ltae.py:99-141, 266-307, 399-416), as built
+    by UNCRTAINTS(use_v=True) (uncrtaints.py:324-336: mlp=[d_model, C], use_dropout=False, return_att=True).
+    down [B,T,C,h,w] -> (values [B,C,h,w], attention [n_head,B,T,h,w])."""
+    B, T, C, h, w = down.shape
+    nh, dk, n = cfg.n_head, cfg.d_k, B * h * w
+    pre = "temporal_encoder."
+    x = down.permute(0, 3, 4, 2, 1).reshape(n, C, T)
+    x = group_norm(x, nh, p[pre + "in_norm.weight"], p[pre + "in_norm.bias"])
+    y = torch.einsum("oc,nct->nto", p[pre + "inconv.weight"][:, :, 0], x) + p[pre + "inconv.bias"]      # [n,T,d_model]
+    if cfg.positional_encoding:
+        pe = positional_table(dates, cfg.d_model // nh, cfg.T_period, nh)
+        y = y + pe[:, None, :, :].expand(B, h * w, T, cfg.d_model).reshape(n, T, cfg.d_model)
+    k = (y @ p[pre + "attention_heads.fc1_k.weight"].t() + p[pre + "attention_heads.fc1_k.bias"]).view(n, T, nh, dk)
+    score = torch.einsum("hd,nthd->hnt", p[pre + "attention_heads.Q"], k) / math.sqrt(dk)
+    pm = pad_mask[:, None, :].expand(B, h * w, T).reshape(n, T)
+    attn = torch.softmax(score.masked_fill(pm[None], -1e3), dim=2)                    # [nh,n,T]; attn dropout p = 0
+    dv = cfg.d_model // nh
+    vh = y.view(n, T, nh, dv)                                                         # head h = channels h*dv..(h+1)*dv
+    out = torch.einsum("hnt,nthd->nhd", attn, vh).reshape(n, cfg.d_model)             # heads concatenated
+    out = out @ p[pre + "mlp.0.weight"].t() + p[pre + "mlp.0.bias"]                   # Linear(d_model -> C)
+    # BatchNorm1d over the n = B*h*w samples == BatchNorm2d on [n, C, 1, 1]
+    out = batch_norm(out.view(n, C, 1, 1), p[pre + "mlp.1.weight"], p[pre + "mlp.1.bias"],
+                     p.get(pre + "mlp.1.running_mean"), p.get(pre + "mlp.1.running_var"), training,
+                     update_running=update_running).view(n, C)
+    out = torch.relu(out)
+    if training:
+        if v_dropout_mask is not None:
+            out = out * v_dropout_mask
+        elif cfg.ltae_dropout > 0:
+            out = F.dropout(out, cfg.ltae_dropout, training=True)
+    out = group_norm(out, nh, p[pre + "out_norm.weight"], p[pre + "out_norm.bias"])    # per sample, C/nh channels per group
+    v = out.view(B, h, w, C).permute(0, 3, 1, 2)
+    return v, attn.view(nh, B, h, w, T).permute(0, 1, 4, 2, 3)
+
+
 def temporal_aggregate(x: Tensor, pad_mask: Tensor, attn: Tensor, cfg: OracleConfig,
                        training: bool, dropout_mask: Optional[Tensor] = None) -> Tensor:
     """Compact_Temporal_Aggregator, mode 'att_group' (uncrtaints.py:156-221).
@@ -271,8 +311,15 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
         g, down, attn = e.view(B, T, C, H, W).squeeze(dim=1), None, None
     else:
         down = F.adaptive_max_pool2d(e, (cfg.att_down, cfg.att_down)).view(B, T, C, cfg.att_down, cfg.att_down)
-        attn = ltae_tiny_attention(down, dates, pad_mask, p, cfg)
+        vals = None
+        if cfg.use_v:
+            vals, attn = ltae2d_values_attention(down, dates, pad_mask, p, cfg, training, update_running)
+        else:
+            attn = ltae_tiny_attention(down, dates, pad_mask, p, cfg)
         g = temporal_aggregate(e.view(B, T, C, H, W), pad_mask, attn, cfg, training, dropout_mask)
+        if cfg.use_v:                                                         # uncrtaints.py:414-417
+            up_v = F.interpolate(vals, size=(H, W), mode="bilinear", align_corners=False)
+            g = conv1x1(torch.cat((g, up_v), dim=1), p["include_v.weight"], p["include_v.bias"])
     if taps is not None:
         taps.update(c0=c0, a0=a0, e=e, down=down, attn=attn, agg=g)
     out = g
@@ -454,6 +501,13 @@ def init_params(cfg: OracleConfig, seed: int = 1) -> Dict[str, Tensor]:
     p["temporal_encoder.attention_heads.fc1_k.weight"] = xavier(cfg.n_head * cfg.d_k, cfg.d_model)
     p["temporal_encoder.attention_heads.fc1_k.bias"] = randn(cfg.n_head * cfg.d_k)
     p["temporal_encoder.in_norm.weight"], p["temporal_encoder.in_norm.bias"] = torch.ones(c), torch.zeros(c)
+    if cfg.use_v:
+        p["temporal_encoder.mlp.0.weight"], p["temporal_encoder.mlp.0.bias"] = xavier(c, cfg.d_model), randn(c)
+        p["temporal_encoder.mlp.1.weight"], p["temporal_encoder.mlp.1.bias"] = randn(c), torch.zeros(c)
+        p["temporal_encoder.mlp.1.running_mean"], p["temporal_encoder.mlp.1.running_var"] = torch.zeros(c), torch.ones(c)
+        p["temporal_encoder.mlp.1.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+        p["temporal_encoder.out_norm.weight"], p["temporal_encoder.out_norm.bias"] = torch.ones(c), torch.zeros(c)
+        p["include_v.weight"], p["include_v.bias"] = xavier(c, 2 * c, 1, 1), randn(c)
     for i, cw in enumerate(cfg.decoder_widths):
         mb(f"out_block.{i}", cw, cfg.decoder_norm)
     oc = cfg.out_conv[-1]

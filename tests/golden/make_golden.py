@@ -368,6 +368,49 @@ def variant_state(state, name):
     return st
 
 
+def case_usev():
+    """G12: UNCRTAINTS(use_v=True): LTAE2d values (attention-weighted, MLP + BatchNorm1d + ReLU + dropout + GroupNorm)
+    up-sampled and merged through include_v (uncrtaints.py:324-338,414-417; ltae.py:10-141,244-307,388-416)."""
+    torch.manual_seed(7)
+    m = uncrtaints.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus",
+                              covmode="diag", scale_by=1.0, use_v=True)
+    m.apply(weight_init)
+    g = torch.Generator().manual_seed(107)
+    for mod in m.modules():
+        if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+            mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=g))
+            mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g))
+        if isinstance(mod, torch.nn.GroupNorm):
+            mod.weight.data.copy_(1.0 + 0.3 * torch.randn(mod.weight.shape, generator=g))
+            mod.bias.data.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+    m.temporal_aggregator.attn_dropout.p = 0.0
+    m.temporal_encoder.dropout.p = 0.0                      # LTAE2d's dropout on the values (ltae.py:97,125)
+    x, y, dates = synth(2, 3, 64, 64, 7)
+    x[1, 2] = 0.0                                           # one padded date
+    out = {"x": x.numpy(), "y": y.numpy(), "dates": dates.numpy()}
+    for k, v in np_state(m.state_dict()).items():
+        out["state/" + k] = v
+    m.eval()
+    with torch.no_grad():
+        oe = m(x, batch_positions=dates)
+    out["eval/out"] = oe.numpy()
+    m.train()
+    xg = x.clone().requires_grad_(True)
+    ot = m(xg, batch_positions=dates)
+    l, _ = crit("diag")(ot[:, :, :13], y, ot[:, :, 13:26])
+    l.backward()
+    out["train/out"] = ot.detach().numpy()
+    out["train/loss"] = np.array(l.item())
+    out["train/dx_b0t0"] = xg.grad[0, 0].numpy()
+    for k, v in m.named_parameters():
+        out["grad/" + k] = v.grad.numpy()
+    for k, v in np_state(m.state_dict()).items():
+        if "running_" in k:
+            out["train/state/" + k] = v
+    np.savez_compressed(os.path.join(HERE, "g12_usev.npz"), **out)
+    print("g12_usev train loss", l.item(), "keys", len(out))
+
+
 def case_variants():
     """G2: secondary variants of the UNCRTAINTS class; weights come from g1_diag_t3."""
     base = np.load(os.path.join(HERE, "g1_diag_t3.npz"))
@@ -416,12 +459,15 @@ if __name__ == "__main__":
     case_prepare(); sys.exit(0)
   if "--only-metrics" in sys.argv:
     case_metrics(); sys.exit(0)
+  if "--only-usev" in sys.argv:
+    case_usev(); sys.exit(0)
   if "--only-trainseq" not in sys.argv:
     case_variants()
     case_mgnll()
     case_eltlosses()
     case_prepare()
     case_metrics()
+    case_usev()
     case_posenc()
     case_ensemble()
   case_trainseq()

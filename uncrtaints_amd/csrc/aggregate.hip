@@ -192,7 +192,8 @@ static int agg_check(int B, int T, int C, int NH, int H, int W, int AH, int AW) 
     if (B <= 0 || T <= 0 || C % NH || C > 256) return UNCR_ESHAPE;
     if (C / NH != 4 && C / NH != 8 && C / NH != 16) return UNCR_ESHAPE;
     if ((W & 3) || ((H * W) % AGG_PX)) return UNCR_ESHAPE;
-    if (H <= AH || W <= AW) return UNCR_ESHAPE;   // avg-pool branch (uncrtaints.py:204) not built
+    if (H < AH || W < AW) return UNCR_ESHAPE;     // avg-pool branch (uncrtaints.py:204) not built; H == AH is the
+                                                  // identity up-sampling (LTAE2d's attention-weighted values)
     return UNCR_OK;
 }
 
@@ -229,6 +230,87 @@ extern "C" int uncr_aggregate_bwd(const float* dg, const float* e, const float* 
     UNCR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(AH, NH * B * T), dim3(256), 0, stream, datt_up, datt, H, W, AH,
                        AW);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+
+// ---- use_v (uncrtaints.py:414-417): out = a + bilinear_up(z) with (sum, sum^2) partials for the next PreNorm.
+// include_v(cat(g, up(v))) = Wa*g + up(Wv*v + b): the 1x1 convolution commutes with the up-sampling, so the value
+// branch is convolved at 32x32 and only this add touches full resolution.  grid = (P/1024, B*C), block 256 x float4.
+__global__ __launch_bounds__(256) void add_upsampled_kernel(const float* __restrict__ a, const float* __restrict__ z,
+                                                            float* __restrict__ out, float2* __restrict__ part, int H,
+                                                            int W, int AH, int AW) {
+    const int plane = blockIdx.y;
+    const int p = blockIdx.x * AGG_PX + threadIdx.x * 4;
+    const float sy = (float)AH / (float)H, sx = (float)AW / (float)W;
+    const int y = p / W, x0 = p % W;              // W % 4 == 0: the four pixels share a row
+    const Bilin by = bilin_src(y, sy, AH);
+    const float* zp = z + (size_t)plane * AH * AW;
+    const float4 va = *(const float4*)(a + (size_t)plane * H * W + p);
+    const float* pa = (const float*)&va;
+    float4 vo;
+    float* o = (float*)&vo;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const Bilin bx = bilin_src(x0 + i, sx, AW);
+        const float up = by.l0 * (bx.l0 * zp[by.i0 * AW + bx.i0] + bx.l1 * zp[by.i0 * AW + bx.i1]) +
+                         by.l1 * (bx.l0 * zp[by.i1 * AW + bx.i0] + bx.l1 * zp[by.i1 * AW + bx.i1]);
+        o[i] = pa[i] + up;
+        s0 += o[i];
+        s1 = fmaf(o[i], o[i], s1);
+    }
+    *(float4*)(out + (size_t)plane * H * W + p) = vo;
+    if (part) {
+        __shared__ float red[8];
+        block_sum2<256>(s0, s1, red);
+        if (threadIdx.x == 0) part[(size_t)plane * gridDim.x + blockIdx.x] = make_float2(s0, s1);
+    }
+}
+extern "C" int uncr_add_upsampled(const float* a, const float* z, float* out, float* part, int planes, int H, int W,
+                                  int AH, int AW, hipStream_t stream) {
+    if (planes <= 0 || (W & 3) || ((H * W) % AGG_PX) || H < AH || W < AW) return UNCR_ESHAPE;
+    if (!a || !z || !out) return UNCR_EINVAL;
+    hipLaunchKernelGGL(add_upsampled_kernel, dim3(H * W / AGG_PX, planes), dim3(256), 0, stream, a, z, out,
+                       (float2*)part, H, W, AH, AW);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+// adjoint of the bilinear up-sampling on its own: dst[q, ay, ax] = sum_{y,x} wy wx src[q, y, x]
+extern "C" int uncr_bilinear_adjoint(const float* src, float* dst, int planes, int H, int W, int AH, int AW,
+                                     hipStream_t stream) {
+    if (planes <= 0 || H < AH || W < AW) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(AH, planes), dim3(256), 0, stream, src, dst, H, W, AH, AW);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+// element-wise helpers of the value branch: out = a + b, and out = a * keep(seed, index) (nn.Dropout with the same
+// counter-based stream as the aggregator; the backward applies the identical mask to the gradient)
+__global__ __launch_bounds__(256) void add2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+extern "C" int uncr_add(const float* a, const float* b, float* out, long long n, hipStream_t stream) {
+    if (n <= 0 || !a || !b || !out) return UNCR_EINVAL;
+    hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, out, n);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ a, float* __restrict__ out, long long n,
+                                                      unsigned long long seed, const long long* __restrict__ seed_dev,
+                                                      float p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long sd = seed + (seed_dev ? (unsigned long long)seed_dev[0] * 0x9E3779B97F4A7C15ull : 0ull);
+    out[i] = hash_uniform(sd, (unsigned long long)i) < p ? 0.f : a[i] / (1.f - p);
+}
+extern "C" int uncr_dropout(const float* a, float* out, long long n, unsigned long long seed, const long long* seed_dev,
+                            float p, hipStream_t stream) {
+    if (n <= 0 || !a || !out || p < 0.f || p >= 1.f) return UNCR_EINVAL;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, out, n, seed,
+                       seed_dev, p);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -519,6 +519,7 @@ extern "C" int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, 
 // weight-gradient shapes: (COP, CIP) in {(128,256), (256,128), (128,32), (32,128), (64,256)}
 static int wg_shape(int Cd, int Cx, int* cop, int* cip) {
     if (Cd > 128 && Cd <= 256 && Cx > 32 && Cx <= 128) { *cop = 256; *cip = 128; return 0; }
+    if (Cd > 64 && Cd <= 128 && Cx > 32 && Cx <= 128) { *cop = 256; *cip = 128; return 0; }   // 128 x 128 (use_v): padded rows
     if (Cd > 64 && Cd <= 128 && Cx > 128 && Cx <= 256) { *cop = 128; *cip = 256; return 1; }
     if (Cd > 32 && Cd <= 128 && Cx <= 32) { *cop = 128; *cip = 32; return 2; }
     if (Cd <= 32 && Cx > 32 && Cx <= 128) { *cop = 32; *cip = 128; return 3; }

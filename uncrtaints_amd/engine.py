@@ -454,8 +454,9 @@ def ltae_attention_forward(down: Tensor, dates: Optional[Tensor], pad: Optional[
     return att, saved
 
 
-def ltae_attention_backward(datt: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int, d_k: int):
-    """-> d(down) [B*T,C,S], {param grads}"""
+def ltae_attention_backward(datt: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int, d_k: int,
+                            dy1_extra: Optional[Tensor] = None):
+    """-> d(down) [B*T,C,S], {param grads}.  dy1_extra: gradient reaching y1 through the values (use_v)."""
     B, T, C, S, D, HK = sv["dims"]
     NF = B * T
     dev = datt.device
@@ -472,6 +473,8 @@ def ltae_attention_backward(datt: Tensor, sv: dict, p: Dict[str, Tensor], n_head
     g["fc_w"], g["fc_b"] = dWk, dbk
     Wkk = pack_wt(p["fc_w"], transpose=False)                     # [k=64][out=256]
     dy1, _ = pw_gemm(dk, Wkk, NF, HK, D, S)
+    if dy1_extra is not None:
+        hb.call("uncr_add", dy1, dy1_extra.contiguous(), dy1, dy1.numel(), _stream())
     dWi, dbi = pw_wgrad(dy1, sv["xn"], NF, D, C, S, rowsum=True)
     g["inconv_w"], g["inconv_b"] = dWi.view_as(p["inconv_w"]), dbi
     Wik = pack_wt(p["inconv_w"].reshape(D, C), transpose=False)   # [k=256][out=128]
@@ -496,8 +499,8 @@ def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: b
     n_head, _, _, ah, aw = att.shape
     if (H * W) % 1024 or W % 4:
         raise RuntimeError(f"unsupported spatial size {H}x{W}")
-    if H <= ah or W <= aw:
-        raise NotImplementedError("feature map not larger than the attention map (AvgPool branch, "
+    if H < ah or W < aw:
+        raise NotImplementedError("feature map smaller than the attention map (AvgPool branch, "
                                   "uncrtaints.py:204) is not built")
     dev = e.device
     g = _f32((B, C, H, W), dev)
@@ -555,11 +558,114 @@ def mean_mode_weights(pad: Optional[Tensor], n_head: int, B: int, T: int, ah: in
     return out
 
 
+def ltae_values_forward(sv_att: dict, pad: Optional[Tensor], p: Dict[str, Tensor], n_head: int, training: bool,
+                        bn_buffers, p_drop: float, seed):
+    """LTAE2d values (ltae.py:122-133): attention-weighted sum over T of the projected features (per head), Linear +
+    BatchNorm1d + ReLU, dropout, GroupNorm.  -> v [B,C,S] (C = mlp[-1]), saved.
+    p: mlp_w [C,D], mlp_b, bn_w, bn_b, on_w, on_b.  The attention-weighted sum IS the temporal aggregation at the
+    attention's own resolution, so it runs on the aggregate kernels."""
+    B, T, Cin, S, D, HK = sv_att["dims"]
+    att, y1 = sv_att["att"], sv_att["y1"]
+    ah, aw = att.shape[-2:]
+    dev = y1.device
+    C = p["mlp_w"].shape[0]
+    vh, sv_agg, _ = aggregate_forward(y1.view(B, T, D, ah, aw), att, pad, False, 0.0, 0, None, want_stats=False)
+    Wm = pack_wt(p["mlp_w"], transpose=True)
+    m1, part = pw_gemm(vh.view(B, D, S), Wm, B, D, C, S, bias=p["mlp_b"].contiguous(), epi=1)
+    spec = NormSpec("batch", 1)
+    rm, rv = bn_buffers if bn_buffers is not None else (None, None)
+    nf = norm_fwd(part, B, C, S, spec, training, p["bn_w"], p["bn_b"], rm, rv)
+    r = _f32((B, C, S), dev)
+    ew(EW_AFFINE_RELU, m1, out=r, k=(nf.A, nf.B, None, None), want_part=False, planes=B * C, P=S)
+    pd = float(p_drop) if training else 0.0
+    seed_val, seed_dev = seed if isinstance(seed, tuple) else (seed, None)
+    rd = r
+    if pd > 0.0:
+        rd = _f32((B, C, S), dev)
+        hb.call("uncr_dropout", r, rd, r.numel(), seed_val, seed_dev, pd, _stream())
+    v, mean, rstd = _f32((B, C, S), dev), _f32((B, n_head, S), dev), _f32((B, n_head, S), dev)
+    hb.call("uncr_ltae_gn_fwd", rd, p["on_w"], p["on_b"], 1e-5, v, mean, rstd, B, 1, C, n_head, S, _stream())
+    saved = dict(agg=sv_agg, vh=vh, m1=m1, nf=nf, r=r, rd=rd, gn=(mean, rstd), pd=pd, seed=seed_val, seed_dev=seed_dev,
+                 dims=(B, T, C, S, D))
+    return v, saved
+
+
+def ltae_values_backward(dv: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int):
+    """-> (dy1 contribution [B*T,D,S], d attention [nh,B,T,ah,aw], {param grads})"""
+    B, T, C, S, D = sv["dims"]
+    dev = dv.device
+    g: Dict[str, Tensor] = {}
+    nchunk = (S + 255) // 256
+    mean, rstd = sv["gn"]
+    drd = _f32((B, C, S), dev)
+    gb_part = _f32((B * nchunk, C, 2), dev)
+    hb.call("uncr_ltae_gn_bwd", dv.contiguous(), sv["rd"], p["on_w"], mean, rstd, drd, gb_part, B, 1, C, n_head, S,
+            _stream())
+    gb = _f32((C * 2,), dev)
+    hb.call("uncr_colsum", gb_part, B * nchunk, C * 2, gb, _stream())
+    gb = gb.view(C, 2)
+    g["on_w"], g["on_b"] = gb[:, 0].contiguous(), gb[:, 1].contiguous()
+    dr = drd
+    if sv["pd"] > 0.0:
+        dr = _f32((B, C, S), dev)
+        hb.call("uncr_dropout", drd, dr, drd.numel(), sv["seed"], sv["seed_dev"], sv["pd"], _stream())
+    nf, m1 = sv["nf"], sv["m1"]
+    du = _f32((B, C, S), dev)
+    _, part = ew(EW_RELU_BWD, dr, b=m1, out=du, k=(nf.A, nf.B, None, None), want_part=True, planes=B * C, P=S)
+    nb = norm_bwd(part, B, C, S, nf, p["bn_w"])
+    g["bn_w"], g["bn_b"] = nb.dgamma, nb.dbeta
+    kk = (nb.c1, nb.c2, nb.c3)
+    dWm, dbm = pw_wgrad(du, sv["vh"].view(B, D, S), B, C, D, S, pro_d=PRO_NORMBWD, dk=kk, d2=m1, rowsum=True)
+    g["mlp_w"], g["mlp_b"] = dWm, dbm
+    Wmk = pack_wt(p["mlp_w"], transpose=False)                # [k=C][out=D]
+    dvh, _ = pw_gemm(du, Wmk, B, C, D, S, pro=PRO_NORMBWD, k=kk, x2=m1)
+    ah, aw = sv["agg"]["dims"][6:8]
+    dy1, datt = aggregate_backward(dvh.view(B, D, ah, aw), sv["agg"])
+    return dy1.view(B * T, D, S), datt, g
+
+
+def include_v_forward(gagg: Tensor, v: Tensor, w: Tensor, b: Tensor, want_stats: bool):
+    """uncrtaints.py:414-417: include_v(cat(g, up(v))) = Wa*g + up(Wv*v + b)  (the 1x1 convolution commutes with the
+    bilinear up-sampling, whose weights sum to one).  gagg [B,C,H,W], v [B,Cv,ah,aw], w [C,C+Cv,1,1]."""
+    B, C, H, W = gagg.shape
+    Cv, ah, aw = v.shape[1:]
+    P, S = H * W, ah * aw
+    w2 = w.reshape(C, C + Cv)
+    wa, wv = w2[:, :C].contiguous(), w2[:, C:].contiguous()
+    z, _ = pw_gemm(v.reshape(B, Cv, S), pack_wt(wv, transpose=True), B, Cv, C, S, bias=b.contiguous())
+    t, _ = pw_gemm(gagg.view(B, C, P), pack_wt(wa, transpose=True), B, C, C, P)
+    out = _f32((B, C, H, W), gagg.device)
+    part = None
+    if want_stats:
+        slots = hb.query("uncr_agg_slots", P)
+        part = Part(_f32((B * C, slots, 2), gagg.device), slots)
+    hb.call("uncr_add_upsampled", t, z, out, part.buf if part else None, B * C, H, W, ah, aw, _stream())
+    return out, dict(g=gagg, v=v, wa=wa, wv=wv, dims=(B, C, Cv, H, W, ah, aw)), part
+
+
+def include_v_backward(dout: Tensor, sv: dict):
+    """-> (d gagg [B,C,H,W], d v [B,Cv,ah,aw], dW [C,C+Cv,1,1], db [C])"""
+    B, C, Cv, H, W, ah, aw = sv["dims"]
+    P, S = H * W, ah * aw
+    dout = dout.contiguous()
+    dz = _f32((B, C, S), dout.device)
+    hb.call("uncr_bilinear_adjoint", dout, dz, B * C, H, W, ah, aw, _stream())
+    dWa, db = pw_wgrad(dout.view(B, C, P), sv["g"].view(B, C, P), B, C, C, P, rowsum=True)     # db = sum dout (= sum dz)
+    dWv, _ = pw_wgrad(dz, sv["v"].reshape(B, Cv, S), B, C, Cv, S)
+    dg, _ = pw_gemm(dout.view(B, C, P), pack_wt(sv["wa"], transpose=False), B, C, C, P)
+    dv, _ = pw_gemm(dz, pack_wt(sv["wv"], transpose=False), B, C, Cv, S)
+    dW = torch.cat((dWa, dWv), dim=1).view(C, C + Cv, 1, 1)
+    return dg.view(B, C, H, W), dv.view(B, Cv, ah, aw), dW, db
+
+
 def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor], p: Dict[str, Tensor],
                        denom: Optional[Tensor], n_head: int, d_k: int, att_down: int, training: bool, p_drop: float,
-                       seed: int, dmask: Optional[Tensor] = None, want_stats: bool = True, mode: str = "att_group"):
+                       seed: int, dmask: Optional[Tensor] = None, want_stats: bool = True, mode: str = "att_group",
+                       values: Optional[dict] = None):
     """Fused stage used by UNCRTAINTS.forward: e [B,T,C,H,W] -> g [B,C,H,W] (+ stats partials of g).
-    mode: 'att_group' | 'att_mean' | 'mean' (uncrtaints.py:156-221)."""
+    mode: 'att_group' | 'att_mean' | 'mean' (uncrtaints.py:156-221).
+    values (use_v): dict(p=value-branch params, include_w, include_b, bn_buffers, p_drop, seed): the LTAE2d values are
+    up-sampled and merged through include_v (uncrtaints.py:414-417)."""
     down, idx = maxpool_forward(e, att_down, att_down)
     att, sv_att = ltae_attention_forward(down, dates, pad, p, denom, n_head, d_k)
     B, T = e.shape[:2]
@@ -573,11 +679,32 @@ def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor]
         dmask = None
     else:
         raise NotImplementedError(mode)
-    g, sv_agg, gpart = aggregate_forward(e, w_att, pad, training, p_drop, seed, dmask, want_stats, shared)
-    return g, dict(att=sv_att, agg=sv_agg, idx=idx, att_down=att_down, mode=mode), gpart, att
+    if values is None:
+        g, sv_agg, gpart = aggregate_forward(e, w_att, pad, training, p_drop, seed, dmask, want_stats, shared)
+        return g, dict(att=sv_att, agg=sv_agg, idx=idx, att_down=att_down, mode=mode), gpart, att
+    if mode != "att_group":
+        raise NotImplementedError("use_v is built for agg_mode='att_group'")
+    g0, sv_agg, _ = aggregate_forward(e, w_att, pad, training, p_drop, seed, dmask, False, shared)
+    v, sv_val = ltae_values_forward(sv_att, pad, values["p"], n_head, training, values.get("bn_buffers"),
+                                    values.get("p_drop", 0.0), values.get("seed", 0))
+    ah, aw = att.shape[-2:]
+    g, sv_inc, gpart = include_v_forward(g0, v.view(B, -1, ah, aw), values["include_w"], values["include_b"], want_stats)
+    return g, dict(att=sv_att, agg=sv_agg, idx=idx, att_down=att_down, mode=mode, val=sv_val, inc=sv_inc,
+                   vp=values["p"]), gpart, att
 
 
 def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int, d_k: int):
+    if "val" in sv:     # use_v: include_v -> (aggregation, values) -> attention
+        dg0, dv, dWinc, dbinc = include_v_backward(dg, sv["inc"])
+        de, datt = aggregate_backward(dg0, sv["agg"])
+        dy1, datt_v, gv = ltae_values_backward(dv.reshape(dv.shape[0], dv.shape[1], -1), sv["val"], sv["vp"], n_head)
+        hb.call("uncr_add", datt, datt_v, datt, datt.numel(), _stream())
+        ddown, g = ltae_attention_backward(datt, sv["att"], p, n_head, d_k, dy1_extra=dy1)
+        H, W = de.shape[-2:]
+        maxpool_backward_into(ddown, sv["idx"], de, H, W, sv["att_down"], sv["att_down"])
+        g.update(gv)
+        g["include_w"], g["include_b"] = dWinc, dbinc
+        return de, g
     de, datt = aggregate_backward(dg, sv["agg"])
     mode = sv.get("mode", "att_group")
     if mode == "mean":

@@ -7,15 +7,15 @@ loads reference checkpoints.  Modules hold parameters in stock `nn.*` layers (we
 dispatch on those types); `forward` routes through autograd Functions over `uncrtaints_amd.engine`.
 There is no PyTorch-op fallback: on a machine without the HIP library or a GPU tensor, forward raises.
 
-Built: block_type='mbconv', agg_mode='att_group', encoder_norm/decoder_norm in {group, batch},
-use_v=False, separate_out=False, out_nonlin_var='softplus', covmode in {diag, iso, uni, None}.
-Not built yet (raise NotImplementedError): block_type='residual', use_v, separate_out, att_mean/mean
-aggregation, is_mono, instance norm."""
+Built: block_type='mbconv', agg_mode in {att_group, att_mean, mean}, encoder_norm/decoder_norm in {group, batch},
+use_v in {False, True}, separate_out, is_mono, out_nonlin_var='softplus', covmode in {diag, iso, uni, None}.
+Not built (raise NotImplementedError): block_type='residual' (dense 3x3 convolutions), instance norm
+(SURVEY 8(a17) / 8(f))."""
 import torch
 import torch.nn as nn
 
 from ... import engine as E
-from .ltae import LTAE2dtiny, _LTAE_KEYS, _ltae_params
+from .ltae import LTAE2d, LTAE2dtiny, _LTAE_KEYS, _LTAEV_KEYS, _ltae_params, _ltae_value_params
 from .utae import ConvBlock, ConvLayer, TemporallySharedBlock
 
 S2_BANDS = 13
@@ -221,9 +221,21 @@ class _StageFn(torch.autograd.Function):
         denom = te.positional_encoder.denom_on(e.device) if te.positional_encoder is not None else None
         want_stats = net.out_block[0]._spec.needs_stats(net.training)
         net._last_pad = pad
+        values = None
+        ctx.use_v = getattr(net, "use_v", False)
+        if ctx.use_v:            # params = L-TAE keys, value-branch keys, include_v weight and bias
+            nk = len(_LTAE_KEYS)
+            vp = dict(zip(_LTAEV_KEYS, params[nk:nk + len(_LTAEV_KEYS)]))
+            bn = te.mlp[1]
+            seed = agg._next_seed()
+            vseed = (seed[0] ^ 0x5bd1e995, seed[1]) if isinstance(seed, tuple) else (seed ^ 0x5bd1e995)
+            values = dict(p=vp, include_w=params[-2], include_b=params[-1], bn_buffers=(bn.running_mean, bn.running_var),
+                          p_drop=te.dropout.p, seed=vseed)
         g, sv, gpart, att = E.ltae_stage_forward(e.contiguous(), dates, pad, p, denom, te.n_head,
                                                  te.attention_heads.d_k, 32, net.training, agg.attn_dropout.p,
-                                                 agg._next_seed(), dmask, want_stats, mode=agg.mode)
+                                                 agg._next_seed(), dmask, want_stats, mode=agg.mode, values=values)
+        if ctx.use_v and net.training:
+            te.mlp[1].num_batches_tracked += 1
         ctx.sv, ctx.p, ctx.te = sv, p, te
         net._last_attention = att
         g._uncr_part = gpart
@@ -232,7 +244,10 @@ class _StageFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dg):
         de, g = E.ltae_stage_backward(dg, ctx.sv, ctx.p, ctx.te.n_head, ctx.te.attention_heads.d_k)
-        return (de, None, None, None, None) + tuple(g[k] for k in _LTAE_KEYS)
+        grads = tuple(g[k] for k in _LTAE_KEYS)
+        if ctx.use_v:
+            grads += tuple(g[k] for k in _LTAEV_KEYS) + (g["include_w"], g["include_b"])
+        return (de, None, None, None, None) + grads
 
 
 class _HeadFn(torch.autograd.Function):
@@ -298,8 +313,8 @@ class UNCRTAINTS(nn.Module):
             decoder_widths = encoder_widths
         if block_type != 'mbconv':
             raise NotImplementedError("block_type='residual' is not built (SURVEY 8(f) rank 2)")
-        if use_v:
-            raise NotImplementedError("use_v (LTAE2d with values) is not built (SURVEY 8(f) rank 2)")
+        if use_v and (agg_mode != "att_group" or is_mono):
+            raise NotImplementedError("use_v is built for agg_mode='att_group' on image time series")
         if agg_mode not in ("att_group", "att_mean", "mean"):
             raise NotImplementedError(f"agg_mode '{agg_mode}'")
         if padding_mode != "reflect":
@@ -311,8 +326,14 @@ class UNCRTAINTS(nn.Module):
         self.in_block = nn.ModuleList([MBConv(layer, layer, downsample=False, expansion=2, norm=encoder_norm)
                                        for layer in encoder_widths])
         if not self.is_mono:     # uncrtaints.py:322-348
-            self.temporal_encoder = LTAE2dtiny(in_channels=encoder_widths[0], d_model=d_model, n_head=n_head, d_k=d_k,
-                                               positional_encoding=positional_encoding)
+            if use_v:            # uncrtaints.py:324-338
+                self.temporal_encoder = LTAE2d(in_channels=encoder_widths[0], d_model=d_model, n_head=n_head,
+                                               mlp=[d_model, encoder_widths[0]], return_att=True, d_k=d_k,
+                                               positional_encoding=positional_encoding, use_dropout=False)
+                self.include_v = nn.Conv2d(encoder_widths[0] + encoder_widths[0], encoder_widths[0], 1)
+            else:
+                self.temporal_encoder = LTAE2dtiny(in_channels=encoder_widths[0], d_model=d_model, n_head=n_head,
+                                                   d_k=d_k, positional_encoding=positional_encoding)
             self.temporal_aggregator = Compact_Temporal_Aggregator(mode=agg_mode)
         self.out_block = nn.ModuleList([MBConv(layer, layer, downsample=False, expansion=2, norm=decoder_norm)
                                         for layer in decoder_widths])
@@ -413,8 +434,12 @@ class UNCRTAINTS(nn.Module):
             if self.temporal_encoder.positional_encoder is not None and batch_positions is None:
                 raise ValueError("batch_positions (dates) are required when positional_encoding=True")
             p = _ltae_params(self.temporal_encoder)
+            extra = []
+            if self.use_v:
+                vp = _ltae_value_params(self.temporal_encoder)
+                extra = [vp[k] for k in _LTAEV_KEYS] + [self.include_v.weight, self.include_v.bias]
             out = _StageFn.apply(out, batch_positions, pad, self, self.temporal_aggregator.dropout_mask,
-                                 *[p[k] for k in _LTAE_KEYS])
+                                 *([p[k] for k in _LTAE_KEYS] + extra))
         else:                                                              # uncrtaints.py:418
             if out.shape[1] != 1:
                 raise ValueError("is_mono expects a single input date (T == 1)")
