@@ -47,6 +47,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define UNCR_EW_SE_POOL 7
 #define UNCR_EW_HEAD_FWD 8
 #define UNCR_EW_HEAD_BWD 9
+#define UNCR_EW_RESIDUAL_RELU 10   /* out = a + relu(A*b + B) (ResidualConvBlock skip) */
 
 int uncr_version(void);
 int uncr_debug_mfma_probe(float* out, int blocks, int iters, hipStream_t stream);   /* fp32-MFMA peak probe */
@@ -163,6 +164,19 @@ int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const 
                        unsigned long long seed, const long long* seed_dev, float p_drop, int shared_mask,
                        float* de, float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int AH,
                        int AW, hipStream_t stream);
+
+/* ---- dense 3x3 reflect convolution of ResidualConvBlock (uncrtaints.py:24-69, utae.py:478-487) as nine accumulating
+ *      pointwise GEMMs on the padded grid (uncr_pw_gemm epi 4 with the input pointer shifted by dy*(W+2)+dx).  Glue:
+ *      padding with the producing norm+ReLU (pro 4) / norm-backward (pro 3) fused in, un-padding with the next norm's
+ *      statistics, adjoint of the reflect padding.  Padded tensors: [planes][uncr_conv3_plane_stride] floats with
+ *      uncr_conv3_margin floats of (zero) slack before and after the whole tensor. ---- */
+int uncr_conv3_plane_stride(int H, int W);
+int uncr_conv3_margin(int W);
+int uncr_pad2d(const float* src, const float* src2, float* dst, const float* k0, const float* k1, const float* k2,
+               int pro, int mode /* 0 reflect, 1 zero */, int planes, int H, int W, hipStream_t stream);
+int uncr_unpad2d(const float* src, float* dst, float* part /* [planes][H*W/1024][2] or null */, int planes, int H,
+                 int W, hipStream_t stream);
+int uncr_unpad2d_reflect_adjoint(const float* src, float* dst, int planes, int H, int W, hipStream_t stream);
 
 /* ---- use_v variant (uncrtaints.py:324-338,414-417; LTAE2d ltae.py:10-141): pieces that are not already covered by the
  *      entry points above.  include_v(cat(g, up(v))) = Wa*g + up(Wv*v + b), so only uncr_add_upsampled touches full

@@ -57,6 +57,7 @@ class OracleConfig:
     attn_dropout: float = 0.1     # uncrtaints.py:154
     separate_out: bool = False    # uncrtaints.py:376-379
     is_mono: bool = False         # uncrtaints.py:322,418
+    block_type: str = "mbconv"    # 'mbconv' | 'residual' (uncrtaints.py:24-69,315-319,349-353)
     use_v: bool = False           # uncrtaints.py:324-338,414-417 (LTAE2d values + include_v)
     ltae_dropout: float = 0.2     # ltae.py:17,97 (dropout on the MLP-processed values; use_v only)
 
@@ -170,6 +171,29 @@ class _NormCtx:
             return batch_norm(x, w, b, self.p[prefix + ".running_mean"], self.p[prefix + ".running_var"],
                               self.training, update_running=self.update)
         raise NotImplementedError(self.kind)
+
+
+def conv3x3_reflect(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """nn.Conv2d(k=3, padding=1, padding_mode='reflect') (utae.py:478-487), dense."""
+    return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b)
+
+
+def residual_block(x: Tensor, p: Dict[str, Tensor], prefix: str, norm: str, training: bool,
+                   update_running: bool = True) -> Tensor:
+    """ResidualConvBlock (uncrtaints.py:24-69): x + CL3(CL2(CL1(x))), every ConvLayer = conv3x3(reflect, bias) ->
+    norm -> ReLU (the third one too: uncrtaints.py:53-62)."""
+    nrm = _NormCtx(p, norm, training, update_running)
+    h = x
+    for i in (1, 2, 3):
+        pre = f"{prefix}.conv{i}.conv"
+        h = torch.relu(nrm(conv3x3_reflect(h, p[pre + ".0.weight"], p[pre + ".0.bias"]), pre + ".1"))
+    return x + h
+
+
+def _block(x, p, prefix, norm, training, update_running, taps, cfg):
+    if cfg.block_type == "residual":
+        return residual_block(x, p, prefix, norm, training, update_running)
+    return mbconv(x, p, prefix, norm, training, update_running, taps)
 
 
 def mbconv(x: Tensor, p: Dict[str, Tensor], prefix: str, norm: str, training: bool,
@@ -305,7 +329,7 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
     f = x.reshape(B * T, Cin, H, W)                                       # smart_forward, utae.py:422-450
     c0 = conv1x1(f, p["in_conv.conv.conv.0.weight"], p["in_conv.conv.conv.0.bias"])
     a0 = torch.relu(group_norm(c0, 4, p["in_conv.conv.conv.1.weight"], p["in_conv.conv.conv.1.bias"]))
-    e = mbconv(a0, p, "in_block.0", cfg.encoder_norm, training, update_running, taps)
+    e = _block(a0, p, "in_block.0", cfg.encoder_norm, training, update_running, taps, cfg)
     C = e.shape[1]
     if cfg.is_mono:
         g, down, attn = e.view(B, T, C, H, W).squeeze(dim=1), None, None
@@ -324,7 +348,7 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
         taps.update(c0=c0, a0=a0, e=e, down=down, attn=attn, agg=g)
     out = g
     for i in range(len(cfg.decoder_widths)):
-        out = mbconv(out, p, f"out_block.{i}", cfg.decoder_norm, training, update_running, taps)
+        out = _block(out, p, f"out_block.{i}", cfg.decoder_norm, training, update_running, taps, cfg)
         if taps is not None:
             taps[f"dec{i}"] = out
     if cfg.separate_out:
@@ -491,6 +515,12 @@ def init_params(cfg: OracleConfig, seed: int = 1) -> Dict[str, Tensor]:
         p[prefix + ".conv.fn.6.fc.2.weight"] = xavier(hd, int(c * 0.25))
         p[prefix + ".conv.fn.7.weight"] = xavier(c, hd, 1, 1)
         norm_params(prefix + ".conv.fn.8", c, kind)
+
+    if cfg.block_type == "residual":
+        def mb(prefix, c, kind):        # noqa: F811 -- ResidualConvBlock parameters instead of MBConv's
+            for i in (1, 2, 3):
+                p[f"{prefix}.conv{i}.conv.0.weight"], p[f"{prefix}.conv{i}.conv.0.bias"] = xavier(c, c, 3, 3), randn(c)
+                norm_params(f"{prefix}.conv{i}.conv.1", c, kind)
 
     c = cfg.encoder_widths[0]
     p["in_conv.conv.conv.0.weight"], p["in_conv.conv.conv.0.bias"] = xavier(c, cfg.input_dim, 1, 1), randn(c)

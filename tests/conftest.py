@@ -70,3 +70,19 @@ def compare_param_grads(got, golden, tol=2e-4, zero_ratio=1e-5):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def residual_state(g):
+    """state_dict of the g13_residual fixture: stored tensors + the dense 3x3 weights regenerated from the numpy seed
+    (the fixture keeps them out to stay small; same generator and order as tests/golden/make_golden.py::case_residual)."""
+    import torch
+    state = {k[len("state/"):]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith("state/")}
+    rng = np.random.default_rng(int(g["regen_seed"]))
+    shapes = {}
+    for k in state:
+        if k.endswith(".conv.1.weight") and ".conv1." in k or ".conv2." in k and k.endswith(".conv.1.weight") \
+                or ".conv3." in k and k.endswith(".conv.1.weight"):
+            shapes[k.replace(".conv.1.weight", ".conv.0.weight")] = (state[k].shape[0], state[k].shape[0], 3, 3)
+    for k in [str(s) for s in g["regenerated"]]:
+        state[k] = torch.from_numpy((rng.standard_normal(shapes[k]) * 0.03).astype(np.float32))
+    return state

@@ -411,6 +411,59 @@ def case_usev():
     print("g12_usev train loss", l.item(), "keys", len(out))
 
 
+def case_residual():
+    """G13: UNCRTAINTS(block_type='residual'): ResidualConvBlock = 3 x (dense conv3x3 reflect + norm + ReLU) + skip
+    (uncrtaints.py:24-69).  Small network (2 decoder blocks) to keep the fixture small."""
+    torch.manual_seed(9)
+    m = uncrtaints.UNCRTAINTS(input_dim=15, decoder_widths=[128, 128], out_conv=[26], out_nonlin_mean=True,
+                              out_nonlin_var="softplus", covmode="diag", scale_by=1.0, block_type="residual")
+    m.apply(weight_init)
+    g = torch.Generator().manual_seed(109)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=g))
+            mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g))
+        if isinstance(mod, torch.nn.GroupNorm):
+            mod.weight.data.copy_(1.0 + 0.3 * torch.randn(mod.weight.shape, generator=g))
+            mod.bias.data.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+    m.temporal_aggregator.attn_dropout.p = 0.0
+    # the dense 3x3 weights (590 KB each) are NOT stored: they are regenerated from a numpy seed by the tests
+    # (tests/conftest.py::residual_conv_weights), in sorted key order
+    rng = np.random.default_rng(913)
+    sd = m.state_dict()
+    big = sorted(k for k, v in sd.items() if v.dim() == 4 and v.shape[-1] == 3 and v.shape[1] > 1)
+    for k in big:
+        sd[k].copy_(torch.from_numpy((rng.standard_normal(tuple(sd[k].shape)) * 0.03).astype(np.float32)))
+    x, y, dates = synth(2, 3, 32, 32, 9)
+    out = {"x": x.numpy(), "y": y.numpy(), "dates": dates.numpy(), "regenerated": np.array(big), "regen_seed": np.array(913)}
+    for k, v in np_state(m.state_dict()).items():
+        if k not in big:
+            out["state/" + k] = v
+    m.eval()
+    with torch.no_grad():
+        oe = m(x, batch_positions=dates)
+    out["eval/out"] = oe.numpy()
+    m.train()
+    xg = x.clone().requires_grad_(True)
+    ot = m(xg, batch_positions=dates)
+    l, _ = crit("diag")(ot[:, :, :13], y, ot[:, :, 13:26])
+    l.backward()
+    out["train/out"] = ot.detach().numpy()
+    out["train/loss"] = np.array(l.item())
+    out["train/dx_b0t0"] = xg.grad[0, 0].numpy()
+    for k, v in m.named_parameters():
+        if k in big:       # big tensors: (sum, abs-sum, random projection) + one output-channel slice
+            out["gradsum/" + k] = checksum(v.grad.numpy())
+            out["gradslice/" + k] = v.grad[::16, ::16].numpy()
+        else:
+            out["grad/" + k] = v.grad.numpy()
+    for k, v in np_state(m.state_dict()).items():
+        if "running_" in k:
+            out["train/state/" + k] = v
+    np.savez_compressed(os.path.join(HERE, "g13_residual.npz"), **out)
+    print("g13_residual train loss", l.item(), "keys", len(out))
+
+
 def case_variants():
     """G2: secondary variants of the UNCRTAINTS class; weights come from g1_diag_t3."""
     base = np.load(os.path.join(HERE, "g1_diag_t3.npz"))
@@ -461,6 +514,8 @@ if __name__ == "__main__":
     case_metrics(); sys.exit(0)
   if "--only-usev" in sys.argv:
     case_usev(); sys.exit(0)
+  if "--only-residual" in sys.argv:
+    case_residual(); sys.exit(0)
   if "--only-trainseq" not in sys.argv:
     case_variants()
     case_mgnll()
@@ -468,6 +523,7 @@ if __name__ == "__main__":
     case_prepare()
     case_metrics()
     case_usev()
+    case_residual()
     case_posenc()
     case_ensemble()
   case_trainseq()

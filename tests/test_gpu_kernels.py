@@ -526,3 +526,115 @@ def test_img_metrics():
     avg = metrics.avg_img_metrics()
     avg.add(d); avg.add(d)
     assert abs(avg.value()["RMSE"] - d["RMSE"]) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------
+# dense 3x3 convolution (ResidualConvBlock, uncrtaints.py:24-69): nine accumulating GEMMs on the padded grid
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 128, 32, 32), (1, 128, 16, 64), (3, 128, 64, 48)])
+def test_conv3x3_fwd_bwd_linear_parts(E, N, C, H, W):
+    """The linear pieces (no ReLU kink): conv forward, and the three backward products given dc = C1*du + C2*c + C3."""
+    from uncrtaints_amd import hip_backend as hb
+    x = rand(N, C, H, W, seed=21, scale=1.0, shift=0.3)
+    w = rand(C, C, 3, 3, seed=22, scale=0.05)
+    b = rand(C, seed=23, scale=0.2)
+    du = rand(N, C, H, W, seed=24)
+    kk = [rand(N * C, seed=25 + i, scale=s, shift=sh) for i, (s, sh) in enumerate(((0.3, 1.0), (0.1, 0.0), (0.1, 0.0)))]
+    # truth in fp64
+    xo = x.double().requires_grad_(True)
+    wo = w.double().requires_grad_(True)
+    bo = b.double().requires_grad_(True)
+    co = F.conv2d(F.pad(xo, (1, 1, 1, 1), mode="reflect"), wo, bo)
+    dc = kk[0].double().view(N, C, 1, 1) * du.double() + kk[1].double().view(N, C, 1, 1) * co.detach() \
+        + kk[2].double().view(N, C, 1, 1)
+    co.backward(dc)
+    # HIP
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    xp = E._Padded(N, C, H, W, xd.device)
+    hb.call("uncr_pad2d", xd, None, xp.view(), None, None, None, E.PRO_NONE, 0, N * C, H, W, E._stream())
+    c, part = E.conv3x3_forward(xp, wd, bd, True)
+    close(f"conv3x3_fwd[{N},{C},{H}x{W}]", c, co.detach().float())
+    s = part.buf.double().sum(1).cpu()
+    ref = torch.stack([co.detach().sum((2, 3)).reshape(-1), (co.detach() ** 2).sum((2, 3)).reshape(-1)], 1)
+    close("conv3x3_stats", s.float(), ref.float(), tol=2e-5)
+    dx, dW, db = E.conv3x3_backward(dev(du), c, [dev(k) for k in kk], xp, wd, True)
+    close("conv3x3_dx", dx, xo.grad.float(), tol=2e-5)
+    close("conv3x3_dW", dW, wo.grad.float(), tol=2e-5)
+    close("conv3x3_db", db, bo.grad.float(), tol=2e-5)
+
+
+@pytest.mark.parametrize("norm,training", [("batch", True), ("group", True), ("batch", False)])
+def test_residual_block_fwd_bwd(E, orc, norm, training):
+    """One whole ResidualConvBlock against the fp64 oracle.  ReLU masks make the gradient discontinuous in the forward
+    values (one mask that flips under a 1e-6 forward difference moves a channel's d(beta) by ~1e-2 at this size), so the
+    input is the first seed for which the HIP path's three ReLU masks equal the fp64 path's -- the exact condition under
+    which the two gradients are comparable -- and then the comparison is tight."""
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    from uncrtaints_amd.src.learning.weight_init import weight_init
+    N, C, H, W = 1, 128, 16, 64
+    torch.manual_seed(31)
+    m = U.ResidualConvBlock([C, C], norm=norm)
+    m.apply(weight_init)
+    g = torch.Generator().manual_seed(32)
+    for mod in m.modules():
+        if isinstance(mod, (torch.nn.GroupNorm, torch.nn.BatchNorm2d)):
+            mod.weight.data.copy_(1 + 0.3 * torch.randn(mod.weight.shape, generator=g))
+            mod.bias.data.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=g))
+            mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g))
+        if isinstance(mod, torch.nn.Conv2d):
+            mod.weight.data.copy_(0.04 * torch.randn(mod.weight.shape, generator=g))
+    m.train(training)
+    sd = {("blk." + k): v.clone() for k, v in m.state_dict().items()}
+    gy = rand(N, C, H, W, seed=34)
+    pt = {k: ((v.clone().double().requires_grad_(True) if "running" not in k else v.clone().double())
+              if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    md = m.to(DEV)
+
+    def masks64(xin):
+        with torch.no_grad():
+            nrm = orc._NormCtx({k: v.detach().clone() for k, v in pt.items()}, norm, training, False)
+            h, out = xin, []
+            for i in (1, 2, 3):
+                z = nrm(orc.conv3x3_reflect(h, pt[f"blk.conv{i}.conv.0.weight"], pt[f"blk.conv{i}.conv.0.bias"]),
+                        f"blk.conv{i}.conv.1")
+                out.append(z > 0)
+                h = torch.relu(z)
+        return out
+
+    def masks_hip(xin):
+        p = {}
+        for i, (conv, nrm) in enumerate(md._layers(), 1):
+            p[f"w{i}"], p[f"b{i}"], p[f"g{i}"], p[f"be{i}"] = (t.detach() for t in (conv.weight, conv.bias, nrm.weight, nrm.bias))
+        with torch.no_grad():
+            _, sv = E.residual_forward(dev(xin), p, md._spec, training, None if training else md._buffers_dict())
+        return [((nf.A.view(N, C, 1, 1) * c + nf.B.view(N, C, 1, 1)) > 0).cpu() for c, nf in zip(sv["c"], sv["nf"])]
+    for seed in range(33, 73):
+        x = rand(N, C, H, W, seed=seed, scale=1.0, shift=0.2)
+        flips = sum(int((a != b).sum()) for a, b in zip(masks64(x.double()), masks_hip(x)))
+        print(f"[parity] residual_block input seed {seed}: {flips} of {3 * N * C * H * W} ReLU masks differ from fp64")
+        if flips == 0:
+            break
+    else:
+        raise AssertionError("no input in 40 seeds on which the HIP and fp64 ReLU masks agree")
+    xo = x.double().requires_grad_(True)
+    yo = orc.residual_block(xo, pt, "blk", norm, training)
+    yo.backward(gy.double())
+    xd = dev(x).requires_grad_(True)
+    yd = md(xd)
+    close(f"residual_fwd[{norm},train={training}]", yd, yo.detach().float())
+    yd.backward(dev(gy))
+    close("residual_dx", xd.grad, xo.grad.float(), tol=5e-5)
+    wmax = max(v.grad.abs().max().item() for k, v in pt.items() if getattr(v, "grad", None) is not None)
+    for k, v in md.named_parameters():
+        ref = pt["blk." + k].grad.float()
+        if ref.abs().max().item() < 1e-9 * wmax:      # conv bias in front of a batch-statistics norm: exactly zero
+            assert v.grad.abs().max().item() < 1e-4 * wmax, k
+            continue
+        close(f"residual_grad[{k}]", v.grad, ref, tol=1e-4)
+    if norm == "batch" and training:
+        for k, v in md.state_dict().items():
+            if "running" in k:
+                close(f"residual_buf[{k}]", v, pt["blk." + k].float())

@@ -17,7 +17,8 @@ enum : int {
     EW_RELU_BWD = 6,     // out = a * [A*b + B > 0];          stats (sum out, sum out*b)   a=d(a0), b=c0
     EW_SE_POOL = 7,      // stats only: (sum gelu(A*a + B), 0)
     EW_HEAD_FWD = 8,     // out = c < n_mean ? scale*sigmoid(a) : softplus(a)+eps   (per-plane channel test)
-    EW_HEAD_BWD = 9      // out = a * f'(b)   a = d(out), b = pre-activation
+    EW_HEAD_BWD = 9,     // out = a * f'(b)   a = d(out), b = pre-activation
+    EW_RESIDUAL_RELU = 10   // out = a + relu(A*b + B)   (ResidualConvBlock skip, uncrtaints.py:67)
 };
 
 struct EwArgs {
@@ -71,6 +72,12 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
             o[i] = pa[i] + fmaf(A, pb[i], B);
             s0 += o[i]; s1 += o[i] * o[i];
         }
+    } else if constexpr (OP == EW_RESIDUAL_RELU) {
+        const float A = g.k0[plane], B = g.k1[plane];
+        const float4 vb = *(const float4*)(g.b + off);
+        const float* pb = (const float*)&vb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = pa[i] + fmaxf(fmaf(A, pb[i], B), 0.f);
     } else if constexpr (OP == EW_PASSB) {
         const float A = g.k0[plane], B = g.k1[plane], S = g.k2[plane], D = g.k3[plane];
         const float4 vb = *(const float4*)(g.b + off);
@@ -173,6 +180,7 @@ extern "C" int uncr_ew(int op, const float* a, const float* b, const float* c, c
         EW_CASE(EW_SE_POOL)
         EW_CASE(EW_HEAD_FWD)
         EW_CASE(EW_HEAD_BWD)
+        EW_CASE(EW_RESIDUAL_RELU)
         default:
             return UNCR_EINVAL;
     }

@@ -483,10 +483,11 @@ extern "C" int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, 
     if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
     if (!in || !Wt || !out) return UNCR_EINVAL;
     if (pro == PRO_NORMBWD && !in2) return UNCR_EINVAL;
-    if (epi && !part) return UNCR_EINVAL;
+    if (epi < 0 || epi > 4) return UNCR_EINVAL;
+    if (epi && epi != 4 && !part) return UNCR_EINVAL;
     if ((epi == 2 || epi == 3) && !aux) return UNCR_EINVAL;
     if (epi == 3 && (!e0 || !e1 || !e2 || !e3)) return UNCR_EINVAL;
-    if (epi < 0 || epi > 3) return UNCR_EINVAL;
+    if (epi == 4 && !use_split(Cout)) return UNCR_EINVAL;     // accumulate mode exists in the split kernels only
     const int tp = uncr_pw_tile_px(Cout);
     if (P % tp) return UNCR_ESHAPE;
     PwArgs g{in, in2, Wt, out, k0, k1, k2, bias, aux, e0, e1, e2, e3, (float2*)part, bias_stride_n, Cin, Cout, P, pro, epi};

@@ -272,7 +272,16 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
             for (int rb = 0; rb < 16; rb += 8) {
-                float4 xa[(EPI == 2 || EPI == 3) ? 8 : 1];   // one request batch = 8 rows
+                float4 xa[(EPI == 2 || EPI == 3 || EPI == 4) ? 8 : 1];   // one request batch = 8 rows
+                if constexpr (EPI == 4) {      // accumulate: out += result (dense 3x3 as nine shifted 1x1 GEMMs)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int rw = row_of(ct, rb + q);
+                        const int rc = rw + 4 < Cout ? rw : (Cout > 8 ? Cout - 8 : 0);
+                        xa[q] = *(const float4*)(g.out + (size_t)(nco + rc) * P + loff);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr (EPI == 2 || EPI == 3) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -307,9 +316,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                     } else if constexpr (EPI == 1) {
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                    } else if constexpr (EPI == 4) {
+                        v.x += xa[q].x; v.y += xa[q].y; v.z += xa[q].z; v.w += xa[q].w;
                     }
                     acc[0][ct][r] = v.x; acc[1][ct][r] = v.y; acc[2][ct][r] = v.z; acc[3][ct][r] = v.w;
-                    if constexpr (EPI != 0) {
+                    if constexpr (EPI != 0 && EPI != 4) {
                         s0 = half_wave_sum_dpp(s0);
                         s1 = half_wave_sum_dpp(s1);
                         if (j == 31) { red[col][0] += s0; red[col][1] += s1; }   // this lane owns column col in the block
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         tepi += __builtin_readcyclecounter() - te0;
 #endif
     }
-    if constexpr (EPI != 0) {
+    if constexpr (EPI != 0 && EPI != 4) {
         // one statistics slot per block (its tiles were summed in a fixed order): G slots per frame instead of P/128
         __syncthreads();
         for (int c = tid; c < COUTP; c += NT)
@@ -471,6 +482,7 @@ int PWS_CAT(pw_split_launch_p, PWS_PRO)(const PwArgs& g, int N, int cp, hipStrea
         case 1: pws_launch_epi<1>(g, grid, cp, stream); break;
         case 2: pws_launch_epi<2>(g, grid, cp, stream); break;
         case 3: pws_launch_epi<3>(g, grid, cp, stream); break;
+        case 4: pws_launch_epi<4>(g, grid, cp, stream); break;
         default: return UNCR_EINVAL;
     }
     UNCR_LAUNCH_CHECK();

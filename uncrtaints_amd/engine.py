@@ -197,7 +197,7 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
     if out is None:
         out = _f32((N, Cout, P), x.device)
     part = None
-    if epi:
+    if epi and epi != 4:          # epi 4 = accumulate into `out`, no statistics
         slots = hb.query("uncr_pw_stat_slots", N, Cout, P)
         if slots <= 0:
             raise RuntimeError(f"pw_gemm: P={P} is not a multiple of the {hb.query('uncr_pw_tile_px', Cout)}-pixel tile")
@@ -356,6 +356,121 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         _, dx_part = ew(EW_PASSE, dy, b=da, c=x, aux=x_h3, out=dx, k=(b0.c1, b0.c2, b0.c3, None),
                         want_part=x_h3 is not None, planes=N * C, P=P)
     return dx, g, dx_part
+
+
+# ------------------------------------------------------------------------------------------------
+# ResidualConvBlock (uncrtaints.py:24-69): x + CL3(CL2(CL1(x))), CL = dense conv3x3 (reflect, bias) -> norm -> ReLU.
+# The dense 3x3 convolution runs as nine accumulating pointwise GEMMs on the padded grid (csrc/conv3.hip).
+# ------------------------------------------------------------------------------------------------
+EW_RESIDUAL_RELU = 10
+RES_KEYS = tuple(f"{n}{i}" for i in (1, 2, 3) for n in ("w", "b", "g", "be"))     # conv weight, bias, norm weight, bias
+
+
+class _Padded:
+    """[planes][S_p] padded planes inside a flat buffer with `margin` zero floats of slack on both sides, so that a
+    tap's shifted view (flat[margin + off : ...]) stays inside the allocation."""
+
+    def __init__(self, N: int, C: int, H: int, W: int, dev):
+        self.N, self.C, self.H, self.W = N, C, H, W
+        self.Sp = hb.query("uncr_conv3_plane_stride", H, W)
+        self.margin = hb.query("uncr_conv3_margin", W)
+        self.n = N * C * self.Sp
+        self.flat = torch.zeros(self.n + 2 * self.margin, device=dev, dtype=torch.float32)
+
+    def view(self, off: int = 0) -> Tensor:
+        return self.flat[self.margin + off: self.margin + off + self.n]
+
+
+def _taps(W: int):
+    return [(ky, kx, (ky - 1) * (W + 2) + (kx - 1)) for ky in range(3) for kx in range(3)]
+
+
+def conv3x3_forward(xp: _Padded, w: Tensor, b: Tensor, want_stats: bool):
+    """xp: reflect-padded input planes.  -> raw conv output c [N,Co,H,W], statistics partials of c."""
+    N, Ci, H, W = xp.N, xp.C, xp.H, xp.W
+    Co = w.shape[0]
+    wt = w.permute(2, 3, 0, 1).contiguous()            # [3,3,Co,Ci]: one contiguous matrix per tap (layout copy)
+    outp = _Padded(N, Co, H, W, w.device)
+    for i, (ky, kx, off) in enumerate(_taps(W)):
+        pw_gemm(xp.view(off), pack_wt(wt[ky, kx], transpose=True), N, Ci, Co, xp.Sp, bias=b.contiguous() if i == 0 else None,
+                epi=0 if i == 0 else 4, out=outp.view().view(N, Co, xp.Sp))
+    c = _f32((N, Co, H, W), w.device)
+    part = None
+    if want_stats:
+        slots = hb.query("uncr_ew_slots", H * W)
+        part = Part(_f32((N * Co, slots, 2), w.device), slots)
+    hb.call("uncr_unpad2d", outp.view(), c, part.buf if part else None, N * Co, H, W, _stream())
+    return c, part
+
+
+def conv3x3_backward(du: Tensor, c: Tensor, kk, xp: _Padded, w: Tensor, need_dx: bool):
+    """du: gradient after the ReLU mask; kk: norm-backward coefficients (dc = C1*du + C2*c + C3).
+    -> (gradient wrt the un-padded conv input or None, dW [Co,Ci,3,3], db [Co])"""
+    N, Ci, H, W = xp.N, xp.C, xp.H, xp.W
+    Co = w.shape[0]
+    dev = w.device
+    dcp = _Padded(N, Co, H, W, dev)
+    hb.call("uncr_pad2d", du.contiguous(), c, dcp.view(), kk[0], kk[1], kk[2], PRO_NORMBWD, 1, N * Co, H, W, _stream())
+    dWt = []
+    db = None
+    for i, (ky, kx, off) in enumerate(_taps(W)):
+        dW_t, rs = pw_wgrad(dcp.view().view(N, Co, xp.Sp), xp.view(off).view(N, Ci, xp.Sp), N, Co, Ci, xp.Sp, rowsum=(i == 0))
+        dWt.append(dW_t)
+        if i == 0:
+            db = rs
+    dW = torch.stack(dWt, dim=0).view(3, 3, Co, Ci).permute(2, 3, 0, 1).contiguous()
+    dx = None
+    if need_dx:
+        wt = w.permute(2, 3, 0, 1).contiguous()
+        dxp = _Padded(N, Ci, H, W, dev)
+        for i, (ky, kx, off) in enumerate(_taps(W)):
+            pw_gemm(dcp.view(-off), pack_wt(wt[ky, kx], transpose=False), N, Co, Ci, xp.Sp, epi=0 if i == 0 else 4,
+                    out=dxp.view().view(N, Ci, xp.Sp))
+        dx = _f32((N, Ci, H, W), dev)
+        hb.call("uncr_unpad2d_reflect_adjoint", dxp.view(), dx, N * Ci, H, W, _stream())
+    return dx, dW, db
+
+
+def residual_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bool, buffers=None):
+    """ResidualConvBlock.forward.  p: RES_KEYS; buffers: {rm1, rv1, ...} BatchNorm running statistics."""
+    N, C, H, W = _check4(x)
+    P = H * W
+    dev = x.device
+    sv = dict(x=x, xp=[], c=[], nf=[], dims=(N, C, H, W))
+    src, pro, k = x, PRO_NONE, (None, None)
+    for i in (1, 2, 3):
+        xp = _Padded(N, C, H, W, dev)
+        hb.call("uncr_pad2d", src, None, xp.view(), k[0], k[1], None, pro, 0, N * C, H, W, _stream())
+        c, part = conv3x3_forward(xp, p[f"w{i}"], p[f"b{i}"], spec.needs_stats(training))
+        rm = buffers.get(f"rm{i}") if buffers else None
+        rv = buffers.get(f"rv{i}") if buffers else None
+        nf = norm_fwd(part, N, C, P, spec, training, p[f"g{i}"], p[f"be{i}"], rm, rv)
+        sv["xp"].append(xp); sv["c"].append(c); sv["nf"].append(nf)
+        src, pro, k = c, PRO_AFFINE_RELU, (nf.A, nf.B)
+    y = _f32((N, C, H, W), dev)
+    ew(EW_RESIDUAL_RELU, x, b=src, out=y, k=(k[0], k[1], None, None), planes=N * C, P=P)
+    return y, sv
+
+
+def residual_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = True):
+    N, C, H, W = sv["dims"]
+    P = H * W
+    dev = dy.device
+    g: Dict[str, Tensor] = {}
+    da = dy.contiguous()
+    for i in (3, 2, 1):
+        c, nf, xp = sv["c"][i - 1], sv["nf"][i - 1], sv["xp"][i - 1]
+        du = _f32((N, C, H, W), dev)
+        _, part = ew(EW_RELU_BWD, da, b=c, out=du, k=(nf.A, nf.B, None, None), want_part=True, planes=N * C, P=P)
+        nb = norm_bwd(part, N, C, P, nf, p[f"g{i}"])
+        g[f"g{i}"], g[f"be{i}"] = nb.dgamma, nb.dbeta
+        da, g[f"w{i}"], g[f"b{i}"] = conv3x3_backward(du, c, (nb.c1, nb.c2, nb.c3), xp, p[f"w{i}"],
+                                                      need_dx or i > 1)
+    dx = None
+    if need_dx:
+        dx = _f32((N, C, H, W), dev)
+        hb.call("uncr_add", dy.contiguous(), da, dx, dx.numel(), _stream())
+    return dx, g
 
 
 # ------------------------------------------------------------------------------------------------

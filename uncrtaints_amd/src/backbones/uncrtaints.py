@@ -7,10 +7,9 @@ loads reference checkpoints.  Modules hold parameters in stock `nn.*` layers (we
 dispatch on those types); `forward` routes through autograd Functions over `uncrtaints_amd.engine`.
 There is no PyTorch-op fallback: on a machine without the HIP library or a GPU tensor, forward raises.
 
-Built: block_type='mbconv', agg_mode in {att_group, att_mean, mean}, encoder_norm/decoder_norm in {group, batch},
+Built: block_type in {mbconv, residual}, agg_mode in {att_group, att_mean, mean}, encoder_norm/decoder_norm in {group, batch},
 use_v in {False, True}, separate_out, is_mono, out_nonlin_var='softplus', covmode in {diag, iso, uni, None}.
-Not built (raise NotImplementedError): block_type='residual' (dense 3x3 convolutions), instance norm
-(SURVEY 8(a17) / 8(f))."""
+Not built (raise NotImplementedError): instance norm."""
 import torch
 import torch.nn as nn
 
@@ -133,6 +132,57 @@ class MBConv(TemporallySharedBlock):
             for m in self._norms():
                 if isinstance(m, nn.BatchNorm2d):
                     m.num_batches_tracked += 1
+        return y
+
+
+class _ResidualFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, *params):
+        p = dict(zip(E.RES_KEYS, params))
+        y, sv = E.residual_forward(x.contiguous(), p, module._spec, module.training, module._buffers_dict())
+        ctx.sv, ctx.p = sv, p
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, g = E.residual_backward(dy, ctx.sv, ctx.p, ctx.needs_input_grad[0])
+        return (dx, None) + tuple(g[k] for k in E.RES_KEYS)
+
+
+class ResidualConvBlock(TemporallySharedBlock):
+    """uncrtaints.py:24-69: x + CL3(CL2(CL1(x))), every ConvLayer = dense conv3x3 (reflect, bias) -> norm -> ReLU.
+    Parameter holder with the reference's attribute paths (conv{1,2,3}.conv.{0,1}); compute in engine.residual_*."""
+
+    def __init__(self, nkernels, pad_value=None, norm="batch", n_groups=4, k=3, s=1, p=1, padding_mode="reflect"):
+        super().__init__(pad_value=pad_value)
+        if (k, s, p) != (3, 1, 1) or padding_mode != "reflect" or len(nkernels) != 2 or nkernels[0] != nkernels[1]:
+            raise NotImplementedError("ResidualConvBlock is built for 3x3 / stride 1 / reflect, equal widths")
+        if norm not in ("batch", "group"):
+            raise NotImplementedError(f"ResidualConvBlock norm '{norm}'")
+        mk = lambda: ConvLayer(nkernels=nkernels, norm=norm, last_relu=True, k=k, s=s, p=p, n_groups=n_groups,
+                               padding_mode=padding_mode)
+        self.conv1, self.conv2, self.conv3 = mk(), mk(), mk()
+        self._spec = E.NormSpec(norm, n_groups)
+
+    def _layers(self):
+        return [(c.conv[0], c.conv[1]) for c in (self.conv1, self.conv2, self.conv3)]
+
+    def _buffers_dict(self):
+        out = {}
+        for i, (_, n) in enumerate(self._layers(), 1):
+            if isinstance(n, nn.BatchNorm2d):
+                out[f"rm{i}"], out[f"rv{i}"] = n.running_mean, n.running_var
+        return out
+
+    def forward(self, x):
+        params = []
+        for conv, nrm in self._layers():
+            params += [conv.weight, conv.bias, nrm.weight, nrm.bias]
+        y = _ResidualFn.apply(x, self, *params)
+        if self.training:
+            for _, n in self._layers():
+                if isinstance(n, nn.BatchNorm2d):
+                    n.num_batches_tracked += 1
         return y
 
 
@@ -311,8 +361,8 @@ class UNCRTAINTS(nn.Module):
             assert encoder_widths[-1] == decoder_widths[-1]
         else:
             decoder_widths = encoder_widths
-        if block_type != 'mbconv':
-            raise NotImplementedError("block_type='residual' is not built (SURVEY 8(f) rank 2)")
+        if block_type not in ('mbconv', 'residual'):
+            raise NotImplementedError(block_type)
         if use_v and (agg_mode != "att_group" or is_mono):
             raise NotImplementedError("use_v is built for agg_mode='att_group' on image time series")
         if agg_mode not in ("att_group", "att_mean", "mean"):
@@ -323,8 +373,12 @@ class UNCRTAINTS(nn.Module):
             raise NotImplementedError("UNCRTAINTS uses a single encoder stage (encoder_widths=[C])")
 
         self.in_conv = ConvBlock(nkernels=[input_dim] + [encoder_widths[0]], k=1, s=1, p=0, norm=encoder_norm)
-        self.in_block = nn.ModuleList([MBConv(layer, layer, downsample=False, expansion=2, norm=encoder_norm)
-                                       for layer in encoder_widths])
+        if block_type == 'residual':      # uncrtaints.py:318-319
+            self.in_block = nn.ModuleList([ResidualConvBlock(nkernels=[layer] + [layer], k=3, s=1, p=1,
+                                                             norm=encoder_norm, n_groups=4) for layer in encoder_widths])
+        else:
+            self.in_block = nn.ModuleList([MBConv(layer, layer, downsample=False, expansion=2, norm=encoder_norm)
+                                           for layer in encoder_widths])
         if not self.is_mono:     # uncrtaints.py:322-348
             if use_v:            # uncrtaints.py:324-338
                 self.temporal_encoder = LTAE2d(in_channels=encoder_widths[0], d_model=d_model, n_head=n_head,
@@ -335,8 +389,12 @@ class UNCRTAINTS(nn.Module):
                 self.temporal_encoder = LTAE2dtiny(in_channels=encoder_widths[0], d_model=d_model, n_head=n_head,
                                                    d_k=d_k, positional_encoding=positional_encoding)
             self.temporal_aggregator = Compact_Temporal_Aggregator(mode=agg_mode)
-        self.out_block = nn.ModuleList([MBConv(layer, layer, downsample=False, expansion=2, norm=decoder_norm)
-                                        for layer in decoder_widths])
+        if block_type == 'residual':      # uncrtaints.py:352-353
+            self.out_block = nn.ModuleList([ResidualConvBlock(nkernels=[layer] + [layer], k=3, s=1, p=1,
+                                                              norm=decoder_norm, n_groups=4) for layer in decoder_widths])
+        else:
+            self.out_block = nn.ModuleList([MBConv(layer, layer, downsample=False, expansion=2, norm=decoder_norm)
+                                            for layer in decoder_widths])
 
         self.covmode = covmode
         if covmode == 'uni':
