@@ -20,6 +20,7 @@ import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -639,3 +640,37 @@ def img_metrics(target: Tensor, pred: Tensor, var: Optional[Tensor] = None, pixe
             pw = lambda x: x.nanmean(0).nanmean(0).flatten().numpy()
             out.update({"pixelwise error": pw(e), "pixelwise ae": pw(ae), "pixelwise se": pw(se), "pixelwise var": pw(var)})
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# calibration of the predicted variance (evaluation loop, after the path)
+# ------------------------------------------------------------------------------------------------
+
+def compute_ece(variances, errors, n_samples: int, percent: int = 5) -> np.ndarray:
+    """model/train_reconstruct.py:475-487: rank the per-sample errors by ascending per-sample uncertainty; entry i is
+    the nan-mean error of the most certain (i+1)*percent % samples."""
+    order = torch.sort(torch.tensor(variances, dtype=torch.float32))[1]
+    e = torch.tensor(errors, dtype=torch.float32)[order]
+    ends = torch.linspace(0, n_samples, 100 // percent + 1, dtype=int)[1:]
+    return np.array([torch.nanmean(e[:int(r)]).item() for r in ends], dtype=np.float32)
+
+
+def compute_uce_auce(variances, errors, n_samples: int, percent: int = 5, l2: bool = True):
+    """model/train_reconstruct.py:492-530 (numerical part): equal-width variance bins between min and max variance;
+    per bin |metric(error) - metric(sqrt(var))| with metric = root-mean-square (l2) or mean-abs (l1); UCE is weighted
+    by the bin population / n_samples, AUCE is the nan-mean over bins."""
+    n_bins = 100 // percent
+    v = torch.tensor(variances, dtype=torch.float32)
+    e = torch.tensor(errors, dtype=torch.float32)
+    edges = np.linspace(v.min().item(), v.max().item(), num=n_bins)[1:]
+    which = torch.from_numpy(np.digitize(v.numpy(), bins=edges))
+    calib = torch.full((n_bins,), float("nan"))
+    for b in range(n_bins):
+        sel = which == b
+        if l2:
+            bv, be = v[sel].sqrt().square().mean().sqrt(), e[sel].square().mean().sqrt()
+        else:
+            bv, be = v[sel].sqrt().abs().mean(), e[sel].abs().mean()
+        calib[b] = (be - bv).abs()
+    weight = torch.histogram(which.float(), n_bins)[0] / n_samples
+    return torch.nansum(weight * calib).item(), torch.nanmean(calib).item()

@@ -291,6 +291,38 @@ def case_metrics():
     print("g11_metrics", idx, "cases", {k: float(v) for k, v in d.items() if np.ndim(v) == 0})
 
 
+def case_calibration():
+    """G14: compute_ece / compute_uce_auce (model/train_reconstruct.py:475-530): calibration of the predicted variance from
+    per-sample (variance, error) lists.  The plotting side of compute_uce_auce goes to stubs; the lambda `binarize`
+    (train_reconstruct.py:490) is re-stated here because it is an assignment, not a function definition."""
+    import types
+
+    class _Anything:                       # absorbs plt.* / writer.* / fig.* / ax.* calls
+        def __getattr__(self, k): return self
+        def __call__(self, *a, **k): return self
+        def __iter__(self): return iter((self, self))
+    binarize = lambda arg, n_bins, floor=0, ceil=1: np.digitize(arg, bins=np.linspace(floor, ceil, num=n_bins)[1:])
+    ns = _reference_functions(os.path.join(REF, "model", "train_reconstruct.py"), ["compute_ece", "compute_uce_auce"],
+                              {"torch": torch, "np": np, "plt": _Anything(), "writer": _Anything(), "binarize": binarize})
+    out = {}
+    rng = np.random.default_rng(14)
+    idx = 0
+    for n, nan in ((40, False), (137, True), (1000, False)):
+        var = (rng.gamma(2.0, 0.01, n)).astype(np.float64)
+        err = np.abs(rng.standard_normal(n)) * np.sqrt(var) * rng.uniform(0.5, 1.5)
+        if nan:
+            err[[3, 50]] = np.nan
+        for l2 in (True, False):
+            uce, auce = ns["compute_uce_auce"](list(var), list(err), n, percent=5, l2=l2, mode="test", step=0)
+            out[f"k{idx}/uce_{'l2' if l2 else 'l1'}"] = np.array([uce.item(), auce.item()])
+        out[f"k{idx}/ece"] = ns["compute_ece"](list(var), list(err ** 2), n, percent=5)
+        out[f"k{idx}/var"], out[f"k{idx}/err"] = var, err
+        idx += 1
+    out["n"] = np.array(idx)
+    np.savez_compressed(os.path.join(HERE, "g14_calibration.npz"), **out)
+    print("g14_calibration", {k: v for k, v in out.items() if "uce" in k})
+
+
 def case_posenc():
     pe = PositionalEncoder(256 // 16, T=1000, repeat=16)
     dates = torch.tensor([[1400., 1433., 1799.], [0., 1., 1000.]])
@@ -512,6 +544,8 @@ if __name__ == "__main__":
     case_prepare(); sys.exit(0)
   if "--only-metrics" in sys.argv:
     case_metrics(); sys.exit(0)
+  if "--only-calibration" in sys.argv:
+    case_calibration(); sys.exit(0)
   if "--only-usev" in sys.argv:
     case_usev(); sys.exit(0)
   if "--only-residual" in sys.argv:
@@ -522,6 +556,7 @@ if __name__ == "__main__":
     case_eltlosses()
     case_prepare()
     case_metrics()
+    case_calibration()
     case_usev()
     case_residual()
     case_posenc()

@@ -181,3 +181,30 @@ def test_img_metrics_match_reference():
             ref = g[f"k{i}/m/{k}"]
             assert np.allclose(np.asarray(v), ref, rtol=2e-5, atol=1e-6, equal_nan=True), k
         assert np.allclose(orc.ssim(targ, pred, size_average=False).numpy(), g[f"k{i}/ssim_items"], rtol=2e-5)
+
+
+def test_calibration_metrics_match_reference():
+    """compute_ece / compute_uce_auce: the oracle restatement AND the package's vectorised host implementation
+    (uncrtaints_amd/src/learning/calibration.py) vs the reference functions' outputs (g14, incl. NaN errors)."""
+    from uncrtaints_amd.src.learning import calibration as cal
+    g = load_golden("g14_calibration")
+    for i in range(int(g["n"])):
+        var, err = g[f"k{i}/var"], g[f"k{i}/err"]
+        n = len(var)
+        for impl in (orc, cal):
+            for l2 in (True, False):
+                uce, auce = impl.compute_uce_auce(list(var), list(err), n, percent=5, l2=l2)
+                ref = g[f"k{i}/uce_{'l2' if l2 else 'l1'}"]
+                assert np.allclose([uce, auce], ref, rtol=2e-5, atol=1e-8), (impl.__name__, i, l2, uce, auce, ref)
+            ece = impl.compute_ece(list(var), list(err ** 2), n, percent=5)
+            assert np.allclose(ece, g[f"k{i}/ece"], rtol=2e-5, atol=1e-9, equal_nan=True), (impl.__name__, i)
+
+
+def test_calibration_bin_ends_follow_torch_integer_linspace():
+    from uncrtaints_amd.src.learning import calibration as cal
+    rng = np.random.default_rng(0)
+    for n in list(range(1, 400)) + [999, 1000, 1001, 4099, 65537]:
+        var, err = rng.random(n) + 0.01, rng.random(n)
+        got = cal.compute_ece(list(var), list(err), n)
+        ref = orc.compute_ece(list(var), list(err), n)
+        assert np.allclose(got, ref, rtol=2e-5, atol=1e-9, equal_nan=True), n
