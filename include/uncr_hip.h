@@ -99,6 +99,22 @@ int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, float* out,
                  const float* k1, const float* k2, const float* bias, int bias_stride_n, const float* aux,
                  const float* e0, const float* e1, const float* e2, const float* e3 /* epi 3 coefficients */,
                  float* part, int N, int Cin, int Cout, int P, int pro, int epi, hipStream_t stream);
+/* Backward of MBConv's pw1 (uncrtaints.py:100-146: x + block(PreNorm(x))) with the PreNorm backward and the skip
+ * connection in the GEMM epilogue: out = dy + c1*(W^T . normbwd(in, in2; k0..k2)) + c2*x + c3; if xh3 (the h3 of the
+ * block that produced x) is given, part receives (sum out, sum out*xh3) for that block's last norm backward.
+ * c1..c3 come from uncr_norm_finalize_bwd on the sums uncr_prenorm_bwd_finish derives without a pass over da. */
+int uncr_pw_gemm_dx_supported(int Cin, int Cout);
+int uncr_pw_gemm_dx(const float* in, const float* in2, const float* Wt, float* out, const float* k0, const float* k1,
+                    const float* k2, const float* dy, const float* x, const float* xh3, const float* c1,
+                    const float* c2, const float* c3, float* part, int N, int Cin, int Cout, int P,
+                    hipStream_t stream);
+/* R [N][Ch][C] = per-frame products sum_p du1n*x (uncr_pw_wgrad with the raw x); part_b / part_f = the (sum du1, .) and
+ * (sum h1, .) partials [N*Ch][NPB|NPF][2] (part_f may be null: no c2 term); c1..c3 [N*Ch] = norm-1 backward
+ * coefficients; A0, B0 [N*C] = PreNorm forward coefficients.  -> part0 [N*C][1][2] = (sum da, sum da*x), dW1 [Ch][C]. */
+int uncr_prenorm_bwd_finish(const float* R, const float* W1, const float* part_b, int NPB, const float* part_f,
+                            int NPF, const float* c1, const float* c2, const float* c3, const float* A0,
+                            const float* B0, float* part0, float* dW1, float* scratch /* 2*N*Ch floats */, int N,
+                            int Ch /* % 8 == 0 */, int C /* % 32 == 0 */, int P, hipStream_t stream);
 int uncr_wgrad_shape(int Cd, int Cx, int* cop, int* cip);
 int uncr_pw_wgrad(const float* d, const float* d2, const float* x, const float* x2, const float* dk0,
                   const float* dk1, const float* dk2, const float* xk0, const float* xk1, const float* xk2,

@@ -200,9 +200,14 @@ def _mb_module(norm, seed):
     return m
 
 
-@pytest.mark.parametrize("norm,training", [("group", True), ("batch", True), ("batch", False)])
-def test_mbconv_fwd_bwd(orc, norm, training):
+@pytest.mark.parametrize("norm,training,fused_dx", [("group", True, True), ("batch", True, True), ("batch", False, True),
+                                                    ("group", True, False), ("batch", True, False)])
+def test_mbconv_fwd_bwd(orc, norm, training, fused_dx, monkeypatch):
+    """fused_dx: pw1's backward with the PreNorm backward + skip in the GEMM epilogue and the statistics derived from the
+    weight-gradient products (engine.mbconv_backward) vs the plain sequence (GEMM, statistics pass, element-wise pass)."""
     from conftest import compare_param_grads  # noqa: F401
+    from uncrtaints_amd import engine
+    monkeypatch.setattr(engine, "_FUSED_DX", fused_dx)
     N, H, W = 3, 64, 64
     m = _mb_module(norm, 3)
     m.train(training)

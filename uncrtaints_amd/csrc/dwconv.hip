@@ -241,15 +241,35 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
 }
 
 // dWdw[c][tap] = sum over frames n and row tiles of dw_part[(n*C+c)][tile][tap]   (fp64, fixed order)
-__global__ void dw_wgrad_reduce_kernel(const float* __restrict__ dw_part, int N, int C, int NPT,
-                                       float* __restrict__ dw) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= C * 9) return;
-    const int c = idx / 9, tap = idx % 9;
-    double s = 0.0;
-    for (int n = 0; n < N; ++n)
-        for (int j = 0; j < NPT; ++j) s += (double)dw_part[(((size_t)n * C + c) * NPT + j) * 9 + tap];
-    dw[idx] = (float)s;
+// grid = C, block = one wave: lanes = (slice, tap).  Latency-bound, so the N*NPT
+// partials of a (channel, tap) are split over 7 lanes and read 4 at a time; fixed combination order.
+__global__ __launch_bounds__(64) void dw_wgrad_reduce_kernel(const float* __restrict__ dw_part, int N, int C, int NPT,
+                                                             float* __restrict__ dw) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int tap = lane % 9, sl = lane / 9;           // 7 slices x 9 taps = 63 lanes
+    __shared__ double comb[7][9];
+    if (lane < 63) {
+        const int cnt = N * NPT;
+        const int i1 = (cnt * (sl + 1)) / 7;
+        int i = (cnt * sl) / 7;
+        double s = 0.0;
+        auto at = [&](int q) {
+            const int n = q / NPT, j = q - n * NPT;
+            return dw_part[(((size_t)n * C + c) * NPT + j) * 9 + tap];
+        };
+        for (; i + 4 <= i1; i += 4) {
+            const float v0 = at(i), v1 = at(i + 1), v2 = at(i + 2), v3 = at(i + 3);
+            s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+        }
+        for (; i < i1; ++i) s += (double)at(i);
+        comb[sl][tap] = s;
+    }
+    __syncthreads();
+    if (lane < 9) {
+        double s = 0.0;
+        for (int q = 0; q < 7; ++q) s += comb[q][lane];
+        dw[c * 9 + lane] = (float)s;
+    }
 }
 
 extern "C" int uncr_dw_slots_fwd(int H) { return (H + DW_TR_FWD - 1) / DW_TR_FWD; }
@@ -303,8 +323,7 @@ extern "C" int uncr_dw_bwd(const float* du2, const float* h2, const float* h1, c
 }
 
 extern "C" int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw, hipStream_t stream) {
-    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, stream, dw_part, N, C, NPT,
-                       dw);
+    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(C), dim3(64), 0, stream, dw_part, N, C, NPT, dw);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -225,6 +225,92 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// PreNorm backward statistics and the pw1 weight gradient from per-frame raw products (MBConv backward).
+//   R[n][k][c] = sum_p du1n[n,k,p] * x[n,c,p]        (weight-gradient GEMM with the UN-normalised block input x)
+// da = W1^T du1n is linear in du1n, so the sums its norm backward needs take no pass over da:
+//   sum_p da[n,c,p]          = sum_k W1[k,c] * S[n,k],        S[n,k] = sum_p du1n[n,k,p]
+//   sum_p da[n,c,p]*x[n,c,p] = sum_k W1[k,c] * R[n,k,c]
+// and, with pw1's input a = A0*x + B0,   dW1[k,c] = sum_n A0[n,c]*R[n,k,c] + B0[n,c]*S[n,k].
+// S needs no pass either: du1n = c1*du1 + c2*h1 + c3  =>  S = c1*sum du1 + c2*sum h1 + c3*P, from the partial sums the
+// depthwise backward (part_b) and the forward pw1 GEMM (part_f) wrote.  fp64, fixed order.
+// Two launches: S (one wave per (n,k) plane), then N*C/32 statistics blocks + Ch*C/256 weight-gradient blocks.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prenorm_bwd_S_kernel(const float2* __restrict__ part_b, int NPB,
+                                                            const float2* __restrict__ part_f, int NPF,
+                                                            const float* __restrict__ c1, const float* __restrict__ c2,
+                                                            const float* __restrict__ c3, int planes, int P,
+                                                            double* __restrict__ S) {
+    const int lane = threadIdx.x & 63;
+    const int pl = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pl >= planes) return;
+    double sb = 0.0, sf = 0.0;
+    for (int j = lane; j < NPB; j += 64) sb += (double)part_b[(size_t)pl * NPB + j].x;
+    if (part_f)
+        for (int j = lane; j < NPF; j += 64) sf += (double)part_f[(size_t)pl * NPF + j].x;
+    sb = wave_sum_d(sb);
+    sf = wave_sum_d(sf);
+    if (lane == 0) S[pl] = (double)c1[pl] * sb + (double)c2[pl] * sf + (double)c3[pl] * (double)P;
+}
+
+__global__ __launch_bounds__(256) void prenorm_bwd_finish_kernel(
+    const float* __restrict__ R, const float* __restrict__ W1, const double* __restrict__ S,
+    const float* __restrict__ A0, const float* __restrict__ B0, float2* __restrict__ part0, float* __restrict__ dW1,
+    int N, int Ch, int C) {
+    const int tid = threadIdx.x;
+    const int nstat = N * (C / 32);
+    if ((int)blockIdx.x < nstat) {
+        // 32 channels x 8 slices of the k range; slices are combined in a fixed order
+        __shared__ double comb[2][256];
+        const int n = blockIdx.x / (C / 32), c = (blockIdx.x % (C / 32)) * 32 + (tid & 31), sl = tid >> 5;
+        const int k0 = (Ch * sl) / 8, k1 = (Ch * (sl + 1)) / 8;
+        const float* r = R + (size_t)n * Ch * C + c;
+        const double* s = S + (size_t)n * Ch;
+        double s1 = 0.0, s2 = 0.0;
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            float w[8], rv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { w[q] = W1[(size_t)(k + q) * C + c]; rv[q] = r[(size_t)(k + q) * C]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { s1 += (double)w[q] * s[k + q]; s2 += (double)w[q] * (double)rv[q]; }
+        }
+        for (; k < k1; ++k) { const double w = W1[(size_t)k * C + c]; s1 += w * s[k]; s2 += w * (double)r[(size_t)k * C]; }
+        comb[0][tid] = s1; comb[1][tid] = s2;
+        __syncthreads();
+        if (tid < 32) {
+            double a = 0.0, b = 0.0;
+            for (int q = 0; q < 8; ++q) { a += comb[0][q * 32 + tid]; b += comb[1][q * 32 + tid]; }
+            part0[(size_t)n * C + c] = make_float2((float)a, (float)b);
+        }
+        return;
+    }
+    const int idx = ((int)blockIdx.x - nstat) * 256 + tid;
+    if (idx >= Ch * C) return;
+    const int k = idx / C, c = idx - k * C;
+    double a = 0.0;
+    for (int n = 0; n < N; ++n)
+        a += (double)A0[n * C + c] * (double)R[((size_t)n * Ch + k) * C + c] + (double)B0[n * C + c] * S[(size_t)n * Ch + k];
+    dW1[idx] = (float)a;
+}
+
+// scratch: 2*N*Ch floats (holds S in fp64)
+extern "C" int uncr_prenorm_bwd_finish(const float* R, const float* W1, const float* part_b, int NPB,
+                                       const float* part_f, int NPF, const float* c1, const float* c2,
+                                       const float* c3, const float* A0, const float* B0, float* part0, float* dW1,
+                                       float* scratch, int N, int Ch, int C, int P, hipStream_t stream) {
+    if (N <= 0 || Ch <= 0 || (Ch & 7) || C <= 0 || (C & 31) || P <= 0) return UNCR_ESHAPE;
+    if (!R || !W1 || !part_b || NPB <= 0 || !c1 || !c2 || !c3 || !A0 || !B0 || !part0 || !dW1 || !scratch) return UNCR_EINVAL;
+    if (part_f && NPF <= 0) return UNCR_EINVAL;
+    hipLaunchKernelGGL(prenorm_bwd_S_kernel, dim3((N * Ch + 3) / 4), dim3(256), 0, stream, (const float2*)part_b, NPB,
+                       (const float2*)part_f, NPF, c1, c2, c3, N * Ch, P, (double*)scratch);
+    UNCR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(prenorm_bwd_finish_kernel, dim3(N * (C / 32) + (Ch * C + 255) / 256), dim3(256), 0, stream, R, W1,
+                       (const double*)scratch, A0, B0, (float2*)part0, dW1, N, Ch, C);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
 extern "C" int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                                       const float* gamma, const float* beta, float* running_mean,
                                       float* running_var, float momentum, float eps, float* coefA, float* coefB,

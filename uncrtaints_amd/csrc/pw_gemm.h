@@ -21,7 +21,10 @@ struct PwArgs {
     int bias_stride_n;
     int Cin, Cout, P;
     int pro;             // PRO_*
-    int epi;             // 0 none, 1 (sum, sum^2), 2 (sum, sum*aux), 3 fused pass-B + (sum, sum*aux)
+    int epi;             // 0 none, 1 (sum, sum^2), 2 (sum, sum*aux), 3 fused pass-B + (sum, sum*aux), 4 accumulate,
+                         // 5 skip + PreNorm backward: out = aux2 + e0*v + e1*aux + e2, statistics (sum, sum*aux3) if part
+    const float* aux2;   // epi 5: dy
+    const float* aux3;   // epi 5: h3 of the producing block (or null: no statistics)
 };
 
 // x = h + m + l exactly, each part a bf16 (kept in the upper half of a 32-bit word).  Truncation split: h takes

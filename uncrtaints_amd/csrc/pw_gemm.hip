@@ -517,6 +517,25 @@ extern "C" int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, 
     return UNCR_OK;
 }
 
+// Backward of pw1 with the PreNorm backward and the skip connection in the epilogue (split kernels only):
+//   out = dy + c1*(W^T . normbwd(in, in2)) + c2*x + c3,   statistics (sum out, sum out*xh3) if xh3 is given.
+// c1..c3 are known before this GEMM because the sums they depend on follow from the weight-gradient products
+// (uncr_prenorm_bwd_finish).
+extern "C" int uncr_pw_gemm_dx_supported(int Cin, int Cout) { return (use_split(Cout) && pw_coutp(Cout) == 128 && Cin <= 256) ? 1 : 0; }
+extern "C" int uncr_pw_gemm_dx(const float* in, const float* in2, const float* Wt, float* out, const float* k0,
+                               const float* k1, const float* k2, const float* dy, const float* x, const float* xh3,
+                               const float* c1, const float* c2, const float* c3, float* part, int N, int Cin,
+                               int Cout, int P, hipStream_t stream) {
+    if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
+    if (!in || !in2 || !Wt || !out || !dy || !x || !c1 || !c2 || !c3) return UNCR_EINVAL;
+    if (xh3 && !part) return UNCR_EINVAL;
+    if (!uncr_pw_gemm_dx_supported(Cin, Cout)) return UNCR_EINVAL;
+    if (P % uncr_pw_tile_px(Cout)) return UNCR_ESHAPE;
+    PwArgs g{in, in2, Wt, out, k0, k1, k2, nullptr, x, c1, c2, c3, c3, xh3 ? (float2*)part : nullptr, 0, Cin, Cout, P,
+             PRO_NORMBWD, 5, dy, xh3};
+    return pw_split_launch_p3(g, N, pw_coutp(Cout), stream);
+}
+
 // weight-gradient shapes: (COP, CIP) in {(128,256), (256,128), (128,32), (32,128), (64,256)}
 static int wg_shape(int Cd, int Cx, int* cop, int* cip) {
     if (Cd > 128 && Cd <= 256 && Cx > 32 && Cx <= 128) { *cop = 256; *cip = 128; return 0; }

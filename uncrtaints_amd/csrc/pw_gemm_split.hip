@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char xs[2][PWS_BUF];
     __shared__ float cf[3][256];
     __shared__ float red[COUTP][2];
-    __shared__ float ecf[EPI == 3 ? 5 : 1][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D
+    __shared__ float ecf[(EPI == 3 || EPI == 5) ? 5 : 1][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar: row addresses stay in SGPRs
@@ -90,6 +90,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
             if constexpr (EPI == 3) {
                 const int ci = n * Cout + cc;
                 ecf[1][c] = g.e0[ci]; ecf[2][c] = g.e1[ci]; ecf[3][c] = g.e2[ci]; ecf[4][c] = g.e3[ci];
+            }
+            if constexpr (EPI == 5) {
+                const int ci = n * Cout + cc;
+                ecf[1][c] = g.e0[ci]; ecf[2][c] = g.e1[ci]; ecf[3][c] = g.e2[ci];
             }
         }
     }
@@ -270,9 +274,24 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         auto row_of = [&](int ct, int r) { return (wn * CT + ct) * 32 + (r & 3) + 8 * (r >> 2); };   // + 4*kg per lane
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
+            constexpr int RB = EPI == 5 ? 4 : 8;     // rows per request batch (epi 5 reads three rows per output row)
 #pragma unroll
-            for (int rb = 0; rb < 16; rb += 8) {
-                float4 xa[(EPI == 2 || EPI == 3 || EPI == 4) ? 8 : 1];   // one request batch = 8 rows
+            for (int rb = 0; rb < 16; rb += RB) {
+                float4 xa[(EPI == 2 || EPI == 3 || EPI == 4 || EPI == 5) ? RB : 1];
+                float4 xb[EPI == 5 ? RB : 1], xc[EPI == 5 ? RB : 1];
+                if constexpr (EPI == 5) {      // skip + PreNorm backward: x, dy, and the producing block's h3 (statistics)
+                    const float* a3 = g.aux3 ? g.aux3 : g.aux2;
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) {
+                        const int rw = row_of(ct, rb + q);
+                        const int rc = rw + 4 < Cout ? rw : (Cout > 8 ? Cout - 8 : 0);
+                        const size_t o = (size_t)(nco + rc) * P + loff;
+                        xa[q] = *(const float4*)(g.aux + o);
+                        xb[q] = *(const float4*)(g.aux2 + o);
+                        xc[q] = *(const float4*)(a3 + o);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr (EPI == 4) {      // accumulate: out += result (dense 3x3 as nine shifted 1x1 GEMMs)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -293,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < RB; ++q) {
                     const int r = rb + q;
                     const int col = row_of(ct, r) + 4 * kg;
                     const float bb = ecf[0][col];
@@ -318,6 +337,16 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                         s1 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
                     } else if constexpr (EPI == 4) {
                         v.x += xa[q].x; v.y += xa[q].y; v.z += xa[q].z; v.w += xa[q].w;
+                    } else if constexpr (EPI == 5) {
+                        // dx = dy + C1*da + C2*x + C3 (PreNorm backward + skip) on the fresh accumulator da
+                        const float4 x = xa[q], y = xb[q], h = xc[q];
+                        const float e1 = ecf[1][col], e2 = ecf[2][col], e3 = ecf[3][col];
+                        v.x = y.x + fmaf(e1, v.x, fmaf(e2, x.x, e3));
+                        v.y = y.y + fmaf(e1, v.y, fmaf(e2, x.y, e3));
+                        v.z = y.z + fmaf(e1, v.z, fmaf(e2, x.z, e3));
+                        v.w = y.w + fmaf(e1, v.w, fmaf(e2, x.w, e3));
+                        s0 = v.x + v.y + v.z + v.w;
+                        s1 = v.x * h.x + v.y * h.y + v.z * h.z + v.w * h.w;
                     }
                     acc[0][ct][r] = v.x; acc[1][ct][r] = v.y; acc[2][ct][r] = v.z; acc[3][ct][r] = v.w;
                     if constexpr (EPI != 0 && EPI != 4) {
@@ -351,8 +380,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     if constexpr (EPI != 0 && EPI != 4) {
         // one statistics slot per block (its tiles were summed in a fixed order): G slots per frame instead of P/128
         __syncthreads();
-        for (int c = tid; c < COUTP; c += NT)
-            if (c < Cout) g.part[((size_t)n * Cout + c) * G + bx] = make_float2(red[c][0], red[c][1]);
+        if (EPI != 5 || g.part)
+            for (int c = tid; c < COUTP; c += NT)
+                if (c < Cout) g.part[((size_t)n * Cout + c) * G + bx] = make_float2(red[c][0], red[c][1]);
     }
 #undef PWS_MF
 #ifdef PWS_STAMP
@@ -483,6 +513,12 @@ int PWS_CAT(pw_split_launch_p, PWS_PRO)(const PwArgs& g, int N, int cp, hipStrea
         case 2: pws_launch_epi<2>(g, grid, cp, stream); break;
         case 3: pws_launch_epi<3>(g, grid, cp, stream); break;
         case 4: pws_launch_epi<4>(g, grid, cp, stream); break;
+#if PWS_PRO == 3
+        case 5:      // the backward of pw1 only: 256 -> 128 channels
+            if (cp != 128) return UNCR_EINVAL;
+            hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 5, 2>), grid, dim3(256), 0, stream, g);
+            break;
+#endif
         default: return UNCR_EINVAL;
     }
     UNCR_LAUNCH_CHECK();

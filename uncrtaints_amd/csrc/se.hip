@@ -5,25 +5,42 @@
 //         dWpw[co,c] = sum_n s[n,c] G[n,co,c]  follow without another pass over the activations.
 #include "common.h"
 
-// grid = N, block = 256.  C <= 256, R <= 64.
-__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float2* __restrict__ pool_part, int NP, int C, int R,
-                                                         int P, const float* __restrict__ W1,
-                                                         const float* __restrict__ W2, float* __restrict__ pooled,
-                                                         float* __restrict__ hid_pre, float* __restrict__ s) {
+// grid = N, block = 1024 (latency-bound: 4 slices of the slot range per channel, 16 waves for the MLP).  C <= 256, R <= 64.
+__global__ __launch_bounds__(1024) void se_mlp_fwd_kernel(const float2* __restrict__ pool_part, int NP, int C, int R,
+                                                          int P, const float* __restrict__ W1,
+                                                          const float* __restrict__ W2, float* __restrict__ pooled,
+                                                          float* __restrict__ hid_pre, float* __restrict__ s) {
     const int n = blockIdx.x, tid = threadIdx.x;
     __shared__ float sp[256], sh[64];
-    if (tid < C) {
+    __shared__ double comb[4][256];
+    {
+        const int c = tid & 255, sl = tid >> 8;
         double a = 0.0;
-        const float2* src = pool_part + ((size_t)n * C + tid) * NP;
-        for (int j = 0; j < NP; ++j) a += (double)src[j].x;
-        const float m = (float)(a / (double)P);
+        if (c < C) {
+            const float2* src = pool_part + ((size_t)n * C + c) * NP;
+            const int j1 = (NP * (sl + 1)) / 4;
+            int j = (NP * sl) / 4;
+            for (; j + 8 <= j1; j += 8) {      // 8 independent loads in flight, fixed summation order
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = src[j + q].x;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a += (double)v[q];
+            }
+            for (; j < j1; ++j) a += (double)src[j].x;
+        }
+        comb[sl][c] = a;
+    }
+    __syncthreads();
+    if (tid < C) {
+        const float m = (float)((comb[0][tid] + comb[1][tid] + comb[2][tid] + comb[3][tid]) / (double)P);
         sp[tid] = m;
         pooled[n * C + tid] = m;
     }
     __syncthreads();
     // hidden: one wave handles rows round-robin
     const int lane = tid & 63, wv = tid >> 6;
-    for (int j = wv; j < R; j += 4) {
+    for (int j = wv; j < R; j += 16) {
         float a = 0.f;
         for (int c = lane; c < C; c += 64) a = fmaf(W1[j * C + c], sp[c], a);
         a = wave_sum(a);
@@ -41,25 +58,36 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float2* __restric
 }
 
 // grid = N.  Produces per-frame ds_pre[n,c], dhid_pre[n,j] and the pass-B coefficient dpool_px[n,c].
-__global__ __launch_bounds__(256) void se_mlp_bwd_frame_kernel(
+__global__ __launch_bounds__(1024) void se_mlp_bwd_frame_kernel(
     const float* __restrict__ G, const float* __restrict__ Wpw, int Co, int C, int R, int P,
     const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ s,
     const float* __restrict__ hid_pre, float* __restrict__ ds_pre, float* __restrict__ dhid_pre,
     float* __restrict__ dpool_px) {
     const int n = blockIdx.x, tid = threadIdx.x;
     __shared__ float sds[256], sdh[64];
-    if (tid < C) {
-        const float* g = G + (size_t)n * Co * C + tid;
+    __shared__ double comb[4][256];
+    {
+        // block = 1024: 4 slices of the co range per channel, combined in a fixed order
+        const int c = tid & 255, sl = tid >> 8;
         double a = 0.0;
-        int co = 0;
-        for (; co + 8 <= Co; co += 8) {       // 16 independent loads in flight, fixed summation order
-            float wv[8], gv[8];
+        if (c < C) {
+            const float* g = G + (size_t)n * Co * C + c;
+            const int co1 = (Co * (sl + 1)) / 4;
+            int co = (Co * sl) / 4;
+            for (; co + 8 <= co1; co += 8) {       // 16 independent loads in flight, fixed summation order
+                float wv[8], gv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { wv[j] = Wpw[(co + j) * C + tid]; gv[j] = g[(size_t)(co + j) * C]; }
+                for (int j = 0; j < 8; ++j) { wv[j] = Wpw[(co + j) * C + c]; gv[j] = g[(size_t)(co + j) * C]; }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a += (double)wv[j] * (double)gv[j];
+                for (int j = 0; j < 8; ++j) a += (double)wv[j] * (double)gv[j];
+            }
+            for (; co < co1; ++co) a += (double)Wpw[co * C + c] * (double)g[(size_t)co * C];
         }
-        for (; co < Co; ++co) a += (double)Wpw[co * C + tid] * (double)g[(size_t)co * C];
+        comb[sl][c] = a;
+    }
+    __syncthreads();
+    if (tid < C) {
+        const double a = comb[0][tid] + comb[1][tid] + comb[2][tid] + comb[3][tid];
         const float sv = s[n * C + tid];
         const float d = (float)a * sv * (1.f - sv);
         sds[tid] = d;
@@ -67,7 +95,7 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_frame_kernel(
     }
     __syncthreads();
     const int lane = tid & 63, wv = tid >> 6;
-    for (int j = wv; j < R; j += 4) {
+    for (int j = wv; j < R; j += 16) {
         float a = 0.f;
         for (int c = lane; c < C; c += 64) a = fmaf(W2[c * R + j], sds[c], a);
         a = wave_sum(a);
@@ -116,7 +144,7 @@ __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__
 extern "C" int uncr_se_mlp_fwd(const float* pool_part, int NP, int N, int C, int R, int P, const float* W1,
                                const float* W2, float* pooled, float* hid_pre, float* s, hipStream_t stream) {
     if (C > 256 || R > 64 || N <= 0) return UNCR_ESHAPE;
-    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(N), dim3(256), 0, stream, (const float2*)pool_part, NP, C, R, P, W1,
+    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(N), dim3(1024), 0, stream, (const float2*)pool_part, NP, C, R, P, W1,
                        W2, pooled, hid_pre, s);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
@@ -127,7 +155,7 @@ extern "C" int uncr_se_mlp_bwd(const float* G, const float* Wpw, int N, int Co, 
                                const float* hid_pre, float* ds_pre, float* dhid_pre, float* dpool_px, float* dWpw,
                                float* dW1, float* dW2, hipStream_t stream) {
     if (C > 256 || R > 64 || N <= 0) return UNCR_ESHAPE;
-    hipLaunchKernelGGL(se_mlp_bwd_frame_kernel, dim3(N), dim3(256), 0, stream, G, Wpw, Co, C, R, P, W1, W2, s,
+    hipLaunchKernelGGL(se_mlp_bwd_frame_kernel, dim3(N), dim3(1024), 0, stream, G, Wpw, Co, C, R, P, W1, W2, s,
                        hid_pre, ds_pre, dhid_pre, dpool_px);
     UNCR_LAUNCH_CHECK();
     hipLaunchKernelGGL(se_wgrad_kernel, dim3(Co + R), dim3(256), 0, stream, G, N, Co, C, R, s, pooled, hid_pre,

@@ -283,8 +283,22 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     _, party = ew(EW_RESIDUAL, x, b=h3, out=y, k=(n3.A, n3.B, None, None), want_part=want_out_stats, planes=N * C,
                   P=P)
     saved = dict(x=x, h1=h1, h2=h2, h3=h3, n0=n0, n1=n1, n2=n2, n3=n3, pooled=pooled, hid_pre=hid_pre, s=s,
-                 dims=(N, C, Ch, R, H, W), x_h3=x_h3)
+                 dims=(N, C, Ch, R, H, W), x_h3=x_h3, part1f=part1)
     return y, saved, party
+
+
+_FUSED_DX = os.environ.get("UNCR_NO_FUSED_DX", "0") != "1"     # A/B switch (development, tests)
+_CONST_PLANES: Dict[tuple, Tuple[Tensor, Tensor]] = {}
+
+
+def _const_planes(dev, n: int) -> Tuple[Tensor, Tensor]:
+    key = (str(dev), n)
+    if key in _CONST_PLANES:
+        return _CONST_PLANES[key]
+    pair = (torch.ones(n, device=dev, dtype=torch.float32), torch.zeros(n, device=dev, dtype=torch.float32))
+    if not torch.cuda.is_current_stream_capturing():     # memory from a graph's private pool must not outlive the capture
+        _CONST_PLANES[key] = pair
+    return pair
 
 
 def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = True,
@@ -341,10 +355,37 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     g["n1w"], g["n1b"] = b1.dgamma, b1.dbeta
     k1 = (b1.c1, b1.c2, b1.c3)
 
+    W1k = pack_wt(p["w1"].reshape(Ch, C), transpose=False)  # [k=co 256][out=ci 128]
+    if need_dx and _FUSED_DX and C % 32 == 0 and Ch % 8 == 0 and hb.query("uncr_pw_gemm_dx_supported", Ch, C) == 1:
+        # pw1 backward without a pass over da: the weight-gradient GEMM runs first, on the UN-normalised x and per frame
+        # (R[n,k,c] = sum_p du1n*x); da = W1^T du1n is linear, so (sum da, sum da*x) and dW1 follow from R and from sums
+        # that exist already (uncr_prenorm_bwd_finish).  The PreNorm backward coefficients are therefore known before the
+        # data GEMM, whose epilogue writes dx = dy + c1*da + c2*x + c3 (and the producing block's norm-3 statistics).
+        one, zero = _const_planes(dev, N * C)
+        Rf, _ = pw_wgrad(du1, x, N, Ch, C, P, pro_d=PRO_NORMBWD, dk=k1, d2=h1, pro_x=PRO_AFFINE, xk=(one, zero, None),
+                         per_frame=True)
+        part0 = Part(_f32((N * C, 1, 2), dev), 1)
+        dW1 = _f32((Ch, C), dev)
+        pf = sv.get("part1f")
+        hb.call("uncr_prenorm_bwd_finish", Rf, p["w1"].reshape(Ch, C).contiguous(), part1.buf, part1.slots,
+                pf.buf if pf is not None else None, pf.slots if pf is not None else 0, k1[0], k1[1], k1[2], n0.A, n0.B,
+                part0.buf, dW1, _f32((2 * N * Ch,), dev), N, Ch, C, P, _stream())
+        g["w1"] = dW1.view_as(p["w1"])
+        b0 = norm_bwd(part0, N, C, P, n0, p["n0w"])
+        g["n0w"], g["n0b"] = b0.dgamma, b0.dbeta
+        dx = _f32((N, C, H, W), dev)
+        x_h3 = sv.get("x_h3")
+        dx_part = None
+        if x_h3 is not None:
+            slots = hb.query("uncr_pw_stat_slots", N, C, P)
+            dx_part = Part(_f32((N * C, slots, 2), dev), slots)
+        hb.call("uncr_pw_gemm_dx", du1, h1, W1k, dx, k1[0], k1[1], k1[2], dy, x, x_h3, b0.c1, b0.c2, b0.c3,
+                dx_part.buf if dx_part is not None else None, N, Ch, C, P, _stream())
+        return dx, g, dx_part
+
     # pw1: weight gradient and data gradient
     dW1, _ = pw_wgrad(du1, x, N, Ch, C, P, pro_d=PRO_NORMBWD, dk=k1, d2=h1, pro_x=PRO_AFFINE, xk=(n0.A, n0.B, None))
     g["w1"] = dW1.view_as(p["w1"])
-    W1k = pack_wt(p["w1"].reshape(Ch, C), transpose=False)  # [k=co 256][out=ci 128]
     da, part0 = pw_gemm(du1, W1k, N, Ch, C, P, pro=PRO_NORMBWD, k=k1, x2=h1, epi=2, aux=x)
     b0 = norm_bwd(part0, N, C, P, n0, p["n0w"])
     g["n0w"], g["n0b"] = b0.dgamma, b0.dbeta
