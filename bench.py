@@ -34,6 +34,9 @@ def kernel_model(name, key):
     if name == "uncr_pw_gemm_dx":          # in, in2 (norm-bwd prologue), dy, x, xh3 -> dx
         N, Cin, Cout, P = key[-4:]
         return (f"pw_gemm_dx[{Cin}->{Cout},N{N},P{P}]", 4.0 * N * P * (2 * Cin + 4 * Cout), 2.0 * N * P * Cin * Cout)
+    if name == "uncr_residual_pool":       # x, h3 -> y (+ 8x8 max-pool)
+        planes, H, W, OH, OW = key[-5:]
+        return (f"residual_pool[planes{planes},{H}x{W}]", 4.0 * planes * H * W * 3, 0.0)
     if name == "uncr_pw_wgrad":
         N, Cd, Cx, P, PXB, pro_d, pro_x = key
         rd = Cd * (2 if pro_d == PRO_NORMBWD else 1) + Cx * (2 if pro_x == PRO_NORMBWD else 1)
@@ -57,7 +60,7 @@ def kernel_model(name, key):
     return (name, 0.0, 0.0)
 
 
-PROFILED = ("uncr_pw_gemm", "uncr_pw_gemm_dx", "uncr_pw_wgrad", "uncr_dw_fwd", "uncr_dw_bwd", "uncr_ew", "uncr_aggregate_fwd",
+PROFILED = ("uncr_pw_gemm", "uncr_pw_gemm_dx", "uncr_residual_pool", "uncr_pw_wgrad", "uncr_dw_fwd", "uncr_dw_bwd", "uncr_ew", "uncr_aggregate_fwd",
             "uncr_aggregate_bwd")
 
 

@@ -152,6 +152,14 @@ int uncr_pad_mask(const float* x, int NF, long long frame_elems, float pad_value
                   hipStream_t stream);   /* pad-frame detection, uncrtaints.py:392-394 */
 int uncr_maxpool_fwd(const float* in, float* out, int* idx, int planes, int H, int W, int OH, int OW,
                      hipStream_t stream);
+/* MBConv's closing residual y = x + A*h3 + B (uncrtaints.py:146) of the LAST encoder block with the L-TAE stage's
+ * AdaptiveMaxPool2d((32,32)) (uncrtaints.py:403-404) taken on the fly: out [planes][H][W], down / idx [planes][OH][OW]
+ * (same scan-order / NaN semantics as uncr_maxpool_fwd), part [planes][uncr_residual_pool_slots(H)][2] = (sum, sum^2)
+ * or null.  Built for W == 256 with 8x8 windows (uncr_residual_pool_supported); other shapes use uncr_ew + uncr_maxpool_fwd. */
+int uncr_residual_pool_supported(int H, int W, int OH, int OW);
+int uncr_residual_pool_slots(int H);
+int uncr_residual_pool(const float* x, const float* h3, const float* cA, const float* cB, float* out, float* part,
+                       float* down, int* idx, int planes, int H, int W, int OH, int OW, hipStream_t stream);
 int uncr_maxpool_bwd(const float* dout, const int* idx, float* din, int planes, int H, int W, int OH, int OW,
                      hipStream_t stream);
 int uncr_ltae_gn_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean,

@@ -367,6 +367,58 @@ def test_maxpool(E):
     close("maxpool_bwd", de, xr.grad)
 
 
+@pytest.mark.parametrize("H", [8, 64, 256])
+def test_residual_with_fused_maxpool(E, H):
+    """uncr_residual_pool (last encoder block: y = x + A*h3 + B with the stage's 8x8 max-pool on the fly) against the
+    element-wise kernel's formula and ATen's adaptive max-pool, with ties (quantised values) and NaNs in the input."""
+    from uncrtaints_amd import hip_backend as hb
+    N, C, W = 2, 8, 256
+    g = torch.Generator().manual_seed(7 + H)
+    x = (torch.randn(N, C, H, W, generator=g) * 2).round() / 2          # many exact ties inside every window
+    h3 = (torch.randn(N, C, H, W, generator=g) * 2).round() / 2
+    A = torch.tensor([1.0, 0.5, -1.0, 2.0] * (N * C // 4))
+    Bc = torch.tensor([0.0, 0.25, 1.0, -0.5] * (N * C // 4))
+    x[0, 0, 3, 5] = float("nan")
+    x[0, 0, 6, 1] = float("nan")                                        # two NaNs in one window
+    x[1, 2, H - 1, W - 1] = float("nan")
+    y_ref = x + A.view(N, C, 1, 1) * h3 + Bc.view(N, C, 1, 1)
+    d_ref, i_ref = F.adaptive_max_pool2d(y_ref, (H // 8, 32), return_indices=True)
+    assert hb.query("uncr_residual_pool_supported", H, W, H // 8, 32) == 1
+    y = torch.empty(N, C, H, W, device=DEV)
+    down = torch.empty(N, C, H // 8, 32, device=DEV)
+    idx = torch.empty(N, C, H // 8, 32, device=DEV, dtype=torch.int32)
+    slots = hb.query("uncr_residual_pool_slots", H)
+    part = torch.empty(N * C, slots, 2, device=DEV)
+    hb.call("uncr_residual_pool", dev(x), dev(h3), dev(A), dev(Bc), y, part, down, idx, N * C, H, W, H // 8, 32, E._stream())
+    assert torch.equal(torch.nan_to_num(y.cpu(), nan=123.0), torch.nan_to_num(y_ref, nan=123.0))
+    assert torch.equal(torch.nan_to_num(down.cpu(), nan=123.0), torch.nan_to_num(d_ref, nan=123.0))
+    assert torch.equal(idx.cpu().long(), i_ref), "argmax: first maximum in scan order, NaN propagates (ATen semantics)"
+    ok = ~torch.isnan(y_ref).flatten(2).any(-1).flatten()               # planes without NaN: statistics
+    s = part.double().sum(1).cpu()
+    close("residual_pool_sum", s[ok, 0].float(), y_ref.flatten(2).sum(-1).flatten()[ok])
+    close("residual_pool_sumsq", s[ok, 1].float(), (y_ref.double() ** 2).flatten(2).sum(-1).flatten()[ok].float())
+
+
+def test_pack_cache_cannot_serve_a_recycled_address(E):
+    """The batched weight pre-pack remembers its results by (address, version).  The entry must keep the weight alive:
+    otherwise a new model's weight that the allocator places at a freed model's address (same version counter) would be
+    served the OLD packed weights."""
+    w = torch.randn(256, 128, device=DEV)
+    E.prepack([(w, True)])
+    ptr = w.data_ptr()
+    ref_old = E.pack_wt(w, True).clone()
+    del w
+    w2 = torch.randn(256, 128, device=DEV)              # same size: the caching allocator would recycle the block at once
+    assert w2.data_ptr() != ptr, "the cache entry does not pin the packed weight's memory"
+    got = E.pack_wt(w2, True)
+    from uncrtaints_amd import hip_backend as hb
+    direct = torch.empty_like(got)
+    hb.call("uncr_pack_wt", w2, 128, 256, 128, 1, direct, E._stream())
+    assert torch.equal(got, direct) and not torch.equal(got, ref_old)
+    E.prepack([(w2, True)])                              # the next pre-pack drops the old entries (and their pins)
+    assert len(E._PACK_CACHE) == 1
+
+
 def test_pad_mask(E):
     x = torch.rand(2, 3, 15, 64, 64)
     x[1, 2] = 0

@@ -55,6 +55,22 @@ def main():
             print(f"dw_fwd N={Nf}: {ms*1e3:.1f} us  {8.0*Nf*C*H*W/ms/1e6:.0f} GB/s")
             ms = timeit(lambda: hb.call("uncr_dw_bwd", du2, h2, h1, k1, k2, k3, cA, cB, w, out, partb, dwp, None, 0, Nf, C, H, W, E._stream()), iters)
             print(f"dw_bwd N={Nf}: {ms*1e3:.1f} us  {16.0*Nf*C*H*W/ms/1e6:.0f} GB/s")
+    elif what == "agg":
+        # the L-TAE stage's full-resolution kernels at the bench shape
+        from uncrtaints_amd import hip_backend as hb
+        B, T, C, H, W, NH, AH = 4, 3, 128, 256, 256, 16, 32
+        e = torch.randn(B, T, C, H, W, device=dev)
+        att = torch.softmax(torch.randn(NH, B, T, AH, AH, device=dev), dim=2)
+        dg = torch.randn(B, C, H, W, device=dev)
+        for train in (False, True):
+            fn = lambda: E.aggregate_forward(e, att, None, train, 0.1, 1234)
+            ms = timeit(fn, iters)
+            print(f"aggregate_fwd train={train}: {ms*1e3:.1f} us  {4.0*B*C*H*W*(T+1)/ms/1e6:.0f} GB/s")
+            _, sv, _ = fn()
+            ms = timeit(lambda: E.aggregate_backward(dg, sv), iters)
+            print(f"aggregate_bwd (+bilinear adjoint) train={train}: {ms*1e3:.1f} us  {4.0*B*H*W*(C*(2*T+1)+NH*T)/ms/1e6:.0f} GB/s")
+        ms = timeit(lambda: E.maxpool_forward(e, AH, AH), iters)
+        print(f"maxpool_fwd: {ms*1e3:.1f} us  {4.0*B*T*C*H*W/ms/1e6:.0f} GB/s")
     elif what == "gemmscale":
         Cin, Cout = 128, 256
         for nb in (128, 256, 512, 1024, 2048):

@@ -10,6 +10,9 @@
 #include "common.h"
 
 #define AGG_PX 1024   // pixels per block
+#ifndef AGG_ABL
+#define AGG_ABL 0      // development ablations: 1 no dropout hash, 2 no attention gathers, 4 one head per block
+#endif
 
 struct AggArgs {
     const float* e;        // [B][T][C][P]
@@ -50,7 +53,7 @@ __device__ __forceinline__ float agg_keep(const AggArgs& g, int h, int b, int t,
     const size_t P = (size_t)g.H * g.W;
     if (g.shared_mask) h = 0;
     if (g.dmask) m = g.dmask[(((size_t)h * g.B + b) * g.T + t) * P + p];
-    else if (g.p_drop > 0.f) {
+    else if (g.p_drop > 0.f && !(AGG_ABL & 1)) {
         const unsigned long long sd = g.seed + (g.seed_dev ? (unsigned long long)g.seed_dev[0] * 0x9E3779B97F4A7C15ull : 0ull);
         const float u = hash_uniform(sd, (((size_t)h * g.B + b) * g.T + t) * P + p);
         m = u < g.p_drop ? 0.f : 1.f / (1.f - g.p_drop);
@@ -59,8 +62,12 @@ __device__ __forceinline__ float agg_keep(const AggArgs& g, int h, int b, int t,
     return m;
 }
 
-template <bool BWD, int CH>
-__global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g) {
+// STAGE: the block's low-resolution attention rows (all its heads and dates) are copied to LDS once; the 16 taps per
+// (head, date) of a thread's 4 pixels then come from LDS instead of 16 scattered global loads (-20 us of 127 at the
+// bench shape).  Dynamic LDS = heads_per_block * T * agg_rows * AW floats; larger problems use the gather path.
+template <bool BWD, int CH, bool STAGE>
+__global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
+    extern __shared__ float att_s[];
     const int b = blockIdx.y;
     const int P = g.H * g.W;
     const int p0 = blockIdx.x * AGG_PX + threadIdx.x * 4;
@@ -76,6 +83,19 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g) {
     // heads are split over blockIdx.z (more blocks in flight: the kernel is pure latency/bandwidth bound)
     const int hpb = (g.NH + gridDim.z - 1) / gridDim.z;
     const int h_beg = blockIdx.z * hpb, h_end = min(g.NH, h_beg + hpb);
+    int rlo = 0;
+    if constexpr (STAGE) {
+        const int pb = blockIdx.x * AGG_PX;
+        rlo = bilin_src(pb / g.W, sy, g.AH).i0;                     // first low-res row any pixel of the block touches
+        const int per_h = g.T * nrows * g.AW;
+        for (int i = threadIdx.x; i < (h_end - h_beg) * per_h; i += 256) {
+            const int hl = i / per_h, rem = i - hl * per_h;
+            const int t = rem / (nrows * g.AW), rr = rem - t * nrows * g.AW;
+            const int r = min(rlo + rr / g.AW, g.AH - 1), ax = rr % g.AW;
+            att_s[i] = g.att[((((size_t)(h_beg + hl) * g.B + b) * g.T + t) * g.AH + r) * g.AW + ax];
+        }
+        __syncthreads();
+    }
     for (int h = h_beg; h < h_end; ++h) {
         float4 acc[CH];                 // fwd: output accumulators; bwd: dg of the head's channels
 #pragma unroll
@@ -85,12 +105,14 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g) {
         }
         for (int t = 0; t < g.T; ++t) {
             // up-sampled attention (x dropout x pad) for this thread's 4 pixels
-            const float* ap = g.att + (((size_t)h * g.B + b) * g.T + t) * g.AH * g.AW;
+            const float* ap = STAGE ? att_s + (((h - h_beg) * g.T + t) * nrows - rlo) * g.AW
+                                    : g.att + (((size_t)h * g.B + b) * g.T + t) * g.AH * g.AW;
             float a[4], keep[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float top = bx[j].l0 * ap[by.i0 * g.AW + bx[j].i0] + bx[j].l1 * ap[by.i0 * g.AW + bx[j].i1];
-                const float bot = bx[j].l0 * ap[by.i1 * g.AW + bx[j].i0] + bx[j].l1 * ap[by.i1 * g.AW + bx[j].i1];
+                float top = bx[j].l0 * ap[by.i0 * g.AW + bx[j].i0] + bx[j].l1 * ap[by.i0 * g.AW + bx[j].i1];
+                float bot = bx[j].l0 * ap[by.i1 * g.AW + bx[j].i0] + bx[j].l1 * ap[by.i1 * g.AW + bx[j].i1];
+                if (AGG_ABL & 2) { top = bx[j].l0 * 0.3f; bot = bx[j].l1 * 0.2f + (float)t; }
                 keep[j] = agg_keep(g, h, b, t, (size_t)p0 + j);
                 a[j] = (by.l0 * top + by.l1 * bot) * keep[j];
             }
@@ -145,44 +167,42 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g) {
 }
 
 // adjoint of the bilinear up-sampling: datt[q, ay, ax] = sum_{y,x} wy(y,ay) wx(x,ax) dup[q, y, x]
-// grid = (AH, planes q = NH*B*T), block = 256 = 8 row lanes x 32 ax
+// grid = (AH, planes q = NH*B*T), block = 256.  Separable: the rows that feed `ay` are read as coalesced float4
+// columns, weighted by wy and summed over rows (4 row lanes -> LDS), then every ax folds its x range of the row sums.
+#define BADJ_MAXW 1024
 __global__ __launch_bounds__(256) void bilinear_adjoint_kernel(const float* __restrict__ dup,
                                                                float* __restrict__ datt, int H, int W, int AH,
                                                                int AW) {
     const int ay = blockIdx.x, q = blockIdx.y;
-    const int axl = threadIdx.x & 31, yl = threadIdx.x >> 5;
+    const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
     const float sy = (float)AH / (float)H, sx = (float)AW / (float)W;
     const int ry = (H + AH - 1) / AH, rx = (W + AW - 1) / AW;
     const int ylo = max(0, (ay - 1) * ry - ry), yhi = min(H, (ay + 2) * ry + ry);
     const float* src = dup + (size_t)q * H * W;
-    __shared__ float red[8][33];
-    for (int ax0 = 0; ax0 < AW; ax0 += 32) {
-        const int ax = ax0 + axl;
-        float acc = 0.f;
-        if (ax < AW) {
-            const int xlo = max(0, (ax - 1) * rx - rx), xhi = min(W, (ax + 2) * rx + rx);
-            for (int yy = ylo + yl; yy < yhi; yy += 8) {
-                const Bilin by = bilin_src(yy, sy, AH);
-                const float wy = (by.i0 == ay ? by.l0 : 0.f) + (by.i1 == ay ? by.l1 : 0.f);
-                if (wy == 0.f) continue;
-                float rowacc = 0.f;
-                for (int xx = xlo; xx < xhi; ++xx) {
-                    const Bilin bx = bilin_src(xx, sx, AW);
-                    const float wx = (bx.i0 == ax ? bx.l0 : 0.f) + (bx.i1 == ax ? bx.l1 : 0.f);
-                    if (wx != 0.f) rowacc = fmaf(wx, src[(size_t)yy * W + xx], rowacc);
-                }
-                acc = fmaf(wy, rowacc, acc);
-            }
+    __shared__ float colsum[4][BADJ_MAXW];
+    const int W4 = W >> 2;
+    for (int c4 = cl; c4 < W4; c4 += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int yy = ylo + rl; yy < yhi; yy += 4) {
+            const Bilin by = bilin_src(yy, sy, AH);
+            const float wy = (by.i0 == ay ? by.l0 : 0.f) + (by.i1 == ay ? by.l1 : 0.f);
+            if (wy == 0.f) continue;
+            const float4 v = *(const float4*)(src + (size_t)yy * W + 4 * c4);
+            acc.x = fmaf(wy, v.x, acc.x); acc.y = fmaf(wy, v.y, acc.y);
+            acc.z = fmaf(wy, v.z, acc.z); acc.w = fmaf(wy, v.w, acc.w);
         }
-        red[yl][axl] = acc;
-        __syncthreads();
-        if (yl == 0 && ax < AW) {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s += red[i][axl];
-            datt[((size_t)q * AH + ay) * AW + ax] = s;
+        *(float4*)&colsum[rl][4 * c4] = acc;
+    }
+    __syncthreads();
+    for (int ax = tid; ax < AW; ax += 256) {
+        const int xlo = max(0, (ax - 1) * rx - rx), xhi = min(W, (ax + 2) * rx + rx);
+        float s = 0.f;
+        for (int xx = xlo; xx < xhi; ++xx) {
+            const Bilin bx = bilin_src(xx, sx, AW);
+            const float wx = (bx.i0 == ax ? bx.l0 : 0.f) + (bx.i1 == ax ? bx.l1 : 0.f);
+            if (wx != 0.f) s = fmaf(wx, (colsum[0][xx] + colsum[1][xx]) + (colsum[2][xx] + colsum[3][xx]), s);
         }
-        __syncthreads();
+        datt[((size_t)q * AH + ay) * AW + ax] = s;
     }
 }
 
@@ -191,10 +211,38 @@ extern "C" int uncr_agg_slots(int P) { return P / AGG_PX; }
 static int agg_check(int B, int T, int C, int NH, int H, int W, int AH, int AW) {
     if (B <= 0 || T <= 0 || C % NH || C > 256) return UNCR_ESHAPE;
     if (C / NH != 4 && C / NH != 8 && C / NH != 16) return UNCR_ESHAPE;
-    if ((W & 3) || ((H * W) % AGG_PX)) return UNCR_ESHAPE;
+    if ((W & 3) || W > BADJ_MAXW || ((H * W) % AGG_PX)) return UNCR_ESHAPE;
     if (H < AH || W < AW) return UNCR_ESHAPE;     // avg-pool branch (uncrtaints.py:204) not built; H == AH is the
                                                   // identity up-sampling (LTAE2d's attention-weighted values)
     return UNCR_OK;
+}
+
+// low-res rows a 1024-pixel block can touch: its (at most 1024/W + 1) image rows map to a span of that many * AH/H
+// source rows, plus the two interpolation partners
+static int agg_rows(int H, int W, int AH) {
+    const int img_rows = (AGG_PX + W - 1) / W + 1;      // a block may straddle one more image row
+    int r = (int)((double)(img_rows - 1) * AH / H) + 3;
+    return r > AH ? AH : r;
+}
+
+template <bool BWD>
+static void agg_launch(const AggArgs& g, hipStream_t stream) {
+    const int zs = (AGG_ABL & 4) ? g.NH : (g.NH % 4 == 0 ? 4 : 1);
+    const dim3 grid(g.H * g.W / AGG_PX, g.B, zs);
+    const int nrows = agg_rows(g.H, g.W, g.AH);
+    const size_t lds = (size_t)((g.NH + zs - 1) / zs) * g.T * nrows * g.AW * sizeof(float);
+    const bool stage = lds <= 48 * 1024;
+#define AGG_GO(CHV)                                                                                              \
+    do {                                                                                                         \
+        if (stage) hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, true>), grid, dim3(256), lds, stream, g, nrows); \
+        else hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, false>), grid, dim3(256), 0, stream, g, nrows);        \
+    } while (0)
+    switch (g.C / g.NH) {
+        case 4: AGG_GO(4); break;
+        case 8: AGG_GO(8); break;
+        default: AGG_GO(16); break;
+    }
+#undef AGG_GO
 }
 
 extern "C" int uncr_aggregate_fwd(const float* e, const float* att, const int* pad, const float* dmask,
@@ -204,12 +252,7 @@ extern "C" int uncr_aggregate_fwd(const float* e, const float* att, const int* p
     const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
     if (rc) return rc;
     AggArgs g{e, att, pad, dmask, out, nullptr, nullptr, nullptr, (float2*)part, seed, seed_dev, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
-    const dim3 grid(H * W / AGG_PX, B, NH % 4 == 0 ? 4 : 1);
-    switch (C / NH) {
-        case 4: hipLaunchKernelGGL((aggregate_kernel<false, 4>), grid, dim3(256), 0, stream, g); break;
-        case 8: hipLaunchKernelGGL((aggregate_kernel<false, 8>), grid, dim3(256), 0, stream, g); break;
-        default: hipLaunchKernelGGL((aggregate_kernel<false, 16>), grid, dim3(256), 0, stream, g); break;
-    }
+    agg_launch<false>(g, stream);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -221,12 +264,7 @@ extern "C" int uncr_aggregate_bwd(const float* dg, const float* e, const float* 
     const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
     if (rc) return rc;
     AggArgs g{e, att, pad, dmask, nullptr, dg, de, datt_up, nullptr, seed, seed_dev, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
-    const dim3 grid(H * W / AGG_PX, B, NH % 4 == 0 ? 4 : 1);
-    switch (C / NH) {
-        case 4: hipLaunchKernelGGL((aggregate_kernel<true, 4>), grid, dim3(256), 0, stream, g); break;
-        case 8: hipLaunchKernelGGL((aggregate_kernel<true, 8>), grid, dim3(256), 0, stream, g); break;
-        default: hipLaunchKernelGGL((aggregate_kernel<true, 16>), grid, dim3(256), 0, stream, g); break;
-    }
+    agg_launch<true>(g, stream);
     UNCR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(AH, NH * B * T), dim3(256), 0, stream, datt_up, datt, H, W, AH,
                        AW);
@@ -280,7 +318,7 @@ extern "C" int uncr_add_upsampled(const float* a, const float* z, float* out, fl
 // adjoint of the bilinear up-sampling on its own: dst[q, ay, ax] = sum_{y,x} wy wx src[q, y, x]
 extern "C" int uncr_bilinear_adjoint(const float* src, float* dst, int planes, int H, int W, int AH, int AW,
                                      hipStream_t stream) {
-    if (planes <= 0 || H < AH || W < AW) return UNCR_ESHAPE;
+    if (planes <= 0 || H < AH || W < AW || (W & 3) || W > BADJ_MAXW) return UNCR_ESHAPE;
     hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(AH, planes), dim3(256), 0, stream, src, dst, H, W, AH, AW);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;

@@ -39,6 +39,69 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     idx[(size_t)plane * OH * OW + o] = bi;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Last encoder block: MBConv's closing residual  y = x + A*h3 + B  (uncrtaints.py:146) with the 8x8 max-pool of the
+// L-TAE stage (uncrtaints.py:403-404) taken while y is in registers -- the pool's own pass over e [B,T,C,H,W]
+// (403 MB at the bench shape) disappears.  Built for W == 256 and 8x8 windows (256^2 -> 32^2): one wave = one strip of
+// 8 image rows, lane = 4 pixels; per-lane running (max, first index) over the 8 rows, then the two lanes of a window
+// are merged.  Scan-order semantics of the stand-alone kernel: first maximum in row-major order wins, NaN propagates.
+// grid = (H/32, planes), block = 256 = 4 strips.  part: [planes][H/8] (sum y, sum y^2) or null.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void residual_pool_kernel(const float* __restrict__ x, const float* __restrict__ h3,
+                                                            const float* __restrict__ cA, const float* __restrict__ cB,
+                                                            float* __restrict__ out, float2* __restrict__ part,
+                                                            float* __restrict__ down, int* __restrict__ idx, int H) {
+    constexpr int W = 256;
+    const int plane = blockIdx.y, lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (strip * 8 >= H) return;
+    const float A = cA[plane], B = cB[plane];
+    const size_t base = (size_t)plane * H * W + (size_t)strip * 8 * W + 4 * lane;
+    float4 xv[8], hv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        xv[r] = *(const float4*)(x + base + (size_t)r * W);
+        hv[r] = *(const float4*)(h3 + base + (size_t)r * W);
+    }
+    float best = -INFINITY, s0 = 0.f, s1 = 0.f;
+    int bi = strip * 8 * W + 4 * lane;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float4 o;
+        o.x = xv[r].x + fmaf(A, hv[r].x, B);
+        o.y = xv[r].y + fmaf(A, hv[r].y, B);
+        o.z = xv[r].z + fmaf(A, hv[r].z, B);
+        o.w = xv[r].w + fmaf(A, hv[r].w, B);
+        *(float4*)(out + base + (size_t)r * W) = o;
+        const float vv[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0 += vv[j];
+            s1 = fmaf(vv[j], vv[j], s1);
+            if (vv[j] > best || vv[j] != vv[j]) { best = vv[j]; bi = (strip * 8 + r) * W + 4 * lane + j; }
+        }
+    }
+    // merge the two half-windows (lanes 2k, 2k+1).  Row-major scan order inside a window == order of the flat index,
+    // so on equal maxima the smaller index wins; a NaN anywhere wins (the later one in scan order, like the serial scan).
+    const float ob = __shfl_xor(best, 1);
+    const int oi = __shfl_xor(bi, 1);
+    const bool me_nan = best != best, ot_nan = ob != ob;
+    bool take;
+    if (me_nan || ot_nan) take = ot_nan && (!me_nan || oi > bi);
+    else take = ob > best || (ob == best && oi < bi);
+    if (take) { best = ob; bi = oi; }
+    if ((lane & 1) == 0) {
+        const size_t o = ((size_t)plane * (H / 8) + strip) * 32 + (lane >> 1);
+        down[o] = best;
+        idx[o] = bi;
+    }
+    if (part) {
+        s0 = wave_sum_dpp(s0);
+        s1 = wave_sum_dpp(s1);
+        if (lane == 63) part[(size_t)plane * (H / 8) + strip] = make_float2(s0, s1);
+    }
+}
+
 // de[plane][idx] += dpooled   (windows are disjoint when H % OH == 0; otherwise atomics)
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx,
                                                           float* __restrict__ din, int HW, int OHW, int disjoint) {
@@ -300,6 +363,21 @@ extern "C" int uncr_maxpool_fwd(const float* in, float* out, int* idx, int plane
     if (planes <= 0 || H < OH || W < OW) return UNCR_ESHAPE;
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((OH * OW + 255) / 256, planes), dim3(256), 0, stream, in, out, idx, H,
                        W, OH, OW);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_residual_pool_supported(int H, int W, int OH, int OW) {
+    return (W == 256 && OW == 32 && H >= 8 && (H & 7) == 0 && OH * 8 == H) ? 1 : 0;
+}
+extern "C" int uncr_residual_pool_slots(int H) { return H / 8; }
+extern "C" int uncr_residual_pool(const float* x, const float* h3, const float* cA, const float* cB, float* out,
+                                  float* part, float* down, int* idx, int planes, int H, int W, int OH, int OW,
+                                  hipStream_t stream) {
+    if (planes <= 0 || !uncr_residual_pool_supported(H, W, OH, OW)) return UNCR_ESHAPE;
+    if (!x || !h3 || !cA || !cB || !out || !down || !idx) return UNCR_EINVAL;
+    hipLaunchKernelGGL(residual_pool_kernel, dim3((H / 8 + 3) / 4, planes), dim3(256), 0, stream, x, h3, cA, cB, out,
+                       (float2*)part, down, idx, H);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -137,7 +137,10 @@ def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor, cen
 
 
 # ---- batched weight packing: every 1x1-conv weight of a model in ONE launch at the start of a forward ----
-_PACK_CACHE: Dict[tuple, tuple] = {}     # (data_ptr, transpose, R, Cc) -> (packed view, weight version)
+# (data_ptr, transpose, R, Cc) -> (packed view, weight version, the weight view itself).  The entry OWNS a reference to the
+# weight: while it exists the allocator cannot hand the same address to another tensor, so a (pointer, version) match can
+# only be the tensor that was packed (a freed model's address re-used by a new model's weights would otherwise hit).
+_PACK_CACHE: Dict[tuple, tuple] = {}
 _PACK_PLANS: Dict[tuple, tuple] = {}     # plan key -> (descriptor tensor, flat output, views, max_threads)
 
 
@@ -173,7 +176,9 @@ def prepack(weights) -> None:
     hb.call("uncr_pack_wt_batch", desc, len(weights), max_threads, _stream())
     _PACK_CACHE.clear()
     for (w, tr), v, k in zip(weights, views, key):
-        _PACK_CACHE[k] = (v, w._version)
+        _PACK_CACHE[k] = (v, w._version, w)
+    while len(_PACK_PLANS) > 8:                       # plans of models that are gone
+        _PACK_PLANS.pop(next(iter(_PACK_PLANS)))
 
 
 def pack_wt(W2d: Tensor, transpose: bool) -> Tensor:
@@ -243,9 +248,11 @@ MB_KEYS = ("n0w", "n0b", "w1", "n1w", "n1b", "wdw", "n2w", "n2b", "se1", "se2", 
 
 def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bool,
                    x_part: Optional[Part] = None, buffers: Optional[Dict[str, Tensor]] = None,
-                   want_out_stats: bool = True, x_h3: Optional[Tensor] = None):
+                   want_out_stats: bool = True, x_h3: Optional[Tensor] = None, pool: Optional[int] = None):
     """x [N,C,H,W] -> y, saved-for-backward dict, partial stats of y (for the next PreNorm).
-    `buffers` holds BatchNorm running_mean/var tensors keyed n{0..3}rm / n{0..3}rv (updated in place)."""
+    `buffers` holds BatchNorm running_mean/var tensors keyed n{0..3}rm / n{0..3}rv (updated in place).
+    pool: also return AdaptiveMaxPool2d((pool, pool))(y) and its argmax as saved["ypool"] (last encoder block: the
+    L-TAE stage's pooling, uncrtaints.py:403-404, taken inside the residual kernel where the shape allows)."""
     N, C, H, W = _check4(x)
     P = H * W
     Ch = p["w1"].shape[0]
@@ -280,9 +287,23 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     n3 = norm_fwd(part3, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))
 
     y = _f32((N, C, H, W), x.device)
-    _, party = ew(EW_RESIDUAL, x, b=h3, out=y, k=(n3.A, n3.B, None, None), want_part=want_out_stats, planes=N * C,
-                  P=P)
-    saved = dict(x=x, h1=h1, h2=h2, h3=h3, n0=n0, n1=n1, n2=n2, n3=n3, pooled=pooled, hid_pre=hid_pre, s=s,
+    ypool = None
+    if pool is not None and hb.query("uncr_residual_pool_supported", H, W, pool, pool) == 1:
+        down = _f32((N, C, pool, pool), x.device)
+        idx = torch.empty((N, C, pool, pool), device=x.device, dtype=torch.int32)
+        party = None
+        if want_out_stats:
+            slots = hb.query("uncr_residual_pool_slots", H)
+            party = Part(_f32((N * C, slots, 2), x.device), slots)
+        hb.call("uncr_residual_pool", x, h3, n3.A, n3.B, y, party.buf if party else None, down, idx, N * C, H, W, pool,
+                pool, _stream())
+        ypool = (down, idx)
+    else:
+        _, party = ew(EW_RESIDUAL, x, b=h3, out=y, k=(n3.A, n3.B, None, None), want_part=want_out_stats, planes=N * C,
+                      P=P)
+        if pool is not None:
+            ypool = maxpool_forward(y, pool, pool)
+    saved = dict(ypool=ypool, x=x, h1=h1, h2=h2, h3=h3, n0=n0, n1=n1, n2=n2, n3=n3, pooled=pooled, hid_pre=hid_pre, s=s,
                  dims=(N, C, Ch, R, H, W), x_h3=x_h3, part1f=part1)
     return y, saved, party
 
@@ -817,14 +838,18 @@ def include_v_backward(dout: Tensor, sv: dict):
 def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor], p: Dict[str, Tensor],
                        denom: Optional[Tensor], n_head: int, d_k: int, att_down: int, training: bool, p_drop: float,
                        seed: int, dmask: Optional[Tensor] = None, want_stats: bool = True, mode: str = "att_group",
-                       values: Optional[dict] = None):
+                       values: Optional[dict] = None, pooled=None):
     """Fused stage used by UNCRTAINTS.forward: e [B,T,C,H,W] -> g [B,C,H,W] (+ stats partials of g).
+    pooled: (down, idx) of AdaptiveMaxPool2d((att_down, att_down))(e) if the producer of e already took it.
     mode: 'att_group' | 'att_mean' | 'mean' (uncrtaints.py:156-221).
     values (use_v): dict(p=value-branch params, include_w, include_b, bn_buffers, p_drop, seed): the LTAE2d values are
     up-sampled and merged through include_v (uncrtaints.py:414-417)."""
-    down, idx = maxpool_forward(e, att_down, att_down)
-    att, sv_att = ltae_attention_forward(down, dates, pad, p, denom, n_head, d_k)
     B, T = e.shape[:2]
+    if pooled is not None:
+        down, idx = (v.view(B, T, e.shape[2], att_down, att_down) for v in pooled)
+    else:
+        down, idx = maxpool_forward(e, att_down, att_down)
+    att, sv_att = ltae_attention_forward(down, dates, pad, p, denom, n_head, d_k)
     if mode == "att_group":
         w_att, shared = att, False
     elif mode == "att_mean":

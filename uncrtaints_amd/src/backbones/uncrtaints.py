@@ -65,9 +65,10 @@ class _MBConvFn(torch.autograd.Function):
         x = x.contiguous()
         y, sv, party = E.mbconv_forward(x, p, module._spec, module.training, getattr(x, "_uncr_part", None),
                                         module._bn_buffers(), want_out_stats=True,
-                                        x_h3=getattr(x, "_uncr_h3", None))
+                                        x_h3=getattr(x, "_uncr_h3", None), pool=getattr(x, "_uncr_pool", None))
         ctx.sv, ctx.p = sv, p
         y._uncr_part = party        # (sum y, sum y^2) partials for the next PreNorm
+        y._uncr_pooled = sv.pop("ypool")   # (max-pooled y, argmax) when the L-TAE stage asked for it
         y._uncr_h3 = sv["h3"]       # lets the consumer of y emit this block's norm-3 backward statistics
         return y
 
@@ -283,7 +284,8 @@ class _StageFn(torch.autograd.Function):
                           p_drop=te.dropout.p, seed=vseed)
         g, sv, gpart, att = E.ltae_stage_forward(e.contiguous(), dates, pad, p, denom, te.n_head,
                                                  te.attention_heads.d_k, 32, net.training, agg.attn_dropout.p,
-                                                 agg._next_seed(), dmask, want_stats, mode=agg.mode, values=values)
+                                                 agg._next_seed(), dmask, want_stats, mode=agg.mode, values=values,
+                                                 pooled=getattr(e, "_uncr_pooled", None))
         if ctx.use_v and net.training:
             te.mlp[1].num_batches_tracked += 1
         ctx.sv, ctx.p, ctx.te = sv, p, te
@@ -477,17 +479,22 @@ class UNCRTAINTS(nn.Module):
                 torch._foreach_add_(nbt, 1)
         pad = E.pad_mask_of(input, float(self.pad_value))                  # [B,T] int32, uncrtaints.py:392-394
         out = self.in_conv.smart_forward(input)                            # [B,T,C,H,W]
-        part = None
-        for layer in self.in_block:
+        part, pooled = None, None
+        for li, layer in enumerate(self.in_block):
             b, t, c, h, w = out.shape
             x4 = out.view(b * t, c, h, w)
             if part is not None:
                 x4._uncr_part = part
             elif hasattr(out, "_uncr_part"):
                 x4._uncr_part = out._uncr_part
+            if li == len(self.in_block) - 1 and not self.is_mono and h % 32 == 0 and w % 32 == 0:
+                x4._uncr_pool = 32          # the stage's 32x32 max-pool rides on the last encoder block's residual kernel
             y4 = layer(x4)
             part = getattr(y4, "_uncr_part", None)
+            pooled = getattr(y4, "_uncr_pooled", None)
             out = y4.view(b, t, c, h, w)
+        if pooled is not None:
+            out._uncr_pooled = pooled
         if not self.is_mono:
             if self.temporal_encoder.positional_encoder is not None and batch_positions is None:
                 raise ValueError("batch_positions (dates) are required when positional_encoding=True")
