@@ -102,12 +102,15 @@ int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, float* out,
 /* Backward of MBConv's pw1 (uncrtaints.py:100-146: x + block(PreNorm(x))) with the PreNorm backward and the skip
  * connection in the GEMM epilogue: out = dy + c1*(W^T . normbwd(in, in2; k0..k2)) + c2*x + c3; if xh3 (the h3 of the
  * block that produced x) is given, part receives (sum out, sum out*xh3) for that block's last norm backward.
- * c1..c3 come from uncr_norm_finalize_bwd on the sums uncr_prenorm_bwd_finish derives without a pass over da. */
+ * c1..c3 come from uncr_norm_finalize_bwd on the sums uncr_prenorm_bwd_finish derives without a pass over da.
+ * relu_a / relu_b [N*Cout] (both or neither; need xh3): x came out of a ConvLayer's norm + ReLU (in_conv, utae.py:453-520)
+ * whose pre-norm output is xh3: the ReLU backward is applied here, out *= [relu_a*xh3 + relu_b > 0], and part gets the
+ * statistics of the masked output for that norm's backward. */
 int uncr_pw_gemm_dx_supported(int Cin, int Cout);
 int uncr_pw_gemm_dx(const float* in, const float* in2, const float* Wt, float* out, const float* k0, const float* k1,
                     const float* k2, const float* dy, const float* x, const float* xh3, const float* c1,
-                    const float* c2, const float* c3, float* part, int N, int Cin, int Cout, int P,
-                    hipStream_t stream);
+                    const float* c2, const float* c3, const float* relu_a, const float* relu_b, float* part, int N,
+                    int Cin, int Cout, int P, hipStream_t stream);
 /* R [N][Ch][C] = per-frame products sum_p du1n*x (uncr_pw_wgrad with the raw x); part_b / part_f = the (sum du1, .) and
  * (sum h1, .) partials [N*Ch][NPB|NPF][2] (part_f may be null: no c2 term); c1..c3 [N*Ch] = norm-1 backward
  * coefficients; A0, B0 [N*C] = PreNorm forward coefficients.  -> part0 [N*C][1][2] = (sum da, sum da*x), dW1 [Ch][C]. */

@@ -24,7 +24,8 @@ struct PwArgs {
     int epi;             // 0 none, 1 (sum, sum^2), 2 (sum, sum*aux), 3 fused pass-B + (sum, sum*aux), 4 accumulate,
                          // 5 skip + PreNorm backward: out = aux2 + e0*v + e1*aux + e2, statistics (sum, sum*aux3) if part
     const float* aux2;   // epi 5: dy
-    const float* aux3;   // epi 5: h3 of the producing block (or null: no statistics)
+    const float* aux3;   // epi 5: h3 of the producing block (or null: no statistics); epi 6: c0 of the producing ConvLayer,
+                         // whose ReLU backward is applied to the output: out *= [e3*aux3 + bias > 0] (bias, e3: [N*Cout])
 };
 
 // x = h + m + l exactly, each part a bf16 (kept in the upper half of a 32-bit word).  Truncation split: h takes

@@ -393,26 +393,36 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void pw_wgrad_kernel(WgArgs g) {
 
 // Reduce partials: out[f][co][ci] = sum over the blocks of frame-group f.  frames_per_out = N gives the
 // total gradient, 1 gives per-frame products (needed for the SE gradient).  fp64, fixed order.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nblk_per_out,
-                                                           int COP, int CIP, int Cout, int Cin,
-                                                           float* __restrict__ out) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= COP * CIP) return;
-    const int co = idx / CIP, ci = idx % CIP;
-    if (co >= Cout || ci >= Cin) return;
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, int nblk_per_out,
+                                                            int COP, int CIP, int Cout, int Cin,
+                                                            float* __restrict__ out) {
+    // block = 256 elements x 4 slices of the partial range (latency-bound: more loads in flight), fixed combination order
+    __shared__ double comb[4][256];
+    const int el = threadIdx.x & 255, sl = threadIdx.x >> 8;
+    const int idx = blockIdx.x * 256 + el;
     const size_t S = (size_t)COP * CIP;
-    const float* src = part + (size_t)blockIdx.y * nblk_per_out * S + idx;
+    const bool live = idx < COP * CIP;
     double s = 0.0;
-    int b = 0;
-    for (; b + 8 <= nblk_per_out; b += 8) {   // 8 independent loads in flight, summed in a fixed order
-        float v[8];
+    if (live) {
+        const float* src = part + (size_t)blockIdx.y * nblk_per_out * S + idx;
+        const int b1 = (nblk_per_out * (sl + 1)) / 4;
+        int b = (nblk_per_out * sl) / 4;
+        for (; b + 8 <= b1; b += 8) {   // 8 independent loads in flight, summed in a fixed order
+            float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(b + j) * S];
+            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(b + j) * S];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += (double)v[j];
+            for (int j = 0; j < 8; ++j) s += (double)v[j];
+        }
+        for (; b < b1; ++b) s += (double)src[(size_t)b * S];
     }
-    for (; b < nblk_per_out; ++b) s += (double)src[(size_t)b * S];
-    out[((size_t)blockIdx.y * Cout + co) * Cin + ci] = (float)s;
+    comb[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && live) {
+        const int co = idx / CIP, ci = idx % CIP;
+        if (co < Cout && ci < Cin)
+            out[((size_t)blockIdx.y * Cout + co) * Cin + ci] = (float)(((comb[0][el] + comb[1][el]) + comb[2][el]) + comb[3][el]);
+    }
 }
 
 // Wt[k][co] (zero padded [Kp][COUTP]) from W[co][k] (transpose=1) or W[k][co] (transpose=0), W row stride = ld
@@ -524,15 +534,16 @@ extern "C" int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, 
 extern "C" int uncr_pw_gemm_dx_supported(int Cin, int Cout) { return (use_split(Cout) && pw_coutp(Cout) == 128 && Cin <= 256) ? 1 : 0; }
 extern "C" int uncr_pw_gemm_dx(const float* in, const float* in2, const float* Wt, float* out, const float* k0,
                                const float* k1, const float* k2, const float* dy, const float* x, const float* xh3,
-                               const float* c1, const float* c2, const float* c3, float* part, int N, int Cin,
-                               int Cout, int P, hipStream_t stream) {
+                               const float* c1, const float* c2, const float* c3, const float* relu_a,
+                               const float* relu_b, float* part, int N, int Cin, int Cout, int P, hipStream_t stream) {
     if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
     if (!in || !in2 || !Wt || !out || !dy || !x || !c1 || !c2 || !c3) return UNCR_EINVAL;
     if (xh3 && !part) return UNCR_EINVAL;
+    if ((relu_a || relu_b) && !(relu_a && relu_b && xh3)) return UNCR_EINVAL;
     if (!uncr_pw_gemm_dx_supported(Cin, Cout)) return UNCR_EINVAL;
     if (P % uncr_pw_tile_px(Cout)) return UNCR_ESHAPE;
-    PwArgs g{in, in2, Wt, out, k0, k1, k2, nullptr, x, c1, c2, c3, c3, xh3 ? (float2*)part : nullptr, 0, Cin, Cout, P,
-             PRO_NORMBWD, 5, dy, xh3};
+    PwArgs g{in, in2, Wt, out, k0, k1, k2, relu_b, x, c1, c2, c3, relu_a ? relu_a : c3, xh3 ? (float2*)part : nullptr,
+             0, Cin, Cout, P, PRO_NORMBWD, relu_a ? 6 : 5, dy, xh3};
     return pw_split_launch_p3(g, N, pw_coutp(Cout), stream);
 }
 
@@ -600,7 +611,7 @@ extern "C" int uncr_pw_wgrad(const float* d, const float* d2, const float* x, co
 extern "C" int uncr_wgrad_reduce(const float* part, int n_out, int nblk_per_out, int COP, int CIP, int Cout, int Cin,
                                  float* out, hipStream_t stream) {
     if (n_out <= 0 || nblk_per_out <= 0) return UNCR_ESHAPE;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((COP * CIP + 255) / 256, n_out), dim3(256), 0, stream, part,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((COP * CIP + 255) / 256, n_out), dim3(1024), 0, stream, part,
                        nblk_per_out, COP, CIP, Cout, Cin, out);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char xs[2][PWS_BUF];
     __shared__ float cf[3][256];
     __shared__ float red[COUTP][2];
-    __shared__ float ecf[(EPI == 3 || EPI == 5) ? 5 : 1][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D
+    __shared__ float ecf[(EPI == 3 || EPI == 5 || EPI == 6) ? 5 : 1][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar: row addresses stay in SGPRs
@@ -91,9 +91,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                 const int ci = n * Cout + cc;
                 ecf[1][c] = g.e0[ci]; ecf[2][c] = g.e1[ci]; ecf[3][c] = g.e2[ci]; ecf[4][c] = g.e3[ci];
             }
-            if constexpr (EPI == 5) {
+            if constexpr (EPI == 5 || EPI == 6) {
                 const int ci = n * Cout + cc;
                 ecf[1][c] = g.e0[ci]; ecf[2][c] = g.e1[ci]; ecf[3][c] = g.e2[ci];
+                if constexpr (EPI == 6) { ecf[0][c] = g.bias[ci]; ecf[4][c] = g.e3[ci]; }   // ReLU mask: e3*aux3 + bias > 0
             }
         }
     }
@@ -274,12 +275,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         auto row_of = [&](int ct, int r) { return (wn * CT + ct) * 32 + (r & 3) + 8 * (r >> 2); };   // + 4*kg per lane
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            constexpr int RB = EPI == 5 ? 4 : 8;     // rows per request batch (epi 5 reads three rows per output row)
+            constexpr int RB = (EPI == 5 || EPI == 6) ? 4 : 8;     // rows per request batch (epi 5 reads three rows per output row)
 #pragma unroll
             for (int rb = 0; rb < 16; rb += RB) {
-                float4 xa[(EPI == 2 || EPI == 3 || EPI == 4 || EPI == 5) ? RB : 1];
-                float4 xb[EPI == 5 ? RB : 1], xc[EPI == 5 ? RB : 1];
-                if constexpr (EPI == 5) {      // skip + PreNorm backward: x, dy, and the producing block's h3 (statistics)
+                float4 xa[(EPI == 2 || EPI == 3 || EPI == 4 || EPI == 5 || EPI == 6) ? RB : 1];
+                float4 xb[(EPI == 5 || EPI == 6) ? RB : 1], xc[(EPI == 5 || EPI == 6) ? RB : 1];
+                if constexpr (EPI == 5 || EPI == 6) {      // skip + PreNorm backward: x, dy, and the producing block's h3 (statistics)
                     const float* a3 = g.aux3 ? g.aux3 : g.aux2;
 #pragma unroll
                     for (int q = 0; q < RB; ++q) {
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                 for (int q = 0; q < RB; ++q) {
                     const int r = rb + q;
                     const int col = row_of(ct, r) + 4 * kg;
-                    const float bb = ecf[0][col];
+                    const float bb = EPI == 6 ? 0.f : ecf[0][col];
                     float4 v = make_float4(acc[0][ct][r] + bb, acc[1][ct][r] + bb, acc[2][ct][r] + bb, acc[3][ct][r] + bb);
                     float s0 = 0.f, s1 = 0.f;
                     if constexpr (EPI == 3) {
@@ -345,6 +346,17 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                         v.y = y.y + fmaf(e1, v.y, fmaf(e2, x.y, e3));
                         v.z = y.z + fmaf(e1, v.z, fmaf(e2, x.z, e3));
                         v.w = y.w + fmaf(e1, v.w, fmaf(e2, x.w, e3));
+                        s0 = v.x + v.y + v.z + v.w;
+                        s1 = v.x * h.x + v.y * h.y + v.z * h.z + v.w * h.w;
+                    } else if constexpr (EPI == 6) {
+                        // as 5, then the producing ConvLayer's ReLU backward: du0 = dx * [rA*c0 + rB > 0], aux3 = c0
+                        const float4 x = xa[q], y = xb[q], h = xc[q];
+                        const float e1 = ecf[1][col], e2 = ecf[2][col], e3 = ecf[3][col];
+                        const float rA = ecf[4][col], rB = ecf[0][col];
+                        v.x = fmaf(rA, h.x, rB) > 0.f ? y.x + fmaf(e1, v.x, fmaf(e2, x.x, e3)) : 0.f;
+                        v.y = fmaf(rA, h.y, rB) > 0.f ? y.y + fmaf(e1, v.y, fmaf(e2, x.y, e3)) : 0.f;
+                        v.z = fmaf(rA, h.z, rB) > 0.f ? y.z + fmaf(e1, v.z, fmaf(e2, x.z, e3)) : 0.f;
+                        v.w = fmaf(rA, h.w, rB) > 0.f ? y.w + fmaf(e1, v.w, fmaf(e2, x.w, e3)) : 0.f;
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * h.x + v.y * h.y + v.z * h.z + v.w * h.w;
                     }
@@ -380,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     if constexpr (EPI != 0 && EPI != 4) {
         // one statistics slot per block (its tiles were summed in a fixed order): G slots per frame instead of P/128
         __syncthreads();
-        if (EPI != 5 || g.part)
+        if ((EPI != 5 && EPI != 6) || g.part)
             for (int c = tid; c < COUTP; c += NT)
                 if (c < Cout) g.part[((size_t)n * Cout + c) * G + bx] = make_float2(red[c][0], red[c][1]);
     }
@@ -517,6 +529,10 @@ int PWS_CAT(pw_split_launch_p, PWS_PRO)(const PwArgs& g, int N, int cp, hipStrea
         case 5:      // the backward of pw1 only: 256 -> 128 channels
             if (cp != 128) return UNCR_EINVAL;
             hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 5, 2>), grid, dim3(256), 0, stream, g);
+            break;
+        case 6:
+            if (cp != 128) return UNCR_EINVAL;
+            hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 6, 2>), grid, dim3(256), 0, stream, g);
             break;
 #endif
         default: return UNCR_EINVAL;

@@ -51,6 +51,7 @@ class Part:
     """Per-block partial statistics float2[N*C][slots] emitted by a producer kernel."""
     buf: Tensor
     slots: int
+    masked: bool = False     # backward partials of a gradient that already carries the producer's ReLU mask (in_conv)
 
 
 @dataclass
@@ -396,11 +397,15 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         g["n0w"], g["n0b"] = b0.dgamma, b0.dbeta
         dx = _f32((N, C, H, W), dev)
         x_h3 = sv.get("x_h3")
+        relu = sv.get("x_relu")       # x = relu(A*c0 + B) of in_conv: its ReLU backward and norm statistics ride along
+        ra = rb = None
+        if relu is not None:
+            x_h3, ra, rb = relu
         dx_part = None
         if x_h3 is not None:
             slots = hb.query("uncr_pw_stat_slots", N, C, P)
-            dx_part = Part(_f32((N * C, slots, 2), dev), slots)
-        hb.call("uncr_pw_gemm_dx", du1, h1, W1k, dx, k1[0], k1[1], k1[2], dy, x, x_h3, b0.c1, b0.c2, b0.c3,
+            dx_part = Part(_f32((N * C, slots, 2), dev), slots, masked=relu is not None)
+        hb.call("uncr_pw_gemm_dx", du1, h1, W1k, dx, k1[0], k1[1], k1[2], dy, x, x_h3, b0.c1, b0.c2, b0.c3, ra, rb,
                 dx_part.buf if dx_part is not None else None, N, Ch, C, P, _stream())
         return dx, g, dx_part
 
@@ -554,13 +559,18 @@ def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec
     return a0, dict(x=x, c0=c0, nf=nf, dims=(N, Cin, Cout, H, W)), parta
 
 
-def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool):
+def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool, masked_part: Optional[Part] = None):
+    """masked_part: da0 is already du0 = da0 * [relu mask] and these are its (sum du0, sum du0*c0) partials (the consumer's
+    backward GEMM applied the mask in its epilogue, uncr_pw_gemm_dx)."""
     N, Cin, Cout, H, W = sv["dims"]
     P = H * W
     nf, c0, x = sv["nf"], sv["c0"], sv["x"]
     da0 = da0.contiguous()
-    du0 = _f32((N, Cout, H, W), da0.device)
-    _, part = ew(EW_RELU_BWD, da0, b=c0, out=du0, k=(nf.A, nf.B, None, None), want_part=True, planes=N * Cout, P=P)
+    if masked_part is not None:
+        du0, part = da0, masked_part
+    else:
+        du0 = _f32((N, Cout, H, W), da0.device)
+        _, part = ew(EW_RELU_BWD, da0, b=c0, out=du0, k=(nf.A, nf.B, None, None), want_part=True, planes=N * Cout, P=P)
     nb = norm_bwd(part, N, Cout, P, nf, gw)
     kk = (nb.c1, nb.c2, nb.c3)
     dW, db = pw_wgrad(du0, x, N, Cout, Cin, P, pro_d=PRO_NORMBWD, dk=kk, d2=c0, rowsum=True)

@@ -66,6 +66,7 @@ class _MBConvFn(torch.autograd.Function):
         y, sv, party = E.mbconv_forward(x, p, module._spec, module.training, getattr(x, "_uncr_part", None),
                                         module._bn_buffers(), want_out_stats=True,
                                         x_h3=getattr(x, "_uncr_h3", None), pool=getattr(x, "_uncr_pool", None))
+        sv["x_relu"] = getattr(x, "_uncr_relu", None)     # x is in_conv's relu(norm(c0)): (c0, A, B)
         ctx.sv, ctx.p = sv, p
         y._uncr_part = party        # (sum y, sum y^2) partials for the next PreNorm
         y._uncr_pooled = sv.pop("ypool")   # (max-pooled y, argmax) when the L-TAE stage asked for it
@@ -77,7 +78,7 @@ class _MBConvFn(torch.autograd.Function):
         # when dy comes straight from the consumer's backward kernel it carries (sum dy, sum dy*h3) partials
         part = getattr(dy, "_uncr_bpart", None)
         N, C, _, _, H, W = ctx.sv["dims"]
-        if part is not None and part.buf.shape[0] != N * C:
+        if part is not None and (part.buf.shape[0] != N * C or part.masked):
             part = None
         dx, g, dx_part = E.mbconv_backward(dy, ctx.sv, ctx.p, need_dx=ctx.needs_input_grad[0], dy_part=part)
         if dx is not None and dx_part is not None:
@@ -478,21 +479,18 @@ class UNCRTAINTS(nn.Module):
             if nbt:
                 torch._foreach_add_(nbt, 1)
         pad = E.pad_mask_of(input, float(self.pad_value))                  # [B,T] int32, uncrtaints.py:392-394
-        out = self.in_conv.smart_forward(input)                            # [B,T,C,H,W]
-        part, pooled = None, None
+        # the encoder runs on the folded [B*T, C, H, W] frames (smart_forward, utae.py:422-450) without autograd views
+        # between its blocks, so the statistics / masks that ride on the tensors survive in both directions
+        b, t, _, h, w = input.shape
+        x4 = self.in_conv(input.view(b * t, input.shape[2], h, w))
+        pooled = None
         for li, layer in enumerate(self.in_block):
-            b, t, c, h, w = out.shape
-            x4 = out.view(b * t, c, h, w)
-            if part is not None:
-                x4._uncr_part = part
-            elif hasattr(out, "_uncr_part"):
-                x4._uncr_part = out._uncr_part
             if li == len(self.in_block) - 1 and not self.is_mono and h % 32 == 0 and w % 32 == 0:
                 x4._uncr_pool = 32          # the stage's 32x32 max-pool rides on the last encoder block's residual kernel
-            y4 = layer(x4)
-            part = getattr(y4, "_uncr_part", None)
-            pooled = getattr(y4, "_uncr_pooled", None)
-            out = y4.view(b, t, c, h, w)
+            x4 = layer(x4)
+            pooled = getattr(x4, "_uncr_pooled", None)
+        part = getattr(x4, "_uncr_part", None)
+        out = x4.view(b, t, x4.shape[1], h, w)
         if pooled is not None:
             out._uncr_pooled = pooled
         if not self.is_mono:

@@ -48,12 +48,16 @@ class _ConvNormActFn(torch.autograd.Function):
         ctx.sv, ctx.layer = sv, layer
         ctx.params = (w, gw)
         a0._uncr_part = part
+        a0._uncr_relu = (sv["c0"], sv["nf"].A, sv["nf"].B)   # lets the consumer's backward apply this ReLU's mask
         return a0
 
     @staticmethod
     def backward(ctx, da):
         w, gw = ctx.params
-        dx, dW, db, dgw, dgb = E.inconv_backward(da, ctx.sv, w, gw, ctx.needs_input_grad[0])
+        part = getattr(da, "_uncr_bpart", None)        # set when the consumer's backward already applied the ReLU mask
+        if part is not None and not (part.masked and part.buf.shape[0] == da.shape[0] * da.shape[1]):
+            part = None
+        dx, dW, db, dgw, dgb = E.inconv_backward(da, ctx.sv, w, gw, ctx.needs_input_grad[0], masked_part=part)
         return dx, dW, db, dgw, dgb, None
 
 
