@@ -69,6 +69,16 @@ int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, 
                            float* c2, float* c3, float* dgamma, float* dbeta, float* scratch /* [2*N*C], GroupNorm */,
                            int centered /* 1: part.y = sum du*(h - mean) (uncr_dw_bwd with a mean array) */,
                            hipStream_t stream);
+/* Synchronised BatchNorm for data parallelism (train mode): per-channel fp64 sums of the local partials -> the host
+ * layer all-reduces them (RCCL) -> coefficients from the GLOBAL sums and element count; d gamma / d beta from the LOCAL
+ * sums (they are averaged with the other gradients).  sums: [C][2] doubles = (S1, S2) in the partials' meaning. */
+int uncr_bn_channel_sums(const float* part, int NP, int N, int C, double* sums, hipStream_t stream);
+int uncr_bn_finalize_fwd_sums(const double* sums, double count, int N, int C, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* coefA,
+                              float* coefB, float* save_mean, float* save_rstd, hipStream_t stream);
+int uncr_bn_finalize_bwd_sums(const double* sums_local, const double* sums_global, double count, int N, int C,
+                              const float* gamma, const float* save_mean, const float* save_rstd, float* c1, float* c2,
+                              float* c3, float* dgamma, float* dbeta, int centered, hipStream_t stream);
 
 /* ---- element-wise family with fused coefficients + partial statistics
  *      (norm-apply/ReLU utae.py:470-494; residual add uncrtaints.py:142-146; SE avg-pool uncrtaints.py:85,95;

@@ -40,19 +40,22 @@ def _grads(m, rank):
     return l
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, sync_bn=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from uncrtaints_amd.parallel import BucketedDataParallel
     m = _model()
-    dp = BucketedDataParallel(m, seed=1)
-    for _ in range(2):
+    dp = BucketedDataParallel(m, seed=1, sync_bn=sync_bn)
+    for _ in range(1 if sync_bn else 2):
         dp.zero_grad()
         _grads(m, rank)
         dp.finish()
     torch.cuda.synchronize()
-    q.put((rank, {n: p.grad.detach().cpu().numpy() for n, p in m.named_parameters()}))   # by value (numpy)
+    res = {n: p.grad.detach().cpu().numpy() for n, p in m.named_parameters()}
+    if sync_bn:
+        res.update({"buf/" + n: b.detach().cpu().numpy() for n, b in m.named_buffers() if "running" in n})
+    q.put((rank, res))   # by value (numpy)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -91,3 +94,39 @@ def test_two_ranks_average_shard_gradients():
         worst = max(worst, (res[0][n] - ref[n]).abs().max().item() / scale)
     print(f"[parity] ddp 2 ranks vs sequential shards: worst rel err {worst:.3e}")
     assert worst < 1e-4
+
+
+def test_two_ranks_with_sync_bn_equal_one_process_on_the_concatenated_batch():
+    """sync_bn=True: BatchNorm sums are all-reduced in forward and backward, so two ranks with one sample
+    each give the gradients and running statistics of ONE process on the 2-sample batch -- with the loss taken per
+    replica-sized group (the MGNLL log-det is summed over the local batch, F10) and averaged."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    res = {r: {n: torch.from_numpy(a) for n, a in d.items()} for r, d in res.items()}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    from uncrtaints_amd.src import losses
+    m = _model()
+    xs, ys, ds = zip(*(_shard(r) for r in range(world)))
+    out = m(torch.cat(xs), batch_positions=torch.cat(ds))
+    crit = losses.MultiGaussianNLLLoss(reduction="mean", full=True, mode="diag")
+    loss = sum(crit(out[r:r + 1, :, :13], ys[r], out[r:r + 1, :, 13:26])[0] for r in range(world)) / world
+    loss.backward()
+    ref = {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
+    ref.update({"buf/" + n: b.detach().cpu() for n, b in m.named_buffers() if "running" in n})
+    worst = 0.0
+    for n in ref:
+        if not n.startswith("buf/"):
+            assert torch.equal(res[0][n], res[1][n]), n
+        scale = ref[n].abs().max().item()
+        if scale == 0:
+            continue
+        worst = max(worst, (res[0][n] - ref[n]).abs().max().item() / scale)
+    print(f"[parity] ddp 2 ranks + sync_bn vs one process on the concatenated batch: worst rel err {worst:.3e}")
+    assert worst < 2e-4

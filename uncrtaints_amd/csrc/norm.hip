@@ -311,6 +311,100 @@ extern "C" int uncr_prenorm_bwd_finish(const float* R, const float* W1, const fl
     return UNCR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Synchronised BatchNorm under data parallelism ("offer sync_bn").  The per-channel sums leave the
+// device-local partials as fp64 pairs, are all-reduced by the host layer (RCCL), and the coefficients are derived from
+// the GLOBAL sums; d gamma / d beta stay LOCAL sums (the gradient all-reduce averages them like every other gradient).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_channel_sums_kernel(const float2* __restrict__ part, int NP, int N, int C,
+                                                              double* __restrict__ sums) {
+    const int c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < N * NP; i += 256) {
+        const int n = i / NP, j = i - n * NP;
+        const float2 v = part[((size_t)n * C + c) * NP + j];
+        a += (double)v.x;
+        b += (double)v.y;
+    }
+    __shared__ double red[8];
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sums[2 * c] = (red[0] + red[2]) + (red[4] + red[6]);
+        sums[2 * c + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+}
+
+// grid = ceil(C/256): one thread per channel (the work is a handful of flops; N coefficient copies per channel)
+__global__ __launch_bounds__(256) void bn_finalize_fwd_sums_kernel(
+    const double* __restrict__ sums, double M, int N, int C, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+    float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ save_mean,
+    float* __restrict__ save_rstd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[2 * c] / M;
+    double var = sums[2 * c + 1] / M - mean * mean;
+    if (var < 0) var = 0;
+    const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = mf;
+    save_rstd[c] = rf;
+    if (running_mean) {
+        const double unb = var * (M / (M > 1 ? M - 1 : 1));
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+    const float a = gamma[c] * rf, b = beta[c] - mf * a;
+    for (int n = 0; n < N; ++n) { coefA[n * C + c] = a; coefB[n * C + c] = b; }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_bwd_sums_kernel(
+    const double* __restrict__ loc, const double* __restrict__ glob, double M, int N, int C,
+    const float* __restrict__ gamma, const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+    float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int centered) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mu = (double)save_mean[c], r = (double)save_rstd[c], gm = (double)gamma[c];
+    dgamma[c] = (float)(r * (centered ? loc[2 * c + 1] : loc[2 * c + 1] - mu * loc[2 * c]));
+    dbeta[c] = (float)loc[2 * c];
+    const double S1 = glob[2 * c], dg = r * (centered ? glob[2 * c + 1] : glob[2 * c + 1] - mu * S1);
+    const double m1 = gm * S1 / M, m2 = gm * dg / M;
+    const float k1 = (float)(r * gm), k2 = (float)(-r * r * m2), k3 = (float)(r * (-m1 + r * mu * m2));
+    for (int n = 0; n < N; ++n) { c1[n * C + c] = k1; c2[n * C + c] = k2; c3[n * C + c] = k3; }
+}
+
+extern "C" int uncr_bn_channel_sums(const float* part, int NP, int N, int C, double* sums, hipStream_t stream) {
+    if (!part || !sums || NP <= 0 || N <= 0 || C <= 0) return UNCR_EINVAL;
+    hipLaunchKernelGGL(bn_channel_sums_kernel, dim3(C), dim3(256), 0, stream, (const float2*)part, NP, N, C, sums);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+extern "C" int uncr_bn_finalize_fwd_sums(const double* sums, double count, int N, int C, const float* gamma,
+                                         const float* beta, float* running_mean, float* running_var, float momentum,
+                                         float eps, float* coefA, float* coefB, float* save_mean, float* save_rstd,
+                                         hipStream_t stream) {
+    if (!sums || count <= 0 || N <= 0 || C <= 0 || !gamma || !beta || !coefA || !coefB || !save_mean || !save_rstd)
+        return UNCR_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_fwd_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, count, N, C,
+                       gamma, beta, running_mean, running_var, momentum, eps, coefA, coefB, save_mean, save_rstd);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+extern "C" int uncr_bn_finalize_bwd_sums(const double* sums_local, const double* sums_global, double count, int N,
+                                         int C, const float* gamma, const float* save_mean, const float* save_rstd,
+                                         float* c1, float* c2, float* c3, float* dgamma, float* dbeta, int centered,
+                                         hipStream_t stream) {
+    if (!sums_local || !sums_global || count <= 0 || N <= 0 || C <= 0 || !gamma || !save_mean || !save_rstd) return UNCR_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_bwd_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums_local,
+                       sums_global, count, N, C, gamma, save_mean, save_rstd, c1, c2, c3, dgamma, dbeta, centered);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
 extern "C" int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                                       const float* gamma, const float* beta, float* running_mean,
                                       float* running_var, float momentum, float eps, float* coefA, float* coefB,

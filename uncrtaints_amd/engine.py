@@ -102,6 +102,24 @@ class NormFwd:
     rstd: Tensor
     kind: int
     groups: int
+    sync_count: float = 0.0     # > 0: BatchNorm statistics were all-reduced over the data-parallel group (global count)
+
+
+_SYNC_BN = None      # process group for synchronised BatchNorm statistics (None: per-replica statistics, torch-DDP default)
+
+
+def set_sync_bn(group) -> None:
+    """group: a torch.distributed process group (e.g. dist.group.WORLD) or None.  With a group, every train-mode BatchNorm
+    on the path all-reduces its per-channel (sum, sum^2) and, in backward, (sum du, sum du*h): N ranks then compute what one
+    process would on the concatenated batch.  Equal local batch sizes are assumed."""
+    global _SYNC_BN
+    _SYNC_BN = group
+
+
+def _all_reduce_sums(sums: Tensor) -> float:
+    import torch.distributed as dist
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_SYNC_BN)
+    return float(dist.get_world_size(_SYNC_BN))
 
 
 def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, training: bool, gamma: Tensor,
@@ -112,6 +130,13 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
     A, B = _f32((N * C,), dev), _f32((N * C,), dev)
     nstat = N * spec.groups if kind == NORM_GROUP else C
     mean, rstd = _f32((nstat,), dev), _f32((nstat,), dev)
+    if kind == NORM_BATCH_TRAIN and _SYNC_BN is not None:
+        sums = torch.empty((C, 2), device=dev, dtype=torch.float64)
+        hb.call("uncr_bn_channel_sums", part.buf, part.slots, N, C, sums, _stream())
+        count = _all_reduce_sums(sums) * N * P
+        hb.call("uncr_bn_finalize_fwd_sums", sums, count, N, C, gamma, beta, running_mean, running_var, float(momentum),
+                float(eps), A, B, mean, rstd, _stream())
+        return NormFwd(A, B, mean, rstd, kind, spec.groups, sync_count=count)
     hb.call("uncr_norm_finalize_fwd", part.buf if part else None, part.slots if part else 0, N, C, spec.groups, P,
             kind, gamma, beta, running_mean, running_var, float(momentum), float(eps), A, B, mean, rstd, _stream())
     return NormFwd(A, B, mean, rstd, kind, spec.groups)
@@ -131,6 +156,14 @@ def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor, cen
     dev = gamma.device
     c1, c2, c3 = _f32((N * C,), dev), _f32((N * C,), dev), _f32((N * C,), dev)
     dg, db = _f32((C,), dev), _f32((C,), dev)
+    if nf.kind == NORM_BATCH_TRAIN and nf.sync_count > 0:
+        loc = torch.empty((C, 2), device=dev, dtype=torch.float64)
+        hb.call("uncr_bn_channel_sums", part.buf, part.slots, N, C, loc, _stream())
+        glob = loc.clone()
+        _all_reduce_sums(glob)
+        hb.call("uncr_bn_finalize_bwd_sums", loc, glob, nf.sync_count, N, C, gamma, nf.mean, nf.rstd, c1, c2, c3, dg, db,
+                1 if centered else 0, _stream())
+        return NormBwd(c1, c2, c3, dg, db)
     scratch = _f32((2 * N * C,), dev) if nf.kind == NORM_GROUP else None
     hb.call("uncr_norm_finalize_bwd", part.buf, part.slots, N, C, nf.groups, P, nf.kind, gamma, nf.mean, nf.rstd,
             c1, c2, c3, dg, db, scratch, 1 if centered else 0, _stream())

@@ -18,6 +18,7 @@ _CTYPES = {
     "float": ctypes.c_float,
     "unsigned long long": ctypes.c_ulonglong,
     "long long": ctypes.c_longlong,
+    "double": ctypes.c_double,
     "hipStream_t": ctypes.c_void_p,
 }
 
@@ -86,7 +87,7 @@ def _ptr(x):
         raise RuntimeError("uncrtaints_amd kernels need tensors on the GPU (cuda device); there is no CPU path")
     if not x.is_contiguous():
         raise RuntimeError("uncrtaints_amd kernels need contiguous tensors")
-    if x.dtype not in (torch.float32, torch.int32, torch.int64):
+    if x.dtype not in (torch.float32, torch.float64, torch.int32, torch.int64):
         raise RuntimeError(f"unsupported dtype {x.dtype}")
     return x.data_ptr()
 

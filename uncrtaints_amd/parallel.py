@@ -4,7 +4,8 @@ as soon as their last gradient is produced -- i.e. overlapped with the rest of t
 
 The reference has no distributed code at all; semantics follow torch-DDP defaults:
   * gradients are averaged over ranks;
-  * BatchNorm statistics and the batch-summed MGNLL log-det (SURVEY F10) are per replica;
+  * BatchNorm statistics and the batch-summed MGNLL log-det are per replica -- `sync_bn=True` all-reduces the
+    BatchNorm sums (forward and backward) instead, so N ranks compute what one process would on the concatenated batch;
   * BatchNorm buffers are broadcast from rank 0 at construction (and on demand via `sync_buffers`);
   * the aggregator's dropout stream is decorrelated per rank (seed + rank).
 
@@ -32,12 +33,14 @@ def default_buckets(named_params) -> List[List[str]]:
 
 class BucketedDataParallel:
     def __init__(self, module: torch.nn.Module, buckets: Optional[Sequence[Sequence[str]]] = None,
-                 process_group=None, seed: int = 0, overlap: bool = True):
+                 process_group=None, seed: int = 0, overlap: bool = True, sync_bn: bool = False):
         """overlap=True: all-reduces are launched from autograd hooks during backward.  overlap=False: nothing is
         launched from hooks and `finish()` reduces all buckets -- for a forward/backward that is replayed from a
         captured HIP graph (hooks do not run on replay, and collectives are kept out of the capture)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
+        from . import engine
+        engine.set_sync_bn((process_group or dist.group.WORLD) if sync_bn else None)
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
