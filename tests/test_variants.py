@@ -131,11 +131,13 @@ def test_iso_ensemble_inference_config5():
         with torch.no_grad():
             out = m(dev(x), batch_positions=dev(dates))
         close(f"member{member}", out, o)
-        mus.append(out[:, 0, :13].contiguous()); vs.append(out[:, 0, 13:14].expand(-1, 13, -1, -1).contiguous())
+        mus.append(out[:, 0, :13].contiguous()); vs.append(out[:, 0, 13:14])      # one variance channel: broadcast by the wrapper
     mu_e, var_e = E.ensemble_combine(torch.stack(mus), torch.stack(vs), "both")
     mu_o, var_o = orc.ensemble_combine(torch.stack(mus_o), torch.stack(vs_o), "both")
     close("ensemble_mean", mu_e, mu_o)
     close("ensemble_var", var_e, var_o, tol=2e-4)
+    with pytest.raises(ValueError):
+        E.ensemble_combine(torch.stack(mus), torch.stack(vs)[:, :, :, :7], "both")
 
 
 # ---- use_v (LTAE2d values + include_v): fixture g12_usev generated from the reference ----

@@ -1052,6 +1052,13 @@ def ensemble_combine(means: Tensor, variances: Optional[Tensor], mode: str = "bo
     """means/variances [M, ...] -> (mean_ens, var_ens) (ensemble_reconstruct.py:116-133)."""
     M = means.shape[0]
     n = means[0].numel()
+    if variances is not None and variances.shape != means.shape:
+        # isotropic members carry one variance channel: broadcast it over the bands like the reference's numpy code does
+        try:
+            variances = variances.expand_as(means)
+        except RuntimeError:
+            raise ValueError(f"ensemble_combine: variances {tuple(variances.shape)} do not broadcast to means "
+                             f"{tuple(means.shape)}") from None
     mu, v = torch.empty_like(means[0]), torch.empty_like(means[0])
     code = {"both": 0, "aleatoric": 1, "epistemic": 2}[mode]
     hb.call("uncr_ensemble_combine", means.contiguous(), variances.contiguous() if variances is not None else None, M,
