@@ -467,6 +467,11 @@ class UNCRTAINTS(nn.Module):
         if not input.is_cuda:
             raise RuntimeError("uncrtaints_amd.UNCRTAINTS runs on the GPU only (HIP kernels); move the model and "
                                "the inputs to the cuda device")
+        conv0 = self.in_conv.conv.conv[0]
+        if input.dim() != 5 or input.shape[2] != conv0.in_channels:
+            raise ValueError(f"expected input [B, T, {conv0.in_channels}, H, W], got {tuple(input.shape)}")
+        if batch_positions is not None and tuple(batch_positions.shape) != tuple(input.shape[:2]):
+            raise ValueError(f"batch_positions {tuple(batch_positions.shape)} must be [B, T] = {tuple(input.shape[:2])}")
         input = input.contiguous().float()
         E.prepack(self._pack_list())                                       # every 1x1-conv weight, one launch
         if self.training:

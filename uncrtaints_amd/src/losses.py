@@ -43,6 +43,11 @@ def multi_gaussian_nll_loss(input: Tensor, target: Tensor, var: Tensor, full: bo
         raise NotImplementedError(f"MGNLL mode '{mode}' is not built (diag | iso)")
     if input.dim() != 5 or input.shape[1] != 1:
         raise ValueError("expected [B,1,C,H,W] tensors")
+    if target.shape != input.shape:
+        raise ValueError(f"target {tuple(target.shape)} and input {tuple(input.shape)} differ in shape")
+    if var.dim() != 5 or var.shape[:2] != input.shape[:2] or var.shape[3:] != input.shape[3:] \
+            or (var.shape[2] != input.shape[2] and (mode != "iso" or var.shape[2] < 1)):
+        raise ValueError(f"var {tuple(var.shape)} does not match input {tuple(input.shape)} (mode '{mode}')")
     if mode == "iso" and var.shape[2] != 1:
         var = var[:, :, :1]
     loss = _MGNLLFn.apply(input, target, var, float(eps), reduction, bool(check_negative))
@@ -74,6 +79,9 @@ class _EltLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, kind, pred, target, var, eps, full, reduction, check_negative):
+        if target.shape != pred.shape or (var is not None and var.shape != pred.shape):
+            raise ValueError(f"loss operands differ in shape: input {tuple(pred.shape)}, target {tuple(target.shape)}"
+                             + (f", var {tuple(var.shape)}" if var is not None else ""))
         pred_c, targ_c = pred.contiguous().float(), target.contiguous().float()
         var_c = var.contiguous().float() if var is not None else None
         loss, vclamp = E.eltloss_forward(kind, pred_c, targ_c, var_c, eps, full, reduction, check_negative)
