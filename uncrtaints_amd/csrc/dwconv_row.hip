@@ -5,6 +5,7 @@
 // window rows.  No LDS, no barriers, two rows of loads in flight per wave, 2/64 halo rows instead of 2/16 -- the
 // same math as the LDS-tiled kernels in dwconv.hip (kept for other widths), restated per row.
 #include "common.h"
+#include <cstdlib>
 
 #define DWR_TR 64
 
@@ -117,14 +118,14 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
     const float* __restrict__ cA1, const float* __restrict__ cB1, const float* __restrict__ w,
     float* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
-    const float* __restrict__ mean1, int mean_groups, int C, int H, int planes, int slots) {
+    const float* __restrict__ mean1, int mean_groups, int C, int H, int planes, int slots, int tiles) {
     constexpr int W = 256;
     const int lane = threadIdx.x & 63;
-    const int tiles = (H + DWR_TR - 1) / DWR_TR;
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (wid >= planes * tiles) return;
     const int plane = wid / tiles, tile = wid - plane * tiles, c = plane % C;
-    const int y0 = tile * DWR_TR, y1 = min(H, y0 + DWR_TR);
+    // the plane's `slots` 16-row units are dealt to `tiles` waves as evenly as possible
+    const int y0 = min(H, ((slots * tile) / tiles) << 4), y1 = min(H, ((slots * (tile + 1)) / tiles) << 4);
     const float C1 = k1[plane], C2 = k2[plane], C3 = k3[plane];
     const float A1 = cA1[plane], B1 = cB1[plane];
     // second statistic sum du1*(h1 - M1): with M1 = the norm's mean it is free of the |mean|/std cancellation
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
             float rg[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) rg[i] = wave_sum_dpp(gw[i]);
-            const int sl = tile * (DWR_TR / 16) + ((Y - y0) >> 4);
+            const int sl = Y >> 4;                          // y0 is a multiple of 16
             if (lane == 63 && sl < slots) {
                 const size_t slot = (size_t)plane * slots + sl;
                 part[slot] = make_float2(r0, r1);
@@ -259,18 +260,6 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
             s0 = 0.f; s1 = 0.f;
 #pragma unroll
             for (int i = 0; i < 9; ++i) gw[i] = 0.f;
-        }
-    }
-    // slots of a partial last tile that received no rows
-    if (lane == 63) {
-        const int used = (y1 - y0 + 15) >> 4;
-        for (int k = used; k < DWR_TR / 16; ++k) {
-            const int sl = tile * (DWR_TR / 16) + k;
-            if (sl < slots) {
-                const size_t slot = (size_t)plane * slots + sl;
-                part[slot] = make_float2(0.f, 0.f);
-                for (int i = 0; i < 9; ++i) dw_part[slot * 9 + i] = 0.f;
-            }
         }
     }
 }
@@ -288,9 +277,14 @@ int dw_bwd_row_launch(const float* du2, const float* h2, const float* h1, const 
                       const float* k3, const float* cA1, const float* cB1, const float* w, float* du1, float* part,
                       float* dw_part, const float* mean1, int mean_groups, int N, int C, int H, int slots,
                       hipStream_t stream) {
-    const int planes = N * C, tiles = (H + DWR_TR - 1) / DWR_TR;
+    const int planes = N * C;
+    // 64-row tiles (2 halo rows per 64).  Measured: 2 ... 8 tiles per 256-row plane are all within 3 % of each other (the
+    // kernel is bound by the memory system, not by how the waves fill the chip); UNCR_DW_TILES overrides for experiments.
+    int tiles = (slots + DWR_TR / 16 - 1) / (DWR_TR / 16);
+    if (const char* ov = getenv("UNCR_DW_TILES"))
+        if (atoi(ov) > 0 && atoi(ov) <= slots) tiles = atoi(ov);
     hipLaunchKernelGGL(dw_bwd_row_kernel, dim3((planes * tiles + 3) / 4), dim3(256), 0, stream, du2, h2, h1, k1, k2,
-                       k3, cA1, cB1, w, du1, (float2*)part, dw_part, mean1, mean_groups, C, H, planes, slots);
+                       k3, cA1, cB1, w, du1, (float2*)part, dw_part, mean1, mean_groups, C, H, planes, slots, tiles);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
