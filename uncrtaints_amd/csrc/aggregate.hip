@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
         float4 acc[CH];                 // fwd: output accumulators; bwd: dg of the head's channels
 #pragma unroll
         for (int jc = 0; jc < CH; ++jc) {
-            if constexpr (BWD) acc[jc] = *(const float4*)(g.dg + ((size_t)b * g.C + h * CH + jc) * P + p0);
+            if constexpr (BWD) acc[jc] = ld_nt4(g.dg + ((size_t)b * g.C + h * CH + jc) * P + p0);
             else acc[jc] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         for (int t = 0; t < g.T; ++t) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
 #pragma unroll
             for (int jc = 0; jc < CH; ++jc) {
                 const size_t eo = (((size_t)b * g.T + t) * g.C + h * CH + jc) * P + p0;
-                const float4 ev = *(const float4*)(g.e + eo);
+                const float4 ev = ld_nt4(g.e + eo);
                 if constexpr (!BWD) {
                     acc[jc].x = fmaf(a[0], ev.x, acc[jc].x);
                     acc[jc].y = fmaf(a[1], ev.y, acc[jc].y);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
                     acc[jc].w = fmaf(a[3], ev.w, acc[jc].w);
                 } else {
                     const float4 dgv = acc[jc];
-                    *(float4*)(g.de + eo) = make_float4(a[0] * dgv.x, a[1] * dgv.y, a[2] * dgv.z, a[3] * dgv.w);
+                    st_nt4(g.de + eo, make_float4(a[0] * dgv.x, a[1] * dgv.y, a[2] * dgv.z, a[3] * dgv.w));
                     d[0] = fmaf(dgv.x, ev.x, d[0]);
                     d[1] = fmaf(dgv.y, ev.y, d[1]);
                     d[2] = fmaf(dgv.z, ev.z, d[2]);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
             for (int jc = 0; jc < CH; ++jc) {
                 const int c = h * CH + jc;
                 const float4 o = acc[jc];
-                *(float4*)(g.out + ((size_t)b * g.C + c) * P + p0) = o;
+                st_nt4(g.out + ((size_t)b * g.C + c) * P + p0, o);
                 if (g.part) {
                     const float s0 = wave_sum_dpp(o.x + o.y + o.z + o.w);
                     const float s1 = wave_sum_dpp(o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w);

@@ -67,6 +67,32 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
+// 16-byte accesses for tensors that are streamed once.  A translation unit opts in to the non-temporal form with
+// `#define UNCR_NT 1` before this header.  Measured per kernel family inside the training step (tools/ab_variants.sh,
+// one GPU session, 2 x 20 steps each): depthwise row kernels -0.30 ms/step (dw_bwd 0.22 -> 0.18-0.19 ms: the three input
+// streams no longer evict each other) -- ON; split GEMM activations/outputs +0.17 ms -- OFF; weight-gradient GEMM,
+// element-wise, aggregate and residual+pool kernels within +-0.06 ms (noise) -- OFF.
+#ifndef UNCR_NT
+#define UNCR_NT 0
+#endif
+typedef float uncr_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_nt4(const float* p) {
+#if UNCR_NT
+    const uncr_f4 v = __builtin_nontemporal_load((const uncr_f4*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *(const float4*)p;
+#endif
+}
+__device__ __forceinline__ void st_nt4(float* p, const float4& v) {
+#if UNCR_NT
+    const uncr_f4 q = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(q, (uncr_f4*)p);
+#else
+    *(float4*)p = v;
+#endif
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
     const int plane = blockIdx.y;
     const size_t off = (size_t)plane * g.P + (size_t)blockIdx.x * EW_CHUNK + threadIdx.x * 4;
     float s0 = 0.f, s1 = 0.f;
-    float4 va = *(const float4*)(g.a + off);
+    float4 va = ld_nt4(g.a + off);
     float4 vo;
     float* o = (float*)&vo;
     const float* pa = (const float*)&va;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s0 += pa[i]; s1 += pa[i] * pa[i]; }
     } else if constexpr (OP == EW_STATS_AUX) {
-        const float4 vb = *(const float4*)(g.b + off);
+        const float4 vb = ld_nt4(g.b + off);
         const float* pb = (const float*)&vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s0 += pa[i]; s1 += pa[i] * pb[i]; }
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         }
     } else if constexpr (OP == EW_RESIDUAL) {
         const float A = g.k0[plane], B = g.k1[plane];
-        const float4 vb = *(const float4*)(g.b + off);
+        const float4 vb = ld_nt4(g.b + off);
         const float* pb = (const float*)&vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -74,13 +74,13 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         }
     } else if constexpr (OP == EW_RESIDUAL_RELU) {
         const float A = g.k0[plane], B = g.k1[plane];
-        const float4 vb = *(const float4*)(g.b + off);
+        const float4 vb = ld_nt4(g.b + off);
         const float* pb = (const float*)&vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = pa[i] + fmaxf(fmaf(A, pb[i], B), 0.f);
     } else if constexpr (OP == EW_PASSB) {
         const float A = g.k0[plane], B = g.k1[plane], S = g.k2[plane], D = g.k3[plane];
-        const float4 vb = *(const float4*)(g.b + off);
+        const float4 vb = ld_nt4(g.b + off);
         const float* pb = (const float*)&vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -90,21 +90,21 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         }
     } else if constexpr (OP == EW_PASSE) {
         const float C1 = g.k0[plane], C2 = g.k1[plane], C3 = g.k2[plane];
-        const float4 vb = *(const float4*)(g.b + off);
-        const float4 vc = *(const float4*)(g.c + off);
+        const float4 vb = ld_nt4(g.b + off);
+        const float4 vc = ld_nt4(g.c + off);
         const float* pb = (const float*)&vb;
         const float* pc = (const float*)&vc;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = pa[i] + fmaf(C1, pb[i], fmaf(C2, pc[i], C3));
         if (g.part) {
-            const float4 vx = *(const float4*)(g.aux + off);
+            const float4 vx = ld_nt4(g.aux + off);
             const float* px = (const float*)&vx;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { s0 += o[i]; s1 += o[i] * px[i]; }
         }
     } else if constexpr (OP == EW_RELU_BWD) {
         const float A = g.k0[plane], B = g.k1[plane];
-        const float4 vb = *(const float4*)(g.b + off);
+        const float4 vb = ld_nt4(g.b + off);
         const float* pb = (const float*)&vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         }
     } else if constexpr (OP == EW_HEAD_BWD) {
         const int ch = plane % g.C;
-        const float4 vb = *(const float4*)(g.b + off);
+        const float4 vb = ld_nt4(g.b + off);
         const float* pb = (const float*)&vb;
         const int nm = g.n_mean < 0 ? -g.n_mean : g.n_mean;
         if (ch < nm) {
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
             for (int i = 0; i < 4; ++i) o[i] = pa[i] * (pb[i] > 20.f ? 1.f : sigmoid_f(pb[i]));
         }
     }
-    if constexpr (OP != EW_STATS_SQ && OP != EW_STATS_AUX && OP != EW_SE_POOL) *(float4*)(g.out + off) = vo;
+    if constexpr (OP != EW_STATS_SQ && OP != EW_STATS_AUX && OP != EW_SE_POOL) st_nt4(g.out + off, vo);
     if constexpr (OP != EW_HEAD_FWD && OP != EW_HEAD_BWD) {
         if (g.part) {
             __shared__ float red[8];

@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void residual_pool_kernel(const float* __restr
     float4 xv[8], hv[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        xv[r] = *(const float4*)(x + base + (size_t)r * W);
-        hv[r] = *(const float4*)(h3 + base + (size_t)r * W);
+        xv[r] = ld_nt4(x + base + (size_t)r * W);
+        hv[r] = ld_nt4(h3 + base + (size_t)r * W);
     }
     float best = -INFINITY, s0 = 0.f, s1 = 0.f;
     int bi = strip * 8 * W + 4 * lane;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void residual_pool_kernel(const float* __restr
         o.y = xv[r].y + fmaf(A, hv[r].y, B);
         o.z = xv[r].z + fmaf(A, hv[r].z, B);
         o.w = xv[r].w + fmaf(A, hv[r].w, B);
-        *(float4*)(out + base + (size_t)r * W) = o;
+        st_nt4(out + base + (size_t)r * W, o);
         const float vv[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

@@ -85,10 +85,10 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
     auto load_piece = [&](int i, int ch) {   // i compile-time after unrolling; ch clamped by the caller
         const size_t po = (size_t)(cbeg + ch) * 32;
         if (i < ND) {
-            dv[i] = *(const float4*)(dbase + (size_t)(64 * i) * P + po);
-            if constexpr (D2) dv2[i] = *(const float4*)(d2base + (size_t)(64 * i) * P + po);
+            dv[i] = ld_nt4(dbase + (size_t)(64 * i) * P + po);
+            if constexpr (D2) dv2[i] = ld_nt4(d2base + (size_t)(64 * i) * P + po);
         } else {
-            xv[i - ND] = *(const float4*)(xbase + (size_t)(64 * (i - ND)) * P + po);
+            xv[i - ND] = ld_nt4(xbase + (size_t)(64 * (i - ND)) * P + po);
         }
     };
     auto stage_piece = [&](int i, int buf) {
