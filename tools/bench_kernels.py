@@ -113,6 +113,27 @@ def main():
         dk = tuple(torch.randn(N * 256, device=dev) for _ in range(3)); xk = (torch.randn(N * 128, device=dev), torch.randn(N * 128, device=dev), None)
         for _ in range(3):
             E.pw_wgrad(d, xx, N, 256, 128, P, pro_d=3, dk=dk, d2=d2, pro_x=1, xk=xk)
+        # backward of pw1 with the PreNorm backward + skip epilogue (uncr_pw_gemm_dx, with the producer's statistics)
+        from uncrtaints_amd import hip_backend as hb
+        W1k = E.pack_wt(torch.randn(256, 128, device=dev) * 0.05, transpose=False)
+        dy, xh3, dx = (torch.randn(N, 128, P, device=dev) for _ in range(3))
+        c = tuple(torch.randn(N * 128, device=dev) for _ in range(3))
+        slots = hb.query("uncr_pw_stat_slots", N, 128, P)
+        part = torch.empty(N * 128, slots, 2, device=dev)
+        for _ in range(3):
+            hb.call("uncr_pw_gemm_dx", d, d2, W1k, dx, dk[0], dk[1], dk[2], dy, xx, xh3, c[0], c[1], c[2], None, None, part,
+                    N, 256, 128, P, E._stream())
+        # the depthwise kernels
+        C, H, W = 256, 256, 256
+        t4 = lambda *s: torch.randn(*s, device=dev)
+        h1, hh2, du2, out = t4(N, C, H, W), t4(N, C, H, W), t4(N, C, H, W), torch.empty(N, C, H, W, device=dev)
+        cA, cB, k1, k2, k3 = (torch.randn(N * C, device=dev) for _ in range(5))
+        w9 = t4(C, 9)
+        sf, sb = hb.query("uncr_dw_slots_fwd", H), hb.query("uncr_dw_slots_bwd", H)
+        partf, partb, dwp = torch.empty(N * C, sf, 2, device=dev), torch.empty(N * C, sb, 2, device=dev), torch.empty(N * C, sb, 9, device=dev)
+        for _ in range(3):
+            hb.call("uncr_dw_fwd", h1, cA, cB, w9, out, partf, N, C, H, W, E._stream())
+            hb.call("uncr_dw_bwd", du2, hh2, h1, k1, k2, k3, cA, cB, w9, out, partb, dwp, None, 0, N, C, H, W, E._stream())
         torch.cuda.synchronize()
         print("done")
     elif what == "ablate":

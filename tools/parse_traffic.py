@@ -1,0 +1,46 @@
+"""Turn the two rocprofv3 PMC passes of `tools/bench_kernels.py traffic` (FETCH_SIZE, WRITE_SIZE) into profiles/<tag>_traffic.json.
+usage: python tools/parse_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+Both counters are reported in KB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)."""
+import csv, json, sys, collections
+
+KEYS = [("dw_bwd_row_kernel", "dw_bwd[N4,C256,256x256]", 4 * 4 * 256 * 65536 * 4),
+        ("dw_fwd_row_kernel", "dw_fwd[N4,C256,256x256]", 4 * 4 * 256 * 65536 * 2),
+        ("pw_gemm_split_kernel<2, 3, 3, 1>", "pw_gemm[128->256,pro3,epi3,N4,P65536]", 4 * 4 * 65536 * (2 * 128 + 2 * 256)),
+        ("pw_gemm_split_kernel<2, 1, 1, 1>", "pw_gemm[128->256,pro1,epi1,N4,P65536]", 4 * 4 * 65536 * (128 + 256)),
+        ("pw_wgrad_split_kernel<4, 2, 3, 1>", "pw_wgrad[256x128,N4,P65536]", 4 * 4 * 65536 * (2 * 256 + 128)),
+        ("pw_gemm_split_kernel<1, 3, 5, 2>", "pw_gemm_dx[256->128,N4,P65536]", 4 * 4 * 65536 * (2 * 256 + 4 * 128))]
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        name = r.get("Kernel_Name") or r.get("Kernel Name") or ""
+        if (r.get("Counter_Name") or r.get("Counter Name")) != counter:
+            continue
+        acc[name].append(float(r.get("Counter_Value") or r.get("Counter Value")))
+    return acc
+
+
+def main():
+    f, w, out = sys.argv[1:4]
+    fe, wr = per_kernel(f, "FETCH_SIZE"), per_kernel(w, "WRITE_SIZE")
+    res = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes: two separate runs (--kernel-trace --pmc FETCH_SIZE, "
+                       "--kernel-trace --pmc WRITE_SIZE) of `python tools/bench_kernels.py traffic` (tools/measure_traffic.sh), which "
+                       "launches the kernels in isolation at the default bench shapes (N=4 frames, P=65536 px), 3 launches each, mean. "
+                       "Both counters are reported in KB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at "
+                       "64 B), WRITE_SIZE is used as reported. hbm_bytes = (2*fetch_kb_raw + write_kb_raw)*1024."}
+    for sub, key, alg in KEYS:
+        fk = [v for n, vs in fe.items() if sub in n for v in vs]
+        wk = [v for n, vs in wr.items() if sub in n for v in vs]
+        if not fk or not wk:
+            print("missing", sub, file=sys.stderr)
+            continue
+        fm, wm = sum(fk) / len(fk), sum(wk) / len(wk)
+        res[key] = {"fetch_kb_raw": round(fm, 1), "write_kb_raw": round(wm, 1), "hbm_bytes": int((2 * fm + wm) * 1024),
+                    "algorithmic_bytes": alg, "launches_averaged": len(fk)}
+        print(key, res[key], "ratio", round(res[key]["hbm_bytes"] / alg, 3))
+    json.dump(res, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
