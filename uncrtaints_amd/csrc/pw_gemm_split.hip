@@ -20,9 +20,26 @@
 //     A[co = lane&31][ci = 16 ks + 8 (lane>>5) + 0..7]); a wave's A load is one contiguous 1 KB read from L2.
 //     A parts are re-loaded for the next k-step right after their last use (no second register set).
 #include "pw_gemm.h"
-#ifndef UNCR_NT_GEMM
-#define UNCR_NT_GEMM 0     // non-temporal activation loads / output stores in the GEMM: measured 1.3 % SLOWER per step
+// non-temporal hints per access class, measured inside the training step (tools/ab_variants.sh, interleaved runs of one
+// session): activation loads -0.09 ms/step (4 of 4 rounds) -> ON; epilogue operand loads +0.15 ms and output stores +0.1 ms
+// (the next kernel re-reads them) -> OFF
+#ifndef UNCR_NTG_LD
+#define UNCR_NTG_LD 1
 #endif
+#ifndef UNCR_NTG_AUX
+#define UNCR_NTG_AUX 0
+#endif
+#ifndef UNCR_NTG_ST
+#define UNCR_NTG_ST 0
+#endif
+template <bool NT> __device__ __forceinline__ float4 pws_ld(const float* p) {
+    if constexpr (NT) { const uncr_f4 v = __builtin_nontemporal_load((const uncr_f4*)p); return make_float4(v.x, v.y, v.z, v.w); }
+    else return *(const float4*)p;
+}
+template <bool NT> __device__ __forceinline__ void pws_st(float* p, const float4& v) {
+    if constexpr (NT) { const uncr_f4 q = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(q, (uncr_f4*)p); }
+    else *(float4*)p = v;
+}
 #include <type_traits>
 
 #ifndef PWS_ABL
@@ -124,10 +141,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         for (int r = 0; r < 4; ++r) {
             const int k = p.c * PWS_KC + 4 * cig + r;
             const int kk = k < Cin ? k : 0;
-            // streamed once -> non-temporal; the dense 3x3 path (epi 4) re-reads its input nine times and keeps it cached
-            if constexpr (EPI == 4 || !UNCR_NT_GEMM) pre[S][r] = *(const float4*)(inb + (size_t)kk * P + px);
-            else pre[S][r] = ld_nt4(inb + (size_t)kk * P + px);
-            if constexpr (PRE2) pre2[S][r] = UNCR_NT_GEMM ? ld_nt4(in2b + (size_t)kk * P + px) : *(const float4*)(in2b + (size_t)kk * P + px);
+            pre[S][r] = pws_ld<UNCR_NTG_LD && EPI != 4>(inb + (size_t)kk * P + px);
+            if constexpr (PRE2) pre2[S][r] = pws_ld<UNCR_NTG_LD && EPI != 4>(in2b + (size_t)kk * P + px);
         }
     };
     auto stage_chunk = [&](int kc, int buf, auto slot) {
@@ -292,9 +307,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                         const int rw = row_of(ct, rb + q);
                         const int rc = rw + 4 < Cout ? rw : (Cout > 8 ? Cout - 8 : 0);
                         const size_t o = (size_t)(nco + rc) * P + loff;
-                        xa[q] = ld_nt4(g.aux + o);
-                        xb[q] = ld_nt4(g.aux2 + o);
-                        xc[q] = ld_nt4(a3 + o);
+                        xa[q] = pws_ld<UNCR_NTG_AUX>(g.aux + o);
+                        xb[q] = pws_ld<UNCR_NTG_AUX>(g.aux2 + o);
+                        xc[q] = pws_ld<UNCR_NTG_AUX>(a3 + o);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                         const int r = rb + q;
                         const int rw = row_of(ct, r);            // rows past Cout (padded tiles) re-read the last valid row
                         const int rc = rw + 4 < Cout ? rw : (Cout > 8 ? Cout - 8 : 0);
-                        xa[q] = ld_nt4(g.aux + (size_t)(nco + rc) * P + loff);
+                        xa[q] = pws_ld<UNCR_NTG_AUX>(g.aux + (size_t)(nco + rc) * P + loff);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -381,8 +396,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                 const int rw = row_of(ct, r);
                 const float4 v = make_float4(acc[0][ct][r], acc[1][ct][r], acc[2][ct][r], acc[3][ct][r]);
                 if (rw + 4 * kg < Cout && (!(PWS_ABL & 1) || v.x == 1.2345e-30f)) {
-                    if constexpr (EPI == 4 || !UNCR_NT_GEMM) *(float4*)(g.out + (size_t)(nco + rw) * P + loff) = v;
-                    else st_nt4(g.out + (size_t)(nco + rw) * P + loff, v);
+                    pws_st<UNCR_NTG_ST && EPI != 4>(g.out + (size_t)(nco + rw) * P + loff, v);
                 }
             }
         }
