@@ -165,6 +165,8 @@ class _NormCtx:
         self.p, self.kind, self.training, self.update = params, kind, training, update_running
 
     def __call__(self, x: Tensor, prefix: str) -> Tensor:
+        if self.kind == "instance":        # nn.InstanceNorm2d defaults: no affine, instance statistics in train and eval
+            return F.instance_norm(x, eps=1e-5)
         w, b = self.p[prefix + ".weight"], self.p[prefix + ".bias"]
         if self.kind == "group":
             return group_norm(x, 4, w, b)
@@ -329,7 +331,7 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
     pad_mask = (x == cfg.pad_value).all(dim=-1).all(dim=-1).all(dim=-1)   # [B,T]
     f = x.reshape(B * T, Cin, H, W)                                       # smart_forward, utae.py:422-450
     c0 = conv1x1(f, p["in_conv.conv.conv.0.weight"], p["in_conv.conv.conv.0.bias"])
-    a0 = torch.relu(group_norm(c0, 4, p["in_conv.conv.conv.1.weight"], p["in_conv.conv.conv.1.bias"]))
+    a0 = torch.relu(_NormCtx(p, cfg.encoder_norm, training, update_running)(c0, "in_conv.conv.conv.1"))   # utae.py:463-473
     e = _block(a0, p, "in_block.0", cfg.encoder_norm, training, update_running, taps, cfg)
     C = e.shape[1]
     if cfg.is_mono:
@@ -502,7 +504,7 @@ def init_params(cfg: OracleConfig, seed: int = 1) -> Dict[str, Tensor]:
             p[prefix + ".weight"], p[prefix + ".bias"] = randn(c), torch.zeros(c)
             p[prefix + ".running_mean"], p[prefix + ".running_var"] = torch.zeros(c), torch.ones(c)
             p[prefix + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
-        else:
+        elif kind != "instance":
             p[prefix + ".weight"], p[prefix + ".bias"] = torch.ones(c), torch.zeros(c)
 
     def mb(prefix, c, kind):

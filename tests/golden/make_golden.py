@@ -385,6 +385,7 @@ VARIANTS = {
     "mean": dict(agg_mode="mean"),
     "separate_out": dict(separate_out=True),
     "is_mono": dict(is_mono=True, n_head=1),
+    "instance": dict(encoder_norm="instance", decoder_norm="instance"),     # nn.InstanceNorm2d everywhere (uncrtaints.py:19)
 }
 
 
@@ -397,6 +398,10 @@ def variant_state(state, name):
         st["out_conv_var_1.conv.conv.0.weight"], st["out_conv_var_1.conv.conv.0.bias"] = w[13:].clone(), b[13:].clone()
     if name == "is_mono":
         st = {k: v for k, v in st.items() if not k.startswith("temporal_encoder")}
+    if name == "instance":      # InstanceNorm2d has neither parameters nor buffers
+        import re
+        st = {k: v for k, v in st.items()
+              if not re.match(r"(in_conv\.conv\.conv\.1|(in|out)_block\.\d+\.conv\.(norm|fn\.[148]))\.", k)}
     return st
 
 

@@ -56,15 +56,15 @@ class Part:
 
 @dataclass
 class NormSpec:
-    kind: str        # 'group' | 'batch'
+    kind: str        # 'group' | 'batch' | 'instance'
     groups: int = 4
 
     def code(self, training: bool) -> int:
-        if self.kind == "group":
+        if self.kind in ("group", "instance"):      # nn.InstanceNorm2d (no affine, no running statistics) = one group per channel
             return NORM_GROUP
         if self.kind == "batch":
             return NORM_BATCH_TRAIN if training else NORM_BATCH_EVAL
-        raise NotImplementedError(f"norm '{self.kind}' is not built (group | batch)")
+        raise NotImplementedError(f"norm '{self.kind}' is not built (group | batch | instance)")
 
     def needs_stats(self, training: bool) -> bool:
         return self.code(training) != NORM_BATCH_EVAL
@@ -126,9 +126,12 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
              beta: Tensor, running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None,
              momentum: float = 0.1, eps: float = 1e-5) -> NormFwd:
     kind = spec.code(training)
+    groups = C if spec.kind == "instance" else spec.groups
+    if gamma is None:                      # norm without affine parameters (InstanceNorm2d): gamma = 1, beta = 0
+        gamma, beta = _const_planes((part.buf if part is not None else running_mean).device, C)
     dev = gamma.device
     A, B = _f32((N * C,), dev), _f32((N * C,), dev)
-    nstat = N * spec.groups if kind == NORM_GROUP else C
+    nstat = N * groups if kind == NORM_GROUP else C
     mean, rstd = _f32((nstat,), dev), _f32((nstat,), dev)
     if kind == NORM_BATCH_TRAIN and _SYNC_BN is not None:
         sums = torch.empty((C, 2), device=dev, dtype=torch.float64)
@@ -136,10 +139,10 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
         count = _all_reduce_sums(sums) * N * P
         hb.call("uncr_bn_finalize_fwd_sums", sums, count, N, C, gamma, beta, running_mean, running_var, float(momentum),
                 float(eps), A, B, mean, rstd, _stream())
-        return NormFwd(A, B, mean, rstd, kind, spec.groups, sync_count=count)
-    hb.call("uncr_norm_finalize_fwd", part.buf if part else None, part.slots if part else 0, N, C, spec.groups, P,
+        return NormFwd(A, B, mean, rstd, kind, groups, sync_count=count)
+    hb.call("uncr_norm_finalize_fwd", part.buf if part else None, part.slots if part else 0, N, C, groups, P,
             kind, gamma, beta, running_mean, running_var, float(momentum), float(eps), A, B, mean, rstd, _stream())
-    return NormFwd(A, B, mean, rstd, kind, spec.groups)
+    return NormFwd(A, B, mean, rstd, kind, groups)
 
 
 @dataclass
@@ -153,6 +156,8 @@ class NormBwd:
 
 def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor, centered: bool = False) -> NormBwd:
     """centered: the partials' second component is sum du*(h - mean) (producer was given nf.mean)."""
+    if gamma is None:
+        gamma = _const_planes(part.buf.device, C)[0]
     dev = gamma.device
     c1, c2, c3 = _f32((N * C,), dev), _f32((N * C,), dev), _f32((N * C,), dev)
     dg, db = _f32((C,), dev), _f32((C,), dev)

@@ -7,9 +7,10 @@ loads reference checkpoints.  Modules hold parameters in stock `nn.*` layers (we
 dispatch on those types); `forward` routes through autograd Functions over `uncrtaints_amd.engine`.
 There is no PyTorch-op fallback: on a machine without the HIP library or a GPU tensor, forward raises.
 
-Built: block_type in {mbconv, residual}, agg_mode in {att_group, att_mean, mean}, encoder_norm/decoder_norm in {group, batch},
+Built: block_type in {mbconv, residual}, agg_mode in {att_group, att_mean, mean}, encoder_norm/decoder_norm in {group, batch,
+instance},
 use_v in {False, True}, separate_out, is_mono, out_nonlin_var='softplus', covmode in {diag, iso, uni, None}.
-Not built (raise NotImplementedError): instance norm."""
+(SURVEY 8(a17) / 8(f))."""
 import torch
 import torch.nn as nn
 
@@ -83,7 +84,8 @@ class _MBConvFn(torch.autograd.Function):
         dx, g, dx_part = E.mbconv_backward(dy, ctx.sv, ctx.p, need_dx=ctx.needs_input_grad[0], dy_part=part)
         if dx is not None and dx_part is not None:
             dx._uncr_bpart = dx_part
-        return (dx, None) + tuple(g[k] for k in E.MB_KEYS)
+        # norms without affine parameters (InstanceNorm2d) were passed as None: no gradient slot for them
+        return (dx, None) + tuple(g[k] if ctx.needs_input_grad[2 + i] else None for i, k in enumerate(E.MB_KEYS))
 
 
 class MBConv(TemporallySharedBlock):
@@ -92,8 +94,8 @@ class MBConv(TemporallySharedBlock):
         if downsample or expansion == 1 or inp != oup:
             raise NotImplementedError("HIP MBConv is built for the UNCRTAINTS configuration: no down-sampling, "
                                       "expansion > 1, inp == oup")
-        if norm not in ("group", "batch"):
-            raise NotImplementedError(f"MBConv norm '{norm}' is not built (group | batch)")
+        if norm not in ("group", "batch", "instance"):
+            raise NotImplementedError(f"MBConv norm '{norm}' is not built (group | batch | instance)")
         self.downsample = downsample
         hidden_dim = int(inp * expansion)
         self.conv = nn.Sequential(
@@ -148,7 +150,7 @@ class _ResidualFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         dx, g = E.residual_backward(dy, ctx.sv, ctx.p, ctx.needs_input_grad[0])
-        return (dx, None) + tuple(g[k] for k in E.RES_KEYS)
+        return (dx, None) + tuple(g[k] if ctx.needs_input_grad[2 + i] else None for i, k in enumerate(E.RES_KEYS))
 
 
 class ResidualConvBlock(TemporallySharedBlock):
@@ -159,7 +161,7 @@ class ResidualConvBlock(TemporallySharedBlock):
         super().__init__(pad_value=pad_value)
         if (k, s, p) != (3, 1, 1) or padding_mode != "reflect" or len(nkernels) != 2 or nkernels[0] != nkernels[1]:
             raise NotImplementedError("ResidualConvBlock is built for 3x3 / stride 1 / reflect, equal widths")
-        if norm not in ("batch", "group"):
+        if norm not in ("batch", "group", "instance"):
             raise NotImplementedError(f"ResidualConvBlock norm '{norm}'")
         mk = lambda: ConvLayer(nkernels=nkernels, norm=norm, last_relu=True, k=k, s=s, p=p, n_groups=n_groups,
                                padding_mode=padding_mode)

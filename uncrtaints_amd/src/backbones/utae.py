@@ -58,6 +58,8 @@ class _ConvNormActFn(torch.autograd.Function):
         if part is not None and not (part.masked and part.buf.shape[0] == da.shape[0] * da.shape[1]):
             part = None
         dx, dW, db, dgw, dgb = E.inconv_backward(da, ctx.sv, w, gw, ctx.needs_input_grad[0], masked_part=part)
+        if gw is None:          # InstanceNorm2d: no affine parameters
+            dgw = dgb = None
         return dx, dW, db, dgw, dgb, None
 
 
@@ -118,6 +120,8 @@ class ConvLayer(nn.Module):
             self._spec = E.NormSpec("group", n_groups)
         elif norm == "batch":
             self._spec = E.NormSpec("batch")
+        elif norm == "instance":
+            self._spec = E.NormSpec("instance")
         else:
             self._spec = None
 
@@ -132,7 +136,7 @@ class ConvLayer(nn.Module):
             raise NotImplementedError("HIP ConvLayer is built for single 1x1 convolutions (the UNCRTAINTS in_conv / "
                                       "out_conv configuration)")
         conv = self.conv[0]
-        if self._norm in ("group", "batch") and self._last_relu:
+        if self._norm in ("group", "batch", "instance") and self._last_relu:
             nrm = self.conv[1]
             out = _ConvNormActFn.apply(input, conv.weight, conv.bias, nrm.weight, nrm.bias, self)
             if isinstance(nrm, nn.BatchNorm2d) and self.training:
