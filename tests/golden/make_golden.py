@@ -386,6 +386,7 @@ VARIANTS = {
     "separate_out": dict(separate_out=True),
     "is_mono": dict(is_mono=True, n_head=1),
     "instance": dict(encoder_norm="instance", decoder_norm="instance"),     # nn.InstanceNorm2d everywhere (uncrtaints.py:19)
+    "enc_batch": dict(encoder_norm="batch"),                                # BatchNorm2d in in_conv / in_block as well
 }
 
 
@@ -398,6 +399,12 @@ def variant_state(state, name):
         st["out_conv_var_1.conv.conv.0.weight"], st["out_conv_var_1.conv.conv.0.bias"] = w[13:].clone(), b[13:].clone()
     if name == "is_mono":
         st = {k: v for k, v in st.items() if not k.startswith("temporal_encoder")}
+    if name == "enc_batch":     # the GroupNorm affine parameters become BatchNorm ones; fresh running statistics
+        import re
+        for k in [k for k in st if re.match(r"(in_conv\.conv\.conv\.1|in_block\.\d+\.conv\.(norm|fn\.[148]))\.weight", k)]:
+            pre = k[:-len("weight")]
+            st[pre + "running_mean"], st[pre + "running_var"] = torch.zeros_like(st[k]), torch.ones_like(st[k])
+            st[pre + "num_batches_tracked"] = torch.zeros((), dtype=torch.long)
     if name == "instance":      # InstanceNorm2d has neither parameters nor buffers
         import re
         st = {k: v for k, v in st.items()
