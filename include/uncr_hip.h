@@ -56,6 +56,9 @@ int uncr_debug_erf(const float* x, float* y, int n, int what, hipStream_t stream
 int uncr_debug_mfma_probe_bf16(float* out, int blocks, int iters, hipStream_t stream);   /* bf16-MFMA peak probe */
 /* debug: out[32][32] = A[32][K] * B[K][32] through the 3-way bf16 split on v_mfma_f32_32x32x16_bf16
  * (terms = 1, 3, 6 or 9 partial products); numerics probe, K % 16 == 0 */
+/* ds_read_b64_tr_b16 semantics probe: lds[i] = i (16-bit); lane l reads at element offset offs[l] (64 ints);
+ * out[l*4 + j] = j-th value received (256 ints). */
+int uncr_debug_tr_b16_probe(const int* offs, int* out, hipStream_t stream);
 int uncr_debug_bf16split_probe(const float* A, const float* B, float* out, int K, int terms, hipStream_t stream);
 
 /* ---- normalisation coefficients: nn.GroupNorm / nn.BatchNorm2d statistics

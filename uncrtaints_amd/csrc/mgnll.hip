@@ -361,4 +361,23 @@ extern "C" int uncr_debug_erf(const float* x, float* y, int n, int what, hipStre
     return UNCR_OK;
 }
 
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read) semantics probe: LDS holds lds[i] = i (16-bit), lane l reads at element
+// offset offs[l]; out[l*4 + j] = the j-th 16-bit value the lane receives.  Groundwork for feeding the same LDS tile to MFMA
+// in both operand orientations (data GEMM + weight-gradient GEMM from one staged tile).
+typedef short uncr_s4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void tr_b16_probe_kernel(const int* __restrict__ offs, int* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) short lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = (short)i;
+    __syncthreads();
+    const uncr_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (uncr_s4 __attribute__((address_space(3)))*)(lds + offs[threadIdx.x]));
+    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = v[j];
+}
+extern "C" int uncr_debug_tr_b16_probe(const int* offs, int* out, hipStream_t stream) {
+    if (!offs || !out) return UNCR_EINVAL;
+    hipLaunchKernelGGL(tr_b16_probe_kernel, dim3(1), dim3(64), 0, stream, offs, out);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
 extern "C" int uncr_version() { return 1; }
