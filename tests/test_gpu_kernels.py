@@ -303,9 +303,10 @@ def test_ltae_attention_fwd_bwd(orc, T, padded):
         close(f"ltae_grad[{k}]", v.grad, ref, tol=2e-4)
 
 
-@pytest.mark.parametrize("padded,masked", [(False, False), (True, False), (False, True)])
-def test_aggregate_fwd_bwd(E, orc, padded, masked):
-    B, T, C, H, W = 2, 3, 128, 64, 64
+@pytest.mark.parametrize("padded,masked,H,W", [(False, False, 64, 64), (True, False, 64, 64), (False, True, 64, 64),
+                                                 (False, False, 80, 64), (True, False, 48, 128)])   # 2.5x / 1.5x x 4x ratios
+def test_aggregate_fwd_bwd(E, orc, padded, masked, H, W):
+    B, T, C = 2, 3, 128
     e = rand(B, T, C, H, W, seed=1)
     att = torch.softmax(rand(16, B, T, 32, 32, seed=2), dim=2)
     pad = torch.zeros(B, T, dtype=torch.bool)

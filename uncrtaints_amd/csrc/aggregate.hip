@@ -176,8 +176,10 @@ __global__ __launch_bounds__(256) void bilinear_adjoint_kernel(const float* __re
     const int ay = blockIdx.x, q = blockIdx.y;
     const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
     const float sy = (float)AH / (float)H, sx = (float)AW / (float)W;
-    const int ry = (H + AH - 1) / AH, rx = (W + AW - 1) / AW;
-    const int ylo = max(0, (ay - 1) * ry - ry), yhi = min(H, (ay + 2) * ry + ry);
+    // rows / columns whose source coordinate sy*(y+0.5)-0.5 lies in [a-1, a+1) can carry weight for cell a; the bounds are
+    // conservative (the weight itself is evaluated exactly per row / column) and hold for non-integer ratios H/AH too
+    const int ylo = max(0, (int)floorf(((float)ay - 0.5f) / sy - 0.5f) - 1);
+    const int yhi = min(H, (int)ceilf(((float)ay + 1.5f) / sy - 0.5f) + 2);
     const float* src = dup + (size_t)q * H * W;
     __shared__ float colsum[4][BADJ_MAXW];
     const int W4 = W >> 2;
@@ -195,7 +197,8 @@ __global__ __launch_bounds__(256) void bilinear_adjoint_kernel(const float* __re
     }
     __syncthreads();
     for (int ax = tid; ax < AW; ax += 256) {
-        const int xlo = max(0, (ax - 1) * rx - rx), xhi = min(W, (ax + 2) * rx + rx);
+        const int xlo = max(0, (int)floorf(((float)ax - 0.5f) / sx - 0.5f) - 1);
+        const int xhi = min(W, (int)ceilf(((float)ax + 1.5f) / sx - 0.5f) + 2);
         float s = 0.f;
         for (int xx = xlo; xx < xhi; ++xx) {
             const Bilin bx = bilin_src(xx, sx, AW);
