@@ -305,7 +305,7 @@ def temporal_aggregate(x: Tensor, pad_mask: Tensor, attn: Tensor, cfg: OracleCon
         attn = attn.mean(dim=0, keepdim=True)
         nh = 1
     a = attn.reshape(nh * B, T, h, w)
-    if H > w:
+    if H > w or cfg.agg_mode == "att_mean":     # 'att_mean' always re-samples and applies dropout (uncrtaints.py:179-186, 211-217)
         a = F.interpolate(a, size=(H, W), mode="bilinear", align_corners=False)
         if training:
             if dropout_mask is not None:

@@ -323,6 +323,32 @@ def case_calibration():
     print("g14_calibration", {k: v for k, v in out.items() if "uce" in k})
 
 
+def case_smallmap():
+    """G15: a 32 x 32 input -- not larger than the 32 x 32 attention map, so the aggregator takes its AvgPool2d branch
+    (identity here) which has NO dropout even in train mode (uncrtaints.py:197-204); weights from g1_diag_t3."""
+    base = np.load(os.path.join(HERE, "g1_diag_t3.npz"))
+    state = {k[len("state/"):]: torch.from_numpy(base[k]) for k in base.files if k.startswith("state/")}
+    torch.manual_seed(0)
+    m = uncrtaints.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus",
+                              covmode="diag", scale_by=1.0)
+    m.load_state_dict(state, strict=True)
+    assert m.temporal_aggregator.attn_dropout.p > 0
+    x, y, dates = synth(1, 3, 32, 32, 15)
+    m.train()
+    with torch.no_grad():
+        o1 = m(x, batch_positions=dates)
+        m.load_state_dict(state, strict=True)
+        o2 = m(x, batch_positions=dates)
+    assert torch.equal(o1, o2), "the reference applied dropout on the small-map branch"
+    m.load_state_dict(state, strict=True)
+    m.eval()
+    with torch.no_grad():
+        oe = m(x, batch_positions=dates)
+    np.savez_compressed(os.path.join(HERE, "g15_smallmap.npz"), x=x.numpy(), dates=dates.numpy(), train_out=o1.numpy(),
+                        eval_out=oe.numpy())
+    print("g15_smallmap", tuple(o1.shape))
+
+
 def case_posenc():
     pe = PositionalEncoder(256 // 16, T=1000, repeat=16)
     dates = torch.tensor([[1400., 1433., 1799.], [0., 1., 1000.]])
@@ -558,6 +584,8 @@ if __name__ == "__main__":
     case_metrics(); sys.exit(0)
   if "--only-calibration" in sys.argv:
     case_calibration(); sys.exit(0)
+  if "--only-smallmap" in sys.argv:
+    case_smallmap(); sys.exit(0)
   if "--only-usev" in sys.argv:
     case_usev(); sys.exit(0)
   if "--only-residual" in sys.argv:
@@ -569,6 +597,7 @@ if __name__ == "__main__":
     case_prepare()
     case_metrics()
     case_calibration()
+    case_smallmap()
     case_usev()
     case_residual()
     case_posenc()

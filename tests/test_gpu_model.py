@@ -220,3 +220,28 @@ def test_full_size_properties_at_the_bench_config():
         e = (m(x[:, perm], batch_positions=dates[:, perm]) - full).abs().max().item() / full.abs().max().item()
         print(f"[parity] bench-config frame permutation: rel_err={e:.3e}")
         assert e < 2e-5, e
+
+
+def test_input_as_small_as_the_attention_map_has_no_dropout():
+    """32 x 32 input: the feature map is not larger than the 32 x 32 attention map, the reference's aggregator takes its
+    AvgPool2d(kernel 1) branch -- identity, and NO dropout even in train mode (uncrtaints.py:197-204)."""
+    from oracle import uncrtaints_oracle as orc
+    cfg = orc.OracleConfig(attn_dropout=0.5)
+    state = orc.init_params(cfg, seed=6)
+    m = _build("diag", state)
+    m.temporal_aggregator.attn_dropout.p = 0.5
+    x, y, dates = orc.synthetic_batch(2, 3, 32, 32, seed=8)
+    m.train()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    o1 = m(dev(x), batch_positions=dev(dates)).detach().clone()
+    m.load_state_dict(sd)
+    o2 = m(dev(x), batch_positions=dev(dates)).detach().clone()
+    assert torch.equal(o1, o2), "dropout was applied on the small-map branch"
+    ref = orc.forward({k: v.clone() for k, v in state.items()}, x, dates, cfg, training=True)
+    close("small_map_train_forward", o1, ref)
+    # and against the reference's own output on its fixture (weights of g1_diag_t3, default dropout 0.1, train mode)
+    g, base = load_golden("g15_smallmap"), load_golden("g1_diag_t3")
+    m = _build("diag", _state(base))
+    m.train()
+    out = m(dev(torch.from_numpy(g["x"])), batch_positions=dev(torch.from_numpy(g["dates"])))
+    close("small_map_train_vs_reference", out, torch.from_numpy(g["train_out"]), tol=2e-5)

@@ -208,3 +208,15 @@ def test_calibration_bin_ends_follow_torch_integer_linspace():
         got = cal.compute_ece(list(var), list(err), n)
         ref = orc.compute_ece(list(var), list(err), n)
         assert np.allclose(got, ref, rtol=2e-5, atol=1e-9, equal_nan=True), n
+
+
+def test_small_map_branch_matches_reference():
+    """32 x 32 input (g15): AvgPool branch of the aggregator, no dropout in train mode; weights from g1_diag_t3."""
+    g, base = load_golden("g15_smallmap"), load_golden("g1_diag_t3")
+    state = {k[len("state/"):]: torch.from_numpy(base[k]) for k in base.files if k.startswith("state/")}
+    x, dates = torch.from_numpy(g["x"]), torch.from_numpy(g["dates"])
+    cfg = orc.OracleConfig()             # attn_dropout 0.1, as in the reference model
+    with torch.no_grad():
+        ot = orc.forward({k: v.clone() for k, v in state.items()}, x, dates, cfg, training=True)
+        oe = orc.forward({k: v.clone() for k, v in state.items()}, x, dates, cfg, training=False)
+    assert rel_err(ot.numpy(), g["train_out"]) < 2e-5 and rel_err(oe.numpy(), g["eval_out"]) < 2e-5

@@ -900,6 +900,8 @@ def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor]
     att, sv_att = ltae_attention_forward(down, dates, pad, p, denom, n_head, d_k)
     if mode == "att_group":
         w_att, shared = att, False
+        if e.shape[-2] <= att_down:      # feature map not larger than the attention map: the reference takes its AvgPool
+            p_drop, dmask = 0.0, None    # branch (kernel 1 = identity at equal size), which has NO dropout (uncrtaints.py:197-204)
     elif mode == "att_mean":
         w_att, shared = head_mean_attention(att), True
     elif mode == "mean":

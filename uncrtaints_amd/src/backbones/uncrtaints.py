@@ -205,6 +205,8 @@ class _AggregateFn(torch.autograd.Function):
             w_att, p_drop, dmask = E.mean_mode_weights(pad, nh, B, T, ah, aw, x.device), 0.0, None
         else:
             w_att = att
+            if x.shape[-2] <= aw:        # AvgPool branch of the reference (identity at equal size): no dropout (uncrtaints.py:197-204)
+                p_drop, dmask = 0.0, None
         g, sv, gpart = E.aggregate_forward(x, w_att, pad, module.training, p_drop, seed, dmask, True, shared)
         ctx.sv, ctx.mode = sv, mode
         g._uncr_part = gpart
