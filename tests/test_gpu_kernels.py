@@ -126,7 +126,7 @@ def test_pw_wgrad(E, Cd, Cx):
 # W == 256 runs the row-streaming kernels (dwconv_row.hip): one / partial / several 64-row tiles, and once more on
 # the LDS-tiled kernels (row=False) so that both implementations stay covered
 @pytest.mark.parametrize("H,W,row", [(64, 64, True), (96, 32, True), (16, 256, True), (72, 256, True), (136, 256, True),
-                                     (72, 256, False)])
+                                     (72, 256, False), (32, 512, True), (16, 1024, True)])
 def test_depthwise_fwd_bwd(E, orc, H, W, row):
     from uncrtaints_amd import hip_backend as hb
     old = hb.query("uncr_dw_set_row", 1 if row else 0)

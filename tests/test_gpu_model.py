@@ -126,15 +126,25 @@ def test_golden_train_sequence():
         assert abs(a - b) < 2e-2 * abs(b), (losses_, ref.tolist())
 
 
-@pytest.mark.parametrize("B,T,H,W", [(1, 3, 256, 256), (2, 2, 128, 64), (1, 2, 80, 64)])   # last: overlapping adaptive-pool windows
-def test_vs_oracle_fresh_inputs(B, T, H, W):
-    """Fresh seeded inputs (incl. the BASELINE 256x256 size) against the CPU oracle, fwd + loss + grads."""
+@pytest.mark.parametrize("B,T,H,W,special", [
+    (1, 3, 256, 256, ""), (2, 2, 128, 64, ""),
+    (1, 2, 80, 64, ""),            # overlapping adaptive-pool windows, 2.5x up-sampling
+    (1, 1, 64, 64, ""),            # a single date through the temporal attention
+    (1, 12, 64, 64, ""),           # a long series
+    (1, 2, 64, 512, ""),           # wide frames: 2x / 16x up-sampling, depthwise kernels for W != 256
+    (2, 3, 64, 64, "all_padded"),  # every date of sample 1 is padding (all-zero frames)
+])
+def test_vs_oracle_fresh_inputs(B, T, H, W, special):
+    """Fresh seeded inputs (incl. the BASELINE 256x256 size and shape / padding edge cases) against the CPU oracle,
+    fwd + loss + grads."""
     from oracle import uncrtaints_oracle as orc
     from uncrtaints_amd.src import losses
     g = load_golden("g1_diag_t3")
     state = _state(g)
     cfg = orc.OracleConfig(attn_dropout=0.0)
     x, y, dates = orc.synthetic_batch(B, T, H, W, seed=3)
+    if special == "all_padded":
+        x[1] = 0.0
     out_o, loss_o, dx32, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32)
     _, _, dx64, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64)
     m = _build("diag", state)

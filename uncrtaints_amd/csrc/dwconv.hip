@@ -290,7 +290,13 @@ extern "C" int uncr_dw_fwd(const float* in, const float* cA, const float* cB, co
     if (N <= 0 || C <= 0 || H < 2 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
     if (g_dw_row && W == 256 && H >= 4 && (H & 3) == 0) return dw_fwd_row_launch(in, cA, cB, w, out, part, N, C, H, uncr_dw_slots_fwd(H), stream);
     const size_t lds = (size_t)(DW_TR_FWD + 2) * (W + 8) * sizeof(float);
-    if (lds > 60 * 1024) return UNCR_ESHAPE;
+    if (lds > 150 * 1024) return UNCR_ESHAPE;
+    static size_t lds_attr = 0;
+    if (lds > 60 * 1024 && lds > lds_attr) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (W > 440)
+        if (hipFuncSetAttribute((const void*)dw_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return UNCR_EINVAL;
+        lds_attr = lds;
+    }
     hipLaunchKernelGGL(dw_fwd_kernel, dim3(uncr_dw_slots_fwd(H), N * C), dim3(256), lds, stream, in, cA, cB, w, out,
                        (float2*)part, C, H, W);
     UNCR_LAUNCH_CHECK();

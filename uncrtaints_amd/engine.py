@@ -902,6 +902,9 @@ def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor]
         w_att, shared = att, False
         if e.shape[-2] <= att_down:      # feature map not larger than the attention map: the reference takes its AvgPool
             p_drop, dmask = 0.0, None    # branch (kernel 1 = identity at equal size), which has NO dropout (uncrtaints.py:197-204)
+            if tuple(e.shape[-2:]) != (att_down, att_down):
+                raise NotImplementedError(f"feature map {tuple(e.shape[-2:])} vs attention map {att_down}x{att_down}: the "
+                                          "reference's AvgPool branch (H <= 32) is built for the equal-size case only")
     elif mode == "att_mean":
         w_att, shared = head_mean_attention(att), True
     elif mode == "mean":
