@@ -255,3 +255,29 @@ def test_input_as_small_as_the_attention_map_has_no_dropout():
     m.train()
     out = m(dev(torch.from_numpy(g["x"])), batch_positions=dev(torch.from_numpy(g["dates"])))
     close("small_map_train_vs_reference", out, torch.from_numpy(g["train_out"]), tol=2e-5)
+
+
+def test_backward_through_the_model_in_eval_mode():
+    """Gradients with the model in eval mode (BatchNorm on running statistics, no dropout): the fine-tuning /
+    frozen-statistics use case; the fused backward paths must not rely on train-mode forward statistics."""
+    from oracle import uncrtaints_oracle as orc
+    from uncrtaints_amd.src import losses
+    g = load_golden("g1_diag_t3")
+    state = _state(g)
+    cfg = orc.OracleConfig(attn_dropout=0.0)
+    x, y, dates = orc.synthetic_batch(2, 3, 64, 64, seed=21)
+    out_o, loss_o, dx32, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32, training=False)
+    _, _, dx64, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64, training=False)
+    m = _build("diag", state)
+    m.eval()
+    xg = dev(x).requires_grad_(True)
+    out = m(xg, batch_positions=dev(dates))
+    l, _ = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode="diag")(out[:, :, :13], dev(y), out[:, :, 13:26])
+    l.backward()
+    close("evalmode/out", out, out_o)
+    close_vs_truth("evalmode/dx", xg.grad, dx32, dx64, kink_frac=3e-3)
+    for k, v in m.named_parameters():
+        if is_zero_grad(k, g64):
+            continue
+        ktol = 5e-4 if k.startswith(("in_conv", "in_block")) else TOL
+        close_vs_truth(f"evalmode/grad[{k}]", v.grad, g32[k], g64[k], tol=ktol, slack=10.0, cap=3e-4)
