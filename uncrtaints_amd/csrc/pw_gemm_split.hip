@@ -32,6 +32,9 @@
 #ifndef UNCR_NTG_ST
 #define UNCR_NTG_ST 0
 #endif
+#ifndef UNCR_NTG_ST2
+#define UNCR_NTG_ST2 0     // stores of the 256-channel outputs only (268 MB at N=4: larger than any cache level)
+#endif
 template <bool NT> __device__ __forceinline__ float4 pws_ld(const float* p) {
     if constexpr (NT) { const uncr_f4 v = __builtin_nontemporal_load((const uncr_f4*)p); return make_float4(v.x, v.y, v.z, v.w); }
     else return *(const float4*)p;
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                 const int rw = row_of(ct, r);
                 const float4 v = make_float4(acc[0][ct][r], acc[1][ct][r], acc[2][ct][r], acc[3][ct][r]);
                 if (rw + 4 * kg < Cout && (!(PWS_ABL & 1) || v.x == 1.2345e-30f)) {
-                    pws_st<UNCR_NTG_ST && EPI != 4>(g.out + (size_t)(nco + rw) * P + loff, v);
+                    pws_st<(UNCR_NTG_ST || (UNCR_NTG_ST2 && CT == 2)) && EPI != 4>(g.out + (size_t)(nco + rw) * P + loff, v);
                 }
             }
         }
