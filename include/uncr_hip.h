@@ -48,6 +48,11 @@ typedef struct ihipStream_t* hipStream_t;
 #define UNCR_EW_HEAD_FWD 8
 #define UNCR_EW_HEAD_BWD 9
 #define UNCR_EW_RESIDUAL_RELU 10   /* out = a + relu(A*b + B) (ResidualConvBlock skip) */
+/* head with the other variance nonlinearities of get_nonlinearity (uncrtaints.py:223-228): elu(a)+1+eps / identity */
+#define UNCR_EW_HEAD_FWD_ELU 11
+#define UNCR_EW_HEAD_BWD_ELU 12
+#define UNCR_EW_HEAD_FWD_ID 13
+#define UNCR_EW_HEAD_BWD_ID 14
 
 int uncr_version(void);
 int uncr_debug_mfma_probe(float* out, int blocks, int iters, hipStream_t stream);   /* fp32-MFMA peak probe */

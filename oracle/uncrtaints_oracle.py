@@ -369,7 +369,13 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
         mean = cfg.scale_by * torch.sigmoid(mean)                          # uncrtaints.py:384
     if not cfg.covmode:
         return mean
-    var = F.softplus(o[:, :, cfg.mean_idx:cfg.vars_idx], beta=1, threshold=20) + cfg.eps   # :225
+    pre = o[:, :, cfg.mean_idx:cfg.vars_idx]
+    if cfg.out_nonlin_var == "softplus":
+        var = F.softplus(pre, beta=1, threshold=20) + cfg.eps          # uncrtaints.py:225
+    elif cfg.out_nonlin_var == "elu":
+        var = F.elu(pre) + 1 + cfg.eps                                  # uncrtaints.py:226
+    else:
+        var = pre                                                       # nn.Identity(), uncrtaints.py:227 (no eps)
     return torch.cat((mean, var), dim=2)
 
 

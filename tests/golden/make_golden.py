@@ -413,6 +413,7 @@ VARIANTS = {
     "is_mono": dict(is_mono=True, n_head=1),
     "instance": dict(encoder_norm="instance", decoder_norm="instance"),     # nn.InstanceNorm2d everywhere (uncrtaints.py:19)
     "enc_batch": dict(encoder_norm="batch"),                                # BatchNorm2d in in_conv / in_block as well
+    "elu": dict(out_nonlin_var="elu"),                                      # variance = elu(.) + 1 + eps (uncrtaints.py:226)
 }
 
 
@@ -542,8 +543,8 @@ def case_variants():
     out = {}
     for name, kw in VARIANTS.items():
         torch.manual_seed(0)
-        m = uncrtaints.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus",
-                                  covmode="diag", scale_by=1.0, **kw)
+        m = uncrtaints.UNCRTAINTS(**{**dict(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus",
+                                            covmode="diag", scale_by=1.0), **kw})
         m.load_state_dict(variant_state(state, name), strict=True)
         if hasattr(m, "temporal_aggregator"):
             m.temporal_aggregator.attn_dropout.p = 0.0

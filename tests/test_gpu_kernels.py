@@ -429,8 +429,9 @@ def test_pad_mask(E):
     assert m.tolist() == [[0, 0, 0], [0, 0, 1]]
 
 
-@pytest.mark.parametrize("covmode", ["diag", "iso"])
-def test_head_fwd_bwd(E, covmode):
+@pytest.mark.parametrize("covmode,var_mode", [("diag", "softplus"), ("iso", "softplus"), ("diag", "elu"), ("diag", "identity")])
+def test_head_fwd_bwd(E, covmode, var_mode):
+    """out_conv + mean / variance nonlinearities (uncrtaints.py:223-228, 384-388, 432-445): softplus, elu + 1, identity."""
     N, C, H, W = 2, 128, 64, 64
     Co = 26 if covmode == "diag" else 14
     y = rand(N, C, H, W, seed=1)
@@ -438,10 +439,11 @@ def test_head_fwd_bwd(E, covmode):
     gy = rand(N, Co, H, W, seed=4)
     yo, wo, bo = (t.clone().requires_grad_(True) for t in (y, w, b))
     o = torch.einsum("oc,nchw->nohw", wo[:, :, 0, 0], yo) + bo.view(1, -1, 1, 1)
-    out = torch.cat((1.0 * torch.sigmoid(o[:, :13]), F.softplus(o[:, 13:]) + 1e-9), dim=1)
+    fv = {"softplus": lambda v: F.softplus(v) + 1e-9, "elu": lambda v: F.elu(v) + 1 + 1e-9, "identity": lambda v: v}[var_mode]
+    out = torch.cat((1.0 * torch.sigmoid(o[:, :13]), fv(o[:, 13:])), dim=1)
     out.backward(gy)
-    got, sv = E.head_forward(dev(y), dev(w), dev(b), 13, True, 1.0, 1e-9)
-    close(f"head_fwd[{covmode}]", got, out)
+    got, sv = E.head_forward(dev(y), dev(w), dev(b), 13, True, 1.0, 1e-9, var_mode)
+    close(f"head_fwd[{covmode},{var_mode}]", got, out)
     dy, dW, db, _ = E.head_backward(dev(gy), sv, dev(w))
     close("head_dy", dy, yo.grad)
     close("head_dW", dW, wo.grad)

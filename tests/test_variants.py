@@ -14,6 +14,7 @@ VARIANTS = {
     "is_mono": dict(is_mono=True, n_head=1),
     "instance": dict(encoder_norm="instance", decoder_norm="instance"),     # nn.InstanceNorm2d everywhere (uncrtaints.py:19)
     "enc_batch": dict(encoder_norm="batch"),                                # BatchNorm2d in in_conv / in_block as well
+    "elu": dict(out_nonlin_var="elu"),                                      # variance = elu(.) + 1 + eps (uncrtaints.py:226)
 }
 
 
@@ -96,8 +97,8 @@ def test_hip_variants(name):
     state, x, y, dates = _inputs(name)
     oe, ot, loss_o, g32 = _oracle(name, state, x, y, dates)
     _, _, _, g64 = _oracle(name, state, x, y, dates, torch.float64)
-    m = U.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag",
-                     scale_by=1.0, **VARIANTS[name])
+    m = U.UNCRTAINTS(**{**dict(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag",
+                            scale_by=1.0), **VARIANTS[name]})
     m.load_state_dict(state, strict=True)
     if hasattr(m, "temporal_aggregator"):
         m.temporal_aggregator.attn_dropout.p = 0.0

@@ -18,8 +18,15 @@ enum : int {
     EW_SE_POOL = 7,      // stats only: (sum gelu(A*a + B), 0)
     EW_HEAD_FWD = 8,     // out = c < n_mean ? scale*sigmoid(a) : softplus(a)+eps   (per-plane channel test)
     EW_HEAD_BWD = 9,     // out = a * f'(b)   a = d(out), b = pre-activation
-    EW_RESIDUAL_RELU = 10   // out = a + relu(A*b + B)   (ResidualConvBlock skip, uncrtaints.py:67)
+    EW_RESIDUAL_RELU = 10,  // out = a + relu(A*b + B)   (ResidualConvBlock skip, uncrtaints.py:67)
+    // the other variance nonlinearities of get_nonlinearity (uncrtaints.py:223-228): 'elu' -> elu(a)+1+eps, else identity
+    EW_HEAD_FWD_ELU = 11, EW_HEAD_BWD_ELU = 12, EW_HEAD_FWD_ID = 13, EW_HEAD_BWD_ID = 14
 };
+__host__ __device__ constexpr bool ew_is_head_fwd(int op) { return op == EW_HEAD_FWD || op == EW_HEAD_FWD_ELU || op == EW_HEAD_FWD_ID; }
+__host__ __device__ constexpr bool ew_is_head_bwd(int op) { return op == EW_HEAD_BWD || op == EW_HEAD_BWD_ELU || op == EW_HEAD_BWD_ID; }
+__host__ __device__ constexpr int ew_var_mode(int op) {      // 0 softplus, 1 elu + 1, 2 identity
+    return (op == EW_HEAD_FWD_ELU || op == EW_HEAD_BWD_ELU) ? 1 : ((op == EW_HEAD_FWD_ID || op == EW_HEAD_BWD_ID) ? 2 : 0);
+}
 
 struct EwArgs {
     const float* a;
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         const float A = g.k0[plane], B = g.k1[plane];
 #pragma unroll
         for (int i = 0; i < 4; ++i) s0 += gelu_f(fmaf(A, pa[i], B));
-    } else if constexpr (OP == EW_HEAD_FWD) {
+    } else if constexpr (ew_is_head_fwd(OP)) {
         // n_mean > 0: first n_mean channels get scale*sigmoid; n_mean < 0: first |n_mean| channels identity
         const int ch = plane % g.C;
         const int nm = g.n_mean < 0 ? -g.n_mean : g.n_mean;
@@ -125,12 +132,13 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                // nn.Softplus(beta=1, threshold=20): identity above the threshold
                 const float x = pa[i];
-                o[i] = (x > 20.f ? x : log1pf(__expf(x))) + g.eps;
+                if constexpr (ew_var_mode(OP) == 0) o[i] = (x > 20.f ? x : log1pf(__expf(x))) + g.eps;   // nn.Softplus(beta=1, threshold=20)
+                else if constexpr (ew_var_mode(OP) == 1) o[i] = (x > 0.f ? x : expm1f(x)) + 1.f + g.eps;  // nn.ELU() + 1 + eps
+                else o[i] = x;                                                                            // nn.Identity()
             }
         }
-    } else if constexpr (OP == EW_HEAD_BWD) {
+    } else if constexpr (ew_is_head_bwd(OP)) {
         const int ch = plane % g.C;
         const float4 vb = ld_nt4(g.b + off);
         const float* pb = (const float*)&vb;
@@ -143,11 +151,15 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = pa[i] * (pb[i] > 20.f ? 1.f : sigmoid_f(pb[i]));
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (ew_var_mode(OP) == 0) o[i] = pa[i] * (pb[i] > 20.f ? 1.f : sigmoid_f(pb[i]));
+                else if constexpr (ew_var_mode(OP) == 1) o[i] = pa[i] * (pb[i] > 0.f ? 1.f : __expf(pb[i]));
+                else o[i] = pa[i];
+            }
         }
     }
     if constexpr (OP != EW_STATS_SQ && OP != EW_STATS_AUX && OP != EW_SE_POOL) st_nt4(g.out + off, vo);
-    if constexpr (OP != EW_HEAD_FWD && OP != EW_HEAD_BWD) {
+    if constexpr (!ew_is_head_fwd(OP) && !ew_is_head_bwd(OP)) {
         if (g.part) {
             __shared__ float red[8];
             block_sum2<256>(s0, s1, red);
@@ -181,6 +193,10 @@ extern "C" int uncr_ew(int op, const float* a, const float* b, const float* c, c
         EW_CASE(EW_HEAD_FWD)
         EW_CASE(EW_HEAD_BWD)
         EW_CASE(EW_RESIDUAL_RELU)
+        EW_CASE(EW_HEAD_FWD_ELU)
+        EW_CASE(EW_HEAD_BWD_ELU)
+        EW_CASE(EW_HEAD_FWD_ID)
+        EW_CASE(EW_HEAD_BWD_ID)
         default:
             return UNCR_EINVAL;
     }

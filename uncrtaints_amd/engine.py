@@ -957,7 +957,11 @@ def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int,
 # out_conv + output nonlinearities (uncrtaints.py:381,432-445)
 # ------------------------------------------------------------------------------------------------
 
-def head_forward(y: Tensor, w: Tensor, b: Tensor, n_mean: int, mean_sigmoid: bool, scale: float, eps: float):
+_HEAD_OPS = {"softplus": (8, 9), "elu": (11, 12), "identity": (13, 14)}     # (forward, backward) element-wise op codes
+
+
+def head_forward(y: Tensor, w: Tensor, b: Tensor, n_mean: int, mean_sigmoid: bool, scale: float, eps: float,
+                 var_mode: str = "softplus"):
     N, C, H, W = _check4(y)
     P = H * W
     Co = w.shape[0]
@@ -965,8 +969,9 @@ def head_forward(y: Tensor, w: Tensor, b: Tensor, n_mean: int, mean_sigmoid: boo
     o, _ = pw_gemm(y, Wt, N, C, Co, P, bias=b.contiguous())
     out = _f32((N, Co, H, W), y.device)
     nm = n_mean if mean_sigmoid else -n_mean
-    ew(EW_HEAD_FWD, o, out=out, planes=N * Co, P=P, C=Co, n_mean=nm, scale=scale, eps=eps)
-    return out, dict(y=y, o=o, nm=nm, scale=scale, dims=(N, C, Co, H, W), y_h3=getattr(y, "_uncr_h3", None))
+    ew(_HEAD_OPS[var_mode][0], o, out=out, planes=N * Co, P=P, C=Co, n_mean=nm, scale=scale, eps=eps)
+    return out, dict(y=y, o=o, nm=nm, scale=scale, dims=(N, C, Co, H, W), y_h3=getattr(y, "_uncr_h3", None),
+                     var_mode=var_mode)
 
 
 def head_backward(dout: Tensor, sv: dict, w: Tensor, need_dy: bool = True):
@@ -974,7 +979,8 @@ def head_backward(dout: Tensor, sv: dict, w: Tensor, need_dy: bool = True):
     P = H * W
     dout = dout.contiguous()
     do = _f32((N, Co, H, W), dout.device)
-    ew(EW_HEAD_BWD, dout, b=sv["o"], out=do, planes=N * Co, P=P, C=Co, n_mean=sv["nm"], scale=sv["scale"])
+    ew(_HEAD_OPS[sv.get("var_mode", "softplus")][1], dout, b=sv["o"], out=do, planes=N * Co, P=P, C=Co, n_mean=sv["nm"],
+       scale=sv["scale"])
     dW, db = pw_wgrad(do, sv["y"], N, Co, C, P, rowsum=True)
     dy, dy_part = None, None
     if need_dy:

@@ -9,7 +9,7 @@ There is no PyTorch-op fallback: on a machine without the HIP library or a GPU t
 
 Built: block_type in {mbconv, residual}, agg_mode in {att_group, att_mean, mean}, encoder_norm/decoder_norm in {group, batch,
 instance},
-use_v in {False, True}, separate_out, is_mono, out_nonlin_var='softplus', covmode in {diag, iso, uni, None}.
+use_v in {False, True}, separate_out, is_mono, out_nonlin_var in {softplus, elu, identity}, covmode in {diag, iso, uni, None}.
 (SURVEY 8(a17) / 8(f))."""
 import torch
 import torch.nn as nn
@@ -312,7 +312,8 @@ class _HeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, w, b, net):
-        out, sv = E.head_forward(y.contiguous(), w, b, net.mean_idx, net._mean_sigmoid, float(net.scale_by), net._eps)
+        out, sv = E.head_forward(y.contiguous(), w, b, net.mean_idx, net._mean_sigmoid, float(net.scale_by), net._eps,
+                                 getattr(net, "_var_mode", "softplus"))
         ctx.sv, ctx.w = sv, w
         return out
 
@@ -433,10 +434,9 @@ class UNCRTAINTS(nn.Module):
         else:
             self.out_mean = nn.Identity()
         if self.covmode in ['uni', 'iso', 'diag']:
-            if out_nonlin_var != 'softplus':
-                raise NotImplementedError(f"out_nonlin_var='{out_nonlin_var}' is not built on the HIP path (the "
-                                          "reference's diag/iso/uni fix-up always selects 'softplus', "
-                                          "train_reconstruct.py:53-61)")
+            # 'softplus' is what the reference's diag/iso/uni fix-up always selects (train_reconstruct.py:53-61); 'elu' and
+            # the identity fall-through of get_nonlinearity are built too ('relu' raises like the reference, above)
+            self._var_mode = out_nonlin_var if out_nonlin_var in ('softplus', 'elu') else 'identity'
             self.diag_var = get_nonlinearity(out_nonlin_var, eps)
             if self.out_dims < self.vars_idx:
                 raise ValueError(f"out_conv[-1]={self.out_dims} < 13 + covar_dim={self.vars_idx}")
