@@ -117,6 +117,13 @@ int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, float* out,
                  const float* k1, const float* k2, const float* bias, int bias_stride_n, const float* aux,
                  const float* e0, const float* e1, const float* e2, const float* e3 /* epi 3 coefficients */,
                  float* part, int N, int Cin, int Cout, int P, int pro, int epi, hipStream_t stream);
+/* out_conv (Conv2d k=1 + bias, uncrtaints.py:432-440) with the output nonlinearities (uncrtaints.py:441-445) in the GEMM
+ * epilogue, Cout <= 64: channel < |n_mean| -> n_mean > 0 ? scale*sigmoid : identity; the others -> var_mode 0 softplus(beta 1,
+ * threshold 20) + eps, 1 elu + 1 + eps, 2 identity.  pre (nullable) also receives the pre-activation for the backward
+ * (uncr_ew HEAD_BWD*); without it, uncr_ew(HEAD_BWD*, C = -Cout) recovers the derivatives from the output (less accurate
+ * where the variance is within rounding of eps). */
+int uncr_head_fwd(const float* y, const float* Wt, const float* bias, float* out, float* pre, int N, int Cin, int Cout,
+                  int P, int n_mean, float scale, float eps, int var_mode, hipStream_t stream);
 /* Backward of MBConv's pw1 (uncrtaints.py:100-146: x + block(PreNorm(x))) with the PreNorm backward and the skip
  * connection in the GEMM epilogue: out = dy + c1*(W^T . normbwd(in, in2; k0..k2)) + c2*x + c3; if xh3 (the h3 of the
  * block that produced x) is given, part receives (sum out, sum out*xh3) for that block's last norm backward.

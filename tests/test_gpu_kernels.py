@@ -448,6 +448,11 @@ def test_head_fwd_bwd(E, covmode, var_mode):
     close("head_dy", dy, yo.grad)
     close("head_dW", dW, wo.grad)
     close("head_db", db, bo.grad)
+    # the derivative can also be recovered from the OUTPUT alone (uncr_ew HEAD_BWD with C = -Cout): same gradient for
+    # pre-activations of moderate size
+    sv2 = dict(sv, o=got, from_out=True)
+    dy2, _, _, _ = E.head_backward(dev(gy), sv2, dev(w))
+    close("head_dy_from_output", dy2, yo.grad, tol=2e-5)
 
 
 def test_mgnll_known_answers():

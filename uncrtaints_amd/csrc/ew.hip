@@ -139,22 +139,31 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
             }
         }
     } else if constexpr (ew_is_head_bwd(OP)) {
-        const int ch = plane % g.C;
+        // C > 0: b holds the pre-activation; C < 0: b holds the head's OUTPUT (fused forward, uncr_head_fwd) and the
+        // derivative is recovered from it: sigmoid: s(1-s) with s = out/scale; softplus: 1 - exp(-(out - eps));
+        // elu + 1: out - eps for out - eps <= 1, else 1
+        const bool from_out = g.C < 0;
+        const int Cc = from_out ? -g.C : g.C;
+        const int ch = plane % Cc;
         const float4 vb = ld_nt4(g.b + off);
         const float* pb = (const float*)&vb;
         const int nm = g.n_mean < 0 ? -g.n_mean : g.n_mean;
         if (ch < nm) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float sg = sigmoid_f(pb[i]);
+                const float sg = from_out ? pb[i] / g.scale : sigmoid_f(pb[i]);
                 o[i] = g.n_mean > 0 ? pa[i] * g.scale * sg * (1.f - sg) : pa[i];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if constexpr (ew_var_mode(OP) == 0) o[i] = pa[i] * (pb[i] > 20.f ? 1.f : sigmoid_f(pb[i]));
-                else if constexpr (ew_var_mode(OP) == 1) o[i] = pa[i] * (pb[i] > 0.f ? 1.f : __expf(pb[i]));
-                else o[i] = pa[i];
+                if constexpr (ew_var_mode(OP) == 0) {
+                    const float d = from_out ? -expm1f(-(pb[i] - g.eps)) : (pb[i] > 20.f ? 1.f : sigmoid_f(pb[i]));
+                    o[i] = pa[i] * d;
+                } else if constexpr (ew_var_mode(OP) == 1) {
+                    const float d = from_out ? fminf(pb[i] - g.eps, 1.f) : (pb[i] > 0.f ? 1.f : __expf(pb[i]));
+                    o[i] = pa[i] * d;
+                } else o[i] = pa[i];
             }
         }
     }

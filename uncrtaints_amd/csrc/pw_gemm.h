@@ -26,6 +26,12 @@ struct PwArgs {
     const float* aux2;   // epi 5: dy
     const float* aux3;   // epi 5: h3 of the producing block (or null: no statistics); epi 6: c0 of the producing ConvLayer,
                          // whose ReLU backward is applied to the output: out *= [e3*aux3 + bias > 0] (bias, e3: [N*Cout])
+    // epi 7 (narrow fp32-MFMA kernels only): head nonlinearities on the fresh accumulator (uncrtaints.py:441-445):
+    //   channel < |head_nm|: head_nm > 0 ? head_scale*sigmoid(v) : v;  else variance f(v) (+ head_eps), head_var 0 softplus,
+    //   1 elu + 1, 2 identity
+    int head_nm = 0, head_var = 0;
+    float head_scale = 1.f, head_eps = 0.f;
+    float* head_pre = nullptr;   // optional second output: the pre-activation [N][Cout][P]
 };
 
 // x = h + m + l exactly, each part a bf16 (kept in the upper half of a 32-bit word).  Truncation split: h takes

@@ -172,6 +172,19 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
                     v.w = gelu_grad_f(fmaf(A, x.w, B)) * fmaf(S, v.w, D);
                     s0 = v.x + v.y + v.z + v.w;
                     s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
+                } else if (epi == 7) {
+                    // out_conv's nonlinearities (uncrtaints.py:441-445): mean channels scale*sigmoid (or identity),
+                    // variance channels softplus / elu+1 / identity (+ eps): the pre-activation never reaches HBM
+                    const int nm = g.head_nm < 0 ? -g.head_nm : g.head_nm;
+                    if (g.head_pre) *(float4*)(g.head_pre + o) = v;     // pre-activation for the backward (exact derivatives)
+                    float* pv = (float*)&v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float x = pv[i];
+                        if (col < nm) pv[i] = g.head_nm > 0 ? g.head_scale * sigmoid_f(x) : x;
+                        else if (g.head_var == 0) pv[i] = (x > 20.f ? x : log1pf(__expf(x))) + g.head_eps;
+                        else if (g.head_var == 1) pv[i] = (x > 0.f ? x : expm1f(x)) + 1.f + g.head_eps;
+                    }
                 }
                 *(float4*)(g.out + o) = v;
                 if (epi == 1) {
@@ -183,14 +196,14 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
                     s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
                 }
             }
-            if (epi) {   // block-uniform
+            if (epi && epi != 7) {   // block-uniform
                 s0 = half_wave_sum_dpp(s0);
                 s1 = half_wave_sum_dpp(s1);
                 if ((lane & 31) == 31) { red[wm][col][0] = s0; red[wm][col][1] = s1; }
             }
         }
     }
-    if (epi) {
+    if (epi && epi != 7) {
         __syncthreads();
         for (int c = tid; c < COUTP; c += NT) {
             if (c < Cout) {
@@ -523,6 +536,23 @@ extern "C" int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, 
         hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, true>), grid, dim3(128), 0, stream, g);
     else
         hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false>), grid, dim3(128), 0, stream, g);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+// out_conv + output nonlinearities in one kernel (narrow fp32-MFMA GEMM, Cout <= 64): uncrtaints.py:432-445
+extern "C" int uncr_head_fwd(const float* y, const float* Wt, const float* bias, float* out, float* pre, int N, int Cin,
+                             int Cout, int P, int n_mean, float scale, float eps, int var_mode, hipStream_t stream) {
+    if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 64 || var_mode < 0 || var_mode > 2) return UNCR_ESHAPE;
+    if (!y || !Wt || !out) return UNCR_EINVAL;
+    const int tp = uncr_pw_tile_px(Cout);
+    if (P % tp) return UNCR_ESHAPE;
+    PwArgs g{y, nullptr, Wt, out, nullptr, nullptr, nullptr, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+             0, Cin, Cout, P, PRO_NONE, 7, nullptr, nullptr};
+    g.head_nm = n_mean; g.head_var = var_mode; g.head_scale = scale; g.head_eps = eps; g.head_pre = pre;
+    dim3 grid(P / tp, N);
+    if (pw_coutp(Cout) == 64) hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false>), grid, dim3(128), 0, stream, g);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

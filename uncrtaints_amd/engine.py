@@ -966,12 +966,19 @@ def head_forward(y: Tensor, w: Tensor, b: Tensor, n_mean: int, mean_sigmoid: boo
     P = H * W
     Co = w.shape[0]
     Wt = pack_wt(w.reshape(Co, C), transpose=True)
-    o, _ = pw_gemm(y, Wt, N, C, Co, P, bias=b.contiguous())
     out = _f32((N, Co, H, W), y.device)
     nm = n_mean if mean_sigmoid else -n_mean
-    ew(_HEAD_OPS[var_mode][0], o, out=out, planes=N * Co, P=P, C=Co, n_mean=nm, scale=scale, eps=eps)
-    return out, dict(y=y, o=o, nm=nm, scale=scale, dims=(N, C, Co, H, W), y_h3=getattr(y, "_uncr_h3", None),
-                     var_mode=var_mode)
+    vm = {"softplus": 0, "elu": 1, "identity": 2}[var_mode]
+    if Co <= 64:       # convolution + nonlinearities in ONE kernel (the pre-activation is a second output, for the backward)
+        o = _f32((N, Co, H, W), y.device)
+        hb.call("uncr_head_fwd", y, Wt, b.contiguous(), out, o, N, C, Co, P, nm, float(scale), float(eps), vm, _stream())
+        from_out = False
+    else:
+        o, _ = pw_gemm(y, Wt, N, C, Co, P, bias=b.contiguous())
+        ew(_HEAD_OPS[var_mode][0], o, out=out, planes=N * Co, P=P, C=Co, n_mean=nm, scale=scale, eps=eps)
+        from_out = False
+    return out, dict(y=y, o=o, nm=nm, scale=scale, eps=eps, from_out=from_out, dims=(N, C, Co, H, W),
+                     y_h3=getattr(y, "_uncr_h3", None), var_mode=var_mode)
 
 
 def head_backward(dout: Tensor, sv: dict, w: Tensor, need_dy: bool = True):
@@ -979,8 +986,8 @@ def head_backward(dout: Tensor, sv: dict, w: Tensor, need_dy: bool = True):
     P = H * W
     dout = dout.contiguous()
     do = _f32((N, Co, H, W), dout.device)
-    ew(_HEAD_OPS[sv.get("var_mode", "softplus")][1], dout, b=sv["o"], out=do, planes=N * Co, P=P, C=Co, n_mean=sv["nm"],
-       scale=sv["scale"])
+    ew(_HEAD_OPS[sv.get("var_mode", "softplus")][1], dout, b=sv["o"], out=do, planes=N * Co, P=P,
+       C=-Co if sv.get("from_out") else Co, n_mean=sv["nm"], scale=sv["scale"], eps=sv.get("eps", 0.0))
     dW, db = pw_wgrad(do, sv["y"], N, Co, C, P, rowsum=True)
     dy, dy_part = None, None
     if need_dy:
