@@ -11,7 +11,7 @@
 
 #define AGG_PX 1024   // pixels per block
 #ifndef AGG_ABL
-#define AGG_ABL 0      // development ablations: 1 no dropout hash, 2 no attention gathers, 4 one head per block
+#define AGG_ABL 0      // development ablations: 1 no dropout hash, 2 no attention gathers
 #endif
 
 struct AggArgs {
@@ -230,7 +230,7 @@ static int agg_rows(int H, int W, int AH) {
 
 template <bool BWD>
 static void agg_launch(const AggArgs& g, hipStream_t stream) {
-    const int zs = (AGG_ABL & 4) ? g.NH : (g.NH % 4 == 0 ? 4 : 1);
+    const int zs = g.NH <= 64 ? g.NH : (g.NH % 4 == 0 ? 4 : 1);      // one head per block: measured 4 % faster than four (more blocks in flight)
     const dim3 grid(g.H * g.W / AGG_PX, g.B, zs);
     const int nrows = agg_rows(g.H, g.W, g.AH);
     const size_t lds = (size_t)((g.NH + zs - 1) / zs) * g.T * nrows * g.AW * sizeof(float);
