@@ -1,5 +1,6 @@
+"""SE-pool (uncr_ew SE_POOL) micro-benchmark at the bench shape (run on the GPU box)."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from uncrtaints_amd import engine as E
 N, C, P = 4, 256, 65536

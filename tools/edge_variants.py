@@ -1,5 +1,8 @@
-import sys, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+"""Variants at edge shapes against the fp64 oracle (run on the GPU box): python tools/edge_variants.py [variants]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
 from oracle import uncrtaints_oracle as orc
 from uncrtaints_amd.src.backbones import uncrtaints as U
 from uncrtaints_amd.src import losses
