@@ -281,3 +281,47 @@ def test_backward_through_the_model_in_eval_mode():
             continue
         ktol = 5e-4 if k.startswith(("in_conv", "in_block")) else TOL
         close_vs_truth(f"evalmode/grad[{k}]", v.grad, g32[k], g64[k], tol=ktol, slack=10.0, cap=3e-4)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("input_dim_13", dict(input_dim=13)),                                              # --use_sar off (model_utils.py:85-108)
+    ("widths_64", dict(encoder_widths=[64], decoder_widths=[64] * 5)),
+    ("widths_96", dict(encoder_widths=[96], decoder_widths=[96] * 2)),
+    ("widths_32", dict(encoder_widths=[32], decoder_widths=[32] * 2)),
+    ("two_decoder_blocks", dict(decoder_widths=[128] * 2)),
+    ("n_head_8", dict(n_head=8)),
+    ("n_head_32", dict(n_head=32)),
+])
+def test_non_default_widths_and_heads(name, kw):
+    """Constructor arguments away from the BASELINE configuration (channel widths, decoder depth, head count, no SAR
+    channels): forward and every gradient against the oracle; these shapes run on the narrow fp32-MFMA kernels."""
+    from oracle import uncrtaints_oracle as orc
+    from uncrtaints_amd.src import losses
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    cfg = orc.OracleConfig(attn_dropout=0.0, **kw)
+    state = orc.init_params(cfg, seed=4)
+    x, y, dates = orc.synthetic_batch(1, 3, 64, 64, seed=5)
+    x = x[:, :, :kw.get("input_dim", 15)].contiguous()
+    out_o, loss_o, dx32, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32)
+    _, _, dx64, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64)
+    mk = dict(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag", scale_by=1.0)
+    mk.update(kw)
+    m = U.UNCRTAINTS(**mk)
+    m.load_state_dict(state, strict=True)
+    m.temporal_aggregator.attn_dropout.p = 0.0
+    m = m.to(DEV).train()
+    out = m(dev(x), batch_positions=dev(dates))
+    l, _ = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode="diag")(out[:, :, :13], dev(y), out[:, :, 13:26])
+    l.backward()
+    close(f"{name}/out", out, out_o)
+    for k, v in m.named_parameters():
+        if is_zero_grad(k, g64):
+            continue
+        ktol = 5e-4 if k.startswith(("in_conv", "in_block")) else TOL
+        close_vs_truth(f"{name}/grad[{k}]", v.grad, g32[k], g64[k], tol=ktol, slack=10.0, cap=3e-4)
+
+
+def test_unsupported_head_split_raises():
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    with pytest.raises(NotImplementedError):
+        U.UNCRTAINTS(input_dim=15, n_head=4)          # 32 channels per head

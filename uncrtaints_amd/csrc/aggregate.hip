@@ -213,7 +213,7 @@ extern "C" int uncr_agg_slots(int P) { return P / AGG_PX; }
 
 static int agg_check(int B, int T, int C, int NH, int H, int W, int AH, int AW) {
     if (B <= 0 || T <= 0 || C % NH || C > 256) return UNCR_ESHAPE;
-    if (C / NH != 4 && C / NH != 8 && C / NH != 16) return UNCR_ESHAPE;
+    { const int ch = C / NH; if (ch != 2 && ch != 4 && ch != 6 && ch != 8 && ch != 16 && ch != 32) return UNCR_ESHAPE; }   // channels per head
     if ((W & 3) || W > BADJ_MAXW || ((H * W) % AGG_PX)) return UNCR_ESHAPE;
     if (H < AH || W < AW) return UNCR_ESHAPE;     // avg-pool branch (uncrtaints.py:204) not built; H == AH is the
                                                   // identity up-sampling (LTAE2d's attention-weighted values)
@@ -241,9 +241,12 @@ static void agg_launch(const AggArgs& g, hipStream_t stream) {
         else hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, false>), grid, dim3(256), 0, stream, g, nrows);        \
     } while (0)
     switch (g.C / g.NH) {
+        case 2: AGG_GO(2); break;
         case 4: AGG_GO(4); break;
+        case 6: AGG_GO(6); break;
         case 8: AGG_GO(8); break;
-        default: AGG_GO(16); break;
+        case 16: AGG_GO(16); break;
+        default: AGG_GO(32); break;
     }
 #undef AGG_GO
 }

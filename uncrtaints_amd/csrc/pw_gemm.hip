@@ -577,7 +577,7 @@ extern "C" int uncr_pw_gemm_dx(const float* in, const float* in2, const float* W
     return pw_split_launch_p3(g, N, pw_coutp(Cout), stream);
 }
 
-// weight-gradient shapes: (COP, CIP) in {(128,256), (256,128), (128,32), (32,128), (64,256)}
+// weight-gradient shapes: (COP, CIP) in {(128,256), (256,128), (128,32), (32,128), (64,256), (32,256), (64,128), (32,32), (64,32)}
 static int wg_shape(int Cd, int Cx, int* cop, int* cip) {
     if (Cd > 128 && Cd <= 256 && Cx > 32 && Cx <= 128) { *cop = 256; *cip = 128; return 0; }
     if (Cd > 64 && Cd <= 128 && Cx > 32 && Cx <= 128) { *cop = 256; *cip = 128; return 0; }   // 128 x 128 (use_v): padded rows
@@ -585,6 +585,11 @@ static int wg_shape(int Cd, int Cx, int* cop, int* cip) {
     if (Cd > 32 && Cd <= 128 && Cx <= 32) { *cop = 128; *cip = 32; return 2; }
     if (Cd <= 32 && Cx > 32 && Cx <= 128) { *cop = 32; *cip = 128; return 3; }
     if (Cd > 32 && Cd <= 64 && Cx > 128 && Cx <= 256) { *cop = 64; *cip = 256; return 4; }
+    if (Cd <= 32 && Cx > 128 && Cx <= 256) { *cop = 32; *cip = 256; return 5; }              // keys of n_head <= 8
+    if (Cd > 32 && Cd <= 64 && Cx > 32 && Cx <= 128) { *cop = 64; *cip = 128; return 6; }     // 64-wide blocks
+    if (Cd <= 32 && Cx <= 32) { *cop = 32; *cip = 32; return 7; }
+    if (Cd > 32 && Cd <= 64 && Cx <= 32) { *cop = 64; *cip = 32; return 8; }
+    if (Cd > 128 && Cd <= 256 && Cx <= 32) { *cop = 256; *cip = 32; return 9; }               // L-TAE inconv of 32-wide encoders
     return -1;
 }
 
@@ -632,6 +637,11 @@ extern "C" int uncr_pw_wgrad(const float* d, const float* d2, const float* x, co
         case 2: WG_LAUNCH(1, 1, 4, 1, 256)
         case 3: WG_LAUNCH(1, 1, 1, 4, 256)
         case 4: WG_LAUNCH(2, 4, 1, 2, 128)
+        case 5: WG_LAUNCH(1, 4, 1, 2, 128)
+        case 6: WG_LAUNCH(2, 4, 1, 1, 64)
+        case 7: WG_LAUNCH(1, 1, 1, 1, 64)
+        case 8: WG_LAUNCH(2, 1, 1, 1, 64)
+        case 9: WG_LAUNCH(2, 1, 4, 1, 256)
 #undef WG_LAUNCH
     }
     UNCR_LAUNCH_CHECK();

@@ -369,6 +369,9 @@ class UNCRTAINTS(nn.Module):
             assert encoder_widths[-1] == decoder_widths[-1]
         else:
             decoder_widths = encoder_widths
+        if not is_mono and (encoder_widths[-1] % n_head or encoder_widths[-1] // n_head not in (2, 4, 6, 8, 16)):
+            raise NotImplementedError(f"encoder width {encoder_widths[-1]} with n_head={n_head}: the L-TAE / aggregation kernels are built "
+                                      "for 2, 4, 6, 8 or 16 channels per head")
         if block_type not in ('mbconv', 'residual'):
             raise NotImplementedError(block_type)
         if use_v and (agg_mode != "att_group" or is_mono):
