@@ -325,3 +325,10 @@ def test_unsupported_head_split_raises():
     from uncrtaints_amd.src.backbones import uncrtaints as U
     with pytest.raises(NotImplementedError):
         U.UNCRTAINTS(input_dim=15, n_head=4)          # 32 channels per head
+    with pytest.raises(NotImplementedError):
+        U.UNCRTAINTS(input_dim=15, d_model=512)       # wider than the GEMM kernels
+    with pytest.raises(NotImplementedError):
+        U.UNCRTAINTS(input_dim=15, encoder_widths=[256], decoder_widths=[256] * 2)
+    from uncrtaints_amd import engine
+    with pytest.raises(NotImplementedError):          # the weight pre-pack refuses what the kernels cannot take (no OOB packing)
+        engine.prepack([(torch.randn(512, 128, device=DEV), True)])

@@ -8,7 +8,8 @@ from uncrtaints_amd.src.backbones import uncrtaints as U
 from uncrtaints_amd.src import losses
 def rel(a, b): return ((a.double().cpu() - b.double()).abs().max() / b.double().abs().max()).item()
 iso = dict(covmode="iso", out_conv=[14])
-cases = [("diag", {}, {}, (1, 6, 96, 64))]
+uv64 = dict(use_v=True, encoder_widths=[64], decoder_widths=[64] * 2)
+cases = [("use_v", uv64, uv64, (2, 3, 64, 64)), ("use_v", dict(use_v=True), dict(use_v=True), (2, 3, 64, 64))]
 if len(sys.argv) > 1 and sys.argv[1] == "variants":
     cases = [("use_v", dict(use_v=True), dict(use_v=True), (2, 3, 80, 64)),
              ("residual", dict(block_type="residual", decoder_widths=[128, 128]), dict(block_type="residual", decoder_widths=[128, 128]), (1, 2, 64, 128)),
@@ -50,6 +51,6 @@ for name, okw, mkw, (B, T, H, W) in cases:
                 if g64 is None or g64.abs().max().item() < 1e-6 * gmax: continue
                 rows.append((rel(v.grad, g64), rel(pt[k].grad, g64), k))
             rows.sort(reverse=True)
-            res.append(rows[:3] if len(cases) > 1 else rows)
+            res.append(rows[:4])
     print(name, (B, T, H, W), "eval %.2e train %.2e" % (res[0], res[1]))
     for hip, cpu, k in res[2]: print("     hip-vs-fp64 %.2e  cpu32-vs-fp64 %.2e  %s" % (hip, cpu, k))

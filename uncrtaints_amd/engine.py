@@ -198,7 +198,11 @@ def prepack(weights) -> None:
         for w, tr in weights:
             R, Cc = w.shape
             rows_k, cols_co = (Cc, R) if tr else (R, Cc)
-            sizes.append((hb.query("uncr_pw_wt_floats", rows_k, cols_co) + 3) // 4 * 4)     # keep 16-B alignment
+            nf = hb.query("uncr_pw_wt_floats", rows_k, cols_co)
+            if nf <= 0:
+                raise NotImplementedError(f"1x1 convolution {rows_k} -> {cols_co}: the GEMM kernels are built for at most 256 "
+                                          "input and 256 output channels")
+            sizes.append((nf + 3) // 4 * 4)     # keep 16-B alignment
             thr.append(hb.query("uncr_pack_wt_threads", rows_k, cols_co))
             dims.append((rows_k, cols_co, Cc))
         flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
@@ -229,7 +233,11 @@ def pack_wt(W2d: Tensor, transpose: bool) -> Tensor:
     if hit is not None and hit[1] == W2d._version:
         return hit[0]
     rows_k, cols_co = (Cc, R) if transpose else (R, Cc)
-    out = _f32((hb.query("uncr_pw_wt_floats", rows_k, cols_co),), W2d.device)
+    nf = hb.query("uncr_pw_wt_floats", rows_k, cols_co)
+    if nf <= 0:
+        raise NotImplementedError(f"1x1 convolution {rows_k} -> {cols_co}: the GEMM kernels are built for at most 256 input and "
+                                  "256 output channels")
+    out = _f32((nf,), W2d.device)
     hb.call("uncr_pack_wt", W2d, rows_k, cols_co, Cc, 1 if transpose else 0, out, _stream())
     return out
 

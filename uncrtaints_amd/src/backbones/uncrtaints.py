@@ -372,6 +372,9 @@ class UNCRTAINTS(nn.Module):
         if not is_mono and (encoder_widths[-1] % n_head or encoder_widths[-1] // n_head not in (2, 4, 6, 8, 16)):
             raise NotImplementedError(f"encoder width {encoder_widths[-1]} with n_head={n_head}: the L-TAE / aggregation kernels are built "
                                       "for 2, 4, 6, 8 or 16 channels per head")
+        if d_model is not None and d_model > 256 or max(list(encoder_widths) + list(decoder_widths)) > 128 and block_type == 'mbconv':
+            raise NotImplementedError("the GEMM kernels are built for at most 256 channels: d_model <= 256 and MBConv widths <= 128 "
+                                      "(hidden width = 2 x width)")
         if block_type not in ('mbconv', 'residual'):
             raise NotImplementedError(block_type)
         if use_v and (agg_mode != "att_group" or is_mono):
