@@ -291,6 +291,12 @@ def test_backward_through_the_model_in_eval_mode():
     ("two_decoder_blocks", dict(decoder_widths=[128] * 2)),
     ("n_head_8", dict(n_head=8)),
     ("n_head_32", dict(n_head=32)),
+    ("scale_by_10", dict(scale_by=10.0)),                   # the README training configuration: eps = 1e-3 on the variance
+    ("no_positional_encoding", dict(positional_encoding=False)),
+    ("d_model_128", dict(d_model=128)),
+    ("d_k_8", dict(d_k=8)),
+    ("mean_without_sigmoid", dict(out_nonlin_mean=False)),
+    ("pad_value_1", dict(pad_value=1.0)),
 ])
 def test_non_default_widths_and_heads(name, kw):
     """Constructor arguments away from the BASELINE configuration (channel widths, decoder depth, head count, no SAR
@@ -302,6 +308,9 @@ def test_non_default_widths_and_heads(name, kw):
     state = orc.init_params(cfg, seed=4)
     x, y, dates = orc.synthetic_batch(1, 3, 64, 64, seed=5)
     x = x[:, :, :kw.get("input_dim", 15)].contiguous()
+    if kw.get("pad_value") == 1.0:
+        x[0, 2] = 1.0                       # one padded date under the non-default pad value
+    y = y * kw.get("scale_by", 1.0)
     out_o, loss_o, dx32, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32)
     _, _, dx64, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64)
     mk = dict(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag", scale_by=1.0)
