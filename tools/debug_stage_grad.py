@@ -36,6 +36,7 @@ l, _ = losses.MultiGaussianNLLLoss(reduction="mean", full=True, mode="diag")(out
 t64, t32 = res[torch.float64], res[torch.float32]
 print("d/d(agg): hip %.2e cpu32 %.2e" % (rel(rec["dagg"], t64["agg"]), rel(t32["agg"], t64["agg"])))
 de_h = rec["de"].view(B, T, 128, H, W)
+t64["e"], t32["e"] = t64["e"].reshape(de_h.shape), t32["e"].reshape(de_h.shape)
 print("d/d(e)  : hip %.2e cpu32 %.2e" % (rel(de_h, t64["e"]), rel(t32["e"], t64["e"])))
 diff = (de_h.double().cpu() - t64["e"]).abs()
 idx = torch.nonzero(diff > 1e-3 * t64["e"].abs().max())
