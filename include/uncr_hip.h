@@ -55,16 +55,6 @@ typedef struct ihipStream_t* hipStream_t;
 #define UNCR_EW_HEAD_BWD_ID 14
 
 int uncr_version(void);
-int uncr_debug_mfma_probe(float* out, int blocks, int iters, hipStream_t stream);   /* fp32-MFMA peak probe */
-/* debug: y = erf_f(x) (what 0), gelu_f (1), gelu_grad_f (2), raw v_exp_f32 2^x (3) -- accuracy probes */
-int uncr_debug_erf(const float* x, float* y, int n, int what, hipStream_t stream);
-int uncr_debug_mfma_probe_bf16(float* out, int blocks, int iters, hipStream_t stream);   /* bf16-MFMA peak probe */
-/* debug: out[32][32] = A[32][K] * B[K][32] through the 3-way bf16 split on v_mfma_f32_32x32x16_bf16
- * (terms = 1, 3, 6 or 9 partial products); numerics probe, K % 16 == 0 */
-/* ds_read_b64_tr_b16 semantics probe: lds[i] = i (16-bit); lane l reads at element offset offs[l] (64 ints);
- * out[l*4 + j] = j-th value received (256 ints). */
-int uncr_debug_tr_b16_probe(const int* offs, int* out, hipStream_t stream);
-int uncr_debug_bf16split_probe(const float* A, const float* B, float* out, int K, int terms, hipStream_t stream);
 
 /* ---- normalisation coefficients: nn.GroupNorm / nn.BatchNorm2d statistics
  *      (uncrtaints.py:16-22 get_norm_layer, utae.py:470-473, uncrtaints.py:72-79 PreNorm) ---- */
@@ -269,7 +259,9 @@ int uncr_eltloss_bwd(int kind, const float* pred, const float* targ, const float
 
 /* ---- MGNLL loss (losses.py:131-218) and ensemble combine (ensemble_reconstruct.py:116-133) ---- */
 int uncr_mgnll_blocks(int P);
-int uncr_mgnll_fwd(const float* pred, const float* targ, const float* var, float* loss_none, float* part,
+/* vclamp (nullable) [B][K][P]: the clamped per-band variance max(var, eps) (iso: the one channel broadcast to K) -- what the
+ * reference returns as the diagonal of its second result (losses.py:145,203-211). */
+int uncr_mgnll_fwd(const float* pred, const float* targ, const float* var, float* loss_none, float* vclamp, float* part,
                    float* loss_out, int* neg_flag, int B, int K, int Kv, int H, int W, float eps, int reduction,
                    hipStream_t stream);
 int uncr_mgnll_bwd(const float* pred, const float* targ, const float* var, const float* gscalar,

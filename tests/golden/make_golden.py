@@ -406,6 +406,68 @@ def case_trainseq():
     print("g6_trainseq", ls)
 
 
+def case_weightinit():
+    """G16: `netG.apply(weight_init)` (train_reconstruct.py:627, weight_init.py:4-74) on a freshly built reference model
+    under a fixed seed: checksums of every parameter and buffer.  The build's classes + weight_init must reproduce them
+    bit for bit (same module types in the same construction / traversal order consume the same RNG stream)."""
+    out = {}
+    for tag, kw in (("diag", dict(covmode="diag", out_conv=[26])), ("iso_usev", dict(covmode="iso", out_conv=[14], use_v=True))):
+        torch.manual_seed(7)
+        m = uncrtaints.UNCRTAINTS(**{**dict(input_dim=15, out_nonlin_mean=True, out_nonlin_var="softplus", scale_by=1.0), **kw})
+        m.apply(weight_init)
+        for k, v in m.state_dict().items():
+            if v.dtype.is_floating_point:
+                out[f"{tag}/sum/{k}"] = checksum(v.numpy())
+        out[f"{tag}/Q"] = m.temporal_encoder.attention_heads.Q.detach().numpy().copy()
+        out[f"{tag}/in_conv_bias"] = m.in_conv.conv.conv[0].bias.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "g16_weightinit.npz"), **out)
+    print("g16_weightinit", len(out))
+
+
+def case_refcheckpoint():
+    """G17: a checkpoint FILE written by the reference's own save_model (model_utils.py:117-125) after one
+    optimize_parameters step of a narrow model (widths 32, d_model 64: the file layout does not depend on the widths and the
+    fixture stays small), plus checksums of what it holds.  The build's load_checkpoint / load_model must read it."""
+    import shutil
+    import tempfile
+    from parse_args import create_parser
+    from src.model_utils import get_model, save_model
+    from src.utils import str2list
+    cfg = create_parser(mode="train").parse_args([])
+    cfg.model, cfg.use_sar, cfg.device, cfg.lr, cfg.input_t = "uncrtaints", True, "cpu", 1e-3, 3
+    cfg = str2list(cfg, ["encoder_widths", "decoder_widths", "out_conv"])
+    cfg.encoder_widths, cfg.decoder_widths, cfg.d_model = [32], [32, 32], 64
+    cfg.out_conv[-1] += 13
+    cfg.var_nonLinearity = "softplus"
+    torch.manual_seed(5)
+    model = get_model(cfg)
+    model.netG.apply(weight_init)
+    model.train()
+    x, y, dates = synth(1, 3, 32, 32, 13)
+    model.set_input({"A": x, "B": y, "dates": dates, "masks": torch.zeros(1)})
+    model.optimize_parameters()
+    tmp = tempfile.mkdtemp()
+    cfg.res_dir, cfg.experiment_name = tmp, "exp"
+    os.makedirs(os.path.join(tmp, "exp"))
+    save_model(cfg, 7, model, "model_epoch_7")
+    shutil.copy(os.path.join(tmp, "exp", "model_epoch_7.pth.tar"), os.path.join(HERE, "g17_refcheckpoint.pth.tar"))
+    out = {"meta": json.dumps(dict(epoch=7, encoder_widths=[32], decoder_widths=[32, 32], d_model=64, out_conv=cfg.out_conv,
+                                   lr=cfg.lr, gamma=cfg.gamma, scale_by=cfg.scale_by))}
+    for k, v in model.netG.state_dict().items():
+        out["sum/" + k] = checksum(v.numpy().astype(np.float64))
+    st = model.optimizer_G.state_dict()["state"]
+    out["adam_exp_avg_sum"] = np.array([float(v["exp_avg"].double().sum()) for v in st.values()])
+    out["adam_step"] = np.array([float(v["step"]) for v in st.values()])
+    # the model's eval-mode output on the saved weights, so a loaded model can be run against it
+    model.eval()
+    with torch.no_grad():
+        o = model.netG(x, batch_positions=dates)
+    out["x"], out["dates"], out["eval_out"] = x.numpy(), dates.numpy(), o.numpy()
+    np.savez_compressed(os.path.join(HERE, "g17_refcheckpoint.npz"), **out)
+    shutil.rmtree(tmp)
+    print("g17_refcheckpoint", os.path.getsize(os.path.join(HERE, "g17_refcheckpoint.pth.tar")))
+
+
 VARIANTS = {
     "att_mean": dict(agg_mode="att_mean"),
     "mean": dict(agg_mode="mean"),
@@ -575,6 +637,10 @@ if __name__ == "__main__":
     case_model("g1_diag_t3", "diag", 2, 3, 64, 64, seed=1, full_grads=True)
     case_model("g1_diag_t3_pad", "diag", 2, 3, 64, 64, seed=1, full_grads=False, pad_last=True, save_state=False, taps=False)
     case_model("g1_iso_t6", "iso", 1, 6, 64, 64, seed=2, full_grads=False)
+  if "--only-weightinit" in sys.argv:
+    case_weightinit(); sys.exit(0)
+  if "--only-refcheckpoint" in sys.argv:
+    case_refcheckpoint(); sys.exit(0)
   if "--only-variants" in sys.argv:
     case_variants(); sys.exit(0)
   if "--only-eltlosses" in sys.argv:
@@ -603,4 +669,6 @@ if __name__ == "__main__":
     case_residual()
     case_posenc()
     case_ensemble()
+    case_weightinit()
+    case_refcheckpoint()
   case_trainseq()

@@ -467,6 +467,13 @@ def test_mgnll_known_answers():
             l, v = losses.multi_gaussian_nll_loss(pred, targ, var, full=True, reduction=red, mode=meta["mode"],
                                                   want_covariance=(red == "mean"))
             close(f"mgnll[{i},{red}]", l, torch.from_numpy(g[f"k{i}/loss_{red}"]), tol=1e-5)
+            if red != "mean":
+                # default second result: the clamped per-band variance [B,1,13,H,W] on the device = the diagonal of the
+                # reference's dense covariance [B,1,13,13,H,W]
+                dense = torch.from_numpy(g[f"k{i}/variance"])
+                diag = torch.diagonal(dense, dim1=2, dim2=3).permute(0, 1, 4, 2, 3)
+                assert v.is_cuda and tuple(v.shape) == tuple(diag.shape)
+                close(f"mgnll_var_per_band[{i},{red}]", v, diag, tol=1e-6)
             if red == "mean":
                 close(f"mgnll_cov[{i}]", v, torch.from_numpy(g[f"k{i}/variance"]), tol=1e-6)
                 gp, gv = torch.autograd.grad(l, (pred, var))
@@ -703,3 +710,25 @@ def test_residual_block_fwd_bwd(E, orc, norm, training):
         for k, v in md.state_dict().items():
             if "running" in k:
                 close(f"residual_buf[{k}]", v, pt["blk." + k].float())
+
+
+@pytest.mark.parametrize("K", [128, 256, 4096])
+def test_bf16_split_accuracy(K):
+    """The exact 3-way bf16 operand split (pw_gemm.h::split3_bf16, x = h + m + l) with the six partial products the wide GEMM
+    kernels keep, on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: error vs fp64 relative to max|out| stays at the level of
+    an fp32 FMA chain (<= 1e-6 at the model's K = 128 / 256, and at K = 4096), which is why `dtype` stays f32 for these
+    kernels.  Three products ("bf16x3") would be 2.5e-5.  Runs through the development-probe library (include/uncr_dev.h)."""
+    import uncrtaints_amd.hip_backend as hb
+    g = torch.Generator().manual_seed(K)
+    A = torch.randn(32, K, generator=g)
+    Bm = torch.randn(K, 32, generator=g)
+    truth = A.double() @ Bm.double()
+    out = torch.empty(32, 32, device=DEV)
+    errs = {}
+    for terms in (3, 6):
+        hb.call("uncr_debug_bf16split_probe", dev(A), dev(Bm), out, K, terms, torch.cuda.current_stream().cuda_stream)
+        errs[terms] = float((out.cpu().double() - truth).abs().max() / truth.abs().max())
+    e32 = float(((A @ Bm).double() - truth).abs().max() / truth.abs().max())
+    print(f"[parity] bf16 split K={K}: six products {errs[6]:.2e}, three products {errs[3]:.2e}, CPU fp32 matmul {e32:.2e}")
+    assert errs[6] <= (1e-6 if K <= 256 else 3e-6), errs
+    assert errs[3] > 4 * errs[6]          # the three dropped cross terms are what buys fp32-grade accuracy

@@ -183,8 +183,9 @@ def test_eval_is_deterministic_and_train_dropout_is_stochastic():
     assert not torch.equal(c, d)
 
 
-def test_full_size_properties_at_the_bench_config():
-    """BASELINE config (B=4, T=3, 15x256x256; no CPU oracle at this size inside a test budget): size-independent
+@pytest.mark.parametrize("B,T", [(4, 3), (2, 6)])      # BASELINE config 2 (the bench line) and config 4 (T=6, B=2 per GPU)
+def test_full_size_properties_at_the_bench_config(B, T):
+    """BASELINE configs 2 and 4 at full size (15x256x256; no CPU oracle at this size inside a test budget): size-independent
     properties of the whole path.  (1) bit-reproducibility of a training step (forward, loss, every gradient);
     (2) batch consistency: in eval mode (running statistics, no batch coupling) sample b of the B=4 batch equals
     the same sample run alone -- this exercises the N=12 / N=4 kernel variants against the N=3 / N=1 ones;
@@ -196,7 +197,7 @@ def test_full_size_properties_at_the_bench_config():
     state = orc.init_params(cfg, seed=3)
     m = _build("diag", state)
     m.temporal_aggregator.attn_dropout.p = 0.0
-    B, T, H, W = 4, 3, 256, 256
+    H, W = 256, 256
     x, y, dates = orc.synthetic_batch(B, T, H, W, seed=5)
     x, y, dates = dev(x), dev(y), dev(dates)
     crit = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode="diag")
@@ -221,15 +222,70 @@ def test_full_size_properties_at_the_bench_config():
     m.eval()
     with torch.no_grad():
         full = m(x, batch_positions=dates)
-        for b in (0, 3):
+        for b in (0, B - 1):
             alone = m(x[b:b + 1], batch_positions=dates[b:b + 1])
             e = (full[b:b + 1] - alone).abs().max().item() / alone.abs().max().item()
             print(f"[parity] bench-config batch consistency sample {b}: rel_err={e:.3e}")
             assert e < 2e-5, e
-        perm = torch.tensor([2, 0, 1], device=x.device)
+        perm = torch.tensor([2, 0, 1] + list(range(3, T))[::-1], device=x.device)
         e = (m(x[:, perm], batch_positions=dates[:, perm]) - full).abs().max().item() / full.abs().max().item()
         print(f"[parity] bench-config frame permutation: rel_err={e:.3e}")
         assert e < 2e-5, e
+        # one fully padded date (all-zero frame): the attention puts (numerically) no weight on it, so its date is irrelevant
+        if T > 3:
+            xp = x.clone()
+            xp[:, T - 1] = 0.0
+            d2 = dates.clone()
+            d2[:, T - 1] += 37.0
+            a, b2 = m(xp, batch_positions=dates), m(xp, batch_positions=d2)
+            e = (a - b2).abs().max().item() / a.abs().max().item()
+            print(f"[parity] padded date is ignored: rel_err={e:.3e}")
+            assert e < 2e-5, e
+            att = m._last_attention
+            assert float(att[:, :, T - 1].max()) < 1e-6
+
+
+def test_full_size_iso_ensemble_inference_config5():
+    """BASELINE config 5 at full size: five covmode='iso' members, inference only, B=2 at 256x256, combined on the device
+    (ensemble_reconstruct.py:116-133).  Properties: the combination equals the formula evaluated with torch on the members'
+    own outputs (mean of means; mean(var + mu^2) - mu_ens^2 with the one variance channel broadcast over the 13 bands);
+    bit-reproducible; a member alone in a 1-member ensemble is returned unchanged (its epistemic term vanishes);
+    variances stay positive; batch consistency of a member."""
+    from oracle import uncrtaints_oracle as orc
+    from uncrtaints_amd import engine as E
+    cfg = orc.OracleConfig(covmode="iso", out_conv=[14], attn_dropout=0.0)
+    B, T, H, W, M = 2, 3, 256, 256, 5
+    x, _, dates = orc.synthetic_batch(B, T, H, W, seed=11)
+    x, dates = dev(x), dev(dates)
+    members = [_build("iso", orc.init_params(cfg, seed=20 + i)).eval() for i in range(M)]
+
+    def run():
+        mus, vs = [], []
+        with torch.no_grad():
+            for m in members:
+                out = m(x, batch_positions=dates)
+                assert tuple(out.shape) == (B, 1, 14, H, W)
+                mus.append(out[:, 0, :13].contiguous())
+                vs.append(out[:, 0, 13:14].contiguous())
+            mu, var = E.ensemble_combine(torch.stack(mus), torch.stack(vs), mode="both")
+        return mus, vs, mu, var
+    mus, vs, mu, var = run()
+    _, _, mu2, var2 = run()
+    assert torch.equal(mu, mu2) and torch.equal(var, var2)
+    smu, sv = torch.stack(mus).double(), torch.stack(vs).double().expand(-1, -1, 13, -1, -1)
+    ref_mu = smu.mean(0)
+    ref_var = (sv + smu ** 2).mean(0) - ref_mu ** 2
+    close("config5/ensemble_mean", mu, ref_mu, tol=1e-6)
+    close("config5/ensemble_var", var, ref_var, tol=1e-5)
+    assert (var > 0).all() and (mu >= 0).all() and (mu <= 1).all()
+    mu1, var1 = E.ensemble_combine(torch.stack(mus[:1]), torch.stack(vs[:1]), mode="both")
+    close("config5/one_member_mean", mu1, mus[0], tol=1e-7)
+    close("config5/one_member_var", var1, vs[0].expand(-1, 13, -1, -1), tol=1e-5)
+    with torch.no_grad():
+        alone = members[0](x[1:2], batch_positions=dates[1:2])[:, 0, :13]
+    e = (alone - mus[0][1:2]).abs().max().item() / alone.abs().max().item()
+    print(f"[parity] config5 member batch consistency: rel_err={e:.3e}")
+    assert e < 2e-5, e
 
 
 def test_input_as_small_as_the_attention_map_has_no_dropout():
@@ -341,3 +397,31 @@ def test_unsupported_head_split_raises():
     from uncrtaints_amd import engine
     with pytest.raises(NotImplementedError):          # the weight pre-pack refuses what the kernels cannot take (no OOB packing)
         engine.prepack([(torch.randn(512, 128, device=DEV), True)])
+
+
+def test_reference_written_checkpoint_runs_on_the_hip_path(tmp_path):
+    """The checkpoint file written by the reference's save_model (fixture g17, narrow model) is loaded with load_checkpoint and
+    evaluated on the HIP path: the output equals what the reference computed with those weights."""
+    import os
+    import shutil
+    from types import SimpleNamespace
+    from conftest import GOLDEN
+    from uncrtaints_amd.src import model_utils as MU
+    from uncrtaints_amd.src.backbones.base_model import BaseModel
+    g = load_golden("g17_refcheckpoint")
+    meta = json.loads(str(g["meta"]))
+    cfg = SimpleNamespace(model="uncrtaints", use_sar=True, encoder_widths=meta["encoder_widths"],
+                          decoder_widths=meta["decoder_widths"], out_conv=meta["out_conv"], mean_nonLinearity=True,
+                          var_nonLinearity="softplus", agg_mode="att_group", encoder_norm="group", decoder_norm="batch",
+                          n_head=16, d_model=meta["d_model"], d_k=4, pad_value=0, padding_mode="reflect",
+                          positional_encoding=True, covmode="diag", scale_by=meta["scale_by"], separate_out=False, use_v=False,
+                          block_type="mbconv", pretrain=False, loss="MGNLL", lr=meta["lr"], gamma=meta["gamma"], device=DEV,
+                          chunk_size=None, res_dir=str(tmp_path), experiment_name="exp", resume_from=False, trained_checkp="")
+    os.makedirs(tmp_path / "exp")
+    shutil.copy(os.path.join(GOLDEN, "g17_refcheckpoint.pth.tar"), tmp_path / "exp" / "model_epoch_7.pth.tar")
+    m = BaseModel(cfg).to(DEV)
+    MU.load_checkpoint(cfg, str(tmp_path), m, "model_epoch_7")
+    m.netG.eval()
+    with torch.no_grad():
+        out = m.netG(dev(torch.from_numpy(g["x"])), batch_positions=dev(torch.from_numpy(g["dates"])))
+    close("reference_checkpoint/eval_out", out, torch.from_numpy(g["eval_out"]))

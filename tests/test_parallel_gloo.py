@@ -49,6 +49,16 @@ def _worker(rank, world, port, q):
     # numpy, not tensors: torch tensors travel through mp queues as shared-memory handles that die with the sender
     grads = {n: p.grad.numpy().copy() for n, p in m.named_parameters()}
     weights = {n: p.detach().numpy().copy() for n, p in m.named_parameters()}
+    # a gradient detached from its bucket (optimizer.zero_grad() with torch's default set_to_none=True) must raise in
+    # finish() instead of all-reducing stale zeros and stepping on local gradients
+    torch.optim.SGD(m.parameters(), lr=0.1).zero_grad()
+    ((dp(xs) - ys) ** 2).mean().backward()
+    try:
+        dp.finish()
+        detached_raises = False
+    except RuntimeError as exc:
+        detached_raises = "bucket" in str(exc)
+    assert detached_raises
     q.put((rank, grads, weights))
     dist.barrier()
     dist.destroy_process_group()

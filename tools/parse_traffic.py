@@ -1,7 +1,9 @@
 """Turn the two rocprofv3 PMC passes of `tools/bench_kernels.py traffic` (FETCH_SIZE, WRITE_SIZE) into profiles/<tag>_traffic.json.
 usage: python tools/parse_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
 Both counters are reported in KB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)."""
-import csv, json, sys, collections
+import csv, json, os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from uncrtaints_amd.build import source_sha
 
 KEYS = [("dw_bwd_row_kernel", "dw_bwd[N4,C256,256x256]", 4 * 4 * 256 * 65536 * 4),
         ("dw_fwd_row_kernel", "dw_fwd[N4,C256,256x256]", 4 * 4 * 256 * 65536 * 2),
@@ -29,6 +31,7 @@ def main():
                        "launches the kernels in isolation at the default bench shapes (N=4 frames, P=65536 px), 3 launches each, mean. "
                        "Both counters are reported in KB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at "
                        "64 B), WRITE_SIZE is used as reported. hbm_bytes = (2*fetch_kb_raw + write_kb_raw)*1024."}
+    res["_source_sha"] = source_sha()      # bench.py attaches these numbers only while the kernel sources still hash to this
     for sub, key, alg in KEYS:
         fk = [v for n, vs in fe.items() if sub in n for v in vs]
         wk = [v for n, vs in wr.items() if sub in n for v in vs]

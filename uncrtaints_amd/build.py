@@ -11,12 +11,25 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libuncr_hip.so")
+DEV_LIB = os.path.join(LIBDIR, "libuncr_dev.so")     # development probes (include/uncr_dev.h): never loaded by the product path
 # (source stem, extra flags, object stem); the split GEMM is compiled once per prologue kind (compile-time PRO)
 SOURCES = [(s, [], s) for s in ["norm", "ew", "pw_gemm", "pw_wgrad_split", "dwconv", "dwconv_row", "se", "ltae", "aggregate", "mgnll", "metrics", "conv3"]] + \
           [("pw_gemm_split", [f"-DPWS_PRO={p}"], f"pw_gemm_split_p{p}") for p in range(5)]
 # -fno-slp-vectorize: the SLP vectoriser packs neighbouring scalar FMAs into v_pk_fma_f32 and pays for it with
 # register-pair moves (depthwise row kernel: 370 vs 282 VALU instructions per row; whole step +1 %)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
+
+
+def source_sha() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources: measurements that depend on the kernels' code (the PMC traffic
+    file under profiles/) record it, and bench.py only attaches them while it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")) and f != "dev_probes.hip":
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _newer(src, dst):
@@ -48,6 +61,9 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     objs = [os.path.join(objdir, o + ".o") for _, _, o in SOURCES]
     if force or jobs or not os.path.exists(LIB):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    dsrc = os.path.join(CSRC, "dev_probes.hip")
+    if force or _newer(dsrc, DEV_LIB) or any(_newer(h, DEV_LIB) for h in hdrs):
+        run([hipcc, *FLAGS, "-shared", "-o", DEV_LIB, dsrc])
     return LIB
 
 

@@ -15,8 +15,9 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void mgnll_fwd_kernel(const float* __restrict__ pred,
                                                         const float* __restrict__ targ,
                                                         const float* __restrict__ var, float* __restrict__ loss_none,
-                                                        float* __restrict__ part, int* __restrict__ neg_flag, int B,
-                                                        int K, int Kv, int H, int W, float eps) {
+                                                        float* __restrict__ vclamp, float* __restrict__ part,
+                                                        int* __restrict__ neg_flag, int B, int K, int Kv, int H, int W,
+                                                        float eps) {
     const int P = H * W;
     const int p = blockIdx.x * MG_PX + threadIdx.x;
     float total = 0.f;
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256) void mgnll_fwd_kernel(const float* __restrict_
                 const float v = fmaxf(var[((size_t)b * Kv + (Kv == 1 ? 0 : c)) * P + p], eps);
                 const float e = pred[((size_t)b * K + c) * P + p] - targ[((size_t)b * K + c) * P + p];
                 maha += e * e / v;
+                if (vclamp) vclamp[((size_t)b * K + c) * P + p] = v;   // the clamped per-band variance (iso: broadcast)
             }
             if (maha != maha) maha = 0.f;                       // nan_to_num
             else if (maha > 3.4028234664e38f) maha = 3.4028234664e38f;
@@ -215,14 +217,14 @@ __global__ __launch_bounds__(256) void ensemble_kernel(const float* __restrict__
 
 extern "C" int uncr_mgnll_blocks(int P) { return (P + MG_PX - 1) / MG_PX; }
 
-extern "C" int uncr_mgnll_fwd(const float* pred, const float* targ, const float* var, float* loss_none, float* part,
-                              float* loss_out, int* neg_flag, int B, int K, int Kv, int H, int W, float eps,
+extern "C" int uncr_mgnll_fwd(const float* pred, const float* targ, const float* var, float* loss_none, float* vclamp,
+                              float* part, float* loss_out, int* neg_flag, int B, int K, int Kv, int H, int W, float eps,
                               int reduction /*0 none, 1 mean, 2 sum*/, hipStream_t stream) {
     if (B <= 0 || K <= 0 || (Kv != K && Kv != 1)) return UNCR_ESHAPE;
     if (!pred || !targ || !var || !part) return UNCR_EINVAL;
     const int P = H * W, nb = uncr_mgnll_blocks(P);
-    hipLaunchKernelGGL(mgnll_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred, targ, var, loss_none, part, neg_flag, B,
-                       K, Kv, H, W, eps);
+    hipLaunchKernelGGL(mgnll_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred, targ, var, loss_none, vclamp, part,
+                       neg_flag, B, K, Kv, H, W, eps);
     UNCR_LAUNCH_CHECK();
     if (reduction != 0) {
         if (!loss_out) return UNCR_EINVAL;
@@ -252,130 +254,6 @@ extern "C" int uncr_ensemble_combine(const float* mu, const float* var, int M, l
     if (mode != 2 && !var) return UNCR_EINVAL;
     hipLaunchKernelGGL(ensemble_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mu, var, M, (size_t)n,
                        mode, mu_out, var_out);
-    UNCR_LAUNCH_CHECK();
-    return UNCR_OK;
-}
-
-// ---- debug: pure fp32-MFMA throughput probe (no memory traffic), used by tools/bench_kernels.py ----
-__global__ __launch_bounds__(256, 2) void mfma_probe_kernel(float* out, int iters, float a0, float b0) {
-    f32x16 acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    float a = a0 + threadIdx.x * 1e-6f, b = b0;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][15];
-    if (s == 12345.678f) out[0] = s;   // keep the chain alive
-}
-__global__ __launch_bounds__(256, 2) void mfma_probe_bf16_kernel(float* out, int iters, unsigned a0, unsigned b0) {
-    f32x16 acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    u4 a = {a0 + threadIdx.x, a0 * 3u + threadIdx.x * 7u, a0 ^ 0x3f803f80u, a0 + 0x3c003c00u};
-    u4 b = {b0 + threadIdx.x * 5u, b0 * 5u, b0 ^ 0x3f003f00u, b0 + 0x3d003d00u};
-    a = (a & 0x3fff3fffu) | 0x30003000u; b = (b & 0x3fff3fffu) | 0x30003000u;   // random finite bf16 pairs
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc[i], 0, 0, 0);
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][15];
-    if (s == 12345.678f) out[0] = s;
-}
-extern "C" int uncr_debug_mfma_probe_bf16(float* out, int blocks, int iters, hipStream_t stream) {
-    hipLaunchKernelGGL(mfma_probe_bf16_kernel, dim3(blocks), dim3(256), 0, stream, out, iters, 0x12345678u, 0x9abcdef1u);
-    UNCR_LAUNCH_CHECK();
-    return UNCR_OK;
-}
-extern "C" int uncr_debug_mfma_probe(float* out, int blocks, int iters, hipStream_t stream) {
-    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, stream, out, iters, 1.0f, 0.5f);
-    UNCR_LAUNCH_CHECK();
-    return UNCR_OK;
-}
-
-// ---- debug: numerics probe for the 3-way bf16 split (x = hi + mid + lo exactly, truncation split) fed to
-// v_mfma_f32_32x32x16_bf16.  terms = 6 keeps hh, hm, mh, mm, hl, lh (drops <= 3*2^-24 |a||b|); 9 keeps all.
-typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
-    const unsigned xb = __float_as_uint(x);
-    const unsigned hb = xb & 0xFFFF0000u;
-    const float r1 = x - __uint_as_float(hb);
-    const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(mb);
-    h = hb >> 16; m = mb >> 16; l = __float_as_uint(r2) >> 16;
-}
-__global__ __launch_bounds__(64) void bf16split_probe_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                             float* __restrict__ out, int K, int terms) {
-    const int lane = threadIdx.x, i = lane & 31, kg = lane >> 5;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        u16x8_t ah, am, al, bh, bm, bl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            unsigned short h, m, l;
-            split3(A[i * K + k0 + 8 * kg + e], h, m, l); ah[e] = h; am[e] = m; al[e] = l;
-            split3(B[(k0 + 8 * kg + e) * 32 + i], h, m, l); bh[e] = h; bm[e] = m; bl[e] = l;
-        }
-#define MF(a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0)
-        if (terms >= 9) { MF(al, bl); MF(am, bl); MF(al, bm); }
-        if (terms >= 6) { MF(ah, bl); MF(al, bh); MF(am, bm); }
-        if (terms >= 3) { MF(ah, bm); MF(am, bh); }
-        MF(ah, bh);
-#undef MF
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * kg) * 32 + i] = acc[r];
-}
-extern "C" int uncr_debug_bf16split_probe(const float* A, const float* B, float* out, int K, int terms,
-                                          hipStream_t stream) {
-    if (K <= 0 || K % 16) return UNCR_ESHAPE;
-    hipLaunchKernelGGL(bf16split_probe_kernel, dim3(1), dim3(64), 0, stream, A, B, out, K, terms);
-    UNCR_LAUNCH_CHECK();
-    return UNCR_OK;
-}
-
-// ---- debug: the device erf_f / gelu_f / gelu_grad_f on an array (accuracy measurements, tools/probe_erf.py) ----
-__global__ __launch_bounds__(256) void erf_probe_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int what) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float v = x[i];
-    y[i] = what == 0 ? erf_f(v) : (what == 1 ? gelu_f(v) : (what == 2 ? gelu_grad_f(v) : __builtin_amdgcn_exp2f(v)));
-}
-extern "C" int uncr_debug_erf(const float* x, float* y, int n, int what, hipStream_t stream) {
-    if (n <= 0) return UNCR_ESHAPE;
-    hipLaunchKernelGGL(erf_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, y, n, what);
-    UNCR_LAUNCH_CHECK();
-    return UNCR_OK;
-}
-
-// ds_read_b64_tr_b16 (gfx950 LDS transpose read) semantics probe: LDS holds lds[i] = i (16-bit), lane l reads at element
-// offset offs[l]; out[l*4 + j] = the j-th 16-bit value the lane receives.  Groundwork for feeding the same LDS tile to MFMA
-// in both operand orientations (data GEMM + weight-gradient GEMM from one staged tile).
-typedef short uncr_s4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(64) void tr_b16_probe_kernel(const int* __restrict__ offs, int* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) short lds[4096];
-    for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = (short)i;
-    __syncthreads();
-    const uncr_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (uncr_s4 __attribute__((address_space(3)))*)(lds + offs[threadIdx.x]));
-    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = v[j];
-}
-extern "C" int uncr_debug_tr_b16_probe(const int* offs, int* out, hipStream_t stream) {
-    if (!offs || !out) return UNCR_EINVAL;
-    hipLaunchKernelGGL(tr_b16_probe_kernel, dim3(1), dim3(64), 0, stream, offs, out);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

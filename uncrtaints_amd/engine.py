@@ -52,6 +52,23 @@ class Part:
     buf: Tensor
     slots: int
     masked: bool = False     # backward partials of a gradient that already carries the producer's ReLU mask (in_conv)
+    owner: tuple = ()        # (data_ptr, _version) of the tensor these partials describe (hand-offs between autograd nodes)
+
+
+def tag_part(t: Tensor, part: Optional["Part"], attr: str = "_uncr_bpart") -> None:
+    """Attach partial statistics to the tensor they were computed from, for the next autograd node.  The tag records the
+    tensor's address and version counter: `claim_part` hands the partials out only while both still match, so a gradient
+    that autograd accumulated into (a second consumer, a tensor hook) is never paired with stale statistics."""
+    if t is not None and part is not None:
+        part.owner = (t.data_ptr(), t._version)
+        setattr(t, attr, part)
+
+
+def claim_part(t: Tensor, attr: str = "_uncr_bpart") -> Optional["Part"]:
+    part = getattr(t, attr, None)
+    if part is None or part.owner != (t.data_ptr(), t._version):
+        return None
+    return part
 
 
 @dataclass
@@ -180,18 +197,24 @@ def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor, cen
 # weight: while it exists the allocator cannot hand the same address to another tensor, so a (pointer, version) match can
 # only be the tensor that was packed (a freed model's address re-used by a new model's weights would otherwise hit).
 _PACK_CACHE: Dict[tuple, tuple] = {}
-_PACK_PLANS: Dict[tuple, tuple] = {}     # plan key -> (descriptor tensor, flat output, views, max_threads)
+_PACK_PLANS: Dict[tuple, tuple] = {}     # plans of callers without an owner: key -> (descriptor, flat output, views, max_threads)
 
 
-def prepack(weights) -> None:
+def prepack(weights, owner=None) -> None:
     """weights: iterable of (W2d [R][Ccols] contiguous view of a parameter, transpose).  Packs all of them with one
     kernel launch into a per-plan static buffer and remembers the results for `pack_wt` until the next `prepack`
-    (entries are ignored when the parameter's version counter has moved, i.e. after an in-place update)."""
+    (entries are ignored when the parameter's version counter has moved, i.e. after an in-place update).
+    owner: the module the weights belong to.  Its plans (train / eval pack lists) live in `owner._uncr_pack_plans` for as
+    long as the module does and are never evicted: a captured HIP graph holds raw pointers into a plan's buffers, so a
+    plan must not be freed while its model can still be replayed."""
     weights = [(w, bool(tr)) for w, tr in weights if w.is_contiguous()]
     if not weights or os.environ.get("UNCR_NO_PREPACK"):      # env: development switch (bisecting)
         return
     key = tuple((w.data_ptr(), tr, w.shape[0], w.shape[1]) for w, tr in weights)
-    plan = _PACK_PLANS.get(key)
+    plans = _PACK_PLANS
+    if owner is not None:
+        plans = owner.__dict__.setdefault("_uncr_pack_plans", {})
+    plan = plans.get(key)
     if plan is None:
         dev = weights[0][0].device
         sizes, thr, dims = [], [], []
@@ -214,13 +237,13 @@ def prepack(weights) -> None:
             off += n
         desc = torch.tensor(rows, dtype=torch.int64).to(dev)
         plan = (desc, flat, views, max(thr))
-        _PACK_PLANS[key] = plan
+        plans[key] = plan
     desc, _, views, max_threads = plan
     hb.call("uncr_pack_wt_batch", desc, len(weights), max_threads, _stream())
     _PACK_CACHE.clear()
     for (w, tr), v, k in zip(weights, views, key):
         _PACK_CACHE[k] = (v, w._version, w)
-    while len(_PACK_PLANS) > 8:                       # plans of models that are gone
+    while len(_PACK_PLANS) > 8 and not torch.cuda.is_current_stream_capturing():   # owner-less plans only
         _PACK_PLANS.pop(next(iter(_PACK_PLANS)))
 
 
@@ -1045,7 +1068,9 @@ def eltloss_backward(kind: int, gout: Tensor, pred: Tensor, target: Tensor, var:
     return dpred, dvar
 
 
-def mgnll_forward(pred: Tensor, target: Tensor, var: Tensor, eps: float, reduction: str, check_negative: bool):
+def mgnll_forward(pred: Tensor, target: Tensor, var: Tensor, eps: float, reduction: str, check_negative: bool,
+                  want_variance: bool = False):
+    """-> (loss, clamped per-band variance [B,1,K,H,W] or None)"""
     B, T1, K, H, W = pred.shape
     Kv = var.shape[2]
     dev = pred.device
@@ -1056,12 +1081,14 @@ def mgnll_forward(pred: Tensor, target: Tensor, var: Tensor, eps: float, reducti
     loss_none = _f32((W, H, B), dev) if red == 0 else None
     loss = _f32((), dev) if red else None
     flag = torch.zeros((1,), device=dev, dtype=torch.int32) if check_negative else None
-    hb.call("uncr_mgnll_fwd", pred, target, var, loss_none, part, loss, flag, B, K, Kv, H, W, float(eps), red, _stream())
+    vclamp = _f32((B, 1, K, H, W), dev) if want_variance else None
+    hb.call("uncr_mgnll_fwd", pred, target, var, loss_none, vclamp, part, loss, flag, B, K, Kv, H, W, float(eps), red,
+            _stream())
     if check_negative and int(flag.item()):      # opt-in host sync (losses.py:199-200)
         raise ValueError("var has negative entry/entries")
     if red == 0:
-        return loss_none[..., 0] if B == 1 else loss_none      # reference .squeeze() drops B == 1
-    return loss
+        return (loss_none[..., 0] if B == 1 else loss_none), vclamp      # reference .squeeze() drops B == 1
+    return loss, vclamp
 
 
 def mgnll_backward(gout: Tensor, pred: Tensor, target: Tensor, var: Tensor, eps: float, reduction: str,

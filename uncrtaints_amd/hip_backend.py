@@ -47,15 +47,19 @@ def _ctype_of(typ: str):
     return _CTYPES[typ.replace("const ", "").strip()]
 
 
+DEV_HEADER = os.path.join(ROOT, "include", "uncr_dev.h")
+DEV_LIB_PATH = os.path.join(HERE, "lib", "libuncr_dev.so")
+
+
 class HipLib:
-    def __init__(self, path: str = LIB_PATH):
+    def __init__(self, path: str = LIB_PATH, header: str = HEADER):
         if not os.path.exists(path):
             raise RuntimeError(
                 f"{path} not found: build it with `python -m uncrtaints_amd.build` (hipcc --offload-arch=gfx950). "
                 "uncrtaints_amd has no CPU / PyTorch fallback for its kernels.")
         self.path = path
         self.cdll = ctypes.CDLL(path)
-        self.protos = parse_header()
+        self.protos = parse_header(header)
         self.fn = {}
         for name, args in self.protos.items():
             f = getattr(self.cdll, name)   # AttributeError if the header and the library disagree
@@ -65,6 +69,15 @@ class HipLib:
 
 
 _LIB = None
+_DEV = None
+
+
+def dev_lib() -> HipLib:
+    """The development-probe library (include/uncr_dev.h); tools and accuracy tests only, never the product path."""
+    global _DEV
+    if _DEV is None:
+        _DEV = HipLib(DEV_LIB_PATH, DEV_HEADER)
+    return _DEV
 
 
 def lib() -> HipLib:
@@ -121,7 +134,7 @@ def set_profiler(p):
 
 def call(name: str, *args):
     """Call an entry point; tensors are converted to pointers; raises RuntimeError on a non-zero code."""
-    L = lib()
+    L = dev_lib() if name.startswith("uncr_debug_") else lib()
     f = L.fn[name]
     proto = L.protos[name]
     if len(args) != len(proto):

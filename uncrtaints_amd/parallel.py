@@ -63,7 +63,7 @@ class BucketedDataParallel:
             for p in params:
                 p.grad = flat[off:off + p.numel()].view_as(p)     # gradients accumulate straight into the bucket
                 off += p.numel()
-            self.buckets.append(dict(flat=flat, n=len(params), ready=0, handle=None))
+            self.buckets.append(dict(flat=flat, n=len(params), ready=0, handle=None, params=params))
             for p in params:
                 p.register_post_accumulate_grad_hook(self._make_hook(bi))
         # same weights / buffers everywhere
@@ -88,8 +88,22 @@ class BucketedDataParallel:
             b["ready"] = 0
             b["handle"] = None
 
+    def _check_views(self):
+        """Every gradient must still be a view into its bucket: `optimizer.zero_grad()` (set_to_none=True, the torch
+        default) or `p.grad = None` detaches them, after which the buckets would be reduced as stale zeros and every rank
+        would step on its local gradients -- silently diverging replicas.  Raise instead."""
+        for b in self.buckets:
+            lo = b["flat"].data_ptr()
+            hi = lo + b["flat"].numel() * b["flat"].element_size()
+            for p in b["params"]:
+                if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+                    raise RuntimeError("a parameter's .grad no longer points into its all-reduce bucket: use "
+                                       "BucketedDataParallel.zero_grad() (or optimizer.zero_grad(set_to_none=False)), "
+                                       "never set_to_none=True")
+
     def finish(self):
         """Wait for the in-flight all-reduces (call after backward, before the optimizer step)."""
+        self._check_views()
         if not self.overlap:
             op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
             for b in self.buckets:

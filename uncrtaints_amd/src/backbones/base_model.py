@@ -24,6 +24,7 @@ class BaseModel(nn.Module):
         self.scheduler_G = torch.optim.lr_scheduler.ExponentialLR(self.optimizer_G, gamma=self.config.gamma)
         self.real_A = self.fake_B = self.real_B = self.dates = self.masks = None
         self.netG.variance = None
+        self.data_parallel = None      # set to a uncrtaints_amd.parallel.BucketedDataParallel(self.netG) for multi-GPU training
 
     def forward(self):
         self.fake_B = self.netG(self.real_A, batch_positions=self.dates)
@@ -59,8 +60,18 @@ class BaseModel(nn.Module):
     def optimize_parameters(self):
         self.forward()
         self.real_A = None
-        self.optimizer_G.zero_grad()
+        # set_to_none=False: under BucketedDataParallel the gradients are views into the flat all-reduce buckets; setting
+        # them to None would detach them (the next backward would allocate fresh tensors and the buckets would be reduced
+        # as stale zeros).  `self.data_parallel` (a BucketedDataParallel, optional) also resets its bucket bookkeeping and
+        # is waited on before the optimizer step.
+        dp = getattr(self, "data_parallel", None)
+        if dp is not None:
+            dp.zero_grad()
+        else:
+            self.optimizer_G.zero_grad(set_to_none=False)
         self.backward_G()
+        if dp is not None:
+            dp.finish()
         self.optimizer_G.step()
         self.rescale()
         self.reset_input()

@@ -69,6 +69,7 @@ class _MBConvFn(torch.autograd.Function):
                                         x_h3=getattr(x, "_uncr_h3", None), pool=getattr(x, "_uncr_pool", None))
         sv["x_relu"] = getattr(x, "_uncr_relu", None)     # x is in_conv's relu(norm(c0)): (c0, A, B)
         ctx.sv, ctx.p = sv, p
+        ctx.versions = tuple(None if t is None else t._version for t in params)
         y._uncr_part = party        # (sum y, sum y^2) partials for the next PreNorm
         y._uncr_pooled = sv.pop("ypool")   # (max-pooled y, argmax) when the L-TAE stage asked for it
         y._uncr_h3 = sv["h3"]       # lets the consumer of y emit this block's norm-3 backward statistics
@@ -76,14 +77,19 @@ class _MBConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        # when dy comes straight from the consumer's backward kernel it carries (sum dy, sum dy*h3) partials
-        part = getattr(dy, "_uncr_bpart", None)
+        # the backward re-packs / re-reads the live parameters: like autograd's saved-tensor check, refuse to differentiate
+        # through weights that were modified in place since the forward (forward -> optimizer.step() -> backward)
+        for t, v, k in zip(ctx.p.values(), ctx.versions, E.MB_KEYS):
+            if t is not None and t._version != v:
+                raise RuntimeError(f"MBConv parameter '{k}' was modified in place between forward and backward")
+        # when dy comes straight from the consumer's backward kernel it carries (sum dy, sum dy*h3) partials; they are
+        # honoured only while dy is still the very tensor (address, version) they were computed from
+        part = E.claim_part(dy)
         N, C, _, _, H, W = ctx.sv["dims"]
         if part is not None and (part.buf.shape[0] != N * C or part.masked):
             part = None
         dx, g, dx_part = E.mbconv_backward(dy, ctx.sv, ctx.p, need_dx=ctx.needs_input_grad[0], dy_part=part)
-        if dx is not None and dx_part is not None:
-            dx._uncr_bpart = dx_part
+        E.tag_part(dx, dx_part)
         # norms without affine parameters (InstanceNorm2d) were passed as None: no gradient slot for them
         return (dx, None) + tuple(g[k] if ctx.needs_input_grad[2 + i] else None for i, k in enumerate(E.MB_KEYS))
 
@@ -320,8 +326,7 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         dy, dW, db, dy_part = E.head_backward(dout, ctx.sv, ctx.w, ctx.needs_input_grad[0])
-        if dy is not None and dy_part is not None:
-            dy._uncr_bpart = dy_part
+        E.tag_part(dy, dy_part)
         return dy, dW, db, None
 
 
@@ -483,7 +488,7 @@ class UNCRTAINTS(nn.Module):
         if batch_positions is not None and tuple(batch_positions.shape) != tuple(input.shape[:2]):
             raise ValueError(f"batch_positions {tuple(batch_positions.shape)} must be [B, T] = {tuple(input.shape[:2])}")
         input = input.contiguous().float()
-        E.prepack(self._pack_list())                                       # every 1x1-conv weight, one launch
+        E.prepack(self._pack_list(), owner=self)                           # every 1x1-conv weight, one launch
         if self.training:
             # BatchNorm bookkeeping of all MBConv blocks in one multi-tensor launch (20 scalar-add kernels otherwise)
             nbt = []       # rebuilt per call: buffers are re-created by .to() / load_state_dict(assign=True)
@@ -559,6 +564,5 @@ class _HeadFnMeanOnly(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         dy, dW, db, dy_part = E.head_backward(dout, ctx.sv, ctx.w, ctx.needs_input_grad[0])
-        if dy is not None and dy_part is not None:
-            dy._uncr_bpart = dy_part
+        E.tag_part(dy, dy_part)
         return dy, dW, db, None

@@ -54,7 +54,7 @@ class _ConvNormActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, da):
         w, gw = ctx.params
-        part = getattr(da, "_uncr_bpart", None)        # set when the consumer's backward already applied the ReLU mask
+        part = E.claim_part(da)        # set when the consumer's backward already applied the ReLU mask (and da is untouched since)
         if part is not None and not (part.masked and part.buf.shape[0] == da.shape[0] * da.shape[1]):
             part = None
         dx, dW, db, dgw, dgb = E.inconv_backward(da, ctx.sv, w, gw, ctx.needs_input_grad[0], masked_part=part)

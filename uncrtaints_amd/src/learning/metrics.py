@@ -40,7 +40,19 @@ def _run(target, pred, var, want_pixelwise):
     if target.dim() != 4 or target.shape != pred.shape:
         raise ValueError("img_metrics expects target and pred of the same [B, C, H, W] shape")
     t, p = target.contiguous().float(), pred.contiguous().float()
-    v = var.contiguous().float() if var is not None else None
+    v = None
+    if var is not None:
+        # the kernels index var with target's [B][C][P] offsets: anything else would read out of bounds
+        if not var.is_cuda:
+            raise RuntimeError("uncrtaints_amd metrics run on the GPU only (HIP kernels)")
+        if var.dim() == 5 and var.shape[1] == 1:          # [B,1,C,H,W] as returned by the MGNLL loss
+            var = var[:, 0]
+        if var.dim() == 4 and var.shape[1] == 1 and target.shape[1] > 1 and var.shape[0] == target.shape[0] \
+                and var.shape[2:] == target.shape[2:]:
+            var = var.expand_as(target)                   # isotropic variance: one channel for all bands
+        if tuple(var.shape) != tuple(target.shape) or var.numel() == 0:
+            raise ValueError(f"img_metrics: var {tuple(var.shape)} does not match target {tuple(target.shape)}")
+        v = var.contiguous().float()
     B, C, H, W = t.shape
     dev = t.device
     win = _WIN.get(dev)

@@ -3,8 +3,9 @@ multi_gaussian_nll_loss, GaussianNLLLoss, gaussian_nll_loss and the l1 / l2 crit
 per direction (csrc/mgnll.hip).
 
 Differences from the reference, all opt-in / documented:
-  * the dense covariance `diag_embed(var)` [B,1,13,13,H,W] (moved to the host inside the reference loss,
-    losses.py:145,211; logging only) is produced only with `want_covariance=True`, on the device;
+  * the second result of the MGNLL is the clamped per-band variance [B,1,13,H,W] on the device; its dense form
+    `diag_embed(var)` [B,1,13,13,H,W] (moved to the host inside the reference loss, losses.py:145,211; logging only) is
+    produced only with `want_covariance=True`, on the device;
   * `torch.any(var < 0)` (a host sync, losses.py:110,199) is checked only with `check_negative=True`."""
 import torch
 import torch.nn as nn
@@ -20,13 +21,14 @@ class _MGNLLFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, var, eps, reduction, check_negative):
         pred, target, var = pred.contiguous().float(), target.contiguous().float(), var.contiguous().float()
-        loss = E.mgnll_forward(pred, target, var, eps, reduction, check_negative)
+        loss, vclamp = E.mgnll_forward(pred, target, var, eps, reduction, check_negative, want_variance=True)
         ctx.save_for_backward(pred, target, var)
         ctx.eps, ctx.reduction = eps, reduction
-        return loss
+        ctx.mark_non_differentiable(vclamp)
+        return loss, vclamp
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, _gv=None):
         pred, target, var = ctx.saved_tensors
         dpred, dvar = E.mgnll_backward(gout, pred, target, var, ctx.eps, ctx.reduction,
                                        ctx.needs_input_grad[0], ctx.needs_input_grad[2])
@@ -50,12 +52,13 @@ def multi_gaussian_nll_loss(input: Tensor, target: Tensor, var: Tensor, full: bo
         raise ValueError(f"var {tuple(var.shape)} does not match input {tuple(input.shape)} (mode '{mode}')")
     if mode == "iso" and var.shape[2] != 1:
         var = var[:, :, :1]
-    loss = _MGNLLFn.apply(input, target, var, float(eps), reduction, bool(check_negative))
-    variance = None
+    # second result: the clamped per-band variance [B,1,13,H,W] on the device (iso: the channel broadcast to the 13 bands),
+    # written by the loss kernel itself.  The reference returns its dense form diag_embed(var) [B,1,13,13,H,W] on the HOST
+    # (losses.py:145,211); the validation / test loops (train_reconstruct.py:302-329) and img_metrics accept the 5-D
+    # per-band form, which carries the same numbers.  The dense layout is opt-in (`want_covariance=True`).
+    loss, variance = _MGNLLFn.apply(input, target, var, float(eps), reduction, bool(check_negative))
     if want_covariance:   # logging-only export, losses.py:145,211 (layout [B,1,13,13,H,W])
-        v = var.detach().expand(-1, -1, S2_BANDS, -1, -1) if mode == "iso" else var.detach()
-        v = v.clamp(min=eps)[:, 0]
-        variance = torch.diag_embed(v.permute(0, 2, 3, 1)).permute(0, 3, 4, 1, 2).unsqueeze(1)
+        variance = torch.diag_embed(variance[:, 0].permute(0, 2, 3, 1)).permute(0, 3, 4, 1, 2).unsqueeze(1)
     return loss, variance
 
 
