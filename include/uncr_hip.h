@@ -7,7 +7,13 @@
  * code (file:line under /root/reference) whose work the entry point replaces.
  *
  * Conventions
- *   - all tensors are contiguous fp32, NCHW planes: [frames N][channels C][pixels P = H*W];
+ *   - all tensors are contiguous NCHW planes: [frames N][channels C][pixels P = H*W].  ACTIVATION tensors (declared
+ *     `void*`: every [N][C][P] activation and activation gradient of in_conv, the MBConv blocks and the temporal
+ *     aggregation) are stored as fp32 (UNCR_F32, the reference's arithmetic; BASELINE configs 1, 2, 4, 5) or as bf16
+ *     (UNCR_BF16: "bf16 activations, fp32 accumulate", BASELINE config 3), selected per call by the `act` / `*_dt`
+ *     argument.  Everything declared `float*` is fp32 in both modes: statistics partials, coefficients, weights and
+ *     their gradients, the 32x32 L-TAE branch, the model outputs and the loss.  Kernels always compute in fp32; with
+ *     bf16 storage a producer rounds once (to nearest even) at its store and takes its statistics from the ROUNDED values;
  *   - the CALLER owns every buffer (incl. partial-statistics workspaces); nothing is allocated, freed or
  *     retained here; kernels are enqueued on the passed stream and never synchronise;
  *   - return 0 on success, negative = argument/shape error, positive = hipError_t of the launch;
@@ -26,6 +32,9 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t;
 
+/* activation storage codes */
+#define UNCR_F32 0
+#define UNCR_BF16 1
 /* prologue kinds (pw_gemm / pw_wgrad) */
 #define UNCR_PRO_NONE 0
 #define UNCR_PRO_AFFINE 1        /* A*v + B                              */
@@ -82,9 +91,12 @@ int uncr_bn_finalize_bwd_sums(const double* sums_local, const double* sums_globa
  *      (norm-apply/ReLU utae.py:470-494; residual add uncrtaints.py:142-146; SE avg-pool uncrtaints.py:85,95;
  *       output nonlinearities uncrtaints.py:384-388,441-445 and their autograd twins) ---- */
 int uncr_ew_slots(int P);
-int uncr_ew(int op, const float* a, const float* b, const float* c, const float* aux, float* out,
+/* act: storage of a, b, c, aux and out (the HEAD_* and RESIDUAL_RELU ops exist for fp32 only) */
+int uncr_ew(int op, const void* a, const void* b, const void* c, const void* aux, void* out,
             const float* k0, const float* k1, const float* k2, const float* k3, float* part, int planes, int P,
-            int C, int n_mean, float scale, float eps, hipStream_t stream);
+            int C, int n_mean, float scale, float eps, int act, hipStream_t stream);
+/* dst = src converted between the storage types (model input -> bf16 activations; bf16 input gradient -> fp32) */
+int uncr_cast(const void* src, void* dst, long long n, int src_dt, int dst_dt, hipStream_t stream);
 
 /* ---- 1x1 convolutions as MFMA GEMMs with fp32 results (nn.Conv2d k=1: utae.py:476-484 in_conv/out_conv,
  *      uncrtaints.py:126 pw, :136 pw-linear; nn.Conv1d k=1 ltae.py:176,214; nn.Linear ltae.py:327,349).
@@ -103,17 +115,21 @@ int uncr_pack_wt(const float* W, int rows_k, int cols_co, int ld, int transpose,
  * transpose, 0, 0}; max_threads = max over items of uncr_pack_wt_threads */
 int uncr_pack_wt_threads(int rows_k, int cols_co);
 int uncr_pack_wt_batch(const long long* desc, int n_items, int max_threads, hipStream_t stream);
-int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, float* out, const float* k0,
-                 const float* k1, const float* k2, const float* bias, int bias_stride_n, const float* aux,
+/* in_dt: storage of in / in2; out_dt: storage of out and aux.  Cout > 64 (bf16 MFMA kernels): in_dt == out_dt; with bf16
+ * the prologue's fp32 result is rounded once to bf16 and multiplied with the two leading weight parts (16 significant bits):
+ * two products per MAC instead of six.  Cout <= 64 (fp32 MFMA kernels): fp32 outputs, fp32 or bf16 inputs. */
+int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, void* out, const float* k0,
+                 const float* k1, const float* k2, const float* bias, int bias_stride_n, const void* aux,
                  const float* e0, const float* e1, const float* e2, const float* e3 /* epi 3 coefficients */,
-                 float* part, int N, int Cin, int Cout, int P, int pro, int epi, hipStream_t stream);
+                 float* part, int N, int Cin, int Cout, int P, int pro, int epi, int in_dt, int out_dt,
+                 hipStream_t stream);
 /* out_conv (Conv2d k=1 + bias, uncrtaints.py:432-440) with the output nonlinearities (uncrtaints.py:441-445) in the GEMM
  * epilogue, Cout <= 64: channel < |n_mean| -> n_mean > 0 ? scale*sigmoid : identity; the others -> var_mode 0 softplus(beta 1,
  * threshold 20) + eps, 1 elu + 1 + eps, 2 identity.  pre (nullable) also receives the pre-activation for the backward
  * (uncr_ew HEAD_BWD*); without it, uncr_ew(HEAD_BWD*, C = -Cout) recovers the derivatives from the output (less accurate
  * where the variance is within rounding of eps). */
-int uncr_head_fwd(const float* y, const float* Wt, const float* bias, float* out, float* pre, int N, int Cin, int Cout,
-                  int P, int n_mean, float scale, float eps, int var_mode, hipStream_t stream);
+int uncr_head_fwd(const void* y, const float* Wt, const float* bias, float* out, float* pre, int N, int Cin, int Cout,
+                  int P, int n_mean, float scale, float eps, int var_mode, int in_dt /* storage of y */, hipStream_t stream);
 /* Backward of MBConv's pw1 (uncrtaints.py:100-146: x + block(PreNorm(x))) with the PreNorm backward and the skip
  * connection in the GEMM epilogue: out = dy + c1*(W^T . normbwd(in, in2; k0..k2)) + c2*x + c3; if xh3 (the h3 of the
  * block that produced x) is given, part receives (sum out, sum out*xh3) for that block's last norm backward.
@@ -122,10 +138,10 @@ int uncr_head_fwd(const float* y, const float* Wt, const float* bias, float* out
  * whose pre-norm output is xh3: the ReLU backward is applied here, out *= [relu_a*xh3 + relu_b > 0], and part gets the
  * statistics of the masked output for that norm's backward. */
 int uncr_pw_gemm_dx_supported(int Cin, int Cout);
-int uncr_pw_gemm_dx(const float* in, const float* in2, const float* Wt, float* out, const float* k0, const float* k1,
-                    const float* k2, const float* dy, const float* x, const float* xh3, const float* c1,
+int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt, void* out, const float* k0, const float* k1,
+                    const float* k2, const void* dy, const void* x, const void* xh3, const float* c1,
                     const float* c2, const float* c3, const float* relu_a, const float* relu_b, float* part, int N,
-                    int Cin, int Cout, int P, hipStream_t stream);
+                    int Cin, int Cout, int P, int act, hipStream_t stream);
 /* R [N][Ch][C] = per-frame products sum_p du1n*x (uncr_pw_wgrad with the raw x); part_b / part_f = the (sum du1, .) and
  * (sum h1, .) partials [N*Ch][NPB|NPF][2] (part_f may be null: no c2 term); c1..c3 [N*Ch] = norm-1 backward
  * coefficients; A0, B0 [N*C] = PreNorm forward coefficients.  -> part0 [N*C][1][2] = (sum da, sum da*x), dW1 [Ch][C]. */
@@ -134,12 +150,14 @@ int uncr_prenorm_bwd_finish(const float* R, const float* W1, const float* part_b
                             const float* B0, float* part0, float* dW1, float* scratch /* 2*N*Ch floats */, int N,
                             int Ch /* % 8 == 0 */, int C /* % 32 == 0 */, int P, hipStream_t stream);
 int uncr_wgrad_shape(int Cd, int Cx, int* cop, int* cip);
-int uncr_pw_wgrad(const float* d, const float* d2, const float* x, const float* x2, const float* dk0,
+/* act: storage of d, d2, x.  bf16: the two wide shapes (256 x 128, 128 x 256) run one bf16 x bf16 product per MAC with fp32
+ * accumulation (P % 64 == 0), the narrow shapes of the path (in_conv 128 x 15, head 26 x 128) the fp32 MFMA kernels. */
+int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const void* x2, const float* dk0,
                   const float* dk1, const float* dk2, const float* xk0, const float* xk1, const float* xk2,
                   float* part /* [N*NBX][COP][CIP] */, float* rs_part, int N, int Cd, int Cx, int P,
-                  int NBX /* blocks (partials) per frame, from uncr_wgrad_nbx */, int pro_d, int pro_x,
+                  int NBX /* blocks (partials) per frame, from uncr_wgrad_nbx */, int pro_d, int pro_x, int act,
                   hipStream_t stream);
-int uncr_wgrad_nbx(int N, int Cd, int Cx, int P, int pro_d, int pro_x, int rowsum);
+int uncr_wgrad_nbx(int N, int Cd, int Cx, int P, int pro_d, int pro_x, int rowsum, int act);
 int uncr_wgrad_reduce(const float* part, int n_out, int nblk_per_out, int COP, int CIP, int Cout, int Cin,
                       float* out, hipStream_t stream);
 
@@ -147,14 +165,14 @@ int uncr_wgrad_reduce(const float* part, int n_out, int nblk_per_out, int COP, i
 int uncr_dw_set_row(int on);   /* 1 (default): W == 256 uses the row-streaming kernels; 0: LDS-tiled kernels only */
 int uncr_dw_slots_fwd(int H);
 int uncr_dw_slots_bwd(int H);
-int uncr_dw_fwd(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part,
-                int N, int C, int H, int W, hipStream_t stream);
-int uncr_dw_bwd(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2,
-                const float* k3, const float* cA1, const float* cB1, const float* w, float* du1, float* part,
+int uncr_dw_fwd(const void* in, const float* cA, const float* cB, const float* w, void* out, float* part,
+                int N, int C, int H, int W, int act, hipStream_t stream);
+int uncr_dw_bwd(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
+                const float* k3, const float* cA1, const float* cB1, const float* w, void* du1, float* part,
                 float* dw_part, const float* mean1 /* null: part.y = sum du1*h1; else sum du1*(h1 - mean), the
                 well-conditioned form for uncr_norm_finalize_bwd(centered = 1) */,
                 int mean_groups /* 0: mean1[c] (BatchNorm); G > 0: mean1[n*G + c/(C/G)] (GroupNorm) */,
-                int N, int C, int H, int W, hipStream_t stream);
+                int N, int C, int H, int W, int act, hipStream_t stream);
 int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw, hipStream_t stream);
 
 /* ---- squeeze-excite MLP (uncrtaints.py:82-97) ---- */
@@ -168,7 +186,7 @@ int uncr_se_mlp_bwd(const float* G, const float* Wpw, int N, int Co, int C, int 
  *      positional_encoding.py:5-31; ltae.py:341-385,431-458 attention) ---- */
 int uncr_pad_mask(const float* x, int NF, long long frame_elems, float pad_value, int* mask,
                   hipStream_t stream);   /* pad-frame detection, uncrtaints.py:392-394 */
-int uncr_maxpool_fwd(const float* in, float* out, int* idx, int planes, int H, int W, int OH, int OW,
+int uncr_maxpool_fwd(const void* in, float* out, int* idx, int planes, int H, int W, int OH, int OW, int act,
                      hipStream_t stream);
 /* MBConv's closing residual y = x + A*h3 + B (uncrtaints.py:146) of the LAST encoder block with the L-TAE stage's
  * AdaptiveMaxPool2d((32,32)) (uncrtaints.py:403-404) taken on the fly: out [planes][H][W], down / idx [planes][OH][OW]
@@ -176,9 +194,9 @@ int uncr_maxpool_fwd(const float* in, float* out, int* idx, int planes, int H, i
  * or null.  Built for W == 256 with 8x8 windows (uncr_residual_pool_supported); other shapes use uncr_ew + uncr_maxpool_fwd. */
 int uncr_residual_pool_supported(int H, int W, int OH, int OW);
 int uncr_residual_pool_slots(int H);
-int uncr_residual_pool(const float* x, const float* h3, const float* cA, const float* cB, float* out, float* part,
-                       float* down, int* idx, int planes, int H, int W, int OH, int OW, hipStream_t stream);
-int uncr_maxpool_bwd(const float* dout, const int* idx, float* din, int planes, int H, int W, int OH, int OW,
+int uncr_residual_pool(const void* x, const void* h3, const float* cA, const float* cB, void* out, float* part,
+                       float* down, int* idx, int planes, int H, int W, int OH, int OW, int act, hipStream_t stream);
+int uncr_maxpool_bwd(const float* dout, const int* idx, void* din, int planes, int H, int W, int OH, int OW, int act,
                      hipStream_t stream);
 int uncr_ltae_gn_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean,
                      float* rstd, int B, int T, int C, int G, int S, hipStream_t stream);
@@ -198,14 +216,14 @@ int uncr_ltae_softmax_bwd(const float* datt, const float* att, const float* k, c
 /* ---- full-resolution temporal aggregation (Compact_Temporal_Aggregator 'att_group',
  *      uncrtaints.py:156-221: bilinear up-sample + dropout + pad mask + V-aggregate) ---- */
 int uncr_agg_slots(int P);
-int uncr_aggregate_fwd(const float* e, const float* att, const int* pad, const float* dmask,
+int uncr_aggregate_fwd(const void* e, const float* att, const int* pad, const float* dmask,
                        unsigned long long seed, const long long* seed_dev, float p_drop, int shared_mask,
-                       float* out, float* part, int B, int T, int C, int NH, int H, int W, int AH, int AW,
-                       hipStream_t stream);
-int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const int* pad, const float* dmask,
+                       void* out, float* part, int B, int T, int C, int NH, int H, int W, int AH, int AW,
+                       int act /* storage of e and out */, hipStream_t stream);
+int uncr_aggregate_bwd(const void* dg, const void* e, const float* att, const int* pad, const float* dmask,
                        unsigned long long seed, const long long* seed_dev, float p_drop, int shared_mask,
-                       float* de, float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int AH,
-                       int AW, hipStream_t stream);
+                       void* de, float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int AH,
+                       int AW, int act /* storage of dg, e and de */, hipStream_t stream);
 
 /* ---- dense 3x3 reflect convolution of ResidualConvBlock (uncrtaints.py:24-69, utae.py:478-487) as nine accumulating
  *      pointwise GEMMs on the padded grid (uncr_pw_gemm epi 4 with the input pointer shifted by dy*(W+2)+dx).  Glue:

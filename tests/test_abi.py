@@ -27,7 +27,7 @@ def test_header_parses_and_has_all_stages():
     for name, args in protos.items():
         for typ, _ in args:
             assert typ.replace("const ", "").replace("*", "").strip() in (
-                "float", "double", "int", "unsigned long long", "long long", "hipStream_t"), (name, typ)
+                "float", "double", "int", "unsigned long long", "long long", "hipStream_t", "void"), (name, typ)
 
 
 def test_library_exports_every_declared_symbol(built):

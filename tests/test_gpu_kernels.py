@@ -148,7 +148,7 @@ def _depthwise_fwd_bwd(E, orc, H, W):
     slots = hb.query("uncr_dw_slots_fwd", H)
     part = torch.empty(N * C, slots, 2, device=DEV)
     hb.call("uncr_dw_fwd", dev(h1.detach()), dev(A), dev(B), dev(w.detach().reshape(C, 9)), h2d, part, N, C, H, W,
-            E._stream())
+            0, E._stream())
     close(f"dw_fwd[{H}x{W}]", h2d, h2)
     close("dw_fwd_stats0", part.sum(1)[:, 0], h2.detach().sum(dim=(2, 3)).reshape(-1))
     close("dw_fwd_stats1", part.sum(1)[:, 1], (h2.detach() ** 2).sum(dim=(2, 3)).reshape(-1))
@@ -166,7 +166,7 @@ def _depthwise_fwd_bwd(E, orc, H, W):
     partb = torch.empty(N * C, sb, 2, device=DEV)
     dwp = torch.empty(N * C, sb, 9, device=DEV)
     hb.call("uncr_dw_bwd", dev(du2), h2d, dev(h1.detach()), dev(c1), dev(c2), dev(c3), dev(A), dev(B),
-            dev(w.detach().reshape(C, 9)), du1, partb, dwp, None, 0, N, C, H, W, E._stream())
+            dev(w.detach().reshape(C, 9)), du1, partb, dwp, None, 0, N, C, H, W, 0, E._stream())
     close(f"dw_bwd_du1[{H}x{W}]", du1, du1_ref)
     close("dw_bwd_stats0", partb.sum(1)[:, 0], du1_ref.sum(dim=(2, 3)).reshape(-1))
     close("dw_bwd_stats1", partb.sum(1)[:, 1], (du1_ref * h1.detach()).sum(dim=(2, 3)).reshape(-1))
@@ -177,7 +177,7 @@ def _depthwise_fwd_bwd(E, orc, H, W):
     for groups in (0, 4):
         mean = rand(C if groups == 0 else N * groups, seed=9, scale=2.0)
         hb.call("uncr_dw_bwd", dev(du2), h2d, dev(h1.detach()), dev(c1), dev(c2), dev(c3), dev(A), dev(B),
-                dev(w.detach().reshape(C, 9)), du1, partb, dwp, dev(mean), groups, N, C, H, W, E._stream())
+                dev(w.detach().reshape(C, 9)), du1, partb, dwp, dev(mean), groups, N, C, H, W, 0, E._stream())
         mfull = mean.view(1, C, 1, 1) if groups == 0 else mean.view(N, groups, 1, 1, 1).expand(N, groups, C // groups, 1, 1).reshape(N, C, 1, 1)
         close(f"dw_bwd_stats1_centered[g{groups}]", partb.sum(1)[:, 1],
               (du1_ref * (h1.detach() - mfull)).sum(dim=(2, 3)).reshape(-1))
@@ -390,7 +390,7 @@ def test_residual_with_fused_maxpool(E, H):
     idx = torch.empty(N, C, H // 8, 32, device=DEV, dtype=torch.int32)
     slots = hb.query("uncr_residual_pool_slots", H)
     part = torch.empty(N * C, slots, 2, device=DEV)
-    hb.call("uncr_residual_pool", dev(x), dev(h3), dev(A), dev(Bc), y, part, down, idx, N * C, H, W, H // 8, 32, E._stream())
+    hb.call("uncr_residual_pool", dev(x), dev(h3), dev(A), dev(Bc), y, part, down, idx, N * C, H, W, H // 8, 32, 0, E._stream())
     assert torch.equal(torch.nan_to_num(y.cpu(), nan=123.0), torch.nan_to_num(y_ref, nan=123.0))
     assert torch.equal(torch.nan_to_num(down.cpu(), nan=123.0), torch.nan_to_num(d_ref, nan=123.0))
     assert torch.equal(idx.cpu().long(), i_ref), "argmax: first maximum in scan order, NaN propagates (ATen semantics)"

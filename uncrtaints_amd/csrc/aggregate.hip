@@ -15,13 +15,13 @@
 #endif
 
 struct AggArgs {
-    const float* e;        // [B][T][C][P]
+    const void* e;         // [B][T][C][P], storage type T (fp32 | bf16) like out / dg / de
     const float* att;      // [NH][B][T][AH][AW]
     const int* pad;        // [B][T] or null
     const float* dmask;    // explicit dropout mask [NH*B][T][P] (values 0 or 1/(1-p)) or null
-    float* out;            // fwd: g [B][C][P]
-    const float* dg;       // bwd: [B][C][P]
-    float* de;             // bwd: [B][T][C][P]
+    void* out;             // fwd: g [B][C][P]
+    const void* dg;        // bwd: [B][C][P]
+    void* de;              // bwd: [B][T][C][P]
     float* datt_up;        // bwd: [NH][B][T][P]
     float2* part;          // fwd: [B*C][NP] or null
     unsigned long long seed;
@@ -65,7 +65,7 @@ __device__ __forceinline__ float agg_keep(const AggArgs& g, int h, int b, int t,
 // STAGE: the block's low-resolution attention rows (all its heads and dates) are copied to LDS once; the 16 taps per
 // (head, date) of a thread's 4 pixels then come from LDS instead of 16 scattered global loads (-20 us of 127 at the
 // bench shape).  Dynamic LDS = heads_per_block * T * agg_rows * AW floats; larger problems use the gather path.
-template <bool BWD, int CH, bool STAGE>
+template <bool BWD, int CH, bool STAGE, typename T>
 __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
     extern __shared__ float att_s[];
     const int b = blockIdx.y;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
         float4 acc[CH];                 // fwd: output accumulators; bwd: dg of the head's channels
 #pragma unroll
         for (int jc = 0; jc < CH; ++jc) {
-            if constexpr (BWD) acc[jc] = ld_nt4(g.dg + ((size_t)b * g.C + h * CH + jc) * P + p0);
+            if constexpr (BWD) acc[jc] = ld_nt4t((const T*)g.dg + ((size_t)b * g.C + h * CH + jc) * P + p0);
             else acc[jc] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         for (int t = 0; t < g.T; ++t) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
 #pragma unroll
             for (int jc = 0; jc < CH; ++jc) {
                 const size_t eo = (((size_t)b * g.T + t) * g.C + h * CH + jc) * P + p0;
-                const float4 ev = ld_nt4(g.e + eo);
+                const float4 ev = ld_nt4t((const T*)g.e + eo);
                 if constexpr (!BWD) {
                     acc[jc].x = fmaf(a[0], ev.x, acc[jc].x);
                     acc[jc].y = fmaf(a[1], ev.y, acc[jc].y);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
                     acc[jc].w = fmaf(a[3], ev.w, acc[jc].w);
                 } else {
                     const float4 dgv = acc[jc];
-                    st_nt4(g.de + eo, make_float4(a[0] * dgv.x, a[1] * dgv.y, a[2] * dgv.z, a[3] * dgv.w));
+                    st_nt4t((T*)g.de + eo, make_float4(a[0] * dgv.x, a[1] * dgv.y, a[2] * dgv.z, a[3] * dgv.w));
                     d[0] = fmaf(dgv.x, ev.x, d[0]);
                     d[1] = fmaf(dgv.y, ev.y, d[1]);
                     d[2] = fmaf(dgv.z, ev.z, d[2]);
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
 #pragma unroll
             for (int jc = 0; jc < CH; ++jc) {
                 const int c = h * CH + jc;
-                const float4 o = acc[jc];
-                st_nt4(g.out + ((size_t)b * g.C + c) * P + p0, o);
+                const float4 o = rnd4<T>(acc[jc]);      // statistics of the values as stored
+                st_nt4t((T*)g.out + ((size_t)b * g.C + c) * P + p0, o);
                 if (g.part) {
                     const float s0 = wave_sum_dpp(o.x + o.y + o.z + o.w);
                     const float s1 = wave_sum_dpp(o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w);
@@ -228,7 +228,7 @@ static int agg_rows(int H, int W, int AH) {
     return r > AH ? AH : r;
 }
 
-template <bool BWD>
+template <bool BWD, typename T>
 static void agg_launch(const AggArgs& g, hipStream_t stream) {
     const int zs = g.NH <= 64 ? g.NH : (g.NH % 4 == 0 ? 4 : 1);      // one head per block: measured 4 % faster than four (more blocks in flight)
     const dim3 grid(g.H * g.W / AGG_PX, g.B, zs);
@@ -237,8 +237,8 @@ static void agg_launch(const AggArgs& g, hipStream_t stream) {
     const bool stage = lds <= 48 * 1024;
 #define AGG_GO(CHV)                                                                                              \
     do {                                                                                                         \
-        if (stage) hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, true>), grid, dim3(256), lds, stream, g, nrows); \
-        else hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, false>), grid, dim3(256), 0, stream, g, nrows);        \
+        if (stage) hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, true, T>), grid, dim3(256), lds, stream, g, nrows); \
+        else hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, false, T>), grid, dim3(256), 0, stream, g, nrows);        \
     } while (0)
     switch (g.C / g.NH) {
         case 2: AGG_GO(2); break;
@@ -251,26 +251,28 @@ static void agg_launch(const AggArgs& g, hipStream_t stream) {
 #undef AGG_GO
 }
 
-extern "C" int uncr_aggregate_fwd(const float* e, const float* att, const int* pad, const float* dmask,
+extern "C" int uncr_aggregate_fwd(const void* e, const float* att, const int* pad, const float* dmask,
                                   unsigned long long seed, const long long* seed_dev, float p_drop, int shared_mask,
-                                  float* out, float* part, int B, int T, int C, int NH, int H, int W, int AH, int AW,
-                                  hipStream_t stream) {
+                                  void* out, float* part, int B, int T, int C, int NH, int H, int W, int AH, int AW,
+                                  int act, hipStream_t stream) {
     const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
     if (rc) return rc;
+    if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
     AggArgs g{e, att, pad, dmask, out, nullptr, nullptr, nullptr, (float2*)part, seed, seed_dev, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
-    agg_launch<false>(g, stream);
+    UNCR_DISPATCH_ACT(act, T, (agg_launch<false, T>(g, stream)));
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
 
-extern "C" int uncr_aggregate_bwd(const float* dg, const float* e, const float* att, const int* pad,
+extern "C" int uncr_aggregate_bwd(const void* dg, const void* e, const float* att, const int* pad,
                                   const float* dmask, unsigned long long seed, const long long* seed_dev,
-                                  float p_drop, int shared_mask, float* de, float* datt_up, float* datt, int B, int T,
-                                  int C, int NH, int H, int W, int AH, int AW, hipStream_t stream) {
+                                  float p_drop, int shared_mask, void* de, float* datt_up, float* datt, int B, int T,
+                                  int C, int NH, int H, int W, int AH, int AW, int act, hipStream_t stream) {
     const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
     if (rc) return rc;
+    if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
     AggArgs g{e, att, pad, dmask, nullptr, dg, de, datt_up, nullptr, seed, seed_dev, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
-    agg_launch<true>(g, stream);
+    UNCR_DISPATCH_ACT(act, T, (agg_launch<true, T>(g, stream)));
     UNCR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(AH, NH * B * T), dim3(256), 0, stream, datt_up, datt, H, W, AH,
                        AW);

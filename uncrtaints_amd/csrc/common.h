@@ -93,6 +93,70 @@ __device__ __forceinline__ void st_nt4(float* p, const float4& v) {
 #endif
 }
 
+// ---- activation storage types -------------------------------------------------------------------------------------
+// Every [frames][channels][pixels] activation / activation-gradient tensor is stored as fp32 (float) or as bf16 (bf16_t:
+// "bf16 activations, fp32 accumulate", BASELINE config 3).  Kernels are templated on the storage type and always compute
+// in fp32: ld4<T> widens four consecutive elements, st4<T> narrows them (round-to-nearest-even, v_cvt_pk_bf16_f32), and
+// rnd4<T> returns the values AS THEY WILL BE STORED -- producers take their (sum, sum^2) statistics from those, so a
+// normalisation is applied to exactly the tensor its statistics describe.
+typedef unsigned short bf16_t;
+typedef __bf16 uncr_bf2 __attribute__((ext_vector_type(2)));
+typedef float uncr_f2 __attribute__((ext_vector_type(2)));
+#define UNCR_F32 0
+#define UNCR_BF16 1
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {       // {lo16 = bf16(a), hi16 = bf16(b)}, RNE
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(uncr_f2{a, b}, uncr_bf2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+__device__ __forceinline__ float bf16_round(float a) { return bf16_lo(cvt_pk_bf16(a, 0.f)); }
+typedef unsigned uncr_u2 __attribute__((ext_vector_type(2)));
+template <typename T, bool NT = false> __device__ __forceinline__ float4 ld4(const T* p) {
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (NT) { const uncr_f4 v = __builtin_nontemporal_load((const uncr_f4*)p); return make_float4(v.x, v.y, v.z, v.w); }
+        else return *(const float4*)p;
+    } else {
+        uncr_u2 r;
+        if constexpr (NT) r = __builtin_nontemporal_load((const uncr_u2*)p);
+        else r = *(const uncr_u2*)p;
+        return make_float4(bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y));
+    }
+}
+template <typename T, bool NT = false> __device__ __forceinline__ void st4(T* p, const float4& v) {
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (NT) { const uncr_f4 q = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(q, (uncr_f4*)p); }
+        else *(float4*)p = v;
+    } else {
+        const uncr_u2 q = {cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w)};
+        if constexpr (NT) __builtin_nontemporal_store(q, (uncr_u2*)p);
+        else *(uncr_u2*)p = q;
+    }
+}
+template <typename T> __device__ __forceinline__ float4 rnd4(const float4& v) {
+    if constexpr (sizeof(T) == 4) return v;
+    else {
+        const unsigned a = cvt_pk_bf16(v.x, v.y), b = cvt_pk_bf16(v.z, v.w);
+        return make_float4(bf16_lo(a), bf16_hi(a), bf16_lo(b), bf16_hi(b));
+    }
+}
+template <typename T> __device__ __forceinline__ float ld1(const T* p) {
+    if constexpr (sizeof(T) == 4) return *p;
+    else return __uint_as_float((unsigned)(*p) << 16);
+}
+template <typename T> __device__ __forceinline__ void st1(T* p, float v) {
+    if constexpr (sizeof(T) == 4) *p = v;
+    else *p = (bf16_t)(cvt_pk_bf16(v, 0.f) & 0xFFFFu);
+}
+// the streamed-once forms follow the translation unit's UNCR_NT switch like ld_nt4 / st_nt4
+template <typename T> __device__ __forceinline__ float4 ld_nt4t(const T* p) { return ld4<T, (UNCR_NT != 0)>(p); }
+template <typename T> __device__ __forceinline__ void st_nt4t(T* p, const float4& v) { st4<T, (UNCR_NT != 0)>(p, v); }
+// host-side dispatch on the storage code of the C ABI (UNCR_F32 / UNCR_BF16)
+#define UNCR_DISPATCH_ACT(code, T, ...)                                   \
+    do {                                                                  \
+        if ((code) == UNCR_BF16) { using T = bf16_t; __VA_ARGS__; }       \
+        else { using T = float; __VA_ARGS__; }                            \
+    } while (0)
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

@@ -17,9 +17,10 @@
 // aligned (one ds_write_b128 per staged float4, one ds_read_b128 + two ds_read_b32 per stencil row); the
 // reflect / zero halo columns sit at offsets 3 and 4 + W.
 // Tile loops are division-free: thread -> (row r0 = tid / W4, column quad c4 = tid % W4) once, then r += 256 / W4.
-__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ in, const float* __restrict__ cA,
+template <typename T>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ in, const float* __restrict__ cA,
                                                      const float* __restrict__ cB, const float* __restrict__ w,
-                                                     float* __restrict__ out, float2* __restrict__ part, int C,
+                                                     T* __restrict__ out, float2* __restrict__ part, int C,
                                                      int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float t[];   // [(TR+2)][W+8]
     constexpr int TR = DW_TR_FWD;
@@ -30,12 +31,12 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ i
     const int r0 = threadIdx.x / W4, c4 = threadIdx.x - r0 * W4;
     const bool active = r0 < rpp;
     const float A = cA[plane], B = cB[plane];
-    const float* src = in + (size_t)plane * H * W;
+    const T* src = in + (size_t)plane * H * W;
     const int rows = min(TR, H - y0) + 2;
     if (active) {
         for (int r = r0; r < rows; r += rpp) {
             const int gy = reflect1(y0 - 1 + r, H);
-            float4 v = *(const float4*)(src + (size_t)gy * W + 4 * c4);
+            float4 v = ld4<T>(src + (size_t)gy * W + 4 * c4);
             v.x = gelu_f(fmaf(A, v.x, B));
             v.y = gelu_f(fmaf(A, v.y, B));
             v.z = gelu_f(fmaf(A, v.z, B));
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ i
     for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
     __syncthreads();
     float s0 = 0.f, s1 = 0.f;
-    float* dst = out + (size_t)plane * H * W;
+    T* dst = out + (size_t)plane * H * W;
     const int orows = rows - 2;
     if (active) {
         for (int r = r0; r < orows; r += rpp) {
@@ -64,9 +65,10 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ i
                 for (int j = 0; j < 4; ++j)
                     o[j] = fmaf(wk[dy * 3 + 0], v[j], fmaf(wk[dy * 3 + 1], v[j + 1], fmaf(wk[dy * 3 + 2], v[j + 2], o[j])));
             }
-            *(float4*)(dst + (size_t)(y0 + r) * W + 4 * c4) = make_float4(o[0], o[1], o[2], o[3]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { s0 += o[j]; s1 += o[j] * o[j]; }
+            const float4 ov = rnd4<T>(make_float4(o[0], o[1], o[2], o[3]));      // statistics of the values as stored
+            st4<T>(dst + (size_t)(y0 + r) * W + 4 * c4, ov);
+            s0 += (ov.x + ov.y) + (ov.z + ov.w);
+            s1 += ov.x * ov.x + ov.y * ov.y + ov.z * ov.z + ov.w * ov.w;
         }
     }
     if (part) {
@@ -76,12 +78,12 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ i
     }
 }
 
-template <int NRMAX>   // row passes per thread: ceil((TR + 2) / (256 / (W/4)))
+template <int NRMAX, typename T>   // row passes per thread: ceil((TR + 2) / (256 / (W/4)))
 __global__ __launch_bounds__(256) void dw_bwd_kernel(
-    const float* __restrict__ du2, const float* __restrict__ h2, const float* __restrict__ h1,
+    const T* __restrict__ du2, const T* __restrict__ h2, const T* __restrict__ h1,
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
     const float* __restrict__ cA1, const float* __restrict__ cB1, const float* __restrict__ w,
-    float* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
+    T* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
     const float* __restrict__ mean1, int mean_groups, int C, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int TR = DW_TR_BWD;
@@ -110,9 +112,9 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
         const int yc = min(max(y, 0), H - 1);
         const int gy = min(max(reflect1(y, H), 0), H - 1);
         const int cc = active ? c4 : 0;
-        ra[i] = *(const float4*)(du2 + pbase + (size_t)yc * W + 4 * cc);
-        rb[i] = *(const float4*)(h2 + pbase + (size_t)yc * W + 4 * cc);
-        rh[i] = *(const float4*)(h1 + pbase + (size_t)gy * W + 4 * cc);
+        ra[i] = ld4<T>(du2 + pbase + (size_t)yc * W + 4 * cc);
+        rb[i] = ld4<T>(h2 + pbase + (size_t)yc * W + 4 * cc);
+        rh[i] = ld4<T>(h1 + pbase + (size_t)gy * W + 4 * cc);
     }
 #pragma unroll
     for (int i = 0; i < NRMAX; ++i) {
@@ -205,7 +207,8 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
                     }
                 }
                 const float u = fmaf(A1, ph[j], B1);
-                const float dv = gelu_grad_f(u) * acc;
+                float dv = gelu_grad_f(u) * acc;
+                if constexpr (sizeof(T) == 2) dv = bf16_round(dv);      // statistics of the value as stored
                 res[j] = dv;
                 s0 += dv;
                 s1 += dv * (ph[j] - M1);
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
 #pragma unroll
                     for (int tx = 0; tx < 3; ++tx) gw[ty * 3 + tx] = fmaf(dc, gt[ty][j + tx], gw[ty * 3 + tx]);
             }
-            *(float4*)(du1 + o) = make_float4(res[0], res[1], res[2], res[3]);
+            st4<T>(du1 + o, make_float4(res[0], res[1], res[2], res[3]));
         }
     }
     __shared__ float red[4][12];
@@ -276,45 +279,46 @@ extern "C" int uncr_dw_slots_fwd(int H) { return (H + DW_TR_FWD - 1) / DW_TR_FWD
 extern "C" int uncr_dw_slots_bwd(int H) { return (H + DW_TR_BWD - 1) / DW_TR_BWD; }
 
 // dwconv_row.hip: streaming kernels for W == 256
-int dw_fwd_row_launch(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part, int N,
-                      int C, int H, int slots, hipStream_t stream);
-int dw_bwd_row_launch(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2,
-                      const float* k3, const float* cA1, const float* cB1, const float* w, float* du1, float* part,
-                      float* dw_part, const float* mean1, int mean_groups, int N, int C, int H, int slots,
+int dw_fwd_row_launch(const void* in, const float* cA, const float* cB, const float* w, void* out, float* part, int N,
+                      int C, int H, int slots, int act, hipStream_t stream);
+int dw_bwd_row_launch(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
+                      const float* k3, const float* cA1, const float* cB1, const float* w, void* du1, float* part,
+                      float* dw_part, const float* mean1, int mean_groups, int N, int C, int H, int slots, int act,
                       hipStream_t stream);
 static int g_dw_row = 1;   // A/B switch (tests exercise both implementations)
 extern "C" int uncr_dw_set_row(int on) { const int old = g_dw_row; g_dw_row = on ? 1 : 0; return old; }
 
-extern "C" int uncr_dw_fwd(const float* in, const float* cA, const float* cB, const float* w, float* out,
-                           float* part, int N, int C, int H, int W, hipStream_t stream) {
-    if (N <= 0 || C <= 0 || H < 2 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
-    if (g_dw_row && W == 256 && H >= 4 && (H & 3) == 0) return dw_fwd_row_launch(in, cA, cB, w, out, part, N, C, H, uncr_dw_slots_fwd(H), stream);
-    const size_t lds = (size_t)(DW_TR_FWD + 2) * (W + 8) * sizeof(float);
-    if (lds > 150 * 1024) return UNCR_ESHAPE;
+template <typename T>
+static int dw_fwd_tiled(const void* in, const float* cA, const float* cB, const float* w, void* out, float* part, int N, int C,
+                        int H, int W, size_t lds, hipStream_t stream) {
     static size_t lds_attr = 0;
     if (lds > 60 * 1024 && lds > lds_attr) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (W > 440)
-        if (hipFuncSetAttribute((const void*)dw_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)dw_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return UNCR_EINVAL;
         lds_attr = lds;
     }
-    hipLaunchKernelGGL(dw_fwd_kernel, dim3(uncr_dw_slots_fwd(H), N * C), dim3(256), lds, stream, in, cA, cB, w, out,
-                       (float2*)part, C, H, W);
+    hipLaunchKernelGGL(dw_fwd_kernel<T>, dim3(uncr_dw_slots_fwd(H), N * C), dim3(256), lds, stream, (const T*)in, cA, cB, w,
+                       (T*)out, (float2*)part, C, H, W);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
 
-extern "C" int uncr_dw_bwd(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2,
-                           const float* k3, const float* cA1, const float* cB1, const float* w, float* du1,
-                           float* part, float* dw_part, const float* mean1, int mean_groups, int N, int C, int H,
-                           int W, hipStream_t stream) {
-    if (mean1 && mean_groups > 0 && C % mean_groups) return UNCR_ESHAPE;
-    if (N <= 0 || C <= 0 || H < 4 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
-    if (g_dw_row && W == 256 && (H & 3) == 0)
-        return dw_bwd_row_launch(du2, h2, h1, k1, k2, k3, cA1, cB1, w, du1, part, dw_part, mean1, mean_groups, N, C, H,
-                                 uncr_dw_slots_bwd(H), stream);
-    const size_t lds = (size_t)2 * (DW_TR_BWD + 2) * (W + 8) * sizeof(float);
+extern "C" int uncr_dw_fwd(const void* in, const float* cA, const float* cB, const float* w, void* out,
+                           float* part, int N, int C, int H, int W, int act, hipStream_t stream) {
+    if (N <= 0 || C <= 0 || H < 2 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
+    if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
+    if (g_dw_row && W == 256 && H >= 4 && (H & 3) == 0) return dw_fwd_row_launch(in, cA, cB, w, out, part, N, C, H, uncr_dw_slots_fwd(H), act, stream);
+    const size_t lds = (size_t)(DW_TR_FWD + 2) * (W + 8) * sizeof(float);
     if (lds > 150 * 1024) return UNCR_ESHAPE;
-    auto kern = W <= 256 ? dw_bwd_kernel<5> : (W <= 512 ? dw_bwd_kernel<9> : dw_bwd_kernel<18>);
+    if (act == UNCR_BF16) return dw_fwd_tiled<bf16_t>(in, cA, cB, w, out, part, N, C, H, W, lds, stream);
+    return dw_fwd_tiled<float>(in, cA, cB, w, out, part, N, C, H, W, lds, stream);
+}
+
+template <typename T>
+static int dw_bwd_tiled(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2, const float* k3,
+                        const float* cA1, const float* cB1, const float* w, void* du1, float* part, float* dw_part,
+                        const float* mean1, int mean_groups, int N, int C, int H, int W, size_t lds, hipStream_t stream) {
+    auto kern = W <= 256 ? dw_bwd_kernel<5, T> : (W <= 512 ? dw_bwd_kernel<9, T> : dw_bwd_kernel<18, T>);
     static size_t lds_attr[3] = {0, 0, 0};
     const int ki = W <= 256 ? 0 : (W <= 512 ? 1 : 2);
     if (lds > lds_attr[ki]) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU)
@@ -322,10 +326,27 @@ extern "C" int uncr_dw_bwd(const float* du2, const float* h2, const float* h1, c
             return UNCR_EINVAL;
         lds_attr[ki] = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(uncr_dw_slots_bwd(H), N * C), dim3(256), lds, stream, du2, h2, h1, k1, k2, k3, cA1,
-                       cB1, w, du1, (float2*)part, dw_part, mean1, mean_groups, C, H, W);
+    hipLaunchKernelGGL(kern, dim3(uncr_dw_slots_bwd(H), N * C), dim3(256), lds, stream, (const T*)du2, (const T*)h2,
+                       (const T*)h1, k1, k2, k3, cA1, cB1, w, (T*)du1, (float2*)part, dw_part, mean1, mean_groups, C, H, W);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
+}
+
+extern "C" int uncr_dw_bwd(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
+                           const float* k3, const float* cA1, const float* cB1, const float* w, void* du1,
+                           float* part, float* dw_part, const float* mean1, int mean_groups, int N, int C, int H,
+                           int W, int act, hipStream_t stream) {
+    if (mean1 && mean_groups > 0 && C % mean_groups) return UNCR_ESHAPE;
+    if (N <= 0 || C <= 0 || H < 4 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
+    if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
+    if (g_dw_row && W == 256 && (H & 3) == 0)
+        return dw_bwd_row_launch(du2, h2, h1, k1, k2, k3, cA1, cB1, w, du1, part, dw_part, mean1, mean_groups, N, C, H,
+                                 uncr_dw_slots_bwd(H), act, stream);
+    const size_t lds = (size_t)2 * (DW_TR_BWD + 2) * (W + 8) * sizeof(float);
+    if (lds > 150 * 1024) return UNCR_ESHAPE;
+    if (act == UNCR_BF16)
+        return dw_bwd_tiled<bf16_t>(du2, h2, h1, k1, k2, k3, cA1, cB1, w, du1, part, dw_part, mean1, mean_groups, N, C, H, W, lds, stream);
+    return dw_bwd_tiled<float>(du2, h2, h1, k1, k2, k3, cA1, cB1, w, du1, part, dw_part, mean1, mean_groups, N, C, H, W, lds, stream);
 }
 
 extern "C" int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw, hipStream_t stream) {

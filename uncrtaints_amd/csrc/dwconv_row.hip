@@ -48,9 +48,10 @@ __device__ __forceinline__ float4 gelu4(float A, float B, const float4& h) {
 
 // ---- forward: out = dw(reflectpad(gelu(A*in+B))), stats (sum, sum^2) per 32-row slot ----
 // grid = ceil(planes * tiles / 4) blocks of 4 independent waves; slots_per_plane = ceil(H / 32)
-__global__ __launch_bounds__(256) void dw_fwd_row_kernel(const float* __restrict__ in, const float* __restrict__ cA,
+template <typename T>
+__global__ __launch_bounds__(256) void dw_fwd_row_kernel(const T* __restrict__ in, const float* __restrict__ cA,
                                                          const float* __restrict__ cB, const float* __restrict__ w,
-                                                         float* __restrict__ out, float2* __restrict__ part, int C,
+                                                         T* __restrict__ out, float2* __restrict__ part, int C,
                                                          int H, int planes, int slots) {
     constexpr int W = 256;
     const int lane = threadIdx.x & 63;
@@ -63,9 +64,9 @@ __global__ __launch_bounds__(256) void dw_fwd_row_kernel(const float* __restrict
     float wk[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
-    const float* src = in + (size_t)plane * H * W + 4 * lane;
-    float* dst = out + (size_t)plane * H * W + 4 * lane;
-    auto ld = [&](int yy) { return ld_nt4(src + (size_t)min(max(yy, 0), H - 1) * W); };
+    const T* src = in + (size_t)plane * H * W + 4 * lane;
+    T* dst = out + (size_t)plane * H * W + 4 * lane;
+    auto ld = [&](int yy) { return ld_nt4t(src + (size_t)min(max(yy, 0), H - 1) * W); };
 
     // 4-slot ring of g rows (row y lives in slot (y - y0) & 3), the row loop unrolled x4 so that every slot index is
     // static: no register rotation.  Raw prefetch registers alternate with the row parity.
@@ -100,7 +101,11 @@ __global__ __launch_bounds__(256) void dw_fwd_row_kernel(const float* __restrict
                 o[j] = a;
             }
                         // plain store: the output is re-read at once by the SE-pool pass and the pw2 GEMM (measured -0.03 ms/step vs non-temporal)
-            *(float4*)(dst + (size_t)y * W) = make_float4(o[0], o[1], o[2], o[3]);
+            {
+                const float4 ov = rnd4<T>(make_float4(o[0], o[1], o[2], o[3]));      // statistics of the values as stored
+                st4<T>(dst + (size_t)y * W, ov);
+                o[0] = ov.x; o[1] = ov.y; o[2] = ov.z; o[3] = ov.w;
+            }
             const float q0 = (o[0] + o[1]) + (o[2] + o[3]);
             const float q1 = fmaf(o[0], o[0], fmaf(o[1], o[1], fmaf(o[2], o[2], o[3] * o[3])));
             if (Y - y0 < 32) { s0 += q0; s1 += q1; } else { t0 += q0; t1 += q1; }
@@ -118,11 +123,12 @@ __global__ __launch_bounds__(256) void dw_fwd_row_kernel(const float* __restrict
 
 // ---- backward (see dwconv.hip for the derivation of the reflect adjoint) ----
 // slots = ceil(H / 16) per plane (the ABI's statistics granularity)
+template <typename T>
 __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
-    const float* __restrict__ du2, const float* __restrict__ h2, const float* __restrict__ h1,
+    const T* __restrict__ du2, const T* __restrict__ h2, const T* __restrict__ h1,
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
     const float* __restrict__ cA1, const float* __restrict__ cB1, const float* __restrict__ w,
-    float* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
+    T* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
     const float* __restrict__ mean1, int mean_groups, int C, int H, int planes, int slots, int tiles) {
     constexpr int W = 256;
     const int lane = threadIdx.x & 63;
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     struct Raw { float4 a, b, h; };
     auto ld = [&](int yy) {
         const size_t o = pb + (size_t)min(max(yy, 0), H - 1) * W;
-        return Raw{ld_nt4(du2 + o), ld_nt4(h2 + o), ld_nt4(h1 + o)};
+        return Raw{ld_nt4t(du2 + o), ld_nt4t(h2 + o), ld_nt4t(h1 + o)};
     };
     auto dh2 = [&](const Raw& r, int yy) {   // zero outside the image
         const float m = (yy >= 0 && yy < H) ? 1.f : 0.f;
@@ -229,12 +235,11 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
                 res[1] += l0 ? e0 : 0.f;
                 res[2] += l63 ? e1 : 0.f;
             }
-            float4 o;
+            float4 o = rnd4<T>(make_float4(pq[0] * res[0], pq[1] * res[1], pq[2] * res[2], pq[3] * res[3]));   // as stored
             float* po = (float*)&o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float dv = pq[j] * res[j];
-                po[j] = dv;
+                const float dv = po[j];
                 s0 += dv;
                 s1 = fmaf(dv, ph[j] - M1, s1);
                 // depthwise weight gradient: dh2 at (y, x) times g1 at the reflect-padded neighbours
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
                     gw[6 + tx] = fmaf(dcj, gp.v[j + tx], gw[6 + tx]);
                 }
             }
-            st_nt4(du1 + pb + (size_t)y * W, o);     // non-temporal: a plain store here costs +0.33 ms/step (measured)
+            st_nt4t(du1 + pb + (size_t)y * W, o);     // non-temporal: a plain store here costs +0.33 ms/step (measured)
         }
         // one statistics slot per 16 rows (the ABI's granularity): short fp32 accumulation chains, the slots are
         // combined in fp64 by the finalize / reduce kernels
@@ -269,18 +274,18 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     }
 }
 
-int dw_fwd_row_launch(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part, int N,
-                      int C, int H, int slots, hipStream_t stream) {
+int dw_fwd_row_launch(const void* in, const float* cA, const float* cB, const float* w, void* out, float* part, int N,
+                      int C, int H, int slots, int act, hipStream_t stream) {
     const int planes = N * C, tiles = (H + DWR_TR - 1) / DWR_TR;
-    hipLaunchKernelGGL(dw_fwd_row_kernel, dim3((planes * tiles + 3) / 4), dim3(256), 0, stream, in, cA, cB, w, out,
-                       (float2*)part, C, H, planes, slots);
+    UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(dw_fwd_row_kernel<T>, dim3((planes * tiles + 3) / 4), dim3(256), 0, stream,
+                                                 (const T*)in, cA, cB, w, (T*)out, (float2*)part, C, H, planes, slots));
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
 
-int dw_bwd_row_launch(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2,
-                      const float* k3, const float* cA1, const float* cB1, const float* w, float* du1, float* part,
-                      float* dw_part, const float* mean1, int mean_groups, int N, int C, int H, int slots,
+int dw_bwd_row_launch(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
+                      const float* k3, const float* cA1, const float* cB1, const float* w, void* du1, float* part,
+                      float* dw_part, const float* mean1, int mean_groups, int N, int C, int H, int slots, int act,
                       hipStream_t stream) {
     const int planes = N * C;
     // 64-row tiles (2 halo rows per 64).  Measured: 2 ... 8 tiles per 256-row plane are all within 3 % of each other (the
@@ -288,8 +293,9 @@ int dw_bwd_row_launch(const float* du2, const float* h2, const float* h1, const 
     int tiles = (slots + DWR_TR / 16 - 1) / (DWR_TR / 16);
     if (const char* ov = getenv("UNCR_DW_TILES"))
         if (atoi(ov) > 0 && atoi(ov) <= slots) tiles = atoi(ov);
-    hipLaunchKernelGGL(dw_bwd_row_kernel, dim3((planes * tiles + 3) / 4), dim3(256), 0, stream, du2, h2, h1, k1, k2,
-                       k3, cA1, cB1, w, du1, (float2*)part, dw_part, mean1, mean_groups, C, H, planes, slots, tiles);
+    UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(dw_bwd_row_kernel<T>, dim3((planes * tiles + 3) / 4), dim3(256), 0, stream,
+                                                 (const T*)du2, (const T*)h2, (const T*)h1, k1, k2, k3, cA1, cB1, w, (T*)du1,
+                                                 (float2*)part, dw_part, mean1, mean_groups, C, H, planes, slots, tiles));
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -29,11 +29,11 @@ __host__ __device__ constexpr int ew_var_mode(int op) {      // 0 softplus, 1 el
 }
 
 struct EwArgs {
-    const float* a;
-    const float* b;
-    const float* c;
-    const float* aux;    // optional second stats operand for PASSE
-    float* out;
+    const void* a;       // activation tensors: fp32 or bf16 (the kernel's storage type T)
+    const void* b;
+    const void* c;
+    const void* aux;     // optional second stats operand for PASSE
+    void* out;
     const float* k0;     // per-plane coefficient arrays [N*C] (meaning depends on op)
     const float* k1;
     const float* k2;
@@ -46,12 +46,12 @@ struct EwArgs {
     float eps;           // HEAD: variance epsilon
 };
 
-template <int OP>
+template <int OP, typename T, typename TO = T>      // T: storage of the inputs, TO: of the output (differs for HEAD_BWD only)
 __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
     const int plane = blockIdx.y;
     const size_t off = (size_t)plane * g.P + (size_t)blockIdx.x * EW_CHUNK + threadIdx.x * 4;
     float s0 = 0.f, s1 = 0.f;
-    float4 va = ld_nt4(g.a + off);
+    float4 va = ld_nt4t((const T*)g.a + off);
     float4 vo;
     float* o = (float*)&vo;
     const float* pa = (const float*)&va;
@@ -59,63 +59,66 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s0 += pa[i]; s1 += pa[i] * pa[i]; }
     } else if constexpr (OP == EW_STATS_AUX) {
-        const float4 vb = ld_nt4(g.b + off);
+        const float4 vb = ld_nt4t((const T*)g.b + off);
         const float* pb = (const float*)&vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s0 += pa[i]; s1 += pa[i] * pb[i]; }
     } else if constexpr (OP == EW_AFFINE_RELU) {
         const float A = g.k0[plane], B = g.k1[plane];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[i] = fmaxf(fmaf(A, pa[i], B), 0.f);
-            s0 += o[i]; s1 += o[i] * o[i];
-        }
+        for (int i = 0; i < 4; ++i) o[i] = fmaxf(fmaf(A, pa[i], B), 0.f);
+        vo = rnd4<T>(vo);       // statistics of the values as stored
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s0 += o[i]; s1 += o[i] * o[i]; }
     } else if constexpr (OP == EW_RESIDUAL) {
         const float A = g.k0[plane], B = g.k1[plane];
-        const float4 vb = ld_nt4(g.b + off);
+        const float4 vb = ld_nt4t((const T*)g.b + off);
         const float* pb = (const float*)&vb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[i] = pa[i] + fmaf(A, pb[i], B);
-            s0 += o[i]; s1 += o[i] * o[i];
-        }
+        for (int i = 0; i < 4; ++i) o[i] = pa[i] + fmaf(A, pb[i], B);
+        vo = rnd4<T>(vo);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s0 += o[i]; s1 += o[i] * o[i]; }
     } else if constexpr (OP == EW_RESIDUAL_RELU) {
         const float A = g.k0[plane], B = g.k1[plane];
-        const float4 vb = ld_nt4(g.b + off);
+        const float4 vb = ld_nt4t((const T*)g.b + off);
         const float* pb = (const float*)&vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = pa[i] + fmaxf(fmaf(A, pb[i], B), 0.f);
     } else if constexpr (OP == EW_PASSB) {
         const float A = g.k0[plane], B = g.k1[plane], S = g.k2[plane], D = g.k3[plane];
-        const float4 vb = ld_nt4(g.b + off);
+        const float4 vb = ld_nt4t((const T*)g.b + off);
         const float* pb = (const float*)&vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float u = fmaf(A, pb[i], B);
             o[i] = gelu_grad_f(u) * fmaf(S, pa[i], D);
-            s0 += o[i]; s1 += o[i] * pb[i];
         }
+        vo = rnd4<T>(vo);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s0 += o[i]; s1 += o[i] * pb[i]; }
     } else if constexpr (OP == EW_PASSE) {
         const float C1 = g.k0[plane], C2 = g.k1[plane], C3 = g.k2[plane];
-        const float4 vb = ld_nt4(g.b + off);
-        const float4 vc = ld_nt4(g.c + off);
+        const float4 vb = ld_nt4t((const T*)g.b + off);
+        const float4 vc = ld_nt4t((const T*)g.c + off);
         const float* pb = (const float*)&vb;
         const float* pc = (const float*)&vc;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = pa[i] + fmaf(C1, pb[i], fmaf(C2, pc[i], C3));
+        vo = rnd4<T>(vo);
         if (g.part) {
-            const float4 vx = ld_nt4(g.aux + off);
+            const float4 vx = ld_nt4t((const T*)g.aux + off);
             const float* px = (const float*)&vx;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { s0 += o[i]; s1 += o[i] * px[i]; }
         }
     } else if constexpr (OP == EW_RELU_BWD) {
         const float A = g.k0[plane], B = g.k1[plane];
-        const float4 vb = ld_nt4(g.b + off);
+        const float4 vb = ld_nt4t((const T*)g.b + off);
         const float* pb = (const float*)&vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            o[i] = fmaf(A, pb[i], B) > 0.f ? pa[i] : 0.f;
+            o[i] = fmaf(A, pb[i], B) > 0.f ? pa[i] : 0.f;      // a is already a stored value: nothing to round
             s0 += o[i]; s1 += o[i] * pb[i];
         }
     } else if constexpr (OP == EW_SE_POOL) {
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         const bool from_out = g.C < 0;
         const int Cc = from_out ? -g.C : g.C;
         const int ch = plane % Cc;
-        const float4 vb = ld_nt4(g.b + off);
+        const float4 vb = ld_nt4t((const T*)g.b + off);
         const float* pb = (const float*)&vb;
         const int nm = g.n_mean < 0 ? -g.n_mean : g.n_mean;
         if (ch < nm) {
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
             }
         }
     }
-    if constexpr (OP != EW_STATS_SQ && OP != EW_STATS_AUX && OP != EW_SE_POOL) st_nt4(g.out + off, vo);
+    if constexpr (OP != EW_STATS_SQ && OP != EW_STATS_AUX && OP != EW_SE_POOL) st_nt4t((TO*)g.out + off, vo);
     if constexpr (!ew_is_head_fwd(OP) && !ew_is_head_bwd(OP)) {
         if (g.part) {
             __shared__ float red[8];
@@ -177,39 +180,71 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
     }
 }
 
+// dst = src converted between storage types (the model input -> bf16 activations; a bf16 input gradient -> fp32)
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long long n) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) st4<TD>(dst + i, ld4<TS>(src + i));
+    else
+        for (long long j = i; j < n; ++j) st1<TD>(dst + j, ld1<TS>(src + j));
+}
+extern "C" int uncr_cast(const void* src, void* dst, long long n, int src_dt, int dst_dt, hipStream_t stream) {
+    if (n <= 0 || !src || !dst) return UNCR_EINVAL;
+    const dim3 grid((unsigned)((n + 1023) / 1024)), blk(256);
+    if (src_dt == UNCR_F32 && dst_dt == UNCR_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, blk, 0, stream, (const float*)src, (bf16_t*)dst, n);
+    else if (src_dt == UNCR_BF16 && dst_dt == UNCR_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, blk, 0, stream, (const bf16_t*)src, (float*)dst, n);
+    else return UNCR_EINVAL;
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
 extern "C" int uncr_ew_slots(int P) { return P / EW_CHUNK; }
 
-extern "C" int uncr_ew(int op, const float* a, const float* b, const float* c, const float* aux, float* out,
+extern "C" int uncr_ew(int op, const void* a, const void* b, const void* c, const void* aux, void* out,
                        const float* k0, const float* k1, const float* k2, const float* k3, float* part, int planes,
-                       int P, int C, int n_mean, float scale, float eps, hipStream_t stream) {
+                       int P, int C, int n_mean, float scale, float eps, int act, hipStream_t stream) {
     if (planes <= 0 || P <= 0 || (P % EW_CHUNK) != 0) return UNCR_ESHAPE;
-    if (!a) return UNCR_EINVAL;
+    if (!a || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
+    // HEAD_FWD* / RESIDUAL_RELU exist for fp32 storage only; HEAD_BWD*: a, b are fp32 (model output side), `act` is the storage
+    // of the OUTPUT (the gradient w.r.t. the head's pre-activation, an activation gradient)
+    if (act == UNCR_BF16 && (ew_is_head_fwd(op) || op == EW_RESIDUAL_RELU)) return UNCR_EINVAL;
     EwArgs g{a, b, c, aux, out, k0, k1, k2, k3, (float2*)part, P, C, n_mean, scale, eps};
     dim3 grid(P / EW_CHUNK, planes), blk(256);
-#define EW_CASE(OPV)                                                  \
-    case OPV:                                                         \
-        hipLaunchKernelGGL(ew_kernel<OPV>, grid, blk, 0, stream, g);  \
+#define EW_CASE(OPV)                                                                                       \
+    case OPV:                                                                                              \
+        hipLaunchKernelGGL((ew_kernel<OPV, float>), grid, blk, 0, stream, g);                              \
+        break;
+#define EW_CASE_HB(OPV)     /* head backward: fp32 inputs, output in the activation storage */                \
+    case OPV:                                                                                              \
+        if (act == UNCR_BF16) hipLaunchKernelGGL((ew_kernel<OPV, float, bf16_t>), grid, blk, 0, stream, g); \
+        else hipLaunchKernelGGL((ew_kernel<OPV, float, float>), grid, blk, 0, stream, g);                  \
+        break;
+#define EW_CASE_A(OPV)      /* ops on activation tensors: fp32 and bf16 storage */                         \
+    case OPV:                                                                                              \
+        UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL((ew_kernel<OPV, T>), grid, blk, 0, stream, g));       \
         break;
     switch (op) {
-        EW_CASE(EW_STATS_SQ)
-        EW_CASE(EW_STATS_AUX)
-        EW_CASE(EW_AFFINE_RELU)
-        EW_CASE(EW_RESIDUAL)
-        EW_CASE(EW_PASSB)
-        EW_CASE(EW_PASSE)
-        EW_CASE(EW_RELU_BWD)
-        EW_CASE(EW_SE_POOL)
+        EW_CASE_A(EW_STATS_SQ)
+        EW_CASE_A(EW_STATS_AUX)
+        EW_CASE_A(EW_AFFINE_RELU)
+        EW_CASE_A(EW_RESIDUAL)
+        EW_CASE_A(EW_PASSB)
+        EW_CASE_A(EW_PASSE)
+        EW_CASE_A(EW_RELU_BWD)
+        EW_CASE_A(EW_SE_POOL)
         EW_CASE(EW_HEAD_FWD)
-        EW_CASE(EW_HEAD_BWD)
+        EW_CASE_HB(EW_HEAD_BWD)
         EW_CASE(EW_RESIDUAL_RELU)
         EW_CASE(EW_HEAD_FWD_ELU)
-        EW_CASE(EW_HEAD_BWD_ELU)
+        EW_CASE_HB(EW_HEAD_BWD_ELU)
         EW_CASE(EW_HEAD_FWD_ID)
-        EW_CASE(EW_HEAD_BWD_ID)
+        EW_CASE_HB(EW_HEAD_BWD_ID)
         default:
             return UNCR_EINVAL;
     }
 #undef EW_CASE
+#undef EW_CASE_A
+#undef EW_CASE_HB
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

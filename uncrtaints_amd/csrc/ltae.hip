@@ -7,7 +7,8 @@
 // adaptive max-pool [planes][H][W] -> [planes][OH][OW] (+ argmax as flat in-plane index)
 // (nn.AdaptiveMaxPool2d window: start = floor(i*H/OH), end = ceil((i+1)*H/OH); first max wins)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ in, float* __restrict__ out,
                                                           int* __restrict__ idx, int H, int W, int OH, int OW) {
     const int plane = blockIdx.y;
     const int o = blockIdx.x * 256 + threadIdx.x;
@@ -15,14 +16,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const int oy = o / OW, ox = o % OW;
     const int ys = (oy * H) / OH, ye = ((oy + 1) * H + OH - 1) / OH;
     const int xs = (ox * W) / OW, xe = ((ox + 1) * W + OW - 1) / OW;
-    const float* p = in + (size_t)plane * H * W;
+    const T* p = in + (size_t)plane * H * W;
     float best = -INFINITY;
     int bi = ys * W + xs;
     if (((xe - xs) & 3) == 0 && (xs & 3) == 0 && (W & 3) == 0) {
         // 16-byte loads along the window rows (the 256->32 case: two float4 per row); same scan order
         for (int y = ys; y < ye; ++y)
             for (int x = xs; x < xe; x += 4) {
-                const float4 q = *(const float4*)(p + y * W + x);
+                const float4 q = ld4<T>(p + y * W + x);
                 const float vv[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     } else {
         for (int y = ys; y < ye; ++y)
             for (int x = xs; x < xe; ++x) {
-                const float v = p[y * W + x];
+                const float v = ld1<T>(p + y * W + x);
                 if (v > best || v != v) { best = v; bi = y * W + x; }   // NaN propagates like ATen
             }
     }
@@ -47,9 +48,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 // are merged.  Scan-order semantics of the stand-alone kernel: first maximum in row-major order wins, NaN propagates.
 // grid = (H/32, planes), block = 256 = 4 strips.  part: [planes][H/8] (sum y, sum y^2) or null.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void residual_pool_kernel(const float* __restrict__ x, const float* __restrict__ h3,
+template <typename T>
+__global__ __launch_bounds__(256) void residual_pool_kernel(const T* __restrict__ x, const T* __restrict__ h3,
                                                             const float* __restrict__ cA, const float* __restrict__ cB,
-                                                            float* __restrict__ out, float2* __restrict__ part,
+                                                            T* __restrict__ out, float2* __restrict__ part,
                                                             float* __restrict__ down, int* __restrict__ idx, int H) {
     constexpr int W = 256;
     const int plane = blockIdx.y, lane = threadIdx.x & 63;
@@ -60,8 +62,8 @@ __global__ __launch_bounds__(256) void residual_pool_kernel(const float* __restr
     float4 xv[8], hv[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        xv[r] = ld_nt4(x + base + (size_t)r * W);
-        hv[r] = ld_nt4(h3 + base + (size_t)r * W);
+        xv[r] = ld_nt4t(x + base + (size_t)r * W);
+        hv[r] = ld_nt4t(h3 + base + (size_t)r * W);
     }
     float best = -INFINITY, s0 = 0.f, s1 = 0.f;
     int bi = strip * 8 * W + 4 * lane;
@@ -72,7 +74,8 @@ __global__ __launch_bounds__(256) void residual_pool_kernel(const float* __restr
         o.y = xv[r].y + fmaf(A, hv[r].y, B);
         o.z = xv[r].z + fmaf(A, hv[r].z, B);
         o.w = xv[r].w + fmaf(A, hv[r].w, B);
-        st_nt4(out + base + (size_t)r * W, o);
+        o = rnd4<T>(o);      // statistics and the pooled maximum of the values as stored
+        st_nt4t(out + base + (size_t)r * W, o);
         const float vv[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -103,15 +106,33 @@ __global__ __launch_bounds__(256) void residual_pool_kernel(const float* __restr
 }
 
 // de[plane][idx] += dpooled   (windows are disjoint when H % OH == 0; otherwise atomics)
+// bf16 storage: two neighbouring elements share a dword and may belong to different windows (threads): the update is a
+// compare-and-swap on the containing dword (the value is rounded once per contribution).
+__device__ __forceinline__ void atomic_add_bf16(bf16_t* dst, float v) {
+    unsigned* w = (unsigned*)((size_t)dst & ~(size_t)3);
+    const bool hi = ((size_t)dst & 2) != 0;
+    unsigned old = *w, assumed;
+    do {
+        assumed = old;
+        const float cur = hi ? bf16_hi(assumed) : bf16_lo(assumed);
+        const unsigned nv = cvt_pk_bf16(cur + v, 0.f) & 0xFFFFu;
+        const unsigned repl = hi ? ((assumed & 0x0000FFFFu) | (nv << 16)) : ((assumed & 0xFFFF0000u) | nv);
+        old = atomicCAS(w, assumed, repl);
+    } while (old != assumed);
+}
+template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx,
-                                                          float* __restrict__ din, int HW, int OHW, int disjoint) {
+                                                          T* __restrict__ din, int HW, int OHW, int disjoint) {
     const int plane = blockIdx.y;
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= OHW) return;
     const size_t q = (size_t)plane * OHW + o;
-    float* dst = din + (size_t)plane * HW + idx[q];
-    if (disjoint) *dst += dout[q];
-    else atomicAdd(dst, dout[q]);
+    T* dst = din + (size_t)plane * HW + idx[q];
+    if constexpr (sizeof(T) == 2) atomic_add_bf16(dst, dout[q]);
+    else {
+        if (disjoint) *dst += dout[q];
+        else atomicAdd(dst, dout[q]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -358,11 +379,12 @@ extern "C" int uncr_pad_mask(const float* x, int NF, long long frame_elems, floa
     return UNCR_OK;
 }
 
-extern "C" int uncr_maxpool_fwd(const float* in, float* out, int* idx, int planes, int H, int W, int OH, int OW,
+extern "C" int uncr_maxpool_fwd(const void* in, float* out, int* idx, int planes, int H, int W, int OH, int OW, int act,
                                 hipStream_t stream) {
     if (planes <= 0 || H < OH || W < OW) return UNCR_ESHAPE;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((OH * OW + 255) / 256, planes), dim3(256), 0, stream, in, out, idx, H,
-                       W, OH, OW);
+    if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
+    UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3((OH * OW + 255) / 256, planes), dim3(256), 0,
+                                                 stream, (const T*)in, out, idx, H, W, OH, OW));
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -371,23 +393,24 @@ extern "C" int uncr_residual_pool_supported(int H, int W, int OH, int OW) {
     return (W == 256 && OW == 32 && H >= 8 && (H & 7) == 0 && OH * 8 == H) ? 1 : 0;
 }
 extern "C" int uncr_residual_pool_slots(int H) { return H / 8; }
-extern "C" int uncr_residual_pool(const float* x, const float* h3, const float* cA, const float* cB, float* out,
-                                  float* part, float* down, int* idx, int planes, int H, int W, int OH, int OW,
+extern "C" int uncr_residual_pool(const void* x, const void* h3, const float* cA, const float* cB, void* out,
+                                  float* part, float* down, int* idx, int planes, int H, int W, int OH, int OW, int act,
                                   hipStream_t stream) {
     if (planes <= 0 || !uncr_residual_pool_supported(H, W, OH, OW)) return UNCR_ESHAPE;
-    if (!x || !h3 || !cA || !cB || !out || !down || !idx) return UNCR_EINVAL;
-    hipLaunchKernelGGL(residual_pool_kernel, dim3((H / 8 + 3) / 4, planes), dim3(256), 0, stream, x, h3, cA, cB, out,
-                       (float2*)part, down, idx, H);
+    if (!x || !h3 || !cA || !cB || !out || !down || !idx || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
+    UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(residual_pool_kernel<T>, dim3((H / 8 + 3) / 4, planes), dim3(256), 0, stream,
+                                                 (const T*)x, (const T*)h3, cA, cB, (T*)out, (float2*)part, down, idx, H));
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
 
-extern "C" int uncr_maxpool_bwd(const float* dout, const int* idx, float* din, int planes, int H, int W, int OH,
-                                int OW, hipStream_t stream) {
+extern "C" int uncr_maxpool_bwd(const float* dout, const int* idx, void* din, int planes, int H, int W, int OH,
+                                int OW, int act, hipStream_t stream) {
     if (planes <= 0) return UNCR_ESHAPE;
+    if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
     const int disjoint = (H % OH == 0) && (W % OW == 0);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((OH * OW + 255) / 256, planes), dim3(256), 0, stream, dout, idx, din,
-                       H * W, OH * OW, disjoint);
+    UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3((OH * OW + 255) / 256, planes), dim3(256), 0,
+                                                 stream, dout, idx, (T*)din, H * W, OH * OW, disjoint));
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

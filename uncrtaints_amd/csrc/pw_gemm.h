@@ -4,15 +4,16 @@
 #include "common.h"
 
 struct PwArgs {
-    const float* in;
-    const float* in2;    // PRO_NORMBWD second operand
+    // activation tensors (in, in2, out, aux, aux2, aux3) are fp32 or bf16: the kernels are templated on the storage type
+    const void* in;
+    const void* in2;     // PRO_NORMBWD second operand
     const float* Wt;     // packed weights (format depends on the kernel variant, see uncr_pack_wt)
-    float* out;          // [N][Cout][P]
+    void* out;           // [N][Cout][P]
     const float* k0;     // prologue coefficients, [N*Cin] each
     const float* k1;
     const float* k2;
     const float* bias;   // [Cout] or [N][Cout] (bias_stride_n = Cout) or null
-    const float* aux;    // EPI_AUX operand [N][Cout][P]
+    const void* aux;     // EPI_AUX operand [N][Cout][P] (storage type of `out`)
     const float* e0;     // epi 3 (fused SE/GELU backward): per-(n,co) A, B, S, D  -> out = gelu'(A*aux+B)*(S*v+D)
     const float* e1;
     const float* e2;
@@ -23,8 +24,8 @@ struct PwArgs {
     int pro;             // PRO_*
     int epi;             // 0 none, 1 (sum, sum^2), 2 (sum, sum*aux), 3 fused pass-B + (sum, sum*aux), 4 accumulate,
                          // 5 skip + PreNorm backward: out = aux2 + e0*v + e1*aux + e2, statistics (sum, sum*aux3) if part
-    const float* aux2;   // epi 5: dy
-    const float* aux3;   // epi 5: h3 of the producing block (or null: no statistics); epi 6: c0 of the producing ConvLayer,
+    const void* aux2;    // epi 5: dy
+    const void* aux3;    // epi 5: h3 of the producing block (or null: no statistics); epi 6: c0 of the producing ConvLayer,
                          // whose ReLU backward is applied to the output: out *= [e3*aux3 + bias > 0] (bias, e3: [N*Cout])
     // epi 7 (narrow fp32-MFMA kernels only): head nonlinearities on the fresh accumulator (uncrtaints.py:441-445):
     //   channel < |head_nm|: head_nm > 0 ? head_scale*sigmoid(v) : v;  else variance f(v) (+ head_eps), head_var 0 softplus,
@@ -53,11 +54,13 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 // pw_gemm_split.hip
 // one object per prologue kind (pw_gemm_split.hip compiled with -DPWS_PRO=0..4); cp in {128, 256}
-int pw_split_launch_p0(const PwArgs& g, int N, int cp, hipStream_t stream);
-int pw_split_launch_p1(const PwArgs& g, int N, int cp, hipStream_t stream);
-int pw_split_launch_p2(const PwArgs& g, int N, int cp, hipStream_t stream);
-int pw_split_launch_p3(const PwArgs& g, int N, int cp, hipStream_t stream);
-int pw_split_launch_p4(const PwArgs& g, int N, int cp, hipStream_t stream);
+// act: UNCR_F32 (exact 3-way split of both operands, six products) | UNCR_BF16 (bf16 activations: one activation part,
+// the two leading weight parts)
+int pw_split_launch_p0(const PwArgs& g, int N, int cp, int act, hipStream_t stream);
+int pw_split_launch_p1(const PwArgs& g, int N, int cp, int act, hipStream_t stream);
+int pw_split_launch_p2(const PwArgs& g, int N, int cp, int act, hipStream_t stream);
+int pw_split_launch_p3(const PwArgs& g, int N, int cp, int act, hipStream_t stream);
+int pw_split_launch_p4(const PwArgs& g, int N, int cp, int act, hipStream_t stream);
 int pw_split_pack(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out, hipStream_t stream);
 size_t pw_split_wt_floats(int rows_k, int cp);
 int pw_split_blocks_per_frame(int N, int P);
@@ -69,3 +72,10 @@ bool pw_wgrad_split_supported(int Cd, int Cx, int pro_d, int pro_x, bool rowsum)
 int pw_wgrad_split_launch(const float* d, const float* d2, const float* x, const float* dk0, const float* dk1,
                           const float* dk2, const float* xk0, const float* xk1, const float* xk2, float* part, int N,
                           int Cd, int Cx, int P, int nbx, int pro_x, hipStream_t stream);
+
+// pw_wgrad_a16.hip: the same weight gradients from bf16 operands (one bf16 x bf16 product per MAC, fp32 accumulation)
+int pw_wgrad_a16_nbx(int N, int P);
+bool pw_wgrad_a16_supported(int Cd, int Cx, int pro_d, int pro_x, bool rowsum);
+int pw_wgrad_a16_launch(const void* d, const void* d2, const void* x, const float* dk0, const float* dk1, const float* dk2,
+                        const float* xk0, const float* xk1, const float* xk2, float* part, int N, int Cd, int Cx, int P,
+                        int nbx, int pro_x, hipStream_t stream);

@@ -20,7 +20,7 @@
 
 // PRE2 = false drops the second prefetch register set (PRO_NORMBWD unavailable): keeps the 32-wide
 // variant (16 prefetch float4 per lane) free of spills.
-template <int CT, int WN, int WM, bool PRE2>
+template <int CT, int WN, int WM, bool PRE2, typename TI = float, typename TO = float>
 __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
     constexpr int NT = 64 * WN * WM;
     constexpr int TP = 128 * WM;
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
     }
 
     const int lrow = tid / (TP / 4), lc4 = tid % (TP / 4);
-    const float* inb = g.in + (size_t)n * Cin * P + px0 + 4 * lc4;
-    const float* in2b = g.in2 ? g.in2 + (size_t)n * Cin * P + px0 + 4 * lc4 : nullptr;
+    const TI* inb = (const TI*)g.in + (size_t)n * Cin * P + px0 + 4 * lc4;
+    const TI* in2b = g.in2 ? (const TI*)g.in2 + (size_t)n * Cin * P + px0 + 4 * lc4 : nullptr;
 
     // Software pipeline: while the MFMAs of chunk kc run from xs[kc&1], the register-prefetched chunk kc+1 is
     // transformed and written to xs[(kc+1)&1], chunk kc+2 is fetched into the registers just freed, and the
@@ -60,8 +60,8 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
     auto load_piece = [&](int i, int kc) {
         const int k = kc * KC + lrow + i * ROWS_PER_I;
         const int kk = k < Cin ? k : 0;                   // out-of-range rows re-read row 0 and are zeroed at staging
-        pre[i] = *(const float4*)(inb + (size_t)kk * P);
-        if constexpr (PRE2) pre2[i] = *(const float4*)((pro == PRO_NORMBWD ? in2b : inb) + (size_t)kk * P);
+        pre[i] = ld4<TI>(inb + (size_t)kk * P);
+        if constexpr (PRE2) pre2[i] = ld4<TI>((pro == PRO_NORMBWD ? in2b : inb) + (size_t)kk * P);
     };
     auto stage_piece = [&](int i, int kc, int buf) {
         const int r = lrow + i * ROWS_PER_I;
@@ -163,13 +163,14 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
                 const size_t o = ((size_t)n * Cout + col) * P + pxw;
                 if (epi == 3) {
                     // du2 = gelu'(A*h2 + B) * (S*dz + D): the SE / GELU backward applied to the fresh accumulator
-                    const float4 x = *(const float4*)(g.aux + o);
+                    const float4 x = ld4<TO>((const TO*)g.aux + o);
                     const int ci = n * Cout + col;
                     const float A = g.e0[ci], B = g.e1[ci], S = g.e2[ci], D = g.e3[ci];
                     v.x = gelu_grad_f(fmaf(A, x.x, B)) * fmaf(S, v.x, D);
                     v.y = gelu_grad_f(fmaf(A, x.y, B)) * fmaf(S, v.y, D);
                     v.z = gelu_grad_f(fmaf(A, x.z, B)) * fmaf(S, v.z, D);
                     v.w = gelu_grad_f(fmaf(A, x.w, B)) * fmaf(S, v.w, D);
+                    v = rnd4<TO>(v);
                     s0 = v.x + v.y + v.z + v.w;
                     s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
                 } else if (epi == 7) {
@@ -186,12 +187,13 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
                         else if (g.head_var == 1) pv[i] = (x > 0.f ? x : expm1f(x)) + 1.f + g.head_eps;
                     }
                 }
-                *(float4*)(g.out + o) = v;
+                v = rnd4<TO>(v);      // statistics of the values as stored
+                st4<TO>((TO*)g.out + o, v);
                 if (epi == 1) {
                     s0 = v.x + v.y + v.z + v.w;
                     s1 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
                 } else if (epi == 2) {
-                    const float4 x = *(const float4*)(g.aux + o);
+                    const float4 x = ld4<TO>((const TO*)g.aux + o);
                     s0 = v.x + v.y + v.z + v.w;
                     s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
                 }
@@ -225,10 +227,10 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
 // four k-steps.
 // ---------------------------------------------------------------------------------------------
 struct WgArgs {
-    const float* d;
-    const float* d2;
-    const float* x;
-    const float* x2;
+    const void* d;       // operands: fp32 or bf16 (kernel template TD / TX)
+    const void* d2;
+    const void* x;
+    const void* x2;
     const float* dk0; const float* dk1; const float* dk2;   // [N*Cd]
     const float* xk0; const float* xk1; const float* xk2;   // [N*Cx]
     float* part;       // [N*NBX][COP][CIP]
@@ -257,7 +259,7 @@ __device__ __forceinline__ float4 apply_pro(int pro, float4 v, const float4& v2,
 }
 
 // D2 = true keeps a second register set for the PRO_NORMBWD operand of D.
-template <int MT, int NTL, int WCO, int WCI, bool D2>
+template <int MT, int NTL, int WCO, int WCI, bool D2, typename TD = float, typename TX = float>
 __global__ __launch_bounds__(64 * WCO * WCI, 2) void pw_wgrad_kernel(WgArgs g) {
     constexpr int NT = 64 * WCO * WCI;
     constexpr int COP = 32 * MT * WCO;
@@ -291,9 +293,9 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void pw_wgrad_kernel(WgArgs g) {
     // loader mapping: float4 index f = tid + i*NT -> (row = f >> 3, c4 = f & 7); rows advance by NT/8 per i
     const int lrow = tid >> 3, lc4 = tid & 7;
     constexpr int RSTEP = NT / 8;
-    const float* dbase = g.d + (size_t)n * Cd * P + 4 * lc4;
-    const float* d2base = g.d2 ? g.d2 + (size_t)n * Cd * P + 4 * lc4 : nullptr;
-    const float* xbase = g.x + (size_t)n * Cx * P + 4 * lc4;
+    const TD* dbase = (const TD*)g.d + (size_t)n * Cd * P + 4 * lc4;
+    const TD* d2base = g.d2 ? (const TD*)g.d2 + (size_t)n * Cd * P + 4 * lc4 : nullptr;
+    const TX* xbase = (const TX*)g.x + (size_t)n * Cx * P + 4 * lc4;
 
     // per-row prologue coefficients of this frame -> LDS (chunk-invariant)
     float* cfd = smem + (COP + CIP) * PITCH;    // [3][COP]
@@ -322,9 +324,9 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void pw_wgrad_kernel(WgArgs g) {
         for (int i = 0; i < ND; ++i) {
             const int row = lrow + i * RSTEP;
             if (row < Cd) {
-                dv[i] = *(const float4*)(dbase + (size_t)row * P + p0);
+                dv[i] = ld4<TD>(dbase + (size_t)row * P + p0);
                 if constexpr (D2) {
-                    if (pro_d == PRO_NORMBWD) dv2[i] = *(const float4*)(d2base + (size_t)row * P + p0);
+                    if (pro_d == PRO_NORMBWD) dv2[i] = ld4<TD>(d2base + (size_t)row * P + p0);
                 }
             } else {
                 dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void pw_wgrad_kernel(WgArgs g) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int row = lrow + i * RSTEP;
-            xv[i] = row < Cx ? *(const float4*)(xbase + (size_t)row * P + p0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[i] = row < Cx ? ld4<TX>(xbase + (size_t)row * P + p0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
@@ -499,12 +501,13 @@ extern "C" int uncr_pack_wt_batch(const long long* desc, int n_items, int max_th
     return pw_pack_batch(desc, n_items, max_threads, g_split, stream);
 }
 
-extern "C" int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, float* out, const float* k0,
-                            const float* k1, const float* k2, const float* bias, int bias_stride_n, const float* aux,
+extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, void* out, const float* k0,
+                            const float* k1, const float* k2, const float* bias, int bias_stride_n, const void* aux,
                             const float* e0, const float* e1, const float* e2, const float* e3, float* part, int N,
-                            int Cin, int Cout, int P, int pro, int epi, hipStream_t stream) {
+                            int Cin, int Cout, int P, int pro, int epi, int in_dt, int out_dt, hipStream_t stream) {
     if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
     if (!in || !Wt || !out) return UNCR_EINVAL;
+    if ((in_dt != UNCR_F32 && in_dt != UNCR_BF16) || (out_dt != UNCR_F32 && out_dt != UNCR_BF16)) return UNCR_EINVAL;
     if (pro == PRO_NORMBWD && !in2) return UNCR_EINVAL;
     if (epi < 0 || epi > 4) return UNCR_EINVAL;
     if (epi && epi != 4 && !part) return UNCR_EINVAL;
@@ -516,43 +519,56 @@ extern "C" int uncr_pw_gemm(const float* in, const float* in2, const float* Wt, 
     PwArgs g{in, in2, Wt, out, k0, k1, k2, bias, aux, e0, e1, e2, e3, (float2*)part, bias_stride_n, Cin, Cout, P, pro, epi};
     const int cp = pw_coutp(Cout);
     if (use_split(Cout)) {
+        if (in_dt != out_dt) return UNCR_EINVAL;      // the wide kernels have one storage type for all activation operands
         switch (pro) {
-            case PRO_NONE: return pw_split_launch_p0(g, N, cp, stream);
-            case PRO_AFFINE: return pw_split_launch_p1(g, N, cp, stream);
-            case PRO_AFFINE_GELU: return pw_split_launch_p2(g, N, cp, stream);
-            case PRO_NORMBWD: return pw_split_launch_p3(g, N, cp, stream);
-            case PRO_AFFINE_RELU: return pw_split_launch_p4(g, N, cp, stream);
+            case PRO_NONE: return pw_split_launch_p0(g, N, cp, in_dt, stream);
+            case PRO_AFFINE: return pw_split_launch_p1(g, N, cp, in_dt, stream);
+            case PRO_AFFINE_GELU: return pw_split_launch_p2(g, N, cp, in_dt, stream);
+            case PRO_NORMBWD: return pw_split_launch_p3(g, N, cp, in_dt, stream);
+            case PRO_AFFINE_RELU: return pw_split_launch_p4(g, N, cp, in_dt, stream);
             default: return UNCR_EINVAL;
         }
     }
+    // fp32-MFMA kernels: fp32 storage, or bf16 inputs with fp32 outputs (the narrow shapes: Cout <= 64)
+    if (out_dt != UNCR_F32 || (in_dt == UNCR_BF16 && cp > 64)) return UNCR_EINVAL;
     dim3 grid(P / tp, N);
     if (cp == 256)
         hipLaunchKernelGGL((pw_gemm_kernel<2, 4, 1, true>), grid, dim3(256), 0, stream, g);
     else if (cp == 128)
         hipLaunchKernelGGL((pw_gemm_kernel<1, 4, 1, true>), grid, dim3(256), 0, stream, g);
-    else if (cp == 64)
-        hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true>), grid, dim3(256), 0, stream, g);
-    else if (pro == PRO_NORMBWD)
-        hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, true>), grid, dim3(128), 0, stream, g);
-    else
-        hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false>), grid, dim3(128), 0, stream, g);
+    else if (cp == 64) {
+        if (in_dt == UNCR_BF16) hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true, bf16_t, float>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true>), grid, dim3(256), 0, stream, g);
+    } else if (pro == PRO_NORMBWD) {
+        if (in_dt == UNCR_BF16) hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, true, bf16_t, float>), grid, dim3(128), 0, stream, g);
+        else hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, true>), grid, dim3(128), 0, stream, g);
+    } else {
+        if (in_dt == UNCR_BF16) hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false, bf16_t, float>), grid, dim3(128), 0, stream, g);
+        else hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false>), grid, dim3(128), 0, stream, g);
+    }
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
 
 // out_conv + output nonlinearities in one kernel (narrow fp32-MFMA GEMM, Cout <= 64): uncrtaints.py:432-445
-extern "C" int uncr_head_fwd(const float* y, const float* Wt, const float* bias, float* out, float* pre, int N, int Cin,
-                             int Cout, int P, int n_mean, float scale, float eps, int var_mode, hipStream_t stream) {
+extern "C" int uncr_head_fwd(const void* y, const float* Wt, const float* bias, float* out, float* pre, int N, int Cin,
+                             int Cout, int P, int n_mean, float scale, float eps, int var_mode, int in_dt,
+                             hipStream_t stream) {
     if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 64 || var_mode < 0 || var_mode > 2) return UNCR_ESHAPE;
-    if (!y || !Wt || !out) return UNCR_EINVAL;
+    if (!y || !Wt || !out || (in_dt != UNCR_F32 && in_dt != UNCR_BF16)) return UNCR_EINVAL;
     const int tp = uncr_pw_tile_px(Cout);
     if (P % tp) return UNCR_ESHAPE;
     PwArgs g{y, nullptr, Wt, out, nullptr, nullptr, nullptr, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
              0, Cin, Cout, P, PRO_NONE, 7, nullptr, nullptr};
     g.head_nm = n_mean; g.head_var = var_mode; g.head_scale = scale; g.head_eps = eps; g.head_pre = pre;
     dim3 grid(P / tp, N);
-    if (pw_coutp(Cout) == 64) hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true>), grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false>), grid, dim3(128), 0, stream, g);
+    if (pw_coutp(Cout) == 64) {
+        if (in_dt == UNCR_BF16) hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true, bf16_t, float>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true>), grid, dim3(256), 0, stream, g);
+    } else {
+        if (in_dt == UNCR_BF16) hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false, bf16_t, float>), grid, dim3(128), 0, stream, g);
+        else hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false>), grid, dim3(128), 0, stream, g);
+    }
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -562,19 +578,21 @@ extern "C" int uncr_head_fwd(const float* y, const float* Wt, const float* bias,
 // c1..c3 are known before this GEMM because the sums they depend on follow from the weight-gradient products
 // (uncr_prenorm_bwd_finish).
 extern "C" int uncr_pw_gemm_dx_supported(int Cin, int Cout) { return (use_split(Cout) && pw_coutp(Cout) == 128 && Cin <= 256) ? 1 : 0; }
-extern "C" int uncr_pw_gemm_dx(const float* in, const float* in2, const float* Wt, float* out, const float* k0,
-                               const float* k1, const float* k2, const float* dy, const float* x, const float* xh3,
+extern "C" int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt, void* out, const float* k0,
+                               const float* k1, const float* k2, const void* dy, const void* x, const void* xh3,
                                const float* c1, const float* c2, const float* c3, const float* relu_a,
-                               const float* relu_b, float* part, int N, int Cin, int Cout, int P, hipStream_t stream) {
+                               const float* relu_b, float* part, int N, int Cin, int Cout, int P, int act,
+                               hipStream_t stream) {
     if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
     if (!in || !in2 || !Wt || !out || !dy || !x || !c1 || !c2 || !c3) return UNCR_EINVAL;
+    if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
     if (xh3 && !part) return UNCR_EINVAL;
     if ((relu_a || relu_b) && !(relu_a && relu_b && xh3)) return UNCR_EINVAL;
     if (!uncr_pw_gemm_dx_supported(Cin, Cout)) return UNCR_EINVAL;
     if (P % uncr_pw_tile_px(Cout)) return UNCR_ESHAPE;
     PwArgs g{in, in2, Wt, out, k0, k1, k2, relu_b, x, c1, c2, c3, relu_a ? relu_a : c3, xh3 ? (float2*)part : nullptr,
              0, Cin, Cout, P, PRO_NORMBWD, relu_a ? 6 : 5, dy, xh3};
-    return pw_split_launch_p3(g, N, pw_coutp(Cout), stream);
+    return pw_split_launch_p3(g, N, pw_coutp(Cout), act, stream);
 }
 
 // weight-gradient shapes: (COP, CIP) in {(128,256), (256,128), (128,32), (32,128), (64,256), (32,256), (64,128), (32,32), (64,32)}
@@ -596,28 +614,35 @@ static int wg_shape(int Cd, int Cx, int* cop, int* cip) {
 extern "C" int uncr_wgrad_shape(int Cd, int Cx, int* cop, int* cip) { return wg_shape(Cd, Cx, cop, cip); }
 
 // blocks (= partial products) per frame that uncr_pw_wgrad will use for this problem
-extern "C" int uncr_wgrad_nbx(int N, int Cd, int Cx, int P, int pro_d, int pro_x, int rowsum) {
+extern "C" int uncr_wgrad_nbx(int N, int Cd, int Cx, int P, int pro_d, int pro_x, int rowsum, int act) {
     if (N <= 0 || P <= 0 || P % 32) return -1;
-    if (g_split && pw_wgrad_split_supported(Cd, Cx, pro_d, pro_x, rowsum != 0)) return pw_wgrad_split_nbx(N, P);
+    if (act == UNCR_BF16 && g_split && pw_wgrad_a16_supported(Cd, Cx, pro_d, pro_x, rowsum != 0) && P % 64 == 0)
+        return pw_wgrad_a16_nbx(N, P);
+    if (act == UNCR_F32 && g_split && pw_wgrad_split_supported(Cd, Cx, pro_d, pro_x, rowsum != 0)) return pw_wgrad_split_nbx(N, P);
     // fp32-MFMA kernel: equal pixel ranges, aim for ~512-1024 blocks on the 256 CUs
     for (int cand = 4096; cand >= 256; cand >>= 1)
         if (P % cand == 0 && (long long)N * (P / cand) >= 512) return P / cand;
     return P % 256 == 0 ? P / 256 : P / 32;
 }
 
-extern "C" int uncr_pw_wgrad(const float* d, const float* d2, const float* x, const float* x2, const float* dk0,
+extern "C" int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const void* x2, const float* dk0,
                              const float* dk1, const float* dk2, const float* xk0, const float* xk1,
                              const float* xk2, float* part, float* rs_part, int N, int Cd, int Cx, int P, int NBX,
-                             int pro_d, int pro_x, hipStream_t stream) {
+                             int pro_d, int pro_x, int act, hipStream_t stream) {
     int cop, cip;
     const int shp = wg_shape(Cd, Cx, &cop, &cip);
     if (shp < 0 || N <= 0 || NBX <= 0) return UNCR_ESHAPE;
-    if (!d || !x || !part) return UNCR_EINVAL;
+    if (!d || !x || !part || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
     if (pro_d == PRO_NORMBWD && !d2) return UNCR_EINVAL;
     if (pro_x == PRO_NORMBWD) return UNCR_EINVAL;   // norm-backward form is only built for the D operand
-    if (g_split && pw_wgrad_split_supported(Cd, Cx, pro_d, pro_x, rs_part != nullptr)) {
+    if (act == UNCR_BF16 && g_split && pw_wgrad_a16_supported(Cd, Cx, pro_d, pro_x, rs_part != nullptr) && P % 64 == 0) {
         if (!dk0 || !dk1 || !dk2 || !xk0 || !xk1) return UNCR_EINVAL;
-        return pw_wgrad_split_launch(d, d2, x, dk0, dk1, dk2, xk0, xk1, xk2, part, N, Cd, Cx, P, NBX, pro_x, stream);
+        return pw_wgrad_a16_launch(d, d2, x, dk0, dk1, dk2, xk0, xk1, xk2, part, N, Cd, Cx, P, NBX, pro_x, stream);
+    }
+    if (act == UNCR_F32 && g_split && pw_wgrad_split_supported(Cd, Cx, pro_d, pro_x, rs_part != nullptr)) {
+        if (!dk0 || !dk1 || !dk2 || !xk0 || !xk1) return UNCR_EINVAL;
+        return pw_wgrad_split_launch((const float*)d, (const float*)d2, (const float*)x, dk0, dk1, dk2, xk0, xk1, xk2, part, N, Cd,
+                                     Cx, P, NBX, pro_x, stream);
     }
     if (P % NBX) return UNCR_ESHAPE;
     const int PXB = P / NBX;
@@ -625,17 +650,23 @@ extern "C" int uncr_pw_wgrad(const float* d, const float* d2, const float* x, co
     WgArgs g{d, d2, x, x2, dk0, dk1, dk2, xk0, xk1, xk2, part, rs_part, Cd, Cx, P, PXB, pro_d, pro_x};
     dim3 grid(P / PXB, N);
     const size_t lds = (size_t)((cop + cip) * 36 + 3 * (cop + cip)) * sizeof(float);
+    // bf16 operands on the fp32-MFMA kernels: the narrow shapes of the path only (in_conv 128 x 15, head 26 x 128)
+    if (act == UNCR_BF16 && shp != 2 && shp != 3) return UNCR_EINVAL;
     switch (shp) {
-#define WG_LAUNCH(MT_, NT_, WCO_, WCI_, THREADS)                                                                   \
-    if (pro_d == PRO_NORMBWD)                                                                                      \
-        hipLaunchKernelGGL((pw_wgrad_kernel<MT_, NT_, WCO_, WCI_, true>), grid, dim3(THREADS), lds, stream, g);    \
-    else                                                                                                           \
-        hipLaunchKernelGGL((pw_wgrad_kernel<MT_, NT_, WCO_, WCI_, false>), grid, dim3(THREADS), lds, stream, g);   \
+#define WG_LAUNCH_T(MT_, NT_, WCO_, WCI_, THREADS, TD, TX)                                                                 \
+    if (pro_d == PRO_NORMBWD)                                                                                              \
+        hipLaunchKernelGGL((pw_wgrad_kernel<MT_, NT_, WCO_, WCI_, true, TD, TX>), grid, dim3(THREADS), lds, stream, g);    \
+    else                                                                                                                   \
+        hipLaunchKernelGGL((pw_wgrad_kernel<MT_, NT_, WCO_, WCI_, false, TD, TX>), grid, dim3(THREADS), lds, stream, g);
+#define WG_LAUNCH(MT_, NT_, WCO_, WCI_, THREADS) WG_LAUNCH_T(MT_, NT_, WCO_, WCI_, THREADS, float, float) break;
+#define WG_LAUNCH_AB(MT_, NT_, WCO_, WCI_, THREADS)                                          \
+    if (act == UNCR_BF16) { WG_LAUNCH_T(MT_, NT_, WCO_, WCI_, THREADS, bf16_t, bf16_t) }       \
+    else { WG_LAUNCH_T(MT_, NT_, WCO_, WCI_, THREADS, float, float) }                          \
     break;
         case 0: WG_LAUNCH(2, 4, 4, 1, 256)
         case 1: WG_LAUNCH(2, 4, 2, 2, 256)
-        case 2: WG_LAUNCH(1, 1, 4, 1, 256)
-        case 3: WG_LAUNCH(1, 1, 1, 4, 256)
+        case 2: WG_LAUNCH_AB(1, 1, 4, 1, 256)
+        case 3: WG_LAUNCH_AB(1, 1, 1, 4, 256)
         case 4: WG_LAUNCH(2, 4, 1, 2, 128)
         case 5: WG_LAUNCH(1, 4, 1, 2, 128)
         case 6: WG_LAUNCH(2, 4, 1, 1, 64)
@@ -643,6 +674,8 @@ extern "C" int uncr_pw_wgrad(const float* d, const float* d2, const float* x, co
         case 8: WG_LAUNCH(2, 1, 1, 1, 64)
         case 9: WG_LAUNCH(2, 1, 4, 1, 256)
 #undef WG_LAUNCH
+#undef WG_LAUNCH_AB
+#undef WG_LAUNCH_T
     }
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;

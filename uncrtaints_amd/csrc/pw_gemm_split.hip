@@ -35,22 +35,35 @@
 #ifndef UNCR_NTG_ST2
 #define UNCR_NTG_ST2 0     // stores of the 256-channel outputs only (268 MB at N=4: larger than any cache level)
 #endif
-template <bool NT> __device__ __forceinline__ float4 pws_ld(const float* p) {
-    if constexpr (NT) { const uncr_f4 v = __builtin_nontemporal_load((const uncr_f4*)p); return make_float4(v.x, v.y, v.z, v.w); }
-    else return *(const float4*)p;
-}
-template <bool NT> __device__ __forceinline__ void pws_st(float* p, const float4& v) {
-    if constexpr (NT) { const uncr_f4 q = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(q, (uncr_f4*)p); }
-    else *(float4*)p = v;
-}
 #include <type_traits>
+// four consecutive activation elements as loaded: fp32 storage keeps the float4, bf16 storage keeps the raw 8 bytes (half the
+// prefetch registers) and is widened at staging
+template <typename TA> struct PwsRaw { using type = float4; };
+template <> struct PwsRaw<bf16_t> { using type = uncr_u2; };
+template <bool NT, typename TA> __device__ __forceinline__ typename PwsRaw<TA>::type pws_ld(const TA* p) {
+    if constexpr (sizeof(TA) == 4) return ld4<TA, NT>(p);
+    else {
+        if constexpr (NT) return __builtin_nontemporal_load((const uncr_u2*)p);
+        else return *(const uncr_u2*)p;
+    }
+}
+__device__ __forceinline__ float pws_get(const float4& r, int e) { return ((const float*)&r)[e]; }
+__device__ __forceinline__ float pws_get(const uncr_u2& r, int e) {      // e is a compile-time constant after unrolling
+    const unsigned w = e < 2 ? r.x : r.y;
+    return (e & 1) ? bf16_hi(w) : bf16_lo(w);
+}
+template <bool NT, typename TA> __device__ __forceinline__ void pws_st(TA* p, const float4& v) { st4<TA, NT>(p, v); }
 
 #ifndef PWS_ABL
 #define PWS_ABL 0   // development ablations (tools/ablate_split.sh): 1 no stores, 2 no staging, 4 no activation loads, 8 no A reloads, 16 no MFMA
 #endif
 #define PWS_TP 128
 #define PWS_KC 32
-#define PWS_BUF 24576   // bytes per LDS stage: 3 parts x 32 ci x 128 px x 2 B
+#define PWS_BUF 24576   // bytes per LDS stage: 3 parts x 32 ci x 128 px x 2 B (bf16 activations: 1 part, 8192 B)
+#ifndef PWS_A16_WPARTS
+#define PWS_A16_WPARTS 2   // bf16 activations: leading weight parts used (2 = 16 significant bits: the weights stay fp32-grade,
+                           // the only rounding is the activations' bf16 storage; 1 product per part and k-step)
+#endif
 
 // DEPTH = chunks of raw activations in flight in registers (2 wherever the register budget allows: a chunk is
 // only ~1.3 us of MFMA work, one chunk of prefetch distance does not cover HBM latency under load).
@@ -63,14 +76,23 @@ template <bool NT> __device__ __forceinline__ void pws_st(float* p, const float4
 // staged in LDS, chunk c under the MFMAs, A/B operands of the next k-step rolling in) runs straight across tile
 // boundaries: when a tile's epilogue stores are issued, the next tile's first chunks and weights are already there.
 // A block's two HBM streams therefore never stop for a prologue, a block relaunch or a store acknowledgement.
-template <int CT, int PRO, int EPI, int DEPTH>
+//
+// TA = bf16_t ("bf16 activations, fp32 accumulate"): activations are read and written as bf16, the prologue still runs in fp32 and
+// its result is rounded ONCE to bf16 (one operand part instead of three); the weights keep their PWS_A16_WPARTS leading parts, so
+// a k-step is PWS_A16_WPARTS products instead of six and the kernel is purely stream-bound.  A fragments are double-buffered over
+// two k-steps (one k-step of MFMAs no longer covers an L2 round trip).
+template <int CT, int PRO, int EPI, int DEPTH, typename TA>
 __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     constexpr int NT = 256, WN = 4;
+    constexpr bool BF = sizeof(TA) == 2;
+    constexpr int NPA = BF ? 1 : 3;            // activation parts in LDS
+    constexpr int NW = PWS_A16_WPARTS;         // weight parts used with bf16 activations
+    using Raw = typename PwsRaw<TA>::type;
     constexpr bool PRE2 = PRO == PRO_NORMBWD;
     constexpr int COUTP = 32 * CT * WN;
     constexpr int NCT = CT * WN;
 
-    __shared__ __attribute__((aligned(16))) unsigned char xs[2][PWS_BUF];
+    __shared__ __attribute__((aligned(16))) unsigned char xs[2][NPA * 8192];
     __shared__ float cf[3][256];
     __shared__ float red[COUTP][2];
     __shared__ float ecf[(EPI == 3 || EPI == 5 || EPI == 6) ? 5 : 1][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D
@@ -93,9 +115,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     // a select): a load under a branch makes hipcc fall back to s_waitcnt vmcnt(0) at the join, and on gfx9 the
     // stores share that counter -- in the epilogue that serialised every row group behind all earlier stores.
     if constexpr (PRO != PRO_NONE) {
-        const float* p0 = g.k0 ? g.k0 + (size_t)n * Cin : g.in;
-        const float* p1 = g.k1 ? g.k1 + (size_t)n * Cin : g.in;
-        const float* p2 = g.k2 ? g.k2 + (size_t)n * Cin : g.in;
+        const float* p0 = g.k0 ? g.k0 + (size_t)n * Cin : g.Wt;      // dummy location: any readable floats
+        const float* p1 = g.k1 ? g.k1 + (size_t)n * Cin : g.Wt;
+        const float* p2 = g.k2 ? g.k2 + (size_t)n * Cin : g.Wt;
         for (int i = tid; i < Cin; i += NT) {
             const float a = p0[i], b = p1[i], c = p2[i];
             cf[0][i] = g.k0 ? a : 1.f;
@@ -104,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         }
     }
     {
-        const float* pb = g.bias ? g.bias + (size_t)n * g.bias_stride_n : g.in;
+        const float* pb = g.bias ? g.bias + (size_t)n * g.bias_stride_n : g.Wt;
         for (int c = tid; c < COUTP; c += NT) {
             const int cc = c < Cout ? c : Cout - 1;
             const float b = pb[g.bias ? cc : 0];
@@ -124,8 +146,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
 
     // staging ownership: rows 4*cig .. 4*cig+3 of the chunk, pixels 4*sj .. 4*sj+3 of the tile
     const int sj = tid & 31, cig = tid >> 5;
-    const float* inb = g.in + (size_t)n * Cin * P + 4 * sj;
-    const float* in2b = g.in2 ? g.in2 + (size_t)n * Cin * P + 4 * sj : inb;
+    const TA* inb = (const TA*)g.in + (size_t)n * Cin * P + 4 * sj;
+    const TA* in2b = g.in2 ? (const TA*)g.in2 + (size_t)n * Cin * P + 4 * sj : inb;
     // LDS byte offset of this thread's 8-B half-slot for (part 0, e 0): ks = cig>>2, kg = (cig>>1)&1, half = cig&1
     const int st_off = ((cig >> 2) * 2 + ((cig >> 1) & 1)) * 2048 + sj * 16 + (cig & 1) * 8;
 
@@ -135,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     auto advance = [&](Pos& p) { const bool wrap = p.c + 1 == nkp; p.c = wrap ? 0 : p.c + 1; p.ti += wrap ? 1 : 0; };
     auto tile_px = [&](int ti) { return (bx + (ti < nt ? ti : nt - 1) * G) * PWS_TP; };
 
-    float4 pre[DEPTH][4], pre2[PRE2 ? DEPTH : 1][4];
+    Raw pre[DEPTH][4], pre2[PRE2 ? DEPTH : 1][4];
     // rows past Cin re-read row 0 (branch-free; they are zeroed at staging)
     auto load_chunk = [&](const Pos& p, auto slot) {
         constexpr int S = decltype(slot)::value;
@@ -144,8 +166,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         for (int r = 0; r < 4; ++r) {
             const int k = p.c * PWS_KC + 4 * cig + r;
             const int kk = k < Cin ? k : 0;
-            pre[S][r] = pws_ld<UNCR_NTG_LD && EPI != 4>(inb + (size_t)kk * P + px);
-            if constexpr (PRE2) pre2[S][r] = pws_ld<UNCR_NTG_LD && EPI != 4>(in2b + (size_t)kk * P + px);
+            pre[S][r] = pws_ld<UNCR_NTG_LD && EPI != 4, TA>(inb + (size_t)kk * P + px);
+            if constexpr (PRE2) pre2[S][r] = pws_ld<UNCR_NTG_LD && EPI != 4, TA>(in2b + (size_t)kk * P + px);
         }
     };
     auto stage_chunk = [&](int kc, int buf, auto slot) {
@@ -164,19 +186,25 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             unsigned hh[4], mm[4], ll[4];
+            float vv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = ((const float*)&pre[S][r])[e];
+                float v = pws_get(pre[S][r], e);
                 if constexpr (PRO == PRO_AFFINE) v = fmaf(c0[r], v, c1[r]);
                 else if constexpr (PRO == PRO_AFFINE_GELU) v = c2[r] * gelu_f(fmaf(c0[r], v, c1[r]));
-                else if constexpr (PRO == PRO_NORMBWD) v = fmaf(c0[r], v, fmaf(c1[r], ((const float*)&pre2[S][r])[e], c2[r]));
+                else if constexpr (PRO == PRO_NORMBWD) v = fmaf(c0[r], v, fmaf(c1[r], pws_get(pre2[PRE2 ? S : 0][r], e), c2[r]));
                 else if constexpr (PRO == PRO_AFFINE_RELU) v = fmaxf(fmaf(c0[r], v, c1[r]), 0.f);
                 if (!valid[r]) v = 0.f;
-                split3_bf16(v, hh[r], mm[r], ll[r]);
+                if constexpr (BF) vv[r] = v;
+                else split3_bf16(v, hh[r], mm[r], ll[r]);
             }
-            *(u32x2_t*)(b + e * 512) = u32x2_t{pack_bf16x2(hh[0], hh[1]), pack_bf16x2(hh[2], hh[3])};
-            *(u32x2_t*)(b + 8192 + e * 512) = u32x2_t{pack_bf16x2(mm[0], mm[1]), pack_bf16x2(mm[2], mm[3])};   // part stride 8192
-            *(u32x2_t*)(b + 16384 + e * 512) = u32x2_t{pack_bf16x2(ll[0], ll[1]), pack_bf16x2(ll[2], ll[3])};
+            if constexpr (BF) {      // one operand part: the prologue's fp32 result rounded to bf16 (RNE)
+                *(u32x2_t*)(b + e * 512) = u32x2_t{cvt_pk_bf16(vv[0], vv[1]), cvt_pk_bf16(vv[2], vv[3])};
+            } else {
+                *(u32x2_t*)(b + e * 512) = u32x2_t{pack_bf16x2(hh[0], hh[1]), pack_bf16x2(hh[2], hh[3])};
+                *(u32x2_t*)(b + 8192 + e * 512) = u32x2_t{pack_bf16x2(mm[0], mm[1]), pack_bf16x2(mm[2], mm[3])};   // part stride 8192
+                *(u32x2_t*)(b + 16384 + e * 512) = u32x2_t{pack_bf16x2(ll[0], ll[1]), pack_bf16x2(ll[2], ll[3])};
+            }
         }
     };
 
@@ -195,12 +223,22 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     const u32x4_t* wp = (const u32x4_t*)g.Wt + (size_t)(wn * CT) * 3 * 64 + lane;
     auto lda = [&](int ks, int ct, int part) { return wp[((size_t)(ks * NCT + ct) * 3 + part) * 64]; };
     u32x4_t ah[CT], am[CT], al[CT];
+    u32x4_t a2[BF ? 2 : 1][BF ? NW : 1][CT];      // bf16 activations: the A fragments of two consecutive k-steps
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, DEPTH - 1>;
     Pos lp{0, 0};                       // next chunk to request from HBM
     load_chunk(lp, S0{}); advance(lp);
+    if constexpr (BF) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) a2[q][w][ct] = lda(q, ct, w);
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
+    }
     __syncthreads();   // cf / ecf visible
     stage_chunk(0, 0, S0{});
     load_chunk(lp, S0{}); advance(lp);
@@ -216,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) b[e] = *(const u32x4_t*)(p0 + part * 8192 + e * 512);   // one ds_read_b128 = the lane's 8 k-values
     };
-    ldb(&xs[0][0] + rd_off, 1, bm);
+    if constexpr (!BF) ldb(&xs[0][0] + rd_off, 1, bm);
     ldb(&xs[0][0] + rd_off, 0, bh);
 
 #define PWS_MF(A, B)                                                                                          \
@@ -252,9 +290,27 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         PWS_SB();
 #undef PWS_SB
     };
+    // bf16 activations: k-step with fragment set q (= its parity): NW products, then the set is re-loaded with the weights of
+    // k-step `ksn` (two k-steps ahead, wrapping into the next tile) and bh with the next k-step's B operand
+    auto kstep_a16 = [&](auto qc, int ksn, const unsigned char* nb) {
+        constexpr int Q = decltype(qc)::value;
+#define PWS_SB() __builtin_amdgcn_sched_barrier(0)
+        PWS_SB();
+#pragma unroll
+        for (int w = 0; w < (BF ? NW : 0); ++w) { PWS_MF(a2[BF ? Q : 0][w], bh); PWS_SB(); }
+#pragma unroll
+        for (int w = 0; w < (BF ? NW : 0); ++w)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) if (!(PWS_ABL & 8)) a2[BF ? Q : 0][w][ct] = lda(ksn, ct, w);
+        if (!(PWS_ABL & 32)) ldb(nb, 0, bh);
+        PWS_SB();
+#undef PWS_SB
+    };
     int par = 0;   // LDS buffer holding the chunk under the MFMAs
     using Roll = std::true_type;
     using NoRoll = std::false_type;
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
     auto compute_chunk = [&](int c, auto slot, auto roll_last) {
         // k-step 0 of chunk c | stage the raw chunk held in the register slot (the stream's next chunk) into the other
         // buffer, refill the slot from HBM | barrier | k-step 1 (its rolling B reads already come from the freshly
@@ -263,11 +319,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         const unsigned char* xb = &xs[par][0] + rd_off;
         const unsigned char* xn = &xs[par ^ 1][0] + rd_off;
         const int cn = c + 1 == nkp ? 0 : c + 1;                 // the next chunk of the stream (wraps into the next tile)
-        kstep(2 * c + 1, xb, xb + 4096, Roll{});
+        if constexpr (BF) kstep_a16(Q0{}, 2 * c + 2 >= nks ? 2 * c + 2 - nks : 2 * c + 2, xb + 4096);
+        else kstep(2 * c + 1, xb, xb + 4096, Roll{});
         if (!(PWS_ABL & 2)) stage_chunk(cn, par ^ 1, slot);
         if (!(PWS_ABL & 4)) { load_chunk(lp, slot); advance(lp); }
         __syncthreads();
-        kstep(2 * c + 2 == nks ? 0 : 2 * c + 2, xb + 4096, xn, roll_last);
+        if constexpr (BF) kstep_a16(Q1{}, 2 * c + 3 >= nks ? 2 * c + 3 - nks : 2 * c + 3, xn);
+        else kstep(2 * c + 2 == nks ? 0 : 2 * c + 2, xb + 4096, xn, roll_last);
         par ^= 1;
     };
 
@@ -304,15 +362,15 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                 float4 xa[(EPI == 2 || EPI == 3 || EPI == 4 || EPI == 5 || EPI == 6) ? RB : 1];
                 float4 xb[(EPI == 5 || EPI == 6) ? RB : 1], xc[(EPI == 5 || EPI == 6) ? RB : 1];
                 if constexpr (EPI == 5 || EPI == 6) {      // skip + PreNorm backward: x, dy, and the producing block's h3 (statistics)
-                    const float* a3 = g.aux3 ? g.aux3 : g.aux2;
+                    const TA* a3 = g.aux3 ? (const TA*)g.aux3 : (const TA*)g.aux2;
 #pragma unroll
                     for (int q = 0; q < RB; ++q) {
                         const int rw = row_of(ct, rb + q);
                         const int rc = rw + 4 < Cout ? rw : (Cout > 8 ? Cout - 8 : 0);
                         const size_t o = (size_t)(nco + rc) * P + loff;
-                        xa[q] = pws_ld<UNCR_NTG_AUX>(g.aux + o);
-                        xb[q] = pws_ld<UNCR_NTG_AUX>(g.aux2 + o);
-                        xc[q] = pws_ld<UNCR_NTG_AUX>(a3 + o);
+                        xa[q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux + o);
+                        xb[q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux2 + o);
+                        xc[q] = ld4<TA, UNCR_NTG_AUX>(a3 + o);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -321,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                     for (int q = 0; q < 8; ++q) {
                         const int rw = row_of(ct, rb + q);
                         const int rc = rw + 4 < Cout ? rw : (Cout > 8 ? Cout - 8 : 0);
-                        xa[q] = *(const float4*)(g.out + (size_t)(nco + rc) * P + loff);
+                        xa[q] = ld4<TA>((const TA*)g.out + (size_t)(nco + rc) * P + loff);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -331,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                         const int r = rb + q;
                         const int rw = row_of(ct, r);            // rows past Cout (padded tiles) re-read the last valid row
                         const int rc = rw + 4 < Cout ? rw : (Cout > 8 ? Cout - 8 : 0);
-                        xa[q] = pws_ld<UNCR_NTG_AUX>(g.aux + (size_t)(nco + rc) * P + loff);
+                        xa[q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux + (size_t)(nco + rc) * P + loff);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -350,13 +408,16 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                         v.y = gelu_grad_f(fmaf(eA, x.y, eB)) * fmaf(eS, v.y, eD);
                         v.z = gelu_grad_f(fmaf(eA, x.z, eB)) * fmaf(eS, v.z, eD);
                         v.w = gelu_grad_f(fmaf(eA, x.w, eB)) * fmaf(eS, v.w, eD);
+                        v = rnd4<TA>(v);      // statistics of the values as stored
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
                     } else if constexpr (EPI == 2) {
                         const float4 x = xa[q];
+                        v = rnd4<TA>(v);
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
                     } else if constexpr (EPI == 1) {
+                        v = rnd4<TA>(v);
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
                     } else if constexpr (EPI == 4) {
@@ -369,6 +430,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                         v.y = y.y + fmaf(e1, v.y, fmaf(e2, x.y, e3));
                         v.z = y.z + fmaf(e1, v.z, fmaf(e2, x.z, e3));
                         v.w = y.w + fmaf(e1, v.w, fmaf(e2, x.w, e3));
+                        v = rnd4<TA>(v);
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * h.x + v.y * h.y + v.z * h.z + v.w * h.w;
                     } else if constexpr (EPI == 6) {
@@ -380,6 +442,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                         v.y = fmaf(rA, h.y, rB) > 0.f ? y.y + fmaf(e1, v.y, fmaf(e2, x.y, e3)) : 0.f;
                         v.z = fmaf(rA, h.z, rB) > 0.f ? y.z + fmaf(e1, v.z, fmaf(e2, x.z, e3)) : 0.f;
                         v.w = fmaf(rA, h.w, rB) > 0.f ? y.w + fmaf(e1, v.w, fmaf(e2, x.w, e3)) : 0.f;
+                        v = rnd4<TA>(v);
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * h.x + v.y * h.y + v.z * h.z + v.w * h.w;
                     }
@@ -399,16 +462,18 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                 const int rw = row_of(ct, r);
                 const float4 v = make_float4(acc[0][ct][r], acc[1][ct][r], acc[2][ct][r], acc[3][ct][r]);
                 if (rw + 4 * kg < Cout && (!(PWS_ABL & 1) || v.x == 1.2345e-30f)) {
-                    pws_st<(UNCR_NTG_ST || (UNCR_NTG_ST2 && CT == 2)) && EPI != 4>(g.out + (size_t)(nco + rw) * P + loff, v);
+                    pws_st<(UNCR_NTG_ST || (UNCR_NTG_ST2 && CT == 2)) && EPI != 4, TA>((TA*)g.out + (size_t)(nco + rw) * P + loff, v);
                 }
             }
         }
         zero_acc();
-        // operands of the next tile's first k-step (its chunk 0 is already staged in xs[par])
+        if constexpr (!BF) {      // (bf16 activations: the rolling operand loads already wrapped into the next tile)
+            // operands of the next tile's first k-step (its chunk 0 is already staged in xs[par])
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
-        ldb(&xs[par][0] + rd_off, 1, bm);
-        ldb(&xs[par][0] + rd_off, 0, bh);
+            for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
+            ldb(&xs[par][0] + rd_off, 1, bm);
+            ldb(&xs[par][0] + rd_off, 0, bh);
+        }
 #ifdef PWS_STAMP
         tepi += __builtin_readcyclecounter() - te0;
 #endif
@@ -511,11 +576,12 @@ int pw_split_pack(const float* W, int rows_k, int cols_co, int ld, int transpose
 }
 #endif
 
-template <int EPI>
+template <int EPI, typename TA>
 static void pws_launch_epi(const PwArgs& g, dim3 grid, int cp, hipStream_t stream) {
-    // prefetch depth 2 where registers allow (CT = 1); the 256-channel tile keeps one chunk in flight
-    if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, 1>), grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 2>), grid, dim3(256), 0, stream, g);
+    // prefetch depth 2 where registers allow (CT = 1); the 256-channel tile keeps one chunk in flight with fp32 storage
+    // (bf16 storage alike: depth 2 spills with the double-buffered A fragments)
+    if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, 1, TA>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 2, TA>), grid, dim3(256), 0, stream, g);
 }
 
 #define PWS_CAT2(a, b) a##b
@@ -540,27 +606,36 @@ int pw_split_blocks_per_frame(int N, int P) {
 }
 #endif
 
-int PWS_CAT(pw_split_launch_p, PWS_PRO)(const PwArgs& g, int N, int cp, hipStream_t stream) {
-    if (g.P % PWS_TP) return UNCR_ESHAPE;
+template <typename TA>
+static int pws_launch_t(const PwArgs& g, int N, int cp, hipStream_t stream) {
     dim3 grid(pw_split_blocks_per_frame(N, g.P), N);
     switch (g.epi) {
-        case 0: pws_launch_epi<0>(g, grid, cp, stream); break;
-        case 1: pws_launch_epi<1>(g, grid, cp, stream); break;
-        case 2: pws_launch_epi<2>(g, grid, cp, stream); break;
-        case 3: pws_launch_epi<3>(g, grid, cp, stream); break;
-        case 4: pws_launch_epi<4>(g, grid, cp, stream); break;
+        case 0: pws_launch_epi<0, TA>(g, grid, cp, stream); break;
+        case 1: pws_launch_epi<1, TA>(g, grid, cp, stream); break;
+        case 2: pws_launch_epi<2, TA>(g, grid, cp, stream); break;
+        case 3: pws_launch_epi<3, TA>(g, grid, cp, stream); break;
+        case 4:      // accumulate (dense 3x3 as nine shifted GEMMs): fp32 storage only
+            if (sizeof(TA) != 4) return UNCR_EINVAL;
+            pws_launch_epi<4, float>(g, grid, cp, stream);
+            break;
 #if PWS_PRO == 3
         case 5:      // the backward of pw1 only: 256 -> 128 channels
             if (cp != 128) return UNCR_EINVAL;
-            hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 5, 2>), grid, dim3(256), 0, stream, g);
+            hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 5, 2, TA>), grid, dim3(256), 0, stream, g);
             break;
         case 6:
             if (cp != 128) return UNCR_EINVAL;
-            hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 6, 2>), grid, dim3(256), 0, stream, g);
+            hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 6, 2, TA>), grid, dim3(256), 0, stream, g);
             break;
 #endif
         default: return UNCR_EINVAL;
     }
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
+}
+
+int PWS_CAT(pw_split_launch_p, PWS_PRO)(const PwArgs& g, int N, int cp, int act, hipStream_t stream) {
+    if (g.P % PWS_TP) return UNCR_ESHAPE;
+    if (act == UNCR_BF16) return pws_launch_t<bf16_t>(g, N, cp, stream);
+    return pws_launch_t<float>(g, N, cp, stream);
 }

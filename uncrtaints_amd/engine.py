@@ -37,9 +37,34 @@ def _f32(shape, dev) -> Tensor:
     return torch.empty(shape, device=dev, dtype=torch.float32)
 
 
+# Activation storage (include/uncr_hip.h: UNCR_F32 / UNCR_BF16).  The mode is carried by the tensors themselves: every stage
+# allocates its activation outputs in the storage type of its activation input, so casting the model input to bf16
+# (UNCRTAINTS.act_dtype) switches the whole path -- "bf16 activations, fp32 accumulate", BASELINE config 3.  Statistics,
+# coefficients, weights, weight gradients, the 32x32 L-TAE branch, the model outputs and the loss stay fp32.
+F32, BF16 = 0, 1
+
+
+def _dt(t: Tensor) -> int:
+    return BF16 if t.dtype == torch.bfloat16 else F32
+
+
+def _act(shape, dev, dt: int) -> Tensor:
+    return torch.empty(shape, device=dev, dtype=torch.bfloat16 if dt == BF16 else torch.float32)
+
+
+def cast(x: Tensor, dt: int) -> Tensor:
+    """x converted to the storage type `dt` by a HIP kernel (no-op when it already has it)."""
+    if _dt(x) == dt:
+        return x
+    x = x.contiguous()
+    out = _act(x.shape, x.device, dt)
+    hb.call("uncr_cast", x, out, x.numel(), _dt(x), dt, _stream())
+    return out
+
+
 def _check4(x: Tensor):
-    if x.dim() != 4 or x.dtype != torch.float32 or not x.is_cuda:
-        raise RuntimeError("expected a 4-D fp32 CUDA tensor [frames, C, H, W]")
+    if x.dim() != 4 or x.dtype not in (torch.float32, torch.bfloat16) or not x.is_cuda:
+        raise RuntimeError("expected a 4-D fp32 / bf16 CUDA tensor [frames, C, H, W]")
     N, C, H, W = x.shape
     if (H * W) % 1024 or W % 4:
         raise RuntimeError(f"unsupported spatial size {H}x{W}: H*W must be a multiple of 1024 and W of 4")
@@ -99,7 +124,7 @@ def ew(op: int, a: Tensor, *, b=None, c=None, aux=None, out: Optional[Tensor] = 
         slots = hb.query("uncr_ew_slots", P)
         part = Part(_f32((planes, slots, 2), a.device), slots)
     hb.call("uncr_ew", op, a, b, c, aux, out, k[0], k[1], k[2], k[3], part.buf if part else None, planes, P, C,
-            n_mean, float(scale), float(eps), _stream())
+            n_mean, float(scale), float(eps), _dt(out if out is not None else a), _stream())
     return out, part
 
 
@@ -268,9 +293,10 @@ def pack_wt(W2d: Tensor, transpose: bool) -> Tensor:
 def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: int = PRO_NONE, k=(None, None, None),
             x2: Optional[Tensor] = None, bias: Optional[Tensor] = None, bias_per_frame: bool = False, epi: int = 0,
             aux: Optional[Tensor] = None, out: Optional[Tensor] = None,
-            ek=(None, None, None, None)) -> Tuple[Tensor, Optional[Part]]:
+            ek=(None, None, None, None), out_dt: Optional[int] = None) -> Tuple[Tensor, Optional[Part]]:
+    """out_dt: storage of the output (default: that of the input; the narrow Cout <= 64 kernels write fp32 only)."""
     if out is None:
-        out = _f32((N, Cout, P), x.device)
+        out = _act((N, Cout, P), x.device, _dt(x) if out_dt is None else out_dt)
     part = None
     if epi and epi != 4:          # epi 4 = accumulate into `out`, no statistics
         slots = hb.query("uncr_pw_stat_slots", N, Cout, P)
@@ -278,7 +304,7 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
             raise RuntimeError(f"pw_gemm: P={P} is not a multiple of the {hb.query('uncr_pw_tile_px', Cout)}-pixel tile")
         part = Part(_f32((N * Cout, slots, 2), x.device), slots)
     hb.call("uncr_pw_gemm", x, x2, Wt, out, k[0], k[1], k[2], bias, Cout if bias_per_frame else 0, aux,
-            ek[0], ek[1], ek[2], ek[3], part.buf if part else None, N, Cin, Cout, P, pro, epi, _stream())
+            ek[0], ek[1], ek[2], ek[3], part.buf if part else None, N, Cin, Cout, P, pro, epi, _dt(x), _dt(out), _stream())
     return out, part
 
 
@@ -292,14 +318,17 @@ def pw_wgrad(d: Tensor, x: Tensor, N: int, Cd: int, Cx: int, P: int, *, pro_d: i
     if hb.lib().cdll.uncr_wgrad_shape(Cd, Cx, ctypes.byref(cop), ctypes.byref(cip)) < 0:
         raise RuntimeError(f"weight-gradient shape ({Cd},{Cx}) not built")
     cop, cip = cop.value, cip.value
-    nbx = hb.query("uncr_wgrad_nbx", N, Cd, Cx, P, pro_d, pro_x, 1 if rowsum else 0)
+    if d.dtype != x.dtype:
+        raise RuntimeError("pw_wgrad: both operands must have the same storage type")
+    act = _dt(d)
+    nbx = hb.query("uncr_wgrad_nbx", N, Cd, Cx, P, pro_d, pro_x, 1 if rowsum else 0, act)
     if nbx <= 0:
         raise RuntimeError(f"weight-gradient problem (N={N}, P={P}) not supported")
     dev = d.device
     part = _f32((N * nbx, cop, cip), dev)
     rs_part = _f32((N * nbx, cop), dev) if rowsum else None
     hb.call("uncr_pw_wgrad", d, d2, x, x2, dk[0], dk[1], dk[2], xk[0], xk[1], xk[2], part, rs_part, N, Cd, Cx, P, nbx,
-            pro_d, pro_x, _stream())
+            pro_d, pro_x, act, _stream())
     n_out = N if per_frame else 1
     dW = _f32((n_out, Cd, Cx), dev)
     hb.call("uncr_wgrad_reduce", part, n_out, (N * nbx) // n_out, cop, cip, Cd, Cx, dW, _stream())
@@ -329,6 +358,9 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     R = p["se1"].shape[0]
     need = spec.needs_stats(training)
     buffers = buffers or {}
+    dt = _dt(x)
+    if dt == BF16 and (C != 128 or Ch != 256):
+        raise NotImplementedError("bf16 activations are built for the BASELINE widths (MBConv 128 -> 256 -> 128)")
 
     def rm(i):
         return buffers.get(f"n{i}rm"), buffers.get(f"n{i}rv")
@@ -340,11 +372,11 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     h1, part1 = pw_gemm(x, W1t, N, C, Ch, P, pro=PRO_AFFINE, k=(n0.A, n0.B, None), epi=1 if need else 0)
     n1 = norm_fwd(part1, N, Ch, P, spec, training, p["n1w"], p["n1b"], *rm(1))
 
-    h2 = _f32((N, Ch, H, W), x.device)
+    h2 = _act((N, Ch, H, W), x.device, dt)
     slots = hb.query("uncr_dw_slots_fwd", H)
     part2 = Part(_f32((N * Ch, slots, 2), x.device), slots) if need else None
     hb.call("uncr_dw_fwd", h1, n1.A, n1.B, p["wdw"].reshape(Ch, 9).contiguous(), h2, part2.buf if need else None, N, Ch,
-            H, W, _stream())
+            H, W, dt, _stream())
     n2 = norm_fwd(part2, N, Ch, P, spec, training, p["n2w"], p["n2b"], *rm(2))
 
     _, ppool = ew(EW_SE_POOL, h2, k=(n2.A, n2.B, None, None), want_part=True, planes=N * Ch, P=P)
@@ -356,7 +388,7 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     h3, part3 = pw_gemm(h2, W2t, N, Ch, C, P, pro=PRO_AFFINE_GELU, k=(n2.A, n2.B, s), epi=1 if need else 0)
     n3 = norm_fwd(part3, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))
 
-    y = _f32((N, C, H, W), x.device)
+    y = _act((N, C, H, W), x.device, dt)
     ypool = None
     if pool is not None and hb.query("uncr_residual_pool_supported", H, W, pool, pool) == 1:
         down = _f32((N, C, pool, pool), x.device)
@@ -366,7 +398,7 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
             slots = hb.query("uncr_residual_pool_slots", H)
             party = Part(_f32((N * C, slots, 2), x.device), slots)
         hb.call("uncr_residual_pool", x, h3, n3.A, n3.B, y, party.buf if party else None, down, idx, N * C, H, W, pool,
-                pool, _stream())
+                pool, dt, _stream())
         ypool = (down, idx)
     else:
         _, party = ew(EW_RESIDUAL, x, b=h3, out=y, k=(n3.A, n3.B, None, None), want_part=want_out_stats, planes=N * C,
@@ -401,7 +433,8 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     dev = dy.device
     x, h1, h2, h3 = sv["x"], sv["h1"], sv["h2"], sv["h3"]
     n0, n1, n2, n3 = sv["n0"], sv["n1"], sv["n2"], sv["n3"]
-    dy = dy.contiguous()
+    dt = _dt(x)
+    dy = cast(dy.contiguous(), dt)
     g: Dict[str, Tensor] = {}
 
     # norm 3 backward coefficients: needs (sum dy, sum dy*h3)
@@ -430,7 +463,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     g["n2w"], g["n2b"] = b2.dgamma, b2.dbeta
 
     # depthwise backward
-    du1 = _f32((N, Ch, H, W), dev)
+    du1 = _act((N, Ch, H, W), dev, dt)
     slots = hb.query("uncr_dw_slots_bwd", H)
     part1 = Part(_f32((N * Ch, slots, 2), dev), slots)
     dw_part = _f32((N * Ch, slots, 9), dev)
@@ -438,7 +471,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     # statistics for the norm-1 backward in centred form (sum du1*(h1 - mean1)): h1 is the raw pw1 output, whose
     # channel means can be many standard deviations from zero
     hb.call("uncr_dw_bwd", du2, h2, h1, b2.c1, b2.c2, b2.c3, n1.A, n1.B, wdw, du1, part1.buf, dw_part, n1.mean,
-            n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, H, W, _stream())
+            n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, H, W, dt, _stream())
     dwdw = _f32((Ch, 9), dev)
     hb.call("uncr_dw_wgrad_reduce", dw_part, N, Ch, slots, dwdw, _stream())
     g["wdw"] = dwdw.view_as(p["wdw"])
@@ -464,7 +497,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         g["w1"] = dW1.view_as(p["w1"])
         b0 = norm_bwd(part0, N, C, P, n0, p["n0w"])
         g["n0w"], g["n0b"] = b0.dgamma, b0.dbeta
-        dx = _f32((N, C, H, W), dev)
+        dx = _act((N, C, H, W), dev, dt)
         x_h3 = sv.get("x_h3")
         relu = sv.get("x_relu")       # x = relu(A*c0 + B) of in_conv: its ReLU backward and norm statistics ride along
         ra = rb = None
@@ -475,7 +508,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
             slots = hb.query("uncr_pw_stat_slots", N, C, P)
             dx_part = Part(_f32((N * C, slots, 2), dev), slots, masked=relu is not None)
         hb.call("uncr_pw_gemm_dx", du1, h1, W1k, dx, k1[0], k1[1], k1[2], dy, x, x_h3, b0.c1, b0.c2, b0.c3, ra, rb,
-                dx_part.buf if dx_part is not None else None, N, Ch, C, P, _stream())
+                dx_part.buf if dx_part is not None else None, N, Ch, C, P, dt, _stream())
         return dx, g, dx_part
 
     # pw1: weight gradient and data gradient
@@ -487,7 +520,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
 
     dx, dx_part = None, None
     if need_dx:
-        dx = _f32((N, C, H, W), dev)
+        dx = _act((N, C, H, W), dev, dt)
         x_h3 = sv.get("x_h3")     # h3 of the block that produced x: emit its norm-3 backward statistics here
         _, dx_part = ew(EW_PASSE, dy, b=da, c=x, aux=x_h3, out=dx, k=(b0.c1, b0.c2, b0.c3, None),
                         want_part=x_h3 is not None, planes=N * C, P=P)
@@ -623,7 +656,7 @@ def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec
     Wt = pack_wt(w.reshape(Cout, Cin), transpose=True)
     c0, part = pw_gemm(x, Wt, N, Cin, Cout, P, bias=b.contiguous(), epi=1 if need else 0)
     nf = norm_fwd(part, N, Cout, P, spec, training, gw, gb, buffers.get("rm"), buffers.get("rv"))
-    a0 = _f32((N, Cout, H, W), x.device)
+    a0 = _act((N, Cout, H, W), x.device, _dt(x))
     _, parta = ew(EW_AFFINE_RELU, c0, out=a0, k=(nf.A, nf.B, None, None), want_part=True, planes=N * Cout, P=P)
     return a0, dict(x=x, c0=c0, nf=nf, dims=(N, Cin, Cout, H, W)), parta
 
@@ -634,11 +667,11 @@ def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool,
     N, Cin, Cout, H, W = sv["dims"]
     P = H * W
     nf, c0, x = sv["nf"], sv["c0"], sv["x"]
-    da0 = da0.contiguous()
+    da0 = cast(da0.contiguous(), _dt(x))
     if masked_part is not None:
         du0, part = da0, masked_part
     else:
-        du0 = _f32((N, Cout, H, W), da0.device)
+        du0 = _act((N, Cout, H, W), da0.device, _dt(x))
         _, part = ew(EW_RELU_BWD, da0, b=c0, out=du0, k=(nf.A, nf.B, None, None), want_part=True, planes=N * Cout, P=P)
     nb = norm_bwd(part, N, Cout, P, nf, gw)
     kk = (nb.c1, nb.c2, nb.c3)
@@ -646,7 +679,7 @@ def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool,
     dx = None
     if need_dx:
         Wk = pack_wt(w.reshape(Cout, Cin), transpose=False)   # [k=128][out=15]
-        dx, _ = pw_gemm(du0, Wk, N, Cout, Cin, P, pro=PRO_NORMBWD, k=kk, x2=c0)
+        dx, _ = pw_gemm(du0, Wk, N, Cout, Cin, P, pro=PRO_NORMBWD, k=kk, x2=c0, out_dt=F32)     # the model input's gradient: fp32
         dx = dx.view(N, Cin, H, W)
     return dx, dW.view_as(w), db, nb.dgamma, nb.dbeta
 
@@ -670,14 +703,14 @@ def maxpool_forward(e: Tensor, OH: int, OW: int):
     lead = tuple(e.shape[:-2])
     down = _f32(lead + (OH, OW), e.device)
     idx = torch.empty(lead + (OH, OW), device=e.device, dtype=torch.int32)
-    hb.call("uncr_maxpool_fwd", e, down, idx, planes, H, W, OH, OW, _stream())
+    hb.call("uncr_maxpool_fwd", e, down, idx, planes, H, W, OH, OW, _dt(e), _stream())
     return down, idx
 
 
 def maxpool_backward_into(ddown: Tensor, idx: Tensor, de: Tensor, H: int, W: int, OH: int, OW: int):
     """de[plane][argmax] += ddown (in place on `de`)."""
     planes = ddown.numel() // (OH * OW)
-    hb.call("uncr_maxpool_bwd", ddown.contiguous(), idx, de, planes, H, W, OH, OW, _stream())
+    hb.call("uncr_maxpool_bwd", ddown.contiguous(), idx, de, planes, H, W, OH, OW, _dt(de), _stream())
 
 
 def ltae_attention_forward(down: Tensor, dates: Optional[Tensor], pad: Optional[Tensor], p: Dict[str, Tensor],
@@ -759,7 +792,7 @@ def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: b
         raise NotImplementedError("feature map smaller than the attention map (AvgPool branch, "
                                   "uncrtaints.py:204) is not built")
     dev = e.device
-    g = _f32((B, C, H, W), dev)
+    g = _act((B, C, H, W), dev, _dt(e))
     gpart = None
     if want_stats:
         slots = hb.query("uncr_agg_slots", H * W)
@@ -768,7 +801,7 @@ def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: b
     pd = float(p_drop) if (training and dmask is None) else 0.0
     seed_val, seed_dev = seed if isinstance(seed, tuple) else (seed, None)
     hb.call("uncr_aggregate_fwd", e, att, pad, use_mask, seed_val, seed_dev, pd, 1 if shared_mask else 0, g,
-            gpart.buf if gpart else None, B, T, C, n_head, H, W, ah, aw, _stream())
+            gpart.buf if gpart else None, B, T, C, n_head, H, W, ah, aw, _dt(e), _stream())
     saved = dict(e=e, att=att, pad=pad, dmask=use_mask, pd=pd, seed=seed_val, seed_dev=seed_dev,
                  shared=1 if shared_mask else 0, dims=(B, T, C, H, W, n_head, ah, aw))
     return g, saved, gpart
@@ -778,11 +811,12 @@ def aggregate_backward(dg: Tensor, sv: dict):
     """-> de [B,T,C,H,W] (freshly written), datt [nh,B,T,ah,aw]"""
     B, T, C, H, W, n_head, ah, aw = sv["dims"]
     dev = dg.device
-    de = _f32((B, T, C, H, W), dev)
+    dt = _dt(sv["e"])
+    de = _act((B, T, C, H, W), dev, dt)
     datt_up = _f32((n_head, B, T, H * W), dev)
     datt = _f32((n_head, B, T, ah, aw), dev)
-    hb.call("uncr_aggregate_bwd", dg.contiguous(), sv["e"], sv["att"], sv["pad"], sv["dmask"], sv["seed"],
-            sv["seed_dev"], sv["pd"], sv["shared"], de, datt_up, datt, B, T, C, n_head, H, W, ah, aw, _stream())
+    hb.call("uncr_aggregate_bwd", cast(dg.contiguous(), dt), sv["e"], sv["att"], sv["pad"], sv["dmask"], sv["seed"],
+            sv["seed_dev"], sv["pd"], sv["shared"], de, datt_up, datt, B, T, C, n_head, H, W, ah, aw, dt, _stream())
     return de, datt
 
 
@@ -1002,9 +1036,12 @@ def head_forward(y: Tensor, w: Tensor, b: Tensor, n_mean: int, mean_sigmoid: boo
     vm = {"softplus": 0, "elu": 1, "identity": 2}[var_mode]
     if Co <= 64:       # convolution + nonlinearities in ONE kernel (the pre-activation is a second output, for the backward)
         o = _f32((N, Co, H, W), y.device)
-        hb.call("uncr_head_fwd", y, Wt, b.contiguous(), out, o, N, C, Co, P, nm, float(scale), float(eps), vm, _stream())
+        hb.call("uncr_head_fwd", y, Wt, b.contiguous(), out, o, N, C, Co, P, nm, float(scale), float(eps), vm, _dt(y),
+                _stream())
         from_out = False
     else:
+        if _dt(y) == BF16:
+            raise NotImplementedError("bf16 activations: out_conv wider than 64 channels is not built")
         o, _ = pw_gemm(y, Wt, N, C, Co, P, bias=b.contiguous())
         ew(_HEAD_OPS[var_mode][0], o, out=out, planes=N * Co, P=P, C=Co, n_mean=nm, scale=scale, eps=eps)
         from_out = False
@@ -1016,7 +1053,8 @@ def head_backward(dout: Tensor, sv: dict, w: Tensor, need_dy: bool = True):
     N, C, Co, H, W = sv["dims"]
     P = H * W
     dout = dout.contiguous()
-    do = _f32((N, Co, H, W), dout.device)
+    # the gradient w.r.t. the head's pre-activation is an activation gradient: stored like the decoder's activations
+    do = _act((N, Co, H, W), dout.device, _dt(sv["y"]))
     ew(_HEAD_OPS[sv.get("var_mode", "softplus")][1], dout, b=sv["o"], out=do, planes=N * Co, P=P,
        C=-Co if sv.get("from_out") else Co, n_mean=sv["nm"], scale=sv["scale"], eps=sv.get("eps", 0.0))
     dW, db = pw_wgrad(do, sv["y"], N, Co, C, P, rowsum=True)

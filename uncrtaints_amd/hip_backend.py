@@ -100,7 +100,7 @@ def _ptr(x):
         raise RuntimeError("uncrtaints_amd kernels need tensors on the GPU (cuda device); there is no CPU path")
     if not x.is_contiguous():
         raise RuntimeError("uncrtaints_amd kernels need contiguous tensors")
-    if x.dtype not in (torch.float32, torch.float64, torch.int32, torch.int64):
+    if x.dtype not in (torch.float32, torch.bfloat16, torch.float64, torch.int32, torch.int64):
         raise RuntimeError(f"unsupported dtype {x.dtype}")
     return x.data_ptr()
 

@@ -313,6 +313,18 @@ class _StageFn(torch.autograd.Function):
         return (de, None, None, None, None) + grads
 
 
+class _CastFn(torch.autograd.Function):
+    """The model input converted to the activation storage type (bf16 activations); its gradient comes back as fp32."""
+
+    @staticmethod
+    def forward(ctx, x, dt):
+        return E.cast(x, dt)
+
+    @staticmethod
+    def backward(ctx, g):
+        return E.cast(g.contiguous(), E.F32), None
+
+
 class _HeadFn(torch.autograd.Function):
     """out_conv (1x1 + bias) + mean/variance nonlinearities (uncrtaints.py:432-445)."""
 
@@ -453,6 +465,26 @@ class UNCRTAINTS(nn.Module):
                 raise ValueError(f"out_conv[-1]={self.out_dims} < 13 + covar_dim={self.vars_idx}")
         self.variance = None
         self._last_attention = None
+        self.act_dtype = torch.float32      # storage of the activations: see set_act_dtype
+
+    def set_act_dtype(self, dtype):
+        """Storage type of every full-resolution activation and activation gradient of the path: torch.float32 (the
+        reference's arithmetic; parity contract 1e-4) or torch.bfloat16 ("bf16 activations, fp32 accumulate", BASELINE config 3:
+        half the HBM bytes per step; statistics, accumulators, weights, weight gradients, the 32x32 attention branch, the outputs
+        and the loss stay fp32; parity contract stated in tests/test_bf16.py).  Parameters and the module API are unchanged."""
+        if isinstance(dtype, str):
+            dtype = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}[dtype]
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("act_dtype must be torch.float32 or torch.bfloat16")
+        if dtype == torch.bfloat16:
+            if self.block_type != 'mbconv' or self.use_v:
+                raise NotImplementedError("bf16 activations are built for block_type='mbconv' without use_v")
+            if any(w != 128 for w in list(self.encoder_widths) + list(self.decoder_widths or [])):
+                raise NotImplementedError("bf16 activations are built for the BASELINE widths (128)")
+            if self.out_dims > 64:
+                raise NotImplementedError("bf16 activations: out_conv wider than 64 channels is not built")
+        self.act_dtype = dtype
+        return self
 
     def _pack_list(self):
         """(weight as [Cout][Cin], transpose) for every pointwise GEMM of forward and backward (engine.pack_wt calls)."""
@@ -502,7 +534,10 @@ class UNCRTAINTS(nn.Module):
         # the encoder runs on the folded [B*T, C, H, W] frames (smart_forward, utae.py:422-450) without autograd views
         # between its blocks, so the statistics / masks that ride on the tensors survive in both directions
         b, t, _, h, w = input.shape
-        x4 = self.in_conv(input.view(b * t, input.shape[2], h, w))
+        x4 = input.view(b * t, input.shape[2], h, w)
+        if self.act_dtype == torch.bfloat16:           # everything downstream allocates in the storage type of its input
+            x4 = _CastFn.apply(x4, E.BF16)
+        x4 = self.in_conv(x4)
         pooled = None
         for li, layer in enumerate(self.in_block):
             if li == len(self.in_block) - 1 and not self.is_mono and h % 32 == 0 and w % 32 == 0:

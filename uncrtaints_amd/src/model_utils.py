@@ -8,7 +8,7 @@ S2_BANDS = 13
 def get_generator(config):
     if config.model != "uncrtaints":
         raise NotImplementedError(f"model '{config.model}' is outside the MI355X hot path (uncrtaints only)")
-    return uncrtaints.UNCRTAINTS(
+    net = uncrtaints.UNCRTAINTS(
         input_dim=S1_BANDS * config.use_sar + S2_BANDS,
         encoder_widths=config.encoder_widths,
         decoder_widths=config.decoder_widths,
@@ -31,6 +31,11 @@ def get_generator(config):
         block_type=config.block_type,
         is_mono=config.pretrain,
     )
+    # not a reference flag: config.act_dtype = 'bf16' stores the activations as bf16 (BASELINE config 3); default fp32
+    act = getattr(config, "act_dtype", None)
+    if act is not None:
+        net.set_act_dtype(act)
+    return net
 
 
 def get_model(config):
