@@ -28,59 +28,67 @@ TRAFFIC_FILE = "r02_traffic.json"
 
 
 def kernel_model(name, key):
-    """-> (label, algorithmic bytes, flops) of one launch from its int arguments."""
+    """-> (label, algorithmic bytes, flops, bf16 MFMA products per fp32-equivalent MAC) of one launch from its int arguments
+    (DESIGN.md section 4).  The last int of every profiled entry point is the activation storage code (0 fp32, 1 bf16)."""
     if name == "uncr_pw_gemm":
-        bias_stride, N, Cin, Cout, P, pro, epi = key
-        rd = Cin * (2 if pro == PRO_NORMBWD else 1) + (Cout if epi in (2, 3) else 0)
-        return (f"pw_gemm[{Cin}->{Cout},pro{pro},epi{epi},N{N},P{P}]", 4.0 * N * P * (rd + Cout), 2.0 * N * P * Cin * Cout,
-                6 if Cout > 64 else 0)
+        bias_stride, N, Cin, Cout, P, pro, epi, in_dt, out_dt = key
+        bi, bo = (2.0 if in_dt else 4.0), (2.0 if out_dt else 4.0)
+        rd = Cin * (2 if pro == PRO_NORMBWD else 1) * bi + (Cout * bo if epi in (2, 3) else 0)
+        return (f"pw_gemm[{Cin}->{Cout},pro{pro},epi{epi},N{N},P{P}]", N * P * (rd + Cout * bo), 2.0 * N * P * Cin * Cout,
+                (2 if in_dt else 6) if Cout > 64 else 0)
     if name == "uncr_pw_gemm_dx":          # in, in2 (norm-bwd prologue), dy, x, xh3 -> dx
-        N, Cin, Cout, P = key[-4:]
-        return (f"pw_gemm_dx[{Cin}->{Cout},N{N},P{P}]", 4.0 * N * P * (2 * Cin + 4 * Cout), 2.0 * N * P * Cin * Cout, 6)
+        N, Cin, Cout, P, act = key[-5:]
+        return (f"pw_gemm_dx[{Cin}->{Cout},N{N},P{P}]", (2.0 if act else 4.0) * N * P * (2 * Cin + 4 * Cout), 2.0 * N * P * Cin * Cout,
+                2 if act else 6)
     if name == "uncr_residual_pool":       # x, h3 -> y (+ 8x8 max-pool)
-        planes, H, W, OH, OW = key[-5:]
-        return (f"residual_pool[planes{planes},{H}x{W}]", 4.0 * planes * H * W * 3, 0.0)
+        planes, H, W, OH, OW, act = key[-6:]
+        return (f"residual_pool[planes{planes},{H}x{W}]", (2.0 if act else 4.0) * planes * H * W * 3, 0.0, 0)
     if name == "uncr_pw_wgrad":
-        N, Cd, Cx, P, PXB, pro_d, pro_x = key
+        N, Cd, Cx, P, PXB, pro_d, pro_x, act = key
         rd = Cd * (2 if pro_d == PRO_NORMBWD else 1) + Cx * (2 if pro_x == PRO_NORMBWD else 1)
-        return (f"pw_wgrad[{Cd}x{Cx},N{N},P{P}]", 4.0 * N * P * rd, 2.0 * N * P * Cd * Cx,
-                6 if (Cd, Cx) in ((128, 256), (256, 128)) else 0)
+        wide = (Cd, Cx) in ((128, 256), (256, 128))
+        return (f"pw_wgrad[{Cd}x{Cx},N{N},P{P}]", (2.0 if act else 4.0) * N * P * rd, 2.0 * N * P * Cd * Cx,
+                (1 if act else 6) if wide else 0)
     if name == "uncr_dw_fwd":
-        N, C, H, W = key
-        return (f"dw_fwd[N{N},C{C},{H}x{W}]", 4.0 * N * C * H * W * 2, 18.0 * N * C * H * W)
+        N, C, H, W, act = key
+        return (f"dw_fwd[N{N},C{C},{H}x{W}]", (2.0 if act else 4.0) * N * C * H * W * 2, 18.0 * N * C * H * W, 0)
     if name == "uncr_dw_bwd":
-        N, C, H, W = key[-4:]
-        return (f"dw_bwd[N{N},C{C},{H}x{W}]", 4.0 * N * C * H * W * 4, 36.0 * N * C * H * W)
+        N, C, H, W, act = key[-5:]
+        return (f"dw_bwd[N{N},C{C},{H}x{W}]", (2.0 if act else 4.0) * N * C * H * W * 4, 36.0 * N * C * H * W, 0)
     if name == "uncr_ew":
-        op, planes, P, C, n_mean = key
+        op, planes, P, C, n_mean, act = key
         tensors = {0: 1, 1: 2, 2: 2, 3: 3, 4: 3, 5: 4, 6: 3, 7: 1, 8: 2, 9: 3}[op]
-        return (f"ew[op{op},planes{planes},P{P}]", 4.0 * planes * P * tensors, 0.0)
+        nbytes = (2.0 if act else 4.0) * planes * P * tensors
+        if op == 9:        # head backward: two fp32 inputs, output in the activation storage
+            nbytes = planes * P * (8.0 + (2.0 if act else 4.0))
+        return (f"ew[op{op},planes{planes},P{P}]", nbytes, 0.0, 0)
     if name == "uncr_aggregate_fwd":
-        B, T, C, NH, H, W, AH, AW = key[-8:]
-        return (f"aggregate_fwd[B{B},T{T}]", 4.0 * B * C * H * W * (T + 1), 2.0 * B * T * C * H * W)
+        B, T, C, NH, H, W, AH, AW, act = key[-9:]
+        return (f"aggregate_fwd[B{B},T{T}]", (2.0 if act else 4.0) * B * C * H * W * (T + 1), 2.0 * B * T * C * H * W, 0)
     if name == "uncr_aggregate_bwd":
-        B, T, C, NH, H, W, AH, AW = key[-8:]
-        return (f"aggregate_bwd[B{B},T{T}]", 4.0 * B * H * W * (C * (2 * T + 1) + NH * T), 4.0 * B * T * C * H * W)
-    return (name, 0.0, 0.0)
+        B, T, C, NH, H, W, AH, AW, act = key[-9:]
+        return (f"aggregate_bwd[B{B},T{T}]", B * H * W * ((2.0 if act else 4.0) * C * (2 * T + 1) + 4.0 * NH * T),
+                4.0 * B * T * C * H * W, 0)
+    return (name, 0.0, 0.0, 0)
 
 
 PROFILED = ("uncr_pw_gemm", "uncr_pw_gemm_dx", "uncr_residual_pool", "uncr_pw_wgrad", "uncr_dw_fwd", "uncr_dw_bwd", "uncr_ew", "uncr_aggregate_fwd",
             "uncr_aggregate_bwd")
 
 
-def a_step_bytes(T, P=65536):
-    """SURVEY 8(d) contract figure: algorithmic HBM bytes of one fwd+bwd step per sample, fp32."""
-    return 2.5 * 4.0 * P * (2206 * T + 9921)
+def a_step_bytes(T, P=65536, bf16=False):
+    """SURVEY 8(d) contract figure: algorithmic HBM bytes of one fwd+bwd step per sample (fp32; bf16 activations halve it)."""
+    return 2.5 * (2.0 if bf16 else 4.0) * P * (2206 * T + 9921)
 
 
-def build_model(device, seed):
+def build_model(device, seed, act_dtype="fp32"):
     from uncrtaints_amd.src.backbones import uncrtaints as U
     from uncrtaints_amd.src.learning.weight_init import weight_init
     torch.manual_seed(seed)
     m = U.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag",
                      scale_by=1.0)
     m.apply(weight_init)
-    return m.to(device).train()
+    return m.to(device).train().set_act_dtype(act_dtype)
 
 
 def synthetic(B, T, H, W, seed, device):
@@ -145,6 +153,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of HIP-graph replays")
+    ap.add_argument("--act-dtype", choices=("fp32", "bf16"), default="fp32",
+                    help="activation storage: fp32 (default: the headline line, BASELINE config 2) or bf16 (BASELINE config 3: bf16 "
+                         "activations, fp32 accumulate; reported as dtype bf16, never as the fp32 headline)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,7 +183,8 @@ def main():
     from uncrtaints_amd.src import losses
     hb.lib()
     B, T, H = args.batch_per_gpu, args.T, args.size
-    model = build_model(device, seed=1)
+    bf16 = args.act_dtype == "bf16"
+    model = build_model(device, seed=1, act_dtype=args.act_dtype)
     crit = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode="diag")
     dp = None
     if world > 1:
@@ -305,21 +317,22 @@ def main():
         res = {
             "metric": "samples/sec fwd+bwd (BxTx15x256x256, T=3)", "value": round(value, 3), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": f"uncrtaints --input_t {T} --n_head 16 --block_type mbconv --covmode diag, "
-                                   f"B={B}/GPU, {H}x{H}, fwd+MGNLL+bwd+Adam, train mode (dropout on), fp32",
+                                   f"B={B}/GPU, {H}x{H}, fwd+MGNLL+bwd+Adam, train mode (dropout on), "
+                                   + ("bf16 activation storage / fp32 accumulate, statistics, weights and loss" if bf16 else "fp32"),
                        "global_batch": world * B, "T": T, "parallelism": f"dp{world}"},
             "final_loss": final_loss, "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
             "launch_mode": graph_note,
-            "step_hbm_roofline_frac": round(value / world * a_step_bytes(T, H * H) / 1e9 / HBM_PEAK_GBS, 4),
+            "step_hbm_roofline_frac": round(value / world * a_step_bytes(T, H * H, bf16) / 1e9 / HBM_PEAK_GBS, 4),
         }
         if prof is not None:
             summ = prof.summarize()
             rows = []
             for (name, key), (n, mean_ms) in summ.items():
-                label, nbytes, flops, *prod = kernel_model(name, key)
-                prod = prod[0] if prod else 0
+                label, nbytes, flops, prod = kernel_model(name, key)
                 rows.append(dict(kernel=label, launches=n, mean_ms=mean_ms, total_ms=n * mean_ms,
+                                 prod=prod,
                                  bf16_pipe_util=(prod * flops / mean_ms / 1e9 / BF16_MFMA_PEAK_TF) if (prod and mean_ms > 0) else None,
                                  gbs=nbytes / mean_ms / 1e6 if mean_ms > 0 else 0.0,
                                  tflops=flops / mean_ms / 1e9 if mean_ms > 0 else 0.0, bytes=nbytes, flops=flops))
@@ -327,9 +340,13 @@ def main():
             tot = sum(r["total_ms"] for r in rows)
             top = rows[0]
             # the bound of a kernel = whichever roof it is closer to
-            hbm_frac, mfma_frac = top["gbs"] / HBM_PEAK_GBS, top["tflops"] / FP32_MFMA_PEAK_TF
+            # matrix roof of a launch: the bf16 pipe for the kernels that run on it (6 / 2 / 1 products per MAC), else fp32 MFMA
+            hbm_frac = top["gbs"] / HBM_PEAK_GBS
+            mfma_frac = top["bf16_pipe_util"] if top["bf16_pipe_util"] is not None else top["tflops"] / FP32_MFMA_PEAK_TF
             if mfma_frac > hbm_frac:
-                res["roofline"] = {"bound": "mfma", "achieved": round(top["tflops"], 2), "peak": FP32_MFMA_PEAK_TF,
+                on_bf16 = top["bf16_pipe_util"] is not None
+                res["roofline"] = {"bound": "mfma", "achieved": round(top["tflops"] * (top["prod"] if on_bf16 else 1), 2),
+                                   "peak": BF16_MFMA_PEAK_TF if on_bf16 else FP32_MFMA_PEAK_TF,
                                    "unit": "TFLOP/s", "frac": round(mfma_frac, 4), "traffic": None,
                                    "kernel": top["kernel"]}
             else:
@@ -365,7 +382,9 @@ def main():
             res["profiled_ms_per_step"] = round(tot / prof_steps, 3)
             # what the step would take if every profiled launch ran at its own roof (HBM 8 TB/s or fp32-MFMA peak,
             # whichever is slower for that launch): the distance to "speed of light" of the whole launch list
-            sol = sum(r["launches"] * max(r["bytes"] / (HBM_PEAK_GBS * 1e6), r["flops"] / (FP32_MFMA_PEAK_TF * 1e9)) for r in rows)
+            sol = sum(r["launches"] * max(r["bytes"] / (HBM_PEAK_GBS * 1e6),
+                                          r["prod"] * r["flops"] / (BF16_MFMA_PEAK_TF * 1e9) if r["prod"] else r["flops"] / (FP32_MFMA_PEAK_TF * 1e9))
+                      for r in rows)
             res["profiled_roofline_ms_per_step"] = round(sol / prof_steps, 3)
             res["profiled_gbytes_per_step"] = round(sum(r["launches"] * r["bytes"] for r in rows) / prof_steps / 1e9, 2)
             if eager_ms is not None:

