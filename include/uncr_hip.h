@@ -21,7 +21,8 @@
  *     slot count of each producer for a given size;
  *   - a normalisation layer is never run on its own: producers emit partial (sum, sum^2), a finalize call
  *     turns them into per-(frame,channel) coefficients A,B, and the CONSUMER applies u = A*h + B in its
- *     prologue.  Backward likewise: dh = C1*du + C2*h + C3.
+ *     prologue.  Backward likewise: dh = C1*du + C2*(h - mu) + C3 (four numbers per plane; a null `kmu` means mu = 0, the
+ *     raw form).
  */
 #ifndef UNCR_HIP_H
 #define UNCR_HIP_H
@@ -39,7 +40,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define UNCR_PRO_NONE 0
 #define UNCR_PRO_AFFINE 1        /* A*v + B                              */
 #define UNCR_PRO_AFFINE_GELU 2   /* S * gelu(A*v + B)                    */
-#define UNCR_PRO_NORMBWD 3       /* C1*v + C2*v2 + C3  (two operands)    */
+#define UNCR_PRO_NORMBWD 3       /* C1*v + C2*(v2 - mu) + C3  (two operands; mu = the kmu array, 0 if null) */
 #define UNCR_PRO_AFFINE_RELU 4
 /* normalisation kinds */
 #define UNCR_NORM_GROUP 0
@@ -73,7 +74,11 @@ int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, int groups, 
                            float* save_rstd, hipStream_t stream);
 int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                            const float* gamma, const float* save_mean, const float* save_rstd, float* c1,
-                           float* c2, float* c3, float* dgamma, float* dbeta, float* scratch /* [2*N*C], GroupNorm */,
+                           float* c2, float* c3,
+                           float* cmu /* [N*C] or null.  Given: CENTRED coefficients, dh = C1*du + C2*(h - cmu) + C3 (cmu = the
+                                         norm's mean per plane): no per-plane rounding offset; consumers take cmu as their
+                                         `kmu` argument.  Null: the raw form dh = C1*du + C2*h + C3 */,
+                           float* dgamma, float* dbeta, float* scratch /* [2*N*C], GroupNorm */,
                            int centered /* 1: part.y = sum du*(h - mean) (uncr_dw_bwd with a mean array) */,
                            hipStream_t stream);
 /* Synchronised BatchNorm for data parallelism (train mode): per-channel fp64 sums of the local partials -> the host
@@ -85,7 +90,7 @@ int uncr_bn_finalize_fwd_sums(const double* sums, double count, int N, int C, co
                               float* coefB, float* save_mean, float* save_rstd, hipStream_t stream);
 int uncr_bn_finalize_bwd_sums(const double* sums_local, const double* sums_global, double count, int N, int C,
                               const float* gamma, const float* save_mean, const float* save_rstd, float* c1, float* c2,
-                              float* c3, float* dgamma, float* dbeta, int centered, hipStream_t stream);
+                              float* c3, float* cmu, float* dgamma, float* dbeta, int centered, hipStream_t stream);
 
 /* ---- element-wise family with fused coefficients + partial statistics
  *      (norm-apply/ReLU utae.py:470-494; residual add uncrtaints.py:142-146; SE avg-pool uncrtaints.py:85,95;
@@ -119,7 +124,8 @@ int uncr_pack_wt_batch(const long long* desc, int n_items, int max_threads, hipS
  * the prologue's fp32 result is rounded once to bf16 and multiplied with the two leading weight parts (16 significant bits):
  * two products per MAC instead of six.  Cout <= 64 (fp32 MFMA kernels): fp32 outputs, fp32 or bf16 inputs. */
 int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, void* out, const float* k0,
-                 const float* k1, const float* k2, const float* bias, int bias_stride_n, const void* aux,
+                 const float* k1, const float* k2, const float* kmu /* PRO_NORMBWD: mean array or null */,
+                 const float* bias, int bias_stride_n, const void* aux,
                  const float* e0, const float* e1, const float* e2, const float* e3 /* epi 3 coefficients */,
                  float* part, int N, int Cin, int Cout, int P, int pro, int epi, int in_dt, int out_dt,
                  hipStream_t stream);
@@ -139,21 +145,24 @@ int uncr_head_fwd(const void* y, const float* Wt, const float* bias, float* out,
  * statistics of the masked output for that norm's backward. */
 int uncr_pw_gemm_dx_supported(int Cin, int Cout);
 int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt, void* out, const float* k0, const float* k1,
-                    const float* k2, const void* dy, const void* x, const void* xh3, const float* c1,
-                    const float* c2, const float* c3, const float* relu_a, const float* relu_b, float* part, int N,
-                    int Cin, int Cout, int P, int act, hipStream_t stream);
+                    const float* k2, const float* kmu, const void* dy, const void* x, const void* xh3, const float* c1,
+                    const float* c2, const float* c3, const float* cmu /* out = dy + c1*da + c2*(x - cmu) + c3 */,
+                    const float* relu_a, const float* relu_b, float* part, int N, int Cin, int Cout, int P, int act,
+                    hipStream_t stream);
 /* R [N][Ch][C] = per-frame products sum_p du1n*x (uncr_pw_wgrad with the raw x); part_b / part_f = the (sum du1, .) and
  * (sum h1, .) partials [N*Ch][NPB|NPF][2] (part_f may be null: no c2 term); c1..c3 [N*Ch] = norm-1 backward
  * coefficients; A0, B0 [N*C] = PreNorm forward coefficients.  -> part0 [N*C][1][2] = (sum da, sum da*x), dW1 [Ch][C]. */
 int uncr_prenorm_bwd_finish(const float* R, const float* W1, const float* part_b, int NPB, const float* part_f,
-                            int NPF, const float* c1, const float* c2, const float* c3, const float* A0,
+                            int NPF, const float* c1, const float* c2, const float* c3,
+                            const float* cmu /* null: raw form; else part_f is required */, const float* A0,
                             const float* B0, float* part0, float* dW1, float* scratch /* 2*N*Ch floats */, int N,
                             int Ch /* % 8 == 0 */, int C /* % 32 == 0 */, int P, hipStream_t stream);
 int uncr_wgrad_shape(int Cd, int Cx, int* cop, int* cip);
 /* act: storage of d, d2, x.  bf16: the two wide shapes (256 x 128, 128 x 256) run one bf16 x bf16 product per MAC with fp32
  * accumulation (P % 64 == 0), the narrow shapes of the path (in_conv 128 x 15, head 26 x 128) the fp32 MFMA kernels. */
 int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const void* x2, const float* dk0,
-                  const float* dk1, const float* dk2, const float* xk0, const float* xk1, const float* xk2,
+                  const float* dk1, const float* dk2, const float* dkmu /* PRO_NORMBWD on d: mean array or null */,
+                  const float* xk0, const float* xk1, const float* xk2,
                   float* part /* [N*NBX][COP][CIP] */, float* rs_part, int N, int Cd, int Cx, int P,
                   int NBX /* blocks (partials) per frame, from uncr_wgrad_nbx */, int pro_d, int pro_x, int act,
                   hipStream_t stream);
@@ -168,7 +177,8 @@ int uncr_dw_slots_bwd(int H);
 int uncr_dw_fwd(const void* in, const float* cA, const float* cB, const float* w, void* out, float* part,
                 int N, int C, int H, int W, int act, hipStream_t stream);
 int uncr_dw_bwd(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
-                const float* k3, const float* cA1, const float* cB1, const float* w, void* du1, float* part,
+                const float* k3, const float* kmu /* dh2 = k1*du2 + k2*(h2 - kmu) + k3; null: kmu = 0 */,
+                const float* cA1, const float* cB1, const float* w, void* du1, float* part,
                 float* dw_part, const float* mean1 /* null: part.y = sum du1*h1; else sum du1*(h1 - mean), the
                 well-conditioned form for uncr_norm_finalize_bwd(centered = 1) */,
                 int mean_groups /* 0: mean1[c] (BatchNorm); G > 0: mean1[n*G + c/(C/G)] (GroupNorm) */,
@@ -233,7 +243,7 @@ int uncr_aggregate_bwd(const void* dg, const void* e, const float* att, const in
 int uncr_conv3_plane_stride(int H, int W);
 int uncr_conv3_margin(int W);
 int uncr_pad2d(const float* src, const float* src2, float* dst, const float* k0, const float* k1, const float* k2,
-               int pro, int mode /* 0 reflect, 1 zero */, int planes, int H, int W, hipStream_t stream);
+               const float* kmu, int pro, int mode /* 0 reflect, 1 zero */, int planes, int H, int W, hipStream_t stream);
 int uncr_unpad2d(const float* src, float* dst, float* part /* [planes][H*W/1024][2] or null */, int planes, int H,
                  int W, hipStream_t stream);
 int uncr_unpad2d_reflect_adjoint(const float* src, float* dst, int planes, int H, int W, hipStream_t stream);

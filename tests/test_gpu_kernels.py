@@ -165,7 +165,7 @@ def _depthwise_fwd_bwd(E, orc, H, W):
     sb = hb.query("uncr_dw_slots_bwd", H)
     partb = torch.empty(N * C, sb, 2, device=DEV)
     dwp = torch.empty(N * C, sb, 9, device=DEV)
-    hb.call("uncr_dw_bwd", dev(du2), h2d, dev(h1.detach()), dev(c1), dev(c2), dev(c3), dev(A), dev(B),
+    hb.call("uncr_dw_bwd", dev(du2), h2d, dev(h1.detach()), dev(c1), dev(c2), dev(c3), None, dev(A), dev(B),
             dev(w.detach().reshape(C, 9)), du1, partb, dwp, None, 0, N, C, H, W, 0, E._stream())
     close(f"dw_bwd_du1[{H}x{W}]", du1, du1_ref)
     close("dw_bwd_stats0", partb.sum(1)[:, 0], du1_ref.sum(dim=(2, 3)).reshape(-1))
@@ -176,7 +176,7 @@ def _depthwise_fwd_bwd(E, orc, H, W):
     # centred second statistic: sum du1*(h1 - mean) with a per-channel (BatchNorm) and a per-(frame, group) mean
     for groups in (0, 4):
         mean = rand(C if groups == 0 else N * groups, seed=9, scale=2.0)
-        hb.call("uncr_dw_bwd", dev(du2), h2d, dev(h1.detach()), dev(c1), dev(c2), dev(c3), dev(A), dev(B),
+        hb.call("uncr_dw_bwd", dev(du2), h2d, dev(h1.detach()), dev(c1), dev(c2), dev(c3), None, dev(A), dev(B),
                 dev(w.detach().reshape(C, 9)), du1, partb, dwp, dev(mean), groups, N, C, H, W, 0, E._stream())
         mfull = mean.view(1, C, 1, 1) if groups == 0 else mean.view(N, groups, 1, 1, 1).expand(N, groups, C // groups, 1, 1).reshape(N, C, 1, 1)
         close(f"dw_bwd_stats1_centered[g{groups}]", partb.sum(1)[:, 1],
@@ -624,7 +624,7 @@ def test_conv3x3_fwd_bwd_linear_parts(E, N, C, H, W):
     # HIP
     xd, wd, bd = dev(x), dev(w), dev(b)
     xp = E._Padded(N, C, H, W, xd.device)
-    hb.call("uncr_pad2d", xd, None, xp.view(), None, None, None, E.PRO_NONE, 0, N * C, H, W, E._stream())
+    hb.call("uncr_pad2d", xd, None, xp.view(), None, None, None, None, E.PRO_NONE, 0, N * C, H, W, E._stream())
     c, part = E.conv3x3_forward(xp, wd, bd, True)
     close(f"conv3x3_fwd[{N},{C},{H}x{W}]", c, co.detach().float())
     s = part.buf.double().sum(1).cpu()

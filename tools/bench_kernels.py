@@ -53,7 +53,7 @@ def main():
             partf, partb, dwp = torch.empty(Nf * C, sf, 2, device=dev), torch.empty(Nf * C, sb, 2, device=dev), torch.empty(Nf * C, sb, 9, device=dev)
             ms = timeit(lambda: hb.call("uncr_dw_fwd", h1, cA, cB, w, out, partf, Nf, C, H, W, 0, E._stream()), iters)
             print(f"dw_fwd N={Nf}: {ms*1e3:.1f} us  {8.0*Nf*C*H*W/ms/1e6:.0f} GB/s")
-            ms = timeit(lambda: hb.call("uncr_dw_bwd", du2, h2, h1, k1, k2, k3, cA, cB, w, out, partb, dwp, None, 0, Nf, C, H, W, 0, E._stream()), iters)
+            ms = timeit(lambda: hb.call("uncr_dw_bwd", du2, h2, h1, k1, k2, k3, None, cA, cB, w, out, partb, dwp, None, 0, Nf, C, H, W, 0, E._stream()), iters)
             print(f"dw_bwd N={Nf}: {ms*1e3:.1f} us  {16.0*Nf*C*H*W/ms/1e6:.0f} GB/s")
     elif what == "agg":
         # the L-TAE stage's full-resolution kernels at the bench shape
@@ -121,7 +121,7 @@ def main():
         slots = hb.query("uncr_pw_stat_slots", N, 128, P)
         part = torch.empty(N * 128, slots, 2, device=dev)
         for _ in range(3):
-            hb.call("uncr_pw_gemm_dx", d, d2, W1k, dx, dk[0], dk[1], dk[2], dy, xx, xh3, c[0], c[1], c[2], None, None, part,
+            hb.call("uncr_pw_gemm_dx", d, d2, W1k, dx, dk[0], dk[1], dk[2], None, dy, xx, xh3, c[0], c[1], c[2], None, None, None, part,
                     N, 256, 128, P, 0, E._stream())
         # the depthwise kernels
         C, H, W = 256, 256, 256
@@ -133,7 +133,7 @@ def main():
         partf, partb, dwp = torch.empty(N * C, sf, 2, device=dev), torch.empty(N * C, sb, 2, device=dev), torch.empty(N * C, sb, 9, device=dev)
         for _ in range(3):
             hb.call("uncr_dw_fwd", h1, cA, cB, w9, out, partf, N, C, H, W, 0, E._stream())
-            hb.call("uncr_dw_bwd", du2, hh2, h1, k1, k2, k3, cA, cB, w9, out, partb, dwp, None, 0, N, C, H, W, 0, E._stream())
+            hb.call("uncr_dw_bwd", du2, hh2, h1, k1, k2, k3, None, cA, cB, w9, out, partb, dwp, None, 0, N, C, H, W, 0, E._stream())
         torch.cuda.synchronize()
         print("done")
     elif what == "ablate":
@@ -142,7 +142,7 @@ def main():
         Wt = E.pack_wt(W, transpose=True); out = torch.empty(N, Cout, P, device=dev)
         from uncrtaints_amd import hip_backend as hb
         for flags, name in [(0, "full")]:
-            fn = lambda: hb.call("uncr_pw_gemm", x, None, Wt, out, None, None, None, None, 0, None, None, None, None, None, None, N, Cin, Cout, P, 0, flags, 0, 0, E._stream())
+            fn = lambda: hb.call("uncr_pw_gemm", x, None, Wt, out, None, None, None, None, None, 0, None, None, None, None, None, None, N, Cin, Cout, P, 0, flags, 0, 0, E._stream())
             ms = timeit(fn, iters)
             print(f"{name:28s}: {ms*1e3:.1f} us  {2.0*N*P*Cin*Cout/ms/1e9:.1f} TF")
     elif what == "mfma":

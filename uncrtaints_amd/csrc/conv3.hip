@@ -12,7 +12,7 @@
 __global__ __launch_bounds__(256) void pad2d_kernel(const float* __restrict__ src, const float* __restrict__ src2,
                                                     float* __restrict__ dst, const float* __restrict__ k0,
                                                     const float* __restrict__ k1, const float* __restrict__ k2,
-                                                    int pro, int mode, int H, int W, int Sp) {
+                                                    const float* __restrict__ kmu, int pro, int mode, int H, int W, int Sp) {
     const int plane = blockIdx.y;
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= Sp) return;
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void pad2d_kernel(const float* __restrict__ sr
             const size_t o = (size_t)plane * H * W + (size_t)y * W + x;
             v = src[o];
             if (pro == PRO_AFFINE_RELU) v = fmaxf(fmaf(k0[plane], v, k1[plane]), 0.f);
-            else if (pro == PRO_NORMBWD) v = fmaf(k0[plane], v, fmaf(k1[plane], src2[o], k2[plane]));
+            else if (pro == PRO_NORMBWD) v = fmaf(k0[plane], v, fmaf(k1[plane], src2[o] - (kmu ? kmu[plane] : 0.f), k2[plane]));
             else if (pro == PRO_AFFINE) v = fmaf(k0[plane], v, k1[plane]);
         }
     }
@@ -89,13 +89,13 @@ extern "C" int uncr_conv3_plane_stride(int H, int W) {          // S_p: padded p
 extern "C" int uncr_conv3_margin(int W) { return W + 3; }       // slack (floats) the caller keeps before and after the tensor
 
 extern "C" int uncr_pad2d(const float* src, const float* src2, float* dst, const float* k0, const float* k1,
-                          const float* k2, int pro, int mode, int planes, int H, int W, hipStream_t stream) {
+                          const float* k2, const float* kmu, int pro, int mode, int planes, int H, int W, hipStream_t stream) {
     const int Sp = uncr_conv3_plane_stride(H, W);
     if (planes <= 0 || Sp <= 0 || mode < 0 || mode > 1) return UNCR_ESHAPE;
     if (!src || !dst || (pro == PRO_NORMBWD && (!src2 || !k0 || !k1 || !k2)) ||
         ((pro == PRO_AFFINE_RELU || pro == PRO_AFFINE) && (!k0 || !k1)))
         return UNCR_EINVAL;
-    hipLaunchKernelGGL(pad2d_kernel, dim3(Sp / 256, planes), dim3(256), 0, stream, src, src2, dst, k0, k1, k2, pro,
+    hipLaunchKernelGGL(pad2d_kernel, dim3(Sp / 256, planes), dim3(256), 0, stream, src, src2, dst, k0, k1, k2, kmu, pro,
                        mode, H, W, Sp);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;

@@ -82,8 +82,8 @@ template <int NRMAX, typename T>   // row passes per thread: ceil((TR + 2) / (25
 __global__ __launch_bounds__(256) void dw_bwd_kernel(
     const T* __restrict__ du2, const T* __restrict__ h2, const T* __restrict__ h1,
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
-    const float* __restrict__ cA1, const float* __restrict__ cB1, const float* __restrict__ w,
-    T* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
+    const float* __restrict__ kmu, const float* __restrict__ cA1, const float* __restrict__ cB1,
+    const float* __restrict__ w, T* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
     const float* __restrict__ mean1, int mean_groups, int C, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int TR = DW_TR_BWD;
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
     float* Dt = sm;                          // zero-padded dh2 tile   (image col x at offset 4 + x)
     float* Gt = sm + (TR + 2) * pitch;       // reflect-padded g1 tile
     const float C1 = k1[plane], C2 = k2[plane], C3 = k3[plane];
+    const float M2 = kmu ? kmu[plane] : 0.f;       // centred norm-2 backward: dh2 = C1*du2 + C2*(h2 - M2) + C3
     const float A1 = cA1[plane], B1 = cB1[plane];
     // second statistic sum du1*(h1 - M1): with M1 = the norm's mean it is free of the |mean|/std cancellation
     const float M1 = mean1 ? mean1[mean_groups > 0 ? (plane / C) * mean_groups + c / (C / mean_groups) : c] : 0.f;
@@ -123,10 +124,10 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(
         if (active && r < rows) {                 // LDS writes only: no memory loads under this branch
             const float m = (y >= 0 && y < H) ? 1.f : 0.f;
             float4 d;
-            d.x = m * fmaf(C1, ra[i].x, fmaf(C2, rb[i].x, C3));
-            d.y = m * fmaf(C1, ra[i].y, fmaf(C2, rb[i].y, C3));
-            d.z = m * fmaf(C1, ra[i].z, fmaf(C2, rb[i].z, C3));
-            d.w = m * fmaf(C1, ra[i].w, fmaf(C2, rb[i].w, C3));
+            d.x = m * fmaf(C1, ra[i].x, fmaf(C2, rb[i].x - M2, C3));
+            d.y = m * fmaf(C1, ra[i].y, fmaf(C2, rb[i].y - M2, C3));
+            d.z = m * fmaf(C1, ra[i].z, fmaf(C2, rb[i].z - M2, C3));
+            d.w = m * fmaf(C1, ra[i].w, fmaf(C2, rb[i].w - M2, C3));
             *(float4*)(Dt + r * pitch + 4 + 4 * c4) = d;
             if (c4 == 0) Dt[r * pitch + 3] = 0.f;
             if (c4 == W4 - 1) Dt[r * pitch + 4 + W] = 0.f;
@@ -282,7 +283,7 @@ extern "C" int uncr_dw_slots_bwd(int H) { return (H + DW_TR_BWD - 1) / DW_TR_BWD
 int dw_fwd_row_launch(const void* in, const float* cA, const float* cB, const float* w, void* out, float* part, int N,
                       int C, int H, int slots, int act, hipStream_t stream);
 int dw_bwd_row_launch(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
-                      const float* k3, const float* cA1, const float* cB1, const float* w, void* du1, float* part,
+                      const float* k3, const float* kmu, const float* cA1, const float* cB1, const float* w, void* du1, float* part,
                       float* dw_part, const float* mean1, int mean_groups, int N, int C, int H, int slots, int act,
                       hipStream_t stream);
 static int g_dw_row = 1;   // A/B switch (tests exercise both implementations)
@@ -316,7 +317,7 @@ extern "C" int uncr_dw_fwd(const void* in, const float* cA, const float* cB, con
 
 template <typename T>
 static int dw_bwd_tiled(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2, const float* k3,
-                        const float* cA1, const float* cB1, const float* w, void* du1, float* part, float* dw_part,
+                        const float* kmu, const float* cA1, const float* cB1, const float* w, void* du1, float* part, float* dw_part,
                         const float* mean1, int mean_groups, int N, int C, int H, int W, size_t lds, hipStream_t stream) {
     auto kern = W <= 256 ? dw_bwd_kernel<5, T> : (W <= 512 ? dw_bwd_kernel<9, T> : dw_bwd_kernel<18, T>);
     static size_t lds_attr[3] = {0, 0, 0};
@@ -327,26 +328,26 @@ static int dw_bwd_tiled(const void* du2, const void* h2, const void* h1, const f
         lds_attr[ki] = lds;
     }
     hipLaunchKernelGGL(kern, dim3(uncr_dw_slots_bwd(H), N * C), dim3(256), lds, stream, (const T*)du2, (const T*)h2,
-                       (const T*)h1, k1, k2, k3, cA1, cB1, w, (T*)du1, (float2*)part, dw_part, mean1, mean_groups, C, H, W);
+                       (const T*)h1, k1, k2, k3, kmu, cA1, cB1, w, (T*)du1, (float2*)part, dw_part, mean1, mean_groups, C, H, W);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
 
 extern "C" int uncr_dw_bwd(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
-                           const float* k3, const float* cA1, const float* cB1, const float* w, void* du1,
+                           const float* k3, const float* kmu, const float* cA1, const float* cB1, const float* w, void* du1,
                            float* part, float* dw_part, const float* mean1, int mean_groups, int N, int C, int H,
                            int W, int act, hipStream_t stream) {
     if (mean1 && mean_groups > 0 && C % mean_groups) return UNCR_ESHAPE;
     if (N <= 0 || C <= 0 || H < 4 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
     if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
     if (g_dw_row && W == 256 && (H & 3) == 0)
-        return dw_bwd_row_launch(du2, h2, h1, k1, k2, k3, cA1, cB1, w, du1, part, dw_part, mean1, mean_groups, N, C, H,
+        return dw_bwd_row_launch(du2, h2, h1, k1, k2, k3, kmu, cA1, cB1, w, du1, part, dw_part, mean1, mean_groups, N, C, H,
                                  uncr_dw_slots_bwd(H), act, stream);
     const size_t lds = (size_t)2 * (DW_TR_BWD + 2) * (W + 8) * sizeof(float);
     if (lds > 150 * 1024) return UNCR_ESHAPE;
     if (act == UNCR_BF16)
-        return dw_bwd_tiled<bf16_t>(du2, h2, h1, k1, k2, k3, cA1, cB1, w, du1, part, dw_part, mean1, mean_groups, N, C, H, W, lds, stream);
-    return dw_bwd_tiled<float>(du2, h2, h1, k1, k2, k3, cA1, cB1, w, du1, part, dw_part, mean1, mean_groups, N, C, H, W, lds, stream);
+        return dw_bwd_tiled<bf16_t>(du2, h2, h1, k1, k2, k3, kmu, cA1, cB1, w, du1, part, dw_part, mean1, mean_groups, N, C, H, W, lds, stream);
+    return dw_bwd_tiled<float>(du2, h2, h1, k1, k2, k3, kmu, cA1, cB1, w, du1, part, dw_part, mean1, mean_groups, N, C, H, W, lds, stream);
 }
 
 extern "C" int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw, hipStream_t stream) {

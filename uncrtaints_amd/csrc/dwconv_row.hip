@@ -127,8 +127,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     const T* __restrict__ du2, const T* __restrict__ h2, const T* __restrict__ h1,
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
-    const float* __restrict__ cA1, const float* __restrict__ cB1, const float* __restrict__ w,
-    T* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
+    const float* __restrict__ kmu, const float* __restrict__ cA1, const float* __restrict__ cB1,
+    const float* __restrict__ w, T* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
     const float* __restrict__ mean1, int mean_groups, int C, int H, int planes, int slots, int tiles) {
     constexpr int W = 256;
     const int lane = threadIdx.x & 63;
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     // the plane's `slots` 16-row units are dealt to `tiles` waves as evenly as possible
     const int y0 = min(H, ((slots * tile) / tiles) << 4), y1 = min(H, ((slots * (tile + 1)) / tiles) << 4);
     const float C1 = k1[plane], C2 = k2[plane], C3 = k3[plane];
+    const float M2 = kmu ? kmu[plane] : 0.f;       // centred norm-2 backward: dh2 = C1*du2 + C2*(h2 - M2) + C3
     const float A1 = cA1[plane], B1 = cB1[plane];
     // second statistic sum du1*(h1 - M1): with M1 = the norm's mean it is free of the |mean|/std cancellation
     const float M1 = mean1 ? mean1[mean_groups > 0 ? (plane / C) * mean_groups + c / (C / mean_groups) : c] : 0.f;
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     };
     auto dh2 = [&](const Raw& r, int yy) {   // zero outside the image
         const float m = (yy >= 0 && yy < H) ? 1.f : 0.f;
-        return make_float4(m * fmaf(C1, r.a.x, fmaf(C2, r.b.x, C3)), m * fmaf(C1, r.a.y, fmaf(C2, r.b.y, C3)),
-                           m * fmaf(C1, r.a.z, fmaf(C2, r.b.z, C3)), m * fmaf(C1, r.a.w, fmaf(C2, r.b.w, C3)));
+        return make_float4(m * fmaf(C1, r.a.x, fmaf(C2, r.b.x - M2, C3)), m * fmaf(C1, r.a.y, fmaf(C2, r.b.y - M2, C3)),
+                           m * fmaf(C1, r.a.z, fmaf(C2, r.b.z - M2, C3)), m * fmaf(C1, r.a.w, fmaf(C2, r.b.w - M2, C3)));
     };
 
     auto both4 = [&](const float4& h, float4& gv, float4& gd) {
@@ -284,7 +285,7 @@ int dw_fwd_row_launch(const void* in, const float* cA, const float* cB, const fl
 }
 
 int dw_bwd_row_launch(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
-                      const float* k3, const float* cA1, const float* cB1, const float* w, void* du1, float* part,
+                      const float* k3, const float* kmu, const float* cA1, const float* cB1, const float* w, void* du1, float* part,
                       float* dw_part, const float* mean1, int mean_groups, int N, int C, int H, int slots, int act,
                       hipStream_t stream) {
     const int planes = N * C;
@@ -294,7 +295,7 @@ int dw_bwd_row_launch(const void* du2, const void* h2, const void* h1, const flo
     if (const char* ov = getenv("UNCR_DW_TILES"))
         if (atoi(ov) > 0 && atoi(ov) <= slots) tiles = atoi(ov);
     UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(dw_bwd_row_kernel<T>, dim3((planes * tiles + 3) / 4), dim3(256), 0, stream,
-                                                 (const T*)du2, (const T*)h2, (const T*)h1, k1, k2, k3, cA1, cB1, w, (T*)du1,
+                                                 (const T*)du2, (const T*)h2, (const T*)h1, k1, k2, k3, kmu, cA1, cB1, w, (T*)du1,
                                                  (float2*)part, dw_part, mean1, mean_groups, C, H, planes, slots, tiles));
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;

@@ -13,7 +13,7 @@ enum : int {
     EW_AFFINE_RELU = 2,  // out = relu(A*a + B);              stats (sum out, sum out^2)
     EW_RESIDUAL = 3,     // out = a + A*b + B;                stats (sum out, sum out^2)   a=x, b=h3
     EW_PASSB = 4,        // out = gelu'(A*b + B) * (S*a + D); stats (sum out, sum out*b)   a=dz, b=h2
-    EW_PASSE = 5,        // out = a + C1*b + C2*c + C3;       stats (sum out, sum out*aux) a=dy, b=da, c=x
+    EW_PASSE = 5,        // out = a + C1*b + C2*(c - M) + C3; stats (sum out, sum out*aux) a=dy, b=da, c=x (M = k3 or 0)
     EW_RELU_BWD = 6,     // out = a * [A*b + B > 0];          stats (sum out, sum out*b)   a=d(a0), b=c0
     EW_SE_POOL = 7,      // stats only: (sum gelu(A*a + B), 0)
     EW_HEAD_FWD = 8,     // out = c < n_mean ? scale*sigmoid(a) : softplus(a)+eps   (per-plane channel test)
@@ -99,12 +99,13 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         for (int i = 0; i < 4; ++i) { s0 += o[i]; s1 += o[i] * pb[i]; }
     } else if constexpr (OP == EW_PASSE) {
         const float C1 = g.k0[plane], C2 = g.k1[plane], C3 = g.k2[plane];
+        const float M = g.k3 ? g.k3[plane] : 0.f;      // centred norm backward
         const float4 vb = ld_nt4t((const T*)g.b + off);
         const float4 vc = ld_nt4t((const T*)g.c + off);
         const float* pb = (const float*)&vb;
         const float* pc = (const float*)&vc;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = pa[i] + fmaf(C1, pb[i], fmaf(C2, pc[i], C3));
+        for (int i = 0; i < 4; ++i) o[i] = pa[i] + fmaf(C1, pb[i], fmaf(C2, pc[i] - M, C3));
         vo = rnd4<T>(vo);
         if (g.part) {
             const float4 vx = ld_nt4t((const T*)g.aux + off);

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(
 __global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(
     const float2* __restrict__ part, int NP, int N, int C, int G, int P, const float* __restrict__ gamma,
     const float* __restrict__ save_mean, const float* __restrict__ save_rstd, float* __restrict__ c1,
-    float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ scratch, int centered) {
+    float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ cmu, float* __restrict__ scratch, int centered) {
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int Cg = C / G;   // <= 256
     __shared__ double s1[256], s2[256];
@@ -159,7 +159,11 @@ __global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(
         const double gm = (double)gamma[ch];
         c1[n * C + ch] = (float)(r * gm);
         c2[n * C + ch] = (float)(-r * r * sm2);
-        c3[n * C + ch] = (float)(r * (-sm1 + r * mu * sm2));
+        // cmu given: the centred form dh = C1*du + C2*(h - mu) + C3 with C3 = -r*m1.  The raw form's constant
+        // r*(-m1 + r*mu*m2) is rounded to fp32 with an error ~ eps*|C2*mu|: a per-plane offset of dh that adds up coherently
+        // in every sum over the plane (bias-type gradients downstream lose |mu|/std * sqrt(P) digits).
+        if (cmu) { c3[n * C + ch] = (float)(-r * sm1); cmu[n * C + ch] = (float)mu; }
+        else c3[n * C + ch] = (float)(r * (-sm1 + r * mu * sm2));
         scratch[(size_t)n * C + ch] = (float)(r * (s2[c] - mus * s1[c]));
         scratch[(size_t)N * C + (size_t)n * C + ch] = (float)s1[c];
     }
@@ -181,11 +185,11 @@ __global__ __launch_bounds__(256) void gn_dgb_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(
     const float2* __restrict__ part, int NP, int N, int C, int P, int train, const float* __restrict__ gamma,
     const float* __restrict__ save_mean, const float* __restrict__ save_rstd, float* __restrict__ c1,
-    float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    int centered) {
+    float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ cmu, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int centered) {
     const int c = blockIdx.x;
     __shared__ double red[8];
-    __shared__ float k1, k2, k3;
+    __shared__ float k1, k2, k3, kmu;
     double a = 0.0, b = 0.0;
     const int cnt = N * NP;
     for (int i = threadIdx.x; i < cnt; i += 256) {
@@ -211,17 +215,19 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(
             const double M = (double)N * (double)P;
             const double m1 = gm * S1 / M, m2 = gm * dg / M;
             k2 = (float)(-r * r * m2);
-            k3 = (float)(r * (-m1 + r * mu * m2));
+            k3 = cmu ? (float)(-r * m1) : (float)(r * (-m1 + r * mu * m2));      // centred / raw form (see the GroupNorm kernel)
         } else {
             k2 = 0.f;
             k3 = 0.f;
         }
+        kmu = (float)mu;
     }
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += 256) {
         c1[n * C + c] = k1;
         c2[n * C + c] = k2;
         c3[n * C + c] = k3;
+        if (cmu) cmu[n * C + c] = kmu;
     }
 }
 
@@ -239,8 +245,8 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(
 __global__ __launch_bounds__(256) void prenorm_bwd_S_kernel(const float2* __restrict__ part_b, int NPB,
                                                             const float2* __restrict__ part_f, int NPF,
                                                             const float* __restrict__ c1, const float* __restrict__ c2,
-                                                            const float* __restrict__ c3, int planes, int P,
-                                                            double* __restrict__ S) {
+                                                            const float* __restrict__ c3, const float* __restrict__ cmu,
+                                                            int planes, int P, double* __restrict__ S) {
     const int lane = threadIdx.x & 63;
     const int pl = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pl >= planes) return;
@@ -250,7 +256,9 @@ __global__ __launch_bounds__(256) void prenorm_bwd_S_kernel(const float2* __rest
         for (int j = lane; j < NPF; j += 64) sf += (double)part_f[(size_t)pl * NPF + j].x;
     sb = wave_sum_d(sb);
     sf = wave_sum_d(sf);
-    if (lane == 0) S[pl] = (double)c1[pl] * sb + (double)c2[pl] * sf + (double)c3[pl] * (double)P;
+    // cmu: centred coefficients, du1n = c1*du1 + c2*(h1 - mu) + c3
+    if (lane == 0)
+        S[pl] = (double)c1[pl] * sb + (double)c2[pl] * (sf - (cmu ? (double)cmu[pl] * (double)P : 0.0)) + (double)c3[pl] * (double)P;
 }
 
 __global__ __launch_bounds__(256) void prenorm_bwd_finish_kernel(
@@ -297,13 +305,14 @@ __global__ __launch_bounds__(256) void prenorm_bwd_finish_kernel(
 // scratch: 2*N*Ch floats (holds S in fp64)
 extern "C" int uncr_prenorm_bwd_finish(const float* R, const float* W1, const float* part_b, int NPB,
                                        const float* part_f, int NPF, const float* c1, const float* c2,
-                                       const float* c3, const float* A0, const float* B0, float* part0, float* dW1,
-                                       float* scratch, int N, int Ch, int C, int P, hipStream_t stream) {
+                                       const float* c3, const float* cmu, const float* A0, const float* B0, float* part0,
+                                       float* dW1, float* scratch, int N, int Ch, int C, int P, hipStream_t stream) {
     if (N <= 0 || Ch <= 0 || (Ch & 7) || C <= 0 || (C & 31) || P <= 0) return UNCR_ESHAPE;
     if (!R || !W1 || !part_b || NPB <= 0 || !c1 || !c2 || !c3 || !A0 || !B0 || !part0 || !dW1 || !scratch) return UNCR_EINVAL;
     if (part_f && NPF <= 0) return UNCR_EINVAL;
+    if (cmu && !part_f) return UNCR_EINVAL;      // the centred form needs sum h1
     hipLaunchKernelGGL(prenorm_bwd_S_kernel, dim3((N * Ch + 3) / 4), dim3(256), 0, stream, (const float2*)part_b, NPB,
-                       (const float2*)part_f, NPF, c1, c2, c3, N * Ch, P, (double*)scratch);
+                       (const float2*)part_f, NPF, c1, c2, c3, cmu, N * Ch, P, (double*)scratch);
     UNCR_LAUNCH_CHECK();
     hipLaunchKernelGGL(prenorm_bwd_finish_kernel, dim3(N * (C / 32) + (Ch * C + 255) / 256), dim3(256), 0, stream, R, W1,
                        (const double*)scratch, A0, B0, (float2*)part0, dW1, N, Ch, C);
@@ -364,8 +373,8 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_sums_kernel(
 __global__ __launch_bounds__(256) void bn_finalize_bwd_sums_kernel(
     const double* __restrict__ loc, const double* __restrict__ glob, double M, int N, int C,
     const float* __restrict__ gamma, const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
-    float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, int centered) {
+    float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ cmu,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int centered) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const double mu = (double)save_mean[c], r = (double)save_rstd[c], gm = (double)gamma[c];
@@ -373,8 +382,12 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_sums_kernel(
     dbeta[c] = (float)loc[2 * c];
     const double S1 = glob[2 * c], dg = r * (centered ? glob[2 * c + 1] : glob[2 * c + 1] - mu * S1);
     const double m1 = gm * S1 / M, m2 = gm * dg / M;
-    const float k1 = (float)(r * gm), k2 = (float)(-r * r * m2), k3 = (float)(r * (-m1 + r * mu * m2));
-    for (int n = 0; n < N; ++n) { c1[n * C + c] = k1; c2[n * C + c] = k2; c3[n * C + c] = k3; }
+    const float k1 = (float)(r * gm), k2 = (float)(-r * r * m2);
+    const float k3 = cmu ? (float)(-r * m1) : (float)(r * (-m1 + r * mu * m2));      // centred / raw form
+    for (int n = 0; n < N; ++n) {
+        c1[n * C + c] = k1; c2[n * C + c] = k2; c3[n * C + c] = k3;
+        if (cmu) cmu[n * C + c] = (float)mu;
+    }
 }
 
 extern "C" int uncr_bn_channel_sums(const float* part, int NP, int N, int C, double* sums, hipStream_t stream) {
@@ -396,11 +409,11 @@ extern "C" int uncr_bn_finalize_fwd_sums(const double* sums, double count, int N
 }
 extern "C" int uncr_bn_finalize_bwd_sums(const double* sums_local, const double* sums_global, double count, int N,
                                          int C, const float* gamma, const float* save_mean, const float* save_rstd,
-                                         float* c1, float* c2, float* c3, float* dgamma, float* dbeta, int centered,
-                                         hipStream_t stream) {
+                                         float* c1, float* c2, float* c3, float* cmu, float* dgamma, float* dbeta,
+                                         int centered, hipStream_t stream) {
     if (!sums_local || !sums_global || count <= 0 || N <= 0 || C <= 0 || !gamma || !save_mean || !save_rstd) return UNCR_EINVAL;
     hipLaunchKernelGGL(bn_finalize_bwd_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums_local,
-                       sums_global, count, N, C, gamma, save_mean, save_rstd, c1, c2, c3, dgamma, dbeta, centered);
+                       sums_global, count, N, C, gamma, save_mean, save_rstd, c1, c2, c3, cmu, dgamma, dbeta, centered);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -430,19 +443,19 @@ extern "C" int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, i
 
 extern "C" int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                                       const float* gamma, const float* save_mean, const float* save_rstd, float* c1,
-                                      float* c2, float* c3, float* dgamma, float* dbeta, float* scratch,
+                                      float* c2, float* c3, float* cmu, float* dgamma, float* dbeta, float* scratch,
                                       int centered, hipStream_t stream) {
     if (N <= 0 || C <= 0 || P <= 0 || !part) return UNCR_ESHAPE;
     if (kind == NORM_GROUP) {
         if (groups <= 0 || C % groups || C / groups > 256 || !scratch) return UNCR_EINVAL;
         hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(N * groups), dim3(256), 0, stream, (const float2*)part, NP, N,
-                           C, groups, P, gamma, save_mean, save_rstd, c1, c2, c3, scratch, centered);
+                           C, groups, P, gamma, save_mean, save_rstd, c1, c2, c3, cmu, scratch, centered);
         UNCR_LAUNCH_CHECK();
         hipLaunchKernelGGL(gn_dgb_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, N, C, dgamma,
                            dbeta);
     } else if (kind == NORM_BATCH_TRAIN || kind == NORM_BATCH_EVAL) {
         hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(256), 0, stream, (const float2*)part, NP, N, C, P,
-                           kind == NORM_BATCH_TRAIN, gamma, save_mean, save_rstd, c1, c2, c3, dgamma, dbeta, centered);
+                           kind == NORM_BATCH_TRAIN, gamma, save_mean, save_rstd, c1, c2, c3, cmu, dgamma, dbeta, centered);
     } else {
         return UNCR_EINVAL;
     }

@@ -33,6 +33,8 @@ struct PwArgs {
     int head_nm = 0, head_var = 0;
     float head_scale = 1.f, head_eps = 0.f;
     float* head_pre = nullptr;   // optional second output: the pre-activation [N][Cout][P]
+    const float* k3 = nullptr;    // PRO_NORMBWD: the norm's mean per (n, ci) -- centred form C1*v + C2*(v2 - mean) + C3; null: 0
+    const float* emu = nullptr;   // epi 5 / 6: mean of the PreNorm per (n, co): out = dy + e0*v + e1*(x - emu) + e2; null: 0
 };
 
 // x = h + m + l exactly, each part a bf16 (kept in the upper half of a 32-bit word).  Truncation split: h takes
@@ -70,12 +72,12 @@ int pw_pack_batch(const long long* desc, int n_items, int max_threads, int split
 int pw_wgrad_split_nbx(int N, int P);
 bool pw_wgrad_split_supported(int Cd, int Cx, int pro_d, int pro_x, bool rowsum);
 int pw_wgrad_split_launch(const float* d, const float* d2, const float* x, const float* dk0, const float* dk1,
-                          const float* dk2, const float* xk0, const float* xk1, const float* xk2, float* part, int N,
-                          int Cd, int Cx, int P, int nbx, int pro_x, hipStream_t stream);
+                          const float* dk2, const float* dkmu, const float* xk0, const float* xk1, const float* xk2, float* part,
+                          int N, int Cd, int Cx, int P, int nbx, int pro_x, hipStream_t stream);
 
 // pw_wgrad_a16.hip: the same weight gradients from bf16 operands (one bf16 x bf16 product per MAC, fp32 accumulation)
 int pw_wgrad_a16_nbx(int N, int P);
 bool pw_wgrad_a16_supported(int Cd, int Cx, int pro_d, int pro_x, bool rowsum);
 int pw_wgrad_a16_launch(const void* d, const void* d2, const void* x, const float* dk0, const float* dk1, const float* dk2,
-                        const float* xk0, const float* xk1, const float* xk2, float* part, int N, int Cd, int Cx, int P,
-                        int nbx, int pro_x, hipStream_t stream);
+                        const float* dkmu, const float* xk0, const float* xk1, const float* xk2, float* part, int N, int Cd, int Cx,
+                        int P, int nbx, int pro_x, hipStream_t stream);

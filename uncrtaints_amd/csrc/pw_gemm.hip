@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
     constexpr int ROWS_PER_I = NT / (TP / 4);     // rows covered per load index
 
     __shared__ __attribute__((aligned(16))) float xs[2][KC][TP];   // double-buffered activation chunk
-    __shared__ float cf[3][256];
+    __shared__ float cf[4][256];      // [3]: the norm's mean (centred PRO_NORMBWD)
     __shared__ float red[WM][COUTP][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
         cf[0][i] = g.k0 ? g.k0[n * Cin + i] : 1.f;
         cf[1][i] = g.k1 ? g.k1[n * Cin + i] : 0.f;
         cf[2][i] = g.k2 ? g.k2[n * Cin + i] : (pro == PRO_AFFINE_GELU ? 1.f : 0.f);
+        cf[3][i] = g.k3 ? g.k3[n * Cin + i] : 0.f;
     }
 
     const int lrow = tid / (TP / 4), lc4 = tid % (TP / 4);
@@ -79,8 +80,9 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
         } else if (pro == PRO_NORMBWD) {
             if constexpr (PRE2) {
                 const float* p2 = (const float*)&pre2[i];
+                const float c3 = cf[3][kk];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], fmaf(c1, p2[j], c2));
+                for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], fmaf(c1, p2[j] - c3, c2));
             }
         } else if (pro == PRO_AFFINE_RELU) {
 #pragma unroll
@@ -237,9 +239,10 @@ struct WgArgs {
     float* rs_part;    // [N*NBX][COP] row sums of fD(d) (bias gradient) or null
     int Cd, Cx, P, PXB;
     int pro_d, pro_x;
+    const float* dk3 = nullptr;     // PRO_NORMBWD on d: the norm's mean per (n, co) (centred form), null: 0
 };
 
-__device__ __forceinline__ float4 apply_pro(int pro, float4 v, const float4& v2, float c0, float c1, float c2) {
+__device__ __forceinline__ float4 apply_pro(int pro, float4 v, const float4& v2, float c0, float c1, float c2, float c3 = 0.f) {
     float* pv = (float*)&v;
     const float* p2 = (const float*)&v2;
     if (pro == PRO_AFFINE) {
@@ -250,7 +253,7 @@ __device__ __forceinline__ float4 apply_pro(int pro, float4 v, const float4& v2,
         for (int j = 0; j < 4; ++j) pv[j] = c2 * gelu_f(fmaf(c0, pv[j], c1));
     } else if (pro == PRO_NORMBWD) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], fmaf(c1, p2[j], c2));
+        for (int j = 0; j < 4; ++j) pv[j] = fmaf(c0, pv[j], fmaf(c1, p2[j] - c3, c2));
     } else if (pro == PRO_AFFINE_RELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) pv[j] = fmaxf(fmaf(c0, pv[j], c1), 0.f);
@@ -298,13 +301,14 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void pw_wgrad_kernel(WgArgs g) {
     const TX* xbase = (const TX*)g.x + (size_t)n * Cx * P + 4 * lc4;
 
     // per-row prologue coefficients of this frame -> LDS (chunk-invariant)
-    float* cfd = smem + (COP + CIP) * PITCH;    // [3][COP]
-    float* cfx = cfd + 3 * COP;                 // [3][CIP]
+    float* cfd = smem + (COP + CIP) * PITCH;    // [4][COP]
+    float* cfx = cfd + 4 * COP;                 // [3][CIP]
     for (int i = tid; i < COP; i += NT) {
         const int ci = n * Cd + (i < Cd ? i : 0);
         cfd[i] = g.dk0 ? g.dk0[ci] : 1.f;
         cfd[COP + i] = g.dk1 ? g.dk1[ci] : 0.f;
         cfd[2 * COP + i] = g.dk2 ? g.dk2[ci] : (pro_d == PRO_AFFINE_GELU ? 1.f : 0.f);
+        cfd[3 * COP + i] = g.dk3 ? g.dk3[ci] : 0.f;
     }
     for (int i = tid; i < CIP; i += NT) {
         const int ci = n * Cx + (i < Cx ? i : 0);
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void pw_wgrad_kernel(WgArgs g) {
         for (int i = 0; i < ND; ++i) {
             const int row = lrow + i * RSTEP;
             float4 v = dv[i];
-            if (row < Cd) v = apply_pro(pro_d, v, D2 ? dv2[D2 ? i : 0] : v, cfd[row], cfd[COP + row], cfd[2 * COP + row]);
+            if (row < Cd) v = apply_pro(pro_d, v, D2 ? dv2[D2 ? i : 0] : v, cfd[row], cfd[COP + row], cfd[2 * COP + row], cfd[3 * COP + row]);
             *(float4*)&ds[row * PITCH + 4 * lc4] = v;
         }
         if constexpr (SPLIT) issue_x(ch);
@@ -502,7 +506,8 @@ extern "C" int uncr_pack_wt_batch(const long long* desc, int n_items, int max_th
 }
 
 extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, void* out, const float* k0,
-                            const float* k1, const float* k2, const float* bias, int bias_stride_n, const void* aux,
+                            const float* k1, const float* k2, const float* kmu, const float* bias, int bias_stride_n,
+                            const void* aux,
                             const float* e0, const float* e1, const float* e2, const float* e3, float* part, int N,
                             int Cin, int Cout, int P, int pro, int epi, int in_dt, int out_dt, hipStream_t stream) {
     if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
@@ -517,6 +522,7 @@ extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, vo
     const int tp = uncr_pw_tile_px(Cout);
     if (P % tp) return UNCR_ESHAPE;
     PwArgs g{in, in2, Wt, out, k0, k1, k2, bias, aux, e0, e1, e2, e3, (float2*)part, bias_stride_n, Cin, Cout, P, pro, epi};
+    g.k3 = pro == PRO_NORMBWD ? kmu : nullptr;
     const int cp = pw_coutp(Cout);
     if (use_split(Cout)) {
         if (in_dt != out_dt) return UNCR_EINVAL;      // the wide kernels have one storage type for all activation operands
@@ -579,10 +585,10 @@ extern "C" int uncr_head_fwd(const void* y, const float* Wt, const float* bias, 
 // (uncr_prenorm_bwd_finish).
 extern "C" int uncr_pw_gemm_dx_supported(int Cin, int Cout) { return (use_split(Cout) && pw_coutp(Cout) == 128 && Cin <= 256) ? 1 : 0; }
 extern "C" int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt, void* out, const float* k0,
-                               const float* k1, const float* k2, const void* dy, const void* x, const void* xh3,
-                               const float* c1, const float* c2, const float* c3, const float* relu_a,
-                               const float* relu_b, float* part, int N, int Cin, int Cout, int P, int act,
-                               hipStream_t stream) {
+                               const float* k1, const float* k2, const float* kmu, const void* dy, const void* x,
+                               const void* xh3, const float* c1, const float* c2, const float* c3, const float* cmu,
+                               const float* relu_a, const float* relu_b, float* part, int N, int Cin, int Cout, int P,
+                               int act, hipStream_t stream) {
     if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
     if (!in || !in2 || !Wt || !out || !dy || !x || !c1 || !c2 || !c3) return UNCR_EINVAL;
     if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
@@ -592,6 +598,8 @@ extern "C" int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt,
     if (P % uncr_pw_tile_px(Cout)) return UNCR_ESHAPE;
     PwArgs g{in, in2, Wt, out, k0, k1, k2, relu_b, x, c1, c2, c3, relu_a ? relu_a : c3, xh3 ? (float2*)part : nullptr,
              0, Cin, Cout, P, PRO_NORMBWD, relu_a ? 6 : 5, dy, xh3};
+    g.k3 = kmu;
+    g.emu = cmu;
     return pw_split_launch_p3(g, N, pw_coutp(Cout), act, stream);
 }
 
@@ -626,7 +634,7 @@ extern "C" int uncr_wgrad_nbx(int N, int Cd, int Cx, int P, int pro_d, int pro_x
 }
 
 extern "C" int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const void* x2, const float* dk0,
-                             const float* dk1, const float* dk2, const float* xk0, const float* xk1,
+                             const float* dk1, const float* dk2, const float* dkmu, const float* xk0, const float* xk1,
                              const float* xk2, float* part, float* rs_part, int N, int Cd, int Cx, int P, int NBX,
                              int pro_d, int pro_x, int act, hipStream_t stream) {
     int cop, cip;
@@ -637,19 +645,20 @@ extern "C" int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const
     if (pro_x == PRO_NORMBWD) return UNCR_EINVAL;   // norm-backward form is only built for the D operand
     if (act == UNCR_BF16 && g_split && pw_wgrad_a16_supported(Cd, Cx, pro_d, pro_x, rs_part != nullptr) && P % 64 == 0) {
         if (!dk0 || !dk1 || !dk2 || !xk0 || !xk1) return UNCR_EINVAL;
-        return pw_wgrad_a16_launch(d, d2, x, dk0, dk1, dk2, xk0, xk1, xk2, part, N, Cd, Cx, P, NBX, pro_x, stream);
+        return pw_wgrad_a16_launch(d, d2, x, dk0, dk1, dk2, dkmu, xk0, xk1, xk2, part, N, Cd, Cx, P, NBX, pro_x, stream);
     }
     if (act == UNCR_F32 && g_split && pw_wgrad_split_supported(Cd, Cx, pro_d, pro_x, rs_part != nullptr)) {
         if (!dk0 || !dk1 || !dk2 || !xk0 || !xk1) return UNCR_EINVAL;
-        return pw_wgrad_split_launch((const float*)d, (const float*)d2, (const float*)x, dk0, dk1, dk2, xk0, xk1, xk2, part, N, Cd,
-                                     Cx, P, NBX, pro_x, stream);
+        return pw_wgrad_split_launch((const float*)d, (const float*)d2, (const float*)x, dk0, dk1, dk2, dkmu, xk0, xk1, xk2, part, N,
+                                     Cd, Cx, P, NBX, pro_x, stream);
     }
     if (P % NBX) return UNCR_ESHAPE;
     const int PXB = P / NBX;
     if (PXB % 32) return UNCR_ESHAPE;
     WgArgs g{d, d2, x, x2, dk0, dk1, dk2, xk0, xk1, xk2, part, rs_part, Cd, Cx, P, PXB, pro_d, pro_x};
+    g.dk3 = pro_d == PRO_NORMBWD ? dkmu : nullptr;
     dim3 grid(P / PXB, N);
-    const size_t lds = (size_t)((cop + cip) * 36 + 3 * (cop + cip)) * sizeof(float);
+    const size_t lds = (size_t)((cop + cip) * 36 + 4 * cop + 3 * cip) * sizeof(float);
     // bf16 operands on the fp32-MFMA kernels: the narrow shapes of the path only (in_conv 128 x 15, head 26 x 128)
     if (act == UNCR_BF16 && shp != 2 && shp != 3) return UNCR_EINVAL;
     switch (shp) {

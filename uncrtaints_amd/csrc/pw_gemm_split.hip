@@ -93,9 +93,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     constexpr int NCT = CT * WN;
 
     __shared__ __attribute__((aligned(16))) unsigned char xs[2][NPA * 8192];
-    __shared__ float cf[3][256];
+    __shared__ float cf[PRO == PRO_NORMBWD ? 4 : 3][256];      // [3]: the norm's mean (centred norm backward)
     __shared__ float red[COUTP][2];
-    __shared__ float ecf[(EPI == 3 || EPI == 5 || EPI == 6) ? 5 : 1][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D
+    __shared__ float ecf[(EPI == 5 || EPI == 6) ? 6 : (EPI == 3 ? 5 : 1)][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D ([5]: epi 5 / 6 mean)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar: row addresses stay in SGPRs
@@ -118,11 +118,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         const float* p0 = g.k0 ? g.k0 + (size_t)n * Cin : g.Wt;      // dummy location: any readable floats
         const float* p1 = g.k1 ? g.k1 + (size_t)n * Cin : g.Wt;
         const float* p2 = g.k2 ? g.k2 + (size_t)n * Cin : g.Wt;
+        const float* p3 = g.k3 ? g.k3 + (size_t)n * Cin : g.Wt;
         for (int i = tid; i < Cin; i += NT) {
             const float a = p0[i], b = p1[i], c = p2[i];
             cf[0][i] = g.k0 ? a : 1.f;
             cf[1][i] = g.k1 ? b : 0.f;
             cf[2][i] = g.k2 ? c : (PRO == PRO_AFFINE_GELU ? 1.f : 0.f);
+            if constexpr (PRO == PRO_NORMBWD) { const float m = p3[i]; cf[3][i] = g.k3 ? m : 0.f; }
         }
     }
     {
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
             if constexpr (EPI == 5 || EPI == 6) {
                 const int ci = n * Cout + cc;
                 ecf[1][c] = g.e0[ci]; ecf[2][c] = g.e1[ci]; ecf[3][c] = g.e2[ci];
+                { const float m = (g.emu ? g.emu : g.e2)[ci]; ecf[5][c] = g.emu ? m : 0.f; }
                 if constexpr (EPI == 6) { ecf[0][c] = g.bias[ci]; ecf[4][c] = g.e3[ci]; }   // ReLU mask: e3*aux3 + bias > 0
             }
         }
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     auto stage_chunk = [&](int kc, int buf, auto slot) {
         constexpr int S = decltype(slot)::value;
         // pixel-major so that only one pixel's 4 rows x 3 parts are live at a time (register pressure)
-        float c0[4], c1[4], c2[4];
+        float c0[4], c1[4], c2[4], c3[4];
         bool valid[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
             const int kk = k < Cin ? k : 0;
             valid[r] = k < Cin;
             if constexpr (PRO != PRO_NONE) { c0[r] = cf[0][kk]; c1[r] = cf[1][kk]; c2[r] = cf[2][kk]; }
+            if constexpr (PRO == PRO_NORMBWD) c3[r] = cf[3][kk];
         }
         unsigned char* b = &xs[buf][0] + st_off;
 #pragma unroll
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                 float v = pws_get(pre[S][r], e);
                 if constexpr (PRO == PRO_AFFINE) v = fmaf(c0[r], v, c1[r]);
                 else if constexpr (PRO == PRO_AFFINE_GELU) v = c2[r] * gelu_f(fmaf(c0[r], v, c1[r]));
-                else if constexpr (PRO == PRO_NORMBWD) v = fmaf(c0[r], v, fmaf(c1[r], pws_get(pre2[PRE2 ? S : 0][r], e), c2[r]));
+                else if constexpr (PRO == PRO_NORMBWD) v = fmaf(c0[r], v, fmaf(c1[r], pws_get(pre2[PRE2 ? S : 0][r], e) - c3[r], c2[r]));
                 else if constexpr (PRO == PRO_AFFINE_RELU) v = fmaxf(fmaf(c0[r], v, c1[r]), 0.f);
                 if (!valid[r]) v = 0.f;
                 if constexpr (BF) vv[r] = v;
@@ -425,23 +429,23 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                     } else if constexpr (EPI == 5) {
                         // dx = dy + C1*da + C2*x + C3 (PreNorm backward + skip) on the fresh accumulator da
                         const float4 x = xa[q], y = xb[q], h = xc[q];
-                        const float e1 = ecf[1][col], e2 = ecf[2][col], e3 = ecf[3][col];
-                        v.x = y.x + fmaf(e1, v.x, fmaf(e2, x.x, e3));
-                        v.y = y.y + fmaf(e1, v.y, fmaf(e2, x.y, e3));
-                        v.z = y.z + fmaf(e1, v.z, fmaf(e2, x.z, e3));
-                        v.w = y.w + fmaf(e1, v.w, fmaf(e2, x.w, e3));
+                        const float e1 = ecf[1][col], e2 = ecf[2][col], e3 = ecf[3][col], em = ecf[5][col];
+                        v.x = y.x + fmaf(e1, v.x, fmaf(e2, x.x - em, e3));
+                        v.y = y.y + fmaf(e1, v.y, fmaf(e2, x.y - em, e3));
+                        v.z = y.z + fmaf(e1, v.z, fmaf(e2, x.z - em, e3));
+                        v.w = y.w + fmaf(e1, v.w, fmaf(e2, x.w - em, e3));
                         v = rnd4<TA>(v);
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * h.x + v.y * h.y + v.z * h.z + v.w * h.w;
                     } else if constexpr (EPI == 6) {
                         // as 5, then the producing ConvLayer's ReLU backward: du0 = dx * [rA*c0 + rB > 0], aux3 = c0
                         const float4 x = xa[q], y = xb[q], h = xc[q];
-                        const float e1 = ecf[1][col], e2 = ecf[2][col], e3 = ecf[3][col];
+                        const float e1 = ecf[1][col], e2 = ecf[2][col], e3 = ecf[3][col], em = ecf[5][col];
                         const float rA = ecf[4][col], rB = ecf[0][col];
-                        v.x = fmaf(rA, h.x, rB) > 0.f ? y.x + fmaf(e1, v.x, fmaf(e2, x.x, e3)) : 0.f;
-                        v.y = fmaf(rA, h.y, rB) > 0.f ? y.y + fmaf(e1, v.y, fmaf(e2, x.y, e3)) : 0.f;
-                        v.z = fmaf(rA, h.z, rB) > 0.f ? y.z + fmaf(e1, v.z, fmaf(e2, x.z, e3)) : 0.f;
-                        v.w = fmaf(rA, h.w, rB) > 0.f ? y.w + fmaf(e1, v.w, fmaf(e2, x.w, e3)) : 0.f;
+                        v.x = fmaf(rA, h.x, rB) > 0.f ? y.x + fmaf(e1, v.x, fmaf(e2, x.x - em, e3)) : 0.f;
+                        v.y = fmaf(rA, h.y, rB) > 0.f ? y.y + fmaf(e1, v.y, fmaf(e2, x.y - em, e3)) : 0.f;
+                        v.z = fmaf(rA, h.z, rB) > 0.f ? y.z + fmaf(e1, v.z, fmaf(e2, x.z - em, e3)) : 0.f;
+                        v.w = fmaf(rA, h.w, rB) > 0.f ? y.w + fmaf(e1, v.w, fmaf(e2, x.w - em, e3)) : 0.f;
                         v = rnd4<TA>(v);
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * h.x + v.y * h.y + v.z * h.z + v.w * h.w;

@@ -22,13 +22,14 @@ struct WgaArgs {
     const float* xk0; const float* xk1; const float* xk2;   // [N*Cx]
     float* part;       // [N*G][COP][CIP]
     int Cd, Cx, P;
+    const float* dk3;  // the norm's mean per (n, co) (centred norm backward on d) or null
 };
 
 template <int PRO>
-__device__ __forceinline__ float wga_pro(float v, float v2, float c0, float c1, float c2) {
+__device__ __forceinline__ float wga_pro(float v, float v2, float c0, float c1, float c2, float c3 = 0.f) {
     if constexpr (PRO == PRO_AFFINE) return fmaf(c0, v, c1);
     else if constexpr (PRO == PRO_AFFINE_GELU) return c2 * gelu_f(fmaf(c0, v, c1));
-    else if constexpr (PRO == PRO_NORMBWD) return fmaf(c0, v, fmaf(c1, v2, c2));
+    else if constexpr (PRO == PRO_NORMBWD) return fmaf(c0, v, fmaf(c1, v2 - c3, c2));
     else return v;
 }
 
@@ -59,7 +60,12 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_a16_kernel(WgaArgs g) {
     unsigned char* st_base = smem + c8 * PS + lrow * 16;      // + buf*BUF + 64*i*16 (+ COP*16 for x rows)
 
     // per-row prologue coefficients of this thread's rows (chunk-invariant); optional pointers read branch-free
-    float k0[ND + NX], k1[ND + NX], k2[ND + NX];
+    float k0[ND + NX], k1[ND + NX], k2[ND + NX], k3[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const float m = (g.dk3 ? g.dk3 : g.dk0)[g.dk3 ? n * COP + lrow + 64 * i : 0];
+        k3[i] = g.dk3 ? m : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < ND + NX; ++i) {
         const bool isd = i < ND;
@@ -92,8 +98,9 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_a16_kernel(WgaArgs g) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float a0 = bf16_lo(v[q]), a1 = bf16_hi(v[q]), b0 = bf16_lo(w[q]), b1 = bf16_hi(w[q]);
-            const float t0 = isd ? wga_pro<PRO_NORMBWD>(a0, b0, c0, c1, c2) : wga_pro<PRO_X>(a0, b0, c0, c1, c2);
-            const float t1 = isd ? wga_pro<PRO_NORMBWD>(a1, b1, c0, c1, c2) : wga_pro<PRO_X>(a1, b1, c0, c1, c2);
+            const float cm = k3[isd ? i : 0];
+            const float t0 = isd ? wga_pro<PRO_NORMBWD>(a0, b0, c0, c1, c2, cm) : wga_pro<PRO_X>(a0, b0, c0, c1, c2);
+            const float t1 = isd ? wga_pro<PRO_NORMBWD>(a1, b1, c0, c1, c2, cm) : wga_pro<PRO_X>(a1, b1, c0, c1, c2);
             o[q] = cvt_pk_bf16(t0, t1);
         }
         const int rofs = isd ? 64 * i : COP + 64 * (i - ND);
@@ -203,10 +210,10 @@ static int wga_launch(const WgaArgs& g, dim3 grid, hipStream_t stream) {
 }
 
 int pw_wgrad_a16_launch(const void* d, const void* d2, const void* x, const float* dk0, const float* dk1, const float* dk2,
-                        const float* xk0, const float* xk1, const float* xk2, float* part, int N, int Cd, int Cx, int P,
-                        int nbx, int pro_x, hipStream_t stream) {
+                        const float* dkmu, const float* xk0, const float* xk1, const float* xk2, float* part, int N, int Cd, int Cx,
+                        int P, int nbx, int pro_x, hipStream_t stream) {
     if (P % 64 || nbx < 1 || nbx > P / 64 || !d2) return UNCR_ESHAPE;
-    WgaArgs g{(const bf16_t*)d, (const bf16_t*)d2, (const bf16_t*)x, dk0, dk1, dk2, xk0, xk1, xk2, part, Cd, Cx, P};
+    WgaArgs g{(const bf16_t*)d, (const bf16_t*)d2, (const bf16_t*)x, dk0, dk1, dk2, xk0, xk1, xk2, part, Cd, Cx, P, dkmu};
     dim3 grid(nbx, N);
     if (Cd == 256) {
         if (pro_x == PRO_AFFINE) return wga_launch<4, 2, PRO_AFFINE>(g, grid, stream);

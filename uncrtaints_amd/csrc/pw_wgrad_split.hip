@@ -25,13 +25,14 @@ struct WgsArgs {
     const float* xk0; const float* xk1; const float* xk2;   // [N*Cx]
     float* part;       // [N*G][COP][CIP]
     int Cd, Cx, P;
+    const float* dk3;  // the norm's mean per (n, co) (centred norm backward on d) or null
 };
 
 template <int PRO>
-__device__ __forceinline__ float wgs_pro(float v, float v2, float c0, float c1, float c2) {
+__device__ __forceinline__ float wgs_pro(float v, float v2, float c0, float c1, float c2, float c3 = 0.f) {
     if constexpr (PRO == PRO_AFFINE) return fmaf(c0, v, c1);
     else if constexpr (PRO == PRO_AFFINE_GELU) return c2 * gelu_f(fmaf(c0, v, c1));
-    else if constexpr (PRO == PRO_NORMBWD) return fmaf(c0, v, fmaf(c1, v2, c2));
+    else if constexpr (PRO == PRO_NORMBWD) return fmaf(c0, v, fmaf(c1, v2 - c3, c2));
     else if constexpr (PRO == PRO_AFFINE_RELU) return fmaxf(fmaf(c0, v, c1), 0.f);
     else return v;
 }
@@ -67,7 +68,12 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
 
     // per-row prologue coefficients of this thread's six rows: chunk-invariant, kept in registers (optional pointers
     // are read branch-free: a null pointer reads a dummy location and the value is replaced by a select)
-    float k0[ND + NX], k1[ND + NX], k2[ND + NX];
+    float k0[ND + NX], k1[ND + NX], k2[ND + NX], k3[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const float m = (g.dk3 ? g.dk3 : g.d)[g.dk3 ? n * COP + lrow + 64 * i : 0];
+        k3[i] = g.dk3 ? m : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < ND + NX; ++i) {
         const bool isd = i < ND;
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float a = ((const float*)&v)[q], b = ((const float*)&w)[q];
-            const float t = isd ? wgs_pro<PRO_D>(a, b, c0, c1, c2) : wgs_pro<PRO_X>(a, b, c0, c1, c2);
+            const float t = isd ? wgs_pro<PRO_D>(a, b, c0, c1, c2, k3[isd ? i : 0]) : wgs_pro<PRO_X>(a, b, c0, c1, c2);
             split3_bf16(t, h[q], m[q], l[q]);
         }
         unsigned char* b = xs + buf * BUF + st_off + (row - lrow) * 16;
@@ -255,10 +261,10 @@ static int wgs_launch(const WgsArgs& g, dim3 grid, hipStream_t stream) {
 }
 
 int pw_wgrad_split_launch(const float* d, const float* d2, const float* x, const float* dk0, const float* dk1,
-                          const float* dk2, const float* xk0, const float* xk1, const float* xk2, float* part, int N,
-                          int Cd, int Cx, int P, int nbx, int pro_x, hipStream_t stream) {
+                          const float* dk2, const float* dkmu, const float* xk0, const float* xk1, const float* xk2, float* part,
+                          int N, int Cd, int Cx, int P, int nbx, int pro_x, hipStream_t stream) {
     if (P % 32 || nbx < 1 || nbx > P / 32) return UNCR_ESHAPE;
-    WgsArgs g{d, d2, x, dk0, dk1, dk2, xk0, xk1, xk2, part, Cd, Cx, P};
+    WgsArgs g{d, d2, x, dk0, dk1, dk2, xk0, xk1, xk2, part, Cd, Cx, P, dkmu};
     dim3 grid(nbx, N);
     if (Cd == 256) {
         if (pro_x == PRO_AFFINE) return wgs_launch<4, 2, PRO_AFFINE>(g, grid, stream);

@@ -189,11 +189,17 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
 
 @dataclass
 class NormBwd:
+    """dh = c1*du + c2*(h - mu) + c3 per plane (centred form: the constant carries no rounding offset of size |c2*mean|)."""
     c1: Tensor
     c2: Tensor
     c3: Tensor
     dgamma: Tensor
     dbeta: Tensor
+    mu: Optional[Tensor] = None
+
+    @property
+    def k(self):
+        return (self.c1, self.c2, self.c3, self.mu)
 
 
 def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor, centered: bool = False) -> NormBwd:
@@ -201,20 +207,20 @@ def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor, cen
     if gamma is None:
         gamma = _const_planes(part.buf.device, C)[0]
     dev = gamma.device
-    c1, c2, c3 = _f32((N * C,), dev), _f32((N * C,), dev), _f32((N * C,), dev)
+    c1, c2, c3, mu = _f32((N * C,), dev), _f32((N * C,), dev), _f32((N * C,), dev), _f32((N * C,), dev)
     dg, db = _f32((C,), dev), _f32((C,), dev)
     if nf.kind == NORM_BATCH_TRAIN and nf.sync_count > 0:
         loc = torch.empty((C, 2), device=dev, dtype=torch.float64)
         hb.call("uncr_bn_channel_sums", part.buf, part.slots, N, C, loc, _stream())
         glob = loc.clone()
         _all_reduce_sums(glob)
-        hb.call("uncr_bn_finalize_bwd_sums", loc, glob, nf.sync_count, N, C, gamma, nf.mean, nf.rstd, c1, c2, c3, dg, db,
+        hb.call("uncr_bn_finalize_bwd_sums", loc, glob, nf.sync_count, N, C, gamma, nf.mean, nf.rstd, c1, c2, c3, mu, dg, db,
                 1 if centered else 0, _stream())
-        return NormBwd(c1, c2, c3, dg, db)
+        return NormBwd(c1, c2, c3, dg, db, mu)
     scratch = _f32((2 * N * C,), dev) if nf.kind == NORM_GROUP else None
     hb.call("uncr_norm_finalize_bwd", part.buf, part.slots, N, C, nf.groups, P, nf.kind, gamma, nf.mean, nf.rstd,
-            c1, c2, c3, dg, db, scratch, 1 if centered else 0, _stream())
-    return NormBwd(c1, c2, c3, dg, db)
+            c1, c2, c3, mu, dg, db, scratch, 1 if centered else 0, _stream())
+    return NormBwd(c1, c2, c3, dg, db, mu)
 
 
 # ---- batched weight packing: every 1x1-conv weight of a model in ONE launch at the start of a forward ----
@@ -303,7 +309,8 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
         if slots <= 0:
             raise RuntimeError(f"pw_gemm: P={P} is not a multiple of the {hb.query('uncr_pw_tile_px', Cout)}-pixel tile")
         part = Part(_f32((N * Cout, slots, 2), x.device), slots)
-    hb.call("uncr_pw_gemm", x, x2, Wt, out, k[0], k[1], k[2], bias, Cout if bias_per_frame else 0, aux,
+    hb.call("uncr_pw_gemm", x, x2, Wt, out, k[0], k[1], k[2], k[3] if len(k) > 3 else None, bias,
+            Cout if bias_per_frame else 0, aux,
             ek[0], ek[1], ek[2], ek[3], part.buf if part else None, N, Cin, Cout, P, pro, epi, _dt(x), _dt(out), _stream())
     return out, part
 
@@ -327,8 +334,8 @@ def pw_wgrad(d: Tensor, x: Tensor, N: int, Cd: int, Cx: int, P: int, *, pro_d: i
     dev = d.device
     part = _f32((N * nbx, cop, cip), dev)
     rs_part = _f32((N * nbx, cop), dev) if rowsum else None
-    hb.call("uncr_pw_wgrad", d, d2, x, x2, dk[0], dk[1], dk[2], xk[0], xk[1], xk[2], part, rs_part, N, Cd, Cx, P, nbx,
-            pro_d, pro_x, act, _stream())
+    hb.call("uncr_pw_wgrad", d, d2, x, x2, dk[0], dk[1], dk[2], dk[3] if len(dk) > 3 else None, xk[0], xk[1], xk[2], part,
+            rs_part, N, Cd, Cx, P, nbx, pro_d, pro_x, act, _stream())
     n_out = N if per_frame else 1
     dW = _f32((n_out, Cd, Cx), dev)
     hb.call("uncr_wgrad_reduce", part, n_out, (N * nbx) // n_out, cop, cip, Cd, Cx, dW, _stream())
@@ -441,7 +448,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     part3 = dy_part if dy_part is not None else stats_aux(dy, h3, N * C, P)
     b3 = norm_bwd(part3, N, C, P, n3, p["n3w"])
     g["n3w"], g["n3b"] = b3.dgamma, b3.dbeta
-    k3 = (b3.c1, b3.c2, b3.c3)
+    k3 = b3.k
 
     # pw2: per-frame products G[n] = dh3 (x) g2  -> dW2 and the SE gradient
     G, _ = pw_wgrad(dy, h2, N, C, Ch, P, pro_d=PRO_NORMBWD, dk=k3, d2=h3, pro_x=PRO_AFFINE_GELU,
@@ -470,14 +477,14 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     wdw = p["wdw"].reshape(Ch, 9).contiguous()
     # statistics for the norm-1 backward in centred form (sum du1*(h1 - mean1)): h1 is the raw pw1 output, whose
     # channel means can be many standard deviations from zero
-    hb.call("uncr_dw_bwd", du2, h2, h1, b2.c1, b2.c2, b2.c3, n1.A, n1.B, wdw, du1, part1.buf, dw_part, n1.mean,
+    hb.call("uncr_dw_bwd", du2, h2, h1, b2.c1, b2.c2, b2.c3, b2.mu, n1.A, n1.B, wdw, du1, part1.buf, dw_part, n1.mean,
             n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, H, W, dt, _stream())
     dwdw = _f32((Ch, 9), dev)
     hb.call("uncr_dw_wgrad_reduce", dw_part, N, Ch, slots, dwdw, _stream())
     g["wdw"] = dwdw.view_as(p["wdw"])
     b1 = norm_bwd(part1, N, Ch, P, n1, p["n1w"], centered=True)
     g["n1w"], g["n1b"] = b1.dgamma, b1.dbeta
-    k1 = (b1.c1, b1.c2, b1.c3)
+    k1 = b1.k
 
     W1k = pack_wt(p["w1"].reshape(Ch, C), transpose=False)  # [k=co 256][out=ci 128]
     if need_dx and _FUSED_DX and C % 32 == 0 and Ch % 8 == 0 and hb.query("uncr_pw_gemm_dx_supported", Ch, C) == 1:
@@ -492,8 +499,8 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         dW1 = _f32((Ch, C), dev)
         pf = sv.get("part1f")
         hb.call("uncr_prenorm_bwd_finish", Rf, p["w1"].reshape(Ch, C).contiguous(), part1.buf, part1.slots,
-                pf.buf if pf is not None else None, pf.slots if pf is not None else 0, k1[0], k1[1], k1[2], n0.A, n0.B,
-                part0.buf, dW1, _f32((2 * N * Ch,), dev), N, Ch, C, P, _stream())
+                pf.buf if pf is not None else None, pf.slots if pf is not None else 0, k1[0], k1[1], k1[2],
+                k1[3] if pf is not None else None, n0.A, n0.B, part0.buf, dW1, _f32((2 * N * Ch,), dev), N, Ch, C, P, _stream())
         g["w1"] = dW1.view_as(p["w1"])
         b0 = norm_bwd(part0, N, C, P, n0, p["n0w"])
         g["n0w"], g["n0b"] = b0.dgamma, b0.dbeta
@@ -507,7 +514,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         if x_h3 is not None:
             slots = hb.query("uncr_pw_stat_slots", N, C, P)
             dx_part = Part(_f32((N * C, slots, 2), dev), slots, masked=relu is not None)
-        hb.call("uncr_pw_gemm_dx", du1, h1, W1k, dx, k1[0], k1[1], k1[2], dy, x, x_h3, b0.c1, b0.c2, b0.c3, ra, rb,
+        hb.call("uncr_pw_gemm_dx", du1, h1, W1k, dx, k1[0], k1[1], k1[2], k1[3], dy, x, x_h3, b0.c1, b0.c2, b0.c3, b0.mu, ra, rb,
                 dx_part.buf if dx_part is not None else None, N, Ch, C, P, dt, _stream())
         return dx, g, dx_part
 
@@ -522,7 +529,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     if need_dx:
         dx = _act((N, C, H, W), dev, dt)
         x_h3 = sv.get("x_h3")     # h3 of the block that produced x: emit its norm-3 backward statistics here
-        _, dx_part = ew(EW_PASSE, dy, b=da, c=x, aux=x_h3, out=dx, k=(b0.c1, b0.c2, b0.c3, None),
+        _, dx_part = ew(EW_PASSE, dy, b=da, c=x, aux=x_h3, out=dx, k=b0.k,
                         want_part=x_h3 is not None, planes=N * C, P=P)
     return dx, g, dx_part
 
@@ -579,7 +586,8 @@ def conv3x3_backward(du: Tensor, c: Tensor, kk, xp: _Padded, w: Tensor, need_dx:
     Co = w.shape[0]
     dev = w.device
     dcp = _Padded(N, Co, H, W, dev)
-    hb.call("uncr_pad2d", du.contiguous(), c, dcp.view(), kk[0], kk[1], kk[2], PRO_NORMBWD, 1, N * Co, H, W, _stream())
+    hb.call("uncr_pad2d", du.contiguous(), c, dcp.view(), kk[0], kk[1], kk[2], kk[3] if len(kk) > 3 else None, PRO_NORMBWD, 1,
+            N * Co, H, W, _stream())
     dWt = []
     db = None
     for i, (ky, kx, off) in enumerate(_taps(W)):
@@ -609,7 +617,7 @@ def residual_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: 
     src, pro, k = x, PRO_NONE, (None, None)
     for i in (1, 2, 3):
         xp = _Padded(N, C, H, W, dev)
-        hb.call("uncr_pad2d", src, None, xp.view(), k[0], k[1], None, pro, 0, N * C, H, W, _stream())
+        hb.call("uncr_pad2d", src, None, xp.view(), k[0], k[1], None, None, pro, 0, N * C, H, W, _stream())
         c, part = conv3x3_forward(xp, p[f"w{i}"], p[f"b{i}"], spec.needs_stats(training))
         rm = buffers.get(f"rm{i}") if buffers else None
         rv = buffers.get(f"rv{i}") if buffers else None
@@ -633,7 +641,7 @@ def residual_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool 
         _, part = ew(EW_RELU_BWD, da, b=c, out=du, k=(nf.A, nf.B, None, None), want_part=True, planes=N * C, P=P)
         nb = norm_bwd(part, N, C, P, nf, p[f"g{i}"])
         g[f"g{i}"], g[f"be{i}"] = nb.dgamma, nb.dbeta
-        da, g[f"w{i}"], g[f"b{i}"] = conv3x3_backward(du, c, (nb.c1, nb.c2, nb.c3), xp, p[f"w{i}"],
+        da, g[f"w{i}"], g[f"b{i}"] = conv3x3_backward(du, c, nb.k, xp, p[f"w{i}"],
                                                       need_dx or i > 1)
     dx = None
     if need_dx:
@@ -674,7 +682,7 @@ def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool,
         du0 = _act((N, Cout, H, W), da0.device, _dt(x))
         _, part = ew(EW_RELU_BWD, da0, b=c0, out=du0, k=(nf.A, nf.B, None, None), want_part=True, planes=N * Cout, P=P)
     nb = norm_bwd(part, N, Cout, P, nf, gw)
-    kk = (nb.c1, nb.c2, nb.c3)
+    kk = nb.k
     dW, db = pw_wgrad(du0, x, N, Cout, Cin, P, pro_d=PRO_NORMBWD, dk=kk, d2=c0, rowsum=True)
     dx = None
     if need_dx:
@@ -904,7 +912,7 @@ def ltae_values_backward(dv: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int
     _, part = ew(EW_RELU_BWD, dr, b=m1, out=du, k=(nf.A, nf.B, None, None), want_part=True, planes=B * C, P=S)
     nb = norm_bwd(part, B, C, S, nf, p["bn_w"])
     g["bn_w"], g["bn_b"] = nb.dgamma, nb.dbeta
-    kk = (nb.c1, nb.c2, nb.c3)
+    kk = nb.k
     dWm, dbm = pw_wgrad(du, sv["vh"].view(B, D, S), B, C, D, S, pro_d=PRO_NORMBWD, dk=kk, d2=m1, rowsum=True)
     g["mlp_w"], g["mlp_b"] = dWm, dbm
     Wmk = pack_wt(p["mlp_w"], transpose=False)                # [k=C][out=D]
