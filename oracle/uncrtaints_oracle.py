@@ -348,8 +348,13 @@ def temporal_aggregate(x: Tensor, pad_mask: Tensor, attn: Tensor, cfg: OracleCon
 
 def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, training: bool = False,
             dropout_mask: Optional[Tensor] = None, update_running: bool = True,
-            taps: Optional[dict] = None) -> Tensor:
-    """UNCRTAINTS.forward (uncrtaints.py:391-447).  x [B,T,Cin,H,W], dates [B,T] -> [B,1,13+covar,H,W]."""
+            taps: Optional[dict] = None, pool_idx: Optional[Tensor] = None) -> Tensor:
+    """UNCRTAINTS.forward (uncrtaints.py:391-447).  x [B,T,Cin,H,W], dates [B,T] -> [B,1,13+covar,H,W].
+    pool_idx (test infrastructure, not a reference argument): flat in-plane arg-max indices [B*T, C, 32, 32] that the max-pool
+    is to take instead of its own.  The max-pool is a kink of the function: where the two largest values of a window differ by
+    less than the forward error, two correct fp32 evaluations may select different elements and route the pooled gradient to
+    different pixels.  A parity test passes the indices the implementation under test selected (after checking that every
+    selected value equals its window's maximum to forward accuracy), so that both sides differentiate the SAME branch."""
     B, T, Cin, H, W = x.shape
     pad_mask = (x == cfg.pad_value).all(dim=-1).all(dim=-1).all(dim=-1)   # [B,T]
     bf = cfg.act_bf16
@@ -361,7 +366,11 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
     if cfg.is_mono:
         g, down, attn = e.view(B, T, C, H, W).squeeze(dim=1), None, None
     else:
-        down = F.adaptive_max_pool2d(e, (cfg.att_down, cfg.att_down)).view(B, T, C, cfg.att_down, cfg.att_down)
+        if pool_idx is not None:
+            down = e.flatten(2).gather(2, pool_idx.to(torch.long).reshape(B * T, C, -1))
+            down = down.view(B, T, C, cfg.att_down, cfg.att_down)
+        else:
+            down = F.adaptive_max_pool2d(e, (cfg.att_down, cfg.att_down)).view(B, T, C, cfg.att_down, cfg.att_down)
         vals = None
         if cfg.use_v:
             vals, attn = ltae2d_values_attention(down, dates, pad_mask, p, cfg, training, update_running)

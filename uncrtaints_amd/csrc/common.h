@@ -56,10 +56,18 @@ __device__ __forceinline__ float gelu_f(float u) {
 __device__ __forceinline__ float gelu_grad_f(float u) {
     // d/du [u * Phi(u)] = Phi(u) + u * phi(u);  phi(u) = exp(-u^2/2)/sqrt(2 pi) = 2^(-u^2 * log2(e)/2)/sqrt(2 pi)
     const float cdf = 0.5f * (1.0f + erf_f(u * 0.70710678118654752440f));
+#ifdef UNCR_EXACT_EXP
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * u * u);
+#else
     const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * u * u);
+#endif
     return cdf + u * pdf;
 }
+#ifdef UNCR_EXACT_EXP
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+#else
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+#endif
 
 // sum over the 64 lanes of a wave (all lanes get the result)
 __device__ __forceinline__ float wave_sum(float v) {

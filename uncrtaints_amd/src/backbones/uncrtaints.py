@@ -301,6 +301,7 @@ class _StageFn(torch.autograd.Function):
             te.mlp[1].num_batches_tracked += 1
         ctx.sv, ctx.p, ctx.te = sv, p, te
         net._last_attention = att
+        net._last_pool_idx = sv["idx"]        # arg-max of the 32x32 max-pool (flat in-plane index per (frame, channel, cell))
         g._uncr_part = gpart
         return g
 
@@ -465,6 +466,7 @@ class UNCRTAINTS(nn.Module):
                 raise ValueError(f"out_conv[-1]={self.out_dims} < 13 + covar_dim={self.vars_idx}")
         self.variance = None
         self._last_attention = None
+        self._last_pool_idx = None
         self.act_dtype = torch.float32      # storage of the activations: see set_act_dtype
 
     def set_act_dtype(self, dtype):
