@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float x = pa[i];
-                if constexpr (ew_var_mode(OP) == 0) o[i] = (x > 20.f ? x : log1pf(__expf(x))) + g.eps;   // nn.Softplus(beta=1, threshold=20)
+                if constexpr (ew_var_mode(OP) == 0) o[i] = (x > 20.f ? x : log1pf(expf(x))) + g.eps;   // nn.Softplus(beta=1, threshold=20)
                 else if constexpr (ew_var_mode(OP) == 1) o[i] = (x > 0.f ? x : expm1f(x)) + 1.f + g.eps;  // nn.ELU() + 1 + eps
                 else o[i] = x;                                                                            // nn.Identity()
             }
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
                     const float d = from_out ? -expm1f(-(pb[i] - g.eps)) : (pb[i] > 20.f ? 1.f : sigmoid_f(pb[i]));
                     o[i] = pa[i] * d;
                 } else if constexpr (ew_var_mode(OP) == 1) {
-                    const float d = from_out ? fminf(pb[i] - g.eps, 1.f) : (pb[i] > 0.f ? 1.f : __expf(pb[i]));
+                    const float d = from_out ? fminf(pb[i] - g.eps, 1.f) : (pb[i] > 0.f ? 1.f : expf(pb[i]));
                     o[i] = pa[i] * d;
                 } else o[i] = pa[i];
             }

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
                     for (int i = 0; i < 4; ++i) {
                         const float x = pv[i];
                         if (col < nm) pv[i] = g.head_nm > 0 ? g.head_scale * sigmoid_f(x) : x;
-                        else if (g.head_var == 0) pv[i] = (x > 20.f ? x : log1pf(__expf(x))) + g.head_eps;
+                        else if (g.head_var == 0) pv[i] = (x > 20.f ? x : log1pf(expf(x))) + g.head_eps;
                         else if (g.head_var == 1) pv[i] = (x > 0.f ? x : expm1f(x)) + 1.f + g.head_eps;
                     }
                 }
