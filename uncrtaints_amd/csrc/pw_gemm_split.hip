@@ -184,7 +184,16 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
             const int kk = k < Cin ? k : 0;
             valid[r] = k < Cin;
             if constexpr (PRO != PRO_NONE) { c0[r] = cf[0][kk]; c1[r] = cf[1][kk]; c2[r] = cf[2][kk]; }
-            if constexpr (PRO == PRO_NORMBWD) c3[r] = cf[3][kk];
+            if constexpr (PRO == PRO_NORMBWD) {
+                c3[r] = cf[3][kk];
+                if constexpr (!BF) {
+                    // fp32 storage: centre the second operand in place right away, so that the means are dead before the
+                    // register-hungry split section (the 256-channel variants spilled 120 B per lane with four live
+                    // coefficient rows)
+                    pre2[PRE2 ? S : 0][r].x -= c3[r]; pre2[PRE2 ? S : 0][r].y -= c3[r];
+                    pre2[PRE2 ? S : 0][r].z -= c3[r]; pre2[PRE2 ? S : 0][r].w -= c3[r];
+                }
+            }
         }
         unsigned char* b = &xs[buf][0] + st_off;
 #pragma unroll
@@ -196,7 +205,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                 float v = pws_get(pre[S][r], e);
                 if constexpr (PRO == PRO_AFFINE) v = fmaf(c0[r], v, c1[r]);
                 else if constexpr (PRO == PRO_AFFINE_GELU) v = c2[r] * gelu_f(fmaf(c0[r], v, c1[r]));
-                else if constexpr (PRO == PRO_NORMBWD) v = fmaf(c0[r], v, fmaf(c1[r], pws_get(pre2[PRE2 ? S : 0][r], e) - c3[r], c2[r]));
+                else if constexpr (PRO == PRO_NORMBWD) {
+                    if constexpr (BF) v = fmaf(c0[r], v, fmaf(c1[r], pws_get(pre2[PRE2 ? S : 0][r], e) - c3[r], c2[r]));
+                    else v = fmaf(c0[r], v, fmaf(c1[r], pws_get(pre2[PRE2 ? S : 0][r], e), c2[r]));
+                }
                 else if constexpr (PRO == PRO_AFFINE_RELU) v = fmaxf(fmaf(c0[r], v, c1[r]), 0.f);
                 if (!valid[r]) v = 0.f;
                 if constexpr (BF) vv[r] = v;

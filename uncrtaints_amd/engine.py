@@ -187,6 +187,9 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
     return NormFwd(A, B, mean, rstd, kind, groups)
 
 
+_CENTRED_NORMBWD = os.environ.get("UNCR_RAW_NORMBWD", "0") != "1"     # development A/B switch
+
+
 @dataclass
 class NormBwd:
     """dh = c1*du + c2*(h - mu) + c3 per plane (centred form: the constant carries no rounding offset of size |c2*mean|)."""
@@ -207,7 +210,8 @@ def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor, cen
     if gamma is None:
         gamma = _const_planes(part.buf.device, C)[0]
     dev = gamma.device
-    c1, c2, c3, mu = _f32((N * C,), dev), _f32((N * C,), dev), _f32((N * C,), dev), _f32((N * C,), dev)
+    c1, c2, c3 = _f32((N * C,), dev), _f32((N * C,), dev), _f32((N * C,), dev)
+    mu = _f32((N * C,), dev) if _CENTRED_NORMBWD else None      # None: raw form dh = c1*du + c2*h + c3 (A/B switch)
     dg, db = _f32((C,), dev), _f32((C,), dev)
     if nf.kind == NORM_BATCH_TRAIN and nf.sync_count > 0:
         loc = torch.empty((C, 2), device=dev, dtype=torch.float64)
