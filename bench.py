@@ -191,15 +191,17 @@ def main():
         from uncrtaints_amd.parallel import BucketedDataParallel
         # with a captured forward/backward the collectives stay outside the graph: no launches from autograd hooks
         dp = BucketedDataParallel(model, seed=1, overlap=args.no_graph)
+        segmented = (not args.no_graph) and len(dp.buckets) == 3
+        model.keep_boundaries = segmented
     else:
         model.temporal_aggregator.set_seed(1)
     use_graph = not args.no_graph
     # fused multi-tensor Adam: one launch per step instead of ~180 per-tensor kernels (0.7 ms/step in the capture);
     # captured with the step at N = 1, launched eagerly after the gradient all-reduce at N > 1
     try:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph and world == 1, fused=True)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph, fused=True)
     except Exception:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph and world == 1)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph)
     x, y, dates = synthetic(B, T, H, H, seed=1 + rank, device=device)
     step_counter = torch.zeros(1, dtype=torch.int64, device=device)
     model.temporal_aggregator.step_counter = step_counter     # dropout stream advances on the device
@@ -222,7 +224,41 @@ def main():
         opt.step()
         return loss
 
+    # N > 1: the backward pass cut at the two bucket boundaries (decoder + head | temporal encoder | encoder): each segment is
+    # its own captured HIP graph, and the all-reduce of a segment's gradient bucket is launched (RCCL, asynchronous) as soon as
+    # that graph has been enqueued -- it travels over xGMI while the next segment computes.
+    def seg_forward_decoder():
+        step_counter.add_(1)
+        dp.zero_grad()
+        out = model(x, batch_positions=dates)
+        loss, _ = crit(out[:, :, :13], y, out[:, :, 13:26])
+        torch.autograd.backward(loss, inputs=dp.bucket_params(0) + [model._boundary_agg])
+        return loss
+
+    def seg_stage():
+        g_t = model._boundary_agg
+        torch.autograd.backward(g_t, grad_tensors=g_t.grad, inputs=dp.bucket_params(1) + [model._boundary_enc])
+
+    def seg_encoder():
+        e_t = model._boundary_enc
+        torch.autograd.backward(e_t, grad_tensors=e_t.grad, inputs=dp.bucket_params(2))
+
+    def segmented_step(run0, run1, run2, run_opt):
+        loss = run0()
+        dp.reduce_bucket(0)
+        run1()
+        dp.reduce_bucket(1)
+        run2()
+        dp.reduce_bucket(2)
+        dp.finish()           # the compute stream waits for the three collectives
+        run_opt()
+        return loss
+
     step = eager_step
+    if dp is not None and use_graph:
+        eager_seg = lambda: segmented_step(seg_forward_decoder, seg_stage, seg_encoder, opt.step)
+        eager_step_plain, eager_step = eager_step, eager_seg      # the same launch order eagerly (warm-up, event-profiled re-run)
+        step = eager_step
     graph_note = "eager launches"
     if use_graph:
         # Capture the whole step (fwd + MGNLL + bwd + Adam, ~450 kernel launches) into one HIP graph: the step is
@@ -248,18 +284,25 @@ def main():
                     return static_loss
                 graph_note = "HIP graph replay of the captured step"
             else:
-                # N > 1: forward + loss + backward replayed from a graph (gradients land in the flat buckets), then
-                # the three bucket all-reduces (RCCL) and the fused Adam step are launched eagerly
-                with torch.cuda.graph(graph):
-                    static_loss = fwd_bwd()
+                # N > 1: four graphs sharing one memory pool (forward + loss + decoder backward | temporal-encoder backward |
+                # encoder backward | fused Adam); the three bucket all-reduces are launched between the replays
+                graphs = [graph] + [torch.cuda.CUDAGraph() for _ in range(3)]
+                pool = None
+                static = {}
+                for gi, fn in enumerate((seg_forward_decoder, seg_stage, seg_encoder, opt.step)):
+                    with torch.cuda.graph(graphs[gi], pool=pool):
+                        r = fn()
+                    if gi == 0:
+                        static["loss"] = r
+                        pool = graphs[0].pool()
                 torch.cuda.synchronize()
+                dp.zero_grad()
 
                 def step():
-                    graph.replay()
-                    dp.finish()
-                    opt.step()
-                    return static_loss
-                graph_note = "HIP graph replay of forward+backward, eager bucket all-reduce + fused Adam"
+                    return segmented_step(lambda: (graphs[0].replay(), static["loss"])[1], graphs[1].replay, graphs[2].replay,
+                                          graphs[3].replay)
+                graph_note = ("HIP graph replays of forward+decoder-backward | temporal-encoder backward | encoder backward | fused "
+                              "Adam, each gradient bucket all-reduced (RCCL, asynchronous) behind its segment")
         except Exception as exc:   # fall back loudly, never silently
             print(f"[bench] HIP-graph capture failed ({type(exc).__name__}: {exc}); timing eager launches",
                   file=sys.stderr)
@@ -322,6 +365,7 @@ def main():
                                    f"B={B}/GPU, {H}x{H}, fwd+MGNLL+bwd+Adam, train mode (dropout on), "
                                    + ("bf16 activation storage / fp32 accumulate, statistics, weights and loss" if bf16 else "fp32"),
                        "global_batch": world * B, "T": T, "parallelism": f"dp{world}"},
+            "ranks": world, "collective_backend": (backend if world > 1 else None),
             "final_loss": final_loss, "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
             "launch_mode": graph_note,
             "step_hbm_roofline_frac": round(value / world * a_step_bytes(T, H * H, bf16) / 1e9 / HBM_PEAK_GBS, 4),

@@ -130,3 +130,83 @@ def test_two_ranks_with_sync_bn_equal_one_process_on_the_concatenated_batch():
         worst = max(worst, (res[0][n] - ref[n]).abs().max().item() / scale)
     print(f"[parity] ddp 2 ranks + sync_bn vs one process on the concatenated batch: worst rel err {worst:.3e}")
     assert worst < 2e-4
+
+
+def _seg_worker(rank, world, port, q):
+    """world-size-1 group: the segmented backward (one autograd.backward per gradient bucket, as bench.py replays it from HIP
+    graphs at N > 1) against the plain loss.backward()."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uncrtaints_amd.parallel import BucketedDataParallel
+    from uncrtaints_amd.src import losses
+    m = _model()
+    dp = BucketedDataParallel(m, seed=1, overlap=False)
+    x, y, d = _shard(0)
+    crit = losses.MultiGaussianNLLLoss(reduction="mean", full=True, mode="diag")
+    dp.zero_grad()
+    out = m(x, batch_positions=d)
+    l, _ = crit(out[:, :, :13], y, out[:, :, 13:26])
+    l.backward()
+    dp.finish()
+    plain = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    m.keep_boundaries = True
+    dp.zero_grad()
+    out = m(x, batch_positions=d)
+    l2, _ = crit(out[:, :, :13], y, out[:, :, 13:26])
+    torch.autograd.backward(l2, inputs=dp.bucket_params(0) + [m._boundary_agg])
+    dp.reduce_bucket(0)
+    g_t = m._boundary_agg
+    torch.autograd.backward(g_t, grad_tensors=g_t.grad, inputs=dp.bucket_params(1) + [m._boundary_enc])
+    dp.reduce_bucket(1)
+    e_t = m._boundary_enc
+    torch.autograd.backward(e_t, grad_tensors=e_t.grad, inputs=dp.bucket_params(2))
+    dp.reduce_bucket(2)
+    dp.finish()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for n, p in m.named_parameters():
+        den = float(plain[n].abs().max())
+        if den > 0:
+            worst = max(worst, float((p.grad - plain[n]).abs().max()) / den)
+    q.put((float(l.item()), float(l2.item()), worst))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_segmented_backward_equals_plain_backward():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_seg_worker, args=(0, 1, port, q))
+    p.start()
+    l, l2, worst = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    print(f"[parity] segmented vs plain backward: loss {l} / {l2}, worst gradient difference {worst:.2e}")
+    assert l == l2 and worst < 2e-6
+
+
+def test_bench_two_ranks_segmented_graphs_gloo():
+    """bench.py's N > 1 path on the one available GPU (UNCR_BENCH_BACKEND=gloo: RCCL rejects two ranks per device): launched
+    exactly as the driver launches it, the rank-0 JSON line is parsed.  Small frames keep it short."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UNCR_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--size", "64", "--batch-per-gpu", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak" and res["value"] > 0
+    assert res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
+    assert "all-reduced" in res["launch_mode"] and "graph" in res["launch_mode"], res["launch_mode"]
+    assert res["ranks"] == 2 and res["collective_backend"] == "gloo"
+    assert "roofline" in res and res["roofline"]["frac"] > 0
+    assert "cpu_baseline" not in res           # N = 1 only
+    import math
+    assert math.isfinite(res["final_loss"])

@@ -82,6 +82,20 @@ class BucketedDataParallel:
                 b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
         return hook
 
+    # ---- segmented backward: forward+backward replayed from HIP graphs, one graph per bucket --------------------------------
+    def reduce_bucket(self, bi: int) -> None:
+        """Launch the all-reduce of bucket `bi` now (asynchronous; RCCL enqueues it behind the work already on the current
+        stream).  For training loops that drive the backward pass in bucket-sized segments themselves -- e.g. one captured
+        HIP graph per segment, where autograd hooks do not run on replay: segment k's gradients travel over xGMI while segment
+        k+1 computes.  `finish()` then only waits."""
+        b = self.buckets[bi]
+        op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
+        b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
+        b["ready"] = b["n"]
+
+    def bucket_params(self, bi: int):
+        return list(self.buckets[bi]["params"])
+
     def zero_grad(self):
         for b in self.buckets:
             b["flat"].zero_()
@@ -107,7 +121,8 @@ class BucketedDataParallel:
         if not self.overlap:
             op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
             for b in self.buckets:
-                b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
+                if b["handle"] is None:          # not already launched through reduce_bucket()
+                    b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
         for b in self.buckets:
             if b["handle"] is None:
                 raise RuntimeError("a gradient bucket never became ready (parameter unused in this step?)")

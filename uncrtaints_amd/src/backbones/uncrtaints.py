@@ -467,6 +467,11 @@ class UNCRTAINTS(nn.Module):
         self.variance = None
         self._last_attention = None
         self._last_pool_idx = None
+        # keep_boundaries = True: forward records the two tensors at which a training loop may cut the backward pass into the
+        # three gradient-bucket segments of uncrtaints_amd.parallel (decoder + head | temporal encoder | encoder):
+        # _boundary_enc (encoder output [B,T,C,H,W]) and _boundary_agg (aggregated features [B,C,H,W])
+        self.keep_boundaries = False
+        self._boundary_enc = self._boundary_agg = None
         self.act_dtype = torch.float32      # storage of the activations: see set_act_dtype
 
     def set_act_dtype(self, dtype):
@@ -558,8 +563,12 @@ class UNCRTAINTS(nn.Module):
             if self.use_v:
                 vp = _ltae_value_params(self.temporal_encoder)
                 extra = [vp[k] for k in _LTAEV_KEYS] + [self.include_v.weight, self.include_v.bias]
+            if self.keep_boundaries:
+                self._boundary_enc = out
             out = _StageFn.apply(out, batch_positions, pad, self, self.temporal_aggregator.dropout_mask,
                                  *([p[k] for k in _LTAE_KEYS] + extra))
+            if self.keep_boundaries:
+                self._boundary_agg = out
         else:                                                              # uncrtaints.py:418
             if out.shape[1] != 1:
                 raise ValueError("is_mono expects a single input date (T == 1)")
