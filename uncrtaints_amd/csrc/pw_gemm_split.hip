@@ -36,6 +36,7 @@
 #define UNCR_NTG_ST2 0     // stores of the 256-channel outputs only (268 MB at N=4: larger than any cache level)
 #endif
 #include <type_traits>
+#include <cstdlib>
 // four consecutive activation elements as loaded: fp32 storage keeps the float4, bf16 storage keeps the raw 8 bytes (half the
 // prefetch registers) and is widened at staging
 template <typename TA> struct PwsRaw { using type = float4; };
@@ -81,8 +82,14 @@ template <bool NT, typename TA> __device__ __forceinline__ void pws_st(TA* p, co
 // its result is rounded ONCE to bf16 (one operand part instead of three); the weights keep their PWS_A16_WPARTS leading parts, so
 // a k-step is PWS_A16_WPARTS products instead of six and the kernel is purely stream-bound.  A fragments are double-buffered over
 // two k-steps (one k-step of MFMAs no longer covers an L2 round trip).
+#ifndef PWS_A16_DEPTH_CT2
+#define PWS_A16_DEPTH_CT2 1    // raw chunks in flight of the 256-channel bf16 variants (experiment knob)
+#endif
+#ifndef PWS_A16_OCC
+#define PWS_A16_OCC 2          // blocks per CU the bf16 variants are compiled for (experiment knob)
+#endif
 template <int CT, int PRO, int EPI, int DEPTH, typename TA>
-__global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
+__global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2) void pw_gemm_split_kernel(PwArgs g) {
     constexpr int NT = 256, WN = 4;
     constexpr bool BF = sizeof(TA) == 2;
     constexpr int NPA = BF ? 1 : 3;            // activation parts in LDS
@@ -596,7 +603,7 @@ template <int EPI, typename TA>
 static void pws_launch_epi(const PwArgs& g, dim3 grid, int cp, hipStream_t stream) {
     // prefetch depth 2 where registers allow (CT = 1); the 256-channel tile keeps one chunk in flight with fp32 storage
     // (bf16 storage alike: depth 2 spills with the double-buffered A fragments)
-    if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, 1, TA>), grid, dim3(256), 0, stream, g);
+    if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, sizeof(TA) == 2 ? PWS_A16_DEPTH_CT2 : 1, TA>), grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 2, TA>), grid, dim3(256), 0, stream, g);
 }
 
@@ -613,6 +620,7 @@ int pw_split_blocks_per_frame(int N, int P) {
             hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
             ncu = 256;
         slots = 2 * ncu;
+        if (const char* ov = getenv("UNCR_PWS_SLOTS")) { const int m = atoi(ov); if (m > 0) slots = m * ncu; }   // experiment: blocks per CU
     }
     const int ntile = P / PWS_TP;
     int bpf = slots / N;
