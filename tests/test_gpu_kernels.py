@@ -267,21 +267,30 @@ def test_inconv_fwd_bwd(orc):
         close(f"inconv_grad[{name}]", got.grad, ref.grad, tol=2e-4)
 
 
-@pytest.mark.parametrize("T,padded", [(3, False), (3, True), (6, False)])
-def test_ltae_attention_fwd_bwd(orc, T, padded):
+@pytest.mark.parametrize("T,padded,fused,heads", [(3, False, True, (16, 4)), (3, True, True, (16, 4)), (6, False, True, (16, 4)),
+                                                  (12, True, True, (8, 8)), (2, False, True, (32, 4)),
+                                                  (3, False, False, (16, 4)), (3, True, False, (16, 4)), (6, False, False, (16, 4))])
+def test_ltae_attention_fwd_bwd(orc, E, T, padded, fused, heads, monkeypatch):
+    """LTAE2dtiny: the fused per-pixel kernels (csrc/ltae_fused.hip: composed score map, GroupNorm + softmax in one kernel per
+    direction, parameter gradients by the chain rule) and the unfused kernel chain, both against the oracle."""
     from uncrtaints_amd.src.backbones.ltae import LTAE2dtiny
     from uncrtaints_amd.src.learning.weight_init import weight_init
+    monkeypatch.setattr(E, "_FUSED_LTAE", fused)
     torch.manual_seed(1)
-    m = LTAE2dtiny(in_channels=128, n_head=16, d_k=4, d_model=256)
+    nh, dk = heads
+    m = LTAE2dtiny(in_channels=128, n_head=nh, d_k=dk, d_model=256)
     m.apply(weight_init)
+    with torch.no_grad():        # a non-trivial GroupNorm affine (weight_init leaves it at 1 / 0)
+        m.in_norm.weight.copy_(1.0 + 0.3 * torch.randn(128))
+        m.in_norm.bias.copy_(0.2 * torch.randn(128))
     B = 2
     down = rand(B, T, 128, 32, 32, seed=3)
     dates = torch.sort(torch.randint(1400, 1800, (B, T)), dim=1).values.float()
     pad = torch.zeros(B, T, dtype=torch.bool)
     if padded:
         pad[0, T - 1] = True
-    gatt = rand(16, B, T, 32, 32, seed=4)
-    cfg = orc.OracleConfig()
+    gatt = rand(nh, B, T, 32, 32, seed=4)
+    cfg = orc.OracleConfig(n_head=nh, d_k=dk)
     p = {"temporal_encoder." + k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
     do = down.clone().requires_grad_(True)
     att_o = orc.ltae_tiny_attention(do, dates, pad, p, cfg)

@@ -755,9 +755,72 @@ def ltae_attention_forward(down: Tensor, dates: Optional[Tensor], pad: Optional[
     return att, saved
 
 
+_FUSED_LTAE = os.environ.get("UNCR_NO_FUSED_LTAE", "0") != "1"     # A/B switch (development, tests)
+
+
+def ltae_fused_ok(T: int, C: int, n_head: int, S: int) -> bool:
+    return _FUSED_LTAE and hb.query("uncr_ltae_fused_supported", T, C, n_head, S) == 1 and n_head in (4, 8, 16, 32)
+
+
+def ltae_attention_forward_fused(down: Tensor, dates: Optional[Tensor], pad: Optional[Tensor], p: Dict[str, Tensor],
+                                 denom: Optional[Tensor], n_head: int, d_k: int):
+    """LTAE2dtiny (ltae.py:197-239) as one fused kernel: the score is a linear functional of the group-normalised input
+    (csrc/ltae_fused.hip); A', B' are composed from the parameters first.  down [B,T,C,h,w] -> att [n_head,B,T,h,w]."""
+    B, T, C, ah, aw = down.shape
+    S = ah * aw
+    D = p["inconv_w"].shape[0]
+    HK = n_head * d_k
+    dev = down.device
+    NF = B * T
+    use_pe = denom is not None
+    bias1 = _f32((NF, D), dev)
+    hb.call("uncr_ltae_posbias", dates.reshape(-1).contiguous().float() if use_pe else None,
+            denom if use_pe else None, denom.numel() if use_pe else 0, p["inconv_b"], bias1, NF, D,
+            1 if use_pe else 0, _stream())
+    Ap, Bp, M, U = _f32((n_head, C), dev), _f32((n_head, NF), dev), _f32((HK, C), dev), _f32((HK, NF), dev)
+    Wi, Wk = p["inconv_w"].reshape(D, C).contiguous(), p["fc_w"].contiguous()
+    hb.call("uncr_ltae_compose", p["Q"].contiguous(), Wk, p["fc_b"].contiguous(), Wi, bias1, p["in_norm_w"], p["in_norm_b"],
+            n_head, d_k, D, C, NF, Ap, Bp, M, U, _stream())
+    att = _f32((n_head, B, T, ah, aw), dev)
+    mean, rstd = _f32((B, n_head, S), dev), _f32((B, n_head, S), dev)
+    hb.call("uncr_ltae_fused_fwd", down, Ap, Bp, pad, 1e-5, att, mean, rstd, B, T, C, n_head, S, _stream())
+    saved = dict(fused=True, down=down, att=att, mean=mean, rstd=rstd, Ap=Ap, M=M, U=U, bias1=bias1, pad=pad,
+                 dims=(B, T, C, S, D, HK))
+    return att, saved
+
+
+def ltae_attention_backward_fused(datt: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int, d_k: int):
+    """-> d(down) [B*T,C,S], {param grads}"""
+    B, T, C, S, D, HK = sv["dims"]
+    dev = datt.device
+    NF = B * T
+    nblk = S // 64
+    ddown = _f32((NF, C, S), dev)
+    partA, partB = _f32((B * nblk, n_head, C), dev), _f32((B * nblk, n_head, T), dev)
+    hb.call("uncr_ltae_fused_bwd", datt.contiguous(), sv["att"], sv["down"], sv["Ap"], sv["pad"], sv["mean"], sv["rstd"], ddown,
+            partA, partB, B, T, C, n_head, S, _stream())
+    dAp, dBp = _f32((n_head, C), dev), _f32((B, n_head, T), dev)
+    hb.call("uncr_colsum", partA, B * nblk, n_head * C, dAp, _stream())
+    for b in range(B):          # d B' per sample: the blocks of sample b
+        hb.call("uncr_colsum", partB[b * nblk:(b + 1) * nblk], nblk, n_head * T, dBp[b], _stream())
+    dA, dQ = _f32((n_head, C), dev), _f32((n_head, d_k), dev)
+    dWk, dbk, dWi, dbi = _f32((HK, D), dev), _f32((HK,), dev), _f32((D, C), dev), _f32((D,), dev)
+    dgb = _f32((n_head, 2, C), dev)
+    Wi, Wk = p["inconv_w"].reshape(D, C).contiguous(), p["fc_w"].contiguous()
+    hb.call("uncr_ltae_compose_bwd", p["Q"].contiguous(), Wk, Wi, sv["bias1"], p["in_norm_w"], p["in_norm_b"], sv["M"], sv["U"],
+            dAp, dBp, n_head, d_k, D, C, NF, T, dA, dQ, dWk, dbk, dWi, dbi, dgb, _stream())
+    gb = _f32((2 * C,), dev)
+    hb.call("uncr_colsum", dgb, n_head, 2 * C, gb, _stream())
+    g = dict(Q=dQ, fc_w=dWk, fc_b=dbk, inconv_w=dWi.view_as(p["inconv_w"]), inconv_b=dbi, in_norm_w=gb[:C], in_norm_b=gb[C:])
+    return ddown, g
+
+
 def ltae_attention_backward(datt: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int, d_k: int,
                             dy1_extra: Optional[Tensor] = None):
     """-> d(down) [B*T,C,S], {param grads}.  dy1_extra: gradient reaching y1 through the values (use_v)."""
+    if sv.get("fused"):
+        assert dy1_extra is None
+        return ltae_attention_backward_fused(datt, sv, p, n_head, d_k)
     B, T, C, S, D, HK = sv["dims"]
     NF = B * T
     dev = datt.device
@@ -974,7 +1037,11 @@ def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor]
         down, idx = (v.view(B, T, e.shape[2], att_down, att_down) for v in pooled)
     else:
         down, idx = maxpool_forward(e, att_down, att_down)
-    att, sv_att = ltae_attention_forward(down, dates, pad, p, denom, n_head, d_k)
+    _, _, Cc, ah_, aw_ = down.shape
+    if values is None and ltae_fused_ok(T, Cc, n_head, ah_ * aw_):
+        att, sv_att = ltae_attention_forward_fused(down.contiguous(), dates, pad, p, denom, n_head, d_k)
+    else:
+        att, sv_att = ltae_attention_forward(down, dates, pad, p, denom, n_head, d_k)
     if mode == "att_group":
         w_att, shared = att, False
         if e.shape[-2] <= att_down:      # feature map not larger than the attention map: the reference takes its AvgPool

@@ -61,8 +61,9 @@ class _LTAEAttnFn(torch.autograd.Function):
     def forward(ctx, down, dates, pad, module, *params):
         p = dict(zip(_LTAE_KEYS, params))
         denom = module.positional_encoder.denom_on(down.device) if module.positional_encoder is not None else None
-        att, sv = E.ltae_attention_forward(down.contiguous(), dates, pad, p, denom, module.n_head,
-                                           module.attention_heads.d_k)
+        _, T, C, ah, aw = down.shape
+        fwd = E.ltae_attention_forward_fused if E.ltae_fused_ok(T, C, module.n_head, ah * aw) else E.ltae_attention_forward
+        att, sv = fwd(down.contiguous(), dates, pad, p, denom, module.n_head, module.attention_heads.d_k)
         ctx.sv, ctx.p, ctx.module = sv, p, module
         return att
 
