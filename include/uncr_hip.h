@@ -229,7 +229,7 @@ int uncr_ltae_softmax_bwd(const float* datt, const float* att, const float* k, c
  *      score = A' . xhat + B' with A' [NH][C], B' [NH][B*T] composed from the parameters by uncr_ltae_compose (fp64; also
  *      returns M = Wk Wi [NH*DK][C] and U = Wk (b_i + PE) + b_k [NH*DK][B*T] for the backward).  bias1 [B*T][D] = b_i + PE comes
  *      from uncr_ltae_posbias.  uncr_ltae_fused_bwd returns d(pooled features) and per-block partials of d A' ([B*nblk][NH][C],
- *      nblk = S/64) and d B' ([B*nblk][NH][T]); after uncr_colsum, uncr_ltae_compose_bwd applies the chain rule (dAp [NH][C],
+ *      nblk = S*NH/256 blocks per sample) and d B' ([B*nblk][NH][T]); after uncr_colsum, uncr_ltae_compose_bwd applies the chain rule (dAp [NH][C],
  *      dBp [B][NH][T]) -> d Q, d fc1_k, d inconv, and per-head d gamma / d beta contributions dgb [NH][2][C]. ---- */
 int uncr_ltae_fused_supported(int T, int C, int NH, int S);
 int uncr_ltae_compose(const float* Q, const float* Wk, const float* bk, const float* Wi, const float* bias1,
@@ -242,8 +242,8 @@ int uncr_ltae_fused_bwd(const float* datt, const float* att, const float* x, con
                         int NH, int S, hipStream_t stream);
 int uncr_ltae_compose_bwd(const float* Q, const float* Wk, const float* Wi, const float* bias1, const float* gamma,
                           const float* beta, const float* M, const float* U, const float* dAp, const float* dBp, int NH,
-                          int DK, int D, int C, int NF, int T, float* dA, float* dQ, float* dWk, float* dbk, float* dWi,
-                          float* dbi, float* dgb, hipStream_t stream);
+                          int DK, int D, int C, int NF, int T, float* dA /* scratch NH*C + NH floats */, float* dQ, float* dWk,
+                          float* dbk, float* dWi, float* dbi, float* dgb, hipStream_t stream);
 
 /* ---- full-resolution temporal aggregation (Compact_Temporal_Aggregator 'att_group',
  *      uncrtaints.py:156-221: bilinear up-sample + dropout + pad mask + V-aggregate) ---- */

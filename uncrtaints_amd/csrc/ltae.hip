@@ -238,7 +238,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
     double s = 0.0;
-    for (int r = 0; r < R; ++r) s += (double)part[(size_t)r * K + k];
+    int r = 0;
+    for (; r + 8 <= R; r += 8) {          // eight loads in flight, summed in a fixed order
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(r + q) * K + k];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += (double)v[q];
+    }
+    for (; r < R; ++r) s += (double)part[(size_t)r * K + k];
     out[k] = (float)s;
 }
 

@@ -15,7 +15,6 @@
 // keeps the unfused path.
 #include "common.h"
 
-#define LF_PX 64       // pixels per block (one wave = the 64 pixels of one head group / channel-group quarter)
 
 struct LfArgs {
     const float* x;        // [B][T][C][S] pooled features
@@ -27,8 +26,8 @@ struct LfArgs {
     float* rstd;
     const float* datt;     // bwd
     float* dx;             // bwd [B][T][C][S]
-    float* partA;          // bwd [B*nblk][NH][C]
-    float* partB;          // bwd [B*nblk][NH][T]
+    float* partA;          // bwd [nblk][NH][C], nblk = B*S / (256/NH) blocks, sample-major
+    float* partB;          // bwd [nblk][NH][T]
     int B, T, C, NH, S;
     float eps;
 };
@@ -41,14 +40,31 @@ __global__ __launch_bounds__(256) void ltae_compose_mu_kernel(const float* __res
                                                               float* __restrict__ U) {
     const int hd = blockIdx.x;
     const float* wk = Wk + (size_t)hd * D;
+    // the loads of 16 steps are issued together (a plain loop serialises 256 L2 round trips: 100 us for a 2-MFLOP product)
     for (int c = threadIdx.x; c < C; c += 256) {
         double s = 0.0;
-        for (int j = 0; j < D; ++j) s += (double)wk[j] * (double)Wi[(size_t)j * C + c];
+        int j = 0;
+        for (; j + 16 <= D; j += 16) {
+            float w[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) w[q] = Wi[(size_t)(j + q) * C + c];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += (double)wk[j + q] * (double)w[q];
+        }
+        for (; j < D; ++j) s += (double)wk[j] * (double)Wi[(size_t)j * C + c];
         M[(size_t)hd * C + c] = (float)s;
     }
     for (int n = threadIdx.x; n < NF; n += 256) {
         double s = (double)bk[hd];
-        for (int j = 0; j < D; ++j) s += (double)wk[j] * (double)bias1[(size_t)n * D + j];
+        int j = 0;
+        for (; j + 16 <= D; j += 16) {
+            float w[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) w[q] = bias1[(size_t)n * D + j + q];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += (double)wk[j + q] * (double)w[q];
+        }
+        for (; j < D; ++j) s += (double)wk[j] * (double)bias1[(size_t)n * D + j];
         U[(size_t)hd * NF + n] = (float)s;
     }
 }
@@ -83,160 +99,185 @@ __global__ __launch_bounds__(256) void ltae_compose_ab_kernel(const float* __res
 }
 
 // ---- fused forward -----------------------------------------------------------------------------------------------------
-// grid = (S / 64, B), block 256: lane = pixel, wave w = heads [w*NH/4, (w+1)*NH/4)
-template <int TMAX, int HPW>     // dates bound, heads per wave
+// thread = (pixel, GroupNorm group g) -- the number of groups equals the number of heads (ltae.py:191-194), so the NH lanes of a
+// pixel hold its NH groups in the first half of the kernel and its NH heads in the second.  Wave = 64 / NH pixels, block = 4 waves,
+// grid = B * S / (256 / NH) blocks (256 blocks at the model's shape: the problem is tiny, parallelism and latency are everything).
+//   1. the thread loads its group's T x CG values once, computes mean / rstd in registers and normalises in place;
+//   2. for every head h the group's partial score  sum_{c in g} A'[h][c] * xhat[t][c]  is summed over the pixel's NH lanes with
+//      wave shuffles; lane h keeps head h's T scores;
+//   3. masked softmax over T, one attention row per lane.
+template <int TMAX, int CG>
 __global__ __launch_bounds__(256) void ltae_fused_fwd_kernel(LfArgs g) {
     extern __shared__ float lds[];          // Ap [NH][C]
-    const int sp = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int b = blockIdx.y, s = blockIdx.x * LF_PX + sp;
-    const int T = g.T, C = g.C, NH = g.NH, S = g.S, Cg = C / NH;
+    const int T = g.T, C = g.C, NH = g.NH, S = g.S;
+    const int ppb = 256 / NH;                                   // pixels per block
+    const int lane_g = threadIdx.x % NH, pl = threadIdx.x / NH;  // group / head of this lane, pixel within the block
+    const long long pix = (long long)blockIdx.x * ppb + pl;     // over B*S
+    const int b = (int)(pix / S), s = (int)(pix % S);
     for (int i = threadIdx.x; i < NH * C; i += 256) lds[i] = g.Ap[i];
     __syncthreads();
-    const int h0 = wv * HPW;
-    float acc[HPW][TMAX];
+    float xv[TMAX][CG];
+    const float* xb = g.x + ((size_t)b * T * C + (size_t)lane_g * CG) * S + s;
+    float sum = 0.f;
 #pragma unroll
-    for (int hh = 0; hh < HPW; ++hh)
+    for (int t = 0; t < TMAX; ++t)
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) acc[hh][t] = 0.f;
-    const float* xb = g.x + (size_t)b * T * C * S + s;
-    const float Mn = (float)(T * Cg);
-    for (int grp = 0; grp < NH; ++grp) {            // GroupNorm groups = heads (ltae.py:191-194)
-        float sum = 0.f;
-        for (int t = 0; t < T; ++t)
-            for (int j = 0; j < Cg; ++j) sum += xb[((size_t)t * C + grp * Cg + j) * S];
-        const float mu = sum / Mn;
-        float var = 0.f;
-        for (int t = 0; t < T; ++t)
-            for (int j = 0; j < Cg; ++j) {
-                const float d = xb[((size_t)t * C + grp * Cg + j) * S] - mu;
-                var = fmaf(d, d, var);
-            }
-        const float r = 1.0f / sqrtf(var / Mn + g.eps);
-        if (wv == 0) {
-            g.mean[((size_t)b * NH + grp) * S + s] = mu;
-            g.rstd[((size_t)b * NH + grp) * S + s] = r;
+        for (int j = 0; j < CG; ++j) {
+            xv[t][j] = t < T ? xb[((size_t)t * C + j) * S] : 0.f;
+            sum += xv[t][j];
         }
+    const float Mn = (float)(T * CG);
+    const float mu = sum / Mn;
+    float var = 0.f;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int j = 0; j < CG; ++j)
+            if (t < T) { const float d = xv[t][j] - mu; var = fmaf(d, d, var); }
+    const float r = 1.0f / sqrtf(var / Mn + g.eps);
+    g.mean[((size_t)b * NH + lane_g) * S + s] = mu;
+    g.rstd[((size_t)b * NH + lane_g) * S + s] = r;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int j = 0; j < CG; ++j) xv[t][j] = (xv[t][j] - mu) * r;
+    float sc[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) sc[t] = 0.f;
+    for (int h = 0; h < NH; ++h) {
+        const float* ap = lds + h * C + lane_g * CG;
+        float a[CG];
+#pragma unroll
+        for (int j = 0; j < CG; ++j) a[j] = ap[j];
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
-            if (t < T) {
-                for (int j = 0; j < Cg; ++j) {
-                    const int c = grp * Cg + j;
-                    const float xh = (xb[((size_t)t * C + c) * S] - mu) * r;
+            if (t < T) {                      // wave-uniform
+                float p = 0.f;
 #pragma unroll
-                    for (int hh = 0; hh < HPW; ++hh) acc[hh][t] = fmaf(lds[(h0 + hh) * C + c], xh, acc[hh][t]);
-                }
+                for (int j = 0; j < CG; ++j) p = fmaf(a[j], xv[t][j], p);
+                for (int m = NH >> 1; m >= 1; m >>= 1) p += __shfl_xor(p, m, 64);    // over the pixel's NH lanes
+                if (lane_g == h) sc[t] = p;
             }
         }
     }
+    const int h = lane_g;
+    float mx = -INFINITY;
 #pragma unroll
-    for (int hh = 0; hh < HPW; ++hh) {
-        const int h = h0 + hh;
-        float mx = -INFINITY;
+    for (int t = 0; t < TMAX; ++t)
+        if (t < T) {
+            float v = sc[t] + g.Bp[(size_t)h * g.B * T + b * T + t];
+            if (g.pad && g.pad[b * T + t]) v = -1e3f;          // masked_fill(pad, -1e3), ltae.py:435
+            sc[t] = v;
+            mx = fmaxf(mx, v);
+        }
+    float den = 0.f;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t)
-            if (t < T) {
-                float sc = acc[hh][t] + g.Bp[(size_t)h * g.B * T + b * T + t];
-                if (g.pad && g.pad[b * T + t]) sc = -1e3f;          // masked_fill(pad, -1e3), ltae.py:435
-                acc[hh][t] = sc;
-                mx = fmaxf(mx, sc);
-            }
-        float den = 0.f;
+    for (int t = 0; t < TMAX; ++t)
+        if (t < T) { sc[t] = expf(sc[t] - mx); den += sc[t]; }
+    const float inv = 1.0f / den;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t)
-            if (t < T) { acc[hh][t] = expf(acc[hh][t] - mx); den += acc[hh][t]; }
-        const float inv = 1.0f / den;
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t)
-            if (t < T) g.att[(((size_t)h * g.B + b) * T + t) * S + s] = acc[hh][t] * inv;
-    }
+    for (int t = 0; t < TMAX; ++t)
+        if (t < T) g.att[(((size_t)h * g.B + b) * T + t) * S + s] = sc[t] * inv;
 }
 
 // ---- fused backward ----------------------------------------------------------------------------------------------------
-// grid = (S / 64, B), block 256.  Phase 1 (wave = head quarter): softmax backward -> ds[h][t][px] in LDS + partial d B'.
-// Phase 2 (wave = GroupNorm-group quarter): d xhat = A'^T ds, GroupNorm backward -> dx, partial d A' (wave sums over the pixels).
-template <int TMAX, int HPW>
+// Same thread mapping.  1. lane (pixel, h): softmax backward -> ds[t]; staged in LDS per pixel ([ppb][NH][T]); block partial of
+// d B'.  2. lane (pixel, g): d xhat[t][c] = sum_h A'[h][c] ds[h][t] for its own channels, GroupNorm backward in registers -> dx;
+// d A'[h][c] contributions (sum_t ds[h][t] xhat[t][c]) reduced over the block's pixels (wave shuffles, then LDS) -> block partial.
+template <int TMAX, int CG>
 __global__ __launch_bounds__(256) void ltae_fused_bwd_kernel(LfArgs g) {
     extern __shared__ float lds[];
-    const int sp = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int b = blockIdx.y, s = blockIdx.x * LF_PX + sp;
-    const int T = g.T, C = g.C, NH = g.NH, S = g.S, Cg = C / NH;
-    float* Ap = lds;                       // [NH][C]
-    float* ds = lds + NH * C;              // [NH][T][64]
+    const int T = g.T, C = g.C, NH = g.NH, S = g.S;
+    const int ppb = 256 / NH, ppw = 64 / NH;
+    const int lane_g = threadIdx.x % NH, pl = threadIdx.x / NH, wv = threadIdx.x >> 6;
+    const long long pix = (long long)blockIdx.x * ppb + pl;
+    const int b = (int)(pix / S), s = (int)(pix % S);
+    float* Ap = lds;                        // [NH][C]
+    float* dsl = Ap + NH * C;               // [ppb][NH][T]
+    float* accA = dsl + ppb * NH * T;       // [4 waves][NH][C]  (d A' partials of the waves)
+    float* accB = accA + 4 * NH * C;        // [4 waves][NH][T]
     for (int i = threadIdx.x; i < NH * C; i += 256) Ap[i] = g.Ap[i];
-    const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
+    // 1. softmax backward (lane = head)
     {
-        const int h0 = wv * HPW;
+        const int h = lane_g;
+        float a[TMAX], d[TMAX], dot = 0.f;
 #pragma unroll
-        for (int hh = 0; hh < HPW; ++hh) {
-            const int h = h0 + hh;
-            float a[TMAX], d[TMAX];
-            float dot = 0.f;
-#pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < T) {
-                    const size_t o = (((size_t)h * g.B + b) * T + t) * S + s;
-                    a[t] = g.att[o];
-                    d[t] = g.datt[o];
-                    dot = fmaf(a[t], d[t], dot);
-                }
-#pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < T) {
-                    float v = a[t] * (d[t] - dot);
-                    if (g.pad && g.pad[b * T + t]) v = 0.f;          // a padded date's score is the constant -1e3
-                    ds[(h * T + t) * LF_PX + sp] = v;
-                    const float sv = wave_sum_dpp(v);                 // over the block's 64 pixels (lane 63 holds the sum)
-                    if (sp == 63) g.partB[(blk * NH + h) * T + t] = sv;
-                }
+        for (int t = 0; t < TMAX; ++t) {
+            a[t] = d[t] = 0.f;
+            if (t < T) {
+                const size_t o = (((size_t)h * g.B + b) * T + t) * S + s;
+                a[t] = g.att[o];
+                d[t] = g.datt[o];
+                dot = fmaf(a[t], d[t], dot);
+            }
         }
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) {
+                float v = a[t] * (d[t] - dot);
+                if (g.pad && g.pad[b * T + t]) v = 0.f;          // a padded date's score is the constant -1e3
+                dsl[(pl * NH + h) * T + t] = v;
+                for (int m = NH; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);      // over the wave's pixels (same head)
+                if ((threadIdx.x & 63) == lane_g) accB[(wv * NH + h) * T + t] = v;
+            }
     }
     __syncthreads();
-    const float Mn = (float)(T * Cg);
-    const float* xb = g.x + (size_t)b * T * C * S + s;
-    float* dxb = g.dx + (size_t)b * T * C * S + s;
-    const int gpw = NH / 4;                 // GroupNorm groups per wave (NH % 4 == 0)
-    for (int gi = 0; gi < gpw; ++gi) {
-        const int grp = wv * gpw + gi;
-        const float mu = g.mean[((size_t)b * NH + grp) * S + s], r = g.rstd[((size_t)b * NH + grp) * S + s];
-        float m1 = 0.f, m2 = 0.f;
-        for (int j = 0; j < Cg; ++j) {
-            const int c = grp * Cg + j;
-            float da[32];                  // d A'[h][c] contributions of this pixel, NH <= 32
+    // 2. (lane = group)
+    float xv[TMAX][CG];
+    const float* xb = g.x + ((size_t)b * T * C + (size_t)lane_g * CG) * S + s;
+    const float mu = g.mean[((size_t)b * NH + lane_g) * S + s], r = g.rstd[((size_t)b * NH + lane_g) * S + s];
 #pragma unroll
-            for (int h = 0; h < 32; ++h) da[h] = 0.f;
-            for (int t = 0; t < T; ++t) {
-                const float xh = (xb[((size_t)t * C + c) * S] - mu) * r;
-                float dxh = 0.f;
+    for (int t = 0; t < TMAX; ++t)
 #pragma unroll
-                for (int h = 0; h < 32; ++h)
-                    if (h < NH) {
-                        const float dv = ds[(h * T + t) * LF_PX + sp];
-                        dxh = fmaf(Ap[h * C + c], dv, dxh);
-                        da[h] = fmaf(dv, xh, da[h]);
-                    }
-                m1 += dxh;
-                m2 = fmaf(dxh, xh, m2);
-            }
+        for (int j = 0; j < CG; ++j) xv[t][j] = t < T ? (xb[((size_t)t * C + j) * S] - mu) * r : 0.f;
+    float dxh[TMAX][CG];
 #pragma unroll
-            for (int h = 0; h < 32; ++h)
-                if (h < NH) {
-                    const float sv = wave_sum_dpp(da[h]);
-                    if (sp == 63) g.partA[(blk * NH + h) * C + c] = sv;
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int j = 0; j < CG; ++j) dxh[t][j] = 0.f;
+    const float* dsp = dsl + pl * NH * T;
+    for (int h = 0; h < NH; ++h) {
+        const float* ap = Ap + h * C + lane_g * CG;
+        float a[CG], da[CG];
+#pragma unroll
+        for (int j = 0; j < CG; ++j) { a[j] = ap[j]; da[j] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) {
+                const float dv = dsp[h * T + t];
+#pragma unroll
+                for (int j = 0; j < CG; ++j) {
+                    dxh[t][j] = fmaf(a[j], dv, dxh[t][j]);
+                    da[j] = fmaf(dv, xv[t][j], da[j]);
                 }
-        }
-        m1 /= Mn;
-        m2 /= Mn;
-        for (int t = 0; t < T; ++t)
-            for (int j = 0; j < Cg; ++j) {
-                const int c = grp * Cg + j;
-                const float xh = (xb[((size_t)t * C + c) * S] - mu) * r;
-                float dxh = 0.f;
-#pragma unroll
-                for (int h = 0; h < 32; ++h)
-                    if (h < NH) dxh = fmaf(Ap[h * C + c], ds[(h * T + t) * LF_PX + sp], dxh);
-                dxb[((size_t)t * C + c) * S] = r * (dxh - m1 - xh * m2);
             }
+#pragma unroll
+        for (int j = 0; j < CG; ++j) {
+            float v = da[j];
+            for (int m = NH; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);          // over the wave's pixels (same group)
+            if ((threadIdx.x & 63) == lane_g) accA[(wv * NH + h) * C + lane_g * CG + j] = v;
+        }
     }
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int j = 0; j < CG; ++j) { m1 += dxh[t][j]; m2 = fmaf(dxh[t][j], xv[t][j], m2); }
+    const float Mn = (float)(T * CG);
+    m1 /= Mn;
+    m2 /= Mn;
+    float* dxb = g.dx + ((size_t)b * T * C + (size_t)lane_g * CG) * S + s;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int j = 0; j < CG; ++j)
+            if (t < T) dxb[((size_t)t * C + j) * S] = r * (dxh[t][j] - m1 - xv[t][j] * m2);
+    __syncthreads();
+    for (int i = threadIdx.x; i < NH * C; i += 256)
+        g.partA[(size_t)blockIdx.x * NH * C + i] = (accA[i] + accA[NH * C + i]) + (accA[2 * NH * C + i] + accA[3 * NH * C + i]);
+    for (int i = threadIdx.x; i < NH * T; i += 256)
+        g.partB[(size_t)blockIdx.x * NH * T + i] = (accB[i] + accB[NH * T + i]) + (accB[2 * NH * T + i] + accB[3 * NH * T + i]);
+    (void)ppw;
 }
 
 // ---- gradients of the parameters from d A' [NH][C] and d B' ([B][NH][T], as the block partials reduce) --------------------
@@ -247,7 +288,8 @@ __global__ __launch_bounds__(256) void ltae_compose_bwd_a_kernel(const float* __
                                                                  const float* __restrict__ beta, const float* __restrict__ dAp,
                                                                  const float* __restrict__ dBp, int DK, int C, int NF, int T,
                                                                  float* __restrict__ dA, float* __restrict__ dQ,
-                                                                 float* __restrict__ dgb /* [NH][2][C] */) {
+                                                                 float* __restrict__ dgb /* [NH][2][C] */,
+                                                                 float* __restrict__ sBout /* [NH] = sum_n dB'[h][n] */) {
     const int h = blockIdx.x, NH = gridDim.x;
     const double sc = 1.0 / sqrt((double)DK);
     __shared__ double red[256];
@@ -260,7 +302,7 @@ __global__ __launch_bounds__(256) void ltae_compose_bwd_a_kernel(const float* __
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) sB = red[0];
+    if (threadIdx.x == 0) { sB = red[0]; sBout[h] = (float)red[0]; }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
         double a = 0.0;
@@ -290,48 +332,70 @@ __global__ __launch_bounds__(256) void ltae_compose_bwd_a_kernel(const float* __
 // grid = HK: d Wk[hd][:], d bk[hd]          (d M[hd][c] = sc Q[h][d] dA[h][c],  d U[hd][n] = sc Q[h][d] dB'[h][n])
 __global__ __launch_bounds__(256) void ltae_compose_bwd_wk_kernel(const float* __restrict__ Q, const float* __restrict__ Wi,
                                                                   const float* __restrict__ bias1, const float* __restrict__ dA,
-                                                                  const float* __restrict__ dBp, int DK, int D, int C, int NF,
-                                                                  int T, float* __restrict__ dWk, float* __restrict__ dbk) {
+                                                                  const float* __restrict__ dBp, const float* __restrict__ sBv,
+                                                                  int DK, int D, int C, int NF, int T, float* __restrict__ dWk,
+                                                                  float* __restrict__ dbk) {
     const int hd = blockIdx.x, h = hd / DK, NH = gridDim.x / DK;
     const double q = (double)Q[hd] / sqrt((double)DK);
     for (int j = threadIdx.x; j < D; j += 256) {
         double s = 0.0;
-        for (int c = 0; c < C; ++c) s += (double)dA[(size_t)h * C + c] * (double)Wi[(size_t)j * C + c];
+        int c = 0;
+        for (; c + 16 <= C; c += 16) {          // loads of 16 steps issued together (see ltae_compose_mu_kernel)
+            float w[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) w[q] = Wi[(size_t)j * C + c + q];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += (double)dA[(size_t)h * C + c + q] * (double)w[q];
+        }
+        for (; c < C; ++c) s += (double)dA[(size_t)h * C + c] * (double)Wi[(size_t)j * C + c];
         for (int n = 0; n < NF; ++n) s += (double)LF_DB(h, n) * (double)bias1[(size_t)n * D + j];
         dWk[(size_t)hd * D + j] = (float)(s * q);
     }
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int n = 0; n < NF; ++n) s += (double)LF_DB(h, n);
-        dbk[hd] = (float)(s * q);
-    }
+    if (threadIdx.x == 0) dbk[hd] = (float)((double)sBv[h] * q);
 }
 // grid = D: d Wi[j][:], d bi[j]
 __global__ __launch_bounds__(256) void ltae_compose_bwd_wi_kernel(const float* __restrict__ Q, const float* __restrict__ Wk,
-                                                                  const float* __restrict__ dA, const float* __restrict__ dBp,
+                                                                  const float* __restrict__ dA, const float* __restrict__ sBv,
                                                                   int NH, int DK, int D, int C, int NF, int T,
                                                                   float* __restrict__ dWi, float* __restrict__ dbi) {
     const int j = blockIdx.x;
     const double sc = 1.0 / sqrt((double)DK);
     for (int c = threadIdx.x; c < C; c += 256) {
         double s = 0.0;
-        for (int hd = 0; hd < NH * DK; ++hd)
+        int hd = 0;
+        for (; hd + 16 <= NH * DK; hd += 16) {
+            float w[16], a[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { w[q] = Wk[(size_t)(hd + q) * D + j] * Q[hd + q]; a[q] = dA[(size_t)((hd + q) / DK) * C + c]; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += (double)w[q] * (double)a[q];
+        }
+        for (; hd < NH * DK; ++hd)
             s += (double)Wk[(size_t)hd * D + j] * (double)Q[hd] * (double)dA[(size_t)(hd / DK) * C + c];
         dWi[(size_t)j * C + c] = (float)(s * sc);
     }
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int h = 0; h < NH; ++h) {
-            double sb = 0.0;
-            for (int n = 0; n < NF; ++n) sb += (double)LF_DB(h, n);
-            for (int d = 0; d < DK; ++d) s += (double)Wk[(size_t)(h * DK + d) * D + j] * (double)Q[h * DK + d] * sb;
-        }
-        dbi[j] = (float)(s * sc);
+    // d b_i[j] = sc * sum_hd Wk[hd][j] Q[hd] sB[h]: the block's threads take one hd each, fixed-order tree sum
+    __shared__ double red[256];
+    double v = 0.0;
+    for (int hd = threadIdx.x; hd < NH * DK; hd += 256) v += (double)Wk[(size_t)hd * D + j] * (double)Q[hd] * (double)sBv[hd / DK];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) dbi[j] = (float)(red[0] * sc);
+    (void)NF; (void)T;
 }
 
 extern "C" int uncr_ltae_fused_supported(int T, int C, int NH, int S) {
-    return (T >= 1 && T <= 16 && NH >= 4 && NH <= 32 && NH % 4 == 0 && C % NH == 0 && C <= 256 && S % LF_PX == 0) ? 1 : 0;
+    if (!(NH == 4 || NH == 8 || NH == 16 || NH == 32) || C % NH || C > 256 || T < 1 || T > 16) return 0;
+    const int cg = C / NH;
+    if (!(cg == 2 || cg == 4 || cg == 8 || cg == 16) || T * cg > 128) return 0;      // T x CG values live in registers
+    if (S % (256 / NH)) return 0;
+    // backward LDS: A' + the pixels' score gradients + the four waves' partials
+    const size_t lds = ((size_t)NH * C * 5 + (size_t)(256 / NH) * NH * T + 4 * (size_t)NH * T) * sizeof(float);
+    return lds <= 64 * 1024 ? 1 : 0;
 }
 
 extern "C" int uncr_ltae_compose(const float* Q, const float* Wk, const float* bk, const float* Wi, const float* bias1,
@@ -346,32 +410,40 @@ extern "C" int uncr_ltae_compose(const float* Q, const float* Wk, const float* b
     return UNCR_OK;
 }
 
+static size_t lf_lds(const LfArgs& g, bool bwd) {
+    const int ppb = 256 / g.NH;
+    size_t f = (size_t)g.NH * g.C;
+    if (bwd) f += (size_t)ppb * g.NH * g.T + 4 * (size_t)g.NH * g.C + 4 * (size_t)g.NH * g.T;
+    return f * sizeof(float);
+}
 template <int TMAX>
-static void lf_launch(const LfArgs& g, bool bwd, hipStream_t stream) {
-    const dim3 grid(g.S / LF_PX, g.B);
-    const size_t lds = (size_t)g.NH * g.C * sizeof(float) + (bwd ? (size_t)g.NH * g.T * LF_PX * sizeof(float) : 0);
-#define LF_GO(HPW)                                                                                                   \
+static int lf_launch(const LfArgs& g, bool bwd, hipStream_t stream) {
+    const int ppb = 256 / g.NH;
+    const dim3 grid((unsigned)((long long)g.B * g.S / ppb));
+    const size_t lds = lf_lds(g, bwd);
+#define LF_GO(CGV)                                                                                                   \
     do {                                                                                                             \
-        if (bwd) hipLaunchKernelGGL((ltae_fused_bwd_kernel<TMAX, HPW>), grid, dim3(256), lds, stream, g);            \
-        else hipLaunchKernelGGL((ltae_fused_fwd_kernel<TMAX, HPW>), grid, dim3(256), lds, stream, g);                \
+        if (bwd) hipLaunchKernelGGL((ltae_fused_bwd_kernel<TMAX, CGV>), grid, dim3(256), lds, stream, g);            \
+        else hipLaunchKernelGGL((ltae_fused_fwd_kernel<TMAX, CGV>), grid, dim3(256), lds, stream, g);                \
     } while (0)
-    switch (g.NH / 4) {
-        case 1: LF_GO(1); break;
+    switch (g.C / g.NH) {
         case 2: LF_GO(2); break;
         case 4: LF_GO(4); break;
-        default: LF_GO(8); break;
+        case 8: LF_GO(8); break;
+        case 16: LF_GO(16); break;
+        default: return UNCR_ESHAPE;
     }
 #undef LF_GO
+    return UNCR_OK;
 }
 
 extern "C" int uncr_ltae_fused_fwd(const float* x, const float* Ap, const float* Bp, const int* pad, float eps, float* att,
                                    float* mean, float* rstd, int B, int T, int C, int NH, int S, hipStream_t stream) {
-    if (!uncr_ltae_fused_supported(T, C, NH, S) || B <= 0 || (NH != 4 && NH != 8 && NH != 16 && NH != 32)) return UNCR_ESHAPE;
+    if (!uncr_ltae_fused_supported(T, C, NH, S) || B <= 0 || false) return UNCR_ESHAPE;
     if (!x || !Ap || !Bp || !att || !mean || !rstd) return UNCR_EINVAL;
     LfArgs g{x, Ap, Bp, pad, att, mean, rstd, nullptr, nullptr, nullptr, nullptr, B, T, C, NH, S, eps};
-    if (T <= 4) lf_launch<4>(g, false, stream);
-    else if (T <= 8) lf_launch<8>(g, false, stream);
-    else lf_launch<16>(g, false, stream);
+    const int rc = T <= 4 ? lf_launch<4>(g, false, stream) : (T <= 8 ? lf_launch<8>(g, false, stream) : lf_launch<16>(g, false, stream));
+    if (rc) return rc;
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -379,14 +451,12 @@ extern "C" int uncr_ltae_fused_fwd(const float* x, const float* Ap, const float*
 extern "C" int uncr_ltae_fused_bwd(const float* datt, const float* att, const float* x, const float* Ap, const int* pad,
                                    const float* mean, const float* rstd, float* dx, float* partA, float* partB, int B, int T,
                                    int C, int NH, int S, hipStream_t stream) {
-    if (!uncr_ltae_fused_supported(T, C, NH, S) || B <= 0 || (NH != 4 && NH != 8 && NH != 16 && NH != 32)) return UNCR_ESHAPE;
+    if (!uncr_ltae_fused_supported(T, C, NH, S) || B <= 0 || false) return UNCR_ESHAPE;
     if (!datt || !att || !x || !Ap || !mean || !rstd || !dx || !partA || !partB) return UNCR_EINVAL;
-    if ((size_t)NH * C * 4 + (size_t)NH * T * LF_PX * 4 > 64 * 1024) return UNCR_ESHAPE;
     LfArgs g{x, Ap, nullptr, pad, const_cast<float*>(att), const_cast<float*>(mean), const_cast<float*>(rstd), datt, dx, partA,
              partB, B, T, C, NH, S, 0.f};
-    if (T <= 4) lf_launch<4>(g, true, stream);
-    else if (T <= 8) lf_launch<8>(g, true, stream);
-    else lf_launch<16>(g, true, stream);
+    const int rc = T <= 4 ? lf_launch<4>(g, true, stream) : (T <= 8 ? lf_launch<8>(g, true, stream) : lf_launch<16>(g, true, stream));
+    if (rc) return rc;
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -395,18 +465,20 @@ extern "C" int uncr_ltae_fused_bwd(const float* datt, const float* att, const fl
 // contributions: sum over h with uncr_colsum), scratch dA [NH][C]
 extern "C" int uncr_ltae_compose_bwd(const float* Q, const float* Wk, const float* Wi, const float* bias1, const float* gamma,
                                      const float* beta, const float* M, const float* U, const float* dAp, const float* dBp,
-                                     int NH, int DK, int D, int C, int NF, int T, float* dA, float* dQ, float* dWk,
-                                     float* dbk, float* dWi, float* dbi, float* dgb, hipStream_t stream) {
+                                     int NH, int DK, int D, int C, int NF, int T, float* dA /* scratch [NH][C] + [NH] */,
+                                     float* dQ, float* dWk, float* dbk, float* dWi, float* dbi, float* dgb,
+                                     hipStream_t stream) {
     if (NH <= 0 || DK <= 0 || D <= 0 || C <= 0 || NF <= 0 || T <= 0 || NF % T) return UNCR_ESHAPE;
     if (!Q || !Wk || !Wi || !bias1 || !gamma || !beta || !M || !U || !dAp || !dBp || !dA || !dQ || !dWk || !dbk || !dWi || !dbi || !dgb)
         return UNCR_EINVAL;
     hipLaunchKernelGGL(ltae_compose_bwd_a_kernel, dim3(NH), dim3(256), 0, stream, Q, M, U, gamma, beta, dAp, dBp, DK, C, NF, T, dA,
-                       dQ, dgb);
+                       dQ, dgb, dA + (size_t)NH * C);
     UNCR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ltae_compose_bwd_wk_kernel, dim3(NH * DK), dim3(256), 0, stream, Q, Wi, bias1, dA, dBp, DK, D, C, NF, T, dWk,
-                       dbk);
+    hipLaunchKernelGGL(ltae_compose_bwd_wk_kernel, dim3(NH * DK), dim3(256), 0, stream, Q, Wi, bias1, dA, dBp, dA + (size_t)NH * C, DK, D,
+                       C, NF, T, dWk, dbk);
     UNCR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ltae_compose_bwd_wi_kernel, dim3(D), dim3(256), 0, stream, Q, Wk, dA, dBp, NH, DK, D, C, NF, T, dWi, dbi);
+    hipLaunchKernelGGL(ltae_compose_bwd_wi_kernel, dim3(D), dim3(256), 0, stream, Q, Wk, dA, dA + (size_t)NH * C, NH, DK, D, C, NF, T, dWi,
+                       dbi);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -794,7 +794,7 @@ def ltae_attention_backward_fused(datt: Tensor, sv: dict, p: Dict[str, Tensor], 
     B, T, C, S, D, HK = sv["dims"]
     dev = datt.device
     NF = B * T
-    nblk = S // 64
+    nblk = S * n_head // 256          # blocks per sample (256 / n_head pixels each)
     ddown = _f32((NF, C, S), dev)
     partA, partB = _f32((B * nblk, n_head, C), dev), _f32((B * nblk, n_head, T), dev)
     hb.call("uncr_ltae_fused_bwd", datt.contiguous(), sv["att"], sv["down"], sv["Ap"], sv["pad"], sv["mean"], sv["rstd"], ddown,
@@ -803,7 +803,7 @@ def ltae_attention_backward_fused(datt: Tensor, sv: dict, p: Dict[str, Tensor], 
     hb.call("uncr_colsum", partA, B * nblk, n_head * C, dAp, _stream())
     for b in range(B):          # d B' per sample: the blocks of sample b
         hb.call("uncr_colsum", partB[b * nblk:(b + 1) * nblk], nblk, n_head * T, dBp[b], _stream())
-    dA, dQ = _f32((n_head, C), dev), _f32((n_head, d_k), dev)
+    dA, dQ = _f32((n_head * C + n_head,), dev), _f32((n_head, d_k), dev)      # dA: scratch [NH][C] + [NH]
     dWk, dbk, dWi, dbi = _f32((HK, D), dev), _f32((HK,), dev), _f32((D, C), dev), _f32((D,), dev)
     dgb = _f32((n_head, 2, C), dev)
     Wi, Wk = p["inconv_w"].reshape(D, C).contiguous(), p["fc_w"].contiguous()

@@ -112,6 +112,17 @@ class EventProfiler:
     def __init__(self, names):
         self.names = set(names)
         self.records = []          # (entry point, int-arg tuple, start event, end event)
+        self.scope = None          # while set (a tag), EVERY launch is timed and also listed in scope_records
+        self.scope_records = []    # (tag, start event, end event)
+
+    def scope_ms(self):
+        """-> {tag: summed kernel milliseconds} of the launches made while a scope tag was set."""
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for tag, e0, e1 in self.scope_records:
+            out[tag] = out.get(tag, 0.0) + e0.elapsed_time(e1)
+        return out
 
     def summarize(self):
         import torch
@@ -145,14 +156,17 @@ def call(name: str, *args):
             conv.append(_ptr(a) if typ != "hipStream_t" else a)
         else:
             conv.append(a)
-    if _PROF is not None and name in _PROF.names:
+    if _PROF is not None and (name in _PROF.names or _PROF.scope is not None):
         import torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = f(*conv)
         e1.record()
-        key = tuple(a for a, (typ, _) in zip(args, proto) if typ == "int")
-        _PROF.records.append((name, key, e0, e1))
+        if name in _PROF.names:
+            key = tuple(a for a, (typ, _) in zip(args, proto) if typ == "int")
+            _PROF.records.append((name, key, e0, e1))
+        if _PROF.scope is not None:
+            _PROF.scope_records.append((_PROF.scope, e0, e1))
     else:
         rc = f(*conv)
     if rc != 0:
