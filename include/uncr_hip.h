@@ -208,6 +208,11 @@ int uncr_residual_pool(const void* x, const void* h3, const float* cA, const flo
                        float* down, int* idx, int planes, int H, int W, int OH, int OW, int act, hipStream_t stream);
 int uncr_maxpool_bwd(const float* dout, const int* idx, void* din, int planes, int H, int W, int OH, int OW, int act,
                      hipStream_t stream);
+/* uncr_maxpool_bwd fused with the (sum de, sum de*h3) statistics pass of the last encoder block's backward: one pass over de and
+ * h3 (the h3 of the block that produced the pooled tensor); part [planes][P/1024][2].  Disjoint windows, (W/OW) % 4 == 0. */
+int uncr_pool_scatter_stats_supported(int H, int W, int OH, int OW);
+int uncr_pool_scatter_stats(const float* dpool, const int* idx, void* de, const void* h3, float* part, int planes, int H, int W,
+                            int OH, int OW, int act, hipStream_t stream);
 int uncr_ltae_gn_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean,
                      float* rstd, int B, int T, int C, int G, int S, hipStream_t stream);
 int uncr_ltae_gn_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,

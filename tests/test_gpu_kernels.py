@@ -741,3 +741,26 @@ def test_bf16_split_accuracy(K):
     print(f"[parity] bf16 split K={K}: six products {errs[6]:.2e}, three products {errs[3]:.2e}, CPU fp32 matmul {e32:.2e}")
     assert errs[6] <= (1e-6 if K <= 256 else 3e-6), errs
     assert errs[3] > 4 * errs[6]          # the three dropped cross terms are what buys fp32-grade accuracy
+
+
+@pytest.mark.parametrize("H,W,bf", [(64, 64, False), (256, 256, False), (64, 128, True)])
+def test_pool_scatter_fused_with_statistics(E, H, W, bf):
+    """uncr_pool_scatter_stats = uncr_maxpool_bwd followed by the (sum de, sum de*h3) statistics pass, in one kernel."""
+    import uncrtaints_amd.hip_backend as hb
+    planes = 6
+    dt = torch.bfloat16 if bf else torch.float32
+    e = dev(rand(planes, H, W, seed=1)).to(dt)
+    down, idx = E.maxpool_forward(e, 32, 32)
+    de0 = dev(rand(planes, H, W, seed=2)).to(dt)
+    h3 = dev(rand(planes, H, W, seed=3)).to(dt)
+    dd = dev(rand(planes, 32, 32, seed=4))
+    ref = de0.clone()
+    E.maxpool_backward_into(dd, idx, ref, H, W, 32, 32)
+    ref_part = E.stats_aux(ref, h3, planes, H * W)
+    got = de0.clone()
+    assert hb.query("uncr_pool_scatter_stats_supported", H, W, 32, 32) == 1
+    slots = hb.query("uncr_ew_slots", H * W)
+    part = torch.empty(planes, slots, 2, device=DEV)
+    hb.call("uncr_pool_scatter_stats", dd, idx, got, h3, part, planes, H, W, 32, 32, 1 if bf else 0, E._stream())
+    assert torch.equal(got, ref)
+    close("pool_scatter_stats/part", part.double().sum(1), ref_part.buf.double().sum(1), tol=2e-6)

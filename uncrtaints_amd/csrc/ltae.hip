@@ -135,6 +135,46 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// The pooled-gradient scatter fused with the statistics pass the last encoder block's backward needs anyway:
+//   de[plane][argmax] += dpooled   and   part = (sum de, sum de*h3) of the UPDATED tensor, in one pass over de and h3
+// (the stand-alone scatter is a sparse read-modify-write of its own, 52 us at the bench shape).  Disjoint windows whose width is a
+// multiple of 4 (a thread's four pixels share a window): H % OH == 0, W % OW == 0, (W / OW) % 4 == 0.  grid = (P/1024, planes).
+template <typename T>
+__global__ __launch_bounds__(256) void pool_scatter_stats_kernel(const float* __restrict__ dpool, const int* __restrict__ idx,
+                                                                 T* __restrict__ de, const T* __restrict__ h3,
+                                                                 float2* __restrict__ part, int H, int W, int OH, int OW) {
+    const int plane = blockIdx.y;
+    const int p = blockIdx.x * 1024 + threadIdx.x * 4;
+    const size_t off = (size_t)plane * H * W + p;
+    float4 v = ld4<T>(de + off);
+    const float4 hv = ld4<T>(h3 + off);
+    const int y = p / W, x0 = p - y * W;
+    const size_t q = (size_t)plane * OH * OW + (size_t)(y / (H / OH)) * OW + x0 / (W / OW);
+    const int k = idx[q] - p;                 // position of the window's arg-max relative to this thread's pixels
+    if (k >= 0 && k < 4) {
+        ((float*)&v)[k] += dpool[q];
+        v = rnd4<T>(v);
+        st4<T>(de + off, v);
+    }
+    float s0 = (v.x + v.y) + (v.z + v.w);
+    float s1 = fmaf(v.x, hv.x, fmaf(v.y, hv.y, fmaf(v.z, hv.z, v.w * hv.w)));
+    __shared__ float red[8];
+    block_sum2<256>(s0, s1, red);
+    if (threadIdx.x == 0) part[(size_t)plane * gridDim.x + blockIdx.x] = make_float2(s0, s1);
+}
+extern "C" int uncr_pool_scatter_stats_supported(int H, int W, int OH, int OW) {
+    return (OH > 0 && OW > 0 && H % OH == 0 && W % OW == 0 && ((W / OW) & 3) == 0 && ((H * W) % 1024) == 0) ? 1 : 0;
+}
+extern "C" int uncr_pool_scatter_stats(const float* dpool, const int* idx, void* de, const void* h3, float* part, int planes,
+                                       int H, int W, int OH, int OW, int act, hipStream_t stream) {
+    if (planes <= 0 || !uncr_pool_scatter_stats_supported(H, W, OH, OW)) return UNCR_ESHAPE;
+    if (!dpool || !idx || !de || !h3 || !part || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
+    UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(pool_scatter_stats_kernel<T>, dim3(H * W / 1024, planes), dim3(256), 0, stream,
+                                                 dpool, idx, (T*)de, (const T*)h3, (float2*)part, H, W, OH, OW));
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-pixel GroupNorm over (Cg channels x T dates)  (ltae.py:191-194,211; n_head groups)
 // x [B][T][C][S] (S = low-res pixels), thread = (b, g, s)

@@ -1071,30 +1071,46 @@ def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor]
                    vp=values["p"]), gpart, att
 
 
-def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int, d_k: int):
+def _pool_scatter(ddown: Tensor, sv: dict, de: Tensor, e_h3: Optional[Tensor]) -> Optional[Part]:
+    """de[argmax] += d(pooled).  With the h3 of the block that produced the pooled tensor this also returns the (sum de, sum de*h3)
+    partials that block's backward needs (one fused pass instead of a sparse scatter + a statistics pass)."""
+    H, W = de.shape[-2:]
+    ad = sv["att_down"]
+    planes = de.numel() // (H * W)
+    if e_h3 is not None and e_h3.numel() == de.numel() and e_h3.dtype == de.dtype \
+            and hb.query("uncr_pool_scatter_stats_supported", H, W, ad, ad) == 1:
+        slots = hb.query("uncr_ew_slots", H * W)
+        part = Part(_f32((planes, slots, 2), de.device), slots)
+        hb.call("uncr_pool_scatter_stats", ddown.contiguous(), sv["idx"], de, e_h3, part.buf, planes, H, W, ad, ad, _dt(de),
+                _stream())
+        return part
+    maxpool_backward_into(ddown, sv["idx"], de, H, W, ad, ad)
+    return None
+
+
+def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int, d_k: int, e_h3: Optional[Tensor] = None):
+    """-> (de, {param grads}, partials (sum de, sum de*h3) or None).  e_h3: h3 of the block that produced e."""
     if "val" in sv:     # use_v: include_v -> (aggregation, values) -> attention
         dg0, dv, dWinc, dbinc = include_v_backward(dg, sv["inc"])
         de, datt = aggregate_backward(dg0, sv["agg"])
         dy1, datt_v, gv = ltae_values_backward(dv.reshape(dv.shape[0], dv.shape[1], -1), sv["val"], sv["vp"], n_head)
         hb.call("uncr_add", datt, datt_v, datt, datt.numel(), _stream())
         ddown, g = ltae_attention_backward(datt, sv["att"], p, n_head, d_k, dy1_extra=dy1)
-        H, W = de.shape[-2:]
-        maxpool_backward_into(ddown, sv["idx"], de, H, W, sv["att_down"], sv["att_down"])
+        part = _pool_scatter(ddown, sv, de, e_h3)
         g.update(gv)
         g["include_w"], g["include_b"] = dWinc, dbinc
-        return de, g
+        return de, g, part
     de, datt = aggregate_backward(dg, sv["agg"])
     mode = sv.get("mode", "att_group")
     if mode == "mean":
         # the attention does not reach the output: no gradient to the temporal encoder (returned as zeros)
         g = {k: torch.zeros_like(v) for k, v in p.items()}
-        return de, g
+        return de, g, None
     if mode == "att_mean":
         datt = head_mean_attention_backward(datt)
     ddown, g = ltae_attention_backward(datt, sv["att"], p, n_head, d_k)
-    H, W = de.shape[-2:]
-    maxpool_backward_into(ddown, sv["idx"], de, H, W, sv["att_down"], sv["att_down"])
-    return de, g
+    part = _pool_scatter(ddown, sv, de, e_h3)
+    return de, g, part
 
 
 # ------------------------------------------------------------------------------------------------

@@ -277,8 +277,13 @@ class _StageFn(torch.autograd.Function):
     """max-pool + L-TAE attention + aggregation as one autograd node (uncrtaints.py:402-412)."""
 
     @staticmethod
-    def forward(ctx, e, dates, pad, net, dmask, *params):
+    def forward(ctx, e4, dates, pad, net, dmask, b, t, *params):
+        # e4: the encoder output on the folded frames [B*T, C, H, W] (no autograd view between the encoder and this node, so the
+        # statistics / pooled values riding on the tensors survive in both directions)
         p = dict(zip(_LTAE_KEYS, params))
+        e = e4.contiguous().view(b, t, *e4.shape[1:])
+        ctx.e_h3 = getattr(e4, "_uncr_h3", None)
+        ctx.bt = (b, t)
         te, agg = net.temporal_encoder, net.temporal_aggregator
         denom = te.positional_encoder.denom_on(e.device) if te.positional_encoder is not None else None
         want_stats = net.out_block[0]._spec.needs_stats(net.training)
@@ -296,7 +301,7 @@ class _StageFn(torch.autograd.Function):
         g, sv, gpart, att = E.ltae_stage_forward(e.contiguous(), dates, pad, p, denom, te.n_head,
                                                  te.attention_heads.d_k, 32, net.training, agg.attn_dropout.p,
                                                  agg._next_seed(), dmask, want_stats, mode=agg.mode, values=values,
-                                                 pooled=getattr(e, "_uncr_pooled", None))
+                                                 pooled=getattr(e4, "_uncr_pooled", None))
         if ctx.use_v and net.training:
             te.mlp[1].num_batches_tracked += 1
         ctx.sv, ctx.p, ctx.te = sv, p, te
@@ -307,11 +312,14 @@ class _StageFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dg):
-        de, g = E.ltae_stage_backward(dg, ctx.sv, ctx.p, ctx.te.n_head, ctx.te.attention_heads.d_k)
+        de, g, part = E.ltae_stage_backward(dg, ctx.sv, ctx.p, ctx.te.n_head, ctx.te.attention_heads.d_k, e_h3=ctx.e_h3)
         grads = tuple(g[k] for k in _LTAE_KEYS)
         if ctx.use_v:
             grads += tuple(g[k] for k in _LTAEV_KEYS) + (g["include_w"], g["include_b"])
-        return (de, None, None, None, None) + grads
+        b, t = ctx.bt
+        de4 = de.view(b * t, *de.shape[2:])
+        E.tag_part(de4, part)          # (sum de, sum de*h3) for the last encoder block's norm-3 backward
+        return (de4, None, None, None, None, None, None) + grads
 
 
 class _CastFn(torch.autograd.Function):
@@ -552,9 +560,7 @@ class UNCRTAINTS(nn.Module):
             x4 = layer(x4)
             pooled = getattr(x4, "_uncr_pooled", None)
         part = getattr(x4, "_uncr_part", None)
-        out = x4.view(b, t, x4.shape[1], h, w)
-        if pooled is not None:
-            out._uncr_pooled = pooled
+        out = x4
         if not self.is_mono:
             if self.temporal_encoder.positional_encoder is not None and batch_positions is None:
                 raise ValueError("batch_positions (dates) are required when positional_encoding=True")
@@ -565,17 +571,14 @@ class UNCRTAINTS(nn.Module):
                 extra = [vp[k] for k in _LTAEV_KEYS] + [self.include_v.weight, self.include_v.bias]
             if self.keep_boundaries:
                 self._boundary_enc = out
-            out = _StageFn.apply(out, batch_positions, pad, self, self.temporal_aggregator.dropout_mask,
+            out = _StageFn.apply(out, batch_positions, pad, self, self.temporal_aggregator.dropout_mask, b, t,
                                  *([p[k] for k in _LTAE_KEYS] + extra))
             if self.keep_boundaries:
                 self._boundary_agg = out
         else:                                                              # uncrtaints.py:418
-            if out.shape[1] != 1:
+            if t != 1:
                 raise ValueError("is_mono expects a single input date (T == 1)")
-            part = getattr(out, "_uncr_part", None) or part
-            out = out.squeeze(dim=1)
-            if part is not None:
-                out._uncr_part = part
+            # B*1 folded frames ARE the [B, C, H, W] decoder input (out.squeeze(dim=1) of the 5-D view in the reference)
         for layer in self.out_block:
             out = layer.smart_forward(out)
         if self.separate_out:
