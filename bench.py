@@ -363,6 +363,9 @@ def main():
         eager_step(); fence()
         if want_events:
             prof = hb.EventProfiler(PROFILED)
+            # the fused pooled-gradient scatter + (sum de, sum de*h3) pass replaces the last encoder block's own statistics pass
+            # (a full read of de and h3 that block needs with or without the L-TAE stage): attributed to that block, not the stage
+            prof.scope_exclude.add("uncr_pool_scatter_stats")
             hb.set_profiler(prof)
         t1 = time.perf_counter()
         for _ in range(n_ev):

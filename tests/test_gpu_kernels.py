@@ -743,7 +743,7 @@ def test_bf16_split_accuracy(K):
     assert errs[3] > 4 * errs[6]          # the three dropped cross terms are what buys fp32-grade accuracy
 
 
-@pytest.mark.parametrize("H,W,bf", [(64, 64, False), (256, 256, False), (64, 128, True)])
+@pytest.mark.parametrize("H,W,bf", [(128, 128, False), (256, 256, False), (64, 128, True)])
 def test_pool_scatter_fused_with_statistics(E, H, W, bf):
     """uncr_pool_scatter_stats = uncr_maxpool_bwd followed by the (sum de, sum de*h3) statistics pass, in one kernel."""
     import uncrtaints_amd.hip_backend as hb
@@ -759,6 +759,7 @@ def test_pool_scatter_fused_with_statistics(E, H, W, bf):
     ref_part = E.stats_aux(ref, h3, planes, H * W)
     got = de0.clone()
     assert hb.query("uncr_pool_scatter_stats_supported", H, W, 32, 32) == 1
+    assert hb.query("uncr_pool_scatter_stats_supported", 64, 64, 32, 32) == 0      # 2-pixel windows: the separate kernels
     slots = hb.query("uncr_ew_slots", H * W)
     part = torch.empty(planes, slots, 2, device=DEV)
     hb.call("uncr_pool_scatter_stats", dd, idx, got, h3, part, planes, H, W, 32, 32, 1 if bf else 0, E._stream())

@@ -113,14 +113,17 @@ class EventProfiler:
         self.names = set(names)
         self.records = []          # (entry point, int-arg tuple, start event, end event)
         self.scope = None          # while set (a tag), EVERY launch is timed and also listed in scope_records
-        self.scope_records = []    # (tag, start event, end event)
+        self.scope_records = []    # (tag, entry point, start event, end event)
+        self.scope_exclude = set() # entry points left out of scope_ms()
 
     def scope_ms(self):
         """-> {tag: summed kernel milliseconds} of the launches made while a scope tag was set."""
         import torch
         torch.cuda.synchronize()
         out = {}
-        for tag, e0, e1 in self.scope_records:
+        for tag, name, e0, e1 in self.scope_records:
+            if name in self.scope_exclude:
+                continue
             out[tag] = out.get(tag, 0.0) + e0.elapsed_time(e1)
         return out
 
@@ -166,7 +169,7 @@ def call(name: str, *args):
             key = tuple(a for a, (typ, _) in zip(args, proto) if typ == "int")
             _PROF.records.append((name, key, e0, e1))
         if _PROF.scope is not None:
-            _PROF.scope_records.append((_PROF.scope, e0, e1))
+            _PROF.scope_records.append((_PROF.scope, name, e0, e1))
     else:
         rc = f(*conv)
     if rc != 0:
