@@ -318,8 +318,9 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void pw_wgrad_kernel(WgArgs g) {
     }
     __syncthreads();
 
-    // staging registers: with both operands in flight at once the big shapes spill, so the X loads are issued
-    // after the D tile has been staged whenever the total exceeds 12 float4 per lane
+    // Register-level software pipeline: the raw tiles of chunk ch+1 are requested right after chunk ch has been staged, so their
+    // HBM latency runs under chunk ch's MFMA phase (one exposed round trip per chunk before: the narrow in_conv shape, 128 x 15 at
+    // N = 12, sat at 2.0 TB/s).  Shapes whose raw tiles exceed 12 float4 per lane keep the two-step order (register budget).
     constexpr bool SPLIT = (ND * (D2 ? 2 : 1) + NX) > 12;
     float4 dv[ND], dv2[D2 ? ND : 1], xv[NX];
     auto issue_d = [&](int ch) {
@@ -327,13 +328,10 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void pw_wgrad_kernel(WgArgs g) {
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int row = lrow + i * RSTEP;
-            if (row < Cd) {
-                dv[i] = ld4<TD>(dbase + (size_t)row * P + p0);
-                if constexpr (D2) {
-                    if (pro_d == PRO_NORMBWD) dv2[i] = ld4<TD>(d2base + (size_t)row * P + p0);
-                }
-            } else {
-                dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int rr = row < Cd ? row : 0;            // rows past Cd re-read row 0 (branch-free) and are zeroed at staging
+            dv[i] = ld4<TD>(dbase + (size_t)rr * P + p0);
+            if constexpr (D2) {
+                if (pro_d == PRO_NORMBWD) dv2[i] = ld4<TD>(d2base + (size_t)rr * P + p0);
             }
         }
     };
@@ -342,29 +340,43 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void pw_wgrad_kernel(WgArgs g) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int row = lrow + i * RSTEP;
-            xv[i] = row < Cx ? ld4<TX>(xbase + (size_t)row * P + p0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[i] = ld4<TX>(xbase + (size_t)(row < Cx ? row : 0) * P + p0);
         }
     };
-
-    for (int ch = 0; ch < nchunks; ++ch) {
-        // all global loads of an operand tile are issued back-to-back (one or two latency exposures per chunk;
-        // the other resident block's MFMA phase covers them), then transformed and staged
-        issue_d(ch);
-        if constexpr (!SPLIT) issue_x(ch);
+    auto stage_d = [&]() {
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int row = lrow + i * RSTEP;
-            float4 v = dv[i];
-            if (row < Cd) v = apply_pro(pro_d, v, D2 ? dv2[D2 ? i : 0] : v, cfd[row], cfd[COP + row], cfd[2 * COP + row], cfd[3 * COP + row]);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < Cd) v = apply_pro(pro_d, dv[i], D2 ? dv2[D2 ? i : 0] : dv[i], cfd[row], cfd[COP + row], cfd[2 * COP + row], cfd[3 * COP + row]);
             *(float4*)&ds[row * PITCH + 4 * lc4] = v;
         }
-        if constexpr (SPLIT) issue_x(ch);
+    };
+    auto stage_x = [&]() {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int row = lrow + i * RSTEP;
-            float4 v = xv[i];
-            if (row < Cx) v = apply_pro(pro_x, v, v, cfx[row], cfx[CIP + row], cfx[2 * CIP + row]);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < Cx) v = apply_pro(pro_x, xv[i], xv[i], cfx[row], cfx[CIP + row], cfx[2 * CIP + row]);
             *(float4*)&xs[row * PITCH + 4 * lc4] = v;
+        }
+    };
+
+    if constexpr (!SPLIT) { issue_d(0); issue_x(0); }
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if constexpr (SPLIT) {
+            // all global loads of an operand tile are issued back-to-back (two latency exposures per chunk; the other resident
+            // block's MFMA phase covers them), then transformed and staged
+            issue_d(ch);
+            stage_d();
+            issue_x(ch);
+            stage_x();
+        } else {
+            stage_d();
+            stage_x();
+            const int nx = ch + 1 < nchunks ? ch + 1 : ch;      // clamped: the last prefetch re-reads the last chunk
+            issue_d(nx);
+            issue_x(nx);
         }
         __syncthreads();
         if (g.rs_part && tid < COP) {
