@@ -361,7 +361,9 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
     f = _store(x.reshape(B * T, Cin, H, W), bf)                           # smart_forward, utae.py:422-450
     c0 = _store(conv1x1(f, p["in_conv.conv.conv.0.weight"], p["in_conv.conv.conv.0.bias"]), bf)
     a0 = _store(torch.relu(_NormCtx(p, cfg.encoder_norm, training, update_running)(c0, "in_conv.conv.conv.1")), bf)   # utae.py:463-473
-    e = _block(a0, p, "in_block.0", cfg.encoder_norm, training, update_running, taps, cfg)
+    e = a0
+    for i in range(len(cfg.encoder_widths)):                              # one block per entry, uncrtaints.py:316-319, 399-400
+        e = _block(e, p, f"in_block.{i}", cfg.encoder_norm, training, update_running, taps, cfg)
     C = e.shape[1]
     if cfg.is_mono:
         g, down, attn = e.view(B, T, C, H, W).squeeze(dim=1), None, None
@@ -567,7 +569,8 @@ def init_params(cfg: OracleConfig, seed: int = 1) -> Dict[str, Tensor]:
     c = cfg.encoder_widths[0]
     p["in_conv.conv.conv.0.weight"], p["in_conv.conv.conv.0.bias"] = xavier(c, cfg.input_dim, 1, 1), randn(c)
     norm_params("in_conv.conv.conv.1", c, cfg.encoder_norm)
-    mb("in_block.0", c, cfg.encoder_norm)
+    for i, ci in enumerate(cfg.encoder_widths):
+        mb(f"in_block.{i}", ci, cfg.encoder_norm)
     p["temporal_encoder.inconv.weight"], p["temporal_encoder.inconv.bias"] = randn(cfg.d_model, c, 1), randn(cfg.d_model)
     p["temporal_encoder.attention_heads.Q"] = randn(cfg.n_head, cfg.d_k) * math.sqrt(2.0 / cfg.d_k)
     p["temporal_encoder.attention_heads.fc1_k.weight"] = xavier(cfg.n_head * cfg.d_k, cfg.d_model)

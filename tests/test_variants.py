@@ -15,6 +15,7 @@ VARIANTS = {
     "instance": dict(encoder_norm="instance", decoder_norm="instance"),     # nn.InstanceNorm2d everywhere (uncrtaints.py:19)
     "enc_batch": dict(encoder_norm="batch"),                                # BatchNorm2d in in_conv / in_block as well
     "elu": dict(out_nonlin_var="elu"),                                      # variance = elu(.) + 1 + eps (uncrtaints.py:226)
+    "two_enc": dict(encoder_widths=[128, 128]),                             # one MBConv per entry (uncrtaints.py:316-317)
 }
 
 
@@ -33,6 +34,9 @@ def variant_state(state, name):
             pre = k[:-len("weight")]
             st[pre + "running_mean"], st[pre + "running_var"] = torch.zeros_like(st[k]), torch.ones_like(st[k])
             st[pre + "num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    if name == "two_enc":       # the second encoder block takes out_block.1's weights (GroupNorm has no running statistics)
+        for k in [k for k in st if k.startswith("out_block.1.") and "running" not in k and "num_batches" not in k]:
+            st["in_block.1." + k[len("out_block.1."):]] = st[k].clone()
     if name == "instance":      # InstanceNorm2d has neither parameters nor buffers
         import re
         st = {k: v for k, v in st.items()

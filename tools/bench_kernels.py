@@ -108,6 +108,10 @@ def main():
         for _ in range(3):
             E.pw_gemm(x, Wt, N, Cin, Cout, P, pro=3, k=k, x2=x2, epi=3, aux=h2, ek=ek)          # fused dz + pass-B
             E.pw_gemm(x, Wt, N, Cin, Cout, P, pro=1, k=k, epi=1)                                # pw1 forward
+        Wt2 = E.pack_wt(torch.randn(Cin, Cout, device=dev) * 0.05, transpose=True)
+        k2f = tuple(torch.rand(N * Cout, device=dev) for _ in range(3))
+        for _ in range(3):
+            E.pw_gemm(h2, Wt2, N, Cout, Cin, P, pro=2, k=k2f, epi=1)                            # pw2 forward (SE scale + GELU prologue)
         # the two wide weight-gradient GEMMs of an MBConv backward
         d = torch.randn(N, 256, P, device=dev); d2 = torch.randn(N, 256, P, device=dev); xx = torch.randn(N, 128, P, device=dev)
         dk = tuple(torch.randn(N * 256, device=dev) for _ in range(3)); xk = (torch.randn(N * 128, device=dev), torch.randn(N * 128, device=dev), None)

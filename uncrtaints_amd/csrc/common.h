@@ -63,6 +63,56 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
 #endif
     return cdf + u * pdf;
 }
+// Two-wide forms on the packed fp32 VALU ops of gfx950 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE fp32 results per lane
+// per issue; per component the same operations in the same order as the scalar forms above, so the values are identical).  The
+// GELU-carrying prologues / epilogues of the streaming kernels were issue-bound on VALU (pw2 forward: 33 VALU instructions per
+// element, 19 of them the GELU; profiles/r02_pipes.json): the polynomial and the affine around it run packed, only min, v_exp_f32
+// and the sign transfer stay per component.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 f2(float a, float b) { f32x2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f32x2 f2(float a) { f32x2 r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 erf_f2(f32x2 x) {
+#ifdef UNCR_EXACT_ERF
+    return f2(erff(x.x), erff(x.y));
+#else
+    const f32x2 t = f2(fminf(fabsf(x.x), 4.0f), fminf(fabsf(x.y), 4.0f));
+    f32x2 q = f2(-1.16047604024061e-05f);
+    q = fma2(q, t, f2(0.00015296389756258577f));
+    q = fma2(q, t, f2(-0.0008482325938530266f));
+    q = fma2(q, t, f2(0.002274781931191683f));
+    q = fma2(q, t, f2(-8.480128599330783e-05f));
+    q = fma2(q, t, f2(-0.027724478393793106f));
+    q = fma2(q, t, f2(0.1483079046010971f));
+    q = fma2(q, t, f2(0.9184429049491882f));
+    q = fma2(q, t, f2(1.6279072761535645f));
+    const f32x2 a = -t * q;
+    return f2(copysignf(1.0f - __builtin_amdgcn_exp2f(a.x), x.x), copysignf(1.0f - __builtin_amdgcn_exp2f(a.y), x.y));
+#endif
+}
+__device__ __forceinline__ f32x2 gelu_f2(f32x2 u) {
+    return f2(0.5f) * u * (f2(1.0f) + erf_f2(u * f2(0.70710678118654752440f)));
+}
+__device__ __forceinline__ f32x2 gelu_grad_f2(f32x2 u) {
+    const f32x2 cdf = f2(0.5f) * (f2(1.0f) + erf_f2(u * f2(0.70710678118654752440f)));
+#ifdef UNCR_EXACT_EXP
+    const f32x2 pdf = f2(0.39894228040143267794f * expf(-0.5f * u.x * u.x), 0.39894228040143267794f * expf(-0.5f * u.y * u.y));
+#else
+    const f32x2 a = f2(-0.72134752044448170368f) * u * u;
+    const f32x2 pdf = f2(0.39894228040143267794f) * f2(__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y));
+#endif
+    return fma2(u, pdf, cdf);
+}
+// gelu(A*h + B) / gelu'(A*h + B) on the four values of a float4
+__device__ __forceinline__ float4 gelu_affine4(float A, float B, const float4& h) {
+    const f32x2 a = gelu_f2(fma2(f2(A), f2(h.x, h.y), f2(B))), b = gelu_f2(fma2(f2(A), f2(h.z, h.w), f2(B)));
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ float4 gelu_grad_affine4(float A, float B, const float4& h) {
+    const f32x2 a = gelu_grad_f2(fma2(f2(A), f2(h.x, h.y), f2(B))), b = gelu_grad_f2(fma2(f2(A), f2(h.z, h.w), f2(B)));
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+
 // Used by the output head (26 channels) and the squeeze-excite MLP only -- never on a bandwidth-critical stream -- so the accurate
 // expf.  The head needs it: a random-init MGNLL is dominated by the few pixels whose variance sits at the 1e-8 clamp, and there
 // the residual mean - target is a difference of O(1) numbers: the fast __expf's ~3e-7 relative error in the sigmoid reached every

@@ -90,9 +90,9 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         const float4 vb = ld_nt4t((const T*)g.b + off);
         const float* pb = (const float*)&vb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float u = fmaf(A, pb[i], B);
-            o[i] = gelu_grad_f(u) * fmaf(S, pa[i], D);
+        for (int i = 0; i < 4; i += 2) {
+            const f32x2 r = gelu_grad_f2(fma2(f2(A), f2(pb[i], pb[i + 1]), f2(B))) * fma2(f2(S), f2(pa[i], pa[i + 1]), f2(D));
+            o[i] = r.x; o[i + 1] = r.y;
         }
         vo = rnd4<T>(vo);
 #pragma unroll
@@ -124,8 +124,15 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         }
     } else if constexpr (OP == EW_SE_POOL) {
         const float A = g.k0[plane], B = g.k1[plane];
+        // polynomial and affine on the packed ops; the accumulation keeps the fused form s0 = fma(u/2, 1 + erf, s0) (one rounding
+        // per term)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s0 += gelu_f(fmaf(A, pa[i], B));
+        for (int i = 0; i < 4; i += 2) {
+            const f32x2 u = fma2(f2(A), f2(pa[i], pa[i + 1]), f2(B));
+            const f32x2 hu = f2(0.5f) * u, pe = f2(1.0f) + erf_f2(u * f2(0.70710678118654752440f));
+            s0 = fmaf(hu.x, pe.x, s0);
+            s0 = fmaf(hu.y, pe.y, s0);
+        }
     } else if constexpr (ew_is_head_fwd(OP)) {
         // n_mean > 0: first n_mean channels get scale*sigmoid; n_mean < 0: first |n_mean| channels identity
         const int ch = plane % g.C;

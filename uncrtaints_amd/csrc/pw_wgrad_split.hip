@@ -37,6 +37,16 @@ __device__ __forceinline__ float wgs_pro(float v, float v2, float c0, float c1, 
     else return v;
 }
 
+// two pixels of one row on the packed fp32 ops (same operations per component as wgs_pro)
+template <int PRO>
+__device__ __forceinline__ f32x2 wgs_pro2(f32x2 v, f32x2 v2, float c0, float c1, float c2, float c3 = 0.f) {
+    if constexpr (PRO == PRO_AFFINE) return fma2(f2(c0), v, f2(c1));
+    else if constexpr (PRO == PRO_AFFINE_GELU) return f2(c2) * gelu_f2(fma2(f2(c0), v, f2(c1)));
+    else if constexpr (PRO == PRO_NORMBWD) return fma2(f2(c0), v, fma2(f2(c1), v2 - f2(c3), f2(c2)));
+    else if constexpr (PRO == PRO_AFFINE_RELU) return f2(fmaxf(fmaf(c0, v.x, c1), 0.f), fmaxf(fmaf(c0, v.y, c1), 0.f));
+    else return v;
+}
+
 template <int WCO, int WCI, int PRO_D, int PRO_X>
 __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
     constexpr int NT = 512;
@@ -105,10 +115,11 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
         const float4 w = (isd && D2) ? dv2[D2 ? i : 0] : v;
         unsigned h[4], m[4], l[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float a = ((const float*)&v)[q], b = ((const float*)&w)[q];
-            const float t = isd ? wgs_pro<PRO_D>(a, b, c0, c1, c2, k3[isd ? i : 0]) : wgs_pro<PRO_X>(a, b, c0, c1, c2);
-            split3_bf16(t, h[q], m[q], l[q]);
+        for (int q = 0; q < 4; q += 2) {
+            const f32x2 a = f2(((const float*)&v)[q], ((const float*)&v)[q + 1]), b = f2(((const float*)&w)[q], ((const float*)&w)[q + 1]);
+            const f32x2 t = isd ? wgs_pro2<PRO_D>(a, b, c0, c1, c2, k3[isd ? i : 0]) : wgs_pro2<PRO_X>(a, b, c0, c1, c2);
+            split3_bf16(t.x, h[q], m[q], l[q]);
+            split3_bf16(t.y, h[q + 1], m[q + 1], l[q + 1]);
         }
         unsigned char* b = xs + buf * BUF + st_off + (row - lrow) * 16;
         *(u32x2_t*)(b) = u32x2_t{pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3])};

@@ -409,8 +409,10 @@ class UNCRTAINTS(nn.Module):
             raise NotImplementedError(f"agg_mode '{agg_mode}'")
         if padding_mode != "reflect":
             raise NotImplementedError("only padding_mode='reflect' is built")
-        if len(encoder_widths) != 1:
-            raise NotImplementedError("UNCRTAINTS uses a single encoder stage (encoder_widths=[C])")
+        if any(w != encoder_widths[0] for w in encoder_widths):
+            # the reference builds MBConv(w, w) per entry behind an in_conv of width encoder_widths[0] (uncrtaints.py:309-319): its
+            # forward only type-checks when all entries are equal
+            raise ValueError(f"encoder_widths {list(encoder_widths)}: every encoder block maps w -> w, so all entries must be equal")
 
         self.in_conv = ConvBlock(nkernels=[input_dim] + [encoder_widths[0]], k=1, s=1, p=0, norm=encoder_norm)
         if block_type == 'residual':      # uncrtaints.py:318-319
