@@ -205,6 +205,19 @@ template <typename T> __device__ __forceinline__ void st1(T* p, float v) {
     if constexpr (sizeof(T) == 4) *p = v;
     else *p = (bf16_t)(cvt_pk_bf16(v, 0.f) & 0xFFFFu);
 }
+// raw (not yet widened) four elements: prefetch rings keep these, so that a bf16 ring holds twice the rows in the same registers
+// and the widening shifts sit at the point of use, not behind the load
+template <typename T> struct raw4 { typedef float4 type; };
+template <> struct raw4<bf16_t> { typedef uncr_u2 type; };
+template <typename T, bool NT = false> __device__ __forceinline__ typename raw4<T>::type ld4raw(const T* p) {
+    if constexpr (sizeof(T) == 4) return ld4<T, NT>(p);
+    else {
+        if constexpr (NT) return __builtin_nontemporal_load((const uncr_u2*)p);
+        else return *(const uncr_u2*)p;
+    }
+}
+__device__ __forceinline__ float4 widen4(const float4& r) { return r; }
+__device__ __forceinline__ float4 widen4(const uncr_u2& r) { return make_float4(bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y)); }
 // the streamed-once forms follow the translation unit's UNCR_NT switch like ld_nt4 / st_nt4
 template <typename T> __device__ __forceinline__ float4 ld_nt4t(const T* p) { return ld4<T, (UNCR_NT != 0)>(p); }
 template <typename T> __device__ __forceinline__ void st_nt4t(T* p, const float4& v) { st4<T, (UNCR_NT != 0)>(p, v); }

@@ -11,6 +11,12 @@
 #include <cstdlib>
 
 #define DWR_TR 64
+#ifndef DWR_PK
+#define DWR_PK 0      // 1: GELU / norm-backward prologues on the packed fp32 ops (measured neutral in fp32 and bf16: -17 % VALU instructions, same time)
+#endif
+#ifndef DWR_DEPTH_BF
+#define DWR_DEPTH_BF 4     // bf16 storage: rows of raw loads in flight per wave
+#endif
 // loads / stores of the streamed tensors are non-temporal (ld_nt4 / st_nt4, common.h): every element is touched once, and
 // keeping it out of the caches' retention order is worth 15 % on the backward kernel inside the training step
 __device__ __forceinline__ float wf_sr1(float v, float border) {   // lane i <- lane i-1; lane 0 <- border
@@ -34,16 +40,29 @@ __device__ __forceinline__ Row6 row6_zero(const float4& d) {
     r.v[0] = wf_sr1(d.w, 0.f); r.v[1] = d.x; r.v[2] = d.y; r.v[3] = d.z; r.v[4] = d.w; r.v[5] = wf_sl1(d.x, 0.f);
     return r;
 }
-// gelu(u) and gelu'(u) of u = A*h + B from ONE erf: Phi = (1 + erf(u/sqrt2))/2, gelu = u*Phi, gelu' = Phi + u*phi(u)
+// gelu(u) and gelu'(u) of u = A*h + B from ONE erf: Phi = (1 + erf(u/sqrt2))/2, gelu = u*Phi, gelu' = Phi + u*phi(u); two values
+// at a time on the packed fp32 ops (common.h; per component the operations of the scalar forms)
+__device__ __forceinline__ void gelu_both2(float A, float B, f32x2 h, f32x2& gv, f32x2& gd) {
+    const f32x2 u = fma2(f2(A), h, f2(B));
+    const f32x2 cdf = f2(0.5f) * (f2(1.0f) + erf_f2(u * f2(0.70710678118654752440f)));
+    const f32x2 a = f2(-0.72134752044448170368f) * u * u;
+    const f32x2 pdf = f2(0.39894228040143267794f) * f2(__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y));
+    gv = u * cdf;
+    gd = fma2(u, pdf, cdf);
+}
+__device__ __forceinline__ float4 gelu4(float A, float B, const float4& h) {
+#if DWR_PK
+    return gelu_affine4(A, B, h);
+#else
+    return make_float4(gelu_f(fmaf(A, h.x, B)), gelu_f(fmaf(A, h.y, B)), gelu_f(fmaf(A, h.z, B)), gelu_f(fmaf(A, h.w, B)));
+#endif
+}
 __device__ __forceinline__ void gelu_both(float A, float B, float h, float& gv, float& gd) {
     const float u = fmaf(A, h, B);
     const float cdf = 0.5f * (1.0f + erf_f(u * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * u * u);
     gv = u * cdf;
     gd = fmaf(u, pdf, cdf);
-}
-__device__ __forceinline__ float4 gelu4(float A, float B, const float4& h) {
-    return make_float4(gelu_f(fmaf(A, h.x, B)), gelu_f(fmaf(A, h.y, B)), gelu_f(fmaf(A, h.z, B)), gelu_f(fmaf(A, h.w, B)));
 }
 
 // ---- forward: out = dw(reflectpad(gelu(A*in+B))), stats (sum, sum^2) per 32-row slot ----
@@ -66,15 +85,20 @@ __global__ __launch_bounds__(256) void dw_fwd_row_kernel(const T* __restrict__ i
     for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
     const T* src = in + (size_t)plane * H * W + 4 * lane;
     T* dst = out + (size_t)plane * H * W + 4 * lane;
-    auto ld = [&](int yy) { return ld_nt4t(src + (size_t)min(max(yy, 0), H - 1) * W); };
+    // raw prefetch ring: DEPTH rows in flight per wave (fp32: 2; bf16: 4 -- the same bytes in flight and the same registers)
+    constexpr int DEPTH = sizeof(T) == 2 ? DWR_DEPTH_BF : 2;
+    typedef typename raw4<T>::type RawT;
+    auto ldr = [&](int yy) { return ld4raw<T, (UNCR_NT != 0)>(src + (size_t)min(max(yy, 0), H - 1) * W); };
+    auto ld = [&](int yy) { return widen4(ldr(yy)); };
 
     // 4-slot ring of g rows (row y lives in slot (y - y0) & 3), the row loop unrolled x4 so that every slot index is
     // static: no register rotation.  Raw prefetch registers alternate with the row parity.
     Row6 gW[4];
-    float4 nx[2];
+    RawT nx[DEPTH];
     gW[3] = row6_reflect(gelu4(A, B, ld(reflect1(y0 - 1, H))));
     gW[0] = row6_reflect(gelu4(A, B, ld(y0)));
-    nx[0] = ld(y0 + 1); nx[1] = ld(y0 + 2);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) nx[d] = ldr(y0 + 1 + d);
     float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;   // (s) first 32-row slot of the tile, (t) second
     for (int Y = y0; Y < y1; Y += 4) {               // (y1 - y0) % 4 == 0 (launcher: H % 4 == 0)
 #pragma unroll
@@ -83,11 +107,11 @@ __global__ __launch_bounds__(256) void dw_fwd_row_kernel(const T* __restrict__ i
             constexpr int dummy = 0; (void)dummy;
             const int im = (s + 3) & 3, ic = s, ip = (s + 1) & 3;
             // row y+1 (reflect at the bottom edge: row H -> row H-2 = the ring's row y-1)
-            const Row6 gnew = row6_reflect(gelu4(A, B, nx[s & 1]));
+            const Row6 gnew = row6_reflect(gelu4(A, B, widen4(nx[s % DEPTH])));
             const bool inside = y + 1 < H;
 #pragma unroll
             for (int k = 0; k < 6; ++k) gW[ip].v[k] = inside ? gnew.v[k] : gW[im].v[k];
-            nx[s & 1] = ld(y + 3);
+            nx[s % DEPTH] = ldr(y + 1 + DEPTH);
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -147,25 +171,43 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
     const size_t pb = (size_t)plane * H * W + 4 * lane;
     struct Raw { float4 a, b, h; };
-    auto ld = [&](int yy) {
+    constexpr int DEPTH = sizeof(T) == 2 ? DWR_DEPTH_BF : 2;      // rows in flight per wave, see the forward kernel
+    typedef typename raw4<T>::type RawT;
+    struct Raw3 { RawT a, b, h; };
+    auto ldr = [&](int yy) {
         const size_t o = pb + (size_t)min(max(yy, 0), H - 1) * W;
-        return Raw{ld_nt4t(du2 + o), ld_nt4t(h2 + o), ld_nt4t(h1 + o)};
+        return Raw3{ld4raw<T, (UNCR_NT != 0)>(du2 + o), ld4raw<T, (UNCR_NT != 0)>(h2 + o), ld4raw<T, (UNCR_NT != 0)>(h1 + o)};
     };
+    auto wide = [&](const Raw3& r) { return Raw{widen4(r.a), widen4(r.b), widen4(r.h)}; };
+    auto ld = [&](int yy) { return wide(ldr(yy)); };
     auto dh2 = [&](const Raw& r, int yy) {   // zero outside the image
         const float m = (yy >= 0 && yy < H) ? 1.f : 0.f;
+#if DWR_PK
+        const f32x2 lo = f2(m) * fma2(f2(C1), f2(r.a.x, r.a.y), fma2(f2(C2), f2(r.b.x, r.b.y) - f2(M2), f2(C3)));
+        const f32x2 hi = f2(m) * fma2(f2(C1), f2(r.a.z, r.a.w), fma2(f2(C2), f2(r.b.z, r.b.w) - f2(M2), f2(C3)));
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
+#endif
         return make_float4(m * fmaf(C1, r.a.x, fmaf(C2, r.b.x - M2, C3)), m * fmaf(C1, r.a.y, fmaf(C2, r.b.y - M2, C3)),
                            m * fmaf(C1, r.a.z, fmaf(C2, r.b.z - M2, C3)), m * fmaf(C1, r.a.w, fmaf(C2, r.b.w - M2, C3)));
     };
 
     auto both4 = [&](const float4& h, float4& gv, float4& gd) {
+#if DWR_PK
+        f32x2 v0, d0, v1, d1;
+        gelu_both2(A1, B1, f2(h.x, h.y), v0, d0);
+        gelu_both2(A1, B1, f2(h.z, h.w), v1, d1);
+        gv = make_float4(v0.x, v0.y, v1.x, v1.y);
+        gd = make_float4(d0.x, d0.y, d1.x, d1.y);
+#else
         gelu_both(A1, B1, h.x, gv.x, gd.x); gelu_both(A1, B1, h.y, gv.y, gd.y);
         gelu_both(A1, B1, h.z, gv.z, gd.z); gelu_both(A1, B1, h.w, gv.w, gd.w);
+#endif
     };
     // 4-slot rings (row y in slot (y - y0) & 3) of the zero-padded dh2 rows, the reflect-padded g1 rows, raw h1 and
     // gelu'(u1); the row loop is unrolled x4 so that every slot index is static (no register rotation)
     Row6 dW[4], gW[4];
     float4 hW[4], qW[4];
-    Raw nx[2];
+    Raw3 nx[DEPTH];
     {
         const Raw q = ld(y0 - 1);
         dW[3] = row6_zero(dh2(q, y0 - 1));
@@ -177,7 +219,8 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
         gW[0] = row6_reflect(gv);
         hW[0] = q0.h;
     }
-    nx[0] = ld(y0 + 1); nx[1] = ld(y0 + 2);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) nx[d] = ldr(y0 + 1 + d);
     const bool l0 = lane == 0, l63 = lane == 63;
 
     float s0 = 0.f, s1 = 0.f, gw[9];
@@ -188,16 +231,17 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
         for (int s = 0; s < 4; ++s) {
             const int y = Y + s;
             const int im = (s + 3) & 3, ic = s, ip = (s + 1) & 3;
-            dW[ip] = row6_zero(dh2(nx[s & 1], y + 1));
+            const Raw cur = wide(nx[s % DEPTH]);
+            dW[ip] = row6_zero(dh2(cur, y + 1));
             float4 gvn;
-            both4(nx[s & 1].h, gvn, qW[ip]);
-            hW[ip] = nx[s & 1].h;
+            both4(cur.h, gvn, qW[ip]);
+            hW[ip] = cur.h;
             const Row6 gnew = row6_reflect(gvn);
             const bool inside = y + 1 < H;                 // reflect: row H -> row H-2
 #pragma unroll
             for (int k = 0; k < 6; ++k) gW[ip].v[k] = inside ? gnew.v[k] : gW[im].v[k];
             if (s == 0 && y == 0) gW[im] = gW[ip];         // reflect: row -1 -> row 1 (wave-uniform, registers only)
-            nx[s & 1] = ld(y + 3);
+            nx[s % DEPTH] = ldr(y + 1 + DEPTH);
             const Row6 &dm = dW[im], &dc = dW[ic], &dp = dW[ip], &gm = gW[im], &gc = gW[ic], &gp = gW[ip];
 
             const bool ry0 = (y == 1), ry1 = (y == H - 2);  // rows that receive the folded-back padding rows
