@@ -63,6 +63,9 @@ typedef struct ihipStream_t* hipStream_t;
 #define UNCR_EW_HEAD_BWD_ELU 12
 #define UNCR_EW_HEAD_FWD_ID 13
 #define UNCR_EW_HEAD_BWD_ID 14
+/* stand-alone norm layers / SE (PreNorm uncrtaints.py:72-79, SE uncrtaints.py:82-97 called outside MBConv) */
+#define UNCR_EW_AFFINE 15          /* out = A*a + B, stats (sum out, sum out^2) */
+#define UNCR_EW_NORMBWD 16         /* out = C1*a + C2*(b - M) + C3 (M = k3 or 0) */
 
 int uncr_version(void);
 
@@ -100,6 +103,8 @@ int uncr_ew_slots(int P);
 int uncr_ew(int op, const void* a, const void* b, const void* c, const void* aux, void* out,
             const float* k0, const float* k1, const float* k2, const float* k3, float* part, int planes, int P,
             int C, int n_mean, float scale, float eps, int act, hipStream_t stream);
+/* per-plane totals (fp64 accumulation, fixed order) of a [planes][slots] (sum0, sum1) partial array; either output may be null */
+int uncr_part_sums(const float* part, int slots, int planes, float* out0, float* out1, hipStream_t stream);
 /* dst = src converted between the storage types (model input -> bf16 activations; bf16 input gradient -> fp32) */
 int uncr_cast(const void* src, void* dst, long long n, int src_dt, int dst_dt, hipStream_t stream);
 

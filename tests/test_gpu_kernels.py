@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden
+from conftest import load_golden, rel_err
 from gpu_util import DEV, TOL, close, dev, rand
 
 pytestmark = pytest.mark.gpu
@@ -765,3 +765,71 @@ def test_pool_scatter_fused_with_statistics(E, H, W, bf):
     hb.call("uncr_pool_scatter_stats", dd, idx, got, h3, part, planes, H, W, 32, 32, 1 if bf else 0, E._stream())
     assert torch.equal(got, ref)
     close("pool_scatter_stats/part", part.double().sum(1), ref_part.buf.double().sum(1), tol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm", ["group", "batch", "instance"])
+@pytest.mark.parametrize("training", [True, False])
+def test_standalone_prenorm_matches_torch(norm, training):
+    """PreNorm called on its own (uncrtaints.py:72-79): fn(norm(x)) with the norm as stand-alone HIP passes, against the same
+    nn modules on the CPU (forward, running statistics, dx, d gamma, d beta)."""
+    import copy
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    torch.manual_seed(3)
+    N, C, H, W = 3, 64, 32, 64
+    x = torch.randn(N, C, H, W) * 1.5 + 0.7
+    gout = torch.randn(N, C, H, W)
+    m = U.PreNorm(C, nn_identity(), norm, n_groups=4)
+    if norm != "instance":
+        with torch.no_grad():
+            m.norm.weight.normal_(1.0, 0.3); m.norm.bias.normal_(0.0, 0.5)
+    if norm == "batch":
+        with torch.no_grad():
+            m.norm.running_mean.normal_(0.5, 0.2); m.norm.running_var.uniform_(1.5, 3.0)
+    ref = copy.deepcopy(m.norm)
+    m.train(training); ref.train(training)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(gout)
+    mg = m.to("cuda")
+    xg = x.cuda().requires_grad_(True)
+    y = mg(xg)
+    y.backward(gout.cuda())
+    assert rel_err(y.detach().cpu().numpy(), yr.detach().numpy()) < 2e-6
+    assert rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) < 2e-5
+    if norm != "instance":
+        assert rel_err(mg.norm.weight.grad.cpu().numpy(), ref.weight.grad.numpy()) < 2e-5
+        assert rel_err(mg.norm.bias.grad.cpu().numpy(), ref.bias.grad.numpy()) < 2e-5
+    if norm == "batch":
+        assert rel_err(mg.norm.running_mean.cpu().numpy(), ref.running_mean.numpy()) < 1e-6
+        assert rel_err(mg.norm.running_var.cpu().numpy(), ref.running_var.numpy()) < 1e-6
+        assert int(mg.norm.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+def nn_identity():
+    return torch.nn.Identity()
+
+
+@pytest.mark.gpu
+def test_standalone_se_matches_torch():
+    """SE called on its own (uncrtaints.py:82-97) against the same arithmetic in torch on the CPU."""
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    torch.manual_seed(4)
+    N, C, H, W = 2, 256, 32, 32
+    x = torch.randn(N, C, H, W) + 0.3
+    gout = torch.randn(N, C, H, W)
+    m = U.SE(128, C)                       # hidden = 32
+    w1, w2 = m.fc[0].weight.detach().clone().requires_grad_(True), m.fc[2].weight.detach().clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    pooled = xr.mean(dim=(2, 3))
+    s = torch.sigmoid(torch.nn.functional.gelu(pooled @ w1.t()) @ w2.t())
+    yr = xr * s[:, :, None, None]
+    yr.backward(gout)
+    mg = m.to("cuda")
+    xg = x.cuda().requires_grad_(True)
+    y = mg(xg)
+    y.backward(gout.cuda())
+    assert rel_err(y.detach().cpu().numpy(), yr.detach().numpy()) < 2e-6
+    assert rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) < 1e-5
+    assert rel_err(mg.fc[0].weight.grad.cpu().numpy(), w1.grad.numpy()) < 2e-5
+    assert rel_err(mg.fc[2].weight.grad.cpu().numpy(), w2.grad.numpy()) < 2e-5

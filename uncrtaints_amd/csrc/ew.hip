@@ -20,7 +20,10 @@ enum : int {
     EW_HEAD_BWD = 9,     // out = a * f'(b)   a = d(out), b = pre-activation
     EW_RESIDUAL_RELU = 10,  // out = a + relu(A*b + B)   (ResidualConvBlock skip, uncrtaints.py:67)
     // the other variance nonlinearities of get_nonlinearity (uncrtaints.py:223-228): 'elu' -> elu(a)+1+eps, else identity
-    EW_HEAD_FWD_ELU = 11, EW_HEAD_BWD_ELU = 12, EW_HEAD_FWD_ID = 13, EW_HEAD_BWD_ID = 14
+    EW_HEAD_FWD_ELU = 11, EW_HEAD_BWD_ELU = 12, EW_HEAD_FWD_ID = 13, EW_HEAD_BWD_ID = 14,
+    // stand-alone calls of the norm layers / SE (a caller using PreNorm or SE outside MBConv; inside it they are prologues)
+    EW_AFFINE = 15,      // out = A*a + B;                    stats (sum out, sum out^2)
+    EW_NORMBWD = 16      // out = C1*a + C2*(b - M) + C3;     (M = k3 or 0)   a=dy, b=x
 };
 __host__ __device__ constexpr bool ew_is_head_fwd(int op) { return op == EW_HEAD_FWD || op == EW_HEAD_FWD_ELU || op == EW_HEAD_FWD_ID; }
 __host__ __device__ constexpr bool ew_is_head_bwd(int op) { return op == EW_HEAD_BWD || op == EW_HEAD_BWD_ELU || op == EW_HEAD_BWD_ID; }
@@ -70,6 +73,20 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         vo = rnd4<T>(vo);       // statistics of the values as stored
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s0 += o[i]; s1 += o[i] * o[i]; }
+    } else if constexpr (OP == EW_AFFINE) {
+        const float A = g.k0[plane], B = g.k1[plane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = fmaf(A, pa[i], B);
+        vo = rnd4<T>(vo);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s0 += o[i]; s1 += o[i] * o[i]; }
+    } else if constexpr (OP == EW_NORMBWD) {
+        const float C1 = g.k0[plane], C2 = g.k1[plane], C3 = g.k2[plane];
+        const float M = g.k3 ? g.k3[plane] : 0.f;
+        const float4 vb = ld_nt4t((const T*)g.b + off);
+        const float* pb = (const float*)&vb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = fmaf(C1, pa[i], fmaf(C2, pb[i] - M, C3));
     } else if constexpr (OP == EW_RESIDUAL) {
         const float A = g.k0[plane], B = g.k1[plane];
         const float4 vb = ld_nt4t((const T*)g.b + off);
@@ -208,6 +225,23 @@ extern "C" int uncr_cast(const void* src, void* dst, long long n, int src_dt, in
 
 extern "C" int uncr_ew_slots(int P) { return P / EW_CHUNK; }
 
+// per-plane totals of a [planes][slots] (sum0, sum1) partial array, fp64 accumulation in a fixed order
+__global__ __launch_bounds__(256) void part_sums_kernel(const float2* __restrict__ part, int slots, int planes,
+                                                        float* __restrict__ out0, float* __restrict__ out1) {
+    const int pl = blockIdx.x * 256 + threadIdx.x;
+    if (pl >= planes) return;
+    double a = 0.0, b = 0.0;
+    for (int j = 0; j < slots; ++j) { const float2 v = part[(size_t)pl * slots + j]; a += (double)v.x; b += (double)v.y; }
+    if (out0) out0[pl] = (float)a;
+    if (out1) out1[pl] = (float)b;
+}
+extern "C" int uncr_part_sums(const float* part, int slots, int planes, float* out0, float* out1, hipStream_t stream) {
+    if (!part || slots <= 0 || planes <= 0 || (!out0 && !out1)) return UNCR_EINVAL;
+    hipLaunchKernelGGL(part_sums_kernel, dim3((planes + 255) / 256), dim3(256), 0, stream, (const float2*)part, slots, planes, out0, out1);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
 extern "C" int uncr_ew(int op, const void* a, const void* b, const void* c, const void* aux, void* out,
                        const float* k0, const float* k1, const float* k2, const float* k3, float* part, int planes,
                        int P, int C, int n_mean, float scale, float eps, int act, hipStream_t stream) {
@@ -240,6 +274,8 @@ extern "C" int uncr_ew(int op, const void* a, const void* b, const void* c, cons
         EW_CASE_A(EW_PASSE)
         EW_CASE_A(EW_RELU_BWD)
         EW_CASE_A(EW_SE_POOL)
+        EW_CASE_A(EW_AFFINE)
+        EW_CASE_A(EW_NORMBWD)
         EW_CASE(EW_HEAD_FWD)
         EW_CASE_HB(EW_HEAD_BWD)
         EW_CASE(EW_RESIDUAL_RELU)

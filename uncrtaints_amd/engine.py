@@ -25,6 +25,7 @@ PRO_NONE, PRO_AFFINE, PRO_AFFINE_GELU, PRO_NORMBWD, PRO_AFFINE_RELU = 0, 1, 2, 3
 NORM_GROUP, NORM_BATCH_TRAIN, NORM_BATCH_EVAL = 0, 1, 2
 EW_STATS_SQ, EW_STATS_AUX, EW_AFFINE_RELU, EW_RESIDUAL, EW_PASSB, EW_PASSE, EW_RELU_BWD, EW_SE_POOL, \
     EW_HEAD_FWD, EW_HEAD_BWD = range(10)
+EW_AFFINE, EW_NORMBWD = 15, 16
 
 Tensor = torch.Tensor
 
@@ -225,6 +226,71 @@ def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor, cen
     hb.call("uncr_norm_finalize_bwd", part.buf, part.slots, N, C, nf.groups, P, nf.kind, gamma, nf.mean, nf.rstd,
             c1, c2, c3, mu, dg, db, scratch, 1 if centered else 0, _stream())
     return NormBwd(c1, c2, c3, dg, db, mu)
+
+
+# ---- stand-alone norm layer and squeeze-excite (PreNorm uncrtaints.py:72-79 / SE uncrtaints.py:82-97 called on their own;
+#      inside MBConv both are prologues of other kernels) ----
+def norm_apply_forward(x: Tensor, spec: NormSpec, training: bool, gamma: Optional[Tensor], beta: Optional[Tensor],
+                       running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None, momentum: float = 0.1,
+                       eps: float = 1e-5):
+    """GroupNorm / BatchNorm2d / InstanceNorm2d of x [N,C,H,W]: one statistics pass, the finalize kernel, one affine pass."""
+    N, C, H, W = _check4(x)
+    P = H * W
+    x = x.contiguous()
+    part = stats_sq(x, N * C, P) if spec.needs_stats(training) else None
+    nf = norm_fwd(part, N, C, P, spec, training, gamma, beta, running_mean, running_var, momentum, eps)
+    out = _act((N, C, H, W), x.device, _dt(x))
+    ew(EW_AFFINE, x, out=out, k=(nf.A, nf.B, None, None), planes=N * C, P=P)
+    return out, dict(x=x, nf=nf, dims=(N, C, H, W))
+
+
+def norm_apply_backward(dy: Tensor, sv: dict, gamma: Optional[Tensor], need_dx: bool = True):
+    N, C, H, W = sv["dims"]
+    P = H * W
+    dy = dy.contiguous()
+    x, nf = sv["x"], sv["nf"]
+    nb = norm_bwd(stats_aux(dy, x, N * C, P), N, C, P, nf, gamma)
+    dx = None
+    if need_dx:
+        dx = _act((N, C, H, W), dy.device, _dt(dy))
+        ew(EW_NORMBWD, dy, b=x, out=dx, k=nb.k, planes=N * C, P=P)
+    return dx, nb.dgamma, nb.dbeta
+
+
+def se_forward(x: Tensor, W1: Tensor, W2: Tensor):
+    """x * sigmoid(W2 gelu(W1 mean_p x)) for x [N,C,H,W] (uncrtaints.py:92-97).  C <= 256, hidden <= 64."""
+    N, C, H, W = _check4(x)
+    P, R = H * W, W1.shape[0]
+    x = x.contiguous()
+    pp = stats_sq(x, N * C, P)                          # (sum x, sum x^2) partials; the MLP kernel takes the first component
+    pooled, hid_pre, s = _f32((N, C), x.device), _f32((N, R), x.device), _f32((N * C,), x.device)
+    hb.call("uncr_se_mlp_fwd", pp.buf, pp.slots, N, C, R, P, W1.contiguous(), W2.contiguous(), pooled, hid_pre, s, _stream())
+    out = _act((N, C, H, W), x.device, _dt(x))
+    zero = torch.zeros(N * C, device=x.device, dtype=torch.float32)
+    ew(EW_AFFINE, x, out=out, k=(s, zero, None, None), planes=N * C, P=P)
+    return out, dict(x=x, s=s, pooled=pooled, hid_pre=hid_pre, dims=(N, C, H, W, R))
+
+
+def se_backward(dy: Tensor, sv: dict, W1: Tensor, W2: Tensor, need_dx: bool = True):
+    """ds[n,c] = sum_p dy*x runs through the SE-MLP backward kernel as a one-row product (G [N,1,C], unit weights);
+    dx = s*dy + dpool/P."""
+    N, C, H, W, R = sv["dims"]
+    P = H * W
+    dev = dy.device
+    dy = dy.contiguous()
+    pp = stats_aux(dy, sv["x"], N * C, P)
+    G = _f32((N, 1, C), dev)
+    hb.call("uncr_part_sums", pp.buf, pp.slots, N * C, None, G, _stream())
+    ones = torch.ones(1, C, device=dev, dtype=torch.float32)
+    ds_pre, dhid_pre, dpool = _f32((N, C), dev), _f32((N, R), dev), _f32((N * C,), dev)
+    dWpw, dW1, dW2 = _f32((1, C), dev), _f32((R, C), dev), _f32((C, R), dev)
+    hb.call("uncr_se_mlp_bwd", G, ones, N, 1, C, R, P, W1.contiguous(), W2.contiguous(), sv["s"], sv["pooled"], sv["hid_pre"],
+            ds_pre, dhid_pre, dpool, dWpw, dW1, dW2, _stream())
+    dx = None
+    if need_dx:
+        dx = _act((N, C, H, W), dev, _dt(dy))
+        ew(EW_AFFINE, dy, out=dx, k=(sv["s"], dpool, None, None), planes=N * C, P=P)
+    return dx, dW1, dW2
 
 
 # ---- batched weight packing: every 1x1-conv weight of a model in ONE launch at the start of a forward ----

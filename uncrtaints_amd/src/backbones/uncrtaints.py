@@ -30,8 +30,36 @@ def get_norm_layer(out_channels, num_feats, n_groups=4, layer_type='batch'):
         return nn.GroupNorm(num_channels=num_feats, num_groups=n_groups)
 
 
+class _NormFn(torch.autograd.Function):
+    """A norm layer on its own (one statistics pass + one affine pass); inside MBConv it is a prologue of the next kernel."""
+
+    @staticmethod
+    def forward(ctx, x, module, gamma, beta):
+        kind = "batch" if isinstance(module, nn.BatchNorm2d) else ("instance" if isinstance(module, nn.InstanceNorm2d) else "group")
+        spec = E.NormSpec(kind, module.num_groups if kind == "group" else 4)
+        rm, rv = (module.running_mean, module.running_var) if kind == "batch" else (None, None)
+        mom = module.momentum if kind == "batch" and module.momentum is not None else 0.1
+        out, sv = E.norm_apply_forward(x, spec, module.training, gamma, beta, rm, rv, mom, module.eps)
+        ctx.sv, ctx.gamma = sv, gamma
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, dg, db = E.norm_apply_backward(dy, ctx.sv, ctx.gamma, ctx.needs_input_grad[0])
+        return dx, None, (dg if ctx.gamma is not None else None), (db if ctx.gamma is not None else None)
+
+
+def apply_norm(module, x):
+    """`module(x)` for nn.GroupNorm / nn.BatchNorm2d / nn.InstanceNorm2d holders on the HIP path (x [N,C,H,W])."""
+    y = _NormFn.apply(x, module, getattr(module, "weight", None), getattr(module, "bias", None))
+    if isinstance(module, nn.BatchNorm2d) and module.training and module.num_batches_tracked is not None:
+        module.num_batches_tracked += 1
+    return y
+
+
 class PreNorm(nn.Module):
-    """Parameter holder: `norm` then `fn` (uncrtaints.py:72-79); applied fused inside MBConv."""
+    """`fn(norm(x))` (uncrtaints.py:72-79).  MBConv evaluates its PreNorm fused (the norm is the prologue of pw1); a stand-alone
+    call runs the norm as its own HIP passes and hands the result to `fn`."""
 
     def __init__(self, dim, fn, norm, n_groups=4):
         super().__init__()
@@ -39,11 +67,25 @@ class PreNorm(nn.Module):
         self.fn = fn
 
     def forward(self, x, **kwargs):
-        raise NotImplementedError("PreNorm is fused into MBConv on the HIP path; call MBConv")
+        return self.fn(apply_norm(self.norm, x), **kwargs)
+
+
+class _SEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, w2):
+        out, sv = E.se_forward(x, w1, w2)
+        ctx.sv, ctx.w = sv, (w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, dw1, dw2 = E.se_backward(dy, ctx.sv, ctx.w[0], ctx.w[1], ctx.needs_input_grad[0])
+        return dx, dw1, dw2
 
 
 class SE(nn.Module):
-    """Parameter holder of the squeeze-excite MLP (uncrtaints.py:82-97); fused inside MBConv."""
+    """Squeeze-excite (uncrtaints.py:82-97): x * sigmoid(fc2(gelu(fc1(avgpool(x))))).  Fused into its neighbours inside MBConv;
+    a stand-alone call runs pooling statistics + the SE-MLP kernel + one scaling pass."""
 
     def __init__(self, inp, oup, expansion=0.25):
         super().__init__()
@@ -56,7 +98,9 @@ class SE(nn.Module):
         )
 
     def forward(self, x):
-        raise NotImplementedError("SE is fused into MBConv on the HIP path; call MBConv")
+        if x.shape[1] > 256 or self.fc[0].weight.shape[0] > 64:
+            raise NotImplementedError("stand-alone SE is built for <= 256 channels and <= 64 hidden units")
+        return _SEFn.apply(x, self.fc[0].weight, self.fc[2].weight)
 
 
 class _MBConvFn(torch.autograd.Function):
