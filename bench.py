@@ -465,7 +465,12 @@ def main():
                                      "definition": "A_ltae_step = (3T+2)*128*P*bytes*B over (stage forward + stage backward) time; "
                                                    "stage = temporal attention at 32x32 + up-sampling + aggregation + pooled-"
                                                    "gradient scatter (SURVEY 8(d)); sum of the per-launch HIP-event times of "
-                                                   "every kernel launched inside the two stage calls"}
+                                                   "every kernel launched inside the two stage calls",
+                                     # per entry point: [launches per step, microseconds per step]; a leading '-' marks launches made
+                                     # inside the stage calls that belong to the encoder (its statistics pass) and are not counted
+                                     "launches": {tag: {k: [round(v[0] / prof_steps, 2), round(1e3 * v[1] / prof_steps, 1)]
+                                                        for k, v in sorted(d.items(), key=lambda kv: -kv[1][1])}
+                                                  for tag, d in prof.scope_detail().items()}}
             if eager_ms is not None:
                 res["eager_event_profiled_ms_per_step"] = round(eager_ms, 3)
                 res["roofline"]["source"] = ("eager re-run of the same steps with a HIP event pair around every launch "

@@ -223,6 +223,8 @@ int uncr_ltae_gn_fwd(const float* x, const float* gamma, const float* beta, floa
 int uncr_ltae_gn_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                      float* dx, float* gb_part, int B, int T, int C, int G, int S, hipStream_t stream);
 int uncr_colsum(const float* part, int R, int K, float* out, hipStream_t stream);
+/* the same for `batches` consecutive [R][K] arrays in one launch: out [batches][K] */
+int uncr_colsum_batched(const float* part, int batches, int R, int K, float* out, hipStream_t stream);
 /* agg_mode 'att_mean' (head-averaged attention, uncrtaints.py:179-188,211-219) and 'mean' (:189-192,220-221) helpers */
 int uncr_bcast_scale(const float* src, int R, long long n, float scale, float* dst, hipStream_t stream);
 int uncr_mean_weights(const int* pad, int NH, int B, int T, int S, float* out, hipStream_t stream);

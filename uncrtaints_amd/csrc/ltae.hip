@@ -277,6 +277,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
                                                      float* __restrict__ out) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
+    part += (size_t)blockIdx.y * R * K;       // batched form: [batches][R][K] -> [batches][K]
+    out += (size_t)blockIdx.y * K;
     double s = 0.0;
     int r = 0;
     for (; r + 8 <= R; r += 8) {          // eight loads in flight, summed in a fixed order
@@ -524,6 +526,12 @@ extern "C" int uncr_mean_weights(const int* pad, int NH, int B, int T, int S, fl
 extern "C" int uncr_colsum(const float* part, int R, int K, float* out, hipStream_t stream) {
     if (R <= 0 || K <= 0) return UNCR_ESHAPE;
     hipLaunchKernelGGL(colsum_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, part, R, K, out);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+extern "C" int uncr_colsum_batched(const float* part, int batches, int R, int K, float* out, hipStream_t stream) {
+    if (batches <= 0 || batches > 65535 || R <= 0 || K <= 0) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(colsum_kernel, dim3((K + 255) / 256, batches), dim3(256), 0, stream, part, R, K, out);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

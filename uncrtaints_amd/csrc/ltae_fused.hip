@@ -329,13 +329,13 @@ __global__ __launch_bounds__(256) void ltae_compose_bwd_a_kernel(const float* __
         __syncthreads();
     }
 }
-// grid = HK: d Wk[hd][:], d bk[hd]          (d M[hd][c] = sc Q[h][d] dA[h][c],  d U[hd][n] = sc Q[h][d] dB'[h][n])
-__global__ __launch_bounds__(256) void ltae_compose_bwd_wk_kernel(const float* __restrict__ Q, const float* __restrict__ Wi,
-                                                                  const float* __restrict__ bias1, const float* __restrict__ dA,
-                                                                  const float* __restrict__ dBp, const float* __restrict__ sBv,
-                                                                  int DK, int D, int C, int NF, int T, float* __restrict__ dWk,
-                                                                  float* __restrict__ dbk) {
-    const int hd = blockIdx.x, h = hd / DK, NH = gridDim.x / DK;
+// block hd of HK: d Wk[hd][:], d bk[hd]          (d M[hd][c] = sc Q[h][d] dA[h][c],  d U[hd][n] = sc Q[h][d] dB'[h][n])
+__device__ __forceinline__ void ltae_compose_bwd_wk_body(int hd, int NH, const float* __restrict__ Q, const float* __restrict__ Wi,
+                                                         const float* __restrict__ bias1, const float* __restrict__ dA,
+                                                         const float* __restrict__ dBp, const float* __restrict__ sBv,
+                                                         int DK, int D, int C, int NF, int T, float* __restrict__ dWk,
+                                                         float* __restrict__ dbk) {
+    const int h = hd / DK;
     const double q = (double)Q[hd] / sqrt((double)DK);
     for (int j = threadIdx.x; j < D; j += 256) {
         double s = 0.0;
@@ -353,12 +353,11 @@ __global__ __launch_bounds__(256) void ltae_compose_bwd_wk_kernel(const float* _
     }
     if (threadIdx.x == 0) dbk[hd] = (float)((double)sBv[h] * q);
 }
-// grid = D: d Wi[j][:], d bi[j]
-__global__ __launch_bounds__(256) void ltae_compose_bwd_wi_kernel(const float* __restrict__ Q, const float* __restrict__ Wk,
-                                                                  const float* __restrict__ dA, const float* __restrict__ sBv,
-                                                                  int NH, int DK, int D, int C, int NF, int T,
-                                                                  float* __restrict__ dWi, float* __restrict__ dbi) {
-    const int j = blockIdx.x;
+// block j of D: d Wi[j][:], d bi[j]
+__device__ __forceinline__ void ltae_compose_bwd_wi_body(int j, const float* __restrict__ Q, const float* __restrict__ Wk,
+                                                         const float* __restrict__ dA, const float* __restrict__ sBv,
+                                                         int NH, int DK, int D, int C, int NF, int T,
+                                                         float* __restrict__ dWi, float* __restrict__ dbi) {
     const double sc = 1.0 / sqrt((double)DK);
     for (int c = threadIdx.x; c < C; c += 256) {
         double s = 0.0;
@@ -386,6 +385,17 @@ __global__ __launch_bounds__(256) void ltae_compose_bwd_wi_kernel(const float* _
     }
     if (threadIdx.x == 0) dbi[j] = (float)(red[0] * sc);
     (void)NF; (void)T;
+}
+// the two weight gradients depend on dA only: one launch, grid = HK + D (blocks [0, HK): d Wk / d bk, the others: d Wi / d bi)
+__global__ __launch_bounds__(256) void ltae_compose_bwd_w_kernel(const float* __restrict__ Q, const float* __restrict__ Wk,
+                                                                 const float* __restrict__ Wi, const float* __restrict__ bias1,
+                                                                 const float* __restrict__ dA, const float* __restrict__ dBp,
+                                                                 const float* __restrict__ sBv, int NH, int DK, int D, int C, int NF,
+                                                                 int T, float* __restrict__ dWk, float* __restrict__ dbk,
+                                                                 float* __restrict__ dWi, float* __restrict__ dbi) {
+    const int b = blockIdx.x, HK = NH * DK;       // block-uniform branch
+    if (b < HK) ltae_compose_bwd_wk_body(b, NH, Q, Wi, bias1, dA, dBp, sBv, DK, D, C, NF, T, dWk, dbk);
+    else ltae_compose_bwd_wi_body(b - HK, Q, Wk, dA, sBv, NH, DK, D, C, NF, T, dWi, dbi);
 }
 
 extern "C" int uncr_ltae_fused_supported(int T, int C, int NH, int S) {
@@ -474,11 +484,8 @@ extern "C" int uncr_ltae_compose_bwd(const float* Q, const float* Wk, const floa
     hipLaunchKernelGGL(ltae_compose_bwd_a_kernel, dim3(NH), dim3(256), 0, stream, Q, M, U, gamma, beta, dAp, dBp, DK, C, NF, T, dA,
                        dQ, dgb, dA + (size_t)NH * C);
     UNCR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ltae_compose_bwd_wk_kernel, dim3(NH * DK), dim3(256), 0, stream, Q, Wi, bias1, dA, dBp, dA + (size_t)NH * C, DK, D,
-                       C, NF, T, dWk, dbk);
-    UNCR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ltae_compose_bwd_wi_kernel, dim3(D), dim3(256), 0, stream, Q, Wk, dA, dA + (size_t)NH * C, NH, DK, D, C, NF, T, dWi,
-                       dbi);
+    hipLaunchKernelGGL(ltae_compose_bwd_w_kernel, dim3(NH * DK + D), dim3(256), 0, stream, Q, Wk, Wi, bias1, dA, dBp, dA + (size_t)NH * C,
+                       NH, DK, D, C, NF, T, dWk, dbk, dWi, dbi);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

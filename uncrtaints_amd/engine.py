@@ -867,8 +867,7 @@ def ltae_attention_backward_fused(datt: Tensor, sv: dict, p: Dict[str, Tensor], 
             partA, partB, B, T, C, n_head, S, _stream())
     dAp, dBp = _f32((n_head, C), dev), _f32((B, n_head, T), dev)
     hb.call("uncr_colsum", partA, B * nblk, n_head * C, dAp, _stream())
-    for b in range(B):          # d B' per sample: the blocks of sample b
-        hb.call("uncr_colsum", partB[b * nblk:(b + 1) * nblk], nblk, n_head * T, dBp[b], _stream())
+    hb.call("uncr_colsum_batched", partB, B, nblk, n_head * T, dBp, _stream())      # d B' per sample: the blocks of sample b
     dA, dQ = _f32((n_head * C + n_head,), dev), _f32((n_head, d_k), dev)      # dA: scratch [NH][C] + [NH]
     dWk, dbk, dWi, dbi = _f32((HK, D), dev), _f32((HK,), dev), _f32((D, C), dev), _f32((D,), dev)
     dgb = _f32((n_head, 2, C), dev)

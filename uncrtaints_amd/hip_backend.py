@@ -127,6 +127,17 @@ class EventProfiler:
             out[tag] = out.get(tag, 0.0) + e0.elapsed_time(e1)
         return out
 
+    def scope_detail(self):
+        """-> {tag: {entry point: [launches, summed ms]}} of the scoped launches (scope_exclude entries marked by a leading '-')."""
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for tag, name, e0, e1 in self.scope_records:
+            d = out.setdefault(tag, {}).setdefault(("-" if name in self.scope_exclude else "") + name, [0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+        return out
+
     def summarize(self):
         import torch
         torch.cuda.synchronize()
