@@ -41,6 +41,7 @@ denom = torch.pow(torch.tensor(1000.0), 2 * (torch.arange(16).float() // 2) / 16
 att, sva = E.ltae_attention_forward(f(t64["down"]), f(d), pad, p, denom, 16, 4)
 print("att fwd err", rel_err(att.cpu().double().numpy(), t64["attn"].detach().numpy()))
 ddown, gr = E.ltae_attention_backward(f(t64["attn"].grad), sva, p, 16, 4)
+E.join_side()
 print("ddown: hip-vs-64", rel_err(ddown.cpu().double().numpy().reshape(-1), t64["down"].grad.numpy().reshape(-1)), " cpu32-vs-64", rel_err(t32["down"].grad.double().numpy(), t64["down"].grad.numpy()))
 dd = (ddown.cpu().double().reshape(B, T, 128, 32, 32) - t64["down"].grad).abs()
 print("per-frame ddown err / global max:", [float(dd[0, t].max() / t64["down"].grad.abs().max()) for t in range(T)])

@@ -13,6 +13,7 @@ into per-(frame,channel) coefficients and the consuming kernel applies them in i
 from __future__ import annotations
 
 import os
+import threading
 
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
@@ -111,6 +112,67 @@ class NormSpec:
 
     def needs_stats(self, training: bool) -> bool:
         return self.code(training) != NORM_BATCH_EVAL
+
+
+# ------------------------------------------------------------------------------------------------
+# side chains: latency-bound launches that only feed parameter gradients run on a second HIP stream next to the bandwidth-bound
+# kernels of the critical path (inside a captured step they become a parallel branch of the graph)
+# ------------------------------------------------------------------------------------------------
+# Opt-in (UNCR_SIDE_STREAM=1): measured neutral on MI355X inside the captured step (12.69 ms with, 12.70 ms without: the ~90 us of
+# parameter-gradient launches do not overlap usefully with the bandwidth-bound kernels next to them), so the default keeps one stream.
+_USE_SIDE = os.environ.get("UNCR_SIDE_STREAM", "0") == "1"
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+_SIDE_TLS = threading.local()
+
+
+class side_chain:
+    """`with side_chain(t1, t2, ...):` -- the launches inside go to the device's side stream, ordered behind everything already
+    enqueued on the current stream.  Rules that keep the caching allocator honest without record_stream(): every tensor the chain
+    WRITES for later use is allocated before entering (on the current stream); the tensors it reads are passed as arguments and
+    kept alive until `join_side()`, which makes the current stream wait for the chain and must be called before the caller
+    returns (temporaries allocated inside belong to the side stream's pool)."""
+
+    def __init__(self, *keep):
+        self.keep = keep
+        self.side = None
+
+    def __enter__(self):
+        if not _USE_SIDE:
+            return self
+        cur = torch.cuda.current_stream()
+        dev = cur.device.index
+        side = _SIDE_STREAMS.get(dev)
+        if side is None:
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=cur.device)
+        side.wait_stream(cur)
+        self._ctx = torch.cuda.stream(side)
+        self._ctx.__enter__()
+        self.side = side
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is None:
+            return False
+        self._ctx.__exit__(*exc)
+        pend = getattr(_SIDE_TLS, "pending", None)
+        if pend is None:
+            pend = _SIDE_TLS.pending = []
+        pend.append((self.side, self.keep))
+        return False
+
+
+def join_side() -> None:
+    """The current stream waits for every side chain this thread started since the last join."""
+    pend = getattr(_SIDE_TLS, "pending", None)
+    if not pend:
+        return
+    cur = torch.cuda.current_stream()
+    seen = set()
+    for side, _ in pend:
+        if id(side) not in seen:
+            cur.wait_stream(side)
+            seen.add(id(side))
+    pend.clear()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -550,7 +612,8 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     hb.call("uncr_dw_bwd", du2, h2, h1, b2.c1, b2.c2, b2.c3, b2.mu, n1.A, n1.B, wdw, du1, part1.buf, dw_part, n1.mean,
             n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, H, W, dt, _stream())
     dwdw = _f32((Ch, 9), dev)
-    hb.call("uncr_dw_wgrad_reduce", dw_part, N, Ch, slots, dwdw, _stream())
+    with side_chain(dw_part):          # feeds a parameter gradient only: next to the pw1 weight-gradient GEMM
+        hb.call("uncr_dw_wgrad_reduce", dw_part, N, Ch, slots, dwdw, _stream())
     g["wdw"] = dwdw.view_as(p["wdw"])
     b1 = norm_bwd(part1, N, Ch, P, n1, p["n1w"], centered=True)
     g["n1w"], g["n1b"] = b1.dgamma, b1.dbeta
@@ -586,6 +649,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
             dx_part = Part(_f32((N * C, slots, 2), dev), slots, masked=relu is not None)
         hb.call("uncr_pw_gemm_dx", du1, h1, W1k, dx, k1[0], k1[1], k1[2], k1[3], dy, x, x_h3, b0.c1, b0.c2, b0.c3, b0.mu, ra, rb,
                 dx_part.buf if dx_part is not None else None, N, Ch, C, P, dt, _stream())
+        join_side()
         return dx, g, dx_part
 
     # pw1: weight gradient and data gradient
@@ -601,6 +665,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         x_h3 = sv.get("x_h3")     # h3 of the block that produced x: emit its norm-3 backward statistics here
         _, dx_part = ew(EW_PASSE, dy, b=da, c=x, aux=x_h3, out=dx, k=b0.k,
                         want_part=x_h3 is not None, planes=N * C, P=P)
+    join_side()
     return dx, g, dx_part
 
 
@@ -865,17 +930,19 @@ def ltae_attention_backward_fused(datt: Tensor, sv: dict, p: Dict[str, Tensor], 
     partA, partB = _f32((B * nblk, n_head, C), dev), _f32((B * nblk, n_head, T), dev)
     hb.call("uncr_ltae_fused_bwd", datt.contiguous(), sv["att"], sv["down"], sv["Ap"], sv["pad"], sv["mean"], sv["rstd"], ddown,
             partA, partB, B, T, C, n_head, S, _stream())
+    # everything from here on only feeds parameter gradients: a side chain next to the pooled-gradient scatter (ltae_stage_backward
+    # joins it).  Outputs are allocated first, on the current stream.
     dAp, dBp = _f32((n_head, C), dev), _f32((B, n_head, T), dev)
-    hb.call("uncr_colsum", partA, B * nblk, n_head * C, dAp, _stream())
-    hb.call("uncr_colsum_batched", partB, B, nblk, n_head * T, dBp, _stream())      # d B' per sample: the blocks of sample b
     dA, dQ = _f32((n_head * C + n_head,), dev), _f32((n_head, d_k), dev)      # dA: scratch [NH][C] + [NH]
     dWk, dbk, dWi, dbi = _f32((HK, D), dev), _f32((HK,), dev), _f32((D, C), dev), _f32((D,), dev)
-    dgb = _f32((n_head, 2, C), dev)
-    Wi, Wk = p["inconv_w"].reshape(D, C).contiguous(), p["fc_w"].contiguous()
-    hb.call("uncr_ltae_compose_bwd", p["Q"].contiguous(), Wk, Wi, sv["bias1"], p["in_norm_w"], p["in_norm_b"], sv["M"], sv["U"],
-            dAp, dBp, n_head, d_k, D, C, NF, T, dA, dQ, dWk, dbk, dWi, dbi, dgb, _stream())
-    gb = _f32((2 * C,), dev)
-    hb.call("uncr_colsum", dgb, n_head, 2 * C, gb, _stream())
+    dgb, gb = _f32((n_head, 2, C), dev), _f32((2 * C,), dev)
+    Wi, Wk, Q = p["inconv_w"].reshape(D, C).contiguous(), p["fc_w"].contiguous(), p["Q"].contiguous()
+    with side_chain(partA, partB, Wi, Wk, Q):
+        hb.call("uncr_colsum", partA, B * nblk, n_head * C, dAp, _stream())
+        hb.call("uncr_colsum_batched", partB, B, nblk, n_head * T, dBp, _stream())      # d B' per sample: the blocks of sample b
+        hb.call("uncr_ltae_compose_bwd", Q, Wk, Wi, sv["bias1"], p["in_norm_w"], p["in_norm_b"], sv["M"], sv["U"],
+                dAp, dBp, n_head, d_k, D, C, NF, T, dA, dQ, dWk, dbk, dWi, dbi, dgb, _stream())
+        hb.call("uncr_colsum", dgb, n_head, 2 * C, gb, _stream())
     g = dict(Q=dQ, fc_w=dWk, fc_b=dbk, inconv_w=dWi.view_as(p["inconv_w"]), inconv_b=dbi, in_norm_w=gb[:C], in_norm_b=gb[C:])
     return ddown, g
 
@@ -1164,6 +1231,7 @@ def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int,
         part = _pool_scatter(ddown, sv, de, e_h3)
         g.update(gv)
         g["include_w"], g["include_b"] = dWinc, dbinc
+        join_side()
         return de, g, part
     de, datt = aggregate_backward(dg, sv["agg"])
     mode = sv.get("mode", "att_group")
@@ -1175,6 +1243,7 @@ def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int,
         datt = head_mean_attention_backward(datt)
     ddown, g = ltae_attention_backward(datt, sv["att"], p, n_head, d_k)
     part = _pool_scatter(ddown, sv, de, e_h3)
+    join_side()          # the attention's parameter-gradient chain ran next to the scatter
     return de, g, part
 
 

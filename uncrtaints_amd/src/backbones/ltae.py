@@ -71,6 +71,7 @@ class _LTAEAttnFn(torch.autograd.Function):
     def backward(ctx, datt):
         m = ctx.module
         ddown, g = E.ltae_attention_backward(datt, ctx.sv, ctx.p, m.n_head, m.attention_heads.d_k)
+        E.join_side()          # the parameter-gradient chain of the fused backward runs on the side stream
         B, T, C, S, _, _ = ctx.sv["dims"]
         ddown = ddown.view(ctx.sv["down"].shape) if ctx.needs_input_grad[0] else None
         return (ddown, None, None, None) + tuple(g[k] for k in _LTAE_KEYS)
