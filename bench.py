@@ -290,7 +290,8 @@ def main():
                 pool = None
                 static = {}
                 for gi, fn in enumerate((seg_forward_decoder, seg_stage, seg_encoder, opt.step)):
-                    with torch.cuda.graph(graphs[gi], pool=pool):
+                    # thread_local: RCCL's watchdog thread may touch its own events while this thread captures
+                    with torch.cuda.graph(graphs[gi], pool=pool, capture_error_mode="thread_local"):
                         r = fn()
                     if gi == 0:
                         static["loss"] = r

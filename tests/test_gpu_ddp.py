@@ -187,8 +187,9 @@ def test_segmented_backward_equals_plain_backward():
     assert l == l2 and worst < 2e-6
 
 
-def test_bench_two_ranks_segmented_graphs_gloo():
-    """bench.py's N > 1 path on the one available GPU (UNCR_BENCH_BACKEND=gloo: RCCL rejects two ranks per device): launched
+@pytest.mark.parametrize("act", ["fp32", "bf16"])
+def test_bench_two_ranks_segmented_graphs_gloo(act):
+    """bench.py's N > 1 path (fp32, and BASELINE config 3: bf16 activation storage under data parallelism) on the one available GPU (UNCR_BENCH_BACKEND=gloo: RCCL rejects two ranks per device): launched
     exactly as the driver launches it, the rank-0 JSON line is parsed.  Small frames keep it short."""
     import json
     import subprocess
@@ -197,7 +198,7 @@ def test_bench_two_ranks_segmented_graphs_gloo():
     env = dict(os.environ, UNCR_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--size", "64", "--batch-per-gpu", "2"]
+           "--size", "64", "--batch-per-gpu", "2", "--act-dtype", act]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
@@ -208,5 +209,6 @@ def test_bench_two_ranks_segmented_graphs_gloo():
     assert res["ranks"] == 2 and res["collective_backend"] == "gloo"
     assert "roofline" in res and res["roofline"]["frac"] > 0
     assert "cpu_baseline" not in res           # N = 1 only
+    assert res["dtype"] == ("bf16" if act == "bf16" else "f32")
     import math
     assert math.isfinite(res["final_loss"])
