@@ -431,7 +431,9 @@ def main():
                 with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as fh:
                     trj = json.load(fh)
                 tr = trj.get(top["kernel"])
-                if tr and trj.get("_source_sha") == source_sha():
+                if bf16:
+                    res["roofline"]["traffic_source"] = f"null: profiles/{TRAFFIC_FILE} holds the fp32 kernels only"
+                elif tr and trj.get("_source_sha") == source_sha():
                     res["roofline"]["traffic"] = tr["hbm_bytes"]
                     res["roofline"]["traffic_source"] = f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc passes, same kernel sources)"
                 else:
