@@ -213,9 +213,13 @@ def main():
         else:
             opt.zero_grad(set_to_none=True)
         out = model(x, batch_positions=dates)
-        loss, _ = crit(out[:, :, :13], y, out[:, :, 13:26])
+        loss, _ = crit(*_split(out, y))
         loss.backward()
         return loss
+
+    def _split(out, y):     # mean / variance channels as BaseModel.get_loss_G hands them to the criterion
+        mean, var = losses.split_prediction(out, 13, 26)
+        return mean, y, var
 
     def eager_step():
         loss = fwd_bwd()
@@ -231,7 +235,7 @@ def main():
         step_counter.add_(1)
         dp.zero_grad()
         out = model(x, batch_positions=dates)
-        loss, _ = crit(out[:, :, :13], y, out[:, :, 13:26])
+        loss, _ = crit(*_split(out, y))
         torch.autograd.backward(loss, inputs=dp.bucket_params(0) + [model._boundary_agg])
         return loss
 

@@ -323,12 +323,16 @@ int uncr_eltloss_bwd(int kind, const float* pred, const float* targ, const float
 int uncr_mgnll_blocks(int P);
 /* vclamp (nullable) [B][K][P]: the clamped per-band variance max(var, eps) (iso: the one channel broadcast to K) -- what the
  * reference returns as the diagonal of its second result (losses.py:145,203-211). */
+/* *_bstride: elements between consecutive samples of pred / var / dpred / dvar (0 = dense, K*H*W resp. Kv*H*W): the mean and the
+ * variance may be channel slices of the head's [B, 13 + cov, H, W] output, read in place, and both gradients may be written
+ * straight into the channel slices of one buffer of that shape (no slicing copies either way). */
 int uncr_mgnll_fwd(const float* pred, const float* targ, const float* var, float* loss_none, float* vclamp, float* part,
                    float* loss_out, int* neg_flag, int B, int K, int Kv, int H, int W, float eps, int reduction,
-                   hipStream_t stream);
+                   long long pred_bstride, long long var_bstride, hipStream_t stream);
 int uncr_mgnll_bwd(const float* pred, const float* targ, const float* var, const float* gscalar,
                    const float* gnone, float* dpred, float* dvar, int B, int K, int Kv, int H, int W, float eps,
-                   int reduction, hipStream_t stream);
+                   int reduction, long long pred_bstride, long long var_bstride, long long dpred_bstride,
+                   long long dvar_bstride, hipStream_t stream);
 int uncr_ensemble_combine(const float* mu, const float* var, int M, long long n, int mode, float* mu_out,
                           float* var_out, hipStream_t stream);
 

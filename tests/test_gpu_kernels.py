@@ -833,3 +833,34 @@ def test_standalone_se_matches_torch():
     assert rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) < 1e-5
     assert rel_err(mg.fc[0].weight.grad.cpu().numpy(), w1.grad.numpy()) < 2e-5
     assert rel_err(mg.fc[2].weight.grad.cpu().numpy(), w2.grad.numpy()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cov,reduction", [("diag", "mean"), ("iso", "sum"), ("diag", "none")])
+def test_mgnll_on_channel_slices_of_the_head_output(cov, reduction):
+    """losses.split_prediction + MGNLL: mean and variance are read in place from the [B,1,13+cov,H,W] prediction and both gradients
+    land in ONE buffer handed back without copies; same numbers as the loss on contiguous copies with torch's own slicing."""
+    from uncrtaints_amd.src import losses
+    torch.manual_seed(11)
+    B, H, W = 3, 32, 64
+    kv = 13 if cov == "diag" else 1
+    base = torch.rand(B, 1, 13 + kv, H, W, device="cuda")
+    base[:, :, 13:] = base[:, :, 13:] * 0.5 + 1e-3
+    y = torch.rand(B, 1, 13, H, W, device="cuda")
+    crit = losses.MultiGaussianNLLLoss(reduction=reduction, eps=1e-8, full=True, mode=cov)
+    a = base.clone().requires_grad_(True)
+    m, v = losses.split_prediction(a, 13, 13 + kv)
+    assert m.data_ptr() == a.data_ptr() and not m.is_contiguous()
+    la, va = crit(m, y, v)
+    b = base.clone().requires_grad_(True)
+    lb, vb = crit(b[:, :, :13].contiguous(), y, b[:, :, 13:].contiguous())
+    g = torch.rand_like(la) if reduction == "none" else None
+    la.backward(g) if g is not None else la.backward()
+    lb.backward(g) if g is not None else lb.backward()
+    assert torch.equal(la, lb) and torch.equal(va, vb)
+    assert torch.equal(a.grad, b.grad)
+    # a consumer that needs only one of the two still gets a full-shape gradient
+    c = base.clone().requires_grad_(True)
+    m, v = losses.split_prediction(c, 13, 13 + kv)
+    (m * 2.0).sum().backward()
+    assert torch.equal(c.grad[:, :, :13], torch.full_like(c.grad[:, :, :13], 2.0)) and float(c.grad[:, :, 13:].abs().max()) == 0.0

@@ -17,7 +17,9 @@ __global__ __launch_bounds__(256) void mgnll_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ var, float* __restrict__ loss_none,
                                                         float* __restrict__ vclamp, float* __restrict__ part,
                                                         int* __restrict__ neg_flag, int B, int K, int Kv, int H, int W,
-                                                        float eps) {
+                                                        float eps, size_t sp, size_t sv) {
+    // sp / sv: elements between consecutive samples of pred / var (K*P / Kv*P when dense; larger when both are channel slices
+    // of the head's [B, 13 + cov, H, W] output, which is then read in place)
     const int P = H * W;
     const int p = blockIdx.x * MG_PX + threadIdx.x;
     float total = 0.f;
@@ -26,7 +28,7 @@ __global__ __launch_bounds__(256) void mgnll_fwd_kernel(const float* __restrict_
         bool neg = false;
         for (int b = 0; b < B; ++b)
             for (int c = 0; c < Kv; ++c) {
-                const float vr = var[((size_t)b * Kv + c) * P + p];
+                const float vr = var[(size_t)b * sv + (size_t)c * P + p];
                 neg |= vr < 0.f;
                 logdet += logf(fmaxf(vr, eps)) * (Kv == 1 ? (float)K : 1.f);
             }
@@ -36,8 +38,8 @@ __global__ __launch_bounds__(256) void mgnll_fwd_kernel(const float* __restrict_
         for (int b = 0; b < B; ++b) {
             float maha = 0.f;
             for (int c = 0; c < K; ++c) {
-                const float v = fmaxf(var[((size_t)b * Kv + (Kv == 1 ? 0 : c)) * P + p], eps);
-                const float e = pred[((size_t)b * K + c) * P + p] - targ[((size_t)b * K + c) * P + p];
+                const float v = fmaxf(var[(size_t)b * sv + (size_t)(Kv == 1 ? 0 : c) * P + p], eps);
+                const float e = pred[(size_t)b * sp + (size_t)c * P + p] - targ[((size_t)b * K + c) * P + p];
                 maha += e * e / v;
                 if (vclamp) vclamp[((size_t)b * K + c) * P + p] = v;   // the clamped per-band variance (iso: broadcast)
             }
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void mgnll_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ gscalar, float scale,
                                                         const float* __restrict__ gnone, float* __restrict__ dpred,
                                                         float* __restrict__ dvar, int B, int K, int Kv, int H, int W,
-                                                        float eps) {
+                                                        float eps, size_t sp, size_t sv, size_t sdp, size_t sdv) {
     const int P = H * W;
     const int p = blockIdx.x * MG_PX + threadIdx.x;
     if (p >= P) return;
@@ -75,23 +77,23 @@ __global__ __launch_bounds__(256) void mgnll_bwd_kernel(const float* __restrict_
         const float gb = gnone ? gnone[((size_t)x * H + y) * B + b] : gs;
         float maha = 0.f;
         for (int c = 0; c < K; ++c) {
-            const float v = fmaxf(var[((size_t)b * Kv + (Kv == 1 ? 0 : c)) * P + p], eps);
-            const float e = pred[((size_t)b * K + c) * P + p] - targ[((size_t)b * K + c) * P + p];
+            const float v = fmaxf(var[(size_t)b * sv + (size_t)(Kv == 1 ? 0 : c) * P + p], eps);
+            const float e = pred[(size_t)b * sp + (size_t)c * P + p] - targ[((size_t)b * K + c) * P + p];
             maha += e * e / v;
         }
         // gradient flows through nan_to_num/clamp only for finite values above the clamp
         const float ind = (maha == maha && maha <= 3.4028234664e38f && maha > 1e-9f) ? 1.f : 0.f;
         float dv_iso = 0.f;
         for (int c = 0; c < K; ++c) {
-            const float v = fmaxf(var[((size_t)b * Kv + (Kv == 1 ? 0 : c)) * P + p], eps);
-            const float e = pred[((size_t)b * K + c) * P + p] - targ[((size_t)b * K + c) * P + p];
+            const float v = fmaxf(var[(size_t)b * sv + (size_t)(Kv == 1 ? 0 : c) * P + p], eps);
+            const float e = pred[(size_t)b * sp + (size_t)c * P + p] - targ[((size_t)b * K + c) * P + p];
             const float iv = 1.f / v;
-            if (dpred) dpred[((size_t)b * K + c) * P + p] = gb * ind * e * iv;
+            if (dpred) dpred[(size_t)b * sdp + (size_t)c * P + p] = gb * ind * e * iv;
             const float dv = 0.5f * gsum * iv - 0.5f * gb * ind * e * e * iv * iv;
             if (Kv == 1) dv_iso += dv;
-            else if (dvar) dvar[((size_t)b * Kv + c) * P + p] = dv;
+            else if (dvar) dvar[(size_t)b * sdv + (size_t)c * P + p] = dv;
         }
-        if (Kv == 1 && dvar) dvar[(size_t)b * P + p] = dv_iso;
+        if (Kv == 1 && dvar) dvar[(size_t)b * sdv + p] = dv_iso;
     }
 }
 
@@ -219,12 +221,15 @@ extern "C" int uncr_mgnll_blocks(int P) { return (P + MG_PX - 1) / MG_PX; }
 
 extern "C" int uncr_mgnll_fwd(const float* pred, const float* targ, const float* var, float* loss_none, float* vclamp,
                               float* part, float* loss_out, int* neg_flag, int B, int K, int Kv, int H, int W, float eps,
-                              int reduction /*0 none, 1 mean, 2 sum*/, hipStream_t stream) {
+                              int reduction /*0 none, 1 mean, 2 sum*/, long long pred_bstride, long long var_bstride,
+                              hipStream_t stream) {
     if (B <= 0 || K <= 0 || (Kv != K && Kv != 1)) return UNCR_ESHAPE;
     if (!pred || !targ || !var || !part) return UNCR_EINVAL;
     const int P = H * W, nb = uncr_mgnll_blocks(P);
+    const size_t sp = pred_bstride > 0 ? (size_t)pred_bstride : (size_t)K * P, sv = var_bstride > 0 ? (size_t)var_bstride : (size_t)Kv * P;
+    if (sp < (size_t)K * P || sv < (size_t)Kv * P) return UNCR_ESHAPE;
     hipLaunchKernelGGL(mgnll_fwd_kernel, dim3(nb), dim3(256), 0, stream, pred, targ, var, loss_none, vclamp, part,
-                       neg_flag, B, K, Kv, H, W, eps);
+                       neg_flag, B, K, Kv, H, W, eps, sp, sv);
     UNCR_LAUNCH_CHECK();
     if (reduction != 0) {
         if (!loss_out) return UNCR_EINVAL;
@@ -237,13 +242,19 @@ extern "C" int uncr_mgnll_fwd(const float* pred, const float* targ, const float*
 
 extern "C" int uncr_mgnll_bwd(const float* pred, const float* targ, const float* var, const float* gscalar,
                               const float* gnone, float* dpred, float* dvar, int B, int K, int Kv, int H, int W,
-                              float eps, int reduction, hipStream_t stream) {
+                              float eps, int reduction, long long pred_bstride, long long var_bstride, long long dpred_bstride,
+                              long long dvar_bstride, hipStream_t stream) {
     if (B <= 0 || K <= 0 || (Kv != K && Kv != 1)) return UNCR_ESHAPE;
     if ((reduction == 0 && !gnone) || (reduction != 0 && !gscalar)) return UNCR_EINVAL;
     const int P = H * W;
+    const size_t dk = (size_t)K * P, dkv = (size_t)Kv * P;
+    const size_t sp = pred_bstride > 0 ? (size_t)pred_bstride : dk, sv = var_bstride > 0 ? (size_t)var_bstride : dkv;
+    const size_t sdp = dpred_bstride > 0 ? (size_t)dpred_bstride : dk, sdv = dvar_bstride > 0 ? (size_t)dvar_bstride : dkv;
+    if (sp < dk || sv < dkv || sdp < dk || sdv < dkv) return UNCR_ESHAPE;
     const float sc = reduction == 1 ? (float)(1.0 / ((double)P * (double)B)) : 1.f;
     hipLaunchKernelGGL(mgnll_bwd_kernel, dim3(uncr_mgnll_blocks(P)), dim3(256), 0, stream, pred, targ, var,
-                       reduction ? gscalar : nullptr, sc, reduction ? nullptr : gnone, dpred, dvar, B, K, Kv, H, W, eps);
+                       reduction ? gscalar : nullptr, sc, reduction ? nullptr : gnone, dpred, dvar, B, K, Kv, H, W, eps, sp, sv, sdp,
+                       sdv);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -1335,13 +1335,32 @@ def eltloss_backward(kind: int, gout: Tensor, pred: Tensor, target: Tensor, var:
     return dpred, dvar
 
 
+def _batch_strided(t: Tensor) -> bool:
+    """[B,1,K,H,W] fp32 whose samples are dense [K,H,W] blocks at any distance >= K*H*W: a channel slice of the head's output."""
+    if t.dim() != 5 or t.dtype != torch.float32 or t.shape[1] != 1:
+        return False
+    B, _, K, H, W = t.shape
+    st = t.stride()
+    return st[4] == 1 and st[3] == W and st[2] == H * W and (B == 1 or st[0] >= K * H * W)
+
+
+def _bs(t: Tensor):
+    """(pointer, batch stride) of a dense or batch-strided tensor for the *_bstride arguments."""
+    return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else t.shape[2] * t.shape[3] * t.shape[4])
+
+
 def mgnll_forward(pred: Tensor, target: Tensor, var: Tensor, eps: float, reduction: str, check_negative: bool,
                   want_variance: bool = False):
-    """-> (loss, clamped per-band variance [B,1,K,H,W] or None)"""
+    """-> (loss, clamped per-band variance [B,1,K,H,W] or None).  pred / var may be channel slices of the head's output (read in
+    place); anything else must be contiguous."""
     B, T1, K, H, W = pred.shape
     Kv = var.shape[2]
     dev = pred.device
     P = H * W
+    if not pred.is_cuda:
+        raise RuntimeError("uncrtaints_amd kernels need tensors on the GPU (cuda device); there is no CPU path")
+    pred = pred if _batch_strided(pred) else pred.contiguous()
+    var = var if _batch_strided(var) else var.contiguous()
     nb = hb.query("uncr_mgnll_blocks", P)
     part = _f32((nb,), dev)
     red = _RED[reduction]
@@ -1349,8 +1368,9 @@ def mgnll_forward(pred: Tensor, target: Tensor, var: Tensor, eps: float, reducti
     loss = _f32((), dev) if red else None
     flag = torch.zeros((1,), device=dev, dtype=torch.int32) if check_negative else None
     vclamp = _f32((B, 1, K, H, W), dev) if want_variance else None
-    hb.call("uncr_mgnll_fwd", pred, target, var, loss_none, vclamp, part, loss, flag, B, K, Kv, H, W, float(eps), red,
-            _stream())
+    (pp, sp), (pv, sv) = _bs(pred), _bs(var)
+    hb.call("uncr_mgnll_fwd", pp, target, pv, loss_none, vclamp, part, loss, flag, B, K, Kv, H, W, float(eps), red,
+            sp, sv, _stream())
     if check_negative and int(flag.item()):      # opt-in host sync (losses.py:199-200)
         raise ValueError("var has negative entry/entries")
     if red == 0:
@@ -1360,16 +1380,28 @@ def mgnll_forward(pred: Tensor, target: Tensor, var: Tensor, eps: float, reducti
 
 def mgnll_backward(gout: Tensor, pred: Tensor, target: Tensor, var: Tensor, eps: float, reduction: str,
                    need_dpred: bool = True, need_dvar: bool = True):
+    """With both gradients requested they are the two channel slices of ONE [B,1,K+Kv,H,W] buffer (written in place by the kernel):
+    when pred / var were split off the head's output with losses.split_prediction, its backward hands that buffer on as the
+    gradient of the output without a copy."""
     B, T1, K, H, W = pred.shape
     Kv = var.shape[2]
     red = _RED[reduction]
-    dpred = torch.empty_like(pred) if need_dpred else None
-    dvar = torch.empty_like(var) if need_dvar else None
+    dpred = dvar = None
+    if need_dpred and need_dvar:
+        full = _f32((B, 1, K + Kv, H, W), pred.device)
+        dpred, dvar = full[:, :, :K], full[:, :, K:]
+    elif need_dpred:
+        dpred = _f32((B, 1, K, H, W), pred.device)
+    elif need_dvar:
+        dvar = _f32((B, 1, Kv, H, W), pred.device)
     gout = gout.contiguous().to(torch.float32)
     if red == 0 and B == 1:
         gout = gout.reshape(W, H, 1)
-    hb.call("uncr_mgnll_bwd", pred, target, var, gout if red else None, gout if red == 0 else None, dpred, dvar, B, K,
-            Kv, H, W, float(eps), red, _stream())
+    (pp, sp), (pv, sv) = _bs(pred), _bs(var)
+    pdp, sdp = _bs(dpred) if dpred is not None else (None, 0)
+    pdv, sdv = _bs(dvar) if dvar is not None else (None, 0)
+    hb.call("uncr_mgnll_bwd", pp, target, pv, gout if red else None, gout if red == 0 else None, pdp, pdv, B, K,
+            Kv, H, W, float(eps), red, sp, sv, sdp, sdv, _stream())
     return dpred, dvar
 
 

@@ -35,9 +35,14 @@ class BaseModel(nn.Module):
         self.loss_G.backward()
 
     def get_loss_G(self):
-        self.loss_G, self.netG.variance = losses.calc_loss(
-            self.criterion, self.config, self.fake_B[:, :, :self.netG.mean_idx, ...], self.real_B,
-            var=self.fake_B[:, :, self.netG.mean_idx:self.netG.vars_idx, ...])
+        mi, vi = self.netG.mean_idx, self.netG.vars_idx
+        if vi > mi and self.fake_B.shape[2] == vi:
+            # the slices of base_model.py:72-85 as one autograd node: the loss kernels read them in place and their backward hands
+            # ONE gradient buffer back to the head (losses.split_prediction)
+            mean, var = losses.split_prediction(self.fake_B, mi, vi)
+        else:
+            mean, var = self.fake_B[:, :, :mi, ...], self.fake_B[:, :, mi:vi, ...]
+        self.loss_G, self.netG.variance = losses.calc_loss(self.criterion, self.config, mean, self.real_B, var=var)
 
     def set_input(self, input):
         dev = self.config.device

@@ -20,7 +20,10 @@ Tensor = torch.Tensor
 class _MGNLLFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, var, eps, reduction, check_negative):
-        pred, target, var = pred.contiguous().float(), target.contiguous().float(), var.contiguous().float()
+        # channel slices of the head's output are read in place (engine._batch_strided); anything else is made dense
+        pred = pred.float() if E._batch_strided(pred.float()) else pred.contiguous().float()
+        var = var.float() if E._batch_strided(var.float()) else var.contiguous().float()
+        target = target.contiguous().float()
         loss, vclamp = E.mgnll_forward(pred, target, var, eps, reduction, check_negative, want_variance=True)
         ctx.save_for_backward(pred, target, var)
         ctx.eps, ctx.reduction = eps, reduction
@@ -33,6 +36,38 @@ class _MGNLLFn(torch.autograd.Function):
         dpred, dvar = E.mgnll_backward(gout, pred, target, var, ctx.eps, ctx.reduction,
                                        ctx.needs_input_grad[0], ctx.needs_input_grad[2])
         return dpred, None, dvar, None, None, None
+
+
+class _SplitFn(torch.autograd.Function):
+    """(out[:, :, :k0], out[:, :, k0:k1]) as views.  Backward: when the two incoming gradients are the channel slices of one buffer
+    (what the MGNLL backward kernel writes), that buffer IS the gradient of `out` -- no zero fills, embedding copies or add."""
+
+    @staticmethod
+    def forward(ctx, out, k0, k1):
+        ctx.k0, ctx.k1, ctx.shape = k0, k1, tuple(out.shape)
+        return out[:, :, :k0], out[:, :, k0:k1]
+
+    @staticmethod
+    def backward(ctx, dm, dv):
+        k0, k1, shape = ctx.k0, ctx.k1, ctx.shape
+        if dm is not None and dv is not None and shape[2] == k1:
+            base = dm._base
+            if (base is not None and base is dv._base and tuple(base.shape) == shape and base.is_contiguous()
+                    and dm.stride() == base.stride() and dv.stride() == base.stride()
+                    and dm.storage_offset() == base.storage_offset()
+                    and dv.storage_offset() == base.storage_offset() + k0 * base.stride(2)):
+                return base, None, None
+        g = torch.zeros(shape, device=(dm if dm is not None else dv).device, dtype=(dm if dm is not None else dv).dtype)
+        if dm is not None:
+            g[:, :, :k0] = dm
+        if dv is not None:
+            g[:, :, k0:k1] = dv
+        return g, None, None
+
+
+def split_prediction(out: Tensor, mean_idx: int, vars_idx: int):
+    """Mean and variance channels of the model output [B,1,13+cov,H,W] -- what base_model.py:72-85 slices out -- for the loss."""
+    return _SplitFn.apply(out, int(mean_idx), int(vars_idx))
 
 
 def multi_gaussian_nll_loss(input: Tensor, target: Tensor, var: Tensor, full: bool = False, eps: float = 1e-8,
