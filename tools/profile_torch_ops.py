@@ -13,7 +13,8 @@ x, y, dates = bench.synthetic(4, 3, 256, 256, seed=1, device=dev)
 def step():
     opt.zero_grad(set_to_none=True)
     out = model(x, batch_positions=dates)
-    loss, _ = crit(out[:, :, :13], y, out[:, :, 13:26])
+    m, v = losses.split_prediction(out, 13, 26)
+    loss, _ = crit(m, y, v)
     loss.backward()
     opt.step()
 for _ in range(2): step()
@@ -21,8 +22,8 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_stack_n=6) if e.key.startswith("aten::") and e.device_time_total > 0]
+rows = [e for e in prof.key_averages(group_by_stack_n=12) if e.key.startswith("aten::") and e.device_time_total > 0]
 rows.sort(key=lambda e: -e.count)
 for e in rows[:40]:
-    st = [s for s in e.stack if "uncrtaints_amd" in s or "bench" in s or "losses" in s][:2]
+    st = [s for s in e.stack if "uncrtaints_amd" in s or "bench" in s or "losses" in s or "optim" in s][:3]
     print(f"{e.key:28s} n={e.count:3d} cuda={e.device_time_total:8.1f}us  {' <- '.join(s.split('/')[-1] for s in st)}")
