@@ -5,35 +5,34 @@
 //         dWpw[co,c] = sum_n s[n,c] G[n,co,c]  follow without another pass over the activations.
 #include "common.h"
 
-// grid = N, block = 1024 (latency-bound: 4 slices of the slot range per channel, 16 waves for the MLP).  C <= 256, R <= 64.
+// grid = N, block = 1024 (latency-bound: 16 waves for every phase).  C <= 256, R <= 64.  Dynamic LDS: W2 staged with coalesced reads
+// ([C][R + 1] floats) so that thread c's sequential dot product -- same order as a plain row walk -- reads LDS, not 64 scattered
+// cache lines per step.
 __global__ __launch_bounds__(1024) void se_mlp_fwd_kernel(const float2* __restrict__ pool_part, int NP, int C, int R,
                                                           int P, const float* __restrict__ W1,
                                                           const float* __restrict__ W2, float* __restrict__ pooled,
                                                           float* __restrict__ hid_pre, float* __restrict__ s) {
     const int n = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ float w2s[];          // [C][R + 1]
     __shared__ float sp[256], sh[64];
     __shared__ double comb[4][256];
+    for (int i = tid; i < C * R; i += 1024) w2s[(i / R) * (R + 1) + (i % R)] = W2[i];      // consumed after two barriers
     {
-        const int c = tid & 255, sl = tid >> 8;
-        double a = 0.0;
-        if (c < C) {
+        // partial sums of the pooling pass: 16 consecutive lanes walk one channel's slots (128 contiguous bytes per step), four
+        // slices of the slot range per channel as before; lanes combined in a fixed order, everything in fp64
+        const int l16 = tid & 15, grp = tid >> 4;              // 64 groups of 16 lanes
+        for (int c = grp; c < C; c += 64) {
             const float2* src = pool_part + ((size_t)n * C + c) * NP;
-            const int j1 = (NP * (sl + 1)) / 4;
-            int j = (NP * sl) / 4;
-            for (; j + 8 <= j1; j += 8) {      // 8 independent loads in flight, fixed summation order
-                float v[8];
+            double a = 0.0;
+            for (int j = l16; j < NP; j += 16) a += (double)src[j].x;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = src[j + q].x;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) a += (double)v[q];
-            }
-            for (; j < j1; ++j) a += (double)src[j].x;
+            for (int m = 8; m >= 1; m >>= 1) a += __shfl_xor(a, m, 16);
+            if (l16 == 0) comb[0][c] = a;
         }
-        comb[sl][c] = a;
     }
     __syncthreads();
     if (tid < C) {
-        const float m = (float)((comb[0][tid] + comb[1][tid] + comb[2][tid] + comb[3][tid]) / (double)P);
+        const float m = (float)(comb[0][tid] / (double)P);
         sp[tid] = m;
         pooled[n * C + tid] = m;
     }
@@ -52,7 +51,7 @@ __global__ __launch_bounds__(1024) void se_mlp_fwd_kernel(const float2* __restri
     __syncthreads();
     if (tid < C) {
         float a = 0.f;
-        for (int j = 0; j < R; ++j) a = fmaf(W2[tid * R + j], sh[j], a);
+        for (int j = 0; j < R; ++j) a = fmaf(w2s[tid * (R + 1) + j], sh[j], a);
         s[n * C + tid] = sigmoid_f(a);
     }
 }
@@ -64,8 +63,10 @@ __global__ __launch_bounds__(1024) void se_mlp_bwd_frame_kernel(
     const float* __restrict__ hid_pre, float* __restrict__ ds_pre, float* __restrict__ dhid_pre,
     float* __restrict__ dpool_px) {
     const int n = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ float w2s[];          // [C][R + 1]: W2 staged with coalesced reads for the column walks below
     __shared__ float sds[256], sdh[64];
     __shared__ double comb[4][256];
+    for (int i = tid; i < C * R; i += 1024) w2s[(i / R) * (R + 1) + (i % R)] = W2[i];
     {
         // block = 1024: 4 slices of the co range per channel, combined in a fixed order
         const int c = tid & 255, sl = tid >> 8;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(1024) void se_mlp_bwd_frame_kernel(
     const int lane = tid & 63, wv = tid >> 6;
     for (int j = wv; j < R; j += 16) {
         float a = 0.f;
-        for (int c = lane; c < C; c += 64) a = fmaf(W2[c * R + j], sds[c], a);
+        for (int c = lane; c < C; c += 64) a = fmaf(w2s[c * (R + 1) + j], sds[c], a);
         a = wave_sum(a);
         if (lane == 0) {
             const float d = a * gelu_grad_f(hid_pre[n * R + j]);
@@ -141,11 +142,21 @@ __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__
     }
 }
 
+// dynamic LDS above 64 KB (C = 256 with R = 64: 66.6 KB) needs the opt-in; done once per process
+static void se_lds_optin() {
+    static bool done = false;
+    if (done) return;
+    hipFuncSetAttribute((const void*)se_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute((const void*)se_mlp_bwd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    done = true;
+}
+
 extern "C" int uncr_se_mlp_fwd(const float* pool_part, int NP, int N, int C, int R, int P, const float* W1,
                                const float* W2, float* pooled, float* hid_pre, float* s, hipStream_t stream) {
     if (C > 256 || R > 64 || N <= 0) return UNCR_ESHAPE;
-    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(N), dim3(1024), 0, stream, (const float2*)pool_part, NP, C, R, P, W1,
-                       W2, pooled, hid_pre, s);
+    se_lds_optin();
+    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(N), dim3(1024), (size_t)C * (R + 1) * sizeof(float), stream, (const float2*)pool_part,
+                       NP, C, R, P, W1, W2, pooled, hid_pre, s);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -155,8 +166,9 @@ extern "C" int uncr_se_mlp_bwd(const float* G, const float* Wpw, int N, int Co, 
                                const float* hid_pre, float* ds_pre, float* dhid_pre, float* dpool_px, float* dWpw,
                                float* dW1, float* dW2, hipStream_t stream) {
     if (C > 256 || R > 64 || N <= 0) return UNCR_ESHAPE;
-    hipLaunchKernelGGL(se_mlp_bwd_frame_kernel, dim3(N), dim3(1024), 0, stream, G, Wpw, Co, C, R, P, W1, W2, s,
-                       hid_pre, ds_pre, dhid_pre, dpool_px);
+    se_lds_optin();
+    hipLaunchKernelGGL(se_mlp_bwd_frame_kernel, dim3(N), dim3(1024), (size_t)C * (R + 1) * sizeof(float), stream, G, Wpw, Co, C, R, P,
+                       W1, W2, s, hid_pre, ds_pre, dhid_pre, dpool_px);
     UNCR_LAUNCH_CHECK();
     hipLaunchKernelGGL(se_wgrad_kernel, dim3(Co + R), dim3(256), 0, stream, G, N, Co, C, R, s, pooled, hid_pre,
                        ds_pre, dhid_pre, dWpw, dW1, dW2);
