@@ -37,12 +37,17 @@ for name, okw, mkw, (B, T, H, W) in cases:
         out = m(x.cuda(), batch_positions=dates.cuda())
         res.append(rel(out.detach(), o.detach()))
         if training:
+            # gradients on the max-pool branch the HIP forward took (an arg-max flip at a near-tie is not an error)
+            from gpu_util import pool_branch
+            pidx, flips = pool_branch(m, p, x, dates, cfg) if not getattr(cfg, "is_mono", False) else (None, 0)
+            pt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in p.items()}
+            o = orc.forward(pt, x, dates, cfg, training=True, pool_idx=pidx, update_running=False)
             lo = orc.loss_from_output(o, y, cfg); lo.backward()
             nv = 13 if cfg.covmode == "diag" else 1
             crit = losses.MultiGaussianNLLLoss(reduction="mean", full=True, mode=cfg.covmode)
             l, _ = crit(out[:, :, :13], y.cuda(), out[:, :, 13:13 + nv]); l.backward()
             p64 = {k: (v.double().clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else (v.double().clone() if v.dtype.is_floating_point else v.clone())) for k, v in p.items()}
-            o64 = orc.forward(p64, x.double(), dates.double(), cfg, training=True)
+            o64 = orc.forward(p64, x.double(), dates.double(), cfg, training=True, pool_idx=pidx, update_running=False)
             orc.loss_from_output(o64, y.double(), cfg).backward()
             gmax = max(q.grad.abs().max().item() for q in p64.values() if getattr(q, "grad", None) is not None)
             rows = []
