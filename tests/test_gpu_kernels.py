@@ -864,3 +864,42 @@ def test_mgnll_on_channel_slices_of_the_head_output(cov, reduction):
     m, v = losses.split_prediction(c, 13, 13 + kv)
     (m * 2.0).sum().backward()
     assert torch.equal(c.grad[:, :, :13], torch.full_like(c.grad[:, :, :13], 2.0)) and float(c.grad[:, :, 13:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,pro", [(128, 256, 1), (256, 128, 2)])
+def test_fp16_two_part_forward_gemm_accuracy(E, Cin, Cout, pro):
+    """The forward wide GEMMs behind a norm prologue use a two-part fp16 split (three products, pw_gemm.h) instead of the exact
+    3 x bf16 split (six): against fp64 both stay at the level of an fp32 FMA chain (<= 1e-6 of max|out|); small and large weight
+    scales keep that (pack-time scaling), and an activation beyond the fp16 range saturates instead of producing inf / nan."""
+    import uncrtaints_amd.hip_backend as hb
+    torch.manual_seed(Cin)
+    N, P = 2, 2048
+    x = torch.randn(N, Cin, P) * 1.3 + 0.2
+    A, B = torch.rand(N * Cin) + 0.5, torch.randn(N * Cin) * 0.3
+    S = torch.rand(N * Cin) + 0.2
+    for wscale in (0.07, 1e-3, 30.0):
+        W = torch.randn(Cout, Cin) * wscale
+        u = A.view(N, Cin, 1).double() * x.double() + B.view(N, Cin, 1).double()
+        if pro == 2:
+            u = S.view(N, Cin, 1).double() * torch.nn.functional.gelu(u)
+        truth = torch.einsum("oc,ncp->nop", W.double(), u)
+        errs = {}
+        for h2 in (1, 0):
+            old = hb.query("uncr_pw_set_h2", h2)
+            try:
+                Wt = E.pack_wt(dev(W), transpose=True)
+                out, part = E.pw_gemm(dev(x), Wt, N, Cin, Cout, P, pro=pro, k=(dev(A), dev(B), dev(S) if pro == 2 else None), epi=1)
+            finally:
+                hb.query("uncr_pw_set_h2", old)
+            errs[h2] = float((out.cpu().double() - truth).abs().max() / truth.abs().max())
+            s = part.buf.view(N * Cout, -1, 2).double().sum(1).cpu()
+            assert float((s[:, 0] - truth.reshape(N * Cout, P).sum(1)).abs().max() / truth.reshape(N * Cout, P).sum(1).abs().max()) < 1e-4
+        print(f"[parity] forward GEMM {Cin}->{Cout} pro {pro} |w|~{wscale:g}: fp16 two-part {errs[1]:.2e}, bf16 three-part {errs[0]:.2e}")
+        assert errs[1] <= 1e-6 and errs[0] <= 1e-6, errs
+    # out-of-range activation: saturates (finite result), never inf / nan
+    xb = x.clone()
+    xb[0, 3, 7] = 3e5
+    out, _ = E.pw_gemm(dev(xb), E.pack_wt(dev(torch.randn(Cout, Cin) * 0.07), transpose=True), N, Cin, Cout, P, pro=pro,
+                       k=(dev(A), dev(B), dev(S) if pro == 2 else None), epi=1)
+    assert bool(torch.isfinite(out).all())

@@ -34,6 +34,7 @@ struct PwArgs {
     float head_scale = 1.f, head_eps = 0.f;
     float* head_pre = nullptr;   // optional second output: the pre-activation [N][Cout][P]
     const float* k3 = nullptr;    // PRO_NORMBWD: the norm's mean per (n, ci) -- centred form C1*v + C2*(v2 - mean) + C3; null: 0
+    int h2 = 0;                   // wide kernels, fp32 storage, PRO_AFFINE / PRO_AFFINE_GELU with EPI 1: fp16 two-part split
     const float* emu = nullptr;   // epi 5 / 6: mean of the PreNorm per (n, co): out = dy + e0*v + e1*(x - emu) + e2; null: 0
 };
 
@@ -49,6 +50,30 @@ __device__ __forceinline__ void split3_bf16(float x, unsigned& h, unsigned& m, u
 __device__ __forceinline__ unsigned pack_bf16x2(unsigned a, unsigned b) {
     return __builtin_amdgcn_perm(b, a, 0x07060302u);
 }
+
+// Two-part fp16 split for the FORWARD wide GEMMs (fp32 storage): x*SC = h + l + r with h, l fp16 (round to nearest) and
+// |r| <= max(2^-22 |x*SC|, 2^-25) -- fp16 has 11 significant bits, so two parts carry 22; the three products h*h', h*l', l*h'
+// reach 2^-22 relative accuracy, the same order as an fp32 FMA chain, at HALF the matrix-pipe work of the exact 3 x bf16 split.
+// fp16's narrow exponent is why this is used only where the range is known: activation operands are outputs of a norm prologue
+// (|u| <= sqrt(group size) * |gamma| + |beta|; saturated at +-65504 rather than overflowing), weights are scaled by 2^6 at pack
+// time (|w| < 1023 keeps its full precision, the scale leaves in the epilogue).  Gradient GEMMs keep the bf16 split: gradients
+// span the whole fp32 exponent range.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2v_t __attribute__((ext_vector_type(2)));
+#define PWS_H2_WSCALE 64.0f
+#define PWS_H2_INV_WSCALE 0.015625f
+// (a, b) -> packed fp16 pairs {lo16 = a, hi16 = b}: hi parts and lo parts
+__device__ __forceinline__ void split2_f16_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+    b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+    const f16x2_t h = __builtin_convertvector(f32x2v_t{a, b}, f16x2_t);
+    const f32x2v_t hf = __builtin_convertvector(h, f32x2v_t);
+    const f16x2_t l = __builtin_convertvector(f32x2v_t{a - hf.x, b - hf.y}, f16x2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+#define PWS_NSLOT 5      // packed weight slots per (k-step, co tile): bf16 h, m, l and fp16 h, l (scaled)
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));

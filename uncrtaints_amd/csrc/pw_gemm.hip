@@ -16,6 +16,7 @@
 //   * weights are tiny (<=128 KB, L2 resident): each wave reads its A fragments (Wt[k][co], co
 //     contiguous => 128-B coalesced) straight from global.
 #include "pw_gemm.h"
+#include <cstdlib>
 
 
 // PRE2 = false drops the second prefetch register set (PRO_NORMBWD unavailable): keeps the 32-wide
@@ -474,6 +475,10 @@ static int pw_coutp(int Cout) { return Cout > 128 ? 256 : (Cout > 64 ? 128 : (Co
 static int g_split = 1;
 extern "C" int uncr_pw_set_split(int on) { const int old = g_split; g_split = on ? 1 : 0; return old; }
 static bool use_split(int Cout) { return g_split && pw_coutp(Cout) >= 128; }
+// fp16 two-part split (three products) for the forward GEMMs behind a norm prologue (pw_gemm.h); 0 keeps the exact 3 x bf16 split
+// (six products) everywhere -- A/B measurements and tests
+static int g_h2 = [] { const char* e = getenv("UNCR_PW_H2"); return (e && atoi(e) == 0) ? 0 : 1; }();      // env: A/B runs
+extern "C" int uncr_pw_set_h2(int on) { const int old = g_h2; g_h2 = on ? 1 : 0; return old; }
 
 extern "C" int uncr_pw_coutp(int Cout) { return Cout <= 256 ? pw_coutp(Cout) : -1; }
 extern "C" int uncr_pw_kpad(int Cin) { return ((Cin + 31) / 32) * 32; }
@@ -509,7 +514,7 @@ extern "C" int uncr_pack_wt(const float* W, int rows_k, int cols_co, int ld, int
 // threads uncr_pack_wt needs for one weight (the batch launch is sized by the largest item)
 extern "C" int uncr_pack_wt_threads(int rows_k, int cols_co) {
     if (cols_co > 256 || rows_k > 256 || cols_co <= 0 || rows_k <= 0) return -1;
-    if (use_split(cols_co)) return (int)(pw_split_wt_floats(rows_k, pw_coutp(cols_co)) / 12);   // 3 x 16 B per thread
+    if (use_split(cols_co)) return (int)(pw_split_wt_floats(rows_k, pw_coutp(cols_co)) / (4 * PWS_NSLOT));   // PWS_NSLOT x 16 B per thread
     return uncr_pw_kpad(rows_k) * pw_coutp(cols_co);
 }
 extern "C" int uncr_pack_wt_batch(const long long* desc, int n_items, int max_threads, hipStream_t stream) {
@@ -535,6 +540,7 @@ extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, vo
     if (P % tp) return UNCR_ESHAPE;
     PwArgs g{in, in2, Wt, out, k0, k1, k2, bias, aux, e0, e1, e2, e3, (float2*)part, bias_stride_n, Cin, Cout, P, pro, epi};
     g.k3 = pro == PRO_NORMBWD ? kmu : nullptr;
+    g.h2 = g_h2;
     const int cp = pw_coutp(Cout);
     if (use_split(Cout)) {
         if (in_dt != out_dt) return UNCR_EINVAL;      // the wide kernels have one storage type for all activation operands

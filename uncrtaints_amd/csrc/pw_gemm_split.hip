@@ -85,14 +85,19 @@ template <bool NT, typename TA> __device__ __forceinline__ void pws_st(TA* p, co
 #ifndef PWS_A16_DEPTH_CT2
 #define PWS_A16_DEPTH_CT2 1    // raw chunks in flight of the 256-channel bf16 variants (experiment knob)
 #endif
+#ifndef PWS_H2_DEPTH_CT2
+#define PWS_H2_DEPTH_CT2 1     // raw chunks in flight of the 256-channel fp16 two-part variant
+#endif
 #ifndef PWS_A16_OCC
 #define PWS_A16_OCC 2          // blocks per CU the bf16 variants are compiled for (experiment knob)
 #endif
-template <int CT, int PRO, int EPI, int DEPTH, typename TA>
+// H2 = true (fp32 storage, forward GEMMs behind a norm prologue): two fp16 parts per operand, three products (pw_gemm.h).
+template <int CT, int PRO, int EPI, int DEPTH, typename TA, bool H2 = false>
 __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2) void pw_gemm_split_kernel(PwArgs g) {
     constexpr int NT = 256, WN = 4;
     constexpr bool BF = sizeof(TA) == 2;
-    constexpr int NPA = BF ? 1 : 3;            // activation parts in LDS
+    static_assert(!(H2 && BF), "the fp16 two-part split is for fp32 storage");
+    constexpr int NPA = BF ? 1 : (H2 ? 2 : 3);            // activation parts in LDS
     constexpr int NW = PWS_A16_WPARTS;         // weight parts used with bf16 activations
     using Raw = typename PwsRaw<TA>::type;
     constexpr bool PRE2 = PRO == PRO_NORMBWD;
@@ -218,11 +223,17 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                 }
                 else if constexpr (PRO == PRO_AFFINE_RELU) v = fmaxf(fmaf(c0[r], v, c1[r]), 0.f);
                 if (!valid[r]) v = 0.f;
-                if constexpr (BF) vv[r] = v;
+                if constexpr (BF || H2) vv[r] = v;
                 else split3_bf16(v, hh[r], mm[r], ll[r]);
             }
             if constexpr (BF) {      // one operand part: the prologue's fp32 result rounded to bf16 (RNE)
                 *(u32x2_t*)(b + e * 512) = u32x2_t{cvt_pk_bf16(vv[0], vv[1]), cvt_pk_bf16(vv[2], vv[3])};
+            } else if constexpr (H2) {
+                unsigned h01, l01, h23, l23;
+                split2_f16_pair(vv[0], vv[1], h01, l01);
+                split2_f16_pair(vv[2], vv[3], h23, l23);
+                *(u32x2_t*)(b + e * 512) = u32x2_t{h01, h23};
+                *(u32x2_t*)(b + 8192 + e * 512) = u32x2_t{l01, l23};
             } else {
                 *(u32x2_t*)(b + e * 512) = u32x2_t{pack_bf16x2(hh[0], hh[1]), pack_bf16x2(hh[2], hh[3])};
                 *(u32x2_t*)(b + 8192 + e * 512) = u32x2_t{pack_bf16x2(mm[0], mm[1]), pack_bf16x2(mm[2], mm[3])};   // part stride 8192
@@ -243,8 +254,8 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
     zero_acc();
 
     // A fragments: Wp[ks][cotile][part][lane] (16 B each)
-    const u32x4_t* wp = (const u32x4_t*)g.Wt + (size_t)(wn * CT) * 3 * 64 + lane;
-    auto lda = [&](int ks, int ct, int part) { return wp[((size_t)(ks * NCT + ct) * 3 + part) * 64]; };
+    const u32x4_t* wp = (const u32x4_t*)g.Wt + (size_t)(wn * CT) * PWS_NSLOT * 64 + lane;
+    auto lda = [&](int ks, int ct, int part) { return wp[((size_t)(ks * NCT + ct) * PWS_NSLOT + (H2 ? 3 : 0) + part) * 64]; };
     u32x4_t ah[CT], am[CT], al[CT];
     u32x4_t a2[BF ? 2 : 1][BF ? NW : 1][CT];      // bf16 activations: the A fragments of two consecutive k-steps
     using S0 = std::integral_constant<int, 0>;
@@ -258,6 +269,9 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
             for (int w = 0; w < NW; ++w)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) a2[q][w][ct] = lda(q, ct, w);
+    } else if constexpr (H2) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); al[ct] = lda(0, ct, 1); }
     } else {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
 #pragma unroll
         for (int e = 0; e < 4; ++e) b[e] = *(const u32x4_t*)(p0 + part * 8192 + e * 512);   // one ds_read_b128 = the lane's 8 k-values
     };
-    if constexpr (!BF) ldb(&xs[0][0] + rd_off, 1, bm);
+    if constexpr (!BF && !H2) ldb(&xs[0][0] + rd_off, 1, bm);
     ldb(&xs[0][0] + rd_off, 0, bh);
 
 #define PWS_MF(A, B)                                                                                          \
@@ -313,6 +327,28 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         PWS_SB();
 #undef PWS_SB
     };
+#define PWS_MF16(A, B)                                                                                        \
+    _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) _Pragma("unroll") for (int e = 0; e < 4; ++e)           \
+        acc[e][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, A[ct]),              \
+                                                            __builtin_bit_cast(f16x8_t, B[e]), acc[e][ct], 0, 0, 0)
+    // fp16 two-part k-step: three products; the low B part is read at the top of its own k-step, everything else rolls
+    auto kstep_h2 = [&](int ksn, const unsigned char* cb, const unsigned char* nb, auto roll) {
+        constexpr bool ROLL = decltype(roll)::value;
+#define PWS_SB() __builtin_amdgcn_sched_barrier(0)
+        ldb(cb, 1, bl);
+        PWS_SB();
+        PWS_MF16(ah, bh); PWS_SB();
+        PWS_MF16(al, bh); PWS_SB();
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) if (ROLL) al[ct] = lda(ksn, ct, 1);
+        PWS_SB();
+        PWS_MF16(ah, bl); PWS_SB();
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) if (ROLL) ah[ct] = lda(ksn, ct, 0);
+        if (ROLL) ldb(nb, 0, bh);
+        PWS_SB();
+#undef PWS_SB
+    };
     // bf16 activations: k-step with fragment set q (= its parity): NW products, then the set is re-loaded with the weights of
     // k-step `ksn` (two k-steps ahead, wrapping into the next tile) and bh with the next k-step's B operand
     auto kstep_a16 = [&](auto qc, int ksn, const unsigned char* nb) {
@@ -343,11 +379,13 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         const unsigned char* xn = &xs[par ^ 1][0] + rd_off;
         const int cn = c + 1 == nkp ? 0 : c + 1;                 // the next chunk of the stream (wraps into the next tile)
         if constexpr (BF) kstep_a16(Q0{}, 2 * c + 2 >= nks ? 2 * c + 2 - nks : 2 * c + 2, xb + 4096);
+        else if constexpr (H2) kstep_h2(2 * c + 1, xb, xb + 4096, Roll{});
         else kstep(2 * c + 1, xb, xb + 4096, Roll{});
         if (!(PWS_ABL & 2)) stage_chunk(cn, par ^ 1, slot);
         if (!(PWS_ABL & 4)) { load_chunk(lp, slot); advance(lp); }
         __syncthreads();
         if constexpr (BF) kstep_a16(Q1{}, 2 * c + 3 >= nks ? 2 * c + 3 - nks : 2 * c + 3, xn);
+        else if constexpr (H2) kstep_h2(2 * c + 2 == nks ? 0 : 2 * c + 2, xb + 4096, xn, roll_last);
         else kstep(2 * c + 2 == nks ? 0 : 2 * c + 2, xb + 4096, xn, roll_last);
         par ^= 1;
     };
@@ -421,7 +459,11 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                     const int r = rb + q;
                     const int col = row_of(ct, r) + 4 * kg;
                     const float bb = EPI == 6 ? 0.f : ecf[0][col];
-                    float4 v = make_float4(acc[0][ct][r] + bb, acc[1][ct][r] + bb, acc[2][ct][r] + bb, acc[3][ct][r] + bb);
+                    float4 v;
+                    if constexpr (H2)       // the weights' pack-time scale leaves here
+                        v = make_float4(fmaf(acc[0][ct][r], PWS_H2_INV_WSCALE, bb), fmaf(acc[1][ct][r], PWS_H2_INV_WSCALE, bb),
+                                        fmaf(acc[2][ct][r], PWS_H2_INV_WSCALE, bb), fmaf(acc[3][ct][r], PWS_H2_INV_WSCALE, bb));
+                    else v = make_float4(acc[0][ct][r] + bb, acc[1][ct][r] + bb, acc[2][ct][r] + bb, acc[3][ct][r] + bb);
                     float s0 = 0.f, s1 = 0.f;
                     if constexpr (EPI == 3) {
                         // du2 = gelu'(A*h2 + B) * (S*dz + D): the SE / GELU backward applied to the fresh accumulator
@@ -493,8 +535,12 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         if constexpr (!BF) {      // (bf16 activations: the rolling operand loads already wrapped into the next tile)
             // operands of the next tile's first k-step (its chunk 0 is already staged in xs[par])
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
-            ldb(&xs[par][0] + rd_off, 1, bm);
+            for (int ct = 0; ct < CT; ++ct) {
+                ah[ct] = lda(0, ct, 0);
+                if constexpr (H2) al[ct] = lda(0, ct, 1);
+                else { am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
+            }
+            if constexpr (!H2) ldb(&xs[par][0] + rd_off, 1, bm);
             ldb(&xs[par][0] + rd_off, 0, bh);
         }
 #ifdef PWS_STAMP
@@ -509,6 +555,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                 if (c < Cout) g.part[((size_t)n * Cout + c) * G + bx] = make_float2(red[c][0], red[c][1]);
     }
 #undef PWS_MF
+#undef PWS_MF16
 #ifdef PWS_STAMP
     const unsigned long long ts2 = __builtin_readcyclecounter();
     __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
@@ -542,7 +589,23 @@ __device__ __forceinline__ void pack_wt_split_item(const float* __restrict__ W, 
         if (k < rows_k && co < cols_co) v = transpose ? W[(size_t)co * ld + k] : W[(size_t)k * ld + co];
         split3_bf16(v, h[q], m[q], l[q]);
     }
-    u32x4_t* o = out + (size_t)(ks * nct + cot) * 3 * 64 + lane;
+    // fp16 two-part split of the scaled weight (pw_gemm.h): k-pairs packed like the bf16 parts
+    unsigned fh[4], fl[4];
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+        float v2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int k = kb + q + t;
+            float v = 0.f;
+            if (k < rows_k && co < cols_co) v = transpose ? W[(size_t)co * ld + k] : W[(size_t)k * ld + co];
+            v2[t] = v * PWS_H2_WSCALE;
+        }
+        split2_f16_pair(v2[0], v2[1], fh[q >> 1], fl[q >> 1]);
+    }
+    u32x4_t* o = out + (size_t)(ks * nct + cot) * PWS_NSLOT * 64 + lane;
+    o[192] = u32x4_t{fh[0], fh[1], fh[2], fh[3]};
+    o[256] = u32x4_t{fl[0], fl[1], fl[2], fl[3]};
     o[0] = u32x4_t{pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]), pack_bf16x2(h[4], h[5]), pack_bf16x2(h[6], h[7])};
     o[64] = u32x4_t{pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7])};
     o[128] = u32x4_t{pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]), pack_bf16x2(l[4], l[5]), pack_bf16x2(l[6], l[7])};
@@ -586,7 +649,7 @@ static int pws_nks(int rows_k) { return 2 * (((rows_k + PWS_KC - 1) / PWS_KC + 1
 
 size_t pw_split_wt_floats(int rows_k, int cp) {
     const int nks = pws_nks(rows_k), nct = cp / 32;
-    return (size_t)nks * nct * 3 * 64 * 4;   // 16 B = 4 floats per lane entry
+    return (size_t)nks * nct * PWS_NSLOT * 64 * 4;   // 16 B = 4 floats per lane entry
 }
 
 int pw_split_pack(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out, hipStream_t stream) {
@@ -603,6 +666,16 @@ template <int EPI, typename TA>
 static void pws_launch_epi(const PwArgs& g, dim3 grid, int cp, hipStream_t stream) {
     // prefetch depth 2 where registers allow (CT = 1); the 256-channel tile keeps one chunk in flight with fp32 storage
     // (bf16 storage alike: depth 2 spills with the double-buffered A fragments)
+#if PWS_PRO == 1 || PWS_PRO == 2
+    // forward GEMMs behind a norm prologue, fp32 storage: the fp16 two-part split (three products instead of six)
+    if constexpr (EPI == 1 && sizeof(TA) == 4) {
+        if (g.h2) {
+            if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, PWS_H2_DEPTH_CT2, TA, true>), grid, dim3(256), 0, stream, g);
+            else hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 2, TA, true>), grid, dim3(256), 0, stream, g);
+            return;
+        }
+    }
+#endif
     if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, sizeof(TA) == 2 ? PWS_A16_DEPTH_CT2 : 1, TA>), grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 2, TA>), grid, dim3(256), 0, stream, g);
 }
