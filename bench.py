@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
-BF16_MFMA_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (what the exact-split GEMMs really run on: 6 products)
+BF16_MFMA_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 / _f16 dense peak (what the split GEMMs really run on: 6, 3 or 2 products)
 
 PRO_NORMBWD = 3
 TRAFFIC_FILE = "r02_traffic.json"
@@ -34,8 +34,11 @@ def kernel_model(name, key):
         bias_stride, N, Cin, Cout, P, pro, epi, in_dt, out_dt = key
         bi, bo = (2.0 if in_dt else 4.0), (2.0 if out_dt else 4.0)
         rd = Cin * (2 if pro == PRO_NORMBWD else 1) * bi + (Cout * bo if epi in (2, 3) else 0)
+        # products per fp32 MAC on the 16-bit matrix pipe: 2 with bf16 storage, 3 for the fp16 two-part forward GEMMs (norm prologue,
+        # statistics epilogue: DESIGN 4.1b), 6 for the exact bf16 split
+        h2 = (not in_dt) and pro in (1, 2) and epi == 1 and os.environ.get("UNCR_PW_H2", "1") != "0"
         return (f"pw_gemm[{Cin}->{Cout},pro{pro},epi{epi},N{N},P{P}]", N * P * (rd + Cout * bo), 2.0 * N * P * Cin * Cout,
-                (2 if in_dt else 6) if Cout > 64 else 0)
+                (2 if in_dt else (3 if h2 else 6)) if Cout > 64 else 0)
     if name == "uncr_pw_gemm_dx":          # in, in2 (norm-bwd prologue), dy, x, xh3 -> dx
         N, Cin, Cout, P, act = key[-5:]
         return (f"pw_gemm_dx[{Cin}->{Cout},N{N},P{P}]", (2.0 if act else 4.0) * N * P * (2 * Cin + 4 * Cout), 2.0 * N * P * Cin * Cout,
