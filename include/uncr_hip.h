@@ -115,7 +115,7 @@ int uncr_cast(const void* src, void* dst, long long n, int src_dt, int dst_dt, h
  *      uncr_pw_set_split(0) routes these to the fp32-MFMA kernels too (returns the previous setting; weights
  *      must be packed under the setting they are used with). ---- */
 int uncr_pw_set_split(int on);
-/* 1 (default): the wide forward GEMMs behind a norm prologue (pro AFFINE / AFFINE_GELU, epi 1, fp32 storage) use a two-part fp16
+/* 1 (default): the wide forward GEMMs behind a norm prologue (pro AFFINE / AFFINE_GELU, epi 0 / 1, fp32 storage) use a two-part fp16
  * split of both operands (three products, 2^-22 relative accuracy) instead of the exact 3 x bf16 split (six products); 0: the exact
  * split everywhere.  Returns the previous setting.  Weights packed under either setting serve both. */
 int uncr_pw_set_h2(int on);

@@ -897,6 +897,14 @@ def test_fp16_two_part_forward_gemm_accuracy(E, Cin, Cout, pro):
             assert float((s[:, 0] - truth.reshape(N * Cout, P).sum(1)).abs().max() / truth.reshape(N * Cout, P).sum(1).abs().max()) < 1e-4
         print(f"[parity] forward GEMM {Cin}->{Cout} pro {pro} |w|~{wscale:g}: fp16 two-part {errs[1]:.2e}, bf16 three-part {errs[0]:.2e}")
         assert errs[1] <= 1e-6 and errs[0] <= 1e-6, errs
+    # epi 0 (eval mode behind a BatchNorm: no statistics) takes the same path
+    W = torch.randn(Cout, Cin) * 0.07
+    u = A.view(N, Cin, 1).double() * x.double() + B.view(N, Cin, 1).double()
+    if pro == 2:
+        u = S.view(N, Cin, 1).double() * torch.nn.functional.gelu(u)
+    truth = torch.einsum("oc,ncp->nop", W.double(), u)
+    out, _ = E.pw_gemm(dev(x), E.pack_wt(dev(W), transpose=True), N, Cin, Cout, P, pro=pro, k=(dev(A), dev(B), dev(S) if pro == 2 else None), epi=0)
+    assert float((out.cpu().double() - truth).abs().max() / truth.abs().max()) <= 1e-6
     # out-of-range activation: saturates (finite result), never inf / nan
     xb = x.clone()
     xb[0, 3, 7] = 3e5

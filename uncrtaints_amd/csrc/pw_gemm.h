@@ -34,7 +34,7 @@ struct PwArgs {
     float head_scale = 1.f, head_eps = 0.f;
     float* head_pre = nullptr;   // optional second output: the pre-activation [N][Cout][P]
     const float* k3 = nullptr;    // PRO_NORMBWD: the norm's mean per (n, ci) -- centred form C1*v + C2*(v2 - mean) + C3; null: 0
-    int h2 = 0;                   // wide kernels, fp32 storage, PRO_AFFINE / PRO_AFFINE_GELU with EPI 1: fp16 two-part split
+    int h2 = 0;                   // wide kernels, fp32 storage, PRO_AFFINE / PRO_AFFINE_GELU with EPI 0 / 1: fp16 two-part split
     const float* emu = nullptr;   // epi 5 / 6: mean of the PreNorm per (n, co): out = dy + e0*v + e1*(x - emu) + e2; null: 0
 };
 

@@ -668,7 +668,7 @@ static void pws_launch_epi(const PwArgs& g, dim3 grid, int cp, hipStream_t strea
     // (bf16 storage alike: depth 2 spills with the double-buffered A fragments)
 #if PWS_PRO == 1 || PWS_PRO == 2
     // forward GEMMs behind a norm prologue, fp32 storage: the fp16 two-part split (three products instead of six)
-    if constexpr (EPI == 1 && sizeof(TA) == 4) {
+    if constexpr ((EPI == 0 || EPI == 1) && sizeof(TA) == 4) {      // epi 0: the same GEMMs in eval mode behind a BatchNorm (running statistics)
         if (g.h2) {
             if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, PWS_H2_DEPTH_CT2, TA, true>), grid, dim3(256), 0, stream, g);
             else hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 2, TA, true>), grid, dim3(256), 0, stream, g);
