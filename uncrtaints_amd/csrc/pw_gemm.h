@@ -55,7 +55,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(unsigned a, unsigned b) {
 // |r| <= max(2^-22 |x*SC|, 2^-25) -- fp16 has 11 significant bits, so two parts carry 22; the three products h*h', h*l', l*h'
 // reach 2^-22 relative accuracy, the same order as an fp32 FMA chain, at HALF the matrix-pipe work of the exact 3 x bf16 split.
 // fp16's narrow exponent is why this is used only where the range is known: activation operands are outputs of a norm prologue
-// (|u| <= sqrt(group size) * |gamma| + |beta|; saturated at +-65504 rather than overflowing), weights are scaled by 2^6 at pack
+// (|u| <= sqrt(group size) * |gamma| + |beta|, far inside +-65504), weights are scaled by 2^6 at pack
 // time (|w| < 1023 keeps its full precision, the scale leaves in the epilogue).  Gradient GEMMs keep the bf16 split: gradients
 // span the whole fp32 exponent range.
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
@@ -64,10 +64,12 @@ typedef float f32x2v_t __attribute__((ext_vector_type(2)));
 #define PWS_H2_WSCALE 64.0f
 #define PWS_H2_INV_WSCALE 0.015625f
 // (a, b) -> packed fp16 pairs {lo16 = a, hi16 = b}: hi parts and lo parts
+// The high part is taken from the value clamped to the fp16 range, the low part from the UNclamped remainder: values up to
+// 2 x 65504 in magnitude are still represented, larger ones overflow to inf and a NaN / inf input stays NaN / inf -- nothing is
+// hidden from a divergence check (v_med3_f32 alone would turn a NaN into -65504).
 __device__ __forceinline__ void split2_f16_pair(float a, float b, unsigned& hi, unsigned& lo) {
-    a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
-    b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
-    const f16x2_t h = __builtin_convertvector(f32x2v_t{a, b}, f16x2_t);
+    const float ac = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), bc = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+    const f16x2_t h = __builtin_convertvector(f32x2v_t{ac, bc}, f16x2_t);
     const f32x2v_t hf = __builtin_convertvector(h, f32x2v_t);
     const f16x2_t l = __builtin_convertvector(f32x2v_t{a - hf.x, b - hf.y}, f16x2_t);
     hi = __builtin_bit_cast(unsigned, h);
