@@ -148,8 +148,8 @@ def cpu_baseline(T, H, W, budget_s=45.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch-per-gpu", type=int, default=4)
     ap.add_argument("--T", type=int, default=3)
     ap.add_argument("--size", type=int, default=256)
