@@ -63,3 +63,28 @@ def test_state_dict_keys_match_reference_fixture():
     missing, unexpected = m.load_state_dict(sd, strict=True)
     assert not missing and not unexpected
     assert sum(p.numel() for p in m.parameters()) == 570010
+
+
+def test_split_prediction_backward_paths():
+    """losses.split_prediction (pure host logic): two gradients that are the channel slices of ONE buffer come back as that buffer
+    without a copy; anything else is assembled; a missing gradient counts as zeros."""
+    import torch
+    from uncrtaints_amd.src import losses
+    out = torch.randn(2, 1, 26, 4, 8, requires_grad=True)
+    mid = out * 1.0                                     # a non-leaf, like the head's output
+    seen = []
+    mid.register_hook(lambda g: seen.append(g))
+    m, v = losses.split_prediction(mid, 13, 26)
+    assert m.shape == (2, 1, 13, 4, 8) and v.shape == (2, 1, 13, 4, 8) and m.data_ptr() == mid.data_ptr()
+    full = torch.randn(2, 1, 26, 4, 8)
+    torch.autograd.backward([m, v], [full[:, :, :13], full[:, :, 13:]])
+    assert seen[0].data_ptr() == full.data_ptr() and torch.equal(out.grad, full)          # handed on, not copied
+    out.grad = None
+    m, v = losses.split_prediction(out, 13, 26)
+    gm, gv = torch.randn_like(m), torch.randn_like(v)
+    torch.autograd.backward([m, v], [gm, gv])
+    assert torch.equal(out.grad[:, :, :13], gm) and torch.equal(out.grad[:, :, 13:], gv)
+    out.grad = None
+    m, v = losses.split_prediction(out, 13, 26)
+    (v * 3.0).sum().backward()
+    assert float(out.grad[:, :, :13].abs().max()) == 0.0 and torch.equal(out.grad[:, :, 13:], torch.full_like(v, 3.0))
