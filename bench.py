@@ -31,7 +31,7 @@ def kernel_model(name, key):
     """-> (label, algorithmic bytes, flops, bf16 MFMA products per fp32-equivalent MAC) of one launch from its int arguments
     (DESIGN.md section 4).  The last int of every profiled entry point is the activation storage code (0 fp32, 1 bf16)."""
     if name == "uncr_pw_gemm":
-        bias_stride, N, Cin, Cout, P, pro, epi, in_dt, out_dt = key
+        bias_stride, N, Cin, Cout, P, pro, epi, in_dt, out_dt = key[:9]      # (then the counts of the magnitude arrays)
         bi, bo = (2.0 if in_dt else 4.0), (2.0 if out_dt else 4.0)
         rd = Cin * (2 if pro == PRO_NORMBWD else 1) * bi + (Cout * bo if epi in (2, 3) else 0)
         # products per fp32 MAC on the 16-bit matrix pipe: 2 with bf16 storage, 3 for the fp16 two-part forward GEMMs (norm prologue,

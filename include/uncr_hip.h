@@ -137,6 +137,12 @@ int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, void* out, co
                  const float* bias, int bias_stride_n, const void* aux,
                  const float* e0, const float* e1, const float* e2, const float* e3 /* epi 3 coefficients */,
                  float* part, int N, int Cin, int Cout, int P, int pro, int epi, int in_dt, int out_dt,
+                 /* magnitude bookkeeping for the fp16 two-part split of GRADIENT GEMMs (all nullable / 0):
+                  * amax_out [N][uncr_pw_stat_slots]: per-block max |stored output| (Cout <= 128 with epi 1 / 2);
+                  * in_amax [N][in_amax_n], in2_amax [N][in2_amax_n]: such arrays (or any per-frame upper bounds) of the two
+                  * operands of a NORMBWD prologue -- with both given, epi 3 (Cout 256, fp32 storage) multiplies in two fp16
+                  * parts scaled by a per-frame power of two derived from them; without, in the exact bf16 split */
+                 float* amax_out, const float* in_amax, int in_amax_n, const float* in2_amax, int in2_amax_n,
                  hipStream_t stream);
 /* out_conv (Conv2d k=1 + bias, uncrtaints.py:432-440) with the output nonlinearities (uncrtaints.py:441-445) in the GEMM
  * epilogue, Cout <= 64: channel < |n_mean| -> n_mean > 0 ? scale*sigmoid : identity; the others -> var_mode 0 softplus(beta 1,
@@ -157,6 +163,7 @@ int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt, void* out,
                     const float* k2, const float* kmu, const void* dy, const void* x, const void* xh3, const float* c1,
                     const float* c2, const float* c3, const float* cmu /* out = dy + c1*da + c2*(x - cmu) + c3 */,
                     const float* relu_a, const float* relu_b, float* part, int N, int Cin, int Cout, int P, int act,
+                    float* amax_out /* [N][uncr_pw_stat_slots] per-block max |out| or null (relu_a == null only) */,
                     hipStream_t stream);
 /* R [N][Ch][C] = per-frame products sum_p du1n*x (uncr_pw_wgrad with the raw x); part_b / part_f = the (sum du1, .) and
  * (sum h1, .) partials [N*Ch][NPB|NPF][2] (part_f may be null: no c2 term); c1..c3 [N*Ch] = norm-1 backward
@@ -221,7 +228,8 @@ int uncr_maxpool_bwd(const float* dout, const int* idx, void* din, int planes, i
  * h3 (the h3 of the block that produced the pooled tensor); part [planes][P/1024][2].  Disjoint windows, (W/OW) % 4 == 0. */
 int uncr_pool_scatter_stats_supported(int H, int W, int OH, int OW);
 int uncr_pool_scatter_stats(const float* dpool, const int* idx, void* de, const void* h3, float* part, int planes, int H, int W,
-                            int OH, int OW, int act, hipStream_t stream);
+                            int OH, int OW, int act,
+                            float* amax_out /* null, or [planes][P/1024]: per-block max |de| */, hipStream_t stream);
 int uncr_ltae_gn_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean,
                      float* rstd, int B, int T, int C, int G, int S, hipStream_t stream);
 int uncr_ltae_gn_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,

@@ -762,9 +762,12 @@ def test_pool_scatter_fused_with_statistics(E, H, W, bf):
     assert hb.query("uncr_pool_scatter_stats_supported", 64, 64, 32, 32) == 0      # 2-pixel windows: the separate kernels
     slots = hb.query("uncr_ew_slots", H * W)
     part = torch.empty(planes, slots, 2, device=DEV)
-    hb.call("uncr_pool_scatter_stats", dd, idx, got, h3, part, planes, H, W, 32, 32, 1 if bf else 0, E._stream())
+    amax = None if bf else torch.empty(planes, slots, device=got.device)
+    hb.call("uncr_pool_scatter_stats", dd, idx, got, h3, part, planes, H, W, 32, 32, 1 if bf else 0, amax, E._stream())
     assert torch.equal(got, ref)
     close("pool_scatter_stats/part", part.double().sum(1), ref_part.buf.double().sum(1), tol=2e-6)
+    if amax is not None:       # per-block max |de|
+        assert torch.equal(amax, ref.float().view(planes, slots, 1024).abs().amax(dim=2))
 
 
 @pytest.mark.gpu
@@ -917,3 +920,40 @@ def test_fp16_two_part_forward_gemm_accuracy(E, Cin, Cout, pro):
     xb[0, 3, 7] = float("nan")
     out, _ = E.pw_gemm(dev(xb), E.pack_wt(dev(Wn), transpose=True), N, Cin, Cout, P, pro=pro, k=kk, epi=1)
     assert bool(torch.isnan(out[0, :, 7]).all()) and bool(torch.isfinite(out[1]).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gscale", [1e-7, 1.0, 3e4])
+def test_scaled_fp16_two_part_dz_gemm(E, gscale):
+    """The dz GEMM of an MBConv backward (norm-backward prologue of (dy, h3), fused pass-B epilogue) in two fp16 parts scaled per
+    frame from the producers' magnitude bounds: against fp64 at the level of the exact bf16 split for gradient scales from 1e-7
+    to 3e4 (the scale is derived, nothing is assumed about the range), and identical statistics conventions."""
+    torch.manual_seed(5)
+    N, C, Ch, P = 3, 128, 256, 2048
+    dy = torch.randn(N, C, P) * gscale
+    dy[1] *= 1e-3                                             # frames of different magnitude get their own scale
+    h3 = torch.randn(N, C, P) * 2.0 + 0.5
+    h2 = torch.randn(N, Ch, P)
+    c1, c2, c3 = torch.rand(N * C) + 0.5, torch.randn(N * C) * 0.1 * gscale, torch.randn(N * C) * 0.01 * gscale
+    mu = torch.randn(N * C) * 0.3
+    W = torch.randn(C, Ch) * 0.07                              # [k = co 128][out = c 256]
+    eA, eB, eS, eD = torch.rand(N * Ch) + 0.5, torch.randn(N * Ch) * 0.2, torch.rand(N * Ch), torch.randn(N * Ch) * 0.01 * gscale
+    d = c1.view(N, C, 1).double() * dy.double() + c2.view(N, C, 1).double() * (h3.double() - mu.view(N, C, 1).double()) + c3.view(N, C, 1).double()
+    dz = torch.einsum("ko,nkp->nop", W.double(), d)
+    u2 = eA.view(N, Ch, 1).double() * h2.double() + eB.view(N, Ch, 1).double()
+    gp = 0.5 * (1 + torch.erf(u2 / 2 ** 0.5)) + u2 * torch.exp(-0.5 * u2 * u2) / (2 * torch.pi) ** 0.5
+    truth = gp * (eS.view(N, Ch, 1).double() * dz + eD.view(N, Ch, 1).double())
+    Wk = E.pack_wt(dev(W), transpose=False)
+    kk = (dev(c1), dev(c2), dev(c3), dev(mu))
+    ek = (dev(eA), dev(eB), dev(eS), dev(eD))
+    amax_dy = dev(dy.abs().amax(dim=(1, 2)).view(N, 1))
+    amax_h3 = dev(h3.abs().amax(dim=(1, 2)).view(N, 1))
+    errs = {}
+    for name, kw in (("scaled fp16", dict(in_amax=amax_dy, in2_amax=amax_h3)), ("exact bf16", dict())):
+        out, part = E.pw_gemm(dev(dy), Wk, N, C, Ch, P, pro=3, k=kk, x2=dev(h3), epi=3, aux=dev(h2), ek=ek, **kw)
+        o = out.cpu().double()
+        errs[name] = max(float((o[n] - truth[n]).abs().max() / truth[n].abs().max()) for n in range(N))      # per frame
+        s = part.buf.view(N * Ch, -1, 2).double().sum(1).cpu()
+        assert float((s[:, 0] - truth.reshape(N * Ch, P).sum(1)).abs().max() / truth.reshape(N * Ch, P).sum(1).abs().max()) < 1e-4
+    print(f"[parity] dz GEMM at gradient scale {gscale:g}: scaled fp16 two-part {errs['scaled fp16']:.2e}, exact bf16 split {errs['exact bf16']:.2e}")
+    assert errs["scaled fp16"] <= 2e-6 and errs["exact bf16"] <= 2e-6, errs

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void pool_scatter_stats_kernel(const float* __restrict__ dpool, const int* __restrict__ idx,
                                                                  T* __restrict__ de, const T* __restrict__ h3,
-                                                                 float2* __restrict__ part, int H, int W, int OH, int OW) {
+                                                                 float2* __restrict__ part, int H, int W, int OH, int OW,
+                                                                 float* __restrict__ amax_out) {
     const int plane = blockIdx.y;
     const int p = blockIdx.x * 1024 + threadIdx.x * 4;
     const size_t off = (size_t)plane * H * W + p;
@@ -161,16 +162,27 @@ __global__ __launch_bounds__(256) void pool_scatter_stats_kernel(const float* __
     __shared__ float red[8];
     block_sum2<256>(s0, s1, red);
     if (threadIdx.x == 0) part[(size_t)plane * gridDim.x + blockIdx.x] = make_float2(s0, s1);
+    if (amax_out) {      // kernel-uniform: this block's max |de| (the consumer reduces a frame's entries; an atomic per frame would serialise
+                         // ~8000 blocks on one address)
+        float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
+        __shared__ float mr[4];
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) mr[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) amax_out[(size_t)plane * gridDim.x + blockIdx.x] = fmaxf(fmaxf(mr[0], mr[1]), fmaxf(mr[2], mr[3]));
+    }
 }
 extern "C" int uncr_pool_scatter_stats_supported(int H, int W, int OH, int OW) {
     return (OH > 0 && OW > 0 && H % OH == 0 && W % OW == 0 && ((W / OW) & 3) == 0 && ((H * W) % 1024) == 0) ? 1 : 0;
 }
 extern "C" int uncr_pool_scatter_stats(const float* dpool, const int* idx, void* de, const void* h3, float* part, int planes,
-                                       int H, int W, int OH, int OW, int act, hipStream_t stream) {
+                                       int H, int W, int OH, int OW, int act, float* amax_out, hipStream_t stream) {
     if (planes <= 0 || !uncr_pool_scatter_stats_supported(H, W, OH, OW)) return UNCR_ESHAPE;
     if (!dpool || !idx || !de || !h3 || !part || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
     UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(pool_scatter_stats_kernel<T>, dim3(H * W / 1024, planes), dim3(256), 0, stream,
-                                                 dpool, idx, (T*)de, (const T*)h3, (float2*)part, H, W, OH, OW));
+                                                 dpool, idx, (T*)de, (const T*)h3, (float2*)part, H, W, OH, OW, amax_out));
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -35,6 +35,13 @@ struct PwArgs {
     float* head_pre = nullptr;   // optional second output: the pre-activation [N][Cout][P]
     const float* k3 = nullptr;    // PRO_NORMBWD: the norm's mean per (n, ci) -- centred form C1*v + C2*(v2 - mean) + C3; null: 0
     int h2 = 0;                   // wide kernels, fp32 storage, PRO_AFFINE / PRO_AFFINE_GELU with EPI 0 / 1: fp16 two-part split
+    // magnitude bounds for the fp16 two-part split of a GRADIENT GEMM (PRO_NORMBWD + EPI 3): per-block max |value| arrays written by
+    // the producers of the two prologue operands ([N][n] floats each); the kernel derives a per-frame power-of-two scale from them
+    // and from its own coefficient rows.  amax_out: this launch's per-block max |stored output| ([N][blocks per frame]) or null.
+    float* amax_out = nullptr;
+    const float* in_amax = nullptr;
+    const float* in2_amax = nullptr;
+    int in_amax_n = 0, in2_amax_n = 0;
     const float* emu = nullptr;   // epi 5 / 6: mean of the PreNorm per (n, co): out = dy + e0*v + e1*(x - emu) + e2; null: 0
 };
 

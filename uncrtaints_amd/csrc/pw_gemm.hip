@@ -526,8 +526,10 @@ extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, vo
                             const float* k1, const float* k2, const float* kmu, const float* bias, int bias_stride_n,
                             const void* aux,
                             const float* e0, const float* e1, const float* e2, const float* e3, float* part, int N,
-                            int Cin, int Cout, int P, int pro, int epi, int in_dt, int out_dt, hipStream_t stream) {
+                            int Cin, int Cout, int P, int pro, int epi, int in_dt, int out_dt, float* amax_out,
+                            const float* in_amax, int in_amax_n, const float* in2_amax, int in2_amax_n, hipStream_t stream) {
     if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
+    if ((in_amax && in_amax_n <= 0) || (in2_amax && in2_amax_n <= 0)) return UNCR_EINVAL;
     if (!in || !Wt || !out) return UNCR_EINVAL;
     if ((in_dt != UNCR_F32 && in_dt != UNCR_BF16) || (out_dt != UNCR_F32 && out_dt != UNCR_BF16)) return UNCR_EINVAL;
     if (pro == PRO_NORMBWD && !in2) return UNCR_EINVAL;
@@ -541,6 +543,9 @@ extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, vo
     PwArgs g{in, in2, Wt, out, k0, k1, k2, bias, aux, e0, e1, e2, e3, (float2*)part, bias_stride_n, Cin, Cout, P, pro, epi};
     g.k3 = pro == PRO_NORMBWD ? kmu : nullptr;
     g.h2 = g_h2;
+    g.amax_out = amax_out;
+    g.in_amax = in_amax; g.in_amax_n = in_amax_n;
+    g.in2_amax = in2_amax; g.in2_amax_n = in2_amax_n;
     const int cp = pw_coutp(Cout);
     if (use_split(Cout)) {
         if (in_dt != out_dt) return UNCR_EINVAL;      // the wide kernels have one storage type for all activation operands
@@ -606,7 +611,7 @@ extern "C" int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt,
                                const float* k1, const float* k2, const float* kmu, const void* dy, const void* x,
                                const void* xh3, const float* c1, const float* c2, const float* c3, const float* cmu,
                                const float* relu_a, const float* relu_b, float* part, int N, int Cin, int Cout, int P,
-                               int act, hipStream_t stream) {
+                               int act, float* amax_out, hipStream_t stream) {
     if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
     if (!in || !in2 || !Wt || !out || !dy || !x || !c1 || !c2 || !c3) return UNCR_EINVAL;
     if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
@@ -618,6 +623,7 @@ extern "C" int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt,
              0, Cin, Cout, P, PRO_NORMBWD, relu_a ? 6 : 5, dy, xh3};
     g.k3 = kmu;
     g.emu = cmu;
+    g.amax_out = amax_out;
     return pw_split_launch_p3(g, N, pw_coutp(Cout), act, stream);
 }
 

@@ -277,6 +277,52 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
     }
     __syncthreads();   // cf / ecf visible
+    // fp16 two-part split of a gradient operand (H2 with the norm-backward prologue): |C1*v + C2*(v2 - mu) + C3| is bounded by
+    // max|C1| * max|v| + max|C2| * (max|v2| + max|mu|) + max|C3| over the frame; the producers of v and v2 left their per-block
+    // maxima, the coefficient rows are in LDS.  A power-of-two scale brings that bound to 2^14 (a factor 4 below the fp16 maximum,
+    // headroom for the rounding of the bound itself); it multiplies C1..C3 here and leaves in the epilogue.  Rigorous: nothing can
+    // overflow, and everything above 2^-29 of the frame's bound keeps 22 bits.
+    float hinv = PWS_H2_INV_WSCALE;
+    if constexpr (H2 && PRO == PRO_NORMBWD) {
+        float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < Cin; i += NT) {
+            m[0] = fmaxf(m[0], fabsf(cf[0][i])); m[1] = fmaxf(m[1], fabsf(cf[1][i]));
+            m[2] = fmaxf(m[2], fabsf(cf[2][i])); m[3] = fmaxf(m[3], fabsf(cf[3][i]));
+        }
+        for (int i = tid; i < g.in_amax_n; i += NT) m[4] = fmaxf(m[4], g.in_amax[(size_t)n * g.in_amax_n + i]);
+        for (int i = tid; i < g.in2_amax_n; i += NT) m[5] = fmaxf(m[5], g.in2_amax[(size_t)n * g.in2_amax_n + i]);
+        __shared__ float bred[4][6];
+        __shared__ float bscale;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) m[q] = fmaxf(m[q], __shfl_xor(m[q], sft, 64));
+            if (lane == 0) bred[wn][q] = m[q];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float mm[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) mm[q] = fmaxf(fmaxf(bred[0][q], bred[1][q]), fmaxf(bred[2][q], bred[3][q]));
+            const float bound = mm[0] * mm[4] + mm[1] * (mm[5] + mm[3]) + mm[2];
+            float sc = 1.f;
+            if (bound > 0.f && bound < 3.0e38f) {
+                int e;
+                (void)frexpf(bound, &e);                       // bound = f * 2^e, f in [0.5, 1)
+                e = 14 - e;
+                e = e > 100 ? 100 : (e < -100 ? -100 : e);
+                sc = ldexpf(1.f, e);
+            }
+            bscale = sc;
+        }
+        __syncthreads();
+        const float sc = bscale;
+        for (int i = tid; i < Cin; i += NT) { cf[0][i] *= sc; cf[1][i] *= sc; cf[2][i] *= sc; }
+        hinv = PWS_H2_INV_WSCALE / sc;
+        __syncthreads();
+    }
+    float amx = 0.f;          // max |stored output| of this block (CT = 1 statistics / skip epilogues)
+    constexpr bool AMAXK = CT == 1 && (EPI == 1 || EPI == 2 || EPI == 5);
     stage_chunk(0, 0, S0{});
     load_chunk(lp, S0{}); advance(lp);
     if constexpr (DEPTH == 2) { load_chunk(lp, S1{}); advance(lp); }
@@ -461,8 +507,8 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                     const float bb = EPI == 6 ? 0.f : ecf[0][col];
                     float4 v;
                     if constexpr (H2)       // the weights' pack-time scale leaves here
-                        v = make_float4(fmaf(acc[0][ct][r], PWS_H2_INV_WSCALE, bb), fmaf(acc[1][ct][r], PWS_H2_INV_WSCALE, bb),
-                                        fmaf(acc[2][ct][r], PWS_H2_INV_WSCALE, bb), fmaf(acc[3][ct][r], PWS_H2_INV_WSCALE, bb));
+                        v = make_float4(fmaf(acc[0][ct][r], hinv, bb), fmaf(acc[1][ct][r], hinv, bb),
+                                        fmaf(acc[2][ct][r], hinv, bb), fmaf(acc[3][ct][r], hinv, bb));
                     else v = make_float4(acc[0][ct][r] + bb, acc[1][ct][r] + bb, acc[2][ct][r] + bb, acc[3][ct][r] + bb);
                     float s0 = 0.f, s1 = 0.f;
                     if constexpr (EPI == 3) {
@@ -512,6 +558,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                         s1 = v.x * h.x + v.y * h.y + v.z * h.z + v.w * h.w;
                     }
                     acc[0][ct][r] = v.x; acc[1][ct][r] = v.y; acc[2][ct][r] = v.z; acc[3][ct][r] = v.w;
+                    if constexpr (AMAXK) amx = fmaxf(amx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                     if constexpr (EPI != 0 && EPI != 4) {
                         s0 = half_wave_sum_dpp(s0);
                         s1 = half_wave_sum_dpp(s1);
@@ -553,6 +600,16 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         if ((EPI != 5 && EPI != 6) || g.part)
             for (int c = tid; c < COUTP; c += NT)
                 if (c < Cout) g.part[((size_t)n * Cout + c) * G + bx] = make_float2(red[c][0], red[c][1]);
+    }
+    if constexpr (AMAXK) {
+        if (g.amax_out) {        // kernel-uniform
+            __shared__ float amr[4];
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) amx = fmaxf(amx, __shfl_xor(amx, sft, 64));
+            if (lane == 0) amr[wn] = amx;
+            __syncthreads();
+            if (tid == 0) g.amax_out[(size_t)n * G + bx] = fmaxf(fmaxf(amr[0], amr[1]), fmaxf(amr[2], amr[3]));
+        }
     }
 #undef PWS_MF
 #undef PWS_MF16
@@ -710,7 +767,15 @@ static int pws_launch_t(const PwArgs& g, int N, int cp, hipStream_t stream) {
         case 0: pws_launch_epi<0, TA>(g, grid, cp, stream); break;
         case 1: pws_launch_epi<1, TA>(g, grid, cp, stream); break;
         case 2: pws_launch_epi<2, TA>(g, grid, cp, stream); break;
-        case 3: pws_launch_epi<3, TA>(g, grid, cp, stream); break;
+        case 3:
+#if PWS_PRO == 3
+            // the dz GEMM of an MBConv backward with both operand bounds at hand: fp16 two-part split with a per-frame scale
+            if (sizeof(TA) == 4 && cp == 256 && g.h2 && g.in_amax && g.in2_amax && g.in_amax_n > 0 && g.in2_amax_n > 0) {
+                hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, 3, 1, float, true>), grid, dim3(256), 0, stream, g);
+                break;
+            }
+#endif
+            pws_launch_epi<3, TA>(g, grid, cp, stream); break;
         case 4:      // accumulate (dense 3x3 as nine shifted GEMMs): fp32 storage only
             if (sizeof(TA) != 4) return UNCR_EINVAL;
             pws_launch_epi<4, float>(g, grid, cp, stream);

@@ -79,6 +79,7 @@ class Part:
     buf: Tensor
     slots: int
     masked: bool = False     # backward partials of a gradient that already carries the producer's ReLU mask (in_conv)
+    amax: Optional[Tensor] = None   # [N][n] upper bounds on |value| per frame (per-block maxima of the producer), or None
     owner: tuple = ()        # (data_ptr, _version) of the tensor these partials describe (hand-offs between autograd nodes)
 
 
@@ -251,6 +252,9 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
 
 
 _CENTRED_NORMBWD = os.environ.get("UNCR_RAW_NORMBWD", "0") != "1"     # development A/B switch
+# fp16 two-part split in the dz GEMM of an MBConv backward, scaled per frame from the producers' magnitude bookkeeping
+# (UNCR_NO_H2_BWD=1: exact bf16 split there, no bookkeeping -- A/B runs)
+_H2_BWD = os.environ.get("UNCR_NO_H2_BWD", "0") != "1"
 
 
 @dataclass
@@ -431,8 +435,12 @@ def pack_wt(W2d: Tensor, transpose: bool) -> Tensor:
 def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: int = PRO_NONE, k=(None, None, None),
             x2: Optional[Tensor] = None, bias: Optional[Tensor] = None, bias_per_frame: bool = False, epi: int = 0,
             aux: Optional[Tensor] = None, out: Optional[Tensor] = None,
-            ek=(None, None, None, None), out_dt: Optional[int] = None) -> Tuple[Tensor, Optional[Part]]:
-    """out_dt: storage of the output (default: that of the input; the narrow Cout <= 64 kernels write fp32 only)."""
+            ek=(None, None, None, None), out_dt: Optional[int] = None, want_amax: bool = False,
+            in_amax: Optional[Tensor] = None, in2_amax: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Part]]:
+    """out_dt: storage of the output (default: that of the input; the narrow Cout <= 64 kernels write fp32 only).
+    want_amax (epi 1 / 2, 64 < Cout <= 128, fp32): the returned Part carries per-block maxima of |out| ([N][slots]).
+    in_amax / in2_amax ([N][n] each): magnitude bounds of the two NORMBWD operands; with both, the epi-3 GEMM of an MBConv backward
+    multiplies in two scaled fp16 parts (three products) instead of the exact bf16 split (six)."""
     if out is None:
         out = _act((N, Cout, P), x.device, _dt(x) if out_dt is None else out_dt)
     part = None
@@ -441,9 +449,16 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
         if slots <= 0:
             raise RuntimeError(f"pw_gemm: P={P} is not a multiple of the {hb.query('uncr_pw_tile_px', Cout)}-pixel tile")
         part = Part(_f32((N * Cout, slots, 2), x.device), slots)
+    amax = None
+    if want_amax and part is not None and epi in (1, 2) and 64 < Cout <= 128 and _dt(x) == F32 and _dt(out) == F32 and _H2_BWD:
+        amax = _f32((N, part.slots), x.device)
+        part.amax = amax
+    use_in = in_amax is not None and in2_amax is not None and _H2_BWD
     hb.call("uncr_pw_gemm", x, x2, Wt, out, k[0], k[1], k[2], k[3] if len(k) > 3 else None, bias,
             Cout if bias_per_frame else 0, aux,
-            ek[0], ek[1], ek[2], ek[3], part.buf if part else None, N, Cin, Cout, P, pro, epi, _dt(x), _dt(out), _stream())
+            ek[0], ek[1], ek[2], ek[3], part.buf if part else None, N, Cin, Cout, P, pro, epi, _dt(x), _dt(out),
+            amax, in_amax if use_in else None, in_amax.shape[1] if use_in else 0,
+            in2_amax if use_in else None, in2_amax.shape[1] if use_in else 0, _stream())
     return out, part
 
 
@@ -524,7 +539,7 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
             pooled, hid_pre, s, _stream())
 
     W2t = pack_wt(p["w2"].reshape(C, Ch), transpose=True)
-    h3, part3 = pw_gemm(h2, W2t, N, Ch, C, P, pro=PRO_AFFINE_GELU, k=(n2.A, n2.B, s), epi=1 if need else 0)
+    h3, part3 = pw_gemm(h2, W2t, N, Ch, C, P, pro=PRO_AFFINE_GELU, k=(n2.A, n2.B, s), epi=1 if need else 0, want_amax=True)
     n3 = norm_fwd(part3, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))
 
     y = _act((N, C, H, W), x.device, dt)
@@ -545,7 +560,7 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
         if pool is not None:
             ypool = maxpool_forward(y, pool, pool)
     saved = dict(ypool=ypool, x=x, h1=h1, h2=h2, h3=h3, n0=n0, n1=n1, n2=n2, n3=n3, pooled=pooled, hid_pre=hid_pre, s=s,
-                 dims=(N, C, Ch, R, H, W), x_h3=x_h3, part1f=part1)
+                 dims=(N, C, Ch, R, H, W), x_h3=x_h3, part1f=part1, h3_amax=part3.amax if part3 is not None else None)
     return y, saved, party
 
 
@@ -578,6 +593,9 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
 
     # norm 3 backward coefficients: needs (sum dy, sum dy*h3)
     part3 = dy_part if dy_part is not None else stats_aux(dy, h3, N * C, P)
+    dy_amax = dy_part.amax if dy_part is not None else None       # per-frame bounds on |dy| left by dy's producer (or None)
+    if dy_amax is not None and dy_amax.shape[0] != N:
+        dy_amax = None
     b3 = norm_bwd(part3, N, C, P, n3, p["n3w"])
     g["n3w"], g["n3b"] = b3.dgamma, b3.dbeta
     k3 = b3.k
@@ -596,8 +614,9 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     W2k = pack_wt(w2, transpose=False)                     # [k=co 128][out=c 256]
     # ... with the SE / GELU backward (du2 = gelu'(u2) * (s*dz + dpool)) and its statistics fused into the
     # GEMM epilogue: dz itself is never written
+    # with the magnitude bookkeeping of dy's producer and of the forward pw2 GEMM at hand: two scaled fp16 parts (three products)
     du2, part2 = pw_gemm(dy, W2k, N, C, Ch, P, pro=PRO_NORMBWD, k=k3, x2=h3, epi=3, aux=h2,
-                         ek=(n2.A, n2.B, sv["s"], dpool))
+                         ek=(n2.A, n2.B, sv["s"], dpool), in_amax=dy_amax, in2_amax=sv.get("h3_amax"))
     b2 = norm_bwd(part2, N, Ch, P, n2, p["n2w"])
     g["n2w"], g["n2b"] = b2.dgamma, b2.dbeta
 
@@ -647,8 +666,11 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         if x_h3 is not None:
             slots = hb.query("uncr_pw_stat_slots", N, C, P)
             dx_part = Part(_f32((N * C, slots, 2), dev), slots, masked=relu is not None)
+            if relu is None and dt == F32 and _H2_BWD:      # dx is the next backward's dy: leave its per-block maxima for that dz GEMM
+                dx_part.amax = _f32((N, slots), dev)
         hb.call("uncr_pw_gemm_dx", du1, h1, W1k, dx, k1[0], k1[1], k1[2], k1[3], dy, x, x_h3, b0.c1, b0.c2, b0.c3, b0.mu, ra, rb,
-                dx_part.buf if dx_part is not None else None, N, Ch, C, P, dt, _stream())
+                dx_part.buf if dx_part is not None else None, N, Ch, C, P, dt,
+                dx_part.amax if dx_part is not None else None, _stream())
         join_side()
         return dx, g, dx_part
 
@@ -1213,8 +1235,11 @@ def _pool_scatter(ddown: Tensor, sv: dict, de: Tensor, e_h3: Optional[Tensor]) -
             and hb.query("uncr_pool_scatter_stats_supported", H, W, ad, ad) == 1:
         slots = hb.query("uncr_ew_slots", H * W)
         part = Part(_f32((planes, slots, 2), de.device), slots)
+        C = de.shape[-3]
+        if _dt(de) == F32 and _H2_BWD and planes % C == 0:
+            part.amax = _f32((planes // C, C * slots), de.device)     # per-block max |de|, one row per frame
         hb.call("uncr_pool_scatter_stats", ddown.contiguous(), sv["idx"], de, e_h3, part.buf, planes, H, W, ad, ad, _dt(de),
-                _stream())
+                part.amax, _stream())
         return part
     maxpool_backward_into(ddown, sv["idx"], de, H, W, ad, ad)
     return None
@@ -1291,7 +1316,7 @@ def head_backward(dout: Tensor, sv: dict, w: Tensor, need_dy: bool = True):
     if need_dy:
         Wk = pack_wt(w.reshape(Co, C), transpose=False)        # [k=26][out=128]
         y_h3 = sv.get("y_h3")       # last decoder block's h3: emit (sum dy, sum dy*h3) in the GEMM epilogue
-        dy, dy_part = pw_gemm(do, Wk, N, Co, C, P, epi=2 if y_h3 is not None else 0, aux=y_h3)
+        dy, dy_part = pw_gemm(do, Wk, N, Co, C, P, epi=2 if y_h3 is not None else 0, aux=y_h3, want_amax=True)
         dy = dy.view(N, C, H, W)
     return dy, dW.view_as(w), db, dy_part
 
