@@ -37,6 +37,9 @@ def kernel_model(name, key):
         # products per fp32 MAC on the 16-bit matrix pipe: 2 with bf16 storage, 3 for the fp16 two-part forward GEMMs (norm prologue,
         # statistics epilogue: DESIGN 4.1b), 6 for the exact bf16 split
         h2 = (not in_dt) and pro in (1, 2) and epi in (0, 1) and os.environ.get("UNCR_PW_H2", "1") != "0"
+        # ... and for the dz GEMM of the MBConv backward when both magnitude arrays were passed (their counts follow in the key)
+        h2 = h2 or ((not in_dt) and pro == PRO_NORMBWD and epi == 3 and len(key) > 10 and key[9] > 0 and key[10] > 0
+                    and os.environ.get("UNCR_PW_H2", "1") != "0")
         return (f"pw_gemm[{Cin}->{Cout},pro{pro},epi{epi},N{N},P{P}]", N * P * (rd + Cout * bo), 2.0 * N * P * Cin * Cout,
                 (2 if in_dt else (3 if h2 else 6)) if Cout > 64 else 0)
     if name == "uncr_pw_gemm_dx":          # in, in2 (norm-bwd prologue), dy, x, xh3 -> dx
