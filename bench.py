@@ -36,10 +36,10 @@ def kernel_model(name, key):
         rd = Cin * (2 if pro == PRO_NORMBWD else 1) * bi + (Cout * bo if epi in (2, 3) else 0)
         # products per fp32 MAC on the 16-bit matrix pipe: 2 with bf16 storage, 3 for the fp16 two-part forward GEMMs (norm prologue,
         # statistics epilogue: DESIGN 4.1b), 6 for the exact bf16 split
-        h2 = (not in_dt) and pro in (1, 2) and epi in (0, 1) and os.environ.get("UNCR_PW_H2", "1") != "0"
-        # ... and for the dz GEMM of the MBConv backward when both magnitude arrays were passed (their counts follow in the key)
-        h2 = h2 or ((not in_dt) and pro == PRO_NORMBWD and epi == 3 and len(key) > 10 and key[9] > 0 and key[10] > 0
-                    and os.environ.get("UNCR_PW_H2", "1") != "0")
+        # (the call carried magnitude bounds for its activation operand: their counts follow in the key)
+        h2 = (not in_dt) and pro in (1, 2) and epi in (0, 1) and len(key) > 9 and key[9] > 0
+        # ... and for the dz GEMM of the MBConv backward when both magnitude arrays were passed
+        h2 = h2 or ((not in_dt) and pro == PRO_NORMBWD and epi == 3 and len(key) > 10 and key[9] > 0 and key[10] > 0)
         return (f"pw_gemm[{Cin}->{Cout},pro{pro},epi{epi},N{N},P{P}]", N * P * (rd + Cout * bo), 2.0 * N * P * Cin * Cout,
                 (2 if in_dt else (3 if h2 else 6)) if Cout > 64 else 0)
     if name == "uncr_pw_gemm_dx":          # in, in2 (norm-bwd prologue), dy, x, xh3 -> dx
@@ -56,10 +56,10 @@ def kernel_model(name, key):
         return (f"pw_wgrad[{Cd}x{Cx},N{N},P{P}]", (2.0 if act else 4.0) * N * P * rd, 2.0 * N * P * Cd * Cx,
                 (1 if act else 6) if wide else 0)
     if name == "uncr_dw_fwd":
-        N, C, H, W, act = key
+        N, C, H, W, act = key[:5]
         return (f"dw_fwd[N{N},C{C},{H}x{W}]", (2.0 if act else 4.0) * N * C * H * W * 2, 18.0 * N * C * H * W, 0)
     if name == "uncr_dw_bwd":
-        N, C, H, W, act = key[-5:]
+        N, C, H, W, act = key[-6:-1]
         return (f"dw_bwd[N{N},C{C},{H}x{W}]", (2.0 if act else 4.0) * N * C * H * W * 4, 36.0 * N * C * H * W, 0)
     if name == "uncr_ew":
         op, planes, P, C, n_mean, act = key

@@ -71,10 +71,13 @@ int uncr_version(void);
 
 /* ---- normalisation coefficients: nn.GroupNorm / nn.BatchNorm2d statistics
  *      (uncrtaints.py:16-22 get_norm_layer, utae.py:470-473, uncrtaints.py:72-79 PreNorm) ---- */
+/* ub (nullable) [N*C]: upper bound on |coefA*h + coefB| per plane, taken from the partials' sums of squares (a block's
+ * elements are bounded by the root of its sum of squares); needs `part` = (sum h, sum h^2) partials of the normalised tensor --
+ * in BatchNorm eval mode too, where they serve nothing else.  Consumed by uncr_pw_gemm (in_amax) to scale its fp16 operand split. */
 int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                            const float* gamma, const float* beta, float* running_mean, float* running_var,
                            float momentum, float eps, float* coefA, float* coefB, float* save_mean,
-                           float* save_rstd, hipStream_t stream);
+                           float* save_rstd, float* ub, hipStream_t stream);
 int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                            const float* gamma, const float* save_mean, const float* save_rstd, float* c1,
                            float* c2, float* c3,
@@ -110,15 +113,13 @@ int uncr_cast(const void* src, void* dst, long long n, int src_dt, int dst_dt, h
 
 /* ---- 1x1 convolutions as MFMA GEMMs with fp32 results (nn.Conv2d k=1: utae.py:476-484 in_conv/out_conv,
  *      uncrtaints.py:126 pw, :136 pw-linear; nn.Conv1d k=1 ltae.py:176,214; nn.Linear ltae.py:327,349).
- *      Cout <= 64: v_mfma_f32_32x32x2_f32.  Cout > 64: exact 3-way bf16 split of both operands, six partial
- *      products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (fp32-grade error, 2.7x fewer MFMA cycles);
- *      uncr_pw_set_split(0) routes these to the fp32-MFMA kernels too (returns the previous setting; weights
- *      must be packed under the setting they are used with). ---- */
-int uncr_pw_set_split(int on);
-/* 1 (default): the wide forward GEMMs behind a norm prologue (pro AFFINE / AFFINE_GELU, epi 0 / 1, fp32 storage) use a two-part fp16
- * split of both operands (three products, 2^-22 relative accuracy) instead of the exact 3 x bf16 split (six products); 0: the exact
- * split everywhere.  Returns the previous setting.  Weights packed under either setting serve both. */
-int uncr_pw_set_h2(int on);
+ *      Cout <= 64: v_mfma_f32_32x32x2_f32.  Cout > 64: the operands are split into 16-bit parts for the bf16 / fp16 matrix pipe
+ *      with fp32 accumulation and fp32-grade results: the exact 3-way bf16 split of both operands (six partial products on
+ *      v_mfma_f32_32x32x16_bf16), or -- where a call carries magnitude bounds for its activation operand (in_amax below) -- two
+ *      fp16 parts per operand (three products on v_mfma_f32_32x32x16_f16, 2^-22 relative accuracy): the activations are scaled
+ *      per frame by a power of two derived from the bound, the weights per output channel at pack time, so no value can leave
+ *      the fp16 range whatever the checkpoint or the data hold.  The library keeps no mutable state: the variant follows from
+ *      the arguments of the call. ---- */
 int uncr_pw_wt_floats(int rows_k, int cols_co);   /* floats to allocate for uncr_pack_wt's output */
 int uncr_pw_coutp(int Cout);      /* padded output-channel count of the kernel variant */
 int uncr_pw_kpad(int Cin);        /* padded reduction length */
@@ -126,9 +127,8 @@ int uncr_pw_tile_px(int Cout);    /* pixels per tile of the kernel variant (P mu
 int uncr_pw_stat_slots(int N, int Cout, int P);   /* statistics slots per (frame, channel) written when epi != 0 */
 int uncr_pack_wt(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out, hipStream_t stream);
 /* the same for many weights in one launch: desc = n_items x 8 int64 in DEVICE memory {W, out, rows_k, cols_co, ld,
- * transpose, 0, 0}; max_threads = max over items of uncr_pack_wt_threads */
-int uncr_pack_wt_threads(int rows_k, int cols_co);
-int uncr_pack_wt_batch(const long long* desc, int n_items, int max_threads, hipStream_t stream);
+ * transpose, 0, 0} */
+int uncr_pack_wt_batch(const long long* desc, int n_items, hipStream_t stream);
 /* in_dt: storage of in / in2; out_dt: storage of out and aux.  Cout > 64 (bf16 MFMA kernels): in_dt == out_dt; with bf16
  * the prologue's fp32 result is rounded once to bf16 and multiplied with the two leading weight parts (16 significant bits):
  * two products per MAC instead of six.  Cout <= 64 (fp32 MFMA kernels): fp32 outputs, fp32 or bf16 inputs. */
@@ -137,11 +137,14 @@ int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, void* out, co
                  const float* bias, int bias_stride_n, const void* aux,
                  const float* e0, const float* e1, const float* e2, const float* e3 /* epi 3 coefficients */,
                  float* part, int N, int Cin, int Cout, int P, int pro, int epi, int in_dt, int out_dt,
-                 /* magnitude bookkeeping for the fp16 two-part split of GRADIENT GEMMs (all nullable / 0):
+                 /* magnitude bookkeeping for the fp16 two-part split (all nullable / 0; Cout > 64, fp32 storage):
                   * amax_out [N][uncr_pw_stat_slots]: per-block max |stored output| (Cout <= 128 with epi 1 / 2);
-                  * in_amax [N][in_amax_n], in2_amax [N][in2_amax_n]: such arrays (or any per-frame upper bounds) of the two
-                  * operands of a NORMBWD prologue -- with both given, epi 3 (Cout 256, fp32 storage) multiplies in two fp16
-                  * parts scaled by a per-frame power of two derived from them; without, in the exact bf16 split */
+                  * pro NORMBWD + epi 3 (Cout 256): in_amax [N][in_amax_n], in2_amax [N][in2_amax_n] = such arrays (or any
+                  *   per-frame upper bounds) of the two prologue operands;
+                  * pro AFFINE / AFFINE_GELU + epi 0 / 1: in_amax [N][in_amax_n = Cin] = upper bounds on |k0*in + k1| per plane
+                  *   (uncr_norm_finalize_fwd's `ub` output), in2_amax unused.
+                  * With the bounds given the GEMM multiplies in two fp16 parts scaled by a per-frame power of two derived from
+                  * them; without, in the exact bf16 split */
                  float* amax_out, const float* in_amax, int in_amax_n, const float* in2_amax, int in2_amax_n,
                  hipStream_t stream);
 /* out_conv (Conv2d k=1 + bias, uncrtaints.py:432-440) with the output nonlinearities (uncrtaints.py:441-445) in the GEMM
@@ -187,18 +190,19 @@ int uncr_wgrad_reduce(const float* part, int n_out, int nblk_per_out, int COP, i
                       float* out, hipStream_t stream);
 
 /* ---- depthwise 3x3 reflect (nn.Conv2d groups=C, padding_mode='reflect', uncrtaints.py:130-131) ---- */
-int uncr_dw_set_row(int on);   /* 1 (default): W == 256 uses the row-streaming kernels; 0: LDS-tiled kernels only */
+/* variant: 0 = automatic (W == 256: the row-streaming kernels; other widths: the LDS-tiled kernels), 1 = LDS-tiled kernels for
+ * every width (tests exercise both implementations on the same input) */
 int uncr_dw_slots_fwd(int H);
 int uncr_dw_slots_bwd(int H);
 int uncr_dw_fwd(const void* in, const float* cA, const float* cB, const float* w, void* out, float* part,
-                int N, int C, int H, int W, int act, hipStream_t stream);
+                int N, int C, int H, int W, int act, int variant, hipStream_t stream);
 int uncr_dw_bwd(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
                 const float* k3, const float* kmu /* dh2 = k1*du2 + k2*(h2 - kmu) + k3; null: kmu = 0 */,
                 const float* cA1, const float* cB1, const float* w, void* du1, float* part,
                 float* dw_part, const float* mean1 /* null: part.y = sum du1*h1; else sum du1*(h1 - mean), the
                 well-conditioned form for uncr_norm_finalize_bwd(centered = 1) */,
                 int mean_groups /* 0: mean1[c] (BatchNorm); G > 0: mean1[n*G + c/(C/G)] (GroupNorm) */,
-                int N, int C, int H, int W, int act, hipStream_t stream);
+                int N, int C, int H, int W, int act, int variant, hipStream_t stream);
 int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw, hipStream_t stream);
 
 /* ---- squeeze-excite MLP (uncrtaints.py:82-97) ---- */

@@ -36,6 +36,15 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(cdll, name), f"{name} declared in include/uncr_hip.h but not exported"
 
 
+def test_library_keeps_no_switches(built):
+    """the entry points are re-entrant and hold no mutable behaviour state -- no process-wide setters in the ABI, no
+    environment reads inside the library (kernel variants follow from the arguments of each call)."""
+    import subprocess
+    assert not [n for n in hb.parse_header() if "_set_" in n]
+    syms = subprocess.run(["nm", "-D", built], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
+
+
 def test_size_queries(built):
     assert hb.query("uncr_version") >= 1
     assert hb.query("uncr_pw_coutp", 26) == 32 and hb.query("uncr_pw_coutp", 128) == 128

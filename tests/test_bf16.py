@@ -103,7 +103,7 @@ def test_depthwise_bf16_storage(H, W):
     h2 = torch.empty_like(h1b)
     slots = hb.query("uncr_dw_slots_fwd", H)
     part = torch.empty(N * C, slots, 2, device=DEV)
-    hb.call("uncr_dw_fwd", h1b, dev(A), dev(B), dev(w.reshape(C, 9)), h2, part, N, C, H, W, 1, E._stream())
+    hb.call("uncr_dw_fwd", h1b, dev(A), dev(B), dev(w.reshape(C, 9)), h2, part, N, C, H, W, 1, 0, E._stream())
     u = A.double().view(N, C, 1, 1) * rb(h1).double() + B.double().view(N, C, 1, 1)
     g1 = 0.5 * u * (1.0 + torch.erf(u / 2 ** 0.5))
     ref = F.conv2d(F.pad(g1, (1, 1, 1, 1), mode="reflect"), w.double().view(C, 1, 3, 3), groups=C)
@@ -120,7 +120,7 @@ def test_depthwise_bf16_storage(H, W):
     partb = torch.empty(N * C, sb, 2, device=DEV)
     dwp = torch.empty(N * C, sb, 9, device=DEV)
     hb.call("uncr_dw_bwd", du2b, h2, h1b, dev(c1), dev(c2), dev(c3), None, dev(A), dev(B), dev(w.reshape(C, 9)), du1, partb, dwp,
-            None, 0, N, C, H, W, 1, E._stream())
+            None, 0, N, C, H, W, 1, 0, E._stream())
     h1r = rb(h1).double().requires_grad_(True)
     u = A.double().view(N, C, 1, 1) * h1r + B.double().view(N, C, 1, 1)
     g1 = 0.5 * u * (1.0 + torch.erf(u / 2 ** 0.5))

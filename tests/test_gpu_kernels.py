@@ -128,15 +128,10 @@ def test_pw_wgrad(E, Cd, Cx):
 @pytest.mark.parametrize("H,W,row", [(64, 64, True), (96, 32, True), (16, 256, True), (72, 256, True), (136, 256, True),
                                      (72, 256, False), (32, 512, True), (16, 1024, True)])
 def test_depthwise_fwd_bwd(E, orc, H, W, row):
-    from uncrtaints_amd import hip_backend as hb
-    old = hb.query("uncr_dw_set_row", 1 if row else 0)
-    try:
-        _depthwise_fwd_bwd(E, orc, H, W)
-    finally:
-        hb.query("uncr_dw_set_row", old)
+    _depthwise_fwd_bwd(E, orc, H, W, 0 if row else 1)
 
 
-def _depthwise_fwd_bwd(E, orc, H, W):
+def _depthwise_fwd_bwd(E, orc, H, W, variant):
     N, C = (2, 64) if W < 256 else (2, 8)
     h1 = rand(N, C, H, W, seed=1).requires_grad_(True)
     w = rand(C, 1, 3, 3, seed=2, scale=0.4).requires_grad_(True)
@@ -148,7 +143,7 @@ def _depthwise_fwd_bwd(E, orc, H, W):
     slots = hb.query("uncr_dw_slots_fwd", H)
     part = torch.empty(N * C, slots, 2, device=DEV)
     hb.call("uncr_dw_fwd", dev(h1.detach()), dev(A), dev(B), dev(w.detach().reshape(C, 9)), h2d, part, N, C, H, W,
-            0, E._stream())
+            0, variant, E._stream())
     close(f"dw_fwd[{H}x{W}]", h2d, h2)
     close("dw_fwd_stats0", part.sum(1)[:, 0], h2.detach().sum(dim=(2, 3)).reshape(-1))
     close("dw_fwd_stats1", part.sum(1)[:, 1], (h2.detach() ** 2).sum(dim=(2, 3)).reshape(-1))
@@ -166,7 +161,7 @@ def _depthwise_fwd_bwd(E, orc, H, W):
     partb = torch.empty(N * C, sb, 2, device=DEV)
     dwp = torch.empty(N * C, sb, 9, device=DEV)
     hb.call("uncr_dw_bwd", dev(du2), h2d, dev(h1.detach()), dev(c1), dev(c2), dev(c3), None, dev(A), dev(B),
-            dev(w.detach().reshape(C, 9)), du1, partb, dwp, None, 0, N, C, H, W, 0, E._stream())
+            dev(w.detach().reshape(C, 9)), du1, partb, dwp, None, 0, N, C, H, W, 0, variant, E._stream())
     close(f"dw_bwd_du1[{H}x{W}]", du1, du1_ref)
     close("dw_bwd_stats0", partb.sum(1)[:, 0], du1_ref.sum(dim=(2, 3)).reshape(-1))
     close("dw_bwd_stats1", partb.sum(1)[:, 1], (du1_ref * h1.detach()).sum(dim=(2, 3)).reshape(-1))
@@ -177,7 +172,7 @@ def _depthwise_fwd_bwd(E, orc, H, W):
     for groups in (0, 4):
         mean = rand(C if groups == 0 else N * groups, seed=9, scale=2.0)
         hb.call("uncr_dw_bwd", dev(du2), h2d, dev(h1.detach()), dev(c1), dev(c2), dev(c3), None, dev(A), dev(B),
-                dev(w.detach().reshape(C, 9)), du1, partb, dwp, dev(mean), groups, N, C, H, W, 0, E._stream())
+                dev(w.detach().reshape(C, 9)), du1, partb, dwp, dev(mean), groups, N, C, H, W, 0, variant, E._stream())
         mfull = mean.view(1, C, 1, 1) if groups == 0 else mean.view(N, groups, 1, 1, 1).expand(N, groups, C // groups, 1, 1).reshape(N, C, 1, 1)
         close(f"dw_bwd_stats1_centered[g{groups}]", partb.sum(1)[:, 1],
               (du1_ref * (h1.detach() - mfull)).sum(dim=(2, 3)).reshape(-1))
@@ -869,57 +864,134 @@ def test_mgnll_on_channel_slices_of_the_head_output(cov, reduction):
     assert torch.equal(c.grad[:, :, :13], torch.full_like(c.grad[:, :, :13], 2.0)) and float(c.grad[:, :, 13:].abs().max()) == 0.0
 
 
+def _row_rel_err(out, truth):
+    """max over (frame, output channel) of max|err| / max|truth| -- every output row is held to its OWN magnitude"""
+    o, t = out.cpu().double(), truth
+    num = (o - t).abs().amax(dim=2)
+    den = t.abs().amax(dim=2).clamp_min(1e-300)
+    return float((num / den).max())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("Cin,Cout,pro", [(128, 256, 1), (256, 128, 2)])
 def test_fp16_two_part_forward_gemm_accuracy(E, Cin, Cout, pro):
-    """The forward wide GEMMs behind a norm prologue use a two-part fp16 split (three products, pw_gemm.h) instead of the exact
-    3 x bf16 split (six): against fp64 both stay at the level of an fp32 FMA chain (<= 1e-6 of max|out|); small and large weight
-    scales keep that (pack-time scaling); values up to twice the fp16 range degrade gracefully (11 bits) and a NaN input stays a NaN."""
-    import uncrtaints_amd.hip_backend as hb
+    """The forward wide GEMMs behind a norm prologue multiply in two fp16 parts (three products, pw_gemm.h) wherever the caller
+    passes bounds on the prologue's result, instead of the exact 3 x bf16 split (six).  The split is RANGE-SAFE: the weights are
+    scaled per output channel at pack time, the activations per frame from the bound -- so against fp64 it stays at the level of an
+    fp32 FMA chain (<= 2e-6 of every output row's own maximum) for weight scales 1e-6 ... 1e5, rows of wildly different magnitude
+    inside one matrix, and activations from 1e-4 to 3e6 (far beyond the fp16 range)."""
     torch.manual_seed(Cin)
     N, P = 2, 2048
-    x = torch.randn(N, Cin, P) * 1.3 + 0.2
+    x0 = torch.randn(N, Cin, P) * 1.3 + 0.2
     A, B = torch.rand(N * Cin) + 0.5, torch.randn(N * Cin) * 0.3
     S = torch.rand(N * Cin) + 0.2
-    for wscale in (0.07, 1e-3, 30.0):
-        W = torch.randn(Cout, Cin) * wscale
+
+    def run(W, x, A, B, label, bound_slack=1.0):
         u = A.view(N, Cin, 1).double() * x.double() + B.view(N, Cin, 1).double()
+        ub = (A.view(N, Cin).abs() * x.abs().amax(dim=2) + B.view(N, Cin).abs()) * bound_slack      # any valid bound serves
         if pro == 2:
             u = S.view(N, Cin, 1).double() * torch.nn.functional.gelu(u)
         truth = torch.einsum("oc,ncp->nop", W.double(), u)
         errs = {}
-        for h2 in (1, 0):
-            old = hb.query("uncr_pw_set_h2", h2)
-            try:
-                Wt = E.pack_wt(dev(W), transpose=True)
-                out, part = E.pw_gemm(dev(x), Wt, N, Cin, Cout, P, pro=pro, k=(dev(A), dev(B), dev(S) if pro == 2 else None), epi=1)
-            finally:
-                hb.query("uncr_pw_set_h2", old)
-            errs[h2] = float((out.cpu().double() - truth).abs().max() / truth.abs().max())
-            s = part.buf.view(N * Cout, -1, 2).double().sum(1).cpu()
-            assert float((s[:, 0] - truth.reshape(N * Cout, P).sum(1)).abs().max() / truth.reshape(N * Cout, P).sum(1).abs().max()) < 1e-4
-        print(f"[parity] forward GEMM {Cin}->{Cout} pro {pro} |w|~{wscale:g}: fp16 two-part {errs[1]:.2e}, bf16 three-part {errs[0]:.2e}")
-        assert errs[1] <= 1e-6 and errs[0] <= 1e-6, errs
-    # epi 0 (eval mode behind a BatchNorm: no statistics) takes the same path
-    W = torch.randn(Cout, Cin) * 0.07
-    u = A.view(N, Cin, 1).double() * x.double() + B.view(N, Cin, 1).double()
-    if pro == 2:
-        u = S.view(N, Cin, 1).double() * torch.nn.functional.gelu(u)
-    truth = torch.einsum("oc,ncp->nop", W.double(), u)
-    out, _ = E.pw_gemm(dev(x), E.pack_wt(dev(W), transpose=True), N, Cin, Cout, P, pro=pro, k=(dev(A), dev(B), dev(S) if pro == 2 else None), epi=0)
-    assert float((out.cpu().double() - truth).abs().max() / truth.abs().max()) <= 1e-6
-    # beyond the fp16 range: up to 2 x 65504 the two parts still carry the value (to 11 bits); a NaN input stays a NaN
+        Wt = E.pack_wt(dev(W), transpose=True)
+        for name, amax in (("fp16x2", dev(ub.reshape(-1).float())), ("bf16x3", None)):
+            for epi in (1, 0):       # epi 0: the same GEMMs in eval mode behind a BatchNorm (no statistics)
+                out, part = E.pw_gemm(dev(x), Wt, N, Cin, Cout, P, pro=pro, k=(dev(A), dev(B), dev(S) if pro == 2 else None), epi=epi,
+                                      in_amax=amax)
+                errs[name, epi] = _row_rel_err(out, truth)
+                if epi == 1:
+                    s = part.buf.view(N * Cout, -1, 2).double().sum(1).cpu()
+                    ts = truth.reshape(N * Cout, P).sum(1)
+                    assert float(((s[:, 0] - ts).abs() / truth.reshape(N * Cout, P).abs().sum(1).clamp_min(1e-300)).max()) < 1e-5
+        print(f"[parity] forward GEMM {Cin}->{Cout} pro {pro} {label}: fp16 two-part {errs['fp16x2', 1]:.2e}, bf16 three-part {errs['bf16x3', 1]:.2e}")
+        assert max(errs.values()) <= 2e-6, (label, errs)     # per output row; an fp32 FMA chain over K = 256 sits at ~1e-6 itself
+
+    for wscale in (1e-6, 1e-4, 0.07, 30.0, 2e3, 1e5):
+        run(torch.randn(Cout, Cin) * wscale, x0, A, B, f"|w|~{wscale:g}")
+    # one matrix whose output rows span eleven orders of magnitude (a per-matrix scale would lose the small rows)
+    rows = 10.0 ** (torch.rand(Cout, 1) * 11 - 6)
+    run(torch.randn(Cout, Cin) * rows, x0, A, B, "rows 1e-6..1e5")
+    # a few huge entries in an otherwise ordinary row / column
+    Wm = torch.randn(Cout, Cin) * 0.07
+    Wm[3, 5], Wm[7, :] = 4.0e4, Wm[7, :] * 1e-9
+    run(Wm, x0, A, B, "outlier entries")
+    # activation magnitudes far outside the fp16 range (and far below it), coefficients alike; a loose bound costs nothing
+    for ascale in (1e-4, 1e4, 3e6):
+        run(torch.randn(Cout, Cin) * 0.07, x0 * ascale, A, B * ascale, f"|x|~{ascale:g}")
+    run(torch.randn(Cout, Cin) * 0.07, x0, A * 3e5, B * 3e5, "|A|~3e5 (tiny running variance)")
+    run(torch.randn(Cout, Cin) * 0.07, x0, A, B, "bound 1000x loose", bound_slack=1000.0)
+    # non-finite data: a NaN input stays a NaN (its frame's bound is NaN: no scaling), the other frame is untouched
     Wn = torch.randn(Cout, Cin) * 0.07
-    kk = (dev(torch.ones(N * Cin)), dev(torch.zeros(N * Cin)), dev(torch.ones(N * Cin)) if pro == 2 else None)
-    xb = x.clone()
-    xb[0, 3, 7] = 1.0e5
-    ub = torch.nn.functional.gelu(xb.double()) if pro == 2 else xb.double()
-    truth = torch.einsum("oc,ncp->nop", Wn.double(), ub)
-    out, _ = E.pw_gemm(dev(xb), E.pack_wt(dev(Wn), transpose=True), N, Cin, Cout, P, pro=pro, k=kk, epi=1)
-    assert float((out.cpu().double() - truth).abs().max() / truth.abs().max()) <= 1e-3      # graceful: the low part's 11 bits
+    xb = x0.clone()
     xb[0, 3, 7] = float("nan")
-    out, _ = E.pw_gemm(dev(xb), E.pack_wt(dev(Wn), transpose=True), N, Cin, Cout, P, pro=pro, k=kk, epi=1)
+    ub = A.view(N, Cin).abs() * xb.abs().amax(dim=2) + B.view(N, Cin).abs()
+    out, _ = E.pw_gemm(dev(xb), E.pack_wt(dev(Wn), transpose=True), N, Cin, Cout, P, pro=pro,
+                       k=(dev(A), dev(B), dev(S) if pro == 2 else None), epi=1, in_amax=dev(ub.reshape(-1)))
     assert bool(torch.isnan(out[0, :, 7]).all()) and bool(torch.isfinite(out[1]).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,training", [("group", True), ("batch", True), ("batch", False)])
+def test_norm_finalize_emits_valid_activation_bounds(E, kind, training):
+    """uncr_norm_finalize_fwd's `ub` output: a rigorous per-plane upper bound on |A*h + B| taken from the partial sums of squares
+    (train and eval mode) -- never below the true maximum, and within a modest factor of it on ordinary data."""
+    torch.manual_seed(3)
+    N, C, H, W = 3, 64, 32, 64
+    P = H * W
+    x = torch.randn(N, C, H, W) * torch.rand(1, C, 1, 1) * 5 + torch.randn(1, C, 1, 1) * 3
+    x[1] *= 40.0                                    # frames of different magnitude
+    x[2, 5, 3, 3] = 5000.0                          # an outlier pixel
+    gamma, beta = torch.randn(C), torch.randn(C)
+    rm, rv = torch.randn(C) * 0.1, torch.rand(C) * 1e-6      # eval mode: running statistics that do not describe the data at all
+    xd = dev(x)
+    part = E.stats_sq(xd, N * C, P)
+    spec = E.NormSpec(kind, 4)
+    nf = E.norm_fwd(part if spec.needs_stats(training) else None, N, C, P, spec, training, dev(gamma), dev(beta),
+                    dev(rm.clone()), dev(rv.clone()), bound_part=part)
+    assert nf.ub is not None
+    u = nf.A.view(N, C, 1, 1) * xd + nf.B.view(N, C, 1, 1)
+    true_max = u.abs().amax(dim=(2, 3)).reshape(-1).double()
+    ub = nf.ub.double()
+    assert bool((ub >= true_max * (1 - 1e-6)).all()), float((true_max / ub).max())
+    ratio = float((ub / true_max.clamp_min(1e-30)).median())
+    print(f"[bounds] {kind} train={training}: median bound / true max = {ratio:.1f}")
+    assert ratio < 200.0
+
+
+@pytest.mark.gpu
+def test_mbconv_eval_mode_with_running_statistics_far_from_the_data(orc, E):
+    """Eval-mode BatchNorm does not bound its output: with running variances ~1e-6 x the data's the normalised activations
+    reach 1e5 ... 1e6, far beyond the fp16 range.  The two-part fp16 GEMMs are scaled per frame from the bounds the statistics
+    finalisation derives, so the block still matches an fp64 evaluation like the exact bf16 split does (and both stay finite)."""
+    from uncrtaints_amd import engine
+    N, H, W = 2, 64, 64
+    m = _mb_module("batch", 11)
+    m.eval()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_var.mul_(1e-6)
+                mod.weight.mul_(3.0)
+    sd = {("blk." + k): v.clone() for k, v in m.state_dict().items()}
+    x = rand(N, 128, H, W, seed=4, scale=30.0, shift=5.0)
+    p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    y64 = orc.mbconv(x.double(), p64, "blk", "batch", False)
+    md = m.to(DEV)
+    errs = {}
+    for name, h2 in (("fp16x2", True), ("bf16x3", False)):
+        old = engine._H2_FWD
+        engine._H2_FWD = h2
+        try:
+            xd = dev(x)
+            xd._uncr_part = E.stats_sq(xd, N * 128, H * W)         # what the producing block leaves on its output
+            with torch.no_grad():
+                yd = md(xd)
+        finally:
+            engine._H2_FWD = old
+        assert bool(torch.isfinite(yd).all())
+        errs[name] = float((yd.cpu().double() - y64).abs().max() / y64.abs().max())
+    print(f"[parity] eval-mode MBConv, running variance 1e-6 x data: fp16 two-part {errs['fp16x2']:.2e}, bf16 three-part {errs['bf16x3']:.2e}")
+    assert errs["fp16x2"] <= 2e-5 and errs["fp16x2"] <= 3 * errs["bf16x3"] + 1e-6, errs
 
 
 @pytest.mark.gpu

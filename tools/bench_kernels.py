@@ -51,9 +51,9 @@ def main():
             w = t(C, 9)
             sf, sb = hb.query("uncr_dw_slots_fwd", H), hb.query("uncr_dw_slots_bwd", H)
             partf, partb, dwp = torch.empty(Nf * C, sf, 2, device=dev), torch.empty(Nf * C, sb, 2, device=dev), torch.empty(Nf * C, sb, 9, device=dev)
-            ms = timeit(lambda: hb.call("uncr_dw_fwd", h1, cA, cB, w, out, partf, Nf, C, H, W, 0, E._stream()), iters)
+            ms = timeit(lambda: hb.call("uncr_dw_fwd", h1, cA, cB, w, out, partf, Nf, C, H, W, 0, 0, E._stream()), iters)
             print(f"dw_fwd N={Nf}: {ms*1e3:.1f} us  {8.0*Nf*C*H*W/ms/1e6:.0f} GB/s")
-            ms = timeit(lambda: hb.call("uncr_dw_bwd", du2, h2, h1, k1, k2, k3, None, cA, cB, w, out, partb, dwp, None, 0, Nf, C, H, W, 0, E._stream()), iters)
+            ms = timeit(lambda: hb.call("uncr_dw_bwd", du2, h2, h1, k1, k2, k3, None, cA, cB, w, out, partb, dwp, None, 0, Nf, C, H, W, 0, 0, E._stream()), iters)
             print(f"dw_bwd N={Nf}: {ms*1e3:.1f} us  {16.0*Nf*C*H*W/ms/1e6:.0f} GB/s")
     elif what == "agg":
         # the L-TAE stage's full-resolution kernels at the bench shape
@@ -136,8 +136,8 @@ def main():
         sf, sb = hb.query("uncr_dw_slots_fwd", H), hb.query("uncr_dw_slots_bwd", H)
         partf, partb, dwp = torch.empty(N * C, sf, 2, device=dev), torch.empty(N * C, sb, 2, device=dev), torch.empty(N * C, sb, 9, device=dev)
         for _ in range(3):
-            hb.call("uncr_dw_fwd", h1, cA, cB, w9, out, partf, N, C, H, W, 0, E._stream())
-            hb.call("uncr_dw_bwd", du2, hh2, h1, k1, k2, k3, None, cA, cB, w9, out, partb, dwp, None, 0, N, C, H, W, 0, E._stream())
+            hb.call("uncr_dw_fwd", h1, cA, cB, w9, out, partf, N, C, H, W, 0, 0, E._stream())
+            hb.call("uncr_dw_bwd", du2, hh2, h1, k1, k2, k3, None, cA, cB, w9, out, partb, dwp, None, 0, N, C, H, W, 0, 0, E._stream())
         torch.cuda.synchronize()
         print("done")
     elif what == "ablate":

@@ -63,6 +63,6 @@ def run(tag):
 
 
 run("default")
-hb.query("uncr_pw_set_split", 0); run("fp32-MFMA GEMMs (split off)"); hb.query("uncr_pw_set_split", 1)
-hb.query("uncr_dw_set_row", 0); run("LDS-tiled depthwise"); hb.query("uncr_dw_set_row", 1)
+E._H2_FWD = E._H2_BWD = False; run("exact bf16 split everywhere"); E._H2_FWD = E._H2_BWD = True
+E._DW_VARIANT = 1; run("LDS-tiled depthwise"); E._DW_VARIANT = 0
 E._FUSED_DX = False; run("unfused dx"); E._FUSED_DX = True

@@ -334,10 +334,8 @@ int dw_bwd_row_launch(const void* du2, const void* h2, const void* h1, const flo
                       hipStream_t stream) {
     const int planes = N * C;
     // 64-row tiles (2 halo rows per 64).  Measured: 2 ... 8 tiles per 256-row plane are all within 3 % of each other (the
-    // kernel is bound by the memory system, not by how the waves fill the chip); UNCR_DW_TILES overrides for experiments.
-    int tiles = (slots + DWR_TR / 16 - 1) / (DWR_TR / 16);
-    if (const char* ov = getenv("UNCR_DW_TILES"))
-        if (atoi(ov) > 0 && atoi(ov) <= slots) tiles = atoi(ov);
+    // kernel is bound by the memory system, not by how the waves fill the chip).
+    const int tiles = (slots + DWR_TR / 16 - 1) / (DWR_TR / 16);
     UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(dw_bwd_row_kernel<T>, dim3((planes * tiles + 3) / 4), dim3(256), 0, stream,
                                                  (const T*)du2, (const T*)h2, (const T*)h1, k1, k2, k3, kmu, cA1, cB1, w, (T*)du1,
                                                  (float2*)part, dw_part, mean1, mean_groups, C, H, planes, slots, tiles));

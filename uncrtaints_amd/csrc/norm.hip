@@ -13,16 +13,25 @@
 __global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(
     const float2* __restrict__ part, int NP, int C, int G, int P, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float* __restrict__ coefA, float* __restrict__ coefB,
-    float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+    float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ ub) {
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int Cg = C / G;
     const float2* src = part + ((size_t)n * C + (size_t)g * Cg) * NP;
     const int cnt = Cg * NP;
+    // ub (optional): per-plane upper bound on |A*h + B|.  |h| <= sqrt(sum of the block's h^2) for every element of a block, so
+    // the largest partial sum of squares of a plane bounds its values (a few bits loose, rigorous); the consumer GEMM derives the
+    // power-of-two scale of its fp16 operand split from these (pw_gemm_split.hip).  Non-negative floats order like their bits.
+    __shared__ unsigned smax[256];
+    if (ub) {
+        for (int c = threadIdx.x; c < Cg; c += 256) smax[c] = 0u;
+        __syncthreads();
+    }
     double s = 0.0, ss = 0.0;
     for (int i = threadIdx.x; i < cnt; i += 256) {
         const float2 v = src[i];
         s += (double)v.x;
         ss += (double)v.y;
+        if (ub) atomicMax(&smax[i / NP], __float_as_uint(v.y));
     }
     __shared__ double red[8];
     __shared__ float sh_mean, sh_rstd;
@@ -47,8 +56,10 @@ __global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(
     for (int c = threadIdx.x; c < Cg; c += 256) {
         const int ch = g * Cg + c;
         const float a = gamma[ch] * sh_rstd;
+        const float b = beta[ch] - sh_mean * a;
         coefA[n * C + ch] = a;
-        coefB[n * C + ch] = beta[ch] - sh_mean * a;
+        coefB[n * C + ch] = b;
+        if (ub) ub[n * C + ch] = fmaf(fabsf(a), sqrtf(__uint_as_float(smax[c])), fabsf(b));
     }
 }
 
@@ -57,10 +68,22 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(
     const float2* __restrict__ part, int NP, int N, int C, int P, int train, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
     float momentum, float eps, float* __restrict__ coefA, float* __restrict__ coefB,
-    float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+    float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ ub) {
     const int c = blockIdx.x;
     __shared__ double red[8];
     __shared__ float sh_mean, sh_rstd;
+    // ub: see gn_finalize_fwd_kernel; one bound per frame (more than 256 frames share one)
+    __shared__ unsigned smax[256];
+    const bool per_frame = N <= 256;
+    if (ub) {
+        for (int i = threadIdx.x; i < 256; i += 256) smax[i] = 0u;
+        __syncthreads();
+        if (!train)      // eval mode: the partials (of the same tensor) only serve the bound
+            for (int i = threadIdx.x; i < N * NP; i += 256) {
+                const int n = i / NP, j = i - n * NP;
+                atomicMax(&smax[per_frame ? n : 0], __float_as_uint(part[((size_t)n * C + c) * NP + j].y));
+            }
+    }
     if (train) {
         double s = 0.0, ss = 0.0;
         const int cnt = N * NP;
@@ -69,6 +92,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(
             const float2 v = part[((size_t)n * C + c) * NP + j];
             s += (double)v.x;
             ss += (double)v.y;
+            if (ub) atomicMax(&smax[per_frame ? n : 0], __float_as_uint(v.y));
         }
         s = wave_sum_d(s);
         ss = wave_sum_d(ss);
@@ -101,6 +125,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(
     for (int n = threadIdx.x; n < N; n += 256) {
         coefA[n * C + c] = a;
         coefB[n * C + c] = b;
+        if (ub) ub[n * C + c] = fmaf(fabsf(a), sqrtf(__uint_as_float(smax[per_frame ? n : 0])), fabsf(b));
     }
 }
 
@@ -421,19 +446,21 @@ extern "C" int uncr_bn_finalize_bwd_sums(const double* sums_local, const double*
 extern "C" int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                                       const float* gamma, const float* beta, float* running_mean,
                                       float* running_var, float momentum, float eps, float* coefA, float* coefB,
-                                      float* save_mean, float* save_rstd, hipStream_t stream) {
+                                      float* save_mean, float* save_rstd, float* ub, hipStream_t stream) {
     if (N <= 0 || C <= 0 || P <= 0) return UNCR_ESHAPE;
+    if (ub && (!part || NP <= 0)) return UNCR_EINVAL;      // the bound is taken from the partial sums of squares
     if (kind == NORM_GROUP) {
         if (groups <= 0 || C % groups || !part) return UNCR_EINVAL;
+        if (ub && C / groups > 256) return UNCR_ESHAPE;
         hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(N * groups), dim3(256), 0, stream, (const float2*)part, NP, C,
-                           groups, P, gamma, beta, eps, coefA, coefB, save_mean, save_rstd);
+                           groups, P, gamma, beta, eps, coefA, coefB, save_mean, save_rstd, ub);
     } else if (kind == NORM_BATCH_TRAIN || kind == NORM_BATCH_EVAL) {
         const int train = kind == NORM_BATCH_TRAIN;
         if (train && !part) return UNCR_EINVAL;
         if (!train && (!running_mean || !running_var)) return UNCR_EINVAL;
         hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(256), 0, stream, (const float2*)part, NP, N, C, P,
                            train, gamma, beta, running_mean, running_var, momentum, eps, coefA, coefB, save_mean,
-                           save_rstd);
+                           save_rstd, ub);
     } else {
         return UNCR_EINVAL;
     }

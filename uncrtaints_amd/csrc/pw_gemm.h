@@ -34,10 +34,12 @@ struct PwArgs {
     float head_scale = 1.f, head_eps = 0.f;
     float* head_pre = nullptr;   // optional second output: the pre-activation [N][Cout][P]
     const float* k3 = nullptr;    // PRO_NORMBWD: the norm's mean per (n, ci) -- centred form C1*v + C2*(v2 - mean) + C3; null: 0
-    int h2 = 0;                   // wide kernels, fp32 storage, PRO_AFFINE / PRO_AFFINE_GELU with EPI 0 / 1: fp16 two-part split
-    // magnitude bounds for the fp16 two-part split of a GRADIENT GEMM (PRO_NORMBWD + EPI 3): per-block max |value| arrays written by
-    // the producers of the two prologue operands ([N][n] floats each); the kernel derives a per-frame power-of-two scale from them
-    // and from its own coefficient rows.  amax_out: this launch's per-block max |stored output| ([N][blocks per frame]) or null.
+    int h2 = 0;                   // wide kernels, fp32 storage: fp16 two-part split wherever the bounds below are given
+    // magnitude bounds for the fp16 two-part split ([N][n] floats each; the kernel derives a per-frame power-of-two scale from them
+    // and from its own coefficient rows).  PRO_NORMBWD + EPI 3 (gradient GEMM): per-block max |value| arrays written by the
+    // producers of the two prologue operands.  PRO_AFFINE / PRO_AFFINE_GELU + EPI 0 / 1 (forward GEMM behind a norm): in_amax =
+    // per-plane bounds on |A*h + B| ([N][Cin], uncr_norm_finalize_fwd), in2_amax unused.  Without them: the exact bf16 split.
+    // amax_out: this launch's per-block max |stored output| ([N][blocks per frame]) or null.
     float* amax_out = nullptr;
     const float* in_amax = nullptr;
     const float* in2_amax = nullptr;
@@ -62,14 +64,12 @@ __device__ __forceinline__ unsigned pack_bf16x2(unsigned a, unsigned b) {
 // |r| <= max(2^-22 |x*SC|, 2^-25) -- fp16 has 11 significant bits, so two parts carry 22; the three products h*h', h*l', l*h'
 // reach 2^-22 relative accuracy, the same order as an fp32 FMA chain, at HALF the matrix-pipe work of the exact 3 x bf16 split.
 // fp16's narrow exponent is why this is used only where the range is known: activation operands are outputs of a norm prologue
-// (|u| <= sqrt(group size) * |gamma| + |beta|, far inside +-65504), weights are scaled by 2^6 at pack
-// time (|w| < 1023 keeps its full precision, the scale leaves in the epilogue).  Gradient GEMMs keep the bf16 split: gradients
-// span the whole fp32 exponent range.
+// and are scaled per frame from a rigorous bound the statistics finalisation derives (PwArgs::in_amax), weights are scaled per
+// output channel at pack time (pack_wt_split_tile); both scales are powers of two and leave in the epilogue.  Gradient GEMMs
+// take the same route where their producers leave magnitude bounds (dz GEMM), and the exact bf16 split otherwise.
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2v_t __attribute__((ext_vector_type(2)));
-#define PWS_H2_WSCALE 64.0f
-#define PWS_H2_INV_WSCALE 0.015625f
 // (a, b) -> packed fp16 pairs {lo16 = a, hi16 = b}: hi parts and lo parts
 // The high part is taken from the value clamped to the fp16 range, the low part from the UNclamped remainder: values up to
 // 2 x 65504 in magnitude are still represented, larger ones overflow to inf and a NaN / inf input stays NaN / inf -- nothing is
@@ -83,6 +83,9 @@ __device__ __forceinline__ void split2_f16_pair(float a, float b, unsigned& hi, 
     lo = __builtin_bit_cast(unsigned, l);
 }
 #define PWS_NSLOT 5      // packed weight slots per (k-step, co tile): bf16 h, m, l and fp16 h, l (scaled)
+#define PWS_KC 32
+// k-steps in the packed weights: chunk count padded to even (the DEPTH = 2 kernels compute chunk pairs)
+__host__ __device__ static inline int pws_nks(int rows_k) { return 2 * (((rows_k + PWS_KC - 1) / PWS_KC + 1) / 2 * 2); }
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -100,7 +103,7 @@ int pw_split_launch_p4(const PwArgs& g, int N, int cp, int act, hipStream_t stre
 int pw_split_pack(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out, hipStream_t stream);
 size_t pw_split_wt_floats(int rows_k, int cp);
 int pw_split_blocks_per_frame(int N, int P);
-int pw_pack_batch(const long long* desc, int n_items, int max_threads, int split_on, hipStream_t stream);
+int pw_pack_batch(const long long* desc, int n_items, hipStream_t stream);
 
 // pw_wgrad_split.hip
 int pw_wgrad_split_nbx(int N, int P);

@@ -470,15 +470,9 @@ __global__ void pack_wt_kernel(const float* __restrict__ W, int rows_k, int cols
 
 static int pw_coutp(int Cout) { return Cout > 128 ? 256 : (Cout > 64 ? 128 : (Cout > 32 ? 64 : 32)); }
 
-// wide shapes (Cout > 64) run on the bf16x3-split kernels (pw_gemm_split.hip) unless switched off -- the switch
-// exists for A/B measurements and for testing both paths; weights must be packed under the same setting.
-static int g_split = 1;
-extern "C" int uncr_pw_set_split(int on) { const int old = g_split; g_split = on ? 1 : 0; return old; }
-static bool use_split(int Cout) { return g_split && pw_coutp(Cout) >= 128; }
-// fp16 two-part split (three products) for the forward GEMMs behind a norm prologue (pw_gemm.h); 0 keeps the exact 3 x bf16 split
-// (six products) everywhere -- A/B measurements and tests
-static int g_h2 = [] { const char* e = getenv("UNCR_PW_H2"); return (e && atoi(e) == 0) ? 0 : 1; }();      // env: A/B runs
-extern "C" int uncr_pw_set_h2(int on) { const int old = g_h2; g_h2 = on ? 1 : 0; return old; }
+// wide shapes (Cout > 64) run on the split kernels of pw_gemm_split.hip (bf16 matrix pipe, fp32 results); the library keeps no
+// mutable state: which split a call uses follows from its arguments alone (magnitude bounds given -> two fp16 parts)
+static bool use_split(int Cout) { return pw_coutp(Cout) >= 128; }
 
 extern "C" int uncr_pw_coutp(int Cout) { return Cout <= 256 ? pw_coutp(Cout) : -1; }
 extern "C" int uncr_pw_kpad(int Cin) { return ((Cin + 31) / 32) * 32; }
@@ -511,15 +505,9 @@ extern "C" int uncr_pack_wt(const float* W, int rows_k, int cols_co, int ld, int
     return UNCR_OK;
 }
 
-// threads uncr_pack_wt needs for one weight (the batch launch is sized by the largest item)
-extern "C" int uncr_pack_wt_threads(int rows_k, int cols_co) {
-    if (cols_co > 256 || rows_k > 256 || cols_co <= 0 || rows_k <= 0) return -1;
-    if (use_split(cols_co)) return (int)(pw_split_wt_floats(rows_k, pw_coutp(cols_co)) / (4 * PWS_NSLOT));   // PWS_NSLOT x 16 B per thread
-    return uncr_pw_kpad(rows_k) * pw_coutp(cols_co);
-}
-extern "C" int uncr_pack_wt_batch(const long long* desc, int n_items, int max_threads, hipStream_t stream) {
-    if (!desc || n_items <= 0 || max_threads <= 0) return UNCR_EINVAL;
-    return pw_pack_batch(desc, n_items, max_threads, g_split, stream);
+extern "C" int uncr_pack_wt_batch(const long long* desc, int n_items, hipStream_t stream) {
+    if (!desc || n_items <= 0) return UNCR_EINVAL;
+    return pw_pack_batch(desc, n_items, stream);
 }
 
 extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, void* out, const float* k0,
@@ -542,7 +530,7 @@ extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, vo
     if (P % tp) return UNCR_ESHAPE;
     PwArgs g{in, in2, Wt, out, k0, k1, k2, bias, aux, e0, e1, e2, e3, (float2*)part, bias_stride_n, Cin, Cout, P, pro, epi};
     g.k3 = pro == PRO_NORMBWD ? kmu : nullptr;
-    g.h2 = g_h2;
+    g.h2 = in_amax != nullptr;
     g.amax_out = amax_out;
     g.in_amax = in_amax; g.in_amax_n = in_amax_n;
     g.in2_amax = in2_amax; g.in2_amax_n = in2_amax_n;
@@ -561,11 +549,7 @@ extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, vo
     // fp32-MFMA kernels: fp32 storage, or bf16 inputs with fp32 outputs (the narrow shapes: Cout <= 64)
     if (out_dt != UNCR_F32 || (in_dt == UNCR_BF16 && cp > 64)) return UNCR_EINVAL;
     dim3 grid(P / tp, N);
-    if (cp == 256)
-        hipLaunchKernelGGL((pw_gemm_kernel<2, 4, 1, true>), grid, dim3(256), 0, stream, g);
-    else if (cp == 128)
-        hipLaunchKernelGGL((pw_gemm_kernel<1, 4, 1, true>), grid, dim3(256), 0, stream, g);
-    else if (cp == 64) {
+    if (cp == 64) {
         if (in_dt == UNCR_BF16) hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true, bf16_t, float>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true>), grid, dim3(256), 0, stream, g);
     } else if (pro == PRO_NORMBWD) {
@@ -648,9 +632,9 @@ extern "C" int uncr_wgrad_shape(int Cd, int Cx, int* cop, int* cip) { return wg_
 // blocks (= partial products) per frame that uncr_pw_wgrad will use for this problem
 extern "C" int uncr_wgrad_nbx(int N, int Cd, int Cx, int P, int pro_d, int pro_x, int rowsum, int act) {
     if (N <= 0 || P <= 0 || P % 32) return -1;
-    if (act == UNCR_BF16 && g_split && pw_wgrad_a16_supported(Cd, Cx, pro_d, pro_x, rowsum != 0) && P % 64 == 0)
+    if (act == UNCR_BF16 && pw_wgrad_a16_supported(Cd, Cx, pro_d, pro_x, rowsum != 0) && P % 64 == 0)
         return pw_wgrad_a16_nbx(N, P);
-    if (act == UNCR_F32 && g_split && pw_wgrad_split_supported(Cd, Cx, pro_d, pro_x, rowsum != 0)) return pw_wgrad_split_nbx(N, P);
+    if (act == UNCR_F32 && pw_wgrad_split_supported(Cd, Cx, pro_d, pro_x, rowsum != 0)) return pw_wgrad_split_nbx(N, P);
     // fp32-MFMA kernel: equal pixel ranges, aim for ~512-1024 blocks on the 256 CUs
     for (int cand = 4096; cand >= 256; cand >>= 1)
         if (P % cand == 0 && (long long)N * (P / cand) >= 512) return P / cand;
@@ -667,11 +651,11 @@ extern "C" int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const
     if (!d || !x || !part || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
     if (pro_d == PRO_NORMBWD && !d2) return UNCR_EINVAL;
     if (pro_x == PRO_NORMBWD) return UNCR_EINVAL;   // norm-backward form is only built for the D operand
-    if (act == UNCR_BF16 && g_split && pw_wgrad_a16_supported(Cd, Cx, pro_d, pro_x, rs_part != nullptr) && P % 64 == 0) {
+    if (act == UNCR_BF16 && pw_wgrad_a16_supported(Cd, Cx, pro_d, pro_x, rs_part != nullptr) && P % 64 == 0) {
         if (!dk0 || !dk1 || !dk2 || !xk0 || !xk1) return UNCR_EINVAL;
         return pw_wgrad_a16_launch(d, d2, x, dk0, dk1, dk2, dkmu, xk0, xk1, xk2, part, N, Cd, Cx, P, NBX, pro_x, stream);
     }
-    if (act == UNCR_F32 && g_split && pw_wgrad_split_supported(Cd, Cx, pro_d, pro_x, rs_part != nullptr)) {
+    if (act == UNCR_F32 && pw_wgrad_split_supported(Cd, Cx, pro_d, pro_x, rs_part != nullptr)) {
         if (!dk0 || !dk1 || !dk2 || !xk0 || !xk1) return UNCR_EINVAL;
         return pw_wgrad_split_launch((const float*)d, (const float*)d2, (const float*)x, dk0, dk1, dk2, dkmu, xk0, xk1, xk2, part, N,
                                      Cd, Cx, P, NBX, pro_x, stream);

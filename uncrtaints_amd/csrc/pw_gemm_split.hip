@@ -59,7 +59,6 @@ template <bool NT, typename TA> __device__ __forceinline__ void pws_st(TA* p, co
 #define PWS_ABL 0   // development ablations (tools/ablate_split.sh): 1 no stores, 2 no staging, 4 no activation loads, 8 no A reloads, 16 no MFMA
 #endif
 #define PWS_TP 128
-#define PWS_KC 32
 #define PWS_BUF 24576   // bytes per LDS stage: 3 parts x 32 ci x 128 px x 2 B (bf16 activations: 1 part, 8192 B)
 #ifndef PWS_A16_WPARTS
 #define PWS_A16_WPARTS 2   // bf16 activations: leading weight parts used (2 = 16 significant bits: the weights stay fp32-grade,
@@ -277,34 +276,53 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
     }
     __syncthreads();   // cf / ecf visible
-    // fp16 two-part split of a gradient operand (H2 with the norm-backward prologue): |C1*v + C2*(v2 - mu) + C3| is bounded by
-    // max|C1| * max|v| + max|C2| * (max|v2| + max|mu|) + max|C3| over the frame; the producers of v and v2 left their per-block
-    // maxima, the coefficient rows are in LDS.  A power-of-two scale brings that bound to 2^14 (a factor 4 below the fp16 maximum,
-    // headroom for the rounding of the bound itself); it multiplies C1..C3 here and leaves in the epilogue.  Rigorous: nothing can
-    // overflow, and everything above 2^-29 of the frame's bound keeps 22 bits.
-    float hinv = PWS_H2_INV_WSCALE;
-    if constexpr (H2 && PRO == PRO_NORMBWD) {
+    // fp16 two-part split (H2): a per-frame power-of-two scale brings a rigorous bound on the staged operand to 2^14 (a factor 4
+    // below the fp16 maximum: headroom for the rounding of the bound itself); it multiplies the prologue coefficients here and
+    // leaves in the epilogue together with the weights' per-channel scale (hsc).  Nothing can overflow, and everything above
+    // 2^-29 of the frame's bound keeps 22 bits.  The bound:
+    //   norm-backward prologue (gradient GEMM): |C1*v + C2*(v2 - mu) + C3| <= max|C1| max|v| + max|C2| (max|v2| + max|mu|) + max|C3|
+    //     with the per-block maxima the producers of v and v2 left (in_amax, in2_amax);
+    //   affine prologue (forward GEMM behind a norm): in_amax = [N][Cin] per-plane bounds on |A*h + B| from the statistics
+    //     finalisation (uncr_norm_finalize_fwd: |h| <= sqrt(max over blocks of the block's sum h^2));
+    //   affine + GELU (+ SE scale): the same times max|S| (|gelu(u)| <= |u|).
+    __shared__ float hsc[H2 ? COUTP : 1];
+    if constexpr (H2) {
         float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < Cin; i += NT) {
-            m[0] = fmaxf(m[0], fabsf(cf[0][i])); m[1] = fmaxf(m[1], fabsf(cf[1][i]));
-            m[2] = fmaxf(m[2], fabsf(cf[2][i])); m[3] = fmaxf(m[3], fabsf(cf[3][i]));
+        if constexpr (PRO == PRO_NORMBWD) {
+            for (int i = tid; i < Cin; i += NT) {
+                m[0] = fmaxf(m[0], fabsf(cf[0][i])); m[1] = fmaxf(m[1], fabsf(cf[1][i]));
+                m[2] = fmaxf(m[2], fabsf(cf[2][i])); m[3] = fmaxf(m[3], fabsf(cf[3][i]));
+            }
+            for (int i = tid; i < g.in2_amax_n; i += NT) m[5] = fmaxf(m[5], g.in2_amax[(size_t)n * g.in2_amax_n + i]);
+        } else if constexpr (PRO == PRO_AFFINE_GELU) {
+            for (int i = tid; i < Cin; i += NT) m[2] = fmaxf(m[2], fabsf(cf[2][i]));
         }
-        for (int i = tid; i < g.in_amax_n; i += NT) m[4] = fmaxf(m[4], g.in_amax[(size_t)n * g.in_amax_n + i]);
-        for (int i = tid; i < g.in2_amax_n; i += NT) m[5] = fmaxf(m[5], g.in2_amax[(size_t)n * g.in2_amax_n + i]);
+        if (g.in_amax)
+            for (int i = tid; i < g.in_amax_n; i += NT) {
+                const float v = g.in_amax[(size_t)n * g.in_amax_n + i];
+                m[4] = v > m[4] || !(v == v) ? v : m[4];         // a NaN bound stays (no scaling below)
+            }
         __shared__ float bred[4][6];
         __shared__ float bscale;
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
 #pragma unroll
-            for (int sft = 32; sft >= 1; sft >>= 1) m[q] = fmaxf(m[q], __shfl_xor(m[q], sft, 64));
+            for (int sft = 32; sft >= 1; sft >>= 1) { const float o = __shfl_xor(m[q], sft, 64); m[q] = o > m[q] || !(o == o) ? o : m[q]; }
             if (lane == 0) bred[wn][q] = m[q];
         }
         __syncthreads();
         if (tid == 0) {
             float mm[6];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) mm[q] = fmaxf(fmaxf(bred[0][q], bred[1][q]), fmaxf(bred[2][q], bred[3][q]));
-            const float bound = mm[0] * mm[4] + mm[1] * (mm[5] + mm[3]) + mm[2];
+            for (int q = 0; q < 6; ++q) {
+                mm[q] = bred[0][q];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) mm[q] = bred[w][q] > mm[q] || !(bred[w][q] == bred[w][q]) ? bred[w][q] : mm[q];
+            }
+            float bound;
+            if constexpr (PRO == PRO_NORMBWD) bound = mm[0] * mm[4] + mm[1] * (mm[5] + mm[3]) + mm[2];
+            else if constexpr (PRO == PRO_AFFINE_GELU) bound = mm[4] * mm[2];
+            else bound = mm[4];
             float sc = 1.f;
             if (bound > 0.f && bound < 3.0e38f) {
                 int e;
@@ -317,8 +335,15 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         }
         __syncthreads();
         const float sc = bscale;
-        for (int i = tid; i < Cin; i += NT) { cf[0][i] *= sc; cf[1][i] *= sc; cf[2][i] *= sc; }
-        hinv = PWS_H2_INV_WSCALE / sc;
+        if constexpr (PRO == PRO_AFFINE_GELU) {
+            for (int i = tid; i < Cin; i += NT) cf[2][i] *= sc;
+        } else {
+            for (int i = tid; i < Cin; i += NT) { cf[0][i] *= sc; cf[1][i] *= sc; if constexpr (PRO == PRO_NORMBWD) cf[2][i] *= sc; }
+        }
+        // the weights' per-output-channel scale (tail of the packed buffer, pack_wt_split_tile) and the frame's scale leave together
+        const float* wtail = g.Wt + (size_t)pws_nks(Cin) * NCT * PWS_NSLOT * 64 * 4;
+        const float isc = 1.f / sc;
+        for (int c = tid; c < COUTP; c += NT) hsc[c] = wtail[c] * isc;
         __syncthreads();
     }
     float amx = 0.f;          // max |stored output| of this block (CT = 1 statistics / skip epilogues)
@@ -506,9 +531,11 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                     const int col = row_of(ct, r) + 4 * kg;
                     const float bb = EPI == 6 ? 0.f : ecf[0][col];
                     float4 v;
-                    if constexpr (H2)       // the weights' pack-time scale leaves here
+                    if constexpr (H2) {     // the weights' pack-time scale and the frame's operand scale leave here
+                        const float hinv = hsc[col];
                         v = make_float4(fmaf(acc[0][ct][r], hinv, bb), fmaf(acc[1][ct][r], hinv, bb),
                                         fmaf(acc[2][ct][r], hinv, bb), fmaf(acc[3][ct][r], hinv, bb));
+                    }
                     else v = make_float4(acc[0][ct][r] + bb, acc[1][ct][r] + bb, acc[2][ct][r] + bb, acc[3][ct][r] + bb);
                     float s0 = 0.f, s1 = 0.f;
                     if constexpr (EPI == 3) {
@@ -630,90 +657,111 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
 #endif
 
 #if PWS_PRO == 0
-// Wp[ks][cotile][part][lane][8 bf16] from W[co][k] (transpose=1) or W[k][co] (transpose=0); zero padded to
-// Kp = 32*ceil(rows_k/32) and cp output channels.  One thread per (ks, cotile, lane): 3 x 16 B.
-__device__ __forceinline__ void pack_wt_split_item(const float* __restrict__ W, int rows_k, int cols_co, int ld,
-                                                   int transpose, int nks, int nct, u32x4_t* __restrict__ out,
-                                                   int idx) {
-    if (idx >= nks * nct * 64) return;
-    const int lane = idx & 63, cot = (idx >> 6) % nct, ks = (idx >> 6) / nct;
-    const int co = cot * 32 + (lane & 31), kb = 16 * ks + 8 * (lane >> 5);
-    unsigned h[8], m[8], l[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int k = kb + q;
-        float v = 0.f;
-        if (k < rows_k && co < cols_co) v = transpose ? W[(size_t)co * ld + k] : W[(size_t)k * ld + co];
-        split3_bf16(v, h[q], m[q], l[q]);
+// Wp[ks][cotile][slot][lane][8 x 16 bit] from W[co][k] (transpose=1) or W[k][co] (transpose=0); zero padded to
+// Kp = 32*ceil(rows_k/32) and cp output channels; slots 0-2 = the exact bf16 parts h, m, l, slots 3-4 = the two fp16 parts of the
+// SCALED weight, followed by a tail of cp floats: the inverse of the per-output-channel scale.
+// fp16 scale (range safety of the two-part split): every output channel co gets its own power of two S[co] with
+// S*max_k|W[k][co]| in [2^14, 2^15) -- nothing can overflow fp16 whatever the checkpoint holds, every weight within 2^17 of its
+// row's maximum keeps 22 significant bits, smaller ones an absolute error of 2^-39 of the row maximum.  The scale leaves in the
+// GEMM epilogue (exact: a power of two).  An all-zero row and a row holding inf / NaN get S = 1 (inf / NaN propagate like in fp32).
+// One block = one co tile (32 output channels) of one weight: phase 1 = the 32 row maxima, phase 2 = the fragments of all k-steps.
+__device__ __forceinline__ float pws_pow2_scale(float amax) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    int e;
+    (void)frexpf(amax, &e);                        // amax = f * 2^e, f in [0.5, 1)
+    e = 15 - e;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);     // 2^100 * (a weight < 2^-86) underflows the low part: as irrelevant as in fp32
+    return ldexpf(1.f, e);
+}
+__device__ __forceinline__ void pack_wt_split_tile(const float* __restrict__ W, int rows_k, int cols_co, int ld,
+                                                   int transpose, int nks, int nct, u32x4_t* __restrict__ out, int cot) {
+    __shared__ float rmax[8][32];
+    __shared__ float rscale[32];
+    const int tid = threadIdx.x;
+    auto wat = [&](int k, int co) -> float {
+        return (k < rows_k && co < cols_co) ? (transpose ? W[(size_t)co * ld + k] : W[(size_t)k * ld + co]) : 0.f;
+    };
+    {
+        const int co = cot * 32 + (tid & 31), sl = tid >> 5;
+        float m = 0.f;
+        bool bad = false;
+        for (int k = sl; k < rows_k; k += 8) { const float v = fabsf(wat(k, co)); bad |= !(v < 3.0e38f); m = fmaxf(m, v); }
+        rmax[sl][tid & 31] = bad ? __builtin_inff() : m;
     }
-    // fp16 two-part split of the scaled weight (pw_gemm.h): k-pairs packed like the bf16 parts
-    unsigned fh[4], fl[4];
+    __syncthreads();
+    if (tid < 32) {
+        float m = rmax[0][tid];
 #pragma unroll
-    for (int q = 0; q < 8; q += 2) {
-        float v2[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int k = kb + q + t;
-            float v = 0.f;
-            if (k < rows_k && co < cols_co) v = transpose ? W[(size_t)co * ld + k] : W[(size_t)k * ld + co];
-            v2[t] = v * PWS_H2_WSCALE;
-        }
-        split2_f16_pair(v2[0], v2[1], fh[q >> 1], fl[q >> 1]);
+        for (int q = 1; q < 8; ++q) m = fmaxf(m, rmax[q][tid]);
+        const float sc = pws_pow2_scale(m);
+        rscale[tid] = sc;
+        float* tail = (float*)(out + (size_t)nks * nct * PWS_NSLOT * 64);
+        tail[cot * 32 + tid] = 1.f / sc;
     }
-    u32x4_t* o = out + (size_t)(ks * nct + cot) * PWS_NSLOT * 64 + lane;
-    o[192] = u32x4_t{fh[0], fh[1], fh[2], fh[3]};
-    o[256] = u32x4_t{fl[0], fl[1], fl[2], fl[3]};
-    o[0] = u32x4_t{pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]), pack_bf16x2(h[4], h[5]), pack_bf16x2(h[6], h[7])};
-    o[64] = u32x4_t{pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7])};
-    o[128] = u32x4_t{pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]), pack_bf16x2(l[4], l[5]), pack_bf16x2(l[6], l[7])};
+    __syncthreads();
+    const int lane = tid & 63;
+    const int co = cot * 32 + (lane & 31);
+    const float sc = rscale[lane & 31];
+    for (int ks = tid >> 6; ks < nks; ks += 4) {
+        const int kb = 16 * ks + 8 * (lane >> 5);
+        unsigned h[8], m[8], l[8], fh[4], fl[4];
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { v[q] = wat(kb + q, co); split3_bf16(v[q], h[q], m[q], l[q]); }
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) split2_f16_pair(v[q] * sc, v[q + 1] * sc, fh[q >> 1], fl[q >> 1]);
+        u32x4_t* o = out + (size_t)(ks * nct + cot) * PWS_NSLOT * 64 + lane;
+        o[192] = u32x4_t{fh[0], fh[1], fh[2], fh[3]};
+        o[256] = u32x4_t{fl[0], fl[1], fl[2], fl[3]};
+        o[0] = u32x4_t{pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]), pack_bf16x2(h[4], h[5]), pack_bf16x2(h[6], h[7])};
+        o[64] = u32x4_t{pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7])};
+        o[128] = u32x4_t{pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]), pack_bf16x2(l[4], l[5]), pack_bf16x2(l[6], l[7])};
+    }
 }
 __global__ __launch_bounds__(256) void pack_wt_split_kernel(const float* __restrict__ W, int rows_k, int cols_co,
                                                             int ld, int transpose, int nks, int nct,
                                                             u32x4_t* __restrict__ out) {
-    pack_wt_split_item(W, rows_k, cols_co, ld, transpose, nks, nct, out, blockIdx.x * 256 + threadIdx.x);
+    pack_wt_split_tile(W, rows_k, cols_co, ld, transpose, nks, nct, out, blockIdx.x);
 }
 
-// all 1x1-conv weights of a model in ONE launch (33 pack launches per step otherwise): blockIdx.y = item,
-// descriptor = 8 x int64 {W, out, rows_k, cols_co, ld, transpose, -, -} in device memory (graph-replay safe)
-__global__ __launch_bounds__(256) void pack_wt_batch_kernel(const long long* __restrict__ desc, int split_on) {
+// all 1x1-conv weights of a model in ONE launch (33 pack launches per step otherwise): grid = (8, items),
+// descriptor = 8 x int64 {W, out, rows_k, cols_co, ld, transpose, -, -} in device memory (graph-replay safe).
+// Wide items (cp >= 128): block x = co tile; narrow items (plain fp32 [Kp][cp]): the 8 blocks stride over the elements.
+__global__ __launch_bounds__(256) void pack_wt_batch_kernel(const long long* __restrict__ desc) {
     const long long* d = desc + (size_t)blockIdx.y * 8;
     const float* W = (const float*)d[0];
     float* out = (float*)d[1];
     const int rows_k = (int)d[2], cols_co = (int)d[3], ld = (int)d[4], transpose = (int)d[5];
     const int cp = cols_co > 128 ? 256 : (cols_co > 64 ? 128 : (cols_co > 32 ? 64 : 32));
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (split_on && cp >= 128) {
-        const int nks = 2 * (((rows_k + PWS_KC - 1) / PWS_KC + 1) / 2 * 2);
-        pack_wt_split_item(W, rows_k, cols_co, ld, transpose, nks, cp / 32, (u32x4_t*)out, idx);
+    if (cp >= 128) {
+        if ((int)blockIdx.x < cp / 32)
+            pack_wt_split_tile(W, rows_k, cols_co, ld, transpose, pws_nks(rows_k), cp / 32, (u32x4_t*)out, blockIdx.x);
     } else {
         const int Kp = (rows_k + 31) / 32 * 32;
-        if (idx >= Kp * cp) return;
-        const int k = idx / cp, co = idx % cp;
-        float v = 0.f;
-        if (k < rows_k && co < cols_co) v = transpose ? W[(size_t)co * ld + k] : W[(size_t)k * ld + co];
-        out[idx] = v;
+        for (int idx = blockIdx.x * 256 + threadIdx.x; idx < Kp * cp; idx += gridDim.x * 256) {
+            const int k = idx / cp, co = idx % cp;
+            float v = 0.f;
+            if (k < rows_k && co < cols_co) v = transpose ? W[(size_t)co * ld + k] : W[(size_t)k * ld + co];
+            out[idx] = v;
+        }
     }
 }
-int pw_pack_batch(const long long* desc, int n_items, int max_threads, int split_on, hipStream_t stream) {
-    hipLaunchKernelGGL(pack_wt_batch_kernel, dim3((max_threads + 255) / 256, n_items), dim3(256), 0, stream, desc,
-                       split_on);
+int pw_pack_batch(const long long* desc, int n_items, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_wt_batch_kernel, dim3(8, n_items), dim3(256), 0, stream, desc);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
 
-// k-steps in the packed weights: chunk count padded to even (the DEPTH = 2 kernels compute chunk pairs)
-static int pws_nks(int rows_k) { return 2 * (((rows_k + PWS_KC - 1) / PWS_KC + 1) / 2 * 2); }
-
 size_t pw_split_wt_floats(int rows_k, int cp) {
     const int nks = pws_nks(rows_k), nct = cp / 32;
-    return (size_t)nks * nct * PWS_NSLOT * 64 * 4;   // 16 B = 4 floats per lane entry
+    return (size_t)nks * nct * PWS_NSLOT * 64 * 4 + cp;   // 16 B = 4 floats per lane entry; tail: 1 / fp16 scale per output channel
 }
 
 int pw_split_pack(const float* W, int rows_k, int cols_co, int ld, int transpose, float* out, hipStream_t stream) {
     const int cp = cols_co > 128 ? 256 : 128;
     const int nks = pws_nks(rows_k), nct = cp / 32;
-    hipLaunchKernelGGL(pack_wt_split_kernel, dim3((nks * nct * 64 + 255) / 256), dim3(256), 0, stream, W, rows_k,
-                       cols_co, ld, transpose, nks, nct, (u32x4_t*)out);
+    hipLaunchKernelGGL(pack_wt_split_kernel, dim3(nct), dim3(256), 0, stream, W, rows_k, cols_co, ld, transpose, nks, nct,
+                       (u32x4_t*)out);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -726,7 +774,7 @@ static void pws_launch_epi(const PwArgs& g, dim3 grid, int cp, hipStream_t strea
 #if PWS_PRO == 1 || PWS_PRO == 2
     // forward GEMMs behind a norm prologue, fp32 storage: the fp16 two-part split (three products instead of six)
     if constexpr ((EPI == 0 || EPI == 1) && sizeof(TA) == 4) {      // epi 0: the same GEMMs in eval mode behind a BatchNorm (running statistics)
-        if (g.h2) {
+        if (g.h2 && g.in_amax && g.in_amax_n > 0) {
             if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, PWS_H2_DEPTH_CT2, TA, true>), grid, dim3(256), 0, stream, g);
             else hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 2, TA, true>), grid, dim3(256), 0, stream, g);
             return;
@@ -750,7 +798,6 @@ int pw_split_blocks_per_frame(int N, int P) {
             hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
             ncu = 256;
         slots = 2 * ncu;
-        if (const char* ov = getenv("UNCR_PWS_SLOTS")) { const int m = atoi(ov); if (m > 0) slots = m * ncu; }   // experiment: blocks per CU
     }
     const int ntile = P / PWS_TP;
     int bpf = slots / N;

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import os
 import threading
+import weakref
 
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
@@ -209,6 +210,7 @@ class NormFwd:
     kind: int
     groups: int
     sync_count: float = 0.0     # > 0: BatchNorm statistics were all-reduced over the data-parallel group (global count)
+    ub: Optional[Tensor] = None  # [N*C] upper bounds on |A*h + B| per plane (range bookkeeping of the fp16 two-part GEMMs), or None
 
 
 _SYNC_BN = None      # process group for synchronised BatchNorm statistics (None: per-replica statistics, torch-DDP default)
@@ -230,7 +232,10 @@ def _all_reduce_sums(sums: Tensor) -> float:
 
 def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, training: bool, gamma: Tensor,
              beta: Tensor, running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None,
-             momentum: float = 0.1, eps: float = 1e-5) -> NormFwd:
+             momentum: float = 0.1, eps: float = 1e-5, bound_part: Optional[Part] = None) -> NormFwd:
+    """bound_part: (sum h, sum h^2) partials of the tensor this norm is applied to (in train mode `part` itself; in BatchNorm eval
+    mode they serve only this): the finalize kernel then also emits per-plane upper bounds on |A*h + B| (NormFwd.ub), with which
+    the consuming wide GEMM multiplies in two range-safe fp16 parts instead of the exact bf16 split (pw_gemm)."""
     kind = spec.code(training)
     groups = C if spec.kind == "instance" else spec.groups
     if gamma is None:                      # norm without affine parameters (InstanceNorm2d): gamma = 1, beta = 0
@@ -246,15 +251,25 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
         hb.call("uncr_bn_finalize_fwd_sums", sums, count, N, C, gamma, beta, running_mean, running_var, float(momentum),
                 float(eps), A, B, mean, rstd, _stream())
         return NormFwd(A, B, mean, rstd, kind, groups, sync_count=count)
+    ub = None
+    if bound_part is not None and _H2_FWD and (kind != NORM_GROUP or C // groups <= 256):
+        if part is None:
+            part = bound_part
+        if part is bound_part:
+            ub = _f32((N * C,), dev)
     hb.call("uncr_norm_finalize_fwd", part.buf if part else None, part.slots if part else 0, N, C, groups, P,
-            kind, gamma, beta, running_mean, running_var, float(momentum), float(eps), A, B, mean, rstd, _stream())
-    return NormFwd(A, B, mean, rstd, kind, groups)
+            kind, gamma, beta, running_mean, running_var, float(momentum), float(eps), A, B, mean, rstd, ub, _stream())
+    return NormFwd(A, B, mean, rstd, kind, groups, ub=ub)
 
 
 _CENTRED_NORMBWD = os.environ.get("UNCR_RAW_NORMBWD", "0") != "1"     # development A/B switch
 # fp16 two-part split in the dz GEMM of an MBConv backward, scaled per frame from the producers' magnitude bookkeeping
 # (UNCR_NO_H2_BWD=1: exact bf16 split there, no bookkeeping -- A/B runs)
 _H2_BWD = os.environ.get("UNCR_NO_H2_BWD", "0") != "1"
+# the same split in the forward GEMMs behind a norm (pw1 / pw2 of an MBConv), scaled per frame from the bounds the statistics
+# finalisation emits (UNCR_NO_H2_FWD=1: exact bf16 split -- A/B runs)
+_H2_FWD = os.environ.get("UNCR_NO_H2_FWD", "0") != "1"
+_DW_VARIANT = 0      # uncr_dw_fwd / uncr_dw_bwd `variant`: 0 = automatic, 1 = LDS-tiled kernels for every width (tests)
 
 
 @dataclass
@@ -364,14 +379,17 @@ def se_backward(dy: Tensor, sv: dict, W1: Tensor, W2: Tensor, need_dx: bool = Tr
 # weight: while it exists the allocator cannot hand the same address to another tensor, so a (pointer, version) match can
 # only be the tensor that was packed (a freed model's address re-used by a new model's weights would otherwise hit).
 _PACK_CACHE: Dict[tuple, tuple] = {}
-_PACK_PLANS: Dict[tuple, tuple] = {}     # plans of callers without an owner: key -> (descriptor, flat output, views, max_threads)
+_PACK_PLANS: Dict[tuple, tuple] = {}     # plans of callers without an owner: key -> (descriptor, flat output, views)
+# plans of a module (prepack(owner=...)): held here, keyed weakly by the module, NOT in the module's __dict__ -- copy.deepcopy(model)
+# and torch.save(model) would otherwise carry the device buffers and their raw weight pointers along
+_OWNER_PLANS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 
 def prepack(weights, owner=None) -> None:
     """weights: iterable of (W2d [R][Ccols] contiguous view of a parameter, transpose).  Packs all of them with one
     kernel launch into a per-plan static buffer and remembers the results for `pack_wt` until the next `prepack`
     (entries are ignored when the parameter's version counter has moved, i.e. after an in-place update).
-    owner: the module the weights belong to.  Its plans (train / eval pack lists) live in `owner._uncr_pack_plans` for as
+    owner: the module the weights belong to.  Its plans (train / eval pack lists) live in `_OWNER_PLANS[owner]` for as
     long as the module does and are never evicted: a captured HIP graph holds raw pointers into a plan's buffers, so a
     plan must not be freed while its model can still be replayed."""
     weights = [(w, bool(tr)) for w, tr in weights if w.is_contiguous()]
@@ -380,11 +398,11 @@ def prepack(weights, owner=None) -> None:
     key = tuple((w.data_ptr(), tr, w.shape[0], w.shape[1]) for w, tr in weights)
     plans = _PACK_PLANS
     if owner is not None:
-        plans = owner.__dict__.setdefault("_uncr_pack_plans", {})
+        plans = _OWNER_PLANS.setdefault(owner, {})
     plan = plans.get(key)
     if plan is None:
         dev = weights[0][0].device
-        sizes, thr, dims = [], [], []
+        sizes, dims = [], []
         for w, tr in weights:
             R, Cc = w.shape
             rows_k, cols_co = (Cc, R) if tr else (R, Cc)
@@ -393,7 +411,6 @@ def prepack(weights, owner=None) -> None:
                 raise NotImplementedError(f"1x1 convolution {rows_k} -> {cols_co}: the GEMM kernels are built for at most 256 "
                                           "input and 256 output channels")
             sizes.append((nf + 3) // 4 * 4)     # keep 16-B alignment
-            thr.append(hb.query("uncr_pack_wt_threads", rows_k, cols_co))
             dims.append((rows_k, cols_co, Cc))
         flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
         views, rows, off = [], [], 0
@@ -403,10 +420,10 @@ def prepack(weights, owner=None) -> None:
             rows.append([w.data_ptr(), v.data_ptr(), rows_k, cols_co, ld, 1 if tr else 0, 0, 0])
             off += n
         desc = torch.tensor(rows, dtype=torch.int64).to(dev)
-        plan = (desc, flat, views, max(thr))
+        plan = (desc, flat, views)
         plans[key] = plan
-    desc, _, views, max_threads = plan
-    hb.call("uncr_pack_wt_batch", desc, len(weights), max_threads, _stream())
+    desc, _, views = plan
+    hb.call("uncr_pack_wt_batch", desc, len(weights), _stream())
     _PACK_CACHE.clear()
     for (w, tr), v, k in zip(weights, views, key):
         _PACK_CACHE[k] = (v, w._version, w)
@@ -440,7 +457,9 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
     """out_dt: storage of the output (default: that of the input; the narrow Cout <= 64 kernels write fp32 only).
     want_amax (epi 1 / 2, 64 < Cout <= 128, fp32): the returned Part carries per-block maxima of |out| ([N][slots]).
     in_amax / in2_amax ([N][n] each): magnitude bounds of the two NORMBWD operands; with both, the epi-3 GEMM of an MBConv backward
-    multiplies in two scaled fp16 parts (three products) instead of the exact bf16 split (six)."""
+    multiplies in two scaled fp16 parts (three products) instead of the exact bf16 split (six).
+    in_amax alone with pro AFFINE / AFFINE_GELU (epi 0 / 1, Cout > 64, fp32): NormFwd.ub of the norm in the prologue ([N*Cin] bounds
+    on |A*h + B|): the forward GEMM takes the same two-part fp16 route, scaled per frame from the bound."""
     if out is None:
         out = _act((N, Cout, P), x.device, _dt(x) if out_dt is None else out_dt)
     part = None
@@ -453,12 +472,19 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
     if want_amax and part is not None and epi in (1, 2) and 64 < Cout <= 128 and _dt(x) == F32 and _dt(out) == F32 and _H2_BWD:
         amax = _f32((N, part.slots), x.device)
         part.amax = amax
-    use_in = in_amax is not None and in2_amax is not None and _H2_BWD
+    fp32_wide = Cout > 64 and _dt(x) == F32 and _dt(out) == F32
+    if pro == PRO_NORMBWD:
+        use_in = in_amax is not None and in2_amax is not None and _H2_BWD and epi == 3 and fp32_wide
+        n1, n2 = (in_amax.shape[1], in2_amax.shape[1]) if use_in else (0, 0)
+    else:
+        use_in = in_amax is not None and _H2_FWD and pro in (PRO_AFFINE, PRO_AFFINE_GELU) and epi in (0, 1) and fp32_wide
+        if use_in and in_amax.numel() != N * Cin:
+            raise RuntimeError("pw_gemm: in_amax of an affine prologue must hold one bound per (frame, input channel)")
+        n1, n2, in2_amax = (Cin if use_in else 0), 0, None
     hb.call("uncr_pw_gemm", x, x2, Wt, out, k[0], k[1], k[2], k[3] if len(k) > 3 else None, bias,
             Cout if bias_per_frame else 0, aux,
             ek[0], ek[1], ek[2], ek[3], part.buf if part else None, N, Cin, Cout, P, pro, epi, _dt(x), _dt(out),
-            amax, in_amax if use_in else None, in_amax.shape[1] if use_in else 0,
-            in2_amax if use_in else None, in2_amax.shape[1] if use_in else 0, _stream())
+            amax, in_amax if use_in else None, n1, in2_amax if use_in else None, n2, _stream())
     return out, part
 
 
@@ -521,17 +547,22 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
 
     if need and x_part is None:
         x_part = stats_sq(x, N * C, P)
-    n0 = norm_fwd(x_part if need else None, N, C, P, spec, training, p["n0w"], p["n0b"], *rm(0))
+    # range bookkeeping of the two wide forward GEMMs (fp32 storage): the (sum, sum^2) partials of their inputs bound the
+    # inputs' magnitude; where a producer left none (eval-mode BatchNorm behind a foreign tensor) the GEMM takes the exact split
+    h2ok = dt == F32 and _H2_FWD and Ch > 64 and C > 64
+    n0 = norm_fwd(x_part if need else None, N, C, P, spec, training, p["n0w"], p["n0b"], *rm(0),
+                  bound_part=x_part if h2ok else None)
     W1t = pack_wt(p["w1"].reshape(Ch, C), transpose=True)
-    h1, part1 = pw_gemm(x, W1t, N, C, Ch, P, pro=PRO_AFFINE, k=(n0.A, n0.B, None), epi=1 if need else 0)
+    h1, part1 = pw_gemm(x, W1t, N, C, Ch, P, pro=PRO_AFFINE, k=(n0.A, n0.B, None), epi=1 if need else 0, in_amax=n0.ub)
     n1 = norm_fwd(part1, N, Ch, P, spec, training, p["n1w"], p["n1b"], *rm(1))
 
     h2 = _act((N, Ch, H, W), x.device, dt)
     slots = hb.query("uncr_dw_slots_fwd", H)
-    part2 = Part(_f32((N * Ch, slots, 2), x.device), slots) if need else None
-    hb.call("uncr_dw_fwd", h1, n1.A, n1.B, p["wdw"].reshape(Ch, 9).contiguous(), h2, part2.buf if need else None, N, Ch,
-            H, W, dt, _stream())
-    n2 = norm_fwd(part2, N, Ch, P, spec, training, p["n2w"], p["n2b"], *rm(2))
+    part2 = Part(_f32((N * Ch, slots, 2), x.device), slots) if (need or h2ok) else None
+    hb.call("uncr_dw_fwd", h1, n1.A, n1.B, p["wdw"].reshape(Ch, 9).contiguous(), h2, part2.buf if part2 is not None else None,
+            N, Ch, H, W, dt, _DW_VARIANT, _stream())
+    n2 = norm_fwd(part2 if need else None, N, Ch, P, spec, training, p["n2w"], p["n2b"], *rm(2),
+                  bound_part=part2 if h2ok else None)
 
     _, ppool = ew(EW_SE_POOL, h2, k=(n2.A, n2.B, None, None), want_part=True, planes=N * Ch, P=P)
     pooled, hid_pre, s = _f32((N, Ch), x.device), _f32((N, R), x.device), _f32((N * Ch,), x.device)
@@ -539,7 +570,8 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
             pooled, hid_pre, s, _stream())
 
     W2t = pack_wt(p["w2"].reshape(C, Ch), transpose=True)
-    h3, part3 = pw_gemm(h2, W2t, N, Ch, C, P, pro=PRO_AFFINE_GELU, k=(n2.A, n2.B, s), epi=1 if need else 0, want_amax=True)
+    h3, part3 = pw_gemm(h2, W2t, N, Ch, C, P, pro=PRO_AFFINE_GELU, k=(n2.A, n2.B, s), epi=1 if need else 0, want_amax=True,
+                        in_amax=n2.ub)
     n3 = norm_fwd(part3, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))
 
     y = _act((N, C, H, W), x.device, dt)
@@ -565,6 +597,7 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
 
 
 _FUSED_DX = os.environ.get("UNCR_NO_FUSED_DX", "0") != "1"     # A/B switch (development, tests)
+
 _CONST_PLANES: Dict[tuple, Tuple[Tensor, Tensor]] = {}
 
 
@@ -629,7 +662,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     # statistics for the norm-1 backward in centred form (sum du1*(h1 - mean1)): h1 is the raw pw1 output, whose
     # channel means can be many standard deviations from zero
     hb.call("uncr_dw_bwd", du2, h2, h1, b2.c1, b2.c2, b2.c3, b2.mu, n1.A, n1.B, wdw, du1, part1.buf, dw_part, n1.mean,
-            n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, H, W, dt, _stream())
+            n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, H, W, dt, _DW_VARIANT, _stream())
     dwdw = _f32((Ch, 9), dev)
     with side_chain(dw_part):          # feeds a parameter gradient only: next to the pw1 weight-gradient GEMM
         hb.call("uncr_dw_wgrad_reduce", dw_part, N, Ch, slots, dwdw, _stream())

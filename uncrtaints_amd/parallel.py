@@ -88,7 +88,13 @@ class BucketedDataParallel:
         stream).  For training loops that drive the backward pass in bucket-sized segments themselves -- e.g. one captured
         HIP graph per segment, where autograd hooks do not run on replay: segment k's gradients travel over xGMI while segment
         k+1 computes.  `finish()` then only waits."""
+        if self.overlap:
+            # with overlap=True the post-accumulate hooks launch the same all-reduce on every eager step (warm-up, capture): a
+            # second one here would sum the bucket twice (SUM + divide) and drop the first handle without a wait
+            raise RuntimeError("reduce_bucket() drives the all-reduces by hand: construct BucketedDataParallel(overlap=False)")
         b = self.buckets[bi]
+        if b["handle"] is not None:
+            raise RuntimeError(f"bucket {bi} already has an all-reduce in flight (reduce_bucket called twice before finish())")
         op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
         b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
         b["ready"] = b["n"]

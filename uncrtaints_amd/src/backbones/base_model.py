@@ -65,15 +65,16 @@ class BaseModel(nn.Module):
     def optimize_parameters(self):
         self.forward()
         self.real_A = None
-        # set_to_none=False: under BucketedDataParallel the gradients are views into the flat all-reduce buckets; setting
-        # them to None would detach them (the next backward would allocate fresh tensors and the buckets would be reduced
-        # as stale zeros).  `self.data_parallel` (a BucketedDataParallel, optional) also resets its bucket bookkeeping and
-        # is waited on before the optimizer step.
+        # Under BucketedDataParallel (`self.data_parallel`, optional) the gradients are views into the flat all-reduce buckets:
+        # they are zeroed in place (setting them to None would detach them and the buckets would be reduced as stale zeros), and
+        # the all-reduces are waited on before the optimizer step.  On a single GPU: the reference's plain zero_grad()
+        # (base_model.py:117, set_to_none=True), so that a parameter without a gradient in a step is skipped by Adam, not
+        # updated from its running moments.
         dp = getattr(self, "data_parallel", None)
         if dp is not None:
             dp.zero_grad()
         else:
-            self.optimizer_G.zero_grad(set_to_none=False)
+            self.optimizer_G.zero_grad()
         self.backward_G()
         if dp is not None:
             dp.finish()

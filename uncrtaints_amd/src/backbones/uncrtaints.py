@@ -38,7 +38,14 @@ class _NormFn(torch.autograd.Function):
         kind = "batch" if isinstance(module, nn.BatchNorm2d) else ("instance" if isinstance(module, nn.InstanceNorm2d) else "group")
         spec = E.NormSpec(kind, module.num_groups if kind == "group" else 4)
         rm, rv = (module.running_mean, module.running_var) if kind == "batch" else (None, None)
-        mom = module.momentum if kind == "batch" and module.momentum is not None else 0.1
+        mom = 0.1
+        if kind == "batch":
+            # momentum=None: cumulative moving average, factor 1 / num_batches_tracked counted INCLUDING this batch (torch
+            # increments the counter before it computes the factor); apply_norm has incremented it already
+            if module.momentum is not None:
+                mom = module.momentum
+            elif module.training and module.num_batches_tracked is not None:
+                mom = 1.0 / max(float(module.num_batches_tracked.item()), 1.0)
         out, sv = E.norm_apply_forward(x, spec, module.training, gamma, beta, rm, rv, mom, module.eps)
         ctx.sv, ctx.gamma = sv, gamma
         return out
@@ -51,10 +58,9 @@ class _NormFn(torch.autograd.Function):
 
 def apply_norm(module, x):
     """`module(x)` for nn.GroupNorm / nn.BatchNorm2d / nn.InstanceNorm2d holders on the HIP path (x [N,C,H,W])."""
-    y = _NormFn.apply(x, module, getattr(module, "weight", None), getattr(module, "bias", None))
     if isinstance(module, nn.BatchNorm2d) and module.training and module.num_batches_tracked is not None:
         module.num_batches_tracked += 1
-    return y
+    return _NormFn.apply(x, module, getattr(module, "weight", None), getattr(module, "bias", None))
 
 
 class PreNorm(nn.Module):
@@ -330,7 +336,9 @@ class _StageFn(torch.autograd.Function):
         ctx.bt = (b, t)
         te, agg = net.temporal_encoder, net.temporal_aggregator
         denom = te.positional_encoder.denom_on(e.device) if te.positional_encoder is not None else None
-        want_stats = net.out_block[0]._spec.needs_stats(net.training)
+        # (sum, sum^2) partials of the aggregated features: the first decoder block's norm statistics in train mode; in eval mode
+        # (running statistics) they still bound the tensor's magnitude for that block's fp16 two-part GEMM (engine.mbconv_forward)
+        want_stats = net.out_block[0]._spec.needs_stats(net.training) or (net.block_type == 'mbconv' and e4.dtype == torch.float32)
         net._last_pad = pad
         values = None
         ctx.use_v = getattr(net, "use_v", False)
@@ -451,8 +459,9 @@ class UNCRTAINTS(nn.Module):
             raise NotImplementedError("use_v is built for agg_mode='att_group' on image time series")
         if agg_mode not in ("att_group", "att_mean", "mean"):
             raise NotImplementedError(f"agg_mode '{agg_mode}'")
-        if padding_mode != "reflect":
-            raise NotImplementedError("only padding_mode='reflect' is built")
+        # padding_mode is stored and never used by the reference's UNCRTAINTS either (uncrtaints.py:299 is its only use: MBConv
+        # hard-codes 'reflect' at :115/:130, ResidualConvBlock is built with its default 'reflect' at :319/:353, in_conv / out_conv
+        # are 1x1 without padding) -- any value is accepted and the convolutions pad by reflection, exactly like the reference
         if any(w != encoder_widths[0] for w in encoder_widths):
             # the reference builds MBConv(w, w) per entry behind an in_conv of width encoder_widths[0] (uncrtaints.py:309-319): its
             # forward only type-checks when all entries are equal
