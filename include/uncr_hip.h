@@ -93,7 +93,9 @@ int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, 
 int uncr_bn_channel_sums(const float* part, int NP, int N, int C, double* sums, hipStream_t stream);
 int uncr_bn_finalize_fwd_sums(const double* sums, double count, int N, int C, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* coefA,
-                              float* coefB, float* save_mean, float* save_rstd, hipStream_t stream);
+                              float* coefB, float* save_mean, float* save_rstd,
+                              const float* part, int NP, float* ub /* nullable: as in uncr_norm_finalize_fwd, from the LOCAL partials */,
+                              hipStream_t stream);
 int uncr_bn_finalize_bwd_sums(const double* sums_local, const double* sums_global, double count, int N, int C,
                               const float* gamma, const float* save_mean, const float* save_rstd, float* c1, float* c2,
                               float* c3, float* cmu, float* dgamma, float* dbeta, int centered, hipStream_t stream);
@@ -284,6 +286,13 @@ int uncr_aggregate_bwd(const void* dg, const void* e, const float* att, const in
                        unsigned long long seed, const long long* seed_dev, float p_drop, int shared_mask,
                        void* de, float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int AH,
                        int AW, int act /* storage of dg, e and de */, hipStream_t stream);
+/* the aggregator's AvgPool branch (uncrtaints.py:197-204: feature map not larger than the attention map): the attention is
+ * average-pooled with kernel = stride = k (= AW / H in the reference) to the feature map's size, no dropout; fp32.
+ * Requires AH / k == H and AW / k == W.  datt [NH][B][T][AH][AW] (cells the pooling never reads get 0). */
+int uncr_aggregate_pool_fwd(const float* e, const float* att, const int* pad, float* out, int B, int T, int C, int NH,
+                            int H, int W, int AH, int AW, int k, hipStream_t stream);
+int uncr_aggregate_pool_bwd(const float* dg, const float* e, const float* att, const int* pad, float* de, float* datt,
+                            int B, int T, int C, int NH, int H, int W, int AH, int AW, int k, hipStream_t stream);
 
 /* ---- dense 3x3 reflect convolution of ResidualConvBlock (uncrtaints.py:24-69, utae.py:478-487) as nine accumulating
  *      pointwise GEMMs on the padded grid (uncr_pw_gemm epi 4 with the input pointer shifted by dy*(W+2)+dx).  Glue:
@@ -307,6 +316,23 @@ int uncr_bilinear_adjoint(const float* src, float* dst, int planes, int H, int W
 int uncr_add(const float* a, const float* b, float* out, long long n, hipStream_t stream);
 int uncr_dropout(const float* a, float* out, long long n, unsigned long long seed, const long long* seed_dev, float p,
                  hipStream_t stream);
+
+/* ---- the attention classes called on their own (ltae.py:388-458 ScaledDotProductAttention[Small], :244-307 / :312-385
+ *      MultiHeadAttention[Small]): pixel-major rows q [q_rows][dk] (q_rows == m, or one query shared by each group of m / q_rows
+ *      consecutive rows), k [m][T][dk], v [m][T][dv], pad [m][T] (non-zero = masked_fill(-1e3)); T <= 64.
+ *      attn_sm = softmax_t(q.k / temperature) (saved for the backward), attn_out = the same after dropout p_drop (counter-based
+ *      stream of (seed, seed_dev), nullable), out = attn_out @ v (nullable), comp = the masked, scaled scores (nullable).
+ *      Backward: any of dattn / dout / dcomp may be null; dq_rows [m][dk] is per row (shared queries: sum the groups). ---- */
+int uncr_sdpa_rows_fwd(const float* q, int q_rows, const float* k, const float* v, const int* pad, float temperature,
+                       float* attn_sm, float* attn_out, float* out, float* comp, int m, int T, int dk, int dv, float p_drop,
+                       unsigned long long seed, const long long* seed_dev, hipStream_t stream);
+int uncr_sdpa_rows_bwd(const float* dattn, const float* dout, const float* dcomp, const float* q, int q_rows, const float* k,
+                       const float* v, const int* pad, const float* attn_sm, float temperature, float* dq_rows, float* dk_out,
+                       float* dv_out, int m, int T, int dk, int dv, float p_drop, unsigned long long seed,
+                       const long long* seed_dev, hipStream_t stream);
+/* dst [cols][dst_ld] = src [rows][cols] transposed, columns >= rows zero-filled: pixel-major rows <-> the channel-major planes of
+ * uncr_pw_gemm (nn.Linear on rows = a 1x1 convolution on the transposed tensor, dst_ld = rows padded to the GEMM's pixel tile) */
+int uncr_transpose2d(const float* src, float* dst, int rows, int cols, int dst_ld, hipStream_t stream);
 
 /* ---- input assembly in front of the path: prepare_data_multi (model/train_reconstruct.py:161-179) stacks the
  *      per-date S1 [B,2,H,W] / S2 [B,13,H,W] tensors into x [B,T,C,H,W] (S1 channels first); with kind != 0 the

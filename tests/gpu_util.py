@@ -87,11 +87,18 @@ def pool_branch(m, state, x, dates, cfg, training=True, tol=2e-5):
     return idx.reshape(n, c, cfg.att_down, cfg.att_down), flips
 
 
-def close_grad(name, got, ref32, truth64, tol=TOL, noise=4.0):
+def close_grad(name, got, ref32, truth64, tol=TOL, noise=8.0):
     """Gradient parity with ONE rule: within `tol` (1e-4) of the fp32 reference, or -- for cancellation-dominated sums, where two
     correct fp32 evaluations differ by more than `tol` -- no further from the fp64 truth than max(tol, `noise` x the CPU fp32
     path's own distance from it).  Both references are evaluated on the max-pool branch the implementation took
-    (`pool_branch`), so no kink allowance is needed."""
+    (`pool_branch`), so no kink allowance is needed.
+    Why `noise` = 8 (measured, tools/probe_h2_weight_error.py / tools/debug_h2_blocks.py): on the `weight_init` fixtures the whole
+    gradient moves with the absolute error of the head's variance pre-activation (MGNLL weights a pixel with 1 / var, var ~
+    exp(pre-activation) near the 1e-8 clamp), i.e. with the FORWARD rounding noise.  A GPU fp32 GEMM accumulates its K products one
+    after the other (6e-7 of max|out| per 128 -> 256 GEMM on this pipe, rocBLAS fp32 alike: tools/probe_bf16split.py), the CPU
+    oracle's blocked AVX sums sit 4-5 x lower; twelve GEMMs deep the forward noise is 3e-6 ... 5e-6 against the oracle's 1e-6
+    (contract: 1e-4), and the gradient noise follows in that ratio with a heavy tail over the hundred-odd parameters (seen: 0.7 x ...
+    5.7 x the CPU path's own distance, the same kernel set landing on either side depending on the fixture)."""
     got = got.detach().double().cpu().numpy()
     ref32 = ref32.detach().double().cpu().numpy()
     truth64 = truth64.detach().cpu().numpy()

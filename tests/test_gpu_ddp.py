@@ -125,6 +125,10 @@ def test_two_ranks_with_sync_bn_equal_one_process_on_the_concatenated_batch():
         if not n.startswith("buf/"):
             assert torch.equal(res[0][n], res[1][n]), n
         scale = ref[n].abs().max().item()
+        if n.startswith("buf/") and n.endswith("running_mean"):
+            # a channel mean is measured against the channel's spread: behind a bias-free convolution of a zero-mean input it is
+            # zero up to rounding, and so is its momentum-weighted share of the buffer
+            scale = max(scale, 0.1 * ref[n.replace("running_mean", "running_var")].abs().max().sqrt().item())
         if scale == 0:
             continue
         worst = max(worst, (res[0][n] - ref[n]).abs().max().item() / scale)

@@ -1,0 +1,181 @@
+"""-m gpu: the attention classes of model/src/backbones/ltae.py called ON THEIR OWN (pixel-major rows [B*H*W, T, d], the layout the
+reference defines them on): ScaledDotProductAttentionSmall (ltae.py:431-458), ScaledDotProductAttention (:399-416),
+MultiHeadAttentionSmall (:341-385), MultiHeadAttention (:266-307), LTAE2d (:84-141) and the d_model=None variants (:49-54, :177-182).
+Checked against the same arithmetic in fp32 torch on the CPU (forward and every gradient)."""
+import math
+
+import pytest
+import torch
+
+from gpu_util import DEV, close, dev, rand
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import uncrtaints_oracle
+    return uncrtaints_oracle
+
+
+def _sdpa_ref(q, k, v, pad, temperature):
+    """score = q.k / temperature, masked_fill(pad, -1e3), softmax over T, attn @ v  (ltae.py:432-452)"""
+    score = torch.einsum("md,mtd->mt", q, k) / temperature
+    comp = score.masked_fill(pad, -1e3) if pad is not None else score
+    attn = torch.softmax(comp, dim=1)
+    out = torch.einsum("mt,mtd->md", attn, v) if v is not None else None
+    return attn, out, comp
+
+
+@pytest.mark.parametrize("T,dk,dv,padded", [(3, 4, 16, False), (6, 4, 16, True), (12, 8, 8, True), (1, 4, 4, False)])
+def test_scaled_dot_product_attention_small_rows(T, dk, dv, padded):
+    from uncrtaints_amd.src.backbones.ltae import ScaledDotProductAttentionSmall
+    m = 700                                                  # not a multiple of the block size
+    q, k, v = rand(m, dk, seed=1), rand(m, T, dk, seed=2), rand(m, T, dv, seed=3)
+    pad = None
+    if padded:
+        pad = torch.rand(m, T, generator=torch.Generator().manual_seed(4)) < 0.3
+        pad[:, 0] = False
+    ga, go, gc = rand(m, 1, T, seed=5), rand(m, 1, dv, seed=6), rand(m, 1, T, seed=7)
+    temp = math.sqrt(dk)
+    qo, ko, vo = (t.clone().requires_grad_(True) for t in (q, k, v))
+    a_ref, o_ref, c_ref = _sdpa_ref(qo, ko, vo, pad, temp)
+    ((a_ref * ga[:, 0]).sum() + (o_ref * go[:, 0]).sum() + (c_ref * gc[:, 0]).sum()).backward()
+    mod = ScaledDotProductAttentionSmall(temperature=temp)
+    qd, kd, vd = (dev(t).requires_grad_(True) for t in (q, k, v))
+    out, attn, comp = mod(qd, kd, vd, pad_mask=dev(pad) if pad is not None else None, return_comp=True, weight_v=True)
+    assert attn.shape == (m, 1, T) and out.shape == (m, 1, dv) and comp.shape == (m, 1, T)
+    close("sdpa_attn", attn[:, 0], a_ref)
+    close("sdpa_out", out[:, 0], o_ref)
+    close("sdpa_comp", comp[:, 0], c_ref)
+    ((attn * dev(ga)).sum() + (out * dev(go)).sum() + (comp * dev(gc)).sum()).backward()
+    close("sdpa_dq", qd.grad, qo.grad)
+    close("sdpa_dk", kd.grad, ko.grad)
+    close("sdpa_dv", vd.grad, vo.grad)
+    # attention only (weight_v=False): one tensor, like the reference
+    only = mod(dev(q), dev(k), dev(v), pad_mask=dev(pad) if pad is not None else None)
+    assert torch.is_tensor(only) and torch.equal(only, attn.detach())
+
+
+@pytest.mark.parametrize("cls_name,weight_v", [("MultiHeadAttentionSmall", False), ("MultiHeadAttentionSmall", True),
+                                               ("MultiHeadAttention", True)])
+def test_multi_head_attention_rows(cls_name, weight_v):
+    from uncrtaints_amd.src.backbones import ltae
+    torch.manual_seed(0)
+    nh, dk, d_in, n, T = 16, 4, 256, 300, 3
+    mod = getattr(ltae, cls_name)(n_head=nh, d_k=dk, d_in=d_in) if cls_name.endswith("Small") \
+        else ltae.MultiHeadAttention(n_head=nh, d_k=dk, d_in=d_in, use_dropout=False)
+    with torch.no_grad():
+        mod.fc1_k.bias.copy_(0.3 * torch.randn(nh * dk))
+    v = rand(n, T, d_in, seed=1)
+    pad = torch.zeros(n, T, dtype=torch.bool)
+    pad[::3, T - 1] = True
+    # reference arithmetic (ltae.py:341-385): keys per head = slices of the projected values, one learned query per head
+    W, b, Q = (t.detach().clone().requires_grad_(True) for t in (mod.fc1_k.weight, mod.fc1_k.bias, mod.Q))
+    vo = v.clone().requires_grad_(True)
+    k = (vo @ W.t() + b).view(n, T, nh, dk)
+    score = torch.einsum("hd,nthd->hnt", Q, k) / math.sqrt(dk)
+    attn_ref = torch.softmax(score.masked_fill(pad[None], -1e3), dim=2)                  # [nh, n, T]
+    out_ref = torch.einsum("hnt,nthd->hnd", attn_ref, vo.view(n, T, nh, d_in // nh))     # [nh, n, d_in / nh]
+    ga, go = rand(nh, n, T, seed=2), rand(nh, n, d_in // nh, seed=3)
+    ((attn_ref * ga).sum() + ((out_ref * go).sum() if weight_v else 0.0)).backward()
+    md = mod.to(DEV).eval()
+    vd = dev(v).requires_grad_(True)
+    if cls_name.endswith("Small"):
+        res = md(vd, pad_mask=dev(pad), weight_v=weight_v)
+    else:
+        res = md(vd, pad_mask=dev(pad))
+    if weight_v:
+        out, attn = res
+        close("mha_out", out, out_ref)
+    else:
+        attn, out = res, None
+    assert attn.shape == (nh, n, T)
+    close("mha_attn", attn, attn_ref)
+    ((attn * dev(ga)).sum() + ((out * dev(go)).sum() if weight_v else 0.0)).backward()
+    close("mha_dv", vd.grad, vo.grad, tol=2e-4)
+    close("mha_dW", md.fc1_k.weight.grad, W.grad, tol=2e-4)
+    close("mha_db", md.fc1_k.bias.grad, b.grad, tol=2e-4)
+    close("mha_dQ", md.Q.grad, Q.grad, tol=2e-4)
+
+
+def test_attention_dropout_stream_of_the_standalone_classes():
+    """ScaledDotProductAttention in train mode: this library's counter-based dropout (statistics, scaling, consistency between the
+    returned attention and the weighted values; the backward uses the same mask)."""
+    from uncrtaints_amd.src.backbones.ltae import ScaledDotProductAttention
+    m, T, dk, dv = 4096, 4, 4, 8
+    mod = ScaledDotProductAttention(temperature=2.0, attn_dropout=0.25).train()
+    q, k, v = dev(rand(m, dk, seed=1)), dev(rand(m, T, dk, seed=2)), dev(rand(m, T, dv, seed=3)).requires_grad_(True)
+    out, attn = mod(q, k, v)
+    a_ref, _, _ = _sdpa_ref(q.cpu(), k.cpu(), None, None, 2.0)
+    kept = attn[:, 0].cpu() != 0
+    frac = 1.0 - kept.float().mean().item()
+    assert abs(frac - 0.25) < 0.02, frac
+    close("dropout_scaled", attn[:, 0].cpu()[kept], (a_ref / 0.75)[kept])
+    close("dropout_out", out[:, 0], torch.einsum("mt,mtd->md", attn[:, 0], v.detach()))
+    out.sum().backward()
+    close("dropout_dv", v.grad, attn[:, 0].detach()[:, :, None].expand(m, T, dv))
+    mod.eval()
+    out_e, attn_e = mod(q, k, v.detach())
+    close("eval_attn", attn_e[:, 0], a_ref)
+
+
+@pytest.mark.parametrize("d_model,training", [(256, False), (256, True), (None, False)])
+def test_ltae2d_standalone(orc, d_model, training):
+    """LTAE2d called on its own ([B,T,C,h,w] -> values [B,C,h,w] + attention), and without the input projection (d_model=None)."""
+    from uncrtaints_amd.src.backbones.ltae import LTAE2d
+    from uncrtaints_amd.src.learning.weight_init import weight_init
+    torch.manual_seed(2)
+    C, nh, dk, B, T = 128, 16, 4, 2, 3
+    dm = d_model if d_model is not None else C
+    m = LTAE2d(in_channels=C, n_head=nh, d_k=dk, mlp=[dm, C], dropout=0.0, d_model=d_model, return_att=True, use_dropout=False)
+    m.apply(weight_init)
+    with torch.no_grad():
+        m.in_norm.weight.copy_(1.0 + 0.3 * torch.randn(C)); m.in_norm.bias.copy_(0.2 * torch.randn(C))
+        m.out_norm.weight.copy_(1.0 + 0.3 * torch.randn(C)); m.out_norm.bias.copy_(0.2 * torch.randn(C))
+        m.mlp[1].running_mean.copy_(0.1 * torch.randn(C)); m.mlp[1].running_var.copy_(0.5 + torch.rand(C))
+    m.train(training)
+    down = rand(B, T, C, 32, 32, seed=3)
+    dates = torch.sort(torch.randint(1400, 1800, (B, T)), dim=1).values.float()
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[1, T - 1] = True
+    gv, ga = rand(B, C, 32, 32, seed=4), rand(nh, B, T, 32, 32, seed=5)
+    cfg = orc.OracleConfig(n_head=nh, d_k=dk, d_model=dm, ltae_dropout=0.0)
+    p = {"temporal_encoder." + k: (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k
+                                    else v.detach().clone()) for k, v in m.state_dict().items()}
+    if d_model is None:      # no projection: the oracle takes the identity
+        p["temporal_encoder.inconv.weight"] = torch.eye(C).view(C, C, 1)
+        p["temporal_encoder.inconv.bias"] = torch.zeros(C)
+    do = down.clone().requires_grad_(True)
+    v_ref, a_ref = orc.ltae2d_values_attention(do, dates, pad, p, cfg, training)
+    ((v_ref * gv).sum() + (a_ref * ga).sum()).backward()
+    md = m.to(DEV)
+    dd = dev(down).requires_grad_(True)
+    v, a = md(dd, batch_positions=dev(dates), pad_mask=dev(pad))
+    close(f"ltae2d_values[d_model={d_model},train={training}]", v, v_ref)
+    close("ltae2d_attn", a, a_ref)
+    ((v * dev(gv)).sum() + (a * dev(ga)).sum()).backward()
+    close("ltae2d_ddown", dd.grad, do.grad, tol=2e-4)
+    for k, par in md.named_parameters():
+        ref = p["temporal_encoder." + k].grad
+        if ref is None or ref.abs().max() < 1e-6 * max(1.0, float(par.grad.abs().max())):
+            continue
+        close(f"ltae2d_grad[{k}]", par.grad, ref, tol=3e-4)
+    if training:
+        close("ltae2d_running_mean", md.mlp[1].running_mean, p["temporal_encoder.mlp.1.running_mean"])
+
+
+def test_ltae2dtiny_without_projection(orc):
+    from uncrtaints_amd.src.backbones.ltae import LTAE2dtiny
+    torch.manual_seed(4)
+    C, nh, dk, B, T = 128, 16, 4, 2, 3
+    m = LTAE2dtiny(in_channels=C, n_head=nh, d_k=dk, d_model=None)
+    down = rand(B, T, C, 32, 32, seed=3)
+    dates = torch.sort(torch.randint(1400, 1800, (B, T)), dim=1).values.float()
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    cfg = orc.OracleConfig(n_head=nh, d_k=dk, d_model=C)
+    p = {"temporal_encoder." + k: v.detach().clone() for k, v in m.state_dict().items()}
+    p["temporal_encoder.inconv.weight"], p["temporal_encoder.inconv.bias"] = torch.eye(C).view(C, C, 1), torch.zeros(C)
+    a_ref = orc.ltae_tiny_attention(down, dates, pad, p, cfg)
+    a = m.to(DEV)(dev(down), batch_positions=dev(dates), pad_mask=dev(pad))
+    close("ltae_tiny_no_projection", a, a_ref)

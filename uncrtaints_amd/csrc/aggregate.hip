@@ -281,6 +281,99 @@ extern "C" int uncr_aggregate_bwd(const void* dg, const void* e, const float* at
 }
 
 
+// ---- the aggregator's AvgPool branch (uncrtaints.py:197-204): feature maps NOT larger than the attention map.  The attention is
+// average-pooled with kernel = stride = k = AW / H (nn.AvgPool2d(kernel_size=w // x.shape[-2])) down to the feature map's size and
+// no dropout is applied.  Planes here are smaller than the 1024-pixel tiles of the streaming kernels above (at most 32 x 32), so
+// these are plain one-thread-per-element kernels: the whole problem is a few hundred KB.
+//   fwd : out[b,c,p] = sum_t pool(att)[c/CH,b,t,p] * [not pad] * e[b,t,c,p]
+//   bwd : de[b,t,c,p] = pool(att) * [not pad] * dg[b,c,p];   datt[h,b,t,ay,ax] = [not pad] / k^2 * sum_{c in h} dg[b,c,p] e[b,t,c,p]
+//         with p = (ay / k, ax / k) for ay < k*H, ax < k*W, else 0 (cells the pooling never reads)
+__device__ __forceinline__ float agg_pool_att(const float* __restrict__ att, int AW, int k, int y, int x) {
+    float s = 0.f;
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) s += att[(y * k + i) * AW + x * k + j];
+    return s / (float)(k * k);
+}
+__global__ __launch_bounds__(256) void aggregate_pool_fwd_kernel(const float* __restrict__ e, const float* __restrict__ att,
+                                                                 const int* __restrict__ pad, float* __restrict__ out, int B,
+                                                                 int T, int C, int NH, int H, int W, int AH, int AW, int k) {
+    const int P = H * W;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * C * P) return;
+    const int p = (int)(i % P), c = (int)((i / P) % C), b = (int)(i / ((long long)P * C));
+    const int h = c / (C / NH), y = p / W, x = p % W;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+        if (pad && pad[b * T + t]) continue;
+        const float a = agg_pool_att(att + (((size_t)h * B + b) * T + t) * AH * AW, AW, k, y, x);
+        acc = fmaf(a, e[(((size_t)b * T + t) * C + c) * P + p], acc);
+    }
+    out[i] = acc;
+}
+__global__ __launch_bounds__(256) void aggregate_pool_bwd_e_kernel(const float* __restrict__ dg, const float* __restrict__ att,
+                                                                   const int* __restrict__ pad, float* __restrict__ de, int B,
+                                                                   int T, int C, int NH, int H, int W, int AH, int AW, int k) {
+    const int P = H * W;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * T * C * P) return;
+    const int p = (int)(i % P), c = (int)((i / P) % C), t = (int)((i / ((long long)P * C)) % T), b = (int)(i / ((long long)P * C * T));
+    const int h = c / (C / NH);
+    float a = 0.f;
+    if (!(pad && pad[b * T + t])) a = agg_pool_att(att + (((size_t)h * B + b) * T + t) * AH * AW, AW, k, p / W, p % W);
+    de[i] = a * dg[((size_t)b * C + c) * P + p];
+}
+__global__ __launch_bounds__(256) void aggregate_pool_bwd_att_kernel(const float* __restrict__ dg, const float* __restrict__ e,
+                                                                     const int* __restrict__ pad, float* __restrict__ datt,
+                                                                     int B, int T, int C, int NH, int H, int W, int AH, int AW,
+                                                                     int k) {
+    const int P = H * W, S = AH * AW, CH = C / NH;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)NH * B * T * S) return;
+    const int a = (int)(i % S), t = (int)((i / S) % T), b = (int)((i / ((long long)S * T)) % B), h = (int)(i / ((long long)S * T * B));
+    const int ay = a / AW, ax = a % AW;
+    float s = 0.f;
+    if (ay < k * H && ax < k * W && !(pad && pad[b * T + t])) {
+        const int p = (ay / k) * W + ax / k;
+        for (int j = 0; j < CH; ++j) {
+            const int c = h * CH + j;
+            s = fmaf(dg[((size_t)b * C + c) * P + p], e[(((size_t)b * T + t) * C + c) * P + p], s);
+        }
+        s /= (float)(k * k);
+    }
+    datt[i] = s;
+}
+static int agg_pool_check(int B, int T, int C, int NH, int H, int W, int AH, int AW, int k) {
+    if (B <= 0 || T <= 0 || NH <= 0 || C % NH || H <= 0 || W <= 0 || k <= 0) return UNCR_ESHAPE;
+    if (AH / k != H || AW / k != W) return UNCR_ESHAPE;       // the pooled attention must have the feature map's size
+    return UNCR_OK;
+}
+extern "C" int uncr_aggregate_pool_fwd(const float* e, const float* att, const int* pad, float* out, int B, int T, int C,
+                                       int NH, int H, int W, int AH, int AW, int k, hipStream_t stream) {
+    const int rc = agg_pool_check(B, T, C, NH, H, W, AH, AW, k);
+    if (rc) return rc;
+    if (!e || !att || !out) return UNCR_EINVAL;
+    const long long n = (long long)B * C * H * W;
+    hipLaunchKernelGGL(aggregate_pool_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, e, att, pad, out, B, T, C,
+                       NH, H, W, AH, AW, k);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+extern "C" int uncr_aggregate_pool_bwd(const float* dg, const float* e, const float* att, const int* pad, float* de,
+                                       float* datt, int B, int T, int C, int NH, int H, int W, int AH, int AW, int k,
+                                       hipStream_t stream) {
+    const int rc = agg_pool_check(B, T, C, NH, H, W, AH, AW, k);
+    if (rc) return rc;
+    if (!dg || !e || !att || !de || !datt) return UNCR_EINVAL;
+    const long long n = (long long)B * T * C * H * W, na = (long long)NH * B * T * AH * AW;
+    hipLaunchKernelGGL(aggregate_pool_bwd_e_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dg, att, pad, de, B, T,
+                       C, NH, H, W, AH, AW, k);
+    UNCR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(aggregate_pool_bwd_att_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, stream, dg, e, pad, datt, B,
+                       T, C, NH, H, W, AH, AW, k);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
 // ---- use_v (uncrtaints.py:414-417): out = a + bilinear_up(z) with (sum, sum^2) partials for the next PreNorm.
 // include_v(cat(g, up(v))) = Wa*g + up(Wv*v + b): the 1x1 convolution commutes with the up-sampling, so the value
 // branch is convolved at 32x32 and only this add touches full resolution.  grid = (P/1024, B*C), block 256 x float4.

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_sums_kernel(
     const double* __restrict__ sums, double M, int N, int C, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
     float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ save_mean,
-    float* __restrict__ save_rstd) {
+    float* __restrict__ save_rstd, const float2* __restrict__ part, int NP, float* __restrict__ ub) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const double mean = sums[2 * c] / M;
@@ -392,7 +392,14 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_sums_kernel(
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
     }
     const float a = gamma[c] * rf, b = beta[c] - mf * a;
-    for (int n = 0; n < N; ++n) { coefA[n * C + c] = a; coefB[n * C + c] = b; }
+    for (int n = 0; n < N; ++n) {
+        coefA[n * C + c] = a; coefB[n * C + c] = b;
+        if (ub) {      // bound on |a*h + b| over the LOCAL plane from its partial sums of squares (bn_finalize_fwd_kernel)
+            float m = 0.f;
+            for (int j = 0; j < NP; ++j) { const float v = part[((size_t)n * C + c) * NP + j].y; m = v > m || !(v == v) ? v : m; }
+            ub[n * C + c] = fmaf(fabsf(a), sqrtf(m), fabsf(b));
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_bwd_sums_kernel(
@@ -424,11 +431,13 @@ extern "C" int uncr_bn_channel_sums(const float* part, int NP, int N, int C, dou
 extern "C" int uncr_bn_finalize_fwd_sums(const double* sums, double count, int N, int C, const float* gamma,
                                          const float* beta, float* running_mean, float* running_var, float momentum,
                                          float eps, float* coefA, float* coefB, float* save_mean, float* save_rstd,
-                                         hipStream_t stream) {
+                                         const float* part, int NP, float* ub, hipStream_t stream) {
     if (!sums || count <= 0 || N <= 0 || C <= 0 || !gamma || !beta || !coefA || !coefB || !save_mean || !save_rstd)
         return UNCR_EINVAL;
+    if (ub && (!part || NP <= 0)) return UNCR_EINVAL;
     hipLaunchKernelGGL(bn_finalize_fwd_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, count, N, C,
-                       gamma, beta, running_mean, running_var, momentum, eps, coefA, coefB, save_mean, save_rstd);
+                       gamma, beta, running_mean, running_var, momentum, eps, coefA, coefB, save_mean, save_rstd,
+                       (const float2*)part, NP, ub);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

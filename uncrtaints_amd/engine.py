@@ -248,9 +248,11 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
         sums = torch.empty((C, 2), device=dev, dtype=torch.float64)
         hb.call("uncr_bn_channel_sums", part.buf, part.slots, N, C, sums, _stream())
         count = _all_reduce_sums(sums) * N * P
+        ub = _f32((N * C,), dev) if (bound_part is part and _H2_FWD) else None
         hb.call("uncr_bn_finalize_fwd_sums", sums, count, N, C, gamma, beta, running_mean, running_var, float(momentum),
-                float(eps), A, B, mean, rstd, _stream())
-        return NormFwd(A, B, mean, rstd, kind, groups, sync_count=count)
+                float(eps), A, B, mean, rstd, part.buf if ub is not None else None, part.slots if ub is not None else 0, ub,
+                _stream())
+        return NormFwd(A, B, mean, rstd, kind, groups, sync_count=count, ub=ub)
     ub = None
     if bound_part is not None and _H2_FWD and (kind != NORM_GROUP or C // groups <= 256):
         if part is None:
@@ -1048,12 +1050,22 @@ def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: b
     """Compact_Temporal_Aggregator 'att_group' (uncrtaints.py:156-221): e [B,T,C,H,W], att [nh,B,T,ah,aw]."""
     B, T, C, H, W = e.shape
     n_head, _, _, ah, aw = att.shape
+    dev = e.device
+    if H <= aw and (H, W) != (ah, aw):
+        # the reference's AvgPool branch (uncrtaints.py:197-204): the attention is pooled down to the feature map, no dropout.
+        # (At equal size the pooling is the identity and the streaming kernel below serves it.)
+        k = aw // H
+        if k <= 0 or ah // k != H or aw // k != W:
+            raise ValueError(f"AvgPool2d(kernel_size={k}) of a {ah}x{aw} attention map does not give the feature map's {H}x{W}")
+        if _dt(e) != F32:
+            raise NotImplementedError("the AvgPool branch of the aggregator is built for fp32 storage")
+        g = _f32((B, C, H, W), dev)
+        hb.call("uncr_aggregate_pool_fwd", e, att, pad, g, B, T, C, n_head, H, W, ah, aw, k, _stream())
+        return g, dict(e=e, att=att, pad=pad, pool_k=k, dims=(B, T, C, H, W, n_head, ah, aw)), None
     if (H * W) % 1024 or W % 4:
         raise RuntimeError(f"unsupported spatial size {H}x{W}")
     if H < ah or W < aw:
-        raise NotImplementedError("feature map smaller than the attention map (AvgPool branch, "
-                                  "uncrtaints.py:204) is not built")
-    dev = e.device
+        raise NotImplementedError(f"feature map {H}x{W} against a {ah}x{aw} attention map")
     g = _act((B, C, H, W), dev, _dt(e))
     gpart = None
     if want_stats:
@@ -1073,6 +1085,11 @@ def aggregate_backward(dg: Tensor, sv: dict):
     """-> de [B,T,C,H,W] (freshly written), datt [nh,B,T,ah,aw]"""
     B, T, C, H, W, n_head, ah, aw = sv["dims"]
     dev = dg.device
+    if "pool_k" in sv:
+        de, datt = _f32((B, T, C, H, W), dev), _f32((n_head, B, T, ah, aw), dev)
+        hb.call("uncr_aggregate_pool_bwd", dg.contiguous().float(), sv["e"], sv["att"], sv["pad"], de, datt, B, T, C, n_head, H, W,
+                ah, aw, sv["pool_k"], _stream())
+        return de, datt
     dt = _dt(sv["e"])
     de = _act((B, T, C, H, W), dev, dt)
     datt_up = _f32((n_head, B, T, H * W), dev)
@@ -1233,9 +1250,6 @@ def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor]
         w_att, shared = att, False
         if e.shape[-2] <= att_down:      # feature map not larger than the attention map: the reference takes its AvgPool
             p_drop, dmask = 0.0, None    # branch (kernel 1 = identity at equal size), which has NO dropout (uncrtaints.py:197-204)
-            if tuple(e.shape[-2:]) != (att_down, att_down):
-                raise NotImplementedError(f"feature map {tuple(e.shape[-2:])} vs attention map {att_down}x{att_down}: the "
-                                          "reference's AvgPool branch (H <= 32) is built for the equal-size case only")
     elif mode == "att_mean":
         w_att, shared = head_mean_attention(att), True
     elif mode == "mean":
@@ -1303,6 +1317,90 @@ def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int,
     part = _pool_scatter(ddown, sv, de, e_h3)
     join_side()          # the attention's parameter-gradient chain ran next to the scatter
     return de, g, part
+
+
+# ------------------------------------------------------------------------------------------------
+# the attention classes called on their own (ltae.py:244-307, 312-385, 388-458): pixel-major rows [m, T, d]
+# ------------------------------------------------------------------------------------------------
+
+def _rows_to_planes(x2d: Tensor, Rp: int) -> Tensor:
+    """[R, D] rows -> [1, D, Rp] channel-major planes (zero-padded to the GEMM's pixel tile): the layout of pw_gemm / pw_wgrad"""
+    R, D = x2d.shape
+    out = _f32((1, D, Rp), x2d.device)
+    hb.call("uncr_transpose2d", x2d.contiguous(), out, R, D, Rp, _stream())
+    return out
+
+
+def _planes_to_rows(xT: Tensor, R: int) -> Tensor:
+    _, D, Rp = xT.shape
+    out = _f32((Rp, D), xT.device)
+    hb.call("uncr_transpose2d", xT, out, D, Rp, D, _stream())
+    return out[:R]
+
+
+def linear_rows_forward(x2d: Tensor, W: Tensor, b: Optional[Tensor]):
+    """nn.Linear on rows: y [R, Dout] = x [R, Din] W^T + b, as a 1x1 convolution on the transposed tensor (MFMA GEMM)."""
+    R, Din = x2d.shape
+    Dout = W.shape[0]
+    Rp = (R + 255) // 256 * 256
+    xT = _rows_to_planes(x2d.float(), Rp)
+    yT, _ = pw_gemm(xT, pack_wt(W, transpose=True), 1, Din, Dout, Rp, bias=b.contiguous() if b is not None else None)
+    return _planes_to_rows(yT, R), dict(xT=xT, dims=(R, Rp, Din, Dout))
+
+
+def linear_rows_backward(dy: Tensor, sv: dict, W: Tensor, need_dx: bool = True):
+    """-> (dx [R, Din] or None, dW [Dout, Din], db [Dout]); the zero padding of the transposed operands contributes nothing."""
+    R, Rp, Din, Dout = sv["dims"]
+    dyT = _rows_to_planes(dy.reshape(R, Dout).float(), Rp)
+    dW, db = pw_wgrad(dyT, sv["xT"], 1, Dout, Din, Rp, rowsum=True)
+    dx = None
+    if need_dx:
+        dxT, _ = pw_gemm(dyT, pack_wt(W, transpose=False), 1, Dout, Din, Rp)
+        dx = _planes_to_rows(dxT, R)
+    return dx, dW, db
+
+
+def sdpa_rows_forward(q: Tensor, k: Tensor, v: Optional[Tensor], pad: Optional[Tensor], temperature: float, p_drop: float,
+                      seed, want_out: bool, want_comp: bool):
+    """q [m, dk] (or [q_rows, dk] shared by consecutive row groups), k [m, T, dk], v [m, T, dv], pad [m, T] int32.
+    -> attention as returned (after dropout) [m, T], attn @ v [m, dv] or None, masked scaled scores [m, T] or None, saved"""
+    m, T, dk = k.shape
+    if T > 64:
+        raise NotImplementedError("stand-alone attention rows are built for sequences of at most 64 dates")
+    dev = k.device
+    q, k = q.contiguous().float(), k.contiguous().float()
+    dv = v.shape[-1] if v is not None else 0
+    if v is not None:
+        v = v.contiguous().float()
+    attn_sm = _f32((m, T), dev)
+    attn_out = _f32((m, T), dev) if p_drop > 0.0 else None
+    out = _f32((m, dv), dev) if want_out else None
+    comp = _f32((m, T), dev) if want_comp else None
+    seed_val, seed_dev = seed if isinstance(seed, tuple) else (seed, None)
+    hb.call("uncr_sdpa_rows_fwd", q, q.shape[0], k, v, pad, float(temperature), attn_sm, attn_out, out, comp, m, T, dk, dv,
+            float(p_drop), seed_val, seed_dev, _stream())
+    sv = dict(q=q, k=k, v=v, pad=pad, attn_sm=attn_sm, temperature=float(temperature), p_drop=float(p_drop), seed=seed_val,
+              seed_dev=seed_dev, dims=(m, T, dk, dv))
+    return (attn_out if attn_out is not None else attn_sm), out, comp, sv
+
+
+def sdpa_rows_backward(dattn: Optional[Tensor], dout: Optional[Tensor], dcomp: Optional[Tensor], sv: dict, need_dv: bool = True):
+    """-> dq (shape of q), dk [m, T, dk], dv [m, T, dv] or None"""
+    m, T, dk, dv = sv["dims"]
+    q = sv["q"]
+    dev = q.device
+    dq_rows, dkk = _f32((m, dk), dev), _f32((m, T, dk), dev)
+    dvv = _f32((m, T, dv), dev) if (need_dv and sv["v"] is not None) else None
+    c = lambda t: t.contiguous().float() if t is not None else None
+    hb.call("uncr_sdpa_rows_bwd", c(dattn), c(dout) if sv["v"] is not None else None, c(dcomp), q, q.shape[0], sv["k"], sv["v"],
+            sv["pad"], sv["attn_sm"], sv["temperature"], dq_rows, dkk, dvv, m, T, dk, dv, sv["p_drop"], sv["seed"],
+            sv["seed_dev"], _stream())
+    if q.shape[0] != m:      # one query per group of m / q_rows consecutive rows: sum each group
+        dq = _f32((q.shape[0], dk), dev)
+        hb.call("uncr_colsum_batched", dq_rows, q.shape[0], m // q.shape[0], dk, dq, _stream())
+    else:
+        dq = dq_rows
+    return dq, dkk, dvv
 
 
 # ------------------------------------------------------------------------------------------------
