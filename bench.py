@@ -179,11 +179,29 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    dist_info = {}
     if world > 1:
+        import datetime
+        # fail fast: a collective error or a lost rank must end the run, not hang it (the driver times the whole command)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "0")
+        tmo = datetime.timedelta(seconds=int(os.environ.get("UNCR_BENCH_COLL_TIMEOUT_S", "180")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
+        # one rank per GPU: every rank reports the device it sits on, rank 0 checks that they are all different
+        props = torch.cuda.get_device_properties(device)
+        me = f"{os.uname().nodename}:{getattr(props, 'uuid', None) or getattr(props, 'pci_bus_id', None) or local_rank}:{local_rank}"
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        if backend == "nccl" and len(set(seen)) != world:
+            raise SystemExit(f"{world} ranks but only {len(set(seen))} distinct devices: {seen}")
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        dist_info = {"devices": seen, "rccl_version": ver, "device_name": props.name}
 
     from uncrtaints_amd import hip_backend as hb
     from uncrtaints_amd.src import losses
@@ -197,6 +215,7 @@ def main():
         from uncrtaints_amd.parallel import BucketedDataParallel
         # with a captured forward/backward the collectives stay outside the graph: no launches from autograd hooks
         dp = BucketedDataParallel(model, seed=1, overlap=args.no_graph)
+        dp.time_waits = True          # HIP event pair around the waits in finish(): the part of the all-reduce NOT hidden
         segmented = (not args.no_graph) and len(dp.buckets) == 3
         model.keep_boundaries = segmented
     else:
@@ -354,6 +373,8 @@ def main():
         prof = hb.EventProfiler(PROFILED)
         hb.set_profiler(prof)
     fence()
+    if dp is not None:
+        dp.wait_ms()                        # drop the warm-up records
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -361,6 +382,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     hb.set_profiler(None)
+    coll_wait = dp.wait_ms() if dp is not None else []
     eager_ms = None
     if world > 1:   # the max over ranks of the timed region, taken before anything else touches the stream
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -401,6 +423,11 @@ def main():
                                    + ("bf16 activation storage / fp32 accumulate, statistics, weights and loss" if bf16 else "fp32"),
                        "global_batch": world * B, "T": T, "parallelism": f"dp{world}"},
             "ranks": world, "collective_backend": (backend if world > 1 else None),
+            # N > 1: what travels (one fp32 bucket per backward segment, all-reduce AVG), on which devices, and how long the compute
+            # stream stood still for it per step (HIP events around the waits in finish(): 0 = fully hidden behind the backward)
+            "collective": (dict(dist_info, bucket_bytes=dp.bucket_bytes(), all_reduces_per_step=len(dp.buckets),
+                                wait_ms_per_step=round(sum(coll_wait) / max(len(coll_wait), 1), 4),
+                                wait_ms_max=round(max(coll_wait), 4) if coll_wait else None) if dp is not None else None),
             "final_loss": final_loss, "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
             "launch_mode": graph_note,
             "step_hbm_roofline_frac": round(value / world * a_step_bytes(T, H * H, bf16) / 1e9 / HBM_PEAK_GBS, 4),
@@ -473,17 +500,27 @@ def main():
                 tf, tb = sms.get("fwd", 0.0) / prof_steps, sms.get("bwd", 0.0) / prof_steps
                 a_stage = (3 * T + 2) * 128 * H * H * (2.0 if bf16 else 4.0) * B
                 gbs = a_stage / ((tf + tb) * 1e6) if tf + tb > 0 else 0.0
+                det = prof.scope_detail()
+                t_scatter = sum(v[1] for d in det.values() for k, v in d.items() if k == "-uncr_pool_scatter_stats") / prof_steps
+                gbs_all = a_stage / ((tf + tb + t_scatter) * 1e6) if tf + tb > 0 else 0.0
                 res["ltae_stage"] = {"ms_forward": round(tf, 4), "ms_backward": round(tb, 4), "algorithmic_bytes": int(a_stage),
                                      "gbs": round(gbs, 1), "roofline_frac": round(gbs / HBM_PEAK_GBS, 4),
+                                     # the same with the fused scatter + statistics kernel charged to the stage in full
+                                     "ms_scatter_stats": round(t_scatter, 4),
+                                     "roofline_frac_with_scatter_stats": round(gbs_all / HBM_PEAK_GBS, 4),
                                      "definition": "A_ltae_step = (3T+2)*128*P*bytes*B over (stage forward + stage backward) time; "
-                                                   "stage = temporal attention at 32x32 + up-sampling + aggregation + pooled-"
-                                                   "gradient scatter (SURVEY 8(d)); sum of the per-launch HIP-event times of "
-                                                   "every kernel launched inside the two stage calls",
+                                                   "stage = temporal attention at 32x32 + up-sampling + aggregation (SURVEY 8(d)); sum "
+                                                   "of the per-launch HIP-event times of every kernel launched inside the two stage "
+                                                   "calls EXCEPT uncr_pool_scatter_stats: that kernel scatters the pooled gradient "
+                                                   "while it takes the last encoder block's (sum de, sum de*h3) statistics -- a full "
+                                                   "read of de and h3 the encoder needs with or without the stage -- and is counted "
+                                                   "with the encoder (the 8x8 max-pool rides on that block's residual kernel "
+                                                   "likewise); roofline_frac_with_scatter_stats charges it to the stage in full",
                                      # per entry point: [launches per step, microseconds per step]; a leading '-' marks launches made
                                      # inside the stage calls that belong to the encoder (its statistics pass) and are not counted
                                      "launches": {tag: {k: [round(v[0] / prof_steps, 2), round(1e3 * v[1] / prof_steps, 1)]
                                                         for k, v in sorted(d.items(), key=lambda kv: -kv[1][1])}
-                                                  for tag, d in prof.scope_detail().items()}}
+                                                  for tag, d in det.items()}}
             if eager_ms is not None:
                 res["eager_event_profiled_ms_per_step"] = round(eager_ms, 3)
                 res["roofline"]["source"] = ("eager re-run of the same steps with a HIP event pair around every launch "

@@ -349,6 +349,31 @@ def case_smallmap():
     print("g15_smallmap", tuple(o1.shape))
 
 
+def case_aggpool():
+    """G18: Compact_Temporal_Aggregator 'att_group' on feature maps SMALLER than the 32 x 32 attention map -- the AvgPool2d
+    branch (uncrtaints.py:197-204: kernel = w // H, no dropout even in train mode), with and without a padded date."""
+    out = {}
+    gen = torch.Generator().manual_seed(18)
+    for i, (H, padded, nh) in enumerate(((16, False, 4), (8, True, 4), (16, True, 16))):
+        B, T, C = 2, 3, 32
+        x = torch.randn(B, T, C, H, H, generator=gen, requires_grad=True)
+        att = torch.softmax(torch.randn(nh, B, T, 32, 32, generator=gen), dim=2).requires_grad_(True)
+        pad = torch.zeros(B, T, dtype=torch.bool)
+        if padded:
+            pad[1, 0] = True
+        gy = torch.randn(B, C, H, H, generator=gen)
+        agg = uncrtaints.Compact_Temporal_Aggregator(mode="att_group").train()
+        o1 = agg(x, pad_mask=pad, attn_mask=att)
+        o2 = agg(x, pad_mask=pad, attn_mask=att)
+        assert torch.equal(o1, o2), "the reference applied dropout on the AvgPool branch"
+        o1.backward(gy)
+        out.update({f"k{i}/x": x.detach().numpy(), f"k{i}/att": att.detach().numpy(), f"k{i}/pad": pad.numpy(),
+                    f"k{i}/gy": gy.numpy(), f"k{i}/out": o1.detach().numpy(), f"k{i}/dx": x.grad.numpy(),
+                    f"k{i}/datt": att.grad.numpy()})
+    np.savez_compressed(os.path.join(HERE, "g18_aggpool.npz"), n=3, **out)
+    print("g18_aggpool", 3)
+
+
 def case_posenc():
     pe = PositionalEncoder(256 // 16, T=1000, repeat=16)
     dates = torch.tensor([[1400., 1433., 1799.], [0., 1., 1000.]])
@@ -657,6 +682,8 @@ if __name__ == "__main__":
     case_calibration(); sys.exit(0)
   if "--only-smallmap" in sys.argv:
     case_smallmap(); sys.exit(0)
+  if "--only-aggpool" in sys.argv:
+    case_aggpool(); sys.exit(0)
   if "--only-usev" in sys.argv:
     case_usev(); sys.exit(0)
   if "--only-residual" in sys.argv:
@@ -669,6 +696,7 @@ if __name__ == "__main__":
     case_metrics()
     case_calibration()
     case_smallmap()
+    case_aggpool()
     case_usev()
     case_residual()
     case_posenc()

@@ -334,6 +334,25 @@ def test_aggregate_fwd_bwd(E, orc, padded, masked, H, W):
     close("agg_datt", datt, ao.grad, tol=2e-4)
 
 
+def test_aggregator_avgpool_branch_vs_reference_fixture():
+    """Compact_Temporal_Aggregator called with feature maps smaller than the 32 x 32 attention map: the reference's AvgPool2d branch
+    (uncrtaints.py:197-204; no dropout, train mode included) -- outputs and both gradients against the reference-generated g18."""
+    from conftest import load_golden
+    from uncrtaints_amd.src.backbones.uncrtaints import Compact_Temporal_Aggregator
+    g = load_golden("g18_aggpool")
+    agg = Compact_Temporal_Aggregator(mode="att_group").train()
+    for i in range(int(g["n"])):
+        x, att, pad, gy = (torch.from_numpy(g[f"k{i}/{k}"]) for k in ("x", "att", "pad", "gy"))
+        xd, ad = dev(x).requires_grad_(True), dev(att).requires_grad_(True)
+        out = agg(xd, pad_mask=dev(pad), attn_mask=ad)
+        close(f"aggpool{i}_out", out, torch.from_numpy(g[f"k{i}/out"]))
+        out.backward(dev(gy))
+        close(f"aggpool{i}_dx", xd.grad, torch.from_numpy(g[f"k{i}/dx"]))
+        close(f"aggpool{i}_datt", ad.grad, torch.from_numpy(g[f"k{i}/datt"]))
+    with pytest.raises(ValueError):      # 32 // 12 = 2 pools to 16 x 16, not 12 x 12: the reference fails to broadcast there too
+        agg(torch.zeros(1, 3, 32, 12, 12, device=DEV), attn_mask=torch.zeros(4, 1, 3, 32, 32, device=DEV))
+
+
 def test_aggregate_hash_dropout_statistics(E):
     """Train-mode dropout uses a counter-based hash stream: check keep-rate and scaling statistically."""
     B, T, C, H, W = 1, 2, 128, 64, 64

@@ -220,3 +220,16 @@ def test_small_map_branch_matches_reference():
         ot = orc.forward({k: v.clone() for k, v in state.items()}, x, dates, cfg, training=True)
         oe = orc.forward({k: v.clone() for k, v in state.items()}, x, dates, cfg, training=False)
     assert rel_err(ot.numpy(), g["train_out"]) < 2e-5 and rel_err(oe.numpy(), g["eval_out"]) < 2e-5
+
+
+def test_aggregator_avgpool_branch_matches_reference():
+    """g18: Compact_Temporal_Aggregator on feature maps smaller than the attention map (AvgPool2d(kernel = w // H), no dropout in
+    train mode, uncrtaints.py:197-204), outputs and both gradients, with and without a padded date."""
+    g = load_golden("g18_aggpool")
+    for i in range(int(g["n"])):
+        x, att, pad, gy = (torch.from_numpy(g[f"k{i}/{k}"]) for k in ("x", "att", "pad", "gy"))
+        x.requires_grad_(True); att.requires_grad_(True)
+        out = orc.temporal_aggregate(x, pad, att, orc.OracleConfig(n_head=att.shape[0]), training=True)
+        out.backward(gy)
+        assert rel_err(out.detach().numpy(), g[f"k{i}/out"]) < 1e-6
+        assert rel_err(x.grad.numpy(), g[f"k{i}/dx"]) < 1e-6 and rel_err(att.grad.numpy(), g[f"k{i}/datt"]) < 1e-6

@@ -121,9 +121,25 @@ class BucketedDataParallel:
                                        "BucketedDataParallel.zero_grad() (or optimizer.zero_grad(set_to_none=False)), "
                                        "never set_to_none=True")
 
+    def bucket_bytes(self):
+        """bytes each all-reduce moves per rank (one flat fp32 bucket each)"""
+        return [int(b["flat"].numel() * b["flat"].element_size()) for b in self.buckets]
+
+    def wait_ms(self):
+        """With `time_waits = True`: milliseconds the compute stream stood still in finish() waiting for the collectives, per
+        recorded step (a HIP event pair around the waits) -- how much of the all-reduce was NOT hidden behind the backward."""
+        torch.cuda.synchronize()
+        out = [e0.elapsed_time(e1) for e0, e1 in self._wait_events]
+        self._wait_events = []
+        return out
+
     def finish(self):
         """Wait for the in-flight all-reduces (call after backward, before the optimizer step)."""
         self._check_views()
+        timed = getattr(self, "time_waits", False) and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing()
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if not self.overlap:
             op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
             for b in self.buckets:
@@ -137,6 +153,11 @@ class BucketedDataParallel:
                 b["flat"].div_(self.world)
             b["ready"] = 0
             b["handle"] = None
+        if timed:
+            e1.record()
+            if not hasattr(self, "_wait_events"):
+                self._wait_events = []
+            self._wait_events.append((e0, e1))
 
     def sync_buffers(self):
         for t in self.module.buffers():
