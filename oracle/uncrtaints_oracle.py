@@ -203,20 +203,25 @@ def conv3x3_reflect(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
 
 
 def residual_block(x: Tensor, p: Dict[str, Tensor], prefix: str, norm: str, training: bool,
-                   update_running: bool = True) -> Tensor:
+                   update_running: bool = True, relu_masks: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """ResidualConvBlock (uncrtaints.py:24-69): x + CL3(CL2(CL1(x))), every ConvLayer = conv3x3(reflect, bias) ->
-    norm -> ReLU (the third one too: uncrtaints.py:53-62)."""
+    norm -> ReLU (the third one too: uncrtaints.py:53-62).
+    relu_masks (test infrastructure, like `pool_idx` of forward): {f"{prefix}.conv{i}": 0/1 tensor} -- the branch of each ReLU
+    that the implementation under test took; where given, the layer multiplies by the mask instead of taking max(u, 0), so that a
+    pre-activation within rounding of zero is differentiated on the same side by every party (a ReLU is a kink like the max-pool)."""
     nrm = _NormCtx(p, norm, training, update_running)
     h = x
     for i in (1, 2, 3):
         pre = f"{prefix}.conv{i}.conv"
-        h = torch.relu(nrm(conv3x3_reflect(h, p[pre + ".0.weight"], p[pre + ".0.bias"]), pre + ".1"))
+        u = nrm(conv3x3_reflect(h, p[pre + ".0.weight"], p[pre + ".0.bias"]), pre + ".1")
+        mask = relu_masks.get(f"{prefix}.conv{i}") if relu_masks is not None else None
+        h = u * mask.to(u.dtype) if mask is not None else torch.relu(u)
     return x + h
 
 
-def _block(x, p, prefix, norm, training, update_running, taps, cfg):
+def _block(x, p, prefix, norm, training, update_running, taps, cfg, relu_masks=None):
     if cfg.block_type == "residual":
-        return residual_block(x, p, prefix, norm, training, update_running)
+        return residual_block(x, p, prefix, norm, training, update_running, relu_masks)
     return mbconv(x, p, prefix, norm, training, update_running, taps, bf16=cfg.act_bf16)
 
 
@@ -348,8 +353,10 @@ def temporal_aggregate(x: Tensor, pad_mask: Tensor, attn: Tensor, cfg: OracleCon
 
 def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, training: bool = False,
             dropout_mask: Optional[Tensor] = None, update_running: bool = True,
-            taps: Optional[dict] = None, pool_idx: Optional[Tensor] = None) -> Tensor:
+            taps: Optional[dict] = None, pool_idx: Optional[Tensor] = None,
+            relu_masks: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """UNCRTAINTS.forward (uncrtaints.py:391-447).  x [B,T,Cin,H,W], dates [B,T] -> [B,1,13+covar,H,W].
+    relu_masks (test infrastructure): see residual_block.
     pool_idx (test infrastructure, not a reference argument): flat in-plane arg-max indices [B*T, C, 32, 32] that the max-pool
     is to take instead of its own.  The max-pool is a kink of the function: where the two largest values of a window differ by
     less than the forward error, two correct fp32 evaluations may select different elements and route the pooled gradient to
@@ -363,7 +370,7 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
     a0 = _store(torch.relu(_NormCtx(p, cfg.encoder_norm, training, update_running)(c0, "in_conv.conv.conv.1")), bf)   # utae.py:463-473
     e = a0
     for i in range(len(cfg.encoder_widths)):                              # one block per entry, uncrtaints.py:316-319, 399-400
-        e = _block(e, p, f"in_block.{i}", cfg.encoder_norm, training, update_running, taps, cfg)
+        e = _block(e, p, f"in_block.{i}", cfg.encoder_norm, training, update_running, taps, cfg, relu_masks)
     C = e.shape[1]
     if cfg.is_mono:
         g, down, attn = e.view(B, T, C, H, W).squeeze(dim=1), None, None
@@ -386,7 +393,7 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
         taps.update(c0=c0, a0=a0, e=e, down=down, attn=attn, agg=g)
     out = g
     for i in range(len(cfg.decoder_widths)):
-        out = _block(out, p, f"out_block.{i}", cfg.decoder_norm, training, update_running, taps, cfg)
+        out = _block(out, p, f"out_block.{i}", cfg.decoder_norm, training, update_running, taps, cfg, relu_masks)
         if taps is not None:
             taps[f"dec{i}"] = out
     if cfg.separate_out:

@@ -116,9 +116,10 @@ def test_golden_train_sequence():
     print("[parity] train sequence losses", losses_, "reference", g["losses"].tolist())
     ref = g["losses"]
     assert abs(losses_[0] - ref[0]) < 1e-4 * abs(ref[0])
-    # later steps go through Adam's 1/sqrt(v) on near-zero gradients: allow a looser band
+    # later steps go through Adam's 1 / sqrt(v) on near-zero gradients (a sign flip of a noise-level gradient moves that weight by
+    # 2 lr): measured 1e-5 on MI355X, held to 1e-3
     for a, b in zip(losses_[1:], ref[1:]):
-        assert abs(a - b) < 2e-2 * abs(b), (losses_, ref.tolist())
+        assert abs(a - b) < 1e-3 * abs(b), (losses_, ref.tolist())
 
 
 @pytest.mark.parametrize("B,T,H,W,special", [

@@ -158,7 +158,7 @@ def test_iso_ensemble_inference_config5():
     mu_e, var_e = E.ensemble_combine(torch.stack(mus), torch.stack(vs), "both")
     mu_o, var_o = orc.ensemble_combine(torch.stack(mus_o), torch.stack(vs_o), "both")
     close("ensemble_mean", mu_e, mu_o)
-    close("ensemble_var", var_e, var_o, tol=2e-4)
+    close("ensemble_var", var_e, var_o)
     with pytest.raises(ValueError):
         E.ensemble_combine(torch.stack(mus), torch.stack(vs)[:, :, :, :7], "both")
 
@@ -237,7 +237,7 @@ def test_hip_usev():
     _, ot64, loss64, g64, _ = _usev_oracle(state, x, y, dates, torch.float64, pool_idx=pidx)
     close("usev/eval", out_eval, oe, tol=2e-5)
     close("usev/eval_vs_reference", out_eval, torch.from_numpy(g["eval/out"]), tol=2e-5)
-    close_vs_truth("usev/train", out, torch.from_numpy(g["train/out"]), ot64, alt32=ot, slack=4.0, cap=5e-4)
+    close_vs_truth("usev/train", out, torch.from_numpy(g["train/out"]), ot64, alt32=ot, slack=4.0, cap=2e-4)
     assert abs(l.item() - loss64) < 2e-4 * abs(loss64)
     sd = m.state_dict()
     for k in g.files:
@@ -259,14 +259,14 @@ def test_hip_usev():
 _RES_KW = dict(decoder_widths=[128, 128], block_type="residual")
 
 
-def _res_oracle(state, x, y, dates, dtype=torch.float32):
+def _res_oracle(state, x, y, dates, dtype=torch.float32, pool_idx=None, relu_masks=None):
     cfg = orc.OracleConfig(block_type="residual", decoder_widths=[128, 128], attn_dropout=0.0)
     cast = lambda v: v.clone().to(dtype) if v.dtype.is_floating_point else v.clone()
     with torch.no_grad():
         oe = orc.forward({k: cast(v) for k, v in state.items()}, x.to(dtype), dates.to(dtype), cfg, training=False)
     pt = {k: (cast(v).requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else cast(v))
           for k, v in state.items()}
-    ot = orc.forward(pt, x.to(dtype), dates.to(dtype), cfg, training=True)
+    ot = orc.forward(pt, x.to(dtype), dates.to(dtype), cfg, training=True, pool_idx=pool_idx, relu_masks=relu_masks)
     loss = orc.loss_from_output(ot, y.to(dtype), cfg)
     loss.backward()
     return oe, ot.detach(), loss.item(), {k: v.grad for k, v in pt.items() if getattr(v, "grad", None) is not None}, \
@@ -320,6 +320,8 @@ def test_hip_residual_blocks():
     close("residual/eval", out, oe, tol=2e-5)
     close("residual/eval_vs_reference", out, torch.from_numpy(g["eval/out"]), tol=2e-5)
     m.train()
+    for blk in list(m.in_block) + list(m.out_block):
+        blk.keep_relu_branch = True
     xg = dev(x).requires_grad_(True)
     out = m(xg, batch_positions=dev(dates))
     l, _ = losses.MultiGaussianNLLLoss(reduction="mean", full=True, mode="diag")(out[:, :, :13], dev(y), out[:, :, 13:26])
@@ -330,16 +332,33 @@ def test_hip_residual_blocks():
     for k in g.files:
         if k.startswith("train/state/"):
             close("residual/" + k, sd[k[len("train/state/"):]], torch.from_numpy(g[k]), tol=1e-4)
+    # Gradients: every block here ends in ReLU masks and the stage holds the 8 x 8 max-pool -- kinks of the function: a mask (an
+    # arg-max) that flips under a 1e-6 forward difference moves a channel's gradient by ~1e-2 of the tensor's max.  Both oracle runs
+    # (fp32 and fp64) are therefore evaluated on the branch the HIP forward took: its ReLU masks [A*c + B > 0] per ConvLayer
+    # (ResidualConvBlock._last_relu) and its arg-max indices (UNCRTAINTS._last_pool_idx), after checking that the branch is a
+    # correct evaluation (pool_branch; for the masks: the fp64 gradients on the pinned branch stay within the kink scale of the
+    # free fp64 evaluation).  Then ONE rule: close_grad.
+    from gpu_util import close_grad, pool_branch
+    masks = {}
+    for name, blk in [(f"in_block.{i}", b) for i, b in enumerate(m.in_block)] + [(f"out_block.{i}", b) for i, b in enumerate(m.out_block)]:
+        for i, (c, A, B) in enumerate(blk._last_relu, 1):
+            n, ch = c.shape[:2]
+            u = A.view(n, ch, 1, 1) * c + B.view(n, ch, 1, 1)
+            masks[f"{name}.conv{i}"] = (u > 0).float().cpu()
+    cfg = orc.OracleConfig(block_type="residual", decoder_widths=[128, 128], attn_dropout=0.0)
+    pidx, pflips = pool_branch(m, state, x, dates, cfg)
+    _, _, _, g32, _ = _res_oracle(state, x, y, dates, torch.float32, pidx, masks)
+    _, _, _, g64, _ = _res_oracle(state, x, y, dates, torch.float64, pidx, masks)
+    # the branch is a correct one: the fp64 oracle's own masks differ from the HIP masks only where its pre-activation is tiny
+    _, _, _, g64_free, _ = _res_oracle(state, x, y, dates, torch.float64, pidx, None)
     gmax = max(float(v.abs().max()) for v in g64.values())
     for k, v in m.named_parameters():
         if float(g64[k].abs().max()) < 1e-6:
             assert float(v.grad.abs().max()) < 1e-3 * gmax, k
             continue
-        # Every block here ends in ReLU masks, and at 2 x 32 x 32 one mask that flips under a 1e-6 forward difference moves
-        # a channel's gradient by ~1e-2 of the tensor's max: the CPU fp32 oracle itself sits 2e-4 ... 1.3e-2 from the fp64
-        # evaluation on these tensors.  Bounded relative to that distance here; the tight (1e-4) gradient parity of the
-        # block is test_gpu_kernels.py::test_residual_block_fwd_bwd / test_conv3x3_fwd_bwd_linear_parts (no mask near a kink).
-        close_vs_truth(f"residual/grad[{k}]", v.grad, g32[k], g64[k], slack=10.0, tol=1e-4)
+        close_grad(f"residual/grad[{k}]", v.grad, g32[k], g64[k])
+        # pinning changed nothing beyond the kinks: the free fp64 evaluation stays within the kink scale of the pinned one
+        assert rel_err(g64_free[k].numpy(), g64[k].numpy()) < 5e-2, k
     close_vs_truth("residual/dx_b0t0", xg.grad[0, 0], torch.from_numpy(g["train/dx_b0t0"]),
                    None if False else _dx64(state, x, y, dates)[0, 0], kink_frac=3e-3)
 
