@@ -89,19 +89,28 @@ class OracleConfig:
 # --------------------------------------------------------------------------------------
 
 class _RoundBf16(torch.autograd.Function):
-    """Round to bf16 and back (value as stored); the gradient of a stored tensor is stored as bf16 as well."""
+    """Round to bf16 and back in the forward (fwd) and / or the backward (bwd) direction: the value as the HIP path stores it,
+    and the gradient as the HIP path stores IT -- the two do not always sit at the same tensor (see mbconv)."""
 
     @staticmethod
-    def forward(ctx, x):
-        return x.to(torch.bfloat16).to(x.dtype)
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return x.to(torch.bfloat16).to(x.dtype) if fwd else x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(g.dtype)
+        return (g.to(torch.bfloat16).to(g.dtype) if ctx.bwd else g), None, None
 
 
-def _store(x: Tensor, on: bool) -> Tensor:
-    return _RoundBf16.apply(x) if on else x
+def _store(x: Tensor, on: bool, grad: bool = True) -> Tensor:
+    """A tensor the HIP path keeps in bf16 (or rounds ahead of the matrix pipe).  grad: its gradient is a bf16 tensor too (a stored
+    activation gradient, or a gradient-GEMM operand)."""
+    return _RoundBf16.apply(x, True, grad) if on else x
+
+
+def _ground(x: Tensor, on: bool) -> Tensor:
+    """A tensor that never exists in memory on the HIP path (it lives in a prologue) but whose GRADIENT is stored in bf16."""
+    return _RoundBf16.apply(x, False, True) if on else x
 
 
 def gelu_exact(x: Tensor) -> Tensor:
@@ -232,12 +241,17 @@ def mbconv(x: Tensor, p: Dict[str, Tensor], prefix: str, norm: str, training: bo
     nrm = _NormCtx(p, norm, training, update_running)
     # bf16 = True: `_store` marks what the HIP path keeps in bf16 (h1, h2, h3, the block output) or rounds ahead of the
     # matrix pipe (the two GEMM operands a and z)
-    a = _store(nrm(x, prefix + ".conv.norm"), bf16)                     # PreNorm (uncrtaints.py:72-79,140)
+    # Where the HIP path rounds in bf16 mode -- forward: x, h1, h2, h3, the block output (stored) and the two GEMM
+    # operands a, z (rounded ahead of the matrix pipe); backward: the stored gradients dx (block input, skip and PreNorm path summed
+    # first), du1 and du2 (gradients of the two norm OUTPUTS u1, u2: written by the depthwise backward / the dz GEMM's epilogue) and
+    # the gradient-GEMM operands dh1, dh3 (norm backward of (du1, h1) / (dy, h3), rounded ahead of the matrix pipe).  The gradients
+    # of a, h2 and z exist in registers only (fp32).
+    a = _store(nrm(x, prefix + ".conv.norm"), bf16, grad=False)         # PreNorm (uncrtaints.py:72-79,140)
     h1 = _store(conv1x1(a, p[prefix + ".conv.fn.0.weight"]), bf16)      # pw 128->256
-    g1 = gelu_exact(nrm(h1, prefix + ".conv.fn.1"))
-    h2 = _store(depthwise3x3_reflect(g1, p[prefix + ".conv.fn.3.weight"]), bf16)      # dw 3x3 reflect
-    g2 = gelu_exact(nrm(h2, prefix + ".conv.fn.4"))
-    z = _store(squeeze_excite(g2, p[prefix + ".conv.fn.6.fc.0.weight"], p[prefix + ".conv.fn.6.fc.2.weight"]), bf16)
+    g1 = gelu_exact(_ground(nrm(h1, prefix + ".conv.fn.1"), bf16))
+    h2 = _store(depthwise3x3_reflect(g1, p[prefix + ".conv.fn.3.weight"]), bf16, grad=False)      # dw 3x3 reflect
+    g2 = gelu_exact(_ground(nrm(h2, prefix + ".conv.fn.4"), bf16))
+    z = _store(squeeze_excite(g2, p[prefix + ".conv.fn.6.fc.0.weight"], p[prefix + ".conv.fn.6.fc.2.weight"]), bf16, grad=False)
     h3 = _store(conv1x1(z, p[prefix + ".conv.fn.7.weight"]), bf16)      # pw-linear 256->128
     u3 = nrm(h3, prefix + ".conv.fn.8")
     if taps is not None:
@@ -365,7 +379,7 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
     B, T, Cin, H, W = x.shape
     pad_mask = (x == cfg.pad_value).all(dim=-1).all(dim=-1).all(dim=-1)   # [B,T]
     bf = cfg.act_bf16
-    f = _store(x.reshape(B * T, Cin, H, W), bf)                           # smart_forward, utae.py:422-450
+    f = _store(x.reshape(B * T, Cin, H, W), bf, grad=False)               # smart_forward, utae.py:422-450 (input gradient: fp32)
     c0 = _store(conv1x1(f, p["in_conv.conv.conv.0.weight"], p["in_conv.conv.conv.0.bias"]), bf)
     a0 = _store(torch.relu(_NormCtx(p, cfg.encoder_norm, training, update_running)(c0, "in_conv.conv.conv.1")), bf)   # utae.py:463-473
     e = a0
@@ -404,6 +418,7 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
         o = o.unsqueeze(1)
     else:
         o = conv1x1(out, p["out_conv.conv.conv.0.weight"], p["out_conv.conv.conv.0.bias"]).unsqueeze(1)
+    o = _ground(o, bf)       # the gradient of the head's pre-activation is an activation gradient: stored like the decoder's
     if taps is not None:
         taps["pre_head"] = o
     mean = o[:, :, :cfg.mean_idx]

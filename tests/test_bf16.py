@@ -309,8 +309,13 @@ def _hip_bf16_step(state, x, y, dates):
 
 def test_model_bf16_vs_fp32_oracle():
     """The model-level contract of the bf16 mode, on a seeded default-initialised network (B=2, T=3, 64x64), forward + MGNLL +
-    backward, against (a) the fp32 CPU oracle -- the cost of bf16 storage -- and (b) the oracle with the SAME roundings
-    emulated (OracleConfig.act_bf16) -- what is left is implementation difference."""
+    backward, against (a) the fp32 CPU oracle -- the cost of bf16 storage -- and (b) the oracle with the SAME roundings emulated
+    at the same tensors, forward and backward (OracleConfig.act_bf16; oracle.mbconv lists them).
+    What is left in (b) is not a difference of rounding PLACES but of rounding TIES: an fp32-level difference (another summation
+    order, 1e-6) ahead of a bf16 rounding tips it for about one element in two thousand, that element moves by 2^-8 of itself, and
+    the perturbation travels on through 3x3 stencils and batch statistics.  The emulation measures its own sensitivity to exactly
+    that -- the same emulated run with the weights perturbed by 1e-6 relative -- and the HIP path has to stay within 2 x that
+    self-distance of the emulation (and inside absolute caps)."""
     from gpu_util import oracle_run
     from oracle import uncrtaints_oracle as orc
     from uncrtaints_amd.src.backbones import uncrtaints as U
@@ -320,18 +325,32 @@ def test_model_bf16_vs_fp32_oracle():
     x, y, dates = orc.synthetic_batch(2, 3, 64, 64, seed=5)
     out_o, loss_o, dx_o, g_o, _ = oracle_run(state, x, y, dates, orc.OracleConfig(attn_dropout=0.0), torch.float32)
     _, _, _, g64, _ = oracle_run(state, x, y, dates, orc.OracleConfig(attn_dropout=0.0), torch.float64)
-    out_e, loss_e, dx_e, g_e, _ = oracle_run(state, x, y, dates, orc.OracleConfig(attn_dropout=0.0, act_bf16=True), torch.float32)
+    emu = orc.OracleConfig(attn_dropout=0.0, act_bf16=True)
+    out_e, loss_e, dx_e, g_e, _ = oracle_run(state, x, y, dates, emu, torch.float32)
+    gen = torch.Generator().manual_seed(9)
+    state_p = {k: (v * (1.0 + 1e-6 * torch.randn(v.shape, generator=gen)) if v.dtype.is_floating_point and "running" not in k else v.clone())
+               for k, v in state.items()}
+    out_p, loss_p, dx_p, g_p, _ = oracle_run(state_p, x, y, dates, emu, torch.float32)
     out, loss, dx, grads = _hip_bf16_step(state, x, y, dates)
+    from gpu_util import is_zero_grad
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    self_out = float((out_p - out_e).abs().max() / out_e.abs().max())
+    self_dx = l2(dx_p, dx_e)
+    self_g = max(l2(g_p[k], g_e[k]) for k in g_e if not is_zero_grad(k, g64))
+    print(f"[bf16] emulation vs itself under a 1e-6 weight perturbation: out {self_out:.2e}, dx rel L2 {self_dx:.2e}, worst gradient rel L2 {self_g:.2e}")
     for tag, ro, rl, rdx, rg, t_out, t_loss, t_l2, t_cos in (
             ("vs fp32 oracle", out_o, loss_o, dx_o, g_o, 4e-2, 5e-3, 1.5e-1, 0.99),
-            ("vs bf16-emulating oracle", out_e, loss_e, dx_e, g_e, 3e-2, 2e-3, 1.2e-1, 0.995)):
+            ("vs bf16-emulating oracle", out_e, loss_e, dx_e, g_e, 3e-2, 2e-3, 1.0e-1, 0.995)):
         e_out = float((out - ro).abs().max() / ro.abs().max())
         e_loss = abs(loss - rl.item()) / abs(rl.item())
-        e_dx = float((dx.double() - rdx.double()).norm() / rdx.double().norm())
+        e_dx = l2(dx, rdx)
         print(f"[bf16] model {tag}: out rel_err {e_out:.2e}, loss rel_err {e_loss:.2e} ({loss:.5f} vs {rl.item():.5f}), dx rel L2 {e_dx:.2e}")
-        l2, cos = _grad_report(tag, grads, rg, g64)
+        wl2, cos = _grad_report(tag, grads, rg, g64)
         assert e_out <= t_out and e_loss <= t_loss, (tag, e_out, e_loss)
-        assert l2 <= t_l2 and cos >= t_cos and e_dx <= t_l2, (tag, l2, cos, e_dx)
+        assert wl2 <= t_l2 and cos >= t_cos and e_dx <= t_l2, (tag, wl2, cos, e_dx)
+        if "emulating" in tag:      # no further from the emulation than two of its own tie-flip distances
+            assert e_out <= 2 * self_out + 1e-3 and e_dx <= 2 * self_dx + 1e-3 and wl2 <= 2 * self_g + 1e-3, \
+                (e_out, self_out, e_dx, self_dx, wl2, self_g)
 
 
 def test_model_bf16_on_the_golden_fixture():

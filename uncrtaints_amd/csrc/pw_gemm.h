@@ -70,13 +70,11 @@ __device__ __forceinline__ unsigned pack_bf16x2(unsigned a, unsigned b) {
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2v_t __attribute__((ext_vector_type(2)));
-// (a, b) -> packed fp16 pairs {lo16 = a, hi16 = b}: hi parts and lo parts
-// The high part is taken from the value clamped to the fp16 range, the low part from the UNclamped remainder: values up to
-// 2 x 65504 in magnitude are still represented, larger ones overflow to inf and a NaN / inf input stays NaN / inf -- nothing is
-// hidden from a divergence check (v_med3_f32 alone would turn a NaN into -65504).
+// (a, b) -> packed fp16 pairs {lo16 = a, hi16 = b}: hi parts and lo parts.  No clamp: every caller scales its operand from a rigorous
+// bound to at most 2^15 first (weights at pack time, activations per frame), so the conversion cannot overflow on finite data; an inf /
+// NaN input (or a frame whose bound is not finite: no scaling) gives inf / NaN parts and the result is NaN, as in fp32.
 __device__ __forceinline__ void split2_f16_pair(float a, float b, unsigned& hi, unsigned& lo) {
-    const float ac = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), bc = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
-    const f16x2_t h = __builtin_convertvector(f32x2v_t{ac, bc}, f16x2_t);
+    const f16x2_t h = __builtin_convertvector(f32x2v_t{a, b}, f16x2_t);
     const f32x2v_t hf = __builtin_convertvector(h, f32x2v_t);
     const f16x2_t l = __builtin_convertvector(f32x2v_t{a - hf.x, b - hf.y}, f16x2_t);
     hi = __builtin_bit_cast(unsigned, h);
