@@ -24,7 +24,7 @@ FP32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 / _f16 dense peak (what the split GEMMs really run on: 6, 3 or 2 products)
 
 PRO_NORMBWD = 3
-TRAFFIC_FILE = "r02_traffic.json"
+TRAFFIC_FILE = "r03_traffic.json"          # fp32 storage; bf16 storage: r03_traffic_bf16.json (tools/measure_traffic.sh <tag> [bf16])
 
 
 def kernel_model(name, key):
@@ -465,16 +465,15 @@ def main():
             res["roofline"]["algorithmic_bytes"] = int(top["bytes"])
             try:
                 from uncrtaints_amd.build import source_sha
-                with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as fh:
+                tfile = TRAFFIC_FILE.replace(".json", "_bf16.json") if bf16 else TRAFFIC_FILE
+                with open(os.path.join(ROOT, "profiles", tfile)) as fh:
                     trj = json.load(fh)
                 tr = trj.get(top["kernel"])
-                if bf16:
-                    res["roofline"]["traffic_source"] = f"null: profiles/{TRAFFIC_FILE} holds the fp32 kernels only"
-                elif tr and trj.get("_source_sha") == source_sha():
+                if tr and trj.get("_source_sha") == source_sha():
                     res["roofline"]["traffic"] = tr["hbm_bytes"]
-                    res["roofline"]["traffic_source"] = f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc passes, same kernel sources)"
+                    res["roofline"]["traffic_source"] = f"profiles/{tfile} (rocprofv3 --pmc passes, same kernel sources)"
                 else:
-                    res["roofline"]["traffic_source"] = (f"null: profiles/{TRAFFIC_FILE} was measured on other kernel sources "
+                    res["roofline"]["traffic_source"] = (f"null: profiles/{tfile} was measured on other kernel sources "
                                                          "or does not hold this kernel")
             except OSError:
                 pass

@@ -96,48 +96,57 @@ def main():
             print(f"tiles={nb} blocks={len(s)} wall {ms*1e3:.1f} us: prologue {s[:,0].mean():.0f}  loop+epilogues {s[:,1].mean():.0f} "
                   f"(per tile {(s[:,1] / s[:,3]).mean():.0f}, of which epilogue {(s[:,2] / s[:,3]).mean():.0f}) ticks; "
                   f"-> {(s[:,:2].sum(1)).mean()/ms/1e3:.0f} ticks/us if blocks span the kernel")
-    elif what == "traffic":
+    elif what in ("traffic", "traffic_bf16"):
         # one launch sequence of the step's dominant kernels at the bench shapes, for rocprofv3 --pmc passes
+        # (traffic_bf16: the same launches on bf16 activation storage, BASELINE config 3)
         import json
-        seq = []
+        from uncrtaints_amd import hip_backend as hb
+        bf = what == "traffic_bf16"
+        adt = torch.bfloat16 if bf else torch.float32
+        act = 1 if bf else 0
+        ta = lambda *s: torch.randn(*s, device=dev).to(adt)
         Cin, Cout = 128, 256
-        x = torch.randn(N, Cin, P, device=dev); x2 = torch.randn(N, Cin, P, device=dev)
-        h2 = torch.randn(N, Cout, P, device=dev)
+        x, x2, h2 = ta(N, Cin, P), ta(N, Cin, P), ta(N, Cout, P)
         Wt = E.pack_wt(torch.randn(Cout, Cin, device=dev) * 0.05, transpose=True)
         k = tuple(torch.randn(N * Cin, device=dev) for _ in range(3)); ek = tuple(torch.rand(N * Cout, device=dev) for _ in range(4))
+        # magnitude bounds, so that the fp32 launches take the fp16 two-part kernels they take inside the step
+        amax = lambda t: t.float().abs().amax(dim=(1, 2)).view(N, 1).contiguous()
+        ub1 = (k[0].abs().view(N, Cin) * x.float().abs().amax(dim=2) + k[1].abs().view(N, Cin)).reshape(-1).contiguous()
         for _ in range(3):
-            E.pw_gemm(x, Wt, N, Cin, Cout, P, pro=3, k=k, x2=x2, epi=3, aux=h2, ek=ek)          # fused dz + pass-B
-            E.pw_gemm(x, Wt, N, Cin, Cout, P, pro=1, k=k, epi=1)                                # pw1 forward
+            E.pw_gemm(x, Wt, N, Cin, Cout, P, pro=3, k=k, x2=x2, epi=3, aux=h2, ek=ek, in_amax=amax(x), in2_amax=amax(x2))   # fused dz + pass-B
+            E.pw_gemm(x, Wt, N, Cin, Cout, P, pro=1, k=k, epi=1, in_amax=ub1)                    # pw1 forward
         Wt2 = E.pack_wt(torch.randn(Cin, Cout, device=dev) * 0.05, transpose=True)
         k2f = tuple(torch.rand(N * Cout, device=dev) for _ in range(3))
+        ub2 = (k2f[0].view(N, Cout) * h2.float().abs().amax(dim=2) + k2f[1].view(N, Cout)).reshape(-1).contiguous()
         for _ in range(3):
-            E.pw_gemm(h2, Wt2, N, Cout, Cin, P, pro=2, k=k2f, epi=1)                            # pw2 forward (SE scale + GELU prologue)
+            E.pw_gemm(h2, Wt2, N, Cout, Cin, P, pro=2, k=k2f, epi=1, in_amax=ub2)                # pw2 forward (SE scale + GELU prologue)
         # the two wide weight-gradient GEMMs of an MBConv backward
-        d = torch.randn(N, 256, P, device=dev); d2 = torch.randn(N, 256, P, device=dev); xx = torch.randn(N, 128, P, device=dev)
+        d, d2, xx = ta(N, 256, P), ta(N, 256, P), ta(N, 128, P)
         dk = tuple(torch.randn(N * 256, device=dev) for _ in range(3)); xk = (torch.randn(N * 128, device=dev), torch.randn(N * 128, device=dev), None)
         for _ in range(3):
             E.pw_wgrad(d, xx, N, 256, 128, P, pro_d=3, dk=dk, d2=d2, pro_x=1, xk=xk)
+            E.pw_wgrad(xx, d, N, 128, 256, P, pro_d=3, dk=tuple(t[:N * 128] for t in dk), d2=x2, pro_x=2, xk=(k2f[0], k2f[1], None))
         # backward of pw1 with the PreNorm backward + skip epilogue (uncr_pw_gemm_dx, with the producer's statistics)
-        from uncrtaints_amd import hip_backend as hb
         W1k = E.pack_wt(torch.randn(256, 128, device=dev) * 0.05, transpose=False)
-        dy, xh3, dx = (torch.randn(N, 128, P, device=dev) for _ in range(3))
+        dy, xh3 = ta(N, 128, P), ta(N, 128, P)
+        dx = torch.empty(N, 128, P, device=dev, dtype=adt)
         c = tuple(torch.randn(N * 128, device=dev) for _ in range(3))
         slots = hb.query("uncr_pw_stat_slots", N, 128, P)
         part = torch.empty(N * 128, slots, 2, device=dev)
         for _ in range(3):
             hb.call("uncr_pw_gemm_dx", d, d2, W1k, dx, dk[0], dk[1], dk[2], None, dy, xx, xh3, c[0], c[1], c[2], None, None, None, part,
-                    N, 256, 128, P, 0, None, E._stream())
+                    N, 256, 128, P, act, None, E._stream())
         # the depthwise kernels
         C, H, W = 256, 256, 256
-        t4 = lambda *s: torch.randn(*s, device=dev)
-        h1, hh2, du2, out = t4(N, C, H, W), t4(N, C, H, W), t4(N, C, H, W), torch.empty(N, C, H, W, device=dev)
+        t4 = lambda *s: torch.randn(*s, device=dev).to(adt)
+        h1, hh2, du2, out = t4(N, C, H, W), t4(N, C, H, W), t4(N, C, H, W), torch.empty(N, C, H, W, device=dev, dtype=adt)
         cA, cB, k1, k2, k3 = (torch.randn(N * C, device=dev) for _ in range(5))
-        w9 = t4(C, 9)
+        w9 = torch.randn(C, 9, device=dev)
         sf, sb = hb.query("uncr_dw_slots_fwd", H), hb.query("uncr_dw_slots_bwd", H)
         partf, partb, dwp = torch.empty(N * C, sf, 2, device=dev), torch.empty(N * C, sb, 2, device=dev), torch.empty(N * C, sb, 9, device=dev)
         for _ in range(3):
-            hb.call("uncr_dw_fwd", h1, cA, cB, w9, out, partf, N, C, H, W, 0, 0, E._stream())
-            hb.call("uncr_dw_bwd", du2, hh2, h1, k1, k2, k3, None, cA, cB, w9, out, partb, dwp, None, 0, N, C, H, W, 0, 0, E._stream())
+            hb.call("uncr_dw_fwd", h1, cA, cB, w9, out, partf, N, C, H, W, act, 0, E._stream())
+            hb.call("uncr_dw_bwd", du2, hh2, h1, k1, k2, k3, None, cA, cB, w9, out, partb, dwp, None, 0, N, C, H, W, act, 0, E._stream())
         torch.cuda.synchronize()
         print("done")
     elif what == "ablate":

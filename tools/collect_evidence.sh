@@ -5,7 +5,9 @@ tag=$1
 cd "$(dirname "$0")/.."
 cp gpurun_out/${tag}_pytest_gpu.log profiles/${tag}_pytest_gpu.log
 cp gpurun_out/${tag}_traffic.json profiles/${tag}_traffic.json
+cp gpurun_out/${tag}_traffic_bf16.json profiles/${tag}_traffic_bf16.json
 cp gpurun_out/${tag}_pmc_FETCH_SIZE.csv gpurun_out/${tag}_pmc_WRITE_SIZE.csv profiles/
+cp gpurun_out/${tag}_pmc_bf16_FETCH_SIZE.csv gpurun_out/${tag}_pmc_bf16_WRITE_SIZE.csv profiles/
 cp gpurun_out/${tag}_pipes.json profiles/${tag}_pipes.json
 cp gpurun_out/${tag}_bench_fp32.json profiles/${tag}_bench_fp32.json
 cp gpurun_out/${tag}_bench_bf16.json profiles/${tag}_bench_bf16.json

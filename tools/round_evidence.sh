@@ -8,8 +8,9 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$root"; mkdir -p gpurun_out
 python -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${tag}_pytest_gpu.log
 # PMC passes first: bench.py attaches roofline.traffic only from a file measured on the current kernel sources
-tools/measure_traffic.sh $tag > gpurun_out/${tag}_traffic.log 2>&1; tail -8 gpurun_out/${tag}_traffic.log
-mkdir -p profiles; cp gpurun_out/${tag}_traffic.json profiles/${tag}_traffic.json
+tools/measure_traffic.sh $tag > gpurun_out/${tag}_traffic.log 2>&1; tail -9 gpurun_out/${tag}_traffic.log
+tools/measure_traffic.sh $tag bf16 > gpurun_out/${tag}_traffic_bf16.log 2>&1; tail -9 gpurun_out/${tag}_traffic_bf16.log
+mkdir -p profiles; cp gpurun_out/${tag}_traffic.json profiles/${tag}_traffic.json; cp gpurun_out/${tag}_traffic_bf16.json profiles/${tag}_traffic_bf16.json
 tools/measure_pipes.sh $tag > gpurun_out/${tag}_pipes.log 2>&1
 python bench.py > gpurun_out/${tag}_bench_fp32.json 2> gpurun_out/${tag}_bench_fp32.err
 python bench.py --no-cpu-baseline --act-dtype bf16 > gpurun_out/${tag}_bench_bf16.json 2> gpurun_out/${tag}_bench_bf16.err
