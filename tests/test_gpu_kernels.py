@@ -235,6 +235,35 @@ def test_mbconv_fwd_bwd(orc, norm, training, fused_dx, monkeypatch):
                 close(f"mbconv_buf[{k}]", v, pt["blk." + k])
 
 
+def test_pad_aware_smart_forward():
+    """TemporallySharedBlock.smart_forward with pad_value (utae.py:433-446): frames that consist of pad_value only skip the block
+    and come out as pad_value; the others equal the block applied to them alone (values and gradients)."""
+    from uncrtaints_amd.src.backbones.utae import ConvBlock
+    torch.manual_seed(0)
+    blk = ConvBlock(nkernels=[15, 128], k=1, s=1, p=0, norm="group", pad_value=0).to(DEV)
+    B, T, H, W = 2, 3, 32, 32
+    x = torch.rand(B, T, 15, H, W)
+    x[0, 2] = 0.0
+    x[1, 0] = 0.0
+    xd = dev(x).requires_grad_(True)
+    y = blk.smart_forward(xd)
+    assert y.shape == (B, T, 128, H, W) and float(y[0, 2].abs().max()) == 0.0 and float(y[1, 0].abs().max()) == 0.0
+    keep = [(0, 0), (0, 1), (1, 1), (1, 2)]
+    xs = torch.stack([x[b, t] for b, t in keep]).to(DEV).requires_grad_(True)
+    ys = blk(xs)
+    for i, (b, t) in enumerate(keep):
+        assert torch.equal(y[b, t], ys[i])
+    g = torch.randn_like(y)
+    y.backward(g)
+    ys.backward(torch.stack([g[b, t] for b, t in keep]))
+    for i, (b, t) in enumerate(keep):
+        close(f"smart_forward_dx[{b},{t}]", xd.grad[b, t], xs.grad[i])
+    assert float(xd.grad[0, 2].abs().max()) == 0.0
+    # no padded frame: the plain path
+    y2 = blk.smart_forward(dev(torch.rand(B, T, 15, H, W) + 0.1))
+    assert y2.shape == (B, T, 128, H, W)
+
+
 def test_inconv_fwd_bwd(orc):
     from uncrtaints_amd.src.backbones.utae import ConvBlock
     from uncrtaints_amd.src.learning.weight_init import weight_init

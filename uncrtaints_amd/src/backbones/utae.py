@@ -22,9 +22,22 @@ class TemporallySharedBlock(nn.Module):
     def smart_forward(self, input):
         if len(input.shape) == 4:
             return self.forward(input)
-        if self.pad_value is not None:
-            raise NotImplementedError("pad-aware smart_forward (utae.py:433-446) is unused by UNCRTAINTS blocks")
         b, t, c, h, w = input.shape
+        if self.pad_value is not None:
+            # utae.py:433-446: frames that consist of pad_value only are not run through the block; their output is pad_value.
+            # (UNCRTAINTS builds its blocks without pad_value; this is the class surface.)  The mask comes from the HIP
+            # frame-scan kernel; selecting / re-inserting the frames is data movement (torch indexing, differentiable); the
+            # `.any()` is the host sync the reference has at the same place.
+            pm = E.pad_mask_of(input.contiguous().float(), float(self.pad_value)).view(-1).bool()
+            if bool(pm.any()):
+                keep = (~pm).nonzero().squeeze(1)
+                if keep.numel() == 0:
+                    raise ValueError("every frame of the sequence equals pad_value")
+                y = self.forward(input.reshape(b * t, c, h, w).index_select(0, keep))
+                self.out_shape = (b * t,) + tuple(y.shape[1:])
+                full = torch.full(self.out_shape, float(self.pad_value), device=y.device, dtype=y.dtype)
+                out4 = full.index_copy(0, keep, y)
+                return out4.view(b, t, *out4.shape[1:])
         out4 = self.forward(input.reshape(b * t, c, h, w))
         _, c, h, w = out4.shape
         out = out4.view(b, t, c, h, w)
