@@ -87,9 +87,6 @@ template <bool NT, typename TA> __device__ __forceinline__ void pws_st(TA* p, co
 #ifndef PWS_H2_DEPTH_CT2
 #define PWS_H2_DEPTH_CT2 1     // raw chunks in flight of the 256-channel fp16 two-part variant
 #endif
-#ifndef PWS_ILV
-#define PWS_ILV 0              // fp16 two-part kernels: staging of the next chunk interleaved with the MFMA groups of k-step 0
-#endif
 #ifndef PWS_A16_OCC
 #define PWS_A16_OCC 2          // blocks per CU the bf16 variants are compiled for (experiment knob)
 #endif
@@ -187,12 +184,8 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
             if constexpr (PRE2) pre2[S][r] = pws_ld<UNCR_NTG_LD && EPI != 4, TA>(in2b + (size_t)kk * P + px);
         }
     };
-    // stages pixels [E0, E1) of the thread's four (PWS_ILV: the fp16 two-part kernels stage one pixel group after each MFMA group of
-    // the k-step ahead of the barrier, so that the prologue's VALU work fills the issue slots the wave would spend waiting on the
-    // matrix pipe; the whole chunk -- (0, 4) -- otherwise)
-    auto stage_part = [&](int kc, int buf, auto slot, auto e0c, auto e1c) {
+    auto stage_chunk = [&](int kc, int buf, auto slot) {
         constexpr int S = decltype(slot)::value;
-        constexpr int E0 = decltype(e0c)::value, E1 = decltype(e1c)::value;
         // pixel-major so that only one pixel's 4 rows x 3 parts are live at a time (register pressure)
         float c0[4], c1[4], c2[4], c3[4];
         bool valid[4];
@@ -205,19 +198,17 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
             if constexpr (PRO == PRO_NORMBWD) {
                 c3[r] = cf[3][kk];
                 if constexpr (!BF) {
-                    // fp32 storage: centre the second operand in place right away (once per chunk: with the first pixel group), so
-                    // that the means are dead before the register-hungry split section (the 256-channel variants spilled 120 B
-                    // per lane with four live coefficient rows)
-                    if constexpr (E0 == 0) {
-                        pre2[PRE2 ? S : 0][r].x -= c3[r]; pre2[PRE2 ? S : 0][r].y -= c3[r];
-                        pre2[PRE2 ? S : 0][r].z -= c3[r]; pre2[PRE2 ? S : 0][r].w -= c3[r];
-                    }
+                    // fp32 storage: centre the second operand in place right away, so that the means are dead before the
+                    // register-hungry split section (the 256-channel variants spilled 120 B per lane with four live
+                    // coefficient rows)
+                    pre2[PRE2 ? S : 0][r].x -= c3[r]; pre2[PRE2 ? S : 0][r].y -= c3[r];
+                    pre2[PRE2 ? S : 0][r].z -= c3[r]; pre2[PRE2 ? S : 0][r].w -= c3[r];
                 }
             }
         }
         unsigned char* b = &xs[buf][0] + st_off;
 #pragma unroll
-        for (int e = E0; e < E1; ++e) {
+        for (int e = 0; e < 4; ++e) {
             unsigned hh[4], mm[4], ll[4];
             float vv[4];
 #pragma unroll
@@ -249,12 +240,6 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
             }
         }
     };
-
-    using E0c = std::integral_constant<int, 0>;
-    using E1c = std::integral_constant<int, 1>;
-    using E2c = std::integral_constant<int, 2>;
-    using E4c = std::integral_constant<int, 4>;
-    auto stage_chunk = [&](int kc, int buf, auto slot) { stage_part(kc, buf, slot, E0c{}, E4c{}); };
 
     f32x16 acc[4][CT];
     auto zero_acc = [&]() {
@@ -418,27 +403,23 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         acc[e][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, A[ct]),              \
                                                             __builtin_bit_cast(f16x8_t, B[e]), acc[e][ct], 0, 0, 0)
     // fp16 two-part k-step: three products; the low B part is read at the top of its own k-step, everything else rolls
-    auto kstep_h2 = [&](int ksn, const unsigned char* cb, const unsigned char* nb, auto roll, auto&& st0, auto&& st1, auto&& st2) {
+    auto kstep_h2 = [&](int ksn, const unsigned char* cb, const unsigned char* nb, auto roll) {
         constexpr bool ROLL = decltype(roll)::value;
 #define PWS_SB() __builtin_amdgcn_sched_barrier(0)
         ldb(cb, 1, bl);
         PWS_SB();
         PWS_MF16(ah, bh); PWS_SB();
-        st0(); PWS_SB();
         PWS_MF16(al, bh); PWS_SB();
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) if (ROLL) al[ct] = lda(ksn, ct, 1);
-        st1();
         PWS_SB();
         PWS_MF16(ah, bl); PWS_SB();
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) if (ROLL) ah[ct] = lda(ksn, ct, 0);
         if (ROLL) ldb(nb, 0, bh);
-        st2();
         PWS_SB();
 #undef PWS_SB
     };
-    auto nost = [] {};
     // bf16 activations: k-step with fragment set q (= its parity): NW products, then the set is re-loaded with the weights of
     // k-step `ksn` (two k-steps ahead, wrapping into the next tile) and bh with the next k-step's B operand
     auto kstep_a16 = [&](auto qc, int ksn, const unsigned char* nb) {
@@ -469,16 +450,13 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         const unsigned char* xn = &xs[par ^ 1][0] + rd_off;
         const int cn = c + 1 == nkp ? 0 : c + 1;                 // the next chunk of the stream (wraps into the next tile)
         if constexpr (BF) kstep_a16(Q0{}, 2 * c + 2 >= nks ? 2 * c + 2 - nks : 2 * c + 2, xb + 4096);
-        else if constexpr (H2 && PWS_ILV && PRO != PRO_NORMBWD)
-            kstep_h2(2 * c + 1, xb, xb + 4096, Roll{}, [&] { stage_part(cn, par ^ 1, slot, E0c{}, E1c{}); },
-                     [&] { stage_part(cn, par ^ 1, slot, E1c{}, E2c{}); }, [&] { stage_part(cn, par ^ 1, slot, E2c{}, E4c{}); });
-        else if constexpr (H2) kstep_h2(2 * c + 1, xb, xb + 4096, Roll{}, nost, nost, nost);
+        else if constexpr (H2) kstep_h2(2 * c + 1, xb, xb + 4096, Roll{});
         else kstep(2 * c + 1, xb, xb + 4096, Roll{});
-        if (!(PWS_ABL & 2) && !(H2 && PWS_ILV && PRO != PRO_NORMBWD)) stage_chunk(cn, par ^ 1, slot);
+        if (!(PWS_ABL & 2)) stage_chunk(cn, par ^ 1, slot);
         if (!(PWS_ABL & 4)) { load_chunk(lp, slot); advance(lp); }
         __syncthreads();
         if constexpr (BF) kstep_a16(Q1{}, 2 * c + 3 >= nks ? 2 * c + 3 - nks : 2 * c + 3, xn);
-        else if constexpr (H2) kstep_h2(2 * c + 2 == nks ? 0 : 2 * c + 2, xb + 4096, xn, roll_last, nost, nost, nost);
+        else if constexpr (H2) kstep_h2(2 * c + 2 == nks ? 0 : 2 * c + 2, xb + 4096, xn, roll_last);
         else kstep(2 * c + 2 == nks ? 0 : 2 * c + 2, xb + 4096, xn, roll_last);
         par ^= 1;
     };
