@@ -59,6 +59,29 @@ def _worker(rank, world, port, q):
     except RuntimeError as exc:
         detached_raises = "bucket" in str(exc)
     assert detached_raises
+    # bookkeeping of the bench's N > 1 line: bytes per all-reduce, the wait-time record (empty without a GPU), and the segmented
+    # interface: reduce_bucket drives the collectives by hand, so it refuses a wrapper whose hooks launch them too
+    assert dp.bucket_bytes() == [4 * b["flat"].numel() for b in dp.buckets] and sum(dp.bucket_bytes()) == 4 * sum(p.numel() for p in m.parameters())
+    assert dp.wait_ms() == []
+    try:
+        dp.reduce_bucket(0)
+        refused = False
+    except RuntimeError as exc:
+        refused = "overlap=False" in str(exc)
+    assert refused
+    m2 = Toy()
+    dp2 = BucketedDataParallel(m2, overlap=False)
+    dp2.zero_grad()
+    ((dp2(xs) - ys) ** 2).mean().backward()
+    for bi in range(len(dp2.buckets)):
+        dp2.reduce_bucket(bi)
+    try:
+        dp2.reduce_bucket(0)
+        twice = False
+    except RuntimeError:
+        twice = True
+    assert twice
+    dp2.finish()
     q.put((rank, grads, weights))
     dist.barrier()
     dist.destroy_process_group()

@@ -128,8 +128,10 @@ class BucketedDataParallel:
     def wait_ms(self):
         """With `time_waits = True`: milliseconds the compute stream stood still in finish() waiting for the collectives, per
         recorded step (a HIP event pair around the waits) -- how much of the all-reduce was NOT hidden behind the backward."""
-        torch.cuda.synchronize()
-        out = [e0.elapsed_time(e1) for e0, e1 in getattr(self, "_wait_events", [])]
+        ev = getattr(self, "_wait_events", [])
+        if ev:
+            torch.cuda.synchronize()
+        out = [e0.elapsed_time(e1) for e0, e1 in ev]
         self._wait_events = []
         return out
 
