@@ -262,24 +262,27 @@ def main():
         out = model(x, batch_positions=dates)
         loss, _ = crit(*_split(out, y))
         torch.autograd.backward(loss, inputs=dp.bucket_params(0) + [model._boundary_agg])
+        dp.pack_bucket(0)     # one multi-tensor copy into the flat bucket, part of the segment (and of its graph)
         return loss
 
     def seg_stage():
         g_t = model._boundary_agg
         torch.autograd.backward(g_t, grad_tensors=g_t.grad, inputs=dp.bucket_params(1) + [model._boundary_enc])
+        dp.pack_bucket(1)
 
     def seg_encoder():
         e_t = model._boundary_enc
         torch.autograd.backward(e_t, grad_tensors=e_t.grad, inputs=dp.bucket_params(2))
+        dp.pack_bucket(2)
 
     def segmented_step(run0, run1, run2, run_opt):
         loss = run0()
-        dp.reduce_bucket(0)
+        dp.reduce_bucket(0, pack=False)
         run1()
-        dp.reduce_bucket(1)
+        dp.reduce_bucket(1, pack=False)
         run2()
-        dp.reduce_bucket(2)
-        dp.finish()           # the compute stream waits for the three collectives
+        dp.reduce_bucket(2, pack=False)
+        dp.finish(packed_by_graph=True)           # the compute stream waits for the three collectives
         run_opt()
         return loss
 

@@ -211,7 +211,11 @@ def test_bench_two_ranks_segmented_graphs_gloo(act):
     assert res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
     assert "all-reduced" in res["launch_mode"] and "graph" in res["launch_mode"], res["launch_mode"]
     assert res["ranks"] == 2 and res["collective_backend"] == "gloo"
-    assert "roofline" in res and res["roofline"]["frac"] > 0
+    # (two ranks time-slice the one GPU here: per-launch event times include the other process, the fractions mean nothing)
+    assert "roofline" in res and res["roofline"]["achieved"] >= 0 and res["roofline"]["kernel"]
+    col = res["collective"]
+    assert col["all_reduces_per_step"] == 3 and len(col["bucket_bytes"]) == 3 and sum(col["bucket_bytes"]) == 4 * 570010
+    assert len(col["devices"]) == 2 and col["wait_ms_per_step"] >= 0
     assert "cpu_baseline" not in res           # N = 1 only
     assert res["dtype"] == ("bf16" if act == "bf16" else "f32")
     import math

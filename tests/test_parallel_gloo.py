@@ -49,16 +49,24 @@ def _worker(rank, world, port, q):
     # numpy, not tensors: torch tensors travel through mp queues as shared-memory handles that die with the sender
     grads = {n: p.grad.numpy().copy() for n, p in m.named_parameters()}
     weights = {n: p.detach().numpy().copy() for n, p in m.named_parameters()}
-    # a gradient detached from its bucket (optimizer.zero_grad() with torch's default set_to_none=True) must raise in
-    # finish() instead of all-reducing stale zeros and stepping on local gradients
+    # optimizer.zero_grad() (torch's default set_to_none=True) is as good as dp.zero_grad(): the wrapper packs whatever gradient
+    # tensors autograd produced into its buckets (one multi-tensor copy per bucket) and points .grad at the bucket views
     torch.optim.SGD(m.parameters(), lr=0.1).zero_grad()
+    dp.zero_grad()
     ((dp(xs) - ys) ** 2).mean().backward()
-    try:
-        dp.finish()
-        detached_raises = False
-    except RuntimeError as exc:
-        detached_raises = "bucket" in str(exc)
-    assert detached_raises
+    dp.finish()
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.grad, torch.from_numpy(grads[n]), rtol=0, atol=0), n
+        assert any(b["flat"].data_ptr() <= p.grad.data_ptr() < b["flat"].data_ptr() + 4 * b["flat"].numel() for b in dp.buckets)
+    # ... and so is zeroing in place: autograd then accumulates straight into the bucket views
+    for p in m.parameters():
+        p.grad.zero_()
+    for b in dp.buckets:
+        b["ready"], b["handle"], b["packed"] = 0, None, False
+    ((dp(xs) - ys) ** 2).mean().backward()
+    dp.finish()
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.grad, torch.from_numpy(grads[n]), rtol=1e-6, atol=1e-7), n
     # bookkeeping of the bench's N > 1 line: bytes per all-reduce, the wait-time record (empty without a GPU), and the segmented
     # interface: reduce_bucket drives the collectives by hand, so it refuses a wrapper whose hooks launch them too
     assert dp.bucket_bytes() == [4 * b["flat"].numel() for b in dp.buckets] and sum(dp.bucket_bytes()) == 4 * sum(p.numel() for p in m.parameters())

@@ -13,7 +13,11 @@ The gradient message is 570 010 fp32 = 2.28 MB: latency-bound on xGMI (a ring ov
 in tens of microseconds), so three buckets in reverse-graph order are plenty: the decoder's gradients are ready
 first and go out while the encoder backward (the expensive half at T frames) is still running.
 
-Gradients live as views into one flat buffer per bucket, so no packing copies are needed."""
+Every bucket is one flat buffer.  Autograd is left to hand each parameter its freshly computed gradient tensor (`.grad` is None
+when the backward starts, so AccumulateGrad keeps the incoming tensor instead of launching one `grad += new` kernel per parameter:
+91 launches, 0.3-0.4 ms per step, measured with tools/probe_grad_accumulate.py); when a bucket's last gradient has landed, ONE
+multi-tensor copy packs the bucket (2.3 MB in total), the all-reduce goes out, and `.grad` of its parameters is pointed at the
+bucket's views, which is what the optimizer then reads."""
 from __future__ import annotations
 
 from typing import Callable, List, Optional, Sequence
@@ -59,11 +63,12 @@ class BucketedDataParallel:
             params = [byname[n] for n in names]
             total = sum(p.numel() for p in params)
             flat = torch.zeros(total, device=params[0].device, dtype=params[0].dtype)
-            off = 0
+            views, off = [], 0
             for p in params:
-                p.grad = flat[off:off + p.numel()].view_as(p)     # gradients accumulate straight into the bucket
+                views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-            self.buckets.append(dict(flat=flat, n=len(params), ready=0, handle=None, params=params))
+                p.grad = None
+            self.buckets.append(dict(flat=flat, views=views, n=len(params), ready=0, handle=None, params=params, packed=False))
             for p in params:
                 p.register_post_accumulate_grad_hook(self._make_hook(bi))
         # same weights / buffers everywhere
@@ -73,21 +78,49 @@ class BucketedDataParallel:
         if agg is not None and hasattr(agg, "set_seed"):
             agg.set_seed(seed + self.rank)
 
+    def _op(self):
+        return dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
+
     def _make_hook(self, bi: int) -> Callable:
         def hook(param):
             b = self.buckets[bi]
             b["ready"] += 1
             if self.overlap and b["ready"] == b["n"]:
-                op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
-                b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
+                self.pack_bucket(bi)
+                b["handle"] = dist.all_reduce(b["flat"], op=self._op(), group=self.pg, async_op=True)
         return hook
 
+    def pack_bucket(self, bi: int) -> None:
+        """Copy the gradients of bucket `bi` into its flat buffer (one multi-tensor launch) and point the parameters' `.grad` at
+        the buffer's views.  A parameter without a gradient in this step contributes zeros (torch-DDP semantics); a gradient that
+        already lives in the buffer (a caller that zeroed in place and let autograd accumulate) is left where it is.  Inside a
+        captured segment (one HIP graph per bucket) the copy is part of the graph: call it at the end of the segment."""
+        b = self.buckets[bi]
+        src, dst, zero = [], [], []
+        for p, v in zip(b["params"], b["views"]):
+            g = p.grad
+            if g is None:
+                zero.append(v)
+            elif g.data_ptr() != v.data_ptr():
+                if g.shape != v.shape or g.dtype != v.dtype:
+                    raise RuntimeError("gradient shape / dtype does not match its parameter")
+                src.append(g)
+                dst.append(v)
+        if zero:
+            torch._foreach_zero_(zero)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(b["params"], b["views"]):
+            p.grad = v
+        b["packed"] = True
+
     # ---- segmented backward: forward+backward replayed from HIP graphs, one graph per bucket --------------------------------
-    def reduce_bucket(self, bi: int) -> None:
+    def reduce_bucket(self, bi: int, pack: bool = True) -> None:
         """Launch the all-reduce of bucket `bi` now (asynchronous; RCCL enqueues it behind the work already on the current
         stream).  For training loops that drive the backward pass in bucket-sized segments themselves -- e.g. one captured
         HIP graph per segment, where autograd hooks do not run on replay: segment k's gradients travel over xGMI while segment
-        k+1 computes.  `finish()` then only waits."""
+        k+1 computes.  `finish()` then only waits.  pack=False: the segment packed the bucket itself (`pack_bucket` inside the
+        captured graph -- on a replay the Python-side `.grad` attributes say nothing about what the graph just wrote)."""
         if self.overlap:
             # with overlap=True the post-accumulate hooks launch the same all-reduce on every eager step (warm-up, capture): a
             # second one here would sum the bucket twice (SUM + divide) and drop the first handle without a wait
@@ -95,31 +128,23 @@ class BucketedDataParallel:
         b = self.buckets[bi]
         if b["handle"] is not None:
             raise RuntimeError(f"bucket {bi} already has an all-reduce in flight (reduce_bucket called twice before finish())")
-        op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
-        b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
+        if pack and not b["packed"]:
+            self.pack_bucket(bi)
+        b["handle"] = dist.all_reduce(b["flat"], op=self._op(), group=self.pg, async_op=True)
         b["ready"] = b["n"]
 
     def bucket_params(self, bi: int):
         return list(self.buckets[bi]["params"])
 
     def zero_grad(self):
+        """Start of a step: every `.grad` back to None (no kernel: the backward hands over fresh tensors, see the module
+        docstring).  `optimizer.zero_grad()` -- set_to_none or in place -- is equally fine."""
         for b in self.buckets:
-            b["flat"].zero_()
+            for p in b["params"]:
+                p.grad = None
             b["ready"] = 0
             b["handle"] = None
-
-    def _check_views(self):
-        """Every gradient must still be a view into its bucket: `optimizer.zero_grad()` (set_to_none=True, the torch
-        default) or `p.grad = None` detaches them, after which the buckets would be reduced as stale zeros and every rank
-        would step on its local gradients -- silently diverging replicas.  Raise instead."""
-        for b in self.buckets:
-            lo = b["flat"].data_ptr()
-            hi = lo + b["flat"].numel() * b["flat"].element_size()
-            for p in b["params"]:
-                if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
-                    raise RuntimeError("a parameter's .grad no longer points into its all-reduce bucket: use "
-                                       "BucketedDataParallel.zero_grad() (or optimizer.zero_grad(set_to_none=False)), "
-                                       "never set_to_none=True")
+            b["packed"] = False
 
     def bucket_bytes(self):
         """bytes each all-reduce moves per rank (one flat fp32 bucket each)"""
@@ -135,26 +160,25 @@ class BucketedDataParallel:
         self._wait_events = []
         return out
 
-    def finish(self):
-        """Wait for the in-flight all-reduces (call after backward, before the optimizer step)."""
-        self._check_views()
+    def finish(self, packed_by_graph: bool = False):
+        """Wait for the in-flight all-reduces (call after backward, before the optimizer step); buckets nobody reduced yet are
+        packed and reduced here.  packed_by_graph: see reduce_bucket(pack=False)."""
         timed = getattr(self, "time_waits", False) and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing()
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if not self.overlap:
-            op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
-            for b in self.buckets:
-                if b["handle"] is None:          # not already launched through reduce_bucket()
-                    b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
+        for bi, b in enumerate(self.buckets):
+            if b["handle"] is None:          # not launched from a hook or through reduce_bucket()
+                if not b["packed"] and not packed_by_graph:
+                    self.pack_bucket(bi)
+                b["handle"] = dist.all_reduce(b["flat"], op=self._op(), group=self.pg, async_op=True)
         for b in self.buckets:
-            if b["handle"] is None:
-                raise RuntimeError("a gradient bucket never became ready (parameter unused in this step?)")
             b["handle"].wait()
             if not self._use_avg:
                 b["flat"].div_(self.world)
             b["ready"] = 0
             b["handle"] = None
+            b["packed"] = False
         if timed:
             e1.record()
             if not hasattr(self, "_wait_events"):

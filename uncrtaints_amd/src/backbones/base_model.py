@@ -65,11 +65,10 @@ class BaseModel(nn.Module):
     def optimize_parameters(self):
         self.forward()
         self.real_A = None
-        # Under BucketedDataParallel (`self.data_parallel`, optional) the gradients are views into the flat all-reduce buckets:
-        # they are zeroed in place (setting them to None would detach them and the buckets would be reduced as stale zeros), and
-        # the all-reduces are waited on before the optimizer step.  On a single GPU: the reference's plain zero_grad()
-        # (base_model.py:117, set_to_none=True), so that a parameter without a gradient in a step is skipped by Adam, not
-        # updated from its running moments.
+        # The reference's plain zero_grad() (base_model.py:117, set_to_none=True): a parameter without a gradient in a step is
+        # skipped by Adam, and autograd hands every parameter its fresh gradient tensor instead of accumulating into an old one.
+        # Under BucketedDataParallel (`self.data_parallel`, optional) the wrapper resets its bucket bookkeeping as well, packs and
+        # all-reduces the buckets from its hooks, and is waited on before the optimizer step.
         dp = getattr(self, "data_parallel", None)
         if dp is not None:
             dp.zero_grad()
