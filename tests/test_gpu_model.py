@@ -122,6 +122,58 @@ def test_golden_train_sequence():
         assert abs(a - b) < 1e-3 * abs(b), (losses_, ref.tolist())
 
 
+def test_train_step_replayed_from_a_hip_graph_equals_eager_steps():
+    """config.hip_graph: BaseModel.optimize_parameters replays forward + loss + backward + Adam from one captured HIP graph (two
+    eager steps first).  Same batches, same initial weights: the loss sequence and the final weights follow the eager loop (the
+    capturable Adam keeps step count and learning rate on the device: last-bit differences in its bias correction only), the
+    learning-rate schedule reaches the captured kernels, and a change of the input shape re-captures."""
+    from types import SimpleNamespace
+    from uncrtaints_amd.src.backbones.base_model import BaseModel
+    g = load_golden("g6_trainseq")
+    meta = json.loads(str(g["meta"]))
+
+    def run(hip_graph):
+        cfg = SimpleNamespace(model="uncrtaints", use_sar=True, encoder_widths=[128], decoder_widths=[128] * 5,
+                              out_conv=[26], mean_nonLinearity=True, var_nonLinearity="softplus", agg_mode="att_group",
+                              encoder_norm="group", decoder_norm="batch", n_head=16, d_model=256, d_k=4, pad_value=0,
+                              padding_mode="reflect", positional_encoding=True, covmode="diag", scale_by=meta["scale_by"],
+                              separate_out=False, use_v=False, block_type="mbconv", pretrain=False, loss="MGNLL",
+                              lr=meta["lr"], gamma=0.5, device=DEV, chunk_size=None, hip_graph=hip_graph)
+        model = BaseModel(cfg)
+        model.netG.load_state_dict(_state(g), strict=True)
+        model.netG.temporal_aggregator.attn_dropout.p = 0.0
+        model.to(DEV).train()
+        x, y, dates = (torch.from_numpy(g[k]) for k in ("x", "y", "dates"))
+        out = []
+        for i in range(6):
+            xi = x if i != 4 else x[:1]                       # step 4: another batch size -> eager steps and a fresh capture
+            model.set_input({"A": xi, "B": y[:xi.shape[0]], "dates": dates[:xi.shape[0]], "masks": None})
+            model.optimize_parameters()
+            out.append(model.loss_G.item())
+            assert model.fake_B.shape == (xi.shape[0], 1, 13, 64, 64)
+            if i == 2:
+                model.scheduler_G.step()                      # halves the learning rate for the steps that follow
+        return out, {k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}
+    le, we = run(False)
+    lg, wg = run(True)
+    print("[parity] eager steps", le, "graph steps", lg)
+    for a, b in zip(le, lg):
+        assert abs(a - b) < 1e-4 * abs(a), (le, lg)
+    # weights: an Adam step moves a weight by at most ~lr whatever the size of its gradient, and a parameter whose gradient is
+    # rounding noise (mathematically zero: e.g. a bias ahead of the temporal softmax) takes the sign of that noise -- so single
+    # elements may sit a few lr apart, while the bulk agrees closely
+    far, total = 0, 0
+    for k in we:
+        if we[k].dtype.is_floating_point and "running" not in k:
+            d = (we[k] - wg[k]).abs()
+            assert float(d.max()) <= 6 * 1.1 * meta["lr"], k
+            far += int((d > 1e-4).sum()); total += d.numel()
+        elif not we[k].dtype.is_floating_point:
+            assert torch.equal(we[k], wg[k]), k
+    print(f"[parity] graph vs eager weights after 6 steps: {far} of {total} elements further apart than 1e-4")
+    assert far <= 0.01 * total
+
+
 @pytest.mark.parametrize("B,T,H,W,special", [
     (1, 3, 256, 256, ""), (2, 2, 128, 64, ""),
     (1, 2, 80, 64, ""),            # overlapping adaptive-pool windows, 2.5x up-sampling

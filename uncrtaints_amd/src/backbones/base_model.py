@@ -20,7 +20,19 @@ class BaseModel(nn.Module):
         self.netG = model_utils.get_generator(self.config)
         self.criterion = losses.get_loss(self.config)
         self.log_vars = None
-        self.optimizer_G = torch.optim.Adam([{'params': self.netG.parameters()}], lr=config.lr)
+        # config.hip_graph (opt-in, not a reference flag): optimize_parameters replays the whole step -- forward, loss, backward,
+        # Adam, ~300 kernel launches -- from ONE captured HIP graph (see _graph_step).  Adam then keeps its step count and its
+        # learning rate on the device (capturable), so that ExponentialLR's per-epoch update reaches the captured kernels.
+        self._use_graph = bool(getattr(config, "hip_graph", False))
+        self._graph = None
+        if self._use_graph:
+            kw = dict(capturable=True, lr=torch.tensor(float(config.lr), device=config.device))
+            try:        # one multi-tensor launch per step instead of a chain of foreach kernels (same arithmetic)
+                self.optimizer_G = torch.optim.Adam([{'params': self.netG.parameters()}], fused=True, **kw)
+            except (RuntimeError, TypeError, ValueError):
+                self.optimizer_G = torch.optim.Adam([{'params': self.netG.parameters()}], **kw)
+        else:
+            self.optimizer_G = torch.optim.Adam([{'params': self.netG.parameters()}], lr=config.lr)
         self.scheduler_G = torch.optim.lr_scheduler.ExponentialLR(self.optimizer_G, gamma=self.config.gamma)
         self.real_A = self.fake_B = self.real_B = self.dates = self.masks = None
         self.netG.variance = None
@@ -62,7 +74,85 @@ class BaseModel(nn.Module):
         if getattr(self.netG, 'variance', None) is not None:
             self.netG.variance = 1 / self.scale_by ** 2 * self.netG.variance
 
+    # ---- the same step from a captured HIP graph (config.hip_graph) ----------------------------------------------------------
+    # An eager step enqueues ~300 launches from Python: on a free host that keeps up with the GPU (12.3 ms at the bench shape,
+    # tools/bench_basemodel.py), on a busy one it does not (18-20 ms measured in round 1); replayed from a graph the step takes the
+    # GPU time whatever the host does.  The first two steps of a given input shape run eagerly (they are real training
+    # steps and size every buffer); the third is captured and replayed, and so is every later one: the batch is copied into static
+    # input tensors, the graph is launched, `fake_B`, `loss_G` (and the covariance export, if requested) are its static outputs.
+    # The dropout stream of the aggregator draws its per-step seed from a device counter the graph increments.  Anything that changes
+    # the launch list (another input shape, train/eval switch, freezing layers, a data-parallel wrapper) falls back to eager steps
+    # and a fresh capture.
+    def _graph_key(self):
+        return (tuple(self.real_A.shape), tuple(self.real_B.shape), None if self.dates is None else tuple(self.dates.shape),
+                self.netG.training, tuple(p.requires_grad for p in self.netG.parameters()))
+
+    def _graph_step(self):
+        key = self._graph_key()
+        g = self._graph
+        if g is None or g["key"] != key:
+            g = self._graph = dict(key=key, eager_left=2, graph=None)
+        agg = getattr(self.netG, "temporal_aggregator", None)
+        if agg is not None and agg.step_counter is None:
+            agg.step_counter = torch.zeros(1, dtype=torch.int64, device=self.real_A.device)
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_gstream", None) is None:
+            # warm-up steps and capture share one side stream (autograd's AccumulateGrad nodes remember the stream they were
+            # created on: a capture on another stream than the warm-up's would have to synchronise the two inside the capture)
+            self._gstream = torch.cuda.Stream(device=self.real_A.device)
+        if g["eager_left"] > 0:
+            g["eager_left"] -= 1
+            self._gstream.wait_stream(cur)
+            with torch.cuda.stream(self._gstream):
+                if agg is not None:
+                    agg.step_counter.add_(1)
+                self._eager_step()
+            cur.wait_stream(self._gstream)
+            return
+        if g["graph"] is None:
+            self._gstream.wait_stream(cur)
+            with torch.cuda.stream(self._gstream):
+                g["A"], g["B"] = self.real_A.clone(), self.real_B.clone()
+                g["dates"] = None if self.dates is None else self.dates.clone()
+                self.optimizer_G.zero_grad(set_to_none=True)
+                graph = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph, stream=self._gstream):
+                    if agg is not None:
+                        agg.step_counter.add_(1)
+                    self.real_A, self.real_B, self.dates = g["A"], g["B"], g["dates"]
+                    self.forward()
+                    self.optimizer_G.zero_grad(set_to_none=True)
+                    self.backward_G()
+                    self.optimizer_G.step()
+                    g["fake_B"], g["loss_G"], g["variance"] = self.fake_B, self.loss_G, self.netG.variance
+            cur.wait_stream(self._gstream)
+            g["graph"] = graph
+        else:
+            g["A"].copy_(self.real_A)
+            g["B"].copy_(self.real_B)
+            if g["dates"] is not None:
+                g["dates"].copy_(self.dates)
+        g["graph"].replay()
+        self.real_A = None
+        self.real_B = g["B"]
+        self.fake_B, self.loss_G, self.netG.variance = g["fake_B"], g["loss_G"], g["variance"]
+        self.rescale()          # new tensors: the static outputs stay untouched
+        self.reset_input()
+        self._export()
+
+    def _export(self):
+        if self.netG.training and getattr(self.config, "export_to_host", False):
+            self.fake_B = self.fake_B.cpu()
+            if self.netG.variance is not None:
+                self.netG.variance = self.netG.variance.cpu()
+
     def optimize_parameters(self):
+        if self._use_graph and self.data_parallel is None and self.real_A is not None and self.real_A.is_cuda:
+            return self._graph_step()
+        return self._eager_step()
+
+    def _eager_step(self):
         self.forward()
         self.real_A = None
         # The reference's plain zero_grad() (base_model.py:117, set_to_none=True): a parameter without a gradient in a step is
@@ -80,7 +170,4 @@ class BaseModel(nn.Module):
         self.optimizer_G.step()
         self.rescale()
         self.reset_input()
-        if self.netG.training and getattr(self.config, "export_to_host", False):
-            self.fake_B = self.fake_B.cpu()
-            if self.netG.variance is not None:
-                self.netG.variance = self.netG.variance.cpu()
+        self._export()
