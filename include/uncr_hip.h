@@ -170,14 +170,16 @@ int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt, void* out,
                     const float* relu_a, const float* relu_b, float* part, int N, int Cin, int Cout, int P, int act,
                     float* amax_out /* [N][uncr_pw_stat_slots] per-block max |out| or null (relu_a == null only) */,
                     hipStream_t stream);
-/* R [N][Ch][C] = per-frame products sum_p du1n*x (uncr_pw_wgrad with the raw x); part_b / part_f = the (sum du1, .) and
- * (sum h1, .) partials [N*Ch][NPB|NPF][2] (part_f may be null: no c2 term); c1..c3 [N*Ch] = norm-1 backward
- * coefficients; A0, B0 [N*C] = PreNorm forward coefficients.  -> part0 [N*C][1][2] = (sum da, sum da*x), dW1 [Ch][C]. */
-int uncr_prenorm_bwd_finish(const float* R, const float* W1, const float* part_b, int NPB, const float* part_f,
-                            int NPF, const float* c1, const float* c2, const float* c3,
+/* wpart [N*nbx][COP][CIP] = the per-block partials of the per-frame products R[n] = sum_p du1n*x (uncr_pw_wgrad with the raw x,
+ * its reduction is done here); part_b / part_f = the (sum du1, .) and (sum h1, .) partials [N*Ch][NPB|NPF][2] (part_f may be
+ * null: no c2 term); c1..c3 [N*Ch] = norm-1 backward coefficients; A0, B0 [N*C] = PreNorm forward coefficients.
+ * -> part0 [N*C][Ch/2][2] = partials of (sum da, sum da*x) for uncr_norm_finalize_bwd (every fp64 tile sum as a value slot and a
+ * remainder slot), dW1 [Ch][C]. */
+int uncr_prenorm_bwd_finish(const float* wpart, int nbx, int COP, int CIP, const float* W1, const float* part_b, int NPB,
+                            const float* part_f, int NPF, const float* c1, const float* c2, const float* c3,
                             const float* cmu /* null: raw form; else part_f is required */, const float* A0,
-                            const float* B0, float* part0, float* dW1, float* scratch /* 2*N*Ch floats */, int N,
-                            int Ch /* % 8 == 0 */, int C /* % 32 == 0 */, int P, hipStream_t stream);
+                            const float* B0, float* part0, float* dW1, int N, int Ch /* % 4 == 0 */, int C /* % 32 == 0 */,
+                            int P, hipStream_t stream);
 int uncr_wgrad_shape(int Cd, int Cx, int* cop, int* cip);
 /* act: storage of d, d2, x.  bf16: the two wide shapes (256 x 128, 128 x 256) run one bf16 x bf16 product per MAC with fp32
  * accumulation (P % 64 == 0), the narrow shapes of the path (in_conv 128 x 15, head 26 x 128) the fp32 MFMA kernels. */
@@ -256,24 +258,26 @@ int uncr_ltae_softmax_bwd(const float* datt, const float* att, const float* k, c
 /* ---- LTAE2dtiny (ltae.py:145-239) fused per low-resolution pixel: GroupNorm over (C/NH channels x T dates), inconv, positional
  *      encoding, fc1_k, query product and the masked temporal softmax in ONE kernel per direction.  Everything between the
  *      GroupNorm and the softmax is linear, so the score is one linear functional of the normalised input per head:
- *      score = A' . xhat + B' with A' [NH][C], B' [NH][B*T] composed from the parameters by uncr_ltae_compose (fp64; also
- *      returns M = Wk Wi [NH*DK][C] and U = Wk (b_i + PE) + b_k [NH*DK][B*T] for the backward).  bias1 [B*T][D] = b_i + PE comes
- *      from uncr_ltae_posbias.  uncr_ltae_fused_bwd returns d(pooled features) and per-block partials of d A' ([B*nblk][NH][C],
- *      nblk = S*NH/256 blocks per sample) and d B' ([B*nblk][NH][T]); after uncr_colsum, uncr_ltae_compose_bwd applies the chain rule (dAp [NH][C],
- *      dBp [B][NH][T]) -> d Q, d fc1_k, d inconv, and per-head d gamma / d beta contributions dgb [NH][2][C]. ---- */
+ *      score = A' . xhat + B' with A' [NH][C], B' [NH][B*T] composed from the parameters by uncr_ltae_compose (fp64, one launch;
+ *      also returns bias1 [B*T][D] = b_i + PE (dates / denom as in uncr_ltae_posbias; use_pe = 0: b_i alone), M = Wk Wi
+ *      [NH*DK][C] and U = Wk bias1 + b_k [NH*DK][B*T] for the backward).  uncr_ltae_fused_bwd returns d(pooled features) and
+ *      per-block partials of d A' ([B*nblk][NH][C], nblk = S*NH/256 blocks per sample) and d B' ([B*nblk][NH][T]);
+ *      uncr_ltae_compose_bwd reduces them and applies the chain rule -> d Q, d fc1_k, d inconv, d gamma / d beta (gb [2][C]);
+ *      scratch: NH*C + NH + B*T*NH + NH*2*C floats. ---- */
 int uncr_ltae_fused_supported(int T, int C, int NH, int S);
-int uncr_ltae_compose(const float* Q, const float* Wk, const float* bk, const float* Wi, const float* bias1,
-                      const float* gamma, const float* beta, int NH, int DK, int D, int C, int NF, float* Ap, float* Bp,
-                      float* M, float* U, hipStream_t stream);
+int uncr_ltae_compose(const float* Q, const float* Wk, const float* bk, const float* Wi, const float* bin /* b_i or null */,
+                      const float* dates /* [NF] */, const float* denom /* [dpe] */, int dpe, int use_pe, const float* gamma,
+                      const float* beta, int NH, int DK, int D, int C, int NF, float* bias1, float* Ap, float* Bp, float* M,
+                      float* U, hipStream_t stream);
 int uncr_ltae_fused_fwd(const float* x, const float* Ap, const float* Bp, const int* pad, float eps, float* att, float* mean,
                         float* rstd, int B, int T, int C, int NH, int S, hipStream_t stream);
 int uncr_ltae_fused_bwd(const float* datt, const float* att, const float* x, const float* Ap, const int* pad,
                         const float* mean, const float* rstd, float* dx, float* partA, float* partB, int B, int T, int C,
                         int NH, int S, hipStream_t stream);
 int uncr_ltae_compose_bwd(const float* Q, const float* Wk, const float* Wi, const float* bias1, const float* gamma,
-                          const float* beta, const float* M, const float* U, const float* dAp, const float* dBp, int NH,
-                          int DK, int D, int C, int NF, int T, float* dA /* scratch NH*C + NH floats */, float* dQ, float* dWk,
-                          float* dbk, float* dWi, float* dbi, float* dgb, hipStream_t stream);
+                          const float* beta, const float* M, const float* U, const float* partA, const float* partB, int nblk,
+                          int NH, int DK, int D, int C /* <= 256 */, int NF, int T, float* scratch, float* dQ, float* dWk,
+                          float* dbk, float* dWi, float* dbi, float* gb, hipStream_t stream);
 
 /* ---- full-resolution temporal aggregation (Compact_Temporal_Aggregator 'att_group',
  *      uncrtaints.py:156-221: bilinear up-sample + dropout + pad mask + V-aggregate) ---- */

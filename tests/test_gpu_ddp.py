@@ -120,7 +120,7 @@ def test_two_ranks_with_sync_bn_equal_one_process_on_the_concatenated_batch():
     loss.backward()
     ref = {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
     ref.update({"buf/" + n: b.detach().cpu() for n, b in m.named_buffers() if "running" in n})
-    worst = 0.0
+    worst, worst_name = 0.0, ""
     for n in ref:
         if not n.startswith("buf/"):
             assert torch.equal(res[0][n], res[1][n]), n
@@ -129,11 +129,17 @@ def test_two_ranks_with_sync_bn_equal_one_process_on_the_concatenated_batch():
             # a channel mean is measured against the channel's spread: behind a bias-free convolution of a zero-mean input it is
             # zero up to rounding, and so is its momentum-weighted share of the buffer
             scale = max(scale, 0.1 * ref[n.replace("running_mean", "running_var")].abs().max().sqrt().item())
+        if n.endswith("conv.norm.bias"):
+            # PreNorm's shift in front of a bias-free convolution + BatchNorm has no effect on the output: its gradient is zero up to
+            # rounding (measured 1e-6 against 1e+2 for the same layer's scale), so it is measured on the layer's scale
+            scale = max(scale, 1e-3 * ref[n.replace(".bias", ".weight")].abs().max().item())
         if scale == 0:
             continue
-        worst = max(worst, (res[0][n] - ref[n]).abs().max().item() / scale)
-    print(f"[parity] ddp 2 ranks + sync_bn vs one process on the concatenated batch: worst rel err {worst:.3e}")
-    assert worst < 2e-4
+        err = (res[0][n] - ref[n]).abs().max().item() / scale
+        if err > worst:
+            worst, worst_name = err, n
+    print(f"[parity] ddp 2 ranks + sync_bn vs one process on the concatenated batch: worst rel err {worst:.3e} ({worst_name})")
+    assert worst < 2e-4, worst_name
 
 
 def _seg_worker(rank, world, port, q):

@@ -33,68 +33,110 @@ struct LfArgs {
 };
 
 // ---- parameter composition ---------------------------------------------------------------------------------------------
-// M[hd][c] = sum_j Wk[hd][j] Wi[j][c];  U[hd][n] = sum_j Wk[hd][j] bias1[n][j] + bk[hd]       grid = HK, block 256
-__global__ __launch_bounds__(256) void ltae_compose_mu_kernel(const float* __restrict__ Wk, const float* __restrict__ bk,
-                                                              const float* __restrict__ Wi, const float* __restrict__ bias1,
-                                                              int D, int C, int NF, float* __restrict__ M,
-                                                              float* __restrict__ U) {
-    const int hd = blockIdx.x;
-    const float* wk = Wk + (size_t)hd * D;
-    // the loads of 16 steps are issued together (a plain loop serialises 256 L2 round trips: 100 us for a 2-MFLOP product)
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double s = 0.0;
-        int j = 0;
-        for (; j + 16 <= D; j += 16) {
-            float w[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) w[q] = Wi[(size_t)(j + q) * C + c];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) s += (double)wk[j + q] * (double)w[q];
+// One launch, grid = NH, block = 1024 (everything here is latency: sixteen waves per head).  Block h:
+//   pe[n][i]   = sin / cos(date[n] / denom[i])                      PositionalEncoder (positional_encoding.py:5-31): channel j of the
+//   bias1[n][j] = b_i[j] + pe[n][j mod d]                           d_model-wide bias uses sinusoid j mod d; block 0 stores bias1
+//   M[hd][c] = sum_j Wk[hd][j] Wi[j][c]                             for the head's DK rows hd = h*DK + d
+//   U[hd][n] = sum_j Wk[hd][j] bias1[n][j] + bk[hd]
+//   Ap[h][c] = gamma[c] * A[h][c], A = sc * sum_d Q[h][d] M[hd][c];  Bp[h][n] = sc * sum_d Q[h][d] U[hd][n] + sum_c A[h][c] beta[c]
+// dynamic LDS: pe [NF*dpe] f32 | Mf [DK*C] f32 | Uf [DK*NF] f32 | comb [2][DK*C] f64 (re-used as the 1024-entry reduction buffer)
+__global__ __launch_bounds__(1024) void ltae_compose_kernel(
+    const float* __restrict__ Q, const float* __restrict__ Wk, const float* __restrict__ bk, const float* __restrict__ Wi,
+    const float* __restrict__ bin, const float* __restrict__ dates, const float* __restrict__ denom, int dpe, int use_pe,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int DK, int D, int C, int NF, float* __restrict__ bias1,
+    float* __restrict__ Ap, float* __restrict__ Bp, float* __restrict__ M, float* __restrict__ U) {
+    extern __shared__ double lds_d[];
+    const int h = blockIdx.x, tid = threadIdx.x;
+    const int ncomb = max(2 * DK * C, 1024);
+    double* comb = lds_d;                                  // [2][DK*C] / red[1024]
+    float* spe = (float*)(lds_d + ncomb);                  // [NF][dpe]
+    float* sM = spe + (size_t)NF * dpe;                    // [DK][C]
+    float* sU = sM + (size_t)DK * C;                       // [DK][NF]
+    for (int i = tid; i < NF * dpe; i += 1024) {
+        float v = 0.f;
+        if (use_pe) {
+            const float a = dates[i / dpe] / denom[i % dpe];
+            v = ((i % dpe) & 1) ? cosf(a) : sinf(a);
         }
-        for (; j < D; ++j) s += (double)wk[j] * (double)Wi[(size_t)j * C + c];
-        M[(size_t)hd * C + c] = (float)s;
+        spe[i] = v;
     }
-    for (int n = threadIdx.x; n < NF; n += 256) {
-        double s = (double)bk[hd];
-        int j = 0;
-        for (; j + 16 <= D; j += 16) {
-            float w[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) w[q] = bias1[(size_t)n * D + j + q];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) s += (double)wk[j + q] * (double)w[q];
+    __syncthreads();
+    if (h == 0)
+        for (int i = tid; i < NF * D; i += 1024) {
+            const int n = i / D, j = i % D;
+            float v = bin ? bin[j] : 0.f;
+            if (use_pe) v += spe[n * dpe + j % dpe];
+            bias1[i] = v;
         }
-        for (; j < D; ++j) s += (double)wk[j] * (double)bias1[(size_t)n * D + j];
-        U[(size_t)hd * NF + n] = (float)s;
+    // M: two halves of the j range per output, the loads of 16 steps issued together (a plain loop serialises 256 L2 round trips)
+    {
+        const int jh = tid >> 9;
+        const int j0 = jh ? D / 2 : 0, j1 = jh ? D : D / 2;
+        for (int o = tid & 511; o < DK * C; o += 512) {
+            const int d = o / C, c = o % C;
+            const float* wk = Wk + (size_t)(h * DK + d) * D;
+            double sacc = 0.0;
+            int j = j0;
+            for (; j + 16 <= j1; j += 16) {
+                float w[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) w[q] = Wi[(size_t)(j + q) * C + c];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sacc += (double)wk[j + q] * (double)w[q];
+            }
+            for (; j < j1; ++j) sacc += (double)wk[j] * (double)Wi[(size_t)j * C + c];
+            comb[(size_t)jh * DK * C + o] = sacc;
+        }
     }
-}
-// Ap[h][c] = gamma[c] * A[h][c], A = sc * sum_d Q[h][d] M[hd][c];  Bp[h][n] = sc * sum_d Q[h][d] U[hd][n] + sum_c A[h][c] beta[c]
-__global__ __launch_bounds__(256) void ltae_compose_ab_kernel(const float* __restrict__ Q, const float* __restrict__ M,
-                                                              const float* __restrict__ U, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, int DK, int C, int NF,
-                                                              float* __restrict__ Ap, float* __restrict__ Bp) {
-    const int h = blockIdx.x;
+    // U: sixteen lanes per (row, frame) pair walk j with stride 16, combined by shuffles in a fixed order
+    {
+        const int l16 = tid & 15;
+        for (int pr = tid >> 4; pr < DK * NF; pr += 64) {
+            const int d = pr / NF, n = pr % NF;
+            const float* wk = Wk + (size_t)(h * DK + d) * D;
+            double sacc = 0.0;
+            for (int j = l16; j < D; j += 16) {
+                float v = bin ? bin[j] : 0.f;
+                if (use_pe) v += spe[n * dpe + j % dpe];
+                sacc += (double)wk[j] * (double)v;
+            }
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 16);
+            if (l16 == 0) {
+                const float u = (float)(sacc + (double)bk[h * DK + d]);
+                sU[d * NF + n] = u;
+                U[(size_t)(h * DK + d) * NF + n] = u;
+            }
+        }
+    }
+    __syncthreads();
+    for (int o = tid; o < DK * C; o += 1024) {
+        const float m = (float)(comb[o] + comb[(size_t)DK * C + o]);
+        sM[o] = m;
+        M[(size_t)h * DK * C + o] = m;
+    }
+    __syncthreads();
     const double sc = 1.0 / sqrt((double)DK);
-    __shared__ double red[256];
     double ab = 0.0;
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = tid; c < C; c += 1024) {
         double a = 0.0;
-        for (int d = 0; d < DK; ++d) a += (double)Q[h * DK + d] * (double)M[(size_t)(h * DK + d) * C + c];
+        for (int d = 0; d < DK; ++d) a += (double)Q[h * DK + d] * (double)sM[d * C + c];
         a *= sc;
         Ap[(size_t)h * C + c] = (float)(a * (double)gamma[c]);
         ab += a * (double)beta[c];
     }
-    red[threadIdx.x] = ab;
+    double* red = comb;
+    red[tid] = ab;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
     }
     const double abt = red[0];
-    for (int n = threadIdx.x; n < NF; n += 256) {
-        double s = 0.0;
-        for (int d = 0; d < DK; ++d) s += (double)Q[h * DK + d] * (double)U[(size_t)(h * DK + d) * NF + n];
-        Bp[(size_t)h * NF + n] = (float)(s * sc + abt);
+    for (int n = tid; n < NF; n += 1024) {
+        double sacc = 0.0;
+        for (int d = 0; d < DK; ++d) sacc += (double)Q[h * DK + d] * (double)sU[d * NF + n];
+        Bp[(size_t)h * NF + n] = (float)(sacc * sc + abt);
     }
 }
 
@@ -282,33 +324,70 @@ __global__ __launch_bounds__(256) void ltae_fused_bwd_kernel(LfArgs g) {
 
 // ---- gradients of the parameters from d A' [NH][C] and d B' ([B][NH][T], as the block partials reduce) --------------------
 #define LF_DB(h, n) dBp[((size_t)((n) / T) * NH + (h)) * T + (n) % T]
-// grid = NH: d A[h][:] (gamma / beta folded back), d Q[h][:], per-head contributions to d gamma / d beta (colsum over h later)
-__global__ __launch_bounds__(256) void ltae_compose_bwd_a_kernel(const float* __restrict__ Q, const float* __restrict__ M,
-                                                                 const float* __restrict__ U, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, const float* __restrict__ dAp,
-                                                                 const float* __restrict__ dBp, int DK, int C, int NF, int T,
-                                                                 float* __restrict__ dA, float* __restrict__ dQ,
-                                                                 float* __restrict__ dgb /* [NH][2][C] */,
-                                                                 float* __restrict__ sBout /* [NH] = sum_n dB'[h][n] */) {
-    const int h = blockIdx.x, NH = gridDim.x;
+// grid = NH, block = 1024: the head's d A' [C] and d B' [NF] from the fused backward's block partials (what two column-sum launches
+// did before: fp64, fixed order), then d A[h][:] (gamma / beta folded back), d Q[h][:] and the per-head contributions to d gamma /
+// d beta (summed over h by the weight-gradient kernel's last block).  dBp [B][NH][T] is stored for that kernel.
+__global__ __launch_bounds__(1024) void ltae_compose_bwd_a_kernel(const float* __restrict__ Q, const float* __restrict__ M,
+                                                                  const float* __restrict__ U, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, const float* __restrict__ partA,
+                                                                  const float* __restrict__ partB, int nblk, int DK, int C, int NF,
+                                                                  int T, float* __restrict__ dBp, float* __restrict__ dA,
+                                                                  float* __restrict__ dQ, float* __restrict__ dgb /* [NH][2][C] */,
+                                                                  float* __restrict__ sBout /* [NH] = sum_n dB'[h][n] */) {
+    const int h = blockIdx.x, NH = gridDim.x, tid = threadIdx.x;
     const double sc = 1.0 / sqrt((double)DK);
-    __shared__ double red[256];
+    __shared__ double red[1024];
+    __shared__ float sdAp[256];         // C <= 256
     __shared__ double sB;
-    double v = 0.0;
-    for (int n = threadIdx.x; n < NF; n += 256) v += (double)LF_DB(h, n);
-    red[threadIdx.x] = v;
+    {
+        // d A'[h][c] = sum over the B*nblk block partials: 4 slices of the row range per channel, combined in a fixed order
+        const int c = tid & 255, sl = tid >> 8, R = (NF / T) * nblk;
+        double acc = 0.0;
+        if (c < C) {
+            const float* src = partA + (size_t)h * C + c;
+            const size_t ld = (size_t)NH * C;
+            const int r1 = (R * (sl + 1)) / 4;
+            int r = (R * sl) / 4;
+            for (; r + 8 <= r1; r += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = src[(size_t)(r + q) * ld];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += (double)v[q];
+            }
+            for (; r < r1; ++r) acc += (double)src[(size_t)r * ld];
+        }
+        red[tid] = acc;
+    }
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    if (tid < C) sdAp[tid] = (float)(((red[tid] + red[256 + tid]) + red[512 + tid]) + red[768 + tid]);
+    // d B'[b][h][t] = sum over the nblk blocks of sample b: one wave per output
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int n = wv; n < NF; n += 16) {
+            const int b = n / T, t = n % T;
+            double acc = 0.0;
+            for (int blk = lane; blk < nblk; blk += 64) acc += (double)partB[(((size_t)b * nblk + blk) * NH + h) * T + t];
+            acc = wave_sum_d(acc);
+            if (lane == 0) LF_DB(h, n) = (float)acc;
+        }
+    }
+    __syncthreads();        // dBp of this head is read back below by other threads of the block (global, same block: visible)
+    double v = 0.0;
+    for (int n = tid; n < NF; n += 1024) v += (double)LF_DB(h, n);
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { sB = red[0]; sBout[h] = (float)red[0]; }
+    if (tid == 0) { sB = red[0]; sBout[h] = (float)red[0]; }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = tid; c < C; c += 1024) {
         double a = 0.0;
         for (int d = 0; d < DK; ++d) a += (double)Q[h * DK + d] * (double)M[(size_t)(h * DK + d) * C + c];
         a *= sc;                                                        // A[h][c]
-        const double dap = (double)dAp[(size_t)h * C + c];
+        const double dap = (double)sdAp[c];
         dA[(size_t)h * C + c] = (float)(dap * (double)gamma[c] + sB * (double)beta[c]);
         dgb[((size_t)h * 2 + 0) * C + c] = (float)(dap * a);            // d gamma contribution
         dgb[((size_t)h * 2 + 1) * C + c] = (float)(a * sB);             // d beta contribution
@@ -316,16 +395,16 @@ __global__ __launch_bounds__(256) void ltae_compose_bwd_a_kernel(const float* __
     __syncthreads();
     for (int d = 0; d < DK; ++d) {
         double q = 0.0;
-        for (int c = threadIdx.x; c < C; c += 256)
-            q += ((double)dAp[(size_t)h * C + c] * (double)gamma[c] + sB * (double)beta[c]) * (double)M[(size_t)(h * DK + d) * C + c];
-        for (int n = threadIdx.x; n < NF; n += 256) q += (double)LF_DB(h, n) * (double)U[(size_t)(h * DK + d) * NF + n];
-        red[threadIdx.x] = q;
+        for (int c = tid; c < C; c += 1024)
+            q += ((double)sdAp[c] * (double)gamma[c] + sB * (double)beta[c]) * (double)M[(size_t)(h * DK + d) * C + c];
+        for (int n = tid; n < NF; n += 1024) q += (double)LF_DB(h, n) * (double)U[(size_t)(h * DK + d) * NF + n];
+        red[tid] = q;
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        for (int o = 512; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
             __syncthreads();
         }
-        if (threadIdx.x == 0) dQ[h * DK + d] = (float)(red[0] * sc);
+        if (tid == 0) dQ[h * DK + d] = (float)(red[0] * sc);
         __syncthreads();
     }
 }
@@ -340,7 +419,7 @@ __device__ __forceinline__ void ltae_compose_bwd_wk_body(int hd, int NH, const f
     for (int j = threadIdx.x; j < D; j += 256) {
         double s = 0.0;
         int c = 0;
-        for (; c + 16 <= C; c += 16) {          // loads of 16 steps issued together (see ltae_compose_mu_kernel)
+        for (; c + 16 <= C; c += 16) {          // loads of 16 steps issued together (see ltae_compose_kernel)
             float w[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) w[q] = Wi[(size_t)j * C + c + q];
@@ -386,16 +465,25 @@ __device__ __forceinline__ void ltae_compose_bwd_wi_body(int j, const float* __r
     if (threadIdx.x == 0) dbi[j] = (float)(red[0] * sc);
     (void)NF; (void)T;
 }
-// the two weight gradients depend on dA only: one launch, grid = HK + D (blocks [0, HK): d Wk / d bk, the others: d Wi / d bi)
+// the two weight gradients depend on dA only: one launch, grid = HK + D + 1 (blocks [0, HK): d Wk / d bk, the next D: d Wi / d bi,
+// the last one: d gamma / d beta = the heads' contributions summed in head order)
 __global__ __launch_bounds__(256) void ltae_compose_bwd_w_kernel(const float* __restrict__ Q, const float* __restrict__ Wk,
                                                                  const float* __restrict__ Wi, const float* __restrict__ bias1,
                                                                  const float* __restrict__ dA, const float* __restrict__ dBp,
-                                                                 const float* __restrict__ sBv, int NH, int DK, int D, int C, int NF,
-                                                                 int T, float* __restrict__ dWk, float* __restrict__ dbk,
-                                                                 float* __restrict__ dWi, float* __restrict__ dbi) {
+                                                                 const float* __restrict__ sBv, const float* __restrict__ dgb,
+                                                                 int NH, int DK, int D, int C, int NF, int T,
+                                                                 float* __restrict__ dWk, float* __restrict__ dbk,
+                                                                 float* __restrict__ dWi, float* __restrict__ dbi,
+                                                                 float* __restrict__ gb /* [2][C] */) {
     const int b = blockIdx.x, HK = NH * DK;       // block-uniform branch
     if (b < HK) ltae_compose_bwd_wk_body(b, NH, Q, Wi, bias1, dA, dBp, sBv, DK, D, C, NF, T, dWk, dbk);
-    else ltae_compose_bwd_wi_body(b - HK, Q, Wk, dA, sBv, NH, DK, D, C, NF, T, dWi, dbi);
+    else if (b < HK + D) ltae_compose_bwd_wi_body(b - HK, Q, Wk, dA, sBv, NH, DK, D, C, NF, T, dWi, dbi);
+    else
+        for (int i = threadIdx.x; i < 2 * C; i += 256) {
+            double acc = 0.0;
+            for (int hh = 0; hh < NH; ++hh) acc += (double)dgb[(size_t)hh * 2 * C + i];
+            gb[i] = (float)acc;
+        }
 }
 
 extern "C" int uncr_ltae_fused_supported(int T, int C, int NH, int S) {
@@ -408,14 +496,19 @@ extern "C" int uncr_ltae_fused_supported(int T, int C, int NH, int S) {
     return lds <= 64 * 1024 ? 1 : 0;
 }
 
-extern "C" int uncr_ltae_compose(const float* Q, const float* Wk, const float* bk, const float* Wi, const float* bias1,
-                                 const float* gamma, const float* beta, int NH, int DK, int D, int C, int NF, float* Ap,
-                                 float* Bp, float* M, float* U, hipStream_t stream) {
-    if (NH <= 0 || DK <= 0 || D <= 0 || C <= 0 || NF <= 0) return UNCR_ESHAPE;
-    if (!Q || !Wk || !bk || !Wi || !bias1 || !gamma || !beta || !Ap || !Bp || !M || !U) return UNCR_EINVAL;
-    hipLaunchKernelGGL(ltae_compose_mu_kernel, dim3(NH * DK), dim3(256), 0, stream, Wk, bk, Wi, bias1, D, C, NF, M, U);
-    UNCR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ltae_compose_ab_kernel, dim3(NH), dim3(256), 0, stream, Q, M, U, gamma, beta, DK, C, NF, Ap, Bp);
+extern "C" int uncr_ltae_compose(const float* Q, const float* Wk, const float* bk, const float* Wi, const float* bin,
+                                 const float* dates, const float* denom, int dpe, int use_pe, const float* gamma,
+                                 const float* beta, int NH, int DK, int D, int C, int NF, float* bias1, float* Ap, float* Bp,
+                                 float* M, float* U, hipStream_t stream) {
+    if (NH <= 0 || DK <= 0 || D <= 0 || (D & 1) || C <= 0 || NF <= 0) return UNCR_ESHAPE;
+    if (!Q || !Wk || !bk || !Wi || !gamma || !beta || !bias1 || !Ap || !Bp || !M || !U) return UNCR_EINVAL;
+    if (use_pe && (!dates || !denom || dpe <= 0)) return UNCR_EINVAL;
+    if (!use_pe) dpe = 1;
+    const size_t ncomb = (size_t)(2 * DK * C > 1024 ? 2 * DK * C : 1024);
+    const size_t lds = ncomb * sizeof(double) + ((size_t)NF * dpe + (size_t)DK * C + (size_t)DK * NF) * sizeof(float);
+    if (lds > 64 * 1024) return UNCR_ESHAPE;
+    hipLaunchKernelGGL(ltae_compose_kernel, dim3(NH), dim3(1024), lds, stream, Q, Wk, bk, Wi, bin, dates, denom, dpe, use_pe, gamma,
+                       beta, DK, D, C, NF, bias1, Ap, Bp, M, U);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -471,21 +564,25 @@ extern "C" int uncr_ltae_fused_bwd(const float* datt, const float* att, const fl
     return UNCR_OK;
 }
 
-// dAp [NH][C], dBp [B][NH][T] (NF = B*T) -> dQ [NH][DK], dWk [HK][D], dbk [HK], dWi [D][C], dbi [D], dgb [NH][2][C] (per-head d gamma / d beta
-// contributions: sum over h with uncr_colsum), scratch dA [NH][C]
+// partA [B*nblk][NH][C], partB [B*nblk][NH][T] (the fused backward's block partials of d A' and d B'; NF = B*T) -> dQ [NH][DK],
+// dWk [HK][D], dbk [HK], dWi [D][C], dbi [D], gb [2][C] (d gamma, d beta); scratch: NH*C + NH + NF*NH + NH*2*C floats
 extern "C" int uncr_ltae_compose_bwd(const float* Q, const float* Wk, const float* Wi, const float* bias1, const float* gamma,
-                                     const float* beta, const float* M, const float* U, const float* dAp, const float* dBp,
-                                     int NH, int DK, int D, int C, int NF, int T, float* dA /* scratch [NH][C] + [NH] */,
-                                     float* dQ, float* dWk, float* dbk, float* dWi, float* dbi, float* dgb,
-                                     hipStream_t stream) {
-    if (NH <= 0 || DK <= 0 || D <= 0 || C <= 0 || NF <= 0 || T <= 0 || NF % T) return UNCR_ESHAPE;
-    if (!Q || !Wk || !Wi || !bias1 || !gamma || !beta || !M || !U || !dAp || !dBp || !dA || !dQ || !dWk || !dbk || !dWi || !dbi || !dgb)
+                                     const float* beta, const float* M, const float* U, const float* partA, const float* partB,
+                                     int nblk, int NH, int DK, int D, int C, int NF, int T, float* scratch, float* dQ, float* dWk,
+                                     float* dbk, float* dWi, float* dbi, float* gb, hipStream_t stream) {
+    if (NH <= 0 || DK <= 0 || D <= 0 || C <= 0 || C > 256 || NF <= 0 || T <= 0 || NF % T || nblk <= 0) return UNCR_ESHAPE;
+    if (!Q || !Wk || !Wi || !bias1 || !gamma || !beta || !M || !U || !partA || !partB || !scratch || !dQ || !dWk || !dbk || !dWi ||
+        !dbi || !gb)
         return UNCR_EINVAL;
-    hipLaunchKernelGGL(ltae_compose_bwd_a_kernel, dim3(NH), dim3(256), 0, stream, Q, M, U, gamma, beta, dAp, dBp, DK, C, NF, T, dA,
-                       dQ, dgb, dA + (size_t)NH * C);
+    float* dA = scratch;                            // [NH][C]
+    float* sB = dA + (size_t)NH * C;                // [NH]
+    float* dBp = sB + NH;                           // [B][NH][T]
+    float* dgb = dBp + (size_t)NF * NH;             // [NH][2][C]
+    hipLaunchKernelGGL(ltae_compose_bwd_a_kernel, dim3(NH), dim3(1024), 0, stream, Q, M, U, gamma, beta, partA, partB, nblk, DK, C,
+                       NF, T, dBp, dA, dQ, dgb, sB);
     UNCR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ltae_compose_bwd_w_kernel, dim3(NH * DK + D), dim3(256), 0, stream, Q, Wk, Wi, bias1, dA, dBp, dA + (size_t)NH * C,
-                       NH, DK, D, C, NF, T, dWk, dbk, dWi, dbi);
+    hipLaunchKernelGGL(ltae_compose_bwd_w_kernel, dim3(NH * DK + D + 1), dim3(256), 0, stream, Q, Wk, Wi, bias1, dA, dBp, sB, dgb, NH,
+                       DK, D, C, NF, T, dWk, dbk, dWi, dbi, gb);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

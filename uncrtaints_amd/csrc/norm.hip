@@ -265,82 +265,106 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(
 // and, with pw1's input a = A0*x + B0,   dW1[k,c] = sum_n A0[n,c]*R[n,k,c] + B0[n,c]*S[n,k].
 // S needs no pass either: du1n = c1*du1 + c2*h1 + c3  =>  S = c1*sum du1 + c2*sum h1 + c3*P, from the partial sums the
 // depthwise backward (part_b) and the forward pw1 GEMM (part_f) wrote.  fp64, fixed order.
-// Two launches: S (one wave per (n,k) plane), then N*C/32 statistics blocks + Ch*C/256 weight-gradient blocks.
+// One launch: the block of (4 rows k) x (32 columns c) reduces the weight-gradient GEMM's per-block partials to R itself (what a
+// separate reduction launch did before), frame by frame, derives the S values of its rows, and leaves dW1 and one statistics
+// partial per (n, c).  grid = (C/32, Ch/4) -- 256 blocks at the model's shape, the reduction is bound by what one CU can pull --,
+// block = 1024 = 32 c x 4 k x 8 slices of the partial range (latency-bound: loads in flight).
+// (Measured and dropped: one block per frame with the last of a tile's blocks adding the frames' terms.  The device-scope release
+// that pattern needs writes the XCD's L2 back; 35 us per launch against 20 us for the three launches this kernel replaces.)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prenorm_bwd_S_kernel(const float2* __restrict__ part_b, int NPB,
-                                                            const float2* __restrict__ part_f, int NPF,
-                                                            const float* __restrict__ c1, const float* __restrict__ c2,
-                                                            const float* __restrict__ c3, const float* __restrict__ cmu,
-                                                            int planes, int P, double* __restrict__ S) {
-    const int lane = threadIdx.x & 63;
-    const int pl = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pl >= planes) return;
-    double sb = 0.0, sf = 0.0;
-    for (int j = lane; j < NPB; j += 64) sb += (double)part_b[(size_t)pl * NPB + j].x;
-    if (part_f)
-        for (int j = lane; j < NPF; j += 64) sf += (double)part_f[(size_t)pl * NPF + j].x;
-    sb = wave_sum_d(sb);
-    sf = wave_sum_d(sf);
-    // cmu: centred coefficients, du1n = c1*du1 + c2*(h1 - mu) + c3
-    if (lane == 0)
-        S[pl] = (double)c1[pl] * sb + (double)c2[pl] * (sf - (cmu ? (double)cmu[pl] * (double)P : 0.0)) + (double)c3[pl] * (double)P;
-}
-
-__global__ __launch_bounds__(256) void prenorm_bwd_finish_kernel(
-    const float* __restrict__ R, const float* __restrict__ W1, const double* __restrict__ S,
-    const float* __restrict__ A0, const float* __restrict__ B0, float2* __restrict__ part0, float* __restrict__ dW1,
-    int N, int Ch, int C) {
-    const int tid = threadIdx.x;
-    const int nstat = N * (C / 32);
-    if ((int)blockIdx.x < nstat) {
-        // 32 channels x 8 slices of the k range; slices are combined in a fixed order
-        __shared__ double comb[2][256];
-        const int n = blockIdx.x / (C / 32), c = (blockIdx.x % (C / 32)) * 32 + (tid & 31), sl = tid >> 5;
-        const int k0 = (Ch * sl) / 8, k1 = (Ch * (sl + 1)) / 8;
-        const float* r = R + (size_t)n * Ch * C + c;
-        const double* s = S + (size_t)n * Ch;
-        double s1 = 0.0, s2 = 0.0;
-        int k = k0;
-        for (; k + 8 <= k1; k += 8) {
-            float w[8], rv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { w[q] = W1[(size_t)(k + q) * C + c]; rv[q] = r[(size_t)(k + q) * C]; }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { s1 += (double)w[q] * s[k + q]; s2 += (double)w[q] * (double)rv[q]; }
+__global__ __launch_bounds__(1024) void prenorm_bwd_finish_kernel(
+    const float* __restrict__ wpart, int nbx, int COP, int CIP, const float* __restrict__ W1,
+    const float2* __restrict__ part_b, int NPB, const float2* __restrict__ part_f, int NPF, const float* __restrict__ c1,
+    const float* __restrict__ c2, const float* __restrict__ c3, const float* __restrict__ cmu, const float* __restrict__ A0,
+    const float* __restrict__ B0, float2* __restrict__ part0, float* __restrict__ dW1, int N, int Ch, int C, int P) {
+    // four frames per round: their loads are all in flight before the round's first barrier
+    __shared__ double comb[4][8][128];
+    __shared__ double sS[4][4];
+    __shared__ double red[4][2][128];
+    __shared__ double dwt[4][128];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cl = tid & 31, kk = (tid >> 5) & 3, sl = tid >> 7, e = tid & 127;
+    const int c = blockIdx.x * 32 + cl, k = blockIdx.y * 4 + kk;
+    const int NP0 = Ch / 2;
+    const size_t SW = (size_t)COP * CIP;
+    const double w = (double)W1[(size_t)k * C + c];
+    double dw = 0.0;
+    for (int n0 = 0; n0 < N; n0 += 4) {
+        const int nf = min(4, N - n0);
+        {       // S of the block's four rows for the round's frames: one wave per plane, the lanes walk the partial slots
+            const int f = wv >> 2, r = wv & 3;
+            if (f < nf) {
+                const int pl = (n0 + f) * Ch + blockIdx.y * 4 + r;
+                double sb = 0.0, sf = 0.0;
+                for (int j = lane; j < NPB; j += 64) sb += (double)part_b[(size_t)pl * NPB + j].x;
+                if (part_f)
+                    for (int j = lane; j < NPF; j += 64) sf += (double)part_f[(size_t)pl * NPF + j].x;
+                sb = wave_sum_d(sb);
+                sf = wave_sum_d(sf);
+                // cmu: centred coefficients, du1n = c1*du1 + c2*(h1 - mu) + c3
+                if (lane == 0)
+                    sS[f][r] = (double)c1[pl] * sb + (double)c2[pl] * (sf - (cmu ? (double)cmu[pl] * (double)P : 0.0)) +
+                               (double)c3[pl] * (double)P;
+            }
         }
-        for (; k < k1; ++k) { const double w = W1[(size_t)k * C + c]; s1 += w * s[k]; s2 += w * (double)r[(size_t)k * C]; }
-        comb[0][tid] = s1; comb[1][tid] = s2;
+        {
+            const int b0 = (nbx * sl) / 8, b1 = (nbx * (sl + 1)) / 8;
+            for (int f = 0; f < nf; ++f) {
+                const float* src = wpart + (size_t)(n0 + f) * nbx * SW + (size_t)k * CIP + c;
+                double s = 0.0;
+                int b = b0;
+                for (; b + 8 <= b1; b += 8) {   // 8 independent loads in flight, summed in a fixed order
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(b + j) * SW];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s += (double)v[j];
+                }
+                for (; b < b1; ++b) s += (double)src[(size_t)b * SW];
+                comb[f][sl][e] = s;
+            }
+        }
         __syncthreads();
-        if (tid < 32) {
-            double a = 0.0, b = 0.0;
-            for (int q = 0; q < 8; ++q) { a += comb[0][q * 32 + tid]; b += comb[1][q * 32 + tid]; }
-            part0[(size_t)n * C + c] = make_float2((float)a, (float)b);
+        if (sl < nf) {      // slice index doubles as the frame of the round
+            const int f = sl, n = n0 + f;
+            double r = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r += comb[f][q][e];
+            const double R = (double)(float)r, S = sS[f][kk];
+            dwt[f][e] = (double)A0[n * C + c] * R + (double)B0[n * C + c] * S;
+            red[f][0][e] = w * S;
+            red[f][1][e] = w * R;
         }
-        return;
+        __syncthreads();
+        if (tid < 32 * nf) {
+            const int f = tid >> 5, n = n0 + f;
+            double a = 0.0, b = 0.0;
+            for (int q = 0; q < 4; ++q) { a += red[f][0][q * 32 + cl]; b += red[f][1][q * 32 + cl]; }
+            // each fp64 tile sum leaves as two fp32 slots (value and remainder): the finalize kernel adds the slots in fp64, so the
+            // cancellation in sum_k W1[k,c]*S[n,k] (exactly zero behind a BatchNorm) survives as it did when one block held all k
+            const float ah = (float)a, bh = (float)b;
+            float2* dst = part0 + ((size_t)n * C + c) * NP0 + 2 * blockIdx.y;
+            dst[0] = make_float2(ah, bh);
+            dst[1] = make_float2((float)(a - (double)ah), (float)(b - (double)bh));
+        }
+        if (sl == 0)
+            for (int f = 0; f < nf; ++f) dw += dwt[f][e];      // frame order
+        __syncthreads();    // red / dwt / comb are rewritten by the next round
     }
-    const int idx = ((int)blockIdx.x - nstat) * 256 + tid;
-    if (idx >= Ch * C) return;
-    const int k = idx / C, c = idx - k * C;
-    double a = 0.0;
-    for (int n = 0; n < N; ++n)
-        a += (double)A0[n * C + c] * (double)R[((size_t)n * Ch + k) * C + c] + (double)B0[n * C + c] * S[(size_t)n * Ch + k];
-    dW1[idx] = (float)a;
+    if (sl == 0) dW1[(size_t)k * C + c] = (float)dw;
 }
 
-// scratch: 2*N*Ch floats (holds S in fp64)
-extern "C" int uncr_prenorm_bwd_finish(const float* R, const float* W1, const float* part_b, int NPB,
-                                       const float* part_f, int NPF, const float* c1, const float* c2,
+extern "C" int uncr_prenorm_bwd_finish(const float* wpart, int nbx, int COP, int CIP, const float* W1, const float* part_b,
+                                       int NPB, const float* part_f, int NPF, const float* c1, const float* c2,
                                        const float* c3, const float* cmu, const float* A0, const float* B0, float* part0,
-                                       float* dW1, float* scratch, int N, int Ch, int C, int P, hipStream_t stream) {
-    if (N <= 0 || Ch <= 0 || (Ch & 7) || C <= 0 || (C & 31) || P <= 0) return UNCR_ESHAPE;
-    if (!R || !W1 || !part_b || NPB <= 0 || !c1 || !c2 || !c3 || !A0 || !B0 || !part0 || !dW1 || !scratch) return UNCR_EINVAL;
+                                       float* dW1, int N, int Ch, int C, int P, hipStream_t stream) {
+    if (N <= 0 || Ch <= 0 || (Ch & 3) || C <= 0 || (C & 31) || P <= 0 || nbx <= 0 || COP < Ch || CIP < C) return UNCR_ESHAPE;
+    if (!wpart || !W1 || !part_b || NPB <= 0 || !c1 || !c2 || !c3 || !A0 || !B0 || !part0 || !dW1) return UNCR_EINVAL;
     if (part_f && NPF <= 0) return UNCR_EINVAL;
     if (cmu && !part_f) return UNCR_EINVAL;      // the centred form needs sum h1
-    hipLaunchKernelGGL(prenorm_bwd_S_kernel, dim3((N * Ch + 3) / 4), dim3(256), 0, stream, (const float2*)part_b, NPB,
-                       (const float2*)part_f, NPF, c1, c2, c3, cmu, N * Ch, P, (double*)scratch);
-    UNCR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(prenorm_bwd_finish_kernel, dim3(N * (C / 32) + (Ch * C + 255) / 256), dim3(256), 0, stream, R, W1,
-                       (const double*)scratch, A0, B0, (float2*)part0, dW1, N, Ch, C);
+    hipLaunchKernelGGL(prenorm_bwd_finish_kernel, dim3(C / 32, Ch / 4), dim3(1024), 0, stream, wpart, nbx, COP, CIP, W1,
+                       (const float2*)part_b, NPB, (const float2*)part_f, NPF, c1, c2, c3, cmu, A0, B0, (float2*)part0, dW1, N, Ch,
+                       C, P);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

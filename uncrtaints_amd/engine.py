@@ -492,9 +492,10 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
 
 def pw_wgrad(d: Tensor, x: Tensor, N: int, Cd: int, Cx: int, P: int, *, pro_d: int = PRO_NONE, dk=(None, None, None),
              d2: Optional[Tensor] = None, pro_x: int = PRO_NONE, xk=(None, None, None), x2: Optional[Tensor] = None,
-             per_frame: bool = False, rowsum: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+             per_frame: bool = False, rowsum: bool = False, partials: bool = False):
     """dW[co,ci] = sum_{n,p} fD(d)[n,co,p] * fX(x)[n,ci,p]  (-> [Cd,Cx], or [N,Cd,Cx] if per_frame);
-    optionally also rowsum[co] = sum_{n,p} fD(d)."""
+    optionally also rowsum[co] = sum_{n,p} fD(d).  partials: the per-block partials themselves, (part [N*nbx, cop, cip], nbx, cop,
+    cip), for a consumer that reduces them on the way (uncr_prenorm_bwd_finish)."""
     import ctypes
     cop, cip = ctypes.c_int(), ctypes.c_int()
     if hb.lib().cdll.uncr_wgrad_shape(Cd, Cx, ctypes.byref(cop), ctypes.byref(cip)) < 0:
@@ -511,6 +512,8 @@ def pw_wgrad(d: Tensor, x: Tensor, N: int, Cd: int, Cx: int, P: int, *, pro_d: i
     rs_part = _f32((N * nbx, cop), dev) if rowsum else None
     hb.call("uncr_pw_wgrad", d, d2, x, x2, dk[0], dk[1], dk[2], dk[3] if len(dk) > 3 else None, xk[0], xk[1], xk[2], part,
             rs_part, N, Cd, Cx, P, nbx, pro_d, pro_x, act, _stream())
+    if partials:
+        return part, nbx, cop, cip
     n_out = N if per_frame else 1
     dW = _f32((n_out, Cd, Cx), dev)
     hb.call("uncr_wgrad_reduce", part, n_out, (N * nbx) // n_out, cop, cip, Cd, Cx, dW, _stream())
@@ -680,14 +683,14 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         # that exist already (uncr_prenorm_bwd_finish).  The PreNorm backward coefficients are therefore known before the
         # data GEMM, whose epilogue writes dx = dy + c1*da + c2*x + c3 (and the producing block's norm-3 statistics).
         one, zero = _const_planes(dev, N * C)
-        Rf, _ = pw_wgrad(du1, x, N, Ch, C, P, pro_d=PRO_NORMBWD, dk=k1, d2=h1, pro_x=PRO_AFFINE, xk=(one, zero, None),
-                         per_frame=True)
-        part0 = Part(_f32((N * C, 1, 2), dev), 1)
+        wpart, nbx, cop, cip = pw_wgrad(du1, x, N, Ch, C, P, pro_d=PRO_NORMBWD, dk=k1, d2=h1, pro_x=PRO_AFFINE,
+                                        xk=(one, zero, None), partials=True)
+        part0 = Part(_f32((N * C, Ch // 2, 2), dev), Ch // 2)
         dW1 = _f32((Ch, C), dev)
         pf = sv.get("part1f")
-        hb.call("uncr_prenorm_bwd_finish", Rf, p["w1"].reshape(Ch, C).contiguous(), part1.buf, part1.slots,
+        hb.call("uncr_prenorm_bwd_finish", wpart, nbx, cop, cip, p["w1"].reshape(Ch, C).contiguous(), part1.buf, part1.slots,
                 pf.buf if pf is not None else None, pf.slots if pf is not None else 0, k1[0], k1[1], k1[2],
-                k1[3] if pf is not None else None, n0.A, n0.B, part0.buf, dW1, _f32((2 * N * Ch,), dev), N, Ch, C, P, _stream())
+                k1[3] if pf is not None else None, n0.A, n0.B, part0.buf, dW1, N, Ch, C, P, _stream())
         g["w1"] = dW1.view_as(p["w1"])
         b0 = norm_bwd(part0, N, C, P, n0, p["n0w"])
         g["n0w"], g["n0b"] = b0.dgamma, b0.dbeta
@@ -962,13 +965,12 @@ def ltae_attention_forward_fused(down: Tensor, dates: Optional[Tensor], pad: Opt
     NF = B * T
     use_pe = denom is not None
     bias1 = _f32((NF, D), dev)
-    hb.call("uncr_ltae_posbias", dates.reshape(-1).contiguous().float() if use_pe else None,
-            denom if use_pe else None, denom.numel() if use_pe else 0, p["inconv_b"], bias1, NF, D,
-            1 if use_pe else 0, _stream())
     Ap, Bp, M, U = _f32((n_head, C), dev), _f32((n_head, NF), dev), _f32((HK, C), dev), _f32((HK, NF), dev)
     Wi, Wk = p["inconv_w"].reshape(D, C).contiguous(), p["fc_w"].contiguous()
-    hb.call("uncr_ltae_compose", p["Q"].contiguous(), Wk, p["fc_b"].contiguous(), Wi, bias1, p["in_norm_w"], p["in_norm_b"],
-            n_head, d_k, D, C, NF, Ap, Bp, M, U, _stream())
+    hb.call("uncr_ltae_compose", p["Q"].contiguous(), Wk, p["fc_b"].contiguous(), Wi, p["inconv_b"],
+            dates.reshape(-1).contiguous().float() if use_pe else None, denom if use_pe else None,
+            denom.numel() if use_pe else 0, 1 if use_pe else 0, p["in_norm_w"], p["in_norm_b"], n_head, d_k, D, C, NF, bias1, Ap, Bp,
+            M, U, _stream())
     att = _f32((n_head, B, T, ah, aw), dev)
     mean, rstd = _f32((B, n_head, S), dev), _f32((B, n_head, S), dev)
     hb.call("uncr_ltae_fused_fwd", down, Ap, Bp, pad, 1e-5, att, mean, rstd, B, T, C, n_head, S, _stream())
@@ -989,17 +991,14 @@ def ltae_attention_backward_fused(datt: Tensor, sv: dict, p: Dict[str, Tensor], 
             partA, partB, B, T, C, n_head, S, _stream())
     # everything from here on only feeds parameter gradients: a side chain next to the pooled-gradient scatter (ltae_stage_backward
     # joins it).  Outputs are allocated first, on the current stream.
-    dAp, dBp = _f32((n_head, C), dev), _f32((B, n_head, T), dev)
-    dA, dQ = _f32((n_head * C + n_head,), dev), _f32((n_head, d_k), dev)      # dA: scratch [NH][C] + [NH]
+    dQ = _f32((n_head, d_k), dev)
+    scratch = _f32((n_head * C + n_head + NF * n_head + n_head * 2 * C,), dev)
     dWk, dbk, dWi, dbi = _f32((HK, D), dev), _f32((HK,), dev), _f32((D, C), dev), _f32((D,), dev)
-    dgb, gb = _f32((n_head, 2, C), dev), _f32((2 * C,), dev)
+    gb = _f32((2 * C,), dev)
     Wi, Wk, Q = p["inconv_w"].reshape(D, C).contiguous(), p["fc_w"].contiguous(), p["Q"].contiguous()
     with side_chain(partA, partB, Wi, Wk, Q):
-        hb.call("uncr_colsum", partA, B * nblk, n_head * C, dAp, _stream())
-        hb.call("uncr_colsum_batched", partB, B, nblk, n_head * T, dBp, _stream())      # d B' per sample: the blocks of sample b
-        hb.call("uncr_ltae_compose_bwd", Q, Wk, Wi, sv["bias1"], p["in_norm_w"], p["in_norm_b"], sv["M"], sv["U"],
-                dAp, dBp, n_head, d_k, D, C, NF, T, dA, dQ, dWk, dbk, dWi, dbi, dgb, _stream())
-        hb.call("uncr_colsum", dgb, n_head, 2 * C, gb, _stream())
+        hb.call("uncr_ltae_compose_bwd", Q, Wk, Wi, sv["bias1"], p["in_norm_w"], p["in_norm_b"], sv["M"], sv["U"], partA, partB,
+                nblk, n_head, d_k, D, C, NF, T, scratch, dQ, dWk, dbk, dWi, dbi, gb, _stream())
     g = dict(Q=dQ, fc_w=dWk, fc_b=dbk, inconv_w=dWi.view_as(p["inconv_w"]), inconv_b=dbi, in_norm_w=gb[:C], in_norm_b=gb[C:])
     return ddown, g
 
