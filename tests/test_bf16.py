@@ -268,9 +268,10 @@ def _state(g, prefix="state/"):
     return {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
 
 
-def _build(state, act):
+def _build(state, act, **widths):
     from uncrtaints_amd.src.backbones import uncrtaints as U
-    m = U.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag", scale_by=1.0)
+    m = U.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag", scale_by=1.0,
+                     **widths)
     m.load_state_dict(state, strict=True)
     m.temporal_aggregator.attn_dropout.p = 0.0
     return m.to(DEV).set_act_dtype(act)
@@ -293,9 +294,9 @@ def _grad_report(tag, grads, ref, zero_ref):
     return worst_l2, worst_cos
 
 
-def _hip_bf16_step(state, x, y, dates):
+def _hip_bf16_step(state, x, y, dates, **widths):
     from uncrtaints_amd.src import losses
-    m = _build(state, BF)
+    m = _build(state, BF, **widths)
     m.train()
     xg = dev(x).requires_grad_(True)
     out = m(xg, batch_positions=dev(dates))
@@ -307,7 +308,8 @@ def _hip_bf16_step(state, x, y, dates):
     return out.detach().cpu(), l.item(), xg.grad.cpu(), {k: p.grad for k, p in m.named_parameters()}
 
 
-def test_model_bf16_vs_fp32_oracle():
+@pytest.mark.parametrize("widths", [{}, dict(encoder_widths=[64], decoder_widths=[64, 64])], ids=["baseline", "w64"])
+def test_model_bf16_vs_fp32_oracle(widths):
     """The model-level contract of the bf16 mode, on a seeded default-initialised network (B=2, T=3, 64x64), forward + MGNLL +
     backward, against (a) the fp32 CPU oracle -- the cost of bf16 storage -- and (b) the oracle with the SAME roundings emulated
     at the same tensors, forward and backward (OracleConfig.act_bf16; oracle.mbconv lists them).
@@ -315,23 +317,24 @@ def test_model_bf16_vs_fp32_oracle():
     order, 1e-6) ahead of a bf16 rounding tips it for about one element in two thousand, that element moves by 2^-8 of itself, and
     the perturbation travels on through 3x3 stencils and batch statistics.  The emulation measures its own sensitivity to exactly
     that -- the same emulated run with the weights perturbed by 1e-6 relative -- and the HIP path has to stay within 2 x that
-    self-distance of the emulation (and inside absolute caps)."""
+    self-distance of the emulation (and inside absolute caps).  `w64`: the same contract away from the BASELINE widths (64-wide blocks:
+    the narrow GEMM and weight-gradient kernels with bf16 storage on both sides)."""
     from gpu_util import oracle_run
     from oracle import uncrtaints_oracle as orc
     from uncrtaints_amd.src.backbones import uncrtaints as U
     torch.manual_seed(3)
     state = {k: v.clone() for k, v in U.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus",
-                                                  covmode="diag", scale_by=1.0).state_dict().items()}
+                                                  covmode="diag", scale_by=1.0, **widths).state_dict().items()}
     x, y, dates = orc.synthetic_batch(2, 3, 64, 64, seed=5)
-    out_o, loss_o, dx_o, g_o, _ = oracle_run(state, x, y, dates, orc.OracleConfig(attn_dropout=0.0), torch.float32)
-    _, _, _, g64, _ = oracle_run(state, x, y, dates, orc.OracleConfig(attn_dropout=0.0), torch.float64)
-    emu = orc.OracleConfig(attn_dropout=0.0, act_bf16=True)
+    out_o, loss_o, dx_o, g_o, _ = oracle_run(state, x, y, dates, orc.OracleConfig(attn_dropout=0.0, **widths), torch.float32)
+    _, _, _, g64, _ = oracle_run(state, x, y, dates, orc.OracleConfig(attn_dropout=0.0, **widths), torch.float64)
+    emu = orc.OracleConfig(attn_dropout=0.0, act_bf16=True, **widths)
     out_e, loss_e, dx_e, g_e, _ = oracle_run(state, x, y, dates, emu, torch.float32)
     gen = torch.Generator().manual_seed(9)
     state_p = {k: (v * (1.0 + 1e-6 * torch.randn(v.shape, generator=gen)) if v.dtype.is_floating_point and "running" not in k else v.clone())
                for k, v in state.items()}
     out_p, loss_p, dx_p, g_p, _ = oracle_run(state_p, x, y, dates, emu, torch.float32)
-    out, loss, dx, grads = _hip_bf16_step(state, x, y, dates)
+    out, loss, dx, grads = _hip_bf16_step(state, x, y, dates, **widths)
     from gpu_util import is_zero_grad
     l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
     self_out = float((out_p - out_e).abs().max() / out_e.abs().max())
@@ -433,9 +436,11 @@ def test_bf16_mode_refuses_what_is_not_built():
     m = U.UNCRTAINTS(input_dim=15, out_conv=[26], covmode="diag", out_nonlin_var="softplus", block_type="residual")
     with pytest.raises(NotImplementedError):
         m.set_act_dtype(torch.bfloat16)
-    m = U.UNCRTAINTS(input_dim=15, out_conv=[26], covmode="diag", out_nonlin_var="softplus", encoder_widths=[64],
-                     decoder_widths=[64, 64])
+    m = U.UNCRTAINTS(input_dim=15, out_conv=[26], covmode="diag", out_nonlin_var="softplus", use_v=True)
     with pytest.raises(NotImplementedError):
         m.set_act_dtype("bf16")
+    m = U.UNCRTAINTS(input_dim=15, out_conv=[26], covmode="diag", out_nonlin_var="softplus", encoder_widths=[64],
+                     decoder_widths=[64, 64])
+    assert m.set_act_dtype("bf16").act_dtype == torch.bfloat16        # any width the fp32 path takes
     with pytest.raises(ValueError):
         m.set_act_dtype(torch.float16)

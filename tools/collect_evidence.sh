@@ -13,4 +13,5 @@ cp gpurun_out/${tag}_bench_fp32.json profiles/${tag}_bench_fp32.json
 cp gpurun_out/${tag}_bench_bf16.json profiles/${tag}_bench_bf16.json
 cp gpurun_out/${tag}_fp32_kernel_stats.csv profiles/${tag}_kernel_stats_fp32.csv
 cp gpurun_out/${tag}_bf16_kernel_stats.csv profiles/${tag}_kernel_stats_bf16.csv
+cp gpurun_out/${tag}_launches.json profiles/${tag}_launches.json
 ls -la profiles | grep " ${tag}_"

@@ -546,19 +546,20 @@ extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, vo
             default: return UNCR_EINVAL;
         }
     }
-    // fp32-MFMA kernels: fp32 storage, or bf16 inputs with fp32 outputs (the narrow shapes: Cout <= 64)
-    if (out_dt != UNCR_F32 || (in_dt == UNCR_BF16 && cp > 64)) return UNCR_EINVAL;
+    // fp32-MFMA kernels (Cout <= 64): fp32 storage, bf16 inputs with fp32 outputs (head-like layers), or bf16 on both sides
+    if (in_dt == UNCR_F32 && out_dt != UNCR_F32) return UNCR_EINVAL;
     dim3 grid(P / tp, N);
-    if (cp == 64) {
-        if (in_dt == UNCR_BF16) hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true, bf16_t, float>), grid, dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true>), grid, dim3(256), 0, stream, g);
-    } else if (pro == PRO_NORMBWD) {
-        if (in_dt == UNCR_BF16) hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, true, bf16_t, float>), grid, dim3(128), 0, stream, g);
-        else hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, true>), grid, dim3(128), 0, stream, g);
-    } else {
-        if (in_dt == UNCR_BF16) hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false, bf16_t, float>), grid, dim3(128), 0, stream, g);
-        else hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false>), grid, dim3(128), 0, stream, g);
-    }
+#define PW_GO(CT_, WN_, WM_, PRE2_, THREADS)                                                                                     \
+    do {                                                                                                                         \
+        if (in_dt == UNCR_F32) hipLaunchKernelGGL((pw_gemm_kernel<CT_, WN_, WM_, PRE2_>), grid, dim3(THREADS), 0, stream, g);     \
+        else if (out_dt == UNCR_F32)                                                                                             \
+            hipLaunchKernelGGL((pw_gemm_kernel<CT_, WN_, WM_, PRE2_, bf16_t, float>), grid, dim3(THREADS), 0, stream, g);         \
+        else hipLaunchKernelGGL((pw_gemm_kernel<CT_, WN_, WM_, PRE2_, bf16_t, bf16_t>), grid, dim3(THREADS), 0, stream, g);       \
+    } while (0)
+    if (cp == 64) PW_GO(1, 2, 2, true, 256);
+    else if (pro == PRO_NORMBWD) PW_GO(1, 1, 2, true, 128);
+    else PW_GO(1, 1, 2, false, 128);
+#undef PW_GO
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -667,8 +668,7 @@ extern "C" int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const
     g.dk3 = pro_d == PRO_NORMBWD ? dkmu : nullptr;
     dim3 grid(P / PXB, N);
     const size_t lds = (size_t)((cop + cip) * 36 + 4 * cop + 3 * cip) * sizeof(float);
-    // bf16 operands on the fp32-MFMA kernels: the narrow shapes of the path only (in_conv 128 x 15, head 26 x 128)
-    if (act == UNCR_BF16 && shp != 2 && shp != 3) return UNCR_EINVAL;
+    // bf16 operands on the fp32-MFMA kernels: every shape the two bf16-product kernels above do not take
     switch (shp) {
 #define WG_LAUNCH_T(MT_, NT_, WCO_, WCI_, THREADS, TD, TX)                                                                 \
     if (pro_d == PRO_NORMBWD)                                                                                              \
@@ -680,16 +680,16 @@ extern "C" int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const
     if (act == UNCR_BF16) { WG_LAUNCH_T(MT_, NT_, WCO_, WCI_, THREADS, bf16_t, bf16_t) }       \
     else { WG_LAUNCH_T(MT_, NT_, WCO_, WCI_, THREADS, float, float) }                          \
     break;
-        case 0: WG_LAUNCH(2, 4, 4, 1, 256)
-        case 1: WG_LAUNCH(2, 4, 2, 2, 256)
+        case 0: WG_LAUNCH_AB(2, 4, 4, 1, 256)
+        case 1: WG_LAUNCH_AB(2, 4, 2, 2, 256)
         case 2: WG_LAUNCH_AB(1, 1, 4, 1, 256)
         case 3: WG_LAUNCH_AB(1, 1, 1, 4, 256)
-        case 4: WG_LAUNCH(2, 4, 1, 2, 128)
-        case 5: WG_LAUNCH(1, 4, 1, 2, 128)
-        case 6: WG_LAUNCH(2, 4, 1, 1, 64)
-        case 7: WG_LAUNCH(1, 1, 1, 1, 64)
-        case 8: WG_LAUNCH(2, 1, 1, 1, 64)
-        case 9: WG_LAUNCH(2, 1, 4, 1, 256)
+        case 4: WG_LAUNCH_AB(2, 4, 1, 2, 128)
+        case 5: WG_LAUNCH_AB(1, 4, 1, 2, 128)
+        case 6: WG_LAUNCH_AB(2, 4, 1, 1, 64)
+        case 7: WG_LAUNCH_AB(1, 1, 1, 1, 64)
+        case 8: WG_LAUNCH_AB(2, 1, 1, 1, 64)
+        case 9: WG_LAUNCH_AB(2, 1, 4, 1, 256)
 #undef WG_LAUNCH
 #undef WG_LAUNCH_AB
 #undef WG_LAUNCH_T

@@ -544,8 +544,6 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     need = spec.needs_stats(training)
     buffers = buffers or {}
     dt = _dt(x)
-    if dt == BF16 and (C != 128 or Ch != 256):
-        raise NotImplementedError("bf16 activations are built for the BASELINE widths (MBConv 128 -> 256 -> 128)")
 
     def rm(i):
         return buffers.get(f"n{i}rm"), buffers.get(f"n{i}rv")

@@ -553,8 +553,6 @@ class UNCRTAINTS(nn.Module):
         if dtype == torch.bfloat16:
             if self.block_type != 'mbconv' or self.use_v:
                 raise NotImplementedError("bf16 activations are built for block_type='mbconv' without use_v")
-            if any(w != 128 for w in list(self.encoder_widths) + list(self.decoder_widths or [])):
-                raise NotImplementedError("bf16 activations are built for the BASELINE widths (128)")
             if self.out_dims > 64:
                 raise NotImplementedError("bf16 activations: out_conv wider than 64 channels is not built")
         self.act_dtype = dtype
