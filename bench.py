@@ -50,11 +50,14 @@ def kernel_model(name, key):
         planes, H, W, OH, OW, act = key[-6:]
         return (f"residual_pool[planes{planes},{H}x{W}]", (2.0 if act else 4.0) * planes * H * W * 3, 0.0, 0)
     if name == "uncr_pw_wgrad":
-        N, Cd, Cx, P, PXB, pro_d, pro_x, act = key
+        N, Cd, Cx, P, PXB, pro_d, pro_x, act = key[:8]       # (then the counts of the two magnitude arrays)
         rd = Cd * (2 if pro_d == PRO_NORMBWD else 1) + Cx * (2 if pro_x == PRO_NORMBWD else 1)
         wide = (Cd, Cx) in ((128, 256), (256, 128))
-        return (f"pw_wgrad[{Cd}x{Cx},N{N},P{P}]", (2.0 if act else 4.0) * N * P * rd, 2.0 * N * P * Cd * Cx,
-                (1 if act else 6) if wide else 0)
+        # products per fp32 MAC: 1 with bf16 storage, 3 when the call carried its operands' magnitude bounds (two row-scaled fp16
+        # parts: MBConv's dW2 products), 6 for the exact bf16 split
+        h2 = (not act) and len(key) > 9 and key[8] > 0 and key[9] > 0
+        return (f"pw_wgrad[{Cd}x{Cx},N{N},P{P}]" + (",fp16x2" if h2 else ""), (2.0 if act else 4.0) * N * P * rd, 2.0 * N * P * Cd * Cx,
+                (1 if act else (3 if h2 else 6)) if wide else 0)
     if name == "uncr_dw_fwd":
         N, C, H, W, act = key[:5]
         return (f"dw_fwd[N{N},C{C},{H}x{W}]", (2.0 if act else 4.0) * N * C * H * W * 2, 18.0 * N * C * H * W, 0)
@@ -413,6 +416,17 @@ def main():
     else:
         prof_steps = args.steps
     final_loss = float(loss.item())
+    # the step is fwd + MGNLL + bwd, "optimizer step reported separately".  The timed step above INCLUDES the Adam
+    # update (the number a training run sees); its own cost is measured here, eagerly, with HIP events on the current stream.
+    opt_ms = None
+    if world == 1 and not args.no_kernel_events:      # (at N > 1 the update is its own captured graph behind the all-reduces)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        opt.step(); fence()
+        e0.record()
+        for _ in range(10):
+            opt.step()
+        e1.record(); fence()
+        opt_ms = e0.elapsed_time(e1) / 10
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -433,6 +447,8 @@ def main():
                                 wait_ms_max=round(max(coll_wait), 4) if coll_wait else None) if dp is not None else None),
             "final_loss": final_loss, "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
             "launch_mode": graph_note,
+            "optimizer": {"kind": "torch.optim.Adam(fused, capturable)", "included_in_step": True,
+                          "ms_per_step_eager": None if opt_ms is None else round(opt_ms, 4)},
             "step_hbm_roofline_frac": round(value / world * a_step_bytes(T, H * H, bf16) / 1e9 / HBM_PEAK_GBS, 4),
         }
         if prof is not None:

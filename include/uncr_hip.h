@@ -182,12 +182,17 @@ int uncr_prenorm_bwd_finish(const float* wpart, int nbx, int COP, int CIP, const
                             int P, hipStream_t stream);
 int uncr_wgrad_shape(int Cd, int Cx, int* cop, int* cip);
 /* act: storage of d, d2, x.  bf16: the two wide shapes (256 x 128, 128 x 256) run one bf16 x bf16 product per MAC with fp32
- * accumulation (P % 64 == 0), the narrow shapes of the path (in_conv 128 x 15, head 26 x 128) the fp32 MFMA kernels. */
+ * accumulation (P % 64 == 0), every other shape the fp32 MFMA kernels.
+ * fp32 storage, 128 x 256 with a norm-backward d and an affine + GELU x (MBConv's dW2): when the per-block maxima of |d| and
+ * |d2| (d_amax [N][d_amax_n], d2_amax [N][d2_amax_n]: what the producers' amax_out left) and the per-plane bounds on x's affine
+ * input (x_ub [N*Cx], uncr_norm_finalize_fwd's ub) are all given, the operands are staged as two row-scaled fp16 parts (three
+ * products); with any of them null, as the exact three-part bf16 split (six products). */
 int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const void* x2, const float* dk0,
                   const float* dk1, const float* dk2, const float* dkmu /* PRO_NORMBWD on d: mean array or null */,
                   const float* xk0, const float* xk1, const float* xk2,
                   float* part /* [N*NBX][COP][CIP] */, float* rs_part, int N, int Cd, int Cx, int P,
                   int NBX /* blocks (partials) per frame, from uncr_wgrad_nbx */, int pro_d, int pro_x, int act,
+                  const float* d_amax, int d_amax_n, const float* d2_amax, int d2_amax_n, const float* x_ub,
                   hipStream_t stream);
 int uncr_wgrad_nbx(int N, int Cd, int Cx, int P, int pro_d, int pro_x, int rowsum, int act);
 int uncr_wgrad_reduce(const float* part, int n_out, int nblk_per_out, int COP, int CIP, int Cout, int Cin,

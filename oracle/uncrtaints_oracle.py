@@ -245,8 +245,11 @@ def mbconv(x: Tensor, p: Dict[str, Tensor], prefix: str, norm: str, training: bo
     # operands a, z (rounded ahead of the matrix pipe); backward: the stored gradients dx (block input, skip and PreNorm path summed
     # first), du1 and du2 (gradients of the two norm OUTPUTS u1, u2: written by the depthwise backward / the dz GEMM's epilogue) and
     # the gradient-GEMM operands dh1, dh3 (norm backward of (du1, h1) / (dy, h3), rounded ahead of the matrix pipe).  The gradients
-    # of a, h2 and z exist in registers only (fp32).
-    a = _store(nrm(x, prefix + ".conv.norm"), bf16, grad=False)         # PreNorm (uncrtaints.py:72-79,140)
+    # of a, h2 and z exist in registers only (fp32) -- except that blocks outside 64 < C <= 128 run pw1's backward unfused on the HIP
+    # path (uncr_pw_gemm_dx_supported): there the gradient of a is a stored tensor, rounded like the others.
+    C, Ch = x.shape[1], p[prefix + ".conv.fn.0.weight"].shape[0]
+    da_in_registers = 64 < C <= 128 and Ch <= 256 and C % 32 == 0 and Ch % 8 == 0
+    a = _store(nrm(x, prefix + ".conv.norm"), bf16, grad=not da_in_registers)         # PreNorm (uncrtaints.py:72-79,140)
     h1 = _store(conv1x1(a, p[prefix + ".conv.fn.0.weight"]), bf16)      # pw 128->256
     g1 = gelu_exact(_ground(nrm(h1, prefix + ".conv.fn.1"), bf16))
     h2 = _store(depthwise3x3_reflect(g1, p[prefix + ".conv.fn.3.weight"]), bf16, grad=False)      # dw 3x3 reflect

@@ -330,16 +330,18 @@ def test_model_bf16_vs_fp32_oracle(widths):
     _, _, _, g64, _ = oracle_run(state, x, y, dates, orc.OracleConfig(attn_dropout=0.0, **widths), torch.float64)
     emu = orc.OracleConfig(attn_dropout=0.0, act_bf16=True, **widths)
     out_e, loss_e, dx_e, g_e, _ = oracle_run(state, x, y, dates, emu, torch.float32)
-    gen = torch.Generator().manual_seed(9)
-    state_p = {k: (v * (1.0 + 1e-6 * torch.randn(v.shape, generator=gen)) if v.dtype.is_floating_point and "running" not in k else v.clone())
-               for k, v in state.items()}
-    out_p, loss_p, dx_p, g_p, _ = oracle_run(state_p, x, y, dates, emu, torch.float32)
     out, loss, dx, grads = _hip_bf16_step(state, x, y, dates, **widths)
     from gpu_util import is_zero_grad
     l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
-    self_out = float((out_p - out_e).abs().max() / out_e.abs().max())
-    self_dx = l2(dx_p, dx_e)
-    self_g = max(l2(g_p[k], g_e[k]) for k in g_e if not is_zero_grad(k, g64))
+    self_out = self_dx = self_g = 0.0
+    for seed in (9, 10, 11):        # the tie-flip distance is a random quantity: the largest of three draws
+        gen = torch.Generator().manual_seed(seed)
+        state_p = {k: (v * (1.0 + 1e-6 * torch.randn(v.shape, generator=gen)) if v.dtype.is_floating_point and "running" not in k else v.clone())
+                   for k, v in state.items()}
+        out_p, loss_p, dx_p, g_p, _ = oracle_run(state_p, x, y, dates, emu, torch.float32)
+        self_out = max(self_out, float((out_p - out_e).abs().max() / out_e.abs().max()))
+        self_dx = max(self_dx, l2(dx_p, dx_e))
+        self_g = max(self_g, max(l2(g_p[k], g_e[k]) for k in g_e if not is_zero_grad(k, g64)))
     print(f"[bf16] emulation vs itself under a 1e-6 weight perturbation: out {self_out:.2e}, dx rel L2 {self_dx:.2e}, worst gradient rel L2 {self_g:.2e}")
     for tag, ro, rl, rdx, rg, t_out, t_loss, t_l2, t_cos in (
             ("vs fp32 oracle", out_o, loss_o, dx_o, g_o, 4e-2, 5e-3, 1.5e-1, 0.99),

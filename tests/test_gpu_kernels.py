@@ -979,6 +979,53 @@ def test_fp16_two_part_forward_gemm_accuracy(E, Cin, Cout, pro):
 
 
 @pytest.mark.gpu
+def test_fp16_two_part_weight_gradient_accuracy(E):
+    """MBConv's dW2 products (norm-backward rows x GELU rows, 128 x 256) take two ROW-scaled fp16 parts and three products when the
+    maxima of both norm-backward operands and the bounds on the GELU's affine input are passed (uncr_pw_wgrad), the exact 3 x bf16
+    split otherwise.  Against fp64, per output element relative to its row's and column's operand norms, both stay at the level of an
+    fp32 accumulation -- for operands from 1e-6 to 1e6, rows of different magnitude, and loose bounds."""
+    torch.manual_seed(7)
+    N, Cd, Cx, P = 2, 128, 256, 4096
+    d0, d20, x0 = torch.randn(N, Cd, P), torch.randn(N, Cd, P) * 0.7 + 0.3, torch.randn(N, Cx, P) * 1.1 + 0.1
+    k = [torch.randn(N * Cd), torch.randn(N * Cd) * 0.3, torch.randn(N * Cd) * 0.1, torch.randn(N * Cd) * 0.2]
+    xA, xB = torch.rand(N * Cx) + 0.5, torch.randn(N * Cx) * 0.3
+
+    def run(d, d2, x, k, xA, xB, label, slack=1.0):
+        fd = (k[0].view(N, Cd, 1).double() * d.double() + k[1].view(N, Cd, 1).double() * (d2.double() - k[3].view(N, Cd, 1).double())
+              + k[2].view(N, Cd, 1).double())
+        u = xA.view(N, Cx, 1).double() * x.double() + xB.view(N, Cx, 1).double()
+        fx = torch.nn.functional.gelu(u)
+        truth = torch.einsum("nop,ncp->noc", fd, fx)
+        scale = torch.einsum("no,nc->noc", fd.norm(dim=2), fx.norm(dim=2)).clamp_min(1e-300)       # Cauchy-Schwarz size of each element
+        d_amax = (d.abs().amax(dim=(1, 2)) * slack).view(N, 1).repeat(1, 3).contiguous()       # per-block maxima: any layout [N][n]
+        d2_amax = (d2.abs().amax(dim=(1, 2)) * slack).view(N, 1).contiguous()
+        x_ub = ((xA.view(N, Cx).abs() * x.abs().amax(dim=2) + xB.view(N, Cx).abs()) * slack).reshape(-1)
+        errs = {}
+        for name, bounds in (("fp16x2", dict(d_amax=dev(d_amax.float()), d2_amax=dev(d2_amax.float()), x_ub=dev(x_ub.float()))), ("bf16x3", {})):
+            G, _ = E.pw_wgrad(dev(d), dev(x), N, Cd, Cx, P, pro_d=3, dk=tuple(dev(t) for t in k), d2=dev(d2), pro_x=2,
+                              xk=(dev(xA), dev(xB), None), per_frame=True, **bounds)
+            errs[name] = float(((G.double().cpu() - truth).abs() / scale).max())
+        print(f"[parity] dW2 products {label}: fp16 two-part {errs['fp16x2']:.2e}, bf16 three-part {errs['bf16x3']:.2e}")
+        assert max(errs.values()) <= 1e-6, (label, errs)
+
+    run(d0, d20, x0, k, xA, xB, "ordinary")
+    for sc in (1e-6, 1e-3, 1e3, 1e6):
+        run(d0 * sc, d20 * sc, x0, [k[0], k[1], k[2] * sc, k[3] * sc], xA, xB, f"|d|~{sc:g}")
+        run(d0, d20, x0 * sc, k, xA, xB * sc, f"|x|~{sc:g}")
+    rows = 10.0 ** (torch.rand(N * Cd) * 10 - 5)
+    run(d0, d20, x0, [k[0] * rows, k[1] * rows, k[2] * rows, k[3]], xA, xB, "rows 1e-5..1e5")
+    run(d0, d20, x0, k, xA, xB, "bounds 1000x loose", slack=1000.0)
+    # a NaN in one frame stays in that frame's products
+    db = d0.clone()
+    db[0, 3, 7] = float("nan")
+    G, _ = E.pw_wgrad(dev(db), dev(x0), N, Cd, Cx, P, pro_d=3, dk=tuple(dev(t) for t in k), d2=dev(d20), pro_x=2,
+                      xk=(dev(xA), dev(xB), None), per_frame=True, d_amax=dev(db.abs().amax(dim=(1, 2)).view(N, 1)),
+                      d2_amax=dev(d20.abs().amax(dim=(1, 2)).view(N, 1)),
+                      x_ub=dev((xA.view(N, Cx).abs() * x0.abs().amax(dim=2) + xB.view(N, Cx).abs()).reshape(-1)))
+    assert bool(torch.isnan(G[0, 3]).all()) and bool(torch.isfinite(G[1]).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind,training", [("group", True), ("batch", True), ("batch", False)])
 def test_norm_finalize_emits_valid_activation_bounds(E, kind, training):
     """uncr_norm_finalize_fwd's `ub` output: a rigorous per-plane upper bound on |A*h + B| taken from the partial sums of squares

@@ -125,7 +125,9 @@ def main():
         dk = tuple(torch.randn(N * 256, device=dev) for _ in range(3)); xk = (torch.randn(N * 128, device=dev), torch.randn(N * 128, device=dev), None)
         for _ in range(3):
             E.pw_wgrad(d, xx, N, 256, 128, P, pro_d=3, dk=dk, d2=d2, pro_x=1, xk=xk)
-            E.pw_wgrad(xx, d, N, 128, 256, P, pro_d=3, dk=tuple(t[:N * 128] for t in dk), d2=x2, pro_x=2, xk=(k2f[0], k2f[1], None))
+            wb = {} if bf else dict(d_amax=amax(xx), d2_amax=amax(x2), x_ub=(k2f[0].view(N, 256) * d.float().abs().amax(dim=2)
+                                                                          + k2f[1].view(N, 256)).reshape(-1).contiguous())
+            E.pw_wgrad(xx, d, N, 128, 256, P, pro_d=3, dk=tuple(t[:N * 128] for t in dk), d2=x2, pro_x=2, xk=(k2f[0], k2f[1], None), **wb)
         # backward of pw1 with the PreNorm backward + skip epilogue (uncr_pw_gemm_dx, with the producer's statistics)
         W1k = E.pack_wt(torch.randn(256, 128, device=dev) * 0.05, transpose=False)
         dy, xh3 = ta(N, 128, P), ta(N, 128, P)

@@ -108,7 +108,8 @@ int pw_wgrad_split_nbx(int N, int P);
 bool pw_wgrad_split_supported(int Cd, int Cx, int pro_d, int pro_x, bool rowsum);
 int pw_wgrad_split_launch(const float* d, const float* d2, const float* x, const float* dk0, const float* dk1,
                           const float* dk2, const float* dkmu, const float* xk0, const float* xk1, const float* xk2, float* part,
-                          int N, int Cd, int Cx, int P, int nbx, int pro_x, hipStream_t stream);
+                          int N, int Cd, int Cx, int P, int nbx, int pro_x, const float* d_amax, int d_amax_n,
+                          const float* d2_amax, int d2_amax_n, const float* x_ub, hipStream_t stream);
 
 // pw_wgrad_a16.hip: the same weight gradients from bf16 operands (one bf16 x bf16 product per MAC, fp32 accumulation)
 int pw_wgrad_a16_nbx(int N, int P);

@@ -645,7 +645,8 @@ extern "C" int uncr_wgrad_nbx(int N, int Cd, int Cx, int P, int pro_d, int pro_x
 extern "C" int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const void* x2, const float* dk0,
                              const float* dk1, const float* dk2, const float* dkmu, const float* xk0, const float* xk1,
                              const float* xk2, float* part, float* rs_part, int N, int Cd, int Cx, int P, int NBX,
-                             int pro_d, int pro_x, int act, hipStream_t stream) {
+                             int pro_d, int pro_x, int act, const float* d_amax, int d_amax_n, const float* d2_amax,
+                             int d2_amax_n, const float* x_ub, hipStream_t stream) {
     int cop, cip;
     const int shp = wg_shape(Cd, Cx, &cop, &cip);
     if (shp < 0 || N <= 0 || NBX <= 0) return UNCR_ESHAPE;
@@ -659,7 +660,7 @@ extern "C" int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const
     if (act == UNCR_F32 && pw_wgrad_split_supported(Cd, Cx, pro_d, pro_x, rs_part != nullptr)) {
         if (!dk0 || !dk1 || !dk2 || !xk0 || !xk1) return UNCR_EINVAL;
         return pw_wgrad_split_launch((const float*)d, (const float*)d2, (const float*)x, dk0, dk1, dk2, dkmu, xk0, xk1, xk2, part, N,
-                                     Cd, Cx, P, NBX, pro_x, stream);
+                                     Cd, Cx, P, NBX, pro_x, d_amax, d_amax_n, d2_amax, d2_amax_n, x_ub, stream);
     }
     if (P % NBX) return UNCR_ESHAPE;
     const int PXB = P / NBX;

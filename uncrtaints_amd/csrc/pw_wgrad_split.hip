@@ -14,6 +14,12 @@
 // The MFMA stream never waits on HBM: the only vm-counter traffic in the loop are those raw loads, each consumed a
 // full chunk after it was issued.  LDS bytes of one buffer: [part 3][plane 4 = ks*2+kg][row R][16 B], plane stride
 // padded by 32 B (bank spread of the 8-B staging writes).
+//
+// H2 (fp32 storage, bounds at hand): two fp16 parts per operand and three products, as the forward GEMMs and the dz GEMM run
+// (pw_gemm.h, split2_f16_pair).  The contraction runs over pixels here, so every ROW of either operand has its own power-of-two
+// scale: a rigorous bound on the staged row -- norm-backward rows |c0| max|d| + |c1| (max|d2| + |mu|) + |c2| from the per-block
+// maxima the producers of d and d2 left, GELU rows the statistics finalisation's bound on |A h + B| (|gelu(u)| <= |u|) times |s| --
+// brought to 2^14.  The scales multiply the rows' prologue coefficients and leave the [COP][CIP] partial in the epilogue (exact).
 #include "pw_gemm.h"
 #include <type_traits>
 
@@ -26,7 +32,21 @@ struct WgsArgs {
     float* part;       // [N*G][COP][CIP]
     int Cd, Cx, P;
     const float* dk3;  // the norm's mean per (n, co) (centred norm backward on d) or null
+    // H2: per-block maxima of |d| and |d2| ([N][d_amax_n], [N][d2_amax_n]) and per-plane bounds on the affine input of x ([N*Cx])
+    const float* d_amax; int d_amax_n;
+    const float* d2_amax; int d2_amax_n;
+    const float* x_ub;
 };
+
+// power of two bringing `bound` to [2^13, 2^14); 1 for a zero / non-finite bound (inf / NaN then propagate as in fp32)
+__device__ __forceinline__ float wgs_scale14(float bound) {
+    if (!(bound > 0.f) || !(bound < 3.0e38f)) return 1.f;
+    int e;
+    (void)frexpf(bound, &e);
+    e = 14 - e;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return ldexpf(1.f, e);
+}
 
 template <int PRO>
 __device__ __forceinline__ float wgs_pro(float v, float v2, float c0, float c1, float c2, float c3 = 0.f) {
@@ -47,7 +67,7 @@ __device__ __forceinline__ f32x2 wgs_pro2(f32x2 v, f32x2 v2, float c0, float c1,
     else return v;
 }
 
-template <int WCO, int WCI, int PRO_D, int PRO_X>
+template <int WCO, int WCI, int PRO_D, int PRO_X, bool H2 = false>
 __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
     constexpr int NT = 512;
     constexpr int COP = 64 * WCO, CIP = 64 * WCI, R = COP + CIP;
@@ -97,6 +117,32 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
         k2[i] = q2 ? c : ((isd ? PRO_D : PRO_X) == PRO_AFFINE_GELU ? 1.f : 0.f);
     }
 
+    __shared__ float rsc[H2 ? R : 1];      // H2: 1 / scale of every staged row
+    if constexpr (H2) {
+        static_assert(PRO_D == PRO_NORMBWD && PRO_X == PRO_AFFINE_GELU, "bounds are derived for these prologues");
+        float a1 = 0.f, a2 = 0.f;       // the frame's max |d|, max |d2| (a NaN maximum stays: no scaling then)
+        for (int j = lane; j < g.d_amax_n; j += 64) { const float v = g.d_amax[(size_t)n * g.d_amax_n + j]; a1 = v > a1 || !(v == v) ? v : a1; }
+        for (int j = lane; j < g.d2_amax_n; j += 64) { const float v = g.d2_amax[(size_t)n * g.d2_amax_n + j]; a2 = v > a2 || !(v == v) ? v : a2; }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const float o1 = __shfl_xor(a1, sft, 64), o2 = __shfl_xor(a2, sft, 64);
+            a1 = o1 > a1 || !(o1 == o1) ? o1 : a1;
+            a2 = o2 > a2 || !(o2 == o2) ? o2 : a2;
+        }
+#pragma unroll
+        for (int i = 0; i < ND + NX; ++i) {
+            float sc;
+            if (i < ND) {
+                sc = wgs_scale14(fabsf(k0[i]) * a1 + fabsf(k1[i]) * (a2 + fabsf(k3[i < ND ? i : 0])) + fabsf(k2[i]));
+                k0[i] *= sc; k1[i] *= sc; k2[i] *= sc;
+            } else {
+                sc = wgs_scale14(g.x_ub[n * CIP + lrow + 64 * (i - ND)] * fabsf(k2[i]));
+                k2[i] *= sc;
+            }
+            if (c4 == 0) rsc[(i < ND ? 0 : COP) + lrow + 64 * (i < ND ? i : i - ND)] = 1.f / sc;
+        }
+    }
+
     float4 dv[ND], dv2[D2 ? ND : 1], xv[NX];
     auto load_piece = [&](int i, int ch) {   // i compile-time after unrolling; ch clamped by the caller
         const size_t po = (size_t)(cbeg + ch) * 32;
@@ -113,18 +159,30 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
         const float c0 = k0[i], c1 = k1[i], c2 = k2[i];
         const float4 v = isd ? dv[i] : xv[i - ND];
         const float4 w = (isd && D2) ? dv2[D2 ? i : 0] : v;
-        unsigned h[4], m[4], l[4];
-#pragma unroll
-        for (int q = 0; q < 4; q += 2) {
-            const f32x2 a = f2(((const float*)&v)[q], ((const float*)&v)[q + 1]), b = f2(((const float*)&w)[q], ((const float*)&w)[q + 1]);
-            const f32x2 t = isd ? wgs_pro2<PRO_D>(a, b, c0, c1, c2, k3[isd ? i : 0]) : wgs_pro2<PRO_X>(a, b, c0, c1, c2);
-            split3_bf16(t.x, h[q], m[q], l[q]);
-            split3_bf16(t.y, h[q + 1], m[q + 1], l[q + 1]);
-        }
         unsigned char* b = xs + buf * BUF + st_off + (row - lrow) * 16;
-        *(u32x2_t*)(b) = u32x2_t{pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3])};
-        *(u32x2_t*)(b + PART) = u32x2_t{pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3])};
-        *(u32x2_t*)(b + 2 * PART) = u32x2_t{pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3])};
+        if constexpr (H2) {
+            unsigned hh[2], ll[2];
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+                const f32x2 a = f2(((const float*)&v)[q], ((const float*)&v)[q + 1]), bb = f2(((const float*)&w)[q], ((const float*)&w)[q + 1]);
+                const f32x2 t = isd ? wgs_pro2<PRO_D>(a, bb, c0, c1, c2, k3[isd ? i : 0]) : wgs_pro2<PRO_X>(a, bb, c0, c1, c2);
+                split2_f16_pair(t.x, t.y, hh[q >> 1], ll[q >> 1]);
+            }
+            *(u32x2_t*)(b) = u32x2_t{hh[0], hh[1]};
+            *(u32x2_t*)(b + PART) = u32x2_t{ll[0], ll[1]};
+        } else {
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+                const f32x2 a = f2(((const float*)&v)[q], ((const float*)&v)[q + 1]), bb = f2(((const float*)&w)[q], ((const float*)&w)[q + 1]);
+                const f32x2 t = isd ? wgs_pro2<PRO_D>(a, bb, c0, c1, c2, k3[isd ? i : 0]) : wgs_pro2<PRO_X>(a, bb, c0, c1, c2);
+                split3_bf16(t.x, h[q], m[q], l[q]);
+                split3_bf16(t.y, h[q + 1], m[q + 1], l[q + 1]);
+            }
+            *(u32x2_t*)(b) = u32x2_t{pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3])};
+            *(u32x2_t*)(b + PART) = u32x2_t{pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3])};
+            *(u32x2_t*)(b + 2 * PART) = u32x2_t{pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3])};
+        }
     };
 
     f32x16 acc[2][2];
@@ -153,6 +211,46 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
 
     // rolling operands (ah, am, bh re-read in place after their last use) and double-buffered single-use ones
     u32x4_t ah[2], am[2], bh[2], al[2][2], bl[2][2], bm[2][2];
+    if constexpr (H2) {
+        // parts: 0 = high, 1 = low.  Products per k-step: ah*bl, ah*bh, al*bh; two staging pieces ride behind each in k-step 0.
+        ldop(0, 0, 0, aoff, ah); ldop(0, 0, 0, boff, bh); ldop(0, 0, 1, aoff, al[0]); ldop(0, 0, 1, boff, bl[0]);
+#define WGS_MFH(A, B)                                                                                            \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)                  \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, A[a]),                    \
+                                                           __builtin_bit_cast(f16x8_t, B[b]), acc[a][b], 0, 0, 0)
+#define WGS_SBH() __builtin_amdgcn_sched_barrier(0)
+        for (int c = 0; c < nc; ++c) {
+            const int cur = c & 1;
+            const int c2 = c + 2 < nc ? c + 2 : nc - 1;
+            WGS_MFH(ah, bl[0]); WGS_SBH();
+            ldop(cur, 1, 1, aoff, al[1]); ldop(cur, 1, 1, boff, bl[1]);
+            if (0 < ND + NX) { stage_piece(0, cur ^ 1); load_piece(0, c2); }
+            if (1 < ND + NX) { stage_piece(1, cur ^ 1); load_piece(1, c2); }
+            WGS_SBH();
+            WGS_MFH(ah, bh); WGS_SBH();
+            ldop(cur, 1, 0, aoff, ah);
+            if (2 < ND + NX) { stage_piece(2, cur ^ 1); load_piece(2, c2); }
+            if (3 < ND + NX) { stage_piece(3, cur ^ 1); load_piece(3, c2); }
+            WGS_SBH();
+            WGS_MFH(al[0], bh); WGS_SBH();
+            ldop(cur, 1, 0, boff, bh);
+            if (4 < ND + NX) { stage_piece(4, cur ^ 1); load_piece(4, c2); }
+            if (5 < ND + NX) { stage_piece(5, cur ^ 1); load_piece(5, c2); }
+            WGS_SBH();
+            __syncthreads();
+            WGS_MFH(ah, bl[1]); WGS_SBH();
+            ldop(cur ^ 1, 0, 1, aoff, al[0]); ldop(cur ^ 1, 0, 1, boff, bl[0]);
+            WGS_SBH();
+            WGS_MFH(ah, bh); WGS_SBH();
+            ldop(cur ^ 1, 0, 0, aoff, ah);
+            WGS_SBH();
+            WGS_MFH(al[1], bh); WGS_SBH();
+            ldop(cur ^ 1, 0, 0, boff, bh);
+            WGS_SBH();
+        }
+#undef WGS_MFH
+#undef WGS_SBH
+    } else {
     ldop(0, 0, 0, aoff, ah); ldop(0, 0, 1, aoff, am); ldop(0, 0, 0, boff, bh);
     ldop(0, 0, 2, aoff, al[0]); ldop(0, 0, 2, boff, bl[0]); ldop(0, 0, 1, boff, bm[0]);
 
@@ -215,6 +313,7 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
     }
 #undef WGS_MF
 #undef WGS_SB
+    }
 
     float* po = g.part + ((size_t)n * gridDim.x + blockIdx.x) * COP * CIP;
 #pragma unroll
@@ -225,7 +324,9 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
             for (int r = 0; r < 16; ++r) {
                 const int co = (wco * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int ci = (wci * 2 + b) * 32 + (lane & 31);
-                po[co * CIP + ci] = acc[a][b][r];
+                float v = acc[a][b][r];
+                if constexpr (H2) v = v * rsc[co] * rsc[COP + ci];      // powers of two: exact
+                po[co * CIP + ci] = v;
             }
 }
 
@@ -255,11 +356,11 @@ bool pw_wgrad_split_supported(int Cd, int Cx, int pro_d, int pro_x, bool rowsum)
     return pro_x == PRO_AFFINE || pro_x == PRO_AFFINE_GELU;
 }
 
-template <int WCO, int WCI, int PRO_X>
+template <int WCO, int WCI, int PRO_X, bool H2 = false>
 static int wgs_launch(const WgsArgs& g, dim3 grid, hipStream_t stream) {
     constexpr int R = 64 * WCO + 64 * WCI;
     constexpr size_t lds = 2 * 3 * 4 * (size_t)(R * 16 + 32);
-    auto kern = pw_wgrad_split_kernel<WCO, WCI, PRO_NORMBWD, PRO_X>;
+    auto kern = pw_wgrad_split_kernel<WCO, WCI, PRO_NORMBWD, PRO_X, H2>;
     static bool once = false;
     if (!once) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -273,10 +374,14 @@ static int wgs_launch(const WgsArgs& g, dim3 grid, hipStream_t stream) {
 
 int pw_wgrad_split_launch(const float* d, const float* d2, const float* x, const float* dk0, const float* dk1,
                           const float* dk2, const float* dkmu, const float* xk0, const float* xk1, const float* xk2, float* part,
-                          int N, int Cd, int Cx, int P, int nbx, int pro_x, hipStream_t stream) {
+                          int N, int Cd, int Cx, int P, int nbx, int pro_x, const float* d_amax, int d_amax_n,
+                          const float* d2_amax, int d2_amax_n, const float* x_ub, hipStream_t stream) {
     if (P % 32 || nbx < 1 || nbx > P / 32) return UNCR_ESHAPE;
-    WgsArgs g{d, d2, x, dk0, dk1, dk2, xk0, xk1, xk2, part, Cd, Cx, P, dkmu};
+    WgsArgs g{d, d2, x, dk0, dk1, dk2, xk0, xk1, xk2, part, Cd, Cx, P, dkmu, d_amax, d_amax_n, d2_amax, d2_amax_n, x_ub};
     dim3 grid(nbx, N);
+    // every bound at hand (and the shape the bounds are derived for): two fp16 parts, three products
+    if (Cd == 128 && pro_x == PRO_AFFINE_GELU && d_amax && d_amax_n > 0 && d2_amax && d2_amax_n > 0 && x_ub)
+        return wgs_launch<2, 4, PRO_AFFINE_GELU, true>(g, grid, stream);
     if (Cd == 256) {
         if (pro_x == PRO_AFFINE) return wgs_launch<4, 2, PRO_AFFINE>(g, grid, stream);
         return wgs_launch<4, 2, PRO_AFFINE_GELU>(g, grid, stream);

@@ -268,6 +268,7 @@ _CENTRED_NORMBWD = os.environ.get("UNCR_RAW_NORMBWD", "0") != "1"     # developm
 # fp16 two-part split in the dz GEMM of an MBConv backward, scaled per frame from the producers' magnitude bookkeeping
 # (UNCR_NO_H2_BWD=1: exact bf16 split there, no bookkeeping -- A/B runs)
 _H2_BWD = os.environ.get("UNCR_NO_H2_BWD", "0") != "1"
+_H2_WGRAD = os.environ.get("UNCR_NO_H2_WGRAD", "0") != "1"    # the dW2 weight-gradient products alone (A/B runs)
 # the same split in the forward GEMMs behind a norm (pw1 / pw2 of an MBConv), scaled per frame from the bounds the statistics
 # finalisation emits (UNCR_NO_H2_FWD=1: exact bf16 split -- A/B runs)
 _H2_FWD = os.environ.get("UNCR_NO_H2_FWD", "0") != "1"
@@ -492,7 +493,8 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
 
 def pw_wgrad(d: Tensor, x: Tensor, N: int, Cd: int, Cx: int, P: int, *, pro_d: int = PRO_NONE, dk=(None, None, None),
              d2: Optional[Tensor] = None, pro_x: int = PRO_NONE, xk=(None, None, None), x2: Optional[Tensor] = None,
-             per_frame: bool = False, rowsum: bool = False, partials: bool = False):
+             per_frame: bool = False, rowsum: bool = False, partials: bool = False, d_amax: Optional[Tensor] = None,
+             d2_amax: Optional[Tensor] = None, x_ub: Optional[Tensor] = None):
     """dW[co,ci] = sum_{n,p} fD(d)[n,co,p] * fX(x)[n,ci,p]  (-> [Cd,Cx], or [N,Cd,Cx] if per_frame);
     optionally also rowsum[co] = sum_{n,p} fD(d).  partials: the per-block partials themselves, (part [N*nbx, cop, cip], nbx, cop,
     cip), for a consumer that reduces them on the way (uncr_prenorm_bwd_finish)."""
@@ -510,8 +512,12 @@ def pw_wgrad(d: Tensor, x: Tensor, N: int, Cd: int, Cx: int, P: int, *, pro_d: i
     dev = d.device
     part = _f32((N * nbx, cop, cip), dev)
     rs_part = _f32((N * nbx, cop), dev) if rowsum else None
+    if not (_H2_BWD and _H2_WGRAD and d_amax is not None and d2_amax is not None and x_ub is not None and d_amax.shape[0] == N
+            and d2_amax.shape[0] == N and x_ub.numel() == N * Cx):
+        d_amax = d2_amax = x_ub = None          # the row-scaled fp16 split needs every bound; the exact split otherwise
     hb.call("uncr_pw_wgrad", d, d2, x, x2, dk[0], dk[1], dk[2], dk[3] if len(dk) > 3 else None, xk[0], xk[1], xk[2], part,
-            rs_part, N, Cd, Cx, P, nbx, pro_d, pro_x, act, _stream())
+            rs_part, N, Cd, Cx, P, nbx, pro_d, pro_x, act, d_amax, d_amax.numel() // N if d_amax is not None else 0, d2_amax,
+            d2_amax.numel() // N if d2_amax is not None else 0, x_ub, _stream())
     if partials:
         return part, nbx, cop, cip
     n_out = N if per_frame else 1
@@ -637,8 +643,9 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     k3 = b3.k
 
     # pw2: per-frame products G[n] = dh3 (x) g2  -> dW2 and the SE gradient
+    # (fp32 storage, magnitude bookkeeping at hand: two row-scaled fp16 parts, like the dz GEMM below)
     G, _ = pw_wgrad(dy, h2, N, C, Ch, P, pro_d=PRO_NORMBWD, dk=k3, d2=h3, pro_x=PRO_AFFINE_GELU,
-                    xk=(n2.A, n2.B, None), per_frame=True)
+                    xk=(n2.A, n2.B, None), per_frame=True, d_amax=dy_amax, d2_amax=sv.get("h3_amax"), x_ub=n2.ub)
     ds_pre, dhid_pre, dpool = _f32((N, Ch), dev), _f32((N, R), dev), _f32((N * Ch,), dev)
     dW2, dse1, dse2 = _f32((C, Ch), dev), _f32((R, Ch), dev), _f32((Ch, R), dev)
     w2 = p["w2"].reshape(C, Ch).contiguous()
