@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of HIP-graph replays")
+    ap.add_argument("--torch-adam", action="store_true", help="torch's fused multi-tensor Adam instead of the one-launch HIP kernel")
     ap.add_argument("--act-dtype", choices=("fp32", "bf16"), default="fp32",
                     help="activation storage: fp32 (default: the headline line, BASELINE config 2) or bf16 (BASELINE config 3: bf16 "
                          "activations, fp32 accumulate; reported as dtype bf16, never as the fp32 headline)")
@@ -224,12 +225,19 @@ def main():
     else:
         model.temporal_aggregator.set_seed(1)
     use_graph = not args.no_graph
-    # fused multi-tensor Adam: one launch per step instead of ~180 per-tensor kernels (0.7 ms/step in the capture);
-    # captured with the step at N = 1, launched eagerly after the gradient all-reduce at N > 1
-    try:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph, fused=True)
-    except Exception:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph)
+    # Adam as ONE launch over the whole parameter set (uncrtaints_amd.optim.FusedAdam: a torch.optim.Adam whose step is a HIP
+    # kernel; torch's own fused multi-tensor path takes three launches of 26 us for the 91 tensors); --torch-adam: torch's.
+    # Captured with the step at N = 1, its own graph behind the gradient all-reduces at N > 1.
+    if args.torch_adam:
+        try:
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph, fused=True)
+        except Exception:
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph)
+        opt_kind = "torch.optim.Adam(fused, capturable)"
+    else:
+        from uncrtaints_amd.optim import FusedAdam
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        opt_kind = "uncrtaints_amd.optim.FusedAdam (torch.optim.Adam arithmetic, one HIP launch)"
     x, y, dates = synthetic(B, T, H, H, seed=1 + rank, device=device)
     step_counter = torch.zeros(1, dtype=torch.int64, device=device)
     model.temporal_aggregator.step_counter = step_counter     # dropout stream advances on the device
@@ -447,7 +455,7 @@ def main():
                                 wait_ms_max=round(max(coll_wait), 4) if coll_wait else None) if dp is not None else None),
             "final_loss": final_loss, "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
             "launch_mode": graph_note,
-            "optimizer": {"kind": "torch.optim.Adam(fused, capturable)", "included_in_step": True,
+            "optimizer": {"kind": opt_kind, "included_in_step": True,
                           "ms_per_step_eager": None if opt_ms is None else round(opt_ms, 4)},
             "step_hbm_roofline_frac": round(value / world * a_step_bytes(T, H * H, bf16) / 1e9 / HBM_PEAK_GBS, 4),
         }

@@ -25,14 +25,13 @@ class BaseModel(nn.Module):
         # learning rate on the device (capturable), so that ExponentialLR's per-epoch update reaches the captured kernels.
         self._use_graph = bool(getattr(config, "hip_graph", False))
         self._graph = None
+        # base_model.py:48: torch.optim.Adam(params, lr).  FusedAdam IS that class (same state, checkpoints exchange with it) with the
+        # update as one HIP launch over all parameters; on CPU parameters it runs torch's own step.
+        from ...optim import FusedAdam
         if self._use_graph:
-            kw = dict(capturable=True, lr=torch.tensor(float(config.lr), device=config.device))
-            try:        # one multi-tensor launch per step instead of a chain of foreach kernels (same arithmetic)
-                self.optimizer_G = torch.optim.Adam([{'params': self.netG.parameters()}], fused=True, **kw)
-            except (RuntimeError, TypeError, ValueError):
-                self.optimizer_G = torch.optim.Adam([{'params': self.netG.parameters()}], **kw)
+            self.optimizer_G = FusedAdam([{'params': self.netG.parameters()}], lr=torch.tensor(float(config.lr), device=config.device))
         else:
-            self.optimizer_G = torch.optim.Adam([{'params': self.netG.parameters()}], lr=config.lr)
+            self.optimizer_G = FusedAdam([{'params': self.netG.parameters()}], lr=config.lr)
         self.scheduler_G = torch.optim.lr_scheduler.ExponentialLR(self.optimizer_G, gamma=self.config.gamma)
         self.real_A = self.fake_B = self.real_B = self.dates = self.masks = None
         self.netG.variance = None
