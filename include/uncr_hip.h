@@ -77,7 +77,9 @@ int uncr_version(void);
 int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                            const float* gamma, const float* beta, float* running_mean, float* running_var,
                            float momentum, float eps, float* coefA, float* coefB, float* save_mean,
-                           float* save_rstd, float* ub, hipStream_t stream);
+                           float* save_rstd, float* ub,
+                           float* hb /* nullable (needs ub) [N*C]: the bound on |h| itself, for consumers that apply another map to h */,
+                           hipStream_t stream);
 int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                            const float* gamma, const float* save_mean, const float* save_rstd, float* c1,
                            float* c2, float* c3,
@@ -95,7 +97,7 @@ int uncr_bn_finalize_fwd_sums(const double* sums, double count, int N, int C, co
                               float* running_mean, float* running_var, float momentum, float eps, float* coefA,
                               float* coefB, float* save_mean, float* save_rstd,
                               const float* part, int NP, float* ub /* nullable: as in uncr_norm_finalize_fwd, from the LOCAL partials */,
-                              hipStream_t stream);
+                              float* hb /* nullable, needs ub */, hipStream_t stream);
 int uncr_bn_finalize_bwd_sums(const double* sums_local, const double* sums_global, double count, int N, int C,
                               const float* gamma, const float* save_mean, const float* save_rstd, float* c1, float* c2,
                               float* c3, float* cmu, float* dgamma, float* dbeta, int centered, hipStream_t stream);
@@ -169,6 +171,9 @@ int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt, void* out,
                     const float* c2, const float* c3, const float* cmu /* out = dy + c1*da + c2*(x - cmu) + c3 */,
                     const float* relu_a, const float* relu_b, float* part, int N, int Cin, int Cout, int P, int act,
                     float* amax_out /* [N][uncr_pw_stat_slots] per-block max |out| or null (relu_a == null only) */,
+                    const float* in_amax, int in_amax_n, const float* in2_amax, int in2_amax_n /* both or neither, fp32 storage:
+                    bounds on |in| and |in2| per frame ([N][n]: per-block maxima or per-plane bounds, e.g. uncr_dw_bwd's amax_out and
+                    uncr_norm_finalize_fwd's hb) -- the operand is then staged as two scaled fp16 parts, as in uncr_pw_gemm */,
                     hipStream_t stream);
 /* wpart [N*nbx][COP][CIP] = the per-block partials of the per-frame products R[n] = sum_p du1n*x (uncr_pw_wgrad with the raw x,
  * its reduction is done here); part_b / part_f = the (sum du1, .) and (sum h1, .) partials [N*Ch][NPB|NPF][2] (part_f may be
@@ -205,13 +210,16 @@ int uncr_dw_slots_fwd(int H);
 int uncr_dw_slots_bwd(int H);
 int uncr_dw_fwd(const void* in, const float* cA, const float* cB, const float* w, void* out, float* part,
                 int N, int C, int H, int W, int act, int variant, hipStream_t stream);
+int uncr_dw_bwd_emits_amax(int H, int W, int act, int variant);
 int uncr_dw_bwd(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
                 const float* k3, const float* kmu /* dh2 = k1*du2 + k2*(h2 - kmu) + k3; null: kmu = 0 */,
                 const float* cA1, const float* cB1, const float* w, void* du1, float* part,
                 float* dw_part, const float* mean1 /* null: part.y = sum du1*h1; else sum du1*(h1 - mean), the
                 well-conditioned form for uncr_norm_finalize_bwd(centered = 1) */,
                 int mean_groups /* 0: mean1[c] (BatchNorm); G > 0: mean1[n*G + c/(C/G)] (GroupNorm) */,
-                int N, int C, int H, int W, int act, int variant, hipStream_t stream);
+                int N, int C, int H, int W, int act, int variant, float* amax_out /* nullable; [N*C][uncr_dw_slots_bwd(H)] max |du1| per statistics slot, only where
+                                   uncr_dw_bwd_emits_amax(H, W, act, variant) */,
+                hipStream_t stream);
 int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw, hipStream_t stream);
 
 /* ---- squeeze-excite MLP (uncrtaints.py:82-97) ---- */

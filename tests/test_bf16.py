@@ -120,7 +120,7 @@ def test_depthwise_bf16_storage(H, W):
     partb = torch.empty(N * C, sb, 2, device=DEV)
     dwp = torch.empty(N * C, sb, 9, device=DEV)
     hb.call("uncr_dw_bwd", du2b, h2, h1b, dev(c1), dev(c2), dev(c3), None, dev(A), dev(B), dev(w.reshape(C, 9)), du1, partb, dwp,
-            None, 0, N, C, H, W, 1, 0, E._stream())
+            None, 0, N, C, H, W, 1, 0, None, E._stream())
     h1r = rb(h1).double().requires_grad_(True)
     u = A.double().view(N, C, 1, 1) * h1r + B.double().view(N, C, 1, 1)
     g1 = 0.5 * u * (1.0 + torch.erf(u / 2 ** 0.5))

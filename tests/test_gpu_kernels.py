@@ -160,9 +160,13 @@ def _depthwise_fwd_bwd(E, orc, H, W, variant):
     sb = hb.query("uncr_dw_slots_bwd", H)
     partb = torch.empty(N * C, sb, 2, device=DEV)
     dwp = torch.empty(N * C, sb, 9, device=DEV)
+    amax = torch.empty(N * C, sb, device=DEV) if hb.query("uncr_dw_bwd_emits_amax", H, W, 0, variant) == 1 else None
     hb.call("uncr_dw_bwd", dev(du2), h2d, dev(h1.detach()), dev(c1), dev(c2), dev(c3), None, dev(A), dev(B),
-            dev(w.detach().reshape(C, 9)), du1, partb, dwp, None, 0, N, C, H, W, 0, variant, E._stream())
+            dev(w.detach().reshape(C, 9)), du1, partb, dwp, None, 0, N, C, H, W, 0, variant, amax, E._stream())
     close(f"dw_bwd_du1[{H}x{W}]", du1, du1_ref)
+    if amax is not None:        # max |du1| of every 16-row statistics slot, exactly (it is a maximum of stored values)
+        rows = torch.nn.functional.pad(du1.abs(), (0, 0, 0, sb * 16 - H)).view(N * C, sb, 16 * W).amax(dim=2)
+        assert torch.equal(amax, rows)
     close("dw_bwd_stats0", partb.sum(1)[:, 0], du1_ref.sum(dim=(2, 3)).reshape(-1))
     close("dw_bwd_stats1", partb.sum(1)[:, 1], (du1_ref * h1.detach()).sum(dim=(2, 3)).reshape(-1))
     dwd = torch.empty(C, 9, device=DEV)
@@ -172,7 +176,7 @@ def _depthwise_fwd_bwd(E, orc, H, W, variant):
     for groups in (0, 4):
         mean = rand(C if groups == 0 else N * groups, seed=9, scale=2.0)
         hb.call("uncr_dw_bwd", dev(du2), h2d, dev(h1.detach()), dev(c1), dev(c2), dev(c3), None, dev(A), dev(B),
-                dev(w.detach().reshape(C, 9)), du1, partb, dwp, dev(mean), groups, N, C, H, W, 0, variant, E._stream())
+                dev(w.detach().reshape(C, 9)), du1, partb, dwp, dev(mean), groups, N, C, H, W, 0, variant, None, E._stream())
         mfull = mean.view(1, C, 1, 1) if groups == 0 else mean.view(N, groups, 1, 1, 1).expand(N, groups, C // groups, 1, 1).reshape(N, C, 1, 1)
         close(f"dw_bwd_stats1_centered[g{groups}]", partb.sum(1)[:, 1],
               (du1_ref * (h1.detach() - mfull)).sum(dim=(2, 3)).reshape(-1))
@@ -976,6 +980,43 @@ def test_fp16_two_part_forward_gemm_accuracy(E, Cin, Cout, pro):
     out, _ = E.pw_gemm(dev(xb), E.pack_wt(dev(Wn), transpose=True), N, Cin, Cout, P, pro=pro,
                        k=(dev(A), dev(B), dev(S) if pro == 2 else None), epi=1, in_amax=dev(ub.reshape(-1)))
     assert bool(torch.isnan(out[0, :, 7]).all()) and bool(torch.isfinite(out[1]).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gscale", [1e-7, 1e-2, 3e4])
+def test_scaled_fp16_two_part_dx_gemm(E, gscale):
+    """pw1's backward GEMM with the PreNorm backward + skip epilogue (uncr_pw_gemm_dx): with bounds on both operands of its
+    norm-backward prologue -- max |du1| per slot from the depthwise backward, the finalisation's bound on |h1| -- it multiplies in two
+    scaled fp16 parts; against fp64 at the level of the exact bf16 split, statistics included."""
+    from uncrtaints_amd import hip_backend as hb
+    torch.manual_seed(11)
+    N, C, Ch, P = 3, 128, 256, 2048
+    du1 = torch.randn(N, Ch, P) * gscale
+    du1[2] *= 1e-4
+    h1 = torch.randn(N, Ch, P) * 3.0 + 1.0
+    k = [torch.rand(N * Ch) + 0.5, torch.randn(N * Ch) * 0.1 * gscale, torch.randn(N * Ch) * 0.01 * gscale, torch.randn(N * Ch) * 0.5]
+    W1 = torch.randn(Ch, C) * 0.07                                   # [k = co 256][out = ci 128]
+    dy, x, xh3 = torch.randn(N, C, P) * gscale, torch.randn(N, C, P), torch.randn(N, C, P)
+    c = [torch.rand(N * C) + 0.5, torch.randn(N * C) * 0.1 * gscale, torch.randn(N * C) * 0.01 * gscale, torch.randn(N * C) * 0.2]
+    v = lambda t, ch: t.view(N, ch, 1).double()
+    d = v(k[0], Ch) * du1.double() + v(k[1], Ch) * (h1.double() - v(k[3], Ch)) + v(k[2], Ch)
+    da = torch.einsum("kc,nkp->ncp", W1.double(), d)
+    truth = dy.double() + v(c[0], C) * da + v(c[1], C) * (x.double() - v(c[3], C)) + v(c[2], C)
+    W1k = E.pack_wt(dev(W1), transpose=False)
+    slots = hb.query("uncr_pw_stat_slots", N, C, P)
+    errs = {}
+    for name, b in (("scaled fp16", (dev(du1.abs().amax(dim=2).contiguous()), Ch, dev(h1.abs().amax(dim=2).contiguous()), Ch)),
+                    ("exact bf16", (None, 0, None, 0))):
+        out, part = torch.empty(N, C, P, device=DEV), torch.empty(N * C, slots, 2, device=DEV)
+        hb.call("uncr_pw_gemm_dx", dev(du1), dev(h1), W1k, out, dev(k[0]), dev(k[1]), dev(k[2]), dev(k[3]), dev(dy), dev(x), dev(xh3),
+                dev(c[0]), dev(c[1]), dev(c[2]), dev(c[3]), None, None, part, N, Ch, C, P, 0, None, *b, E._stream())
+        o = out.cpu().double()
+        errs[name] = max(float((o[n] - truth[n]).abs().max() / truth[n].abs().max()) for n in range(N))
+        sm = part.view(N * C, -1, 2).double().sum(1).cpu()
+        ref1 = (truth * xh3.double()).reshape(N * C, P).sum(1)
+        assert float((sm[:, 1] - ref1).abs().max() / (truth.abs() * xh3.double().abs()).reshape(N * C, P).sum(1).max()) < 1e-5
+    print(f"[parity] dx GEMM at gradient scale {gscale:g}: scaled fp16 two-part {errs['scaled fp16']:.2e}, exact bf16 split {errs['exact bf16']:.2e}")
+    assert errs["scaled fp16"] <= 2e-6 and errs["exact bf16"] <= 2e-6, errs
 
 
 @pytest.mark.gpu

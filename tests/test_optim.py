@@ -47,7 +47,7 @@ def test_fused_adam_follows_torch_adam(wd):
     for x, y, y0 in zip(a, b, _params("cuda")):
         # the parameters are compared through what the optimizer did to them -- the distance travelled in ten steps -- plus the
         # rounding of the parameter itself (a few ulp of its magnitude: the two implementations round different partial results)
-        worst["update"] = max(worst["update"], float((x - y).abs().max() / ((y - y0).abs().max() + 0.25 * y.abs().max())))
+        worst["update"] = max(worst["update"], float((x.detach() - y.detach()).abs().max() / ((y.detach() - y0.detach()).abs().max() + 0.25 * y.detach().abs().max())))
         for k in ("exp_avg", "exp_avg_sq"):
             u, v = oa.state[x][k], ob.state[y][k]
             worst[k] = max(worst[k], float((u - v).abs().max() / v.abs().max().clamp_min(1e-30)))

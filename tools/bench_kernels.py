@@ -53,7 +53,7 @@ def main():
             partf, partb, dwp = torch.empty(Nf * C, sf, 2, device=dev), torch.empty(Nf * C, sb, 2, device=dev), torch.empty(Nf * C, sb, 9, device=dev)
             ms = timeit(lambda: hb.call("uncr_dw_fwd", h1, cA, cB, w, out, partf, Nf, C, H, W, 0, 0, E._stream()), iters)
             print(f"dw_fwd N={Nf}: {ms*1e3:.1f} us  {8.0*Nf*C*H*W/ms/1e6:.0f} GB/s")
-            ms = timeit(lambda: hb.call("uncr_dw_bwd", du2, h2, h1, k1, k2, k3, None, cA, cB, w, out, partb, dwp, None, 0, Nf, C, H, W, 0, 0, E._stream()), iters)
+            ms = timeit(lambda: hb.call("uncr_dw_bwd", du2, h2, h1, k1, k2, k3, None, cA, cB, w, out, partb, dwp, None, 0, Nf, C, H, W, 0, 0, None, E._stream()), iters)
             print(f"dw_bwd N={Nf}: {ms*1e3:.1f} us  {16.0*Nf*C*H*W/ms/1e6:.0f} GB/s")
     elif what == "agg":
         # the L-TAE stage's full-resolution kernels at the bench shape
@@ -137,7 +137,7 @@ def main():
         part = torch.empty(N * 128, slots, 2, device=dev)
         for _ in range(3):
             hb.call("uncr_pw_gemm_dx", d, d2, W1k, dx, dk[0], dk[1], dk[2], None, dy, xx, xh3, c[0], c[1], c[2], None, None, None, part,
-                    N, 256, 128, P, act, None, E._stream())
+                    N, 256, 128, P, act, None, None if bf else amax(d), 0 if bf else 1, None if bf else amax(d2), 0 if bf else 1, E._stream())
         # the depthwise kernels
         C, H, W = 256, 256, 256
         t4 = lambda *s: torch.randn(*s, device=dev).to(adt)
@@ -148,7 +148,8 @@ def main():
         partf, partb, dwp = torch.empty(N * C, sf, 2, device=dev), torch.empty(N * C, sb, 2, device=dev), torch.empty(N * C, sb, 9, device=dev)
         for _ in range(3):
             hb.call("uncr_dw_fwd", h1, cA, cB, w9, out, partf, N, C, H, W, act, 0, E._stream())
-            hb.call("uncr_dw_bwd", du2, hh2, h1, k1, k2, k3, None, cA, cB, w9, out, partb, dwp, None, 0, N, C, H, W, act, 0, E._stream())
+            hb.call("uncr_dw_bwd", du2, hh2, h1, k1, k2, k3, None, cA, cB, w9, out, partb, dwp, None, 0, N, C, H, W, act, 0,
+                    None if bf else torch.empty(N * C * hb.query("uncr_dw_slots_bwd", H), device=dev), E._stream())
         torch.cuda.synchronize()
         print("done")
     elif what == "ablate":

@@ -19,14 +19,14 @@ if BF16:
             ("pw_wgrad_a16_kernel<2, 4", "pw_wgrad[128x256,N4,P65536]", EB * 4 * 65536 * (2 * 128 + 256)),
             ("pw_gemm_split_kernel<1, 3, 5, 2, unsigned short, false>", "pw_gemm_dx[256->128,N4,P65536]", EB * 4 * 65536 * (2 * 256 + 4 * 128))]
 else:
-    KEYS = [("dw_bwd_row_kernel<float>", "dw_bwd[N4,C256,256x256]", 4 * 4 * 256 * 65536 * 4),
+    KEYS = [("dw_bwd_row_kernel<float, true>", "dw_bwd[N4,C256,256x256]", 4 * 4 * 256 * 65536 * 4),
             ("dw_fwd_row_kernel<float>", "dw_fwd[N4,C256,256x256]", 4 * 4 * 256 * 65536 * 2),
             ("pw_gemm_split_kernel<2, 3, 3, 1, float, true>", "pw_gemm[128->256,pro3,epi3,N4,P65536]", 4 * 4 * 65536 * (2 * 128 + 2 * 256)),
             ("pw_gemm_split_kernel<2, 1, 1, 1, float, true>", "pw_gemm[128->256,pro1,epi1,N4,P65536]", 4 * 4 * 65536 * (128 + 256)),
             ("pw_gemm_split_kernel<1, 2, 1, 2, float, true>", "pw_gemm[256->128,pro2,epi1,N4,P65536]", 4 * 4 * 65536 * (256 + 128)),
             ("pw_wgrad_split_kernel<4, 2, 3, 1, false>", "pw_wgrad[256x128,N4,P65536]", 4 * 4 * 65536 * (2 * 256 + 128)),
             ("pw_wgrad_split_kernel<2, 4, 3, 2, true>", "pw_wgrad[128x256,N4,P65536],fp16x2", 4 * 4 * 65536 * (2 * 128 + 256)),
-            ("pw_gemm_split_kernel<1, 3, 5, 2, float, false>", "pw_gemm_dx[256->128,N4,P65536]", 4 * 4 * 65536 * (2 * 256 + 4 * 128))]
+            ("pw_gemm_split_kernel<1, 3, 5, 2, float, true>", "pw_gemm_dx[256->128,N4,P65536]", 4 * 4 * 65536 * (2 * 256 + 4 * 128))]
 
 
 def per_kernel(path, counter):

@@ -285,7 +285,7 @@ int dw_fwd_row_launch(const void* in, const float* cA, const float* cB, const fl
 int dw_bwd_row_launch(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
                       const float* k3, const float* kmu, const float* cA1, const float* cB1, const float* w, void* du1, float* part,
                       float* dw_part, const float* mean1, int mean_groups, int N, int C, int H, int slots, int act,
-                      hipStream_t stream);
+                      float* amax_out, hipStream_t stream);
 
 template <typename T>
 static int dw_fwd_tiled(const void* in, const float* cA, const float* cB, const float* w, void* out, float* part, int N, int C,
@@ -331,16 +331,22 @@ static int dw_bwd_tiled(const void* du2, const void* h2, const void* h1, const f
     return UNCR_OK;
 }
 
+// the row-streaming kernel (fp32 storage) can leave max |du1| per statistics slot; the LDS-tiled kernels do not
+extern "C" int uncr_dw_bwd_emits_amax(int H, int W, int act, int variant) {
+    return (variant == 0 && W == 256 && (H & 3) == 0 && act == UNCR_F32) ? 1 : 0;
+}
+
 extern "C" int uncr_dw_bwd(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
                            const float* k3, const float* kmu, const float* cA1, const float* cB1, const float* w, void* du1,
                            float* part, float* dw_part, const float* mean1, int mean_groups, int N, int C, int H,
-                           int W, int act, int variant, hipStream_t stream) {
+                           int W, int act, int variant, float* amax_out, hipStream_t stream) {
     if (mean1 && mean_groups > 0 && C % mean_groups) return UNCR_ESHAPE;
     if (N <= 0 || C <= 0 || H < 4 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
     if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
+    if (amax_out && !uncr_dw_bwd_emits_amax(H, W, act, variant)) return UNCR_EINVAL;
     if (variant == 0 && W == 256 && (H & 3) == 0)
         return dw_bwd_row_launch(du2, h2, h1, k1, k2, k3, kmu, cA1, cB1, w, du1, part, dw_part, mean1, mean_groups, N, C, H,
-                                 uncr_dw_slots_bwd(H), act, stream);
+                                 uncr_dw_slots_bwd(H), act, amax_out, stream);
     const size_t lds = (size_t)2 * (DW_TR_BWD + 2) * (W + 8) * sizeof(float);
     if (lds > 150 * 1024) return UNCR_ESHAPE;
     if (act == UNCR_BF16)

@@ -147,13 +147,14 @@ __global__ __launch_bounds__(256) void dw_fwd_row_kernel(const T* __restrict__ i
 
 // ---- backward (see dwconv.hip for the derivation of the reflect adjoint) ----
 // slots = ceil(H / 16) per plane (the ABI's statistics granularity)
-template <typename T>
+template <typename T, bool AMAX = false>
 __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     const T* __restrict__ du2, const T* __restrict__ h2, const T* __restrict__ h1,
     const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
     const float* __restrict__ kmu, const float* __restrict__ cA1, const float* __restrict__ cB1,
     const float* __restrict__ w, T* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
-    const float* __restrict__ mean1, int mean_groups, int C, int H, int planes, int slots, int tiles) {
+    const float* __restrict__ mean1, int mean_groups, int C, int H, int planes, int slots, int tiles,
+    float* __restrict__ amax_out /* AMAX: [planes][slots] max |du1| of every 16-row slot (for the fp16 split of its consumers) */) {
     constexpr int W = 256;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     const bool l0 = lane == 0, l63 = lane == 63;
 
     float s0 = 0.f, s1 = 0.f, gw[9];
+    float am = 0.f;
 #pragma unroll
     for (int i = 0; i < 9; ++i) gw[i] = 0.f;
     for (int Y = y0; Y < y1; Y += 4) {                     // (y1 - y0) % 4 == 0 (launcher: H % 4 == 0)
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
                 const float dv = po[j];
                 s0 += dv;
                 s1 = fmaf(dv, ph[j] - M1, s1);
+                if constexpr (AMAX) am = fabsf(dv) > am || !(dv == dv) ? fabsf(dv) : am;      // (a NaN stays)
                 // depthwise weight gradient: dh2 at (y, x) times g1 at the reflect-padded neighbours
                 const float dcj = dc.v[j + 1];
 #pragma unroll
@@ -306,11 +309,19 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
 #pragma unroll
             for (int i = 0; i < 9; ++i) rg[i] = wave_sum_dpp(gw[i]);
             const int sl = Y >> 4;                          // y0 is a multiple of 16
+            float ra = 0.f;
+            if constexpr (AMAX) {
+                ra = am;
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) { const float o = __shfl_xor(ra, sft, 64); ra = o > ra || !(o == o) ? o : ra; }
+                am = 0.f;
+            }
             if (lane == 63 && sl < slots) {
                 const size_t slot = (size_t)plane * slots + sl;
                 part[slot] = make_float2(r0, r1);
 #pragma unroll
                 for (int i = 0; i < 9; ++i) dw_part[slot * 9 + i] = rg[i];
+                if constexpr (AMAX) amax_out[slot] = ra;
             }
             s0 = 0.f; s1 = 0.f;
 #pragma unroll
@@ -331,14 +342,22 @@ int dw_fwd_row_launch(const void* in, const float* cA, const float* cB, const fl
 int dw_bwd_row_launch(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
                       const float* k3, const float* kmu, const float* cA1, const float* cB1, const float* w, void* du1, float* part,
                       float* dw_part, const float* mean1, int mean_groups, int N, int C, int H, int slots, int act,
-                      hipStream_t stream) {
+                      float* amax_out, hipStream_t stream) {
     const int planes = N * C;
     // 64-row tiles (2 halo rows per 64).  Measured: 2 ... 8 tiles per 256-row plane are all within 3 % of each other (the
     // kernel is bound by the memory system, not by how the waves fill the chip).
     const int tiles = (slots + DWR_TR / 16 - 1) / (DWR_TR / 16);
+    if (amax_out) {
+        if (act != UNCR_F32) return UNCR_EINVAL;      // the maxima serve the fp32 path's fp16 operand split only
+        hipLaunchKernelGGL((dw_bwd_row_kernel<float, true>), dim3((planes * tiles + 3) / 4), dim3(256), 0, stream, (const float*)du2,
+                           (const float*)h2, (const float*)h1, k1, k2, k3, kmu, cA1, cB1, w, (float*)du1, (float2*)part, dw_part, mean1,
+                           mean_groups, C, H, planes, slots, tiles, amax_out);
+        UNCR_LAUNCH_CHECK();
+        return UNCR_OK;
+    }
     UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(dw_bwd_row_kernel<T>, dim3((planes * tiles + 3) / 4), dim3(256), 0, stream,
                                                  (const T*)du2, (const T*)h2, (const T*)h1, k1, k2, k3, kmu, cA1, cB1, w, (T*)du1,
-                                                 (float2*)part, dw_part, mean1, mean_groups, C, H, planes, slots, tiles));
+                                                 (float2*)part, dw_part, mean1, mean_groups, C, H, planes, slots, tiles, nullptr));
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -13,7 +13,7 @@
 __global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(
     const float2* __restrict__ part, int NP, int C, int G, int P, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float* __restrict__ coefA, float* __restrict__ coefB,
-    float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ ub) {
+    float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ ub, float* __restrict__ hb) {
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int Cg = C / G;
     const float2* src = part + ((size_t)n * C + (size_t)g * Cg) * NP;
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(
         coefA[n * C + ch] = a;
         coefB[n * C + ch] = b;
         if (ub) ub[n * C + ch] = fmaf(fabsf(a), sqrtf(__uint_as_float(smax[c])), fabsf(b));
+        if (hb) hb[n * C + ch] = sqrtf(__uint_as_float(smax[c]));          // the raw bound on |h| itself (needs ub)
     }
 }
 
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(
     const float2* __restrict__ part, int NP, int N, int C, int P, int train, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
     float momentum, float eps, float* __restrict__ coefA, float* __restrict__ coefB,
-    float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ ub) {
+    float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ ub, float* __restrict__ hb) {
     const int c = blockIdx.x;
     __shared__ double red[8];
     __shared__ float sh_mean, sh_rstd;
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(
         coefA[n * C + c] = a;
         coefB[n * C + c] = b;
         if (ub) ub[n * C + c] = fmaf(fabsf(a), sqrtf(__uint_as_float(smax[per_frame ? n : 0])), fabsf(b));
+        if (hb) hb[n * C + c] = sqrtf(__uint_as_float(smax[per_frame ? n : 0]));
     }
 }
 
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_sums_kernel(
     const double* __restrict__ sums, double M, int N, int C, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
     float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ save_mean,
-    float* __restrict__ save_rstd, const float2* __restrict__ part, int NP, float* __restrict__ ub) {
+    float* __restrict__ save_rstd, const float2* __restrict__ part, int NP, float* __restrict__ ub, float* __restrict__ hb) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const double mean = sums[2 * c] / M;
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_sums_kernel(
             float m = 0.f;
             for (int j = 0; j < NP; ++j) { const float v = part[((size_t)n * C + c) * NP + j].y; m = v > m || !(v == v) ? v : m; }
             ub[n * C + c] = fmaf(fabsf(a), sqrtf(m), fabsf(b));
+            if (hb) hb[n * C + c] = sqrtf(m);
         }
     }
 }
@@ -455,13 +458,14 @@ extern "C" int uncr_bn_channel_sums(const float* part, int NP, int N, int C, dou
 extern "C" int uncr_bn_finalize_fwd_sums(const double* sums, double count, int N, int C, const float* gamma,
                                          const float* beta, float* running_mean, float* running_var, float momentum,
                                          float eps, float* coefA, float* coefB, float* save_mean, float* save_rstd,
-                                         const float* part, int NP, float* ub, hipStream_t stream) {
+                                         const float* part, int NP, float* ub, float* hb, hipStream_t stream) {
     if (!sums || count <= 0 || N <= 0 || C <= 0 || !gamma || !beta || !coefA || !coefB || !save_mean || !save_rstd)
         return UNCR_EINVAL;
     if (ub && (!part || NP <= 0)) return UNCR_EINVAL;
+    if (hb && !ub) return UNCR_EINVAL;
     hipLaunchKernelGGL(bn_finalize_fwd_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, count, N, C,
                        gamma, beta, running_mean, running_var, momentum, eps, coefA, coefB, save_mean, save_rstd,
-                       (const float2*)part, NP, ub);
+                       (const float2*)part, NP, ub, hb);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -479,21 +483,22 @@ extern "C" int uncr_bn_finalize_bwd_sums(const double* sums_local, const double*
 extern "C" int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                                       const float* gamma, const float* beta, float* running_mean,
                                       float* running_var, float momentum, float eps, float* coefA, float* coefB,
-                                      float* save_mean, float* save_rstd, float* ub, hipStream_t stream) {
+                                      float* save_mean, float* save_rstd, float* ub, float* hb, hipStream_t stream) {
     if (N <= 0 || C <= 0 || P <= 0) return UNCR_ESHAPE;
     if (ub && (!part || NP <= 0)) return UNCR_EINVAL;      // the bound is taken from the partial sums of squares
+    if (hb && !ub) return UNCR_EINVAL;
     if (kind == NORM_GROUP) {
         if (groups <= 0 || C % groups || !part) return UNCR_EINVAL;
         if (ub && C / groups > 256) return UNCR_ESHAPE;
         hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(N * groups), dim3(256), 0, stream, (const float2*)part, NP, C,
-                           groups, P, gamma, beta, eps, coefA, coefB, save_mean, save_rstd, ub);
+                           groups, P, gamma, beta, eps, coefA, coefB, save_mean, save_rstd, ub, hb);
     } else if (kind == NORM_BATCH_TRAIN || kind == NORM_BATCH_EVAL) {
         const int train = kind == NORM_BATCH_TRAIN;
         if (train && !part) return UNCR_EINVAL;
         if (!train && (!running_mean || !running_var)) return UNCR_EINVAL;
         hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(256), 0, stream, (const float2*)part, NP, N, C, P,
                            train, gamma, beta, running_mean, running_var, momentum, eps, coefA, coefB, save_mean,
-                           save_rstd, ub);
+                           save_rstd, ub, hb);
     } else {
         return UNCR_EINVAL;
     }

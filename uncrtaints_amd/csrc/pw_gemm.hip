@@ -596,7 +596,8 @@ extern "C" int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt,
                                const float* k1, const float* k2, const float* kmu, const void* dy, const void* x,
                                const void* xh3, const float* c1, const float* c2, const float* c3, const float* cmu,
                                const float* relu_a, const float* relu_b, float* part, int N, int Cin, int Cout, int P,
-                               int act, float* amax_out, hipStream_t stream) {
+                               int act, float* amax_out, const float* in_amax, int in_amax_n, const float* in2_amax,
+                               int in2_amax_n, hipStream_t stream) {
     if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
     if (!in || !in2 || !Wt || !out || !dy || !x || !c1 || !c2 || !c3) return UNCR_EINVAL;
     if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
@@ -609,6 +610,11 @@ extern "C" int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt,
     g.k3 = kmu;
     g.emu = cmu;
     g.amax_out = amax_out;
+    if ((in_amax && in_amax_n <= 0) || (in2_amax && in2_amax_n <= 0)) return UNCR_EINVAL;
+    // both operand bounds given (fp32 storage): two scaled fp16 parts, as the dz GEMM
+    g.h2 = in_amax != nullptr && in2_amax != nullptr;
+    g.in_amax = in_amax; g.in_amax_n = in_amax_n;
+    g.in2_amax = in2_amax; g.in2_amax_n = in2_amax_n;
     return pw_split_launch_p3(g, N, pw_coutp(Cout), act, stream);
 }
 

@@ -830,11 +830,17 @@ static int pws_launch_t(const PwArgs& g, int N, int cp, hipStream_t stream) {
 #if PWS_PRO == 3
         case 5:      // the backward of pw1 only: 256 -> 128 channels
             if (cp != 128) return UNCR_EINVAL;
-            hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 5, 2, TA>), grid, dim3(256), 0, stream, g);
+            if (sizeof(TA) == 4 && g.h2 && g.in_amax && g.in2_amax && g.in_amax_n > 0 && g.in2_amax_n > 0)
+                hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 5, 2, float, true>), grid, dim3(256), 0, stream, g);
+            else
+                hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 5, 2, TA>), grid, dim3(256), 0, stream, g);
             break;
         case 6:
             if (cp != 128) return UNCR_EINVAL;
-            hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 6, 2, TA>), grid, dim3(256), 0, stream, g);
+            if (sizeof(TA) == 4 && g.h2 && g.in_amax && g.in2_amax && g.in_amax_n > 0 && g.in2_amax_n > 0)
+                hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 6, 2, float, true>), grid, dim3(256), 0, stream, g);
+            else
+                hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 6, 2, TA>), grid, dim3(256), 0, stream, g);
             break;
 #endif
         default: return UNCR_EINVAL;

@@ -211,6 +211,7 @@ class NormFwd:
     groups: int
     sync_count: float = 0.0     # > 0: BatchNorm statistics were all-reduced over the data-parallel group (global count)
     ub: Optional[Tensor] = None  # [N*C] upper bounds on |A*h + B| per plane (range bookkeeping of the fp16 two-part GEMMs), or None
+    hb: Optional[Tensor] = None  # [N*C] upper bounds on |h| itself (for the gradient GEMMs that read h through a norm backward)
 
 
 _SYNC_BN = None      # process group for synchronised BatchNorm statistics (None: per-replica statistics, torch-DDP default)
@@ -232,7 +233,7 @@ def _all_reduce_sums(sums: Tensor) -> float:
 
 def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, training: bool, gamma: Tensor,
              beta: Tensor, running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None,
-             momentum: float = 0.1, eps: float = 1e-5, bound_part: Optional[Part] = None) -> NormFwd:
+             momentum: float = 0.1, eps: float = 1e-5, bound_part: Optional[Part] = None, want_hb: bool = False) -> NormFwd:
     """bound_part: (sum h, sum h^2) partials of the tensor this norm is applied to (in train mode `part` itself; in BatchNorm eval
     mode they serve only this): the finalize kernel then also emits per-plane upper bounds on |A*h + B| (NormFwd.ub), with which
     the consuming wide GEMM multiplies in two range-safe fp16 parts instead of the exact bf16 split (pw_gemm)."""
@@ -249,19 +250,21 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
         hb.call("uncr_bn_channel_sums", part.buf, part.slots, N, C, sums, _stream())
         count = _all_reduce_sums(sums) * N * P
         ub = _f32((N * C,), dev) if (bound_part is part and _H2_FWD) else None
+        hbt = _f32((N * C,), dev) if (ub is not None and want_hb) else None
         hb.call("uncr_bn_finalize_fwd_sums", sums, count, N, C, gamma, beta, running_mean, running_var, float(momentum),
-                float(eps), A, B, mean, rstd, part.buf if ub is not None else None, part.slots if ub is not None else 0, ub,
+                float(eps), A, B, mean, rstd, part.buf if ub is not None else None, part.slots if ub is not None else 0, ub, hbt,
                 _stream())
-        return NormFwd(A, B, mean, rstd, kind, groups, sync_count=count, ub=ub)
+        return NormFwd(A, B, mean, rstd, kind, groups, sync_count=count, ub=ub, hb=hbt)
     ub = None
     if bound_part is not None and _H2_FWD and (kind != NORM_GROUP or C // groups <= 256):
         if part is None:
             part = bound_part
         if part is bound_part:
             ub = _f32((N * C,), dev)
+    hbt = _f32((N * C,), dev) if (ub is not None and want_hb) else None
     hb.call("uncr_norm_finalize_fwd", part.buf if part else None, part.slots if part else 0, N, C, groups, P,
-            kind, gamma, beta, running_mean, running_var, float(momentum), float(eps), A, B, mean, rstd, ub, _stream())
-    return NormFwd(A, B, mean, rstd, kind, groups, ub=ub)
+            kind, gamma, beta, running_mean, running_var, float(momentum), float(eps), A, B, mean, rstd, ub, hbt, _stream())
+    return NormFwd(A, B, mean, rstd, kind, groups, ub=ub, hb=hbt)
 
 
 _CENTRED_NORMBWD = os.environ.get("UNCR_RAW_NORMBWD", "0") != "1"     # development A/B switch
@@ -269,6 +272,7 @@ _CENTRED_NORMBWD = os.environ.get("UNCR_RAW_NORMBWD", "0") != "1"     # developm
 # (UNCR_NO_H2_BWD=1: exact bf16 split there, no bookkeeping -- A/B runs)
 _H2_BWD = os.environ.get("UNCR_NO_H2_BWD", "0") != "1"
 _H2_WGRAD = os.environ.get("UNCR_NO_H2_WGRAD", "0") != "1"    # the dW2 weight-gradient products alone (A/B runs)
+_H2_DX = os.environ.get("UNCR_NO_H2_DX", "0") != "1"          # the dx GEMM (+ max |du1| in the depthwise backward) alone (A/B runs)
 # the same split in the forward GEMMs behind a norm (pw1 / pw2 of an MBConv), scaled per frame from the bounds the statistics
 # finalisation emits (UNCR_NO_H2_FWD=1: exact bf16 split -- A/B runs)
 _H2_FWD = os.environ.get("UNCR_NO_H2_FWD", "0") != "1"
@@ -563,7 +567,9 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
                   bound_part=x_part if h2ok else None)
     W1t = pack_wt(p["w1"].reshape(Ch, C), transpose=True)
     h1, part1 = pw_gemm(x, W1t, N, C, Ch, P, pro=PRO_AFFINE, k=(n0.A, n0.B, None), epi=1 if need else 0, in_amax=n0.ub)
-    n1 = norm_fwd(part1, N, Ch, P, spec, training, p["n1w"], p["n1b"], *rm(1))
+    # (hb: the bound on |h1| itself, for the backward's dx GEMM, which reads h1 through the norm-1 backward)
+    n1 = norm_fwd(part1, N, Ch, P, spec, training, p["n1w"], p["n1b"], *rm(1),
+                  bound_part=part1 if (h2ok and _H2_BWD and part1 is not None) else None, want_hb=True)
 
     h2 = _act((N, Ch, H, W), x.device, dt)
     slots = hb.query("uncr_dw_slots_fwd", H)
@@ -671,8 +677,13 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     wdw = p["wdw"].reshape(Ch, 9).contiguous()
     # statistics for the norm-1 backward in centred form (sum du1*(h1 - mean1)): h1 is the raw pw1 output, whose
     # channel means can be many standard deviations from zero
+    # with the bound on |h1| at hand (NormFwd.hb), the row kernel also leaves max |du1| per slot: the two operands of the dx GEMM are
+    # then bounded and it multiplies in two scaled fp16 parts
+    du1_amax = None
+    if _H2_BWD and _H2_DX and n1.hb is not None and hb.query("uncr_dw_bwd_emits_amax", H, W, dt, _DW_VARIANT) == 1:
+        du1_amax = _f32((N, Ch * slots), dev)
     hb.call("uncr_dw_bwd", du2, h2, h1, b2.c1, b2.c2, b2.c3, b2.mu, n1.A, n1.B, wdw, du1, part1.buf, dw_part, n1.mean,
-            n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, H, W, dt, _DW_VARIANT, _stream())
+            n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, H, W, dt, _DW_VARIANT, du1_amax, _stream())
     dwdw = _f32((Ch, 9), dev)
     with side_chain(dw_part):          # feeds a parameter gradient only: next to the pw1 weight-gradient GEMM
         hb.call("uncr_dw_wgrad_reduce", dw_part, N, Ch, slots, dwdw, _stream())
@@ -713,7 +724,8 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
                 dx_part.amax = _f32((N, slots), dev)
         hb.call("uncr_pw_gemm_dx", du1, h1, W1k, dx, k1[0], k1[1], k1[2], k1[3], dy, x, x_h3, b0.c1, b0.c2, b0.c3, b0.mu, ra, rb,
                 dx_part.buf if dx_part is not None else None, N, Ch, C, P, dt,
-                dx_part.amax if dx_part is not None else None, _stream())
+                dx_part.amax if dx_part is not None else None, du1_amax, du1_amax.shape[1] if du1_amax is not None else 0,
+                n1.hb if du1_amax is not None else None, Ch if du1_amax is not None else 0, _stream())
         join_side()
         return dx, g, dx_part
 
