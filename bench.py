@@ -43,9 +43,10 @@ def kernel_model(name, key):
         return (f"pw_gemm[{Cin}->{Cout},pro{pro},epi{epi},N{N},P{P}]", N * P * (rd + Cout * bo), 2.0 * N * P * Cin * Cout,
                 (2 if in_dt else (3 if h2 else 6)) if Cout > 64 else 0)
     if name == "uncr_pw_gemm_dx":          # in, in2 (norm-bwd prologue), dy, x, xh3 -> dx
-        N, Cin, Cout, P, act = key[-5:]
+        N, Cin, Cout, P, act = key[:5]        # (then the counts of the two magnitude arrays: both given = two scaled fp16 parts)
+        h2 = (not act) and len(key) > 6 and key[5] > 0 and key[6] > 0
         return (f"pw_gemm_dx[{Cin}->{Cout},N{N},P{P}]", (2.0 if act else 4.0) * N * P * (2 * Cin + 4 * Cout), 2.0 * N * P * Cin * Cout,
-                2 if act else 6)
+                2 if act else (3 if h2 else 6))
     if name == "uncr_residual_pool":       # x, h3 -> y (+ 8x8 max-pool)
         planes, H, W, OH, OW, act = key[-6:]
         return (f"residual_pool[planes{planes},{H}x{W}]", (2.0 if act else 4.0) * planes * H * W * 3, 0.0, 0)

@@ -214,6 +214,9 @@ def test_bench_two_ranks_segmented_graphs_gloo(act):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak" and res["value"] > 0
+    # the per-kernel model parses every profiled launch from its integer arguments: no entry may come out above the hardware
+    assert 0.0 <= res["roofline"]["frac"] <= 1.0, res["roofline"]
+    assert all(0.0 <= (r.get("gbs") or 0.0) <= 8000.0 for r in res.get("kernel_breakdown", [])), res.get("kernel_breakdown")
     assert res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
     assert "all-reduced" in res["launch_mode"] and "graph" in res["launch_mode"], res["launch_mode"]
     assert res["ranks"] == 2 and res["collective_backend"] == "gloo"
