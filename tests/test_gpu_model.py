@@ -397,11 +397,13 @@ def test_backward_through_the_model_in_eval_mode():
     ("widths_96", dict(encoder_widths=[96], decoder_widths=[96] * 2)),
     ("widths_32", dict(encoder_widths=[32], decoder_widths=[32] * 2)),
     ("two_decoder_blocks", dict(decoder_widths=[128] * 2)),
+    ("n_head_4", dict(n_head=4)),                           # 32 channels per head: the unfused L-TAE kernels
     ("n_head_8", dict(n_head=8)),
     ("n_head_32", dict(n_head=32)),
     ("scale_by_10", dict(scale_by=10.0)),                   # the README training configuration: eps = 1e-3 on the variance
     ("no_positional_encoding", dict(positional_encoding=False)),
     ("d_model_128", dict(d_model=128)),
+    ("d_model_512", dict(d_model=512)),                     # beyond the GEMM kernels' 256 channels: the fused L-TAE path never builds them
     ("d_k_8", dict(d_k=8)),
     ("mean_without_sigmoid", dict(out_nonlin_mean=False)),
     ("pad_value_1", dict(pad_value=1.0)),
@@ -441,9 +443,9 @@ def test_non_default_widths_and_heads(name, kw):
 def test_unsupported_head_split_raises():
     from uncrtaints_amd.src.backbones import uncrtaints as U
     with pytest.raises(NotImplementedError):
-        U.UNCRTAINTS(input_dim=15, n_head=4)          # 32 channels per head
+        U.UNCRTAINTS(input_dim=15, n_head=2)          # 64 channels per head
     with pytest.raises(NotImplementedError):
-        U.UNCRTAINTS(input_dim=15, d_model=512)       # wider than the GEMM kernels
+        U.UNCRTAINTS(input_dim=15, d_model=512, use_v=True)       # value projections wider than the GEMM kernels
     with pytest.raises(NotImplementedError):
         U.UNCRTAINTS(input_dim=15, encoder_widths=[256], decoder_widths=[256] * 2)
     from uncrtaints_amd import engine

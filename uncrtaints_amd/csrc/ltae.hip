@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256) void ltae_gn_fwd_kernel(const float* __restric
     (void)sq;
 }
 
-// backward; gb_part[(b*nchunk+chunk)][C][2] = per-block (d gamma, d beta) partials.  Cg <= 16.
+// backward; gb_part[(b*nchunk+chunk)][C][2] = per-block (d gamma, d beta) partials.  Cg <= CGMAX (16, or 32 for four heads at 128 channels).
+template <int CGMAX>
 __global__ __launch_bounds__(256) void ltae_gn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ mean,
@@ -239,15 +240,15 @@ __global__ __launch_bounds__(256) void ltae_gn_bwd_kernel(const float* __restric
     const int Cg = C / G;
     const bool act = s < S;
     float mu = 0.f, r = 0.f, m1 = 0.f, m2 = 0.f;
-    float dgam[16], dbet[16];
+    float dgam[CGMAX], dbet[CGMAX];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { dgam[j] = 0.f; dbet[j] = 0.f; }
+    for (int j = 0; j < CGMAX; ++j) { dgam[j] = 0.f; dbet[j] = 0.f; }
     if (act) {
         mu = mean[((size_t)b * G + g) * S + s];
         r = rstd[((size_t)b * G + g) * S + s];
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
+            for (int j = 0; j < CGMAX; ++j)
                 if (j < Cg) {
                     const int c = g * Cg + j;
                     const size_t o = (((size_t)b * T + t) * C + c) * S + s;
@@ -268,10 +269,10 @@ __global__ __launch_bounds__(256) void ltae_gn_bwd_kernel(const float* __restric
                 dx[o] = r * (gamma[c] * dy[o] - m1 - xh * m2);
             }
     }
-    __shared__ float red[4][32];
+    __shared__ float red[4][2 * CGMAX];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < CGMAX; ++j) {
         const float a = wave_sum(dgam[j]), bb = wave_sum(dbet[j]);
         if (lane == 0) { red[wv][2 * j] = a; red[wv][2 * j + 1] = bb; }
     }
@@ -489,9 +490,13 @@ extern "C" int uncr_ltae_gn_fwd(const float* x, const float* gamma, const float*
 extern "C" int uncr_ltae_gn_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                 const float* rstd, float* dx, float* gb_part, int B, int T, int C, int G, int S,
                                 hipStream_t stream) {
-    if (B <= 0 || T <= 0 || C % G || C / G > 16) return UNCR_ESHAPE;
-    hipLaunchKernelGGL(ltae_gn_bwd_kernel, dim3((S + 255) / 256, G, B), dim3(256), 0, stream, dy, x, gamma, mean,
-                       rstd, dx, gb_part, T, C, G, S);
+    if (B <= 0 || T <= 0 || C % G || C / G > 32) return UNCR_ESHAPE;
+    if (C / G > 16)
+        hipLaunchKernelGGL(ltae_gn_bwd_kernel<32>, dim3((S + 255) / 256, G, B), dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx,
+                           gb_part, T, C, G, S);
+    else
+        hipLaunchKernelGGL(ltae_gn_bwd_kernel<16>, dim3((S + 255) / 256, G, B), dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx,
+                           gb_part, T, C, G, S);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

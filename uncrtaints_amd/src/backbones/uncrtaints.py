@@ -451,12 +451,14 @@ class UNCRTAINTS(nn.Module):
             assert encoder_widths[-1] == decoder_widths[-1]
         else:
             decoder_widths = encoder_widths
-        if not is_mono and (encoder_widths[-1] % n_head or encoder_widths[-1] // n_head not in (2, 4, 6, 8, 16)):
+        if not is_mono and (encoder_widths[-1] % n_head or encoder_widths[-1] // n_head not in (2, 4, 6, 8, 16, 32)):
             raise NotImplementedError(f"encoder width {encoder_widths[-1]} with n_head={n_head}: the L-TAE / aggregation kernels are built "
-                                      "for 2, 4, 6, 8 or 16 channels per head")
-        if d_model is not None and d_model > 256 or max(list(encoder_widths) + list(decoder_widths)) > 128 and block_type == 'mbconv':
-            raise NotImplementedError("the GEMM kernels are built for at most 256 channels: d_model <= 256 and MBConv widths <= 128 "
-                                      "(hidden width = 2 x width)")
+                                      "for 2, 4, 6, 8, 16 or 32 channels per head")
+        # d_model beyond 256 runs wherever the fused L-TAE kernels apply (use_v off: the d_model-wide projections are folded into one
+        # [n_head, C] functional and never exist as activations, csrc/ltae_fused.hip); the unfused path's GEMMs end at 256 channels
+        if (d_model is not None and d_model > 256 and use_v) or max(list(encoder_widths) + list(decoder_widths)) > 128 and block_type == 'mbconv':
+            raise NotImplementedError("the GEMM kernels are built for at most 256 channels: MBConv widths <= 128 (hidden width = 2 x width), "
+                                      "d_model <= 256 with use_v")
         if block_type not in ('mbconv', 'residual'):
             raise NotImplementedError(block_type)
         if use_v and (agg_mode != "att_group" or is_mono):
@@ -576,8 +578,9 @@ class UNCRTAINTS(nn.Module):
         if not self.is_mono:
             te = self.temporal_encoder
             p = _ltae_params(te)
-            both(p["inconv_w"])
-            both(p["fc_w"])
+            if p["inconv_w"].shape[0] <= 256:       # (wider: only the fused kernels run it, and they read the raw weights)
+                both(p["inconv_w"])
+                both(p["fc_w"])
         if not self.separate_out:
             both(self.out_conv.conv.conv[0].weight)
         return out
