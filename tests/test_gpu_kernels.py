@@ -341,14 +341,15 @@ def test_ltae_attention_fwd_bwd(orc, E, T, padded, fused, heads, monkeypatch):
 
 
 @pytest.mark.parametrize("padded,masked,H,W", [(False, False, 64, 64), (True, False, 64, 64), (False, True, 64, 64),
-                                                 (False, False, 80, 64), (True, False, 48, 128)])   # 2.5x / 1.5x x 4x ratios
+                                                 (False, False, 80, 64), (True, False, 48, 128),    # 2.5x / 1.5x x 4x ratios
+                                                 (True, True, 256, 256)])   # the 8x case: the attention gradient is reduced in-kernel
 def test_aggregate_fwd_bwd(E, orc, padded, masked, H, W):
-    B, T, C = 2, 3, 128
+    B, T, C = (1, 3, 128) if H == 256 else (2, 3, 128)
     e = rand(B, T, C, H, W, seed=1)
     att = torch.softmax(rand(16, B, T, 32, 32, seed=2), dim=2)
     pad = torch.zeros(B, T, dtype=torch.bool)
     if padded:
-        pad[1, 0] = True
+        pad[B - 1, 0] = True
     dm = None
     if masked:
         dm = (torch.rand(16 * B, T, H, W, generator=torch.Generator().manual_seed(5)) > 0.1).float() / 0.9

@@ -65,7 +65,14 @@ __device__ __forceinline__ float agg_keep(const AggArgs& g, int h, int b, int t,
 // STAGE: the block's low-resolution attention rows (all its heads and dates) are copied to LDS once; the 16 taps per
 // (head, date) of a thread's 4 pixels then come from LDS instead of 16 scattered global loads (-20 us of 127 at the
 // bench shape).  Dynamic LDS = heads_per_block * T * agg_rows * AW floats; larger problems use the gather path.
-template <bool BWD, int CH, bool STAGE, typename T>
+// FOLD (backward, W == 256, H == 8 AH, W == 8 AW): the gradient of the up-sampled attention is reduced to the low-resolution grid
+// inside the kernel instead of being written at full resolution (NH*T planes, 50 MB at the bench shape) for a separate adjoint pass.
+// A wave holds one image row (64 lanes x 4 pixels); a lane's four pixels interpolate between the same two low-res columns, so its
+// contributions fall on cells f-1, f, f+1 (f = lane / 2) and a cell collects from four neighbouring lanes by shuffles in a fixed
+// order; the block's four rows interpolate between the same two low-res rows, whose 2 x 32 cells the waves combine through LDS, again
+// in a fixed order.  Per (head, date) the block leaves 2 x AW partial cells in datt_up (re-used as [NH*B*T][tiles][2][AW]);
+// datt_fold_reduce_kernel adds the (at most four) tiles that touch a low-res row.  Deterministic; no atomics.
+template <bool BWD, int CH, bool STAGE, typename T, bool FOLD = false>
 __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
     extern __shared__ float att_s[];
     const int b = blockIdx.y;
@@ -80,6 +87,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
     __shared__ float wred[4][256][2];   // per-wave statistics partials (forward), C <= 256
+    __shared__ float rowc[FOLD ? 2 : 1][4][32];      // FOLD: the four rows' cells, weighted for the two low-res rows
     // heads are split over blockIdx.z (more blocks in flight: the kernel is pure latency/bandwidth bound)
     const int hpb = (g.NH + gridDim.z - 1) / gridDim.z;
     const int h_beg = blockIdx.z * hpb, h_end = min(g.NH, h_beg + hpb);
@@ -135,10 +143,37 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
                     d[3] = fmaf(dgv.w, ev.w, d[3]);
                 }
             }
-            if constexpr (BWD) {
+            if constexpr (BWD && !FOLD) {
                 // gradient w.r.t. the up-sampled attention: keep * sum_j dg * e
                 *(float4*)(g.datt_up + (((size_t)h * g.B + b) * g.T + t) * P + p0) =
                     make_float4(d[0] * keep[0], d[1] * keep[1], d[2] * keep[2], d[3] * keep[3]);
+            }
+            if constexpr (BWD && FOLD) {
+                const int f = lane >> 1;
+                float vm = 0.f, v0 = 0.f, vp = 0.f;      // this lane's contributions to the cells f-1, f, f+1 of its row
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float dv = d[j] * keep[j];
+                    const float c0 = bx[j].l0 * dv, c1 = bx[j].l1 * dv;
+                    vm += (bx[j].i0 == f - 1 ? c0 : 0.f) + (bx[j].i1 == f - 1 ? c1 : 0.f);
+                    v0 += (bx[j].i0 == f ? c0 : 0.f) + (bx[j].i1 == f ? c1 : 0.f);
+                    vp += (bx[j].i0 == f + 1 ? c0 : 0.f) + (bx[j].i1 == f + 1 ? c1 : 0.f);
+                }
+                // cell a (at lane 2a) = vp[2a-1] + v0[2a] + v0[2a+1] + vm[2a+2]
+                const float from_left = __shfl(vp, (lane + 63) & 63, 64), from_r1 = __shfl(v0, (lane + 1) & 63, 64),
+                            from_r2 = __shfl(vm, (lane + 2) & 63, 64);
+                const float cell = (((lane > 0 ? from_left : 0.f) + v0) + from_r1) + (lane < 62 ? from_r2 : 0.f);
+                __syncthreads();                 // the previous date's cells have been read
+                if ((lane & 1) == 0) {
+                    rowc[0][wv][f] = by.l0 * cell;
+                    rowc[1][wv][f] = by.l1 * cell;
+                }
+                __syncthreads();
+                if (threadIdx.x < 64) {
+                    const int r = threadIdx.x >> 5, a = threadIdx.x & 31;
+                    g.datt_up[((((size_t)h * g.B + b) * g.T + t) * gridDim.x + blockIdx.x) * 2 * g.AW + r * g.AW + a] =
+                        ((rowc[r][0][a] + rowc[r][1][a]) + rowc[r][2][a]) + rowc[r][3][a];
+                }
             }
         }
         if constexpr (!BWD) {
@@ -209,6 +244,27 @@ __global__ __launch_bounds__(256) void bilinear_adjoint_kernel(const float* __re
     }
 }
 
+// datt[q][r][a] = sum over the 1024-pixel tiles whose rows interpolate from low-res row r (tile order, fixed)
+__global__ __launch_bounds__(256) void datt_fold_reduce_kernel(const float* __restrict__ dpart, float* __restrict__ datt, int H, int W,
+                                                               int AH, int AW, int ntile, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int a = (int)(i % AW), r = (int)((i / AW) % AH);
+    const long long q = i / ((long long)AW * AH);
+    const float sy = (float)AH / (float)H;
+    const int rows_per_tile = AGG_PX / W;
+    // rows 8r-8 .. 8r+15 can interpolate from low-res row r: the tiles that hold them
+    const int t0 = max(0, (8 * r - 8) / rows_per_tile), t1 = min(ntile - 1, (8 * r + 15) / rows_per_tile);
+    float s = 0.f;
+    for (int k = t0; k <= t1; ++k) {
+        const Bilin by = bilin_src(k * rows_per_tile, sy, AH);
+        const float* src = dpart + ((size_t)q * ntile + k) * 2 * AW + a;
+        if (by.i0 == r) s += src[0];
+        if (by.i1 == r) s += src[AW];
+    }
+    datt[i] = s;
+}
+
 extern "C" int uncr_agg_slots(int P) { return P / AGG_PX; }
 
 static int agg_check(int B, int T, int C, int NH, int H, int W, int AH, int AW) {
@@ -228,6 +284,9 @@ static int agg_rows(int H, int W, int AH) {
     return r > AH ? AH : r;
 }
 
+// the in-kernel adjoint of the up-sampling (aggregate_kernel FOLD) applies to the 8x up-sampling of 256-pixel rows
+static bool agg_fold(const AggArgs& g) { return g.W == 256 && g.W == 8 * g.AW && g.H == 8 * g.AH && g.AW == 32; }
+
 template <bool BWD, typename T>
 static void agg_launch(const AggArgs& g, hipStream_t stream) {
     const int zs = g.NH <= 64 ? g.NH : (g.NH % 4 == 0 ? 4 : 1);      // one head per block: measured 4 % faster than four (more blocks in flight)
@@ -235,9 +294,12 @@ static void agg_launch(const AggArgs& g, hipStream_t stream) {
     const int nrows = agg_rows(g.H, g.W, g.AH);
     const size_t lds = (size_t)((g.NH + zs - 1) / zs) * g.T * nrows * g.AW * sizeof(float);
     const bool stage = lds <= 48 * 1024;
+    const bool fold = BWD && agg_fold(g);
 #define AGG_GO(CHV)                                                                                              \
     do {                                                                                                         \
-        if (stage) hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, true, T>), grid, dim3(256), lds, stream, g, nrows); \
+        if (fold && stage) hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, true, T, BWD>), grid, dim3(256), lds, stream, g, nrows); \
+        else if (fold) hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, false, T, BWD>), grid, dim3(256), 0, stream, g, nrows);      \
+        else if (stage) hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, true, T>), grid, dim3(256), lds, stream, g, nrows); \
         else hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, false, T>), grid, dim3(256), 0, stream, g, nrows);        \
     } while (0)
     switch (g.C / g.NH) {
@@ -274,8 +336,13 @@ extern "C" int uncr_aggregate_bwd(const void* dg, const void* e, const float* at
     AggArgs g{e, att, pad, dmask, nullptr, dg, de, datt_up, nullptr, seed, seed_dev, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
     UNCR_DISPATCH_ACT(act, T, (agg_launch<true, T>(g, stream)));
     UNCR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(AH, NH * B * T), dim3(256), 0, stream, datt_up, datt, H, W, AH,
-                       AW);
+    if (agg_fold(g)) {       // the kernel left per-tile partial cells in datt_up
+        const long long n = (long long)NH * B * T * AH * AW;
+        hipLaunchKernelGGL(datt_fold_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, datt_up, datt, H, W, AH,
+                           AW, H * W / AGG_PX, n);
+    } else {
+        hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(AH, NH * B * T), dim3(256), 0, stream, datt_up, datt, H, W, AH, AW);
+    }
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
