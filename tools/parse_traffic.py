@@ -10,7 +10,7 @@ if BF16:
     sys.argv.remove("--bf16")
 EB = 2 if BF16 else 4
 if BF16:
-    KEYS = [("dw_bwd_row_kernel<unsigned short>", "dw_bwd[N4,C256,256x256]", EB * 4 * 256 * 65536 * 4),
+    KEYS = [("dw_bwd_row_kernel<unsigned short", "dw_bwd[N4,C256,256x256]", EB * 4 * 256 * 65536 * 4),
             ("dw_fwd_row_kernel<unsigned short>", "dw_fwd[N4,C256,256x256]", EB * 4 * 256 * 65536 * 2),
             ("pw_gemm_split_kernel<2, 3, 3, 1, unsigned short, false>", "pw_gemm[128->256,pro3,epi3,N4,P65536]", EB * 4 * 65536 * (2 * 128 + 2 * 256)),
             ("pw_gemm_split_kernel<2, 1, 1, 1, unsigned short, false>", "pw_gemm[128->256,pro1,epi1,N4,P65536]", EB * 4 * 65536 * (128 + 256)),
