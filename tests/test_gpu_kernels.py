@@ -368,6 +368,22 @@ def test_aggregate_fwd_bwd(E, orc, padded, masked, H, W):
     close("agg_datt", datt, ao.grad)
 
 
+def test_ltae_parameter_composition_at_a_large_batch(E, orc):
+    """B*T = 768 frames: the composition kernel's per-frame tables (80 B of LDS per frame) pass the default 48 KB dynamic-LDS limit;
+    the attention still matches the oracle (4 x 4 low-resolution pixels keep the CPU side small)."""
+    from uncrtaints_amd.src.backbones.ltae import LTAE2dtiny
+    torch.manual_seed(2)
+    B, T = 128, 6
+    m = LTAE2dtiny(in_channels=128, n_head=16, d_k=4, d_model=256)
+    down = rand(B, T, 128, 4, 4, seed=3)
+    dates = torch.sort(torch.randint(1400, 1800, (B, T)), dim=1).values.float()
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    p = {"temporal_encoder." + k: v.detach().clone() for k, v in m.state_dict().items()}
+    att_o = orc.ltae_tiny_attention(down, dates, pad, p, orc.OracleConfig())
+    att = m.to(DEV)(dev(down), batch_positions=dev(dates), pad_mask=dev(pad))
+    close("ltae_att[B*T=768]", att, att_o)
+
+
 def test_aggregator_avgpool_branch_vs_reference_fixture():
     """Compact_Temporal_Aggregator called with feature maps smaller than the 32 x 32 attention map: the reference's AvgPool2d branch
     (uncrtaints.py:197-204; no dropout, train mode included) -- outputs and both gradients against the reference-generated g18."""

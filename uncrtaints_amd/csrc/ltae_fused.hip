@@ -506,7 +506,15 @@ extern "C" int uncr_ltae_compose(const float* Q, const float* Wk, const float* b
     if (!use_pe) dpe = 1;
     const size_t ncomb = (size_t)(2 * DK * C > 1024 ? 2 * DK * C : 1024);
     const size_t lds = ncomb * sizeof(double) + ((size_t)NF * dpe + (size_t)DK * C + (size_t)DK * NF) * sizeof(float);
-    if (lds > 64 * 1024) return UNCR_ESHAPE;
+    if (lds > 150 * 1024) return UNCR_ESHAPE;       // B*T beyond ~1800 frames
+    if (lds > 48 * 1024) {      // dynamic LDS above the default limit needs the opt-in (large batches: 80 B per frame)
+        static size_t allowed = 0;
+        if (lds > allowed) {
+            if (hipFuncSetAttribute((const void*)ltae_compose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                return UNCR_ESHAPE;
+            allowed = 150 * 1024;
+        }
+    }
     hipLaunchKernelGGL(ltae_compose_kernel, dim3(NH), dim3(1024), lds, stream, Q, Wk, bk, Wi, bin, dates, denom, dpe, use_pe, gamma,
                        beta, DK, D, C, NF, bias1, Ap, Bp, M, U);
     UNCR_LAUNCH_CHECK();
