@@ -396,18 +396,18 @@ int uncr_ensemble_combine(const float* mu, const float* var, int M, long long n,
                           float* var_out, hipStream_t stream);
 
 /* ---- the optimizer step of the reference's train step (base_model.py:48,60-131: torch.optim.Adam(params, lr), default betas and eps)
- *      for up to uncr_adam_max_tensors() tensors in one launch.  desc (device) [n_tensors][4] int64 = {param, exp_avg, exp_avg_sq
- *      addresses, element count}; grads_host: HOST array [n_tensors] of the gradients' device addresses (they change every step; they
+ *      for up to uncr_adam_max_tensors() tensors in one launch.  desc (device) [n_tensors][5] int64 = {param, exp_avg, exp_avg_sq
+ *      addresses, element count, address of the tensor's own step counter}; grads_host: HOST array [n_tensors] of the gradients' device addresses (they change every step; they
  *      travel by value in the kernel arguments, so a captured graph holds them without a copy node); chunks (device) [n_chunks][2]
  *      int32 = {tensor index, first element}, one block each, uncr_adam_chunk() elements per chunk.
- *      step_dev: device float holding the step count t ALREADY incremented for this update; lr_dev (nullable): device float that
+ *      step counter: one device float PER TENSOR (torch.optim.Adam keeps a step per parameter; they diverge when layers are unfrozen
+ *      later, train_reconstruct.py:657-660) holding the count t ALREADY incremented for this update; lr_dev (nullable): device float that
  *      overrides lr.  Arithmetic as torch.optim.Adam (L2 weight decay, no amsgrad): m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2;
  *      p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps). ---- */
 int uncr_adam_chunk(void);
 int uncr_adam_max_tensors(void);
 int uncr_adam_step(const long long* desc, const long long* grads_host, int n_tensors, const int* chunks, int n_chunks, float lr,
-                   const float* lr_dev, double beta1, double beta2, float eps, float weight_decay, const float* step_dev,
-                   hipStream_t stream);
+                   const float* lr_dev, double beta1, double beta2, float eps, float weight_decay, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -374,6 +374,92 @@ def case_aggpool():
     print("g18_aggpool", 3)
 
 
+def case_attention_rows():
+    """G19: the attention classes of model/src/backbones/ltae.py called ON THEIR OWN on pixel-major rows (their native layout):
+    ScaledDotProductAttentionSmall (:418-458), ScaledDotProductAttention (:388-416, eval: no dropout), MultiHeadAttentionSmall
+    (:313-385), MultiHeadAttention (:244-307) and LTAE2d (:10-141, eval and train) -- forward outputs and every gradient, each case
+    with a padded date.  The stand-alone entries of the HIP path (csrc/attn_rows.hip) are held to these."""
+    from src.backbones import ltae as R
+    out = {}
+    gen = torch.Generator().manual_seed(19)
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    # -- scaled dot-product attention on rows: q [m, dk], k [m, T, dk], v [m, T, dv], pad [m, T]
+    for i, (cls, T, dk, dv) in enumerate((("ScaledDotProductAttentionSmall", 3, 4, 16), ("ScaledDotProductAttentionSmall", 6, 8, 8),
+                                          ("ScaledDotProductAttention", 4, 4, 16))):
+        m = 333
+        q, k, v = (t.requires_grad_(True) for t in (rn(m, dk), rn(m, T, dk), rn(m, T, dv)))
+        pad = torch.rand(m, T, generator=gen) < 0.3
+        pad[:, 0] = False
+        ga, go, gc = rn(m, 1, T), rn(m, 1, dv), rn(m, 1, T)
+        temp = float(np.power(dk, 0.5))
+        if cls.endswith("Small"):
+            mod = R.ScaledDotProductAttentionSmall(temperature=temp)
+            o, a, c = mod(q, k, v, pad_mask=pad, return_comp=True, weight_v=True)
+        else:
+            mod = R.ScaledDotProductAttention(temperature=temp, attn_dropout=0.1).eval()
+            o, a, c = mod(q, k, v, pad_mask=pad, return_comp=True)
+        ((a * ga).sum() + (o * go).sum() + (c * gc).sum()).backward()
+        out.update({f"sdpa{i}/cls": np.array(cls), f"sdpa{i}/temperature": np.float64(temp), f"sdpa{i}/q": q.detach().numpy(),
+                    f"sdpa{i}/k": k.detach().numpy(), f"sdpa{i}/v": v.detach().numpy(), f"sdpa{i}/pad": pad.numpy(),
+                    f"sdpa{i}/ga": ga.numpy(), f"sdpa{i}/go": go.numpy(), f"sdpa{i}/gc": gc.numpy(),
+                    f"sdpa{i}/out": o.detach().numpy(), f"sdpa{i}/attn": a.detach().numpy(), f"sdpa{i}/comp": c.detach().numpy(),
+                    f"sdpa{i}/dq": q.grad.numpy(), f"sdpa{i}/dk": k.grad.numpy(), f"sdpa{i}/dv": v.grad.numpy()})
+    # -- multi-head attention on rows: v [n, T, d_in]
+    for i, (cls, weight_v) in enumerate((("MultiHeadAttentionSmall", False), ("MultiHeadAttentionSmall", True), ("MultiHeadAttention", True))):
+        nh, dk, d_in, n, T = 16, 4, 256, 70, 3
+        torch.manual_seed(190 + i)
+        mod = R.MultiHeadAttentionSmall(n_head=nh, d_k=dk, d_in=d_in) if cls.endswith("Small") \
+            else R.MultiHeadAttention(n_head=nh, d_k=dk, d_in=d_in, use_dropout=False)
+        with torch.no_grad():
+            mod.fc1_k.bias.copy_(0.3 * rn(nh * dk))
+        mod.eval()
+        v = rn(n, T, d_in).requires_grad_(True)
+        pad = torch.zeros(n, T, dtype=torch.bool)
+        pad[::3, T - 1] = True
+        ga, go = rn(nh, n, T), rn(nh, n, d_in // nh)
+        if cls.endswith("Small"):
+            res = mod(v, pad_mask=pad, weight_v=weight_v)
+            o, a = res if weight_v else (None, res)
+        else:
+            o, a = mod(v, pad_mask=pad)
+        ((a * ga).sum() + ((o * go).sum() if o is not None else 0.0)).backward()
+        out.update({f"mha{i}/cls": np.array(cls), f"mha{i}/weight_v": np.array(weight_v), f"mha{i}/v": v.detach().numpy(),
+                    f"mha{i}/pad": pad.numpy(), f"mha{i}/ga": ga.numpy(), f"mha{i}/go": go.numpy(), f"mha{i}/attn": a.detach().numpy(),
+                    f"mha{i}/dv": v.grad.numpy(), f"mha{i}/W": mod.fc1_k.weight.detach().numpy(), f"mha{i}/b": mod.fc1_k.bias.detach().numpy(),
+                    f"mha{i}/Q": mod.Q.detach().numpy(), f"mha{i}/dW": mod.fc1_k.weight.grad.numpy(), f"mha{i}/db": mod.fc1_k.bias.grad.numpy(),
+                    f"mha{i}/dQ": mod.Q.grad.numpy()})
+        if o is not None:
+            out[f"mha{i}/out"] = o.detach().numpy()
+    # -- LTAE2d on [B, T, C, h, w] (values + attention), eval and train (dropout 0: the reference's streams do not travel)
+    for i, training in enumerate((False, True)):
+        C, nh, dk, B, T, hw = 128, 16, 4, 2, 3, 8
+        torch.manual_seed(195 + i)
+        mod = R.LTAE2d(in_channels=C, n_head=nh, d_k=dk, mlp=[256, C], dropout=0.0, d_model=256, return_att=True, use_dropout=False)
+        with torch.no_grad():
+            mod.in_norm.weight.copy_(1.0 + 0.3 * rn(C)); mod.in_norm.bias.copy_(0.2 * rn(C))
+            mod.out_norm.weight.copy_(1.0 + 0.3 * rn(C)); mod.out_norm.bias.copy_(0.2 * rn(C))
+            mod.mlp[1].weight.copy_(1.0 + 0.3 * rn(C)); mod.mlp[1].bias.copy_(0.2 * rn(C))
+            mod.mlp[1].running_mean.copy_(0.1 * rn(C)); mod.mlp[1].running_var.copy_(0.5 + torch.rand(C, generator=gen))
+            mod.attention_heads.fc1_k.bias.copy_(0.3 * rn(nh * dk))
+        mod.train(training)
+        state0 = {k: v.detach().clone().numpy() for k, v in mod.state_dict().items()}
+        x = rn(B, T, C, hw, hw).requires_grad_(True)
+        dates = torch.sort(torch.randint(1400, 1800, (B, T), generator=gen), dim=1).values.float()
+        pad = torch.zeros(B, T, dtype=torch.bool)
+        pad[1, T - 1] = True
+        gv, ga = rn(B, C, hw, hw), rn(nh, B, T, hw, hw)
+        o, a = mod(x, batch_positions=dates, pad_mask=pad)
+        ((o * gv).sum() + (a * ga).sum()).backward()
+        out.update({f"ltae{i}/training": np.array(training), f"ltae{i}/x": x.detach().numpy(), f"ltae{i}/dates": dates.numpy(),
+                    f"ltae{i}/pad": pad.numpy(), f"ltae{i}/gv": gv.numpy(), f"ltae{i}/ga": ga.numpy(), f"ltae{i}/out": o.detach().numpy(),
+                    f"ltae{i}/attn": a.detach().numpy(), f"ltae{i}/dx": x.grad.numpy()})
+        out.update({f"ltae{i}/state/{k}": v for k, v in state0.items()})
+        out.update({f"ltae{i}/grad/{k}": p.grad.numpy() for k, p in mod.named_parameters() if p.grad is not None})
+        out.update({f"ltae{i}/after/{k}": v.detach().numpy() for k, v in mod.state_dict().items() if "running" in k})
+    np.savez_compressed(os.path.join(HERE, "g19_attention_rows.npz"), **out)
+    print("g19_attention_rows", len(out), "arrays")
+
+
 def case_posenc():
     pe = PositionalEncoder(256 // 16, T=1000, repeat=16)
     dates = torch.tensor([[1400., 1433., 1799.], [0., 1., 1000.]])
@@ -684,6 +770,8 @@ if __name__ == "__main__":
     case_smallmap(); sys.exit(0)
   if "--only-aggpool" in sys.argv:
     case_aggpool(); sys.exit(0)
+  if "--only-attention-rows" in sys.argv:
+    case_attention_rows(); sys.exit(0)
   if "--only-usev" in sys.argv:
     case_usev(); sys.exit(0)
   if "--only-residual" in sys.argv:
@@ -697,6 +785,7 @@ if __name__ == "__main__":
     case_calibration()
     case_smallmap()
     case_aggpool()
+    case_attention_rows()
     case_usev()
     case_residual()
     case_posenc()

@@ -45,6 +45,25 @@ def test_library_keeps_no_switches(built):
     assert "getenv" not in syms
 
 
+def test_python_layer_reads_no_environment_switches():
+    """The arithmetic path of the Python layer above the library is fixed as well: engine.py and the module classes never read the
+    process environment (development switches are module constants flipped through `engine.dev_options(...)` by tools and tests)."""
+    import glob
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "uncrtaints_amd")
+    files = [os.path.join(root, "engine.py"), os.path.join(root, "optim.py"), os.path.join(root, "parallel.py")] + \
+        glob.glob(os.path.join(root, "src", "**", "*.py"), recursive=True)
+    for f in files:
+        src = open(f).read()
+        assert "os.environ" not in src and "getenv" not in src, f
+    from uncrtaints_amd import engine
+    with engine.dev_options(h2_fwd=False):
+        assert engine._H2_FWD is False
+    assert engine._H2_FWD is True
+    with pytest.raises(KeyError):
+        engine.dev_options(no_such_switch=1)
+
+
 def test_size_queries(built):
     assert hb.query("uncr_version") >= 1
     assert hb.query("uncr_pw_coutp", 26) == 32 and hb.query("uncr_pw_coutp", 128) == 128

@@ -1132,15 +1132,11 @@ def test_mbconv_eval_mode_with_running_statistics_far_from_the_data(orc, E):
     md = m.to(DEV)
     errs = {}
     for name, h2 in (("fp16x2", True), ("bf16x3", False)):
-        old = engine._H2_FWD
-        engine._H2_FWD = h2
-        try:
+        with engine.dev_options(h2_fwd=h2):
             xd = dev(x)
             xd._uncr_part = E.stats_sq(xd, N * 128, H * W)         # what the producing block leaves on its output
             with torch.no_grad():
                 yd = md(xd)
-        finally:
-            engine._H2_FWD = old
         assert bool(torch.isfinite(yd).all())
         errs[name] = float((yd.cpu().double() - y64).abs().max() / y64.abs().max())
     print(f"[parity] eval-mode MBConv, running variance 1e-6 x data: fp16 two-part {errs['fp16x2']:.2e}, bf16 three-part {errs['bf16x3']:.2e}")

@@ -174,6 +174,65 @@ def test_train_step_replayed_from_a_hip_graph_equals_eager_steps():
     assert far <= 0.01 * total
 
 
+def test_graph_mode_survives_an_optimizer_checkpoint_with_a_float_learning_rate():
+    """Resume in graph mode from a checkpoint whose optimizer state carries `lr` as a Python float (what the reference and an eager
+    run save, model_utils.py:117-196): the captured step must keep reading the learning rate from the device -- the schedule has to
+    reach the replays -- and a state reload after a capture must re-capture (the graph held the old moments' addresses)."""
+    import copy
+    from types import SimpleNamespace
+    from uncrtaints_amd.src.backbones.base_model import BaseModel
+    g = load_golden("g6_trainseq")
+    meta = json.loads(str(g["meta"]))
+
+    def make(hip_graph):
+        cfg = SimpleNamespace(model="uncrtaints", use_sar=True, encoder_widths=[128], decoder_widths=[128] * 5,
+                              out_conv=[26], mean_nonLinearity=True, var_nonLinearity="softplus", agg_mode="att_group",
+                              encoder_norm="group", decoder_norm="batch", n_head=16, d_model=256, d_k=4, pad_value=0,
+                              padding_mode="reflect", positional_encoding=True, covmode="diag", scale_by=meta["scale_by"],
+                              separate_out=False, use_v=False, block_type="mbconv", pretrain=False, loss="MGNLL",
+                              lr=meta["lr"], gamma=0.5, device=DEV, chunk_size=None, hip_graph=hip_graph)
+        model = BaseModel(cfg)
+        model.netG.load_state_dict(_state(g), strict=True)
+        model.netG.temporal_aggregator.attn_dropout.p = 0.0
+        return model.to(DEV).train()
+    x, y, dates = (torch.from_numpy(g[k]) for k in ("x", "y", "dates"))
+    batch = {"A": x, "B": y, "dates": dates, "masks": None}
+
+    def step(m):
+        m.set_input(batch); m.optimize_parameters(); return m.loss_G.item()
+    eager = make(False)
+    for _ in range(2):
+        step(eager)
+    ckpt_opt = copy.deepcopy(eager.optimizer_G.state_dict())
+    ckpt_net = {k: v.clone() for k, v in eager.netG.state_dict().items()}
+    assert isinstance(ckpt_opt["param_groups"][0]["lr"], float)
+    # the eager continuation: three more steps, the learning rate halved after the first of them
+    ref = []
+    for i in range(4):
+        ref.append(step(eager))
+        if i == 0:
+            eager.scheduler_G.step()
+    # graph mode: capture first (three steps), THEN load the checkpoint -- the graph must be dropped and the lr stay on the device
+    gm = make(True)
+    for _ in range(3):
+        step(gm)
+    assert any(v["graph"] is not None for v in gm._graphs.values())
+    gm.netG.load_state_dict(ckpt_net)
+    gm.optimizer_G.load_state_dict(copy.deepcopy(ckpt_opt))
+    lr = gm.optimizer_G.param_groups[0]["lr"]
+    assert isinstance(lr, torch.Tensor) and lr.is_cuda
+    got = []
+    for i in range(4):
+        got.append(step(gm))
+        if i == 0:
+            gm.scheduler_G.step()
+    assert gm.optimizer_G.param_groups[0]["lr"] is lr and abs(float(lr) - 0.5 * meta["lr"]) < 1e-9
+    print("[parity] resumed eager", ref, "resumed graph", got)
+    for a, b in zip(ref, got):
+        assert abs(a - b) < 1e-4 * abs(a), (ref, got)
+    assert any(v["graph"] is not None for v in gm._graphs.values())      # steps 3, 4 were replays of a fresh capture
+
+
 @pytest.mark.parametrize("B,T,H,W,special", [
     (1, 3, 256, 256, ""), (2, 2, 128, 64, ""),
     (1, 2, 80, 64, ""),            # overlapping adaptive-pool windows, 2.5x up-sampling

@@ -123,3 +123,59 @@ def test_fused_adam_in_a_captured_graph_with_a_device_learning_rate():
     for x, y in zip(a, b):
         assert float((x - y).abs().max() / (5e-3 + 0.25 * y.abs().max())) < 5e-6            # 5e-3: the distance the six steps cover
     assert float(oa.state[a[0]]["step"]) == 6.0
+
+
+@pytest.mark.gpu
+def test_parameters_that_join_later_keep_their_own_step_count():
+    """torch.optim.Adam counts steps PER PARAMETER: layers unfrozen after `unfreeze_after` epochs (train_reconstruct.py:657-660), or
+    any parameter without a gradient in some steps, start their bias corrections at 1 while the others are far ahead.  Half of the
+    group receives gradients from step 0, the other half only from step 4 on -- the first tensor of the group among the late ones."""
+    from uncrtaints_amd.optim import FusedAdam
+    a, b = _params("cuda"), _params("cuda")
+    oa, ob = FusedAdam(a, lr=2e-3), torch.optim.Adam(b, lr=2e-3)
+    late = {0, 2, 5, 7}
+    for s in range(9):
+        _grads(a, s); _grads(b, s)
+        if s < 4:
+            for i in late:
+                a[i].grad = None; b[i].grad = None
+        oa.step(); ob.step()
+    for i, (x, y, y0) in enumerate(zip(a, b, _params("cuda"))):
+        assert float(oa.state[x]["step"]) == float(ob.state[y]["step"]) == (5.0 if i in late else 9.0)
+        e = float((x.detach() - y.detach()).abs().max() / ((y.detach() - y0.detach()).abs().max() + 0.25 * y.detach().abs().max()))
+        assert e < 2e-6, (i, e)
+        for k in ("exp_avg", "exp_avg_sq"):
+            u, v = oa.state[x][k], ob.state[y][k]
+            assert float((u - v).abs().max() / v.abs().max().clamp_min(1e-30)) < 2e-6, (i, k)
+
+
+@pytest.mark.gpu
+def test_load_state_dict_keeps_a_device_learning_rate_and_signals_new_state():
+    """A checkpoint of the reference (or of an eager run) holds `lr` as a float; torch's load_state_dict would replace the device scalar
+    a captured step reads.  FusedAdam keeps the tensor, fills it with the loaded value, drops its address tables and bumps state_epoch."""
+    import copy
+    from uncrtaints_amd.optim import FusedAdam
+    a, b = _params("cuda"), _params("cuda")
+    ob = torch.optim.Adam(b, lr=7e-4)
+    for s in range(2):
+        _grads(b, s); ob.step()
+    lr = torch.tensor(1e-3, device="cuda")
+    oa = FusedAdam(a, lr=lr)
+    sched = torch.optim.lr_scheduler.ExponentialLR(oa, gamma=0.5)
+    _grads(a, 0); oa.step()
+    e0 = oa.state_epoch
+    oa.load_state_dict(copy.deepcopy(ob.state_dict()))
+    assert oa.param_groups[0]["lr"] is lr and abs(float(lr) - 7e-4) < 1e-10
+    assert oa.state_epoch == e0 + 1 and not oa._uncr_tables
+    for x, y in zip(a, b):
+        x.data.copy_(y.data)
+    sched.step(); ob.param_groups[0]["lr"] = float(oa.param_groups[0]["lr"])
+    assert oa.param_groups[0]["lr"] is lr          # the scheduler updates the SAME device scalar
+    _grads(a, 5); _grads(b, 5)
+    oa.step(); ob.step()
+    for x, y in zip(a, b):
+        assert float((x - y).abs().max() / (1e-3 + 0.25 * y.abs().max())) < 5e-6
+    # the raw-pointer update is visible to version-checked caches
+    v0 = a[1]._version
+    _grads(a, 6); oa.step()
+    assert a[1]._version > v0

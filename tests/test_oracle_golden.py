@@ -233,3 +233,28 @@ def test_aggregator_avgpool_branch_matches_reference():
         out.backward(gy)
         assert rel_err(out.detach().numpy(), g[f"k{i}/out"]) < 1e-6
         assert rel_err(x.grad.numpy(), g[f"k{i}/dx"]) < 1e-6 and rel_err(att.grad.numpy(), g[f"k{i}/datt"]) < 1e-6
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_oracle_ltae2d_vs_reference_rows_fixture(i):
+    """G19 (reference LTAE2d called on its own, eval and train): the oracle's value + attention path reproduces the reference's
+    outputs, input gradient and running statistics."""
+    import torch
+    from oracle import uncrtaints_oracle as orc
+    g, pre = load_golden("g19_attention_rows"), f"ltae{i}/"
+    training = bool(g[pre + "training"])
+    p = {}
+    for k in g.files:
+        if k.startswith(pre + "state/"):
+            t = torch.from_numpy(g[k]).clone()
+            p["temporal_encoder." + k[len(pre + "state/"):]] = t
+    nh, dk = p["temporal_encoder.attention_heads.Q"].shape
+    cfg = orc.OracleConfig(n_head=nh, d_k=dk, d_model=256, ltae_dropout=0.0)
+    x = torch.from_numpy(g[pre + "x"]).clone().requires_grad_(True)
+    v, a = orc.ltae2d_values_attention(x, torch.from_numpy(g[pre + "dates"]), torch.from_numpy(g[pre + "pad"]), p, cfg, training)
+    assert rel_err(v.detach().numpy(), g[pre + "out"]) < 2e-5
+    assert rel_err(a.detach().numpy(), g[pre + "attn"]) < 2e-5
+    ((v * torch.from_numpy(g[pre + "gv"])).sum() + (a * torch.from_numpy(g[pre + "ga"])).sum()).backward()
+    assert rel_err(x.grad.numpy(), g[pre + "dx"]) < 1e-4
+    if training:
+        assert rel_err(p["temporal_encoder.mlp.1.running_mean"].numpy(), g[pre + "after/mlp.1.running_mean"]) < 2e-5

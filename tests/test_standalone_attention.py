@@ -1,8 +1,11 @@
 """-m gpu: the attention classes of model/src/backbones/ltae.py called ON THEIR OWN (pixel-major rows [B*H*W, T, d], the layout the
 reference defines them on): ScaledDotProductAttentionSmall (ltae.py:431-458), ScaledDotProductAttention (:399-416),
 MultiHeadAttentionSmall (:341-385), MultiHeadAttention (:266-307), LTAE2d (:84-141) and the d_model=None variants (:49-54, :177-182).
-Checked against the same arithmetic in fp32 torch on the CPU (forward and every gradient)."""
+Checked against the same arithmetic in fp32 torch on the CPU (forward and every gradient) AND against outputs of the reference's own
+classes (fixture g19_attention_rows, made by tests/golden/make_golden.py::case_attention_rows)."""
 import math
+
+import numpy as np
 
 import pytest
 import torch
@@ -188,3 +191,95 @@ def test_ltae2dtiny_without_projection(orc):
     a_ref = orc.ltae_tiny_attention(down, dates, pad, p, cfg)
     a = m.to(DEV)(dev(down), batch_positions=dev(dates), pad_mask=dev(pad))
     close("ltae_tiny_no_projection", a, a_ref)
+
+
+# ---- the same classes against outputs of the REFERENCE's own classes (fixture g19_attention_rows, written by
+# tests/golden/make_golden.py::case_attention_rows from /root/reference/model/src/backbones/ltae.py) ------------------------------
+@pytest.fixture(scope="module")
+def g19():
+    from conftest import load_golden
+    return load_golden("g19_attention_rows")
+
+
+def _t(g, k):
+    return torch.from_numpy(g[k])
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_sdpa_rows_vs_reference_fixture(g19, i):
+    from uncrtaints_amd.src.backbones import ltae
+    g, pre = g19, f"sdpa{i}/"
+    cls = str(g[pre + "cls"])
+    temp = float(g[pre + "temperature"])
+    q, k, v = (dev(_t(g, pre + n)).requires_grad_(True) for n in ("q", "k", "v"))
+    pad = dev(_t(g, pre + "pad"))
+    if cls.endswith("Small"):
+        out, attn, comp = ltae.ScaledDotProductAttentionSmall(temperature=temp)(q, k, v, pad_mask=pad, return_comp=True, weight_v=True)
+    else:
+        out, attn, comp = ltae.ScaledDotProductAttention(temperature=temp, attn_dropout=0.1).eval()(q, k, v, pad_mask=pad, return_comp=True)
+    close(f"g19 {cls} attn", attn, _t(g, pre + "attn"))
+    close(f"g19 {cls} out", out, _t(g, pre + "out"))
+    close(f"g19 {cls} comp", comp, _t(g, pre + "comp"))
+    ((attn * dev(_t(g, pre + "ga"))).sum() + (out * dev(_t(g, pre + "go"))).sum() + (comp * dev(_t(g, pre + "gc"))).sum()).backward()
+    for n, t in (("dq", q), ("dk", k), ("dv", v)):
+        close(f"g19 {cls} {n}", t.grad, _t(g, pre + n))
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_multi_head_attention_rows_vs_reference_fixture(g19, i):
+    from uncrtaints_amd.src.backbones import ltae
+    g, pre = g19, f"mha{i}/"
+    cls, weight_v = str(g[pre + "cls"]), bool(g[pre + "weight_v"])
+    nh, dk = g[pre + "Q"].shape
+    d_in = g[pre + "W"].shape[1]
+    mod = ltae.MultiHeadAttentionSmall(n_head=nh, d_k=dk, d_in=d_in) if cls.endswith("Small") \
+        else ltae.MultiHeadAttention(n_head=nh, d_k=dk, d_in=d_in, use_dropout=False)
+    with torch.no_grad():
+        mod.fc1_k.weight.copy_(_t(g, pre + "W")); mod.fc1_k.bias.copy_(_t(g, pre + "b")); mod.Q.copy_(_t(g, pre + "Q"))
+    mod = mod.to(DEV).eval()
+    v = dev(_t(g, pre + "v")).requires_grad_(True)
+    pad = dev(_t(g, pre + "pad"))
+    if cls.endswith("Small"):
+        res = mod(v, pad_mask=pad, weight_v=weight_v)
+        out, attn = res if weight_v else (None, res)
+    else:
+        out, attn = mod(v, pad_mask=pad)
+    close(f"g19 {cls} attn", attn, _t(g, pre + "attn"))
+    if out is not None:
+        close(f"g19 {cls} out", out, _t(g, pre + "out"))
+    ((attn * dev(_t(g, pre + "ga"))).sum() + ((out * dev(_t(g, pre + "go"))).sum() if out is not None else 0.0)).backward()
+    close(f"g19 {cls} dv", v.grad, _t(g, pre + "dv"))
+    close(f"g19 {cls} dW", mod.fc1_k.weight.grad, _t(g, pre + "dW"))
+    close(f"g19 {cls} dQ", mod.Q.grad, _t(g, pre + "dQ"))
+    # the key bias shifts every date's score alike: mathematically zero gradient, rounding noise on both sides
+    assert float(mod.fc1_k.bias.grad.abs().max()) < 1e-3 * float(mod.fc1_k.weight.grad.abs().max())
+    assert float(np.abs(g[pre + "db"]).max()) < 1e-3 * float(np.abs(g[pre + "dW"]).max())
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_ltae2d_vs_reference_fixture(g19, i):
+    from uncrtaints_amd.src.backbones.ltae import LTAE2d
+    g, pre = g19, f"ltae{i}/"
+    training = bool(g[pre + "training"])
+    state = {k[len(pre + "state/"):]: _t(g, k) for k in g.files if k.startswith(pre + "state/")}
+    C = state["in_norm.weight"].numel()
+    nh, dk = state["attention_heads.Q"].shape
+    m = LTAE2d(in_channels=C, n_head=nh, d_k=dk, mlp=[256, C], dropout=0.0, d_model=256, return_att=True, use_dropout=False)
+    m.load_state_dict(state, strict=True)
+    m = m.to(DEV).train(training)
+    x = dev(_t(g, pre + "x")).requires_grad_(True)
+    out, attn = m(x, batch_positions=dev(_t(g, pre + "dates")), pad_mask=dev(_t(g, pre + "pad")))
+    close(f"g19 LTAE2d[train={training}] values", out, _t(g, pre + "out"))
+    close(f"g19 LTAE2d[train={training}] attn", attn, _t(g, pre + "attn"))
+    ((out * dev(_t(g, pre + "gv"))).sum() + (attn * dev(_t(g, pre + "ga"))).sum()).backward()
+    close("g19 LTAE2d dx", x.grad, _t(g, pre + "dx"))
+    for k, par in m.named_parameters():
+        ref = _t(g, pre + "grad/" + k)
+        if k == "attention_heads.fc1_k.bias" or (training and k in ("inconv.bias", "mlp.0.bias", "in_norm.bias")):
+            sib = m.get_parameter(k.replace(".bias", ".weight")).grad       # zero gradients (see test_ltae2d_standalone)
+            assert float(par.grad.abs().max()) < 1e-3 * float(sib.abs().max()), k
+            continue
+        close(f"g19 LTAE2d grad[{k}]", par.grad, ref)
+    if training:
+        for k in ("mlp.1.running_mean", "mlp.1.running_var"):
+            close("g19 LTAE2d " + k, m.state_dict()[k], _t(g, pre + "after/" + k))

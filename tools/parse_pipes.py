@@ -7,11 +7,11 @@ and valu_issue_busy = (SQ_INSTS_VALU - SQ_INSTS_MFMA) * 4 / (1024 * kernel_cycle
 import csv, json, sys, collections
 
 NAMES = [("dw_bwd_row_kernel<float>", "dw_bwd"), ("dw_fwd_row_kernel<float>", "dw_fwd"),
-         ("pw_gemm_split_kernel<2, 3, 3, 1, float, false>", "pw_gemm[128->256,pro3,epi3] (dz)"),
-         ("pw_gemm_split_kernel<2, 1, 1, 1, float, true>", "pw_gemm[128->256,pro1,epi1] (pw1 fwd)"),
-         ("pw_gemm_split_kernel<1, 2, 1, 2, float, true>", "pw_gemm[256->128,pro2,epi1] (pw2 fwd)"),
-         ("pw_gemm_split_kernel<1, 3, 5, 2, float, false>", "pw_gemm_dx[256->128]"),
-         ("pw_wgrad_split_kernel<4, 2, 3, 1>", "pw_wgrad[256x128]")]
+         ("pw_gemm_split_kernel<2, 3, 3, 1, float, ", "pw_gemm[128->256,pro3,epi3] (dz)"),
+         ("pw_gemm_split_kernel<2, 1, 1, 1, float, ", "pw_gemm[128->256,pro1,epi1] (pw1 fwd)"),
+         ("pw_gemm_split_kernel<1, 2, 1, 2, float, ", "pw_gemm[256->128,pro2,epi1] (pw2 fwd)"),
+         ("pw_gemm_split_kernel<1, 3, 5, 2, float, ", "pw_gemm_dx[256->128]"),
+         ("pw_wgrad_split_kernel<4, 2,", "pw_wgrad[256x128]"), ("pw_wgrad_split_kernel<2, 4,", "pw_wgrad[128x256]")]
 
 
 def main():

@@ -125,3 +125,61 @@ extern "C" int uncr_debug_tr_b16_probe(const int* offs, int* out, hipStream_t st
     return UNCR_OK;
 }
 
+
+// ---- stream roofs (round 4): what a pure HBM stream reaches on this part for a given read : write mix ----
+// mode 0 read-only (R reads per element group, one tiny guarded store), 1 write-only, 2 copy (1 : 1), 3 two reads : one write,
+// 4 one read : two writes, 5 three reads : one write.  float4 per lane, each block walks a CONTIGUOUS slab of every stream with
+// UNR groups in flight (the access pattern of the plane-tiled kernels of the step); nt = non-temporal loads AND stores.
+// Streams are separate buffers (a, b, c read; x, y written), n4 float4 elements each.
+template <int MODE, bool NT>
+__global__ __launch_bounds__(256) void stream_probe_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                           const float4* __restrict__ c, float4* __restrict__ x,
+                                                           float4* __restrict__ y, size_t n4) {
+    constexpr int UNR = 4;
+    const size_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
+    float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld = [&](const float4* p) { return ld4<float, NT>((const float*)p); };
+    auto st = [&](float4* p, const float4& v) { st4<float, NT>((float*)p, v); };
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256 * UNR) {
+        float4 va[UNR], vb[UNR], vc[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const size_t k = i + (size_t)u * 256 < hi ? i + (size_t)u * 256 : i;
+            if constexpr (MODE != 1) va[u] = ld(a + k);
+            if constexpr (MODE == 3 || MODE == 5) vb[u] = ld(b + k);
+            if constexpr (MODE == 5) vc[u] = ld(c + k);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const size_t k = i + (size_t)u * 256;
+            float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+            if constexpr (MODE != 1) v = va[u];
+            if constexpr (MODE == 3 || MODE == 5) { v.x += vb[u].x; v.y += vb[u].y; v.z += vb[u].z; v.w += vb[u].w; }
+            if constexpr (MODE == 5) { v.x += vc[u].x; v.y += vc[u].y; v.z += vc[u].z; v.w += vc[u].w; }
+            if constexpr (MODE == 0) { keep.x += v.x; keep.y += v.y; keep.z += v.z; keep.w += v.w; }
+            else if (k < hi) {
+                st(x + k, v);
+                if constexpr (MODE == 4) st(y + k, v);
+            }
+        }
+    }
+    if constexpr (MODE == 0)
+        if (keep.x + keep.y + keep.z + keep.w == 1.2345e-30f) x[0] = keep;
+}
+extern "C" int uncr_debug_stream_probe(const float* a, const float* b, const float* c, float* x, float* y, long long n_floats,
+                                       int mode, int nt, int blocks, hipStream_t stream) {
+    if (n_floats <= 0 || n_floats % 4 || blocks <= 0 || mode < 0 || mode > 5) return UNCR_ESHAPE;
+    const size_t n4 = (size_t)n_floats / 4;
+#define SP_LAUNCH(M)                                                                                                          \
+    case M:                                                                                                                   \
+        if (nt) hipLaunchKernelGGL((stream_probe_kernel<M, true>), dim3(blocks), dim3(256), 0, stream, (const float4*)a,      \
+                                   (const float4*)b, (const float4*)c, (float4*)x, (float4*)y, n4);                           \
+        else hipLaunchKernelGGL((stream_probe_kernel<M, false>), dim3(blocks), dim3(256), 0, stream, (const float4*)a,        \
+                                (const float4*)b, (const float4*)c, (float4*)x, (float4*)y, n4);                              \
+        break;
+    switch (mode) { SP_LAUNCH(0) SP_LAUNCH(1) SP_LAUNCH(2) SP_LAUNCH(3) SP_LAUNCH(4) SP_LAUNCH(5) }
+#undef SP_LAUNCH
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}

@@ -2,7 +2,8 @@
 // betas / eps, no weight decay, no amsgrad).  torch's own multi-tensor kernel takes three launches of ~26 us for the path's 91 tensors
 // (0.57 M parameters, 16 MB of traffic: microseconds at HBM speed); here every block owns one chunk of one tensor, found through two small
 // device tables the caller builds from the tensors' addresses:
-//   desc   [n_tensors][4] int64 : param, exp_avg, exp_avg_sq (addresses), element count     -- fixed for the life of the optimizer state
+//   desc   [n_tensors][5] int64 : param, exp_avg, exp_avg_sq (addresses), element count, address of the tensor's OWN step counter
+//                                 (a float device scalar, torch.optim.Adam's state["step"])  -- fixed for the life of the optimizer state
 //   chunks [n_chunks][2]  int32 : tensor index, first element
 // The gradients' addresses change from step to step (autograd allocates them) and, inside a graph capture, are only known at capture
 // time; they travel BY VALUE in the kernel arguments (up to ADAM_MAXT pointers, 2 KB of the 4 KB argument segment), so neither an eager
@@ -10,7 +11,9 @@
 // Arithmetic as torch's (torch/optim/adam.py, ATen fused_adam_utils.cuh), fp32 with the bias corrections taken in fp64:
 //   g += wd * p (if wd);  m = lerp(m, g, 1 - b1);  v = b2 * v + (1 - b2) * g * g
 //   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
-// t is read from a device scalar the caller has already incremented (so a captured graph advances it on every replay); lr is a float
+// t is read PER TENSOR from the device scalar the caller has already incremented (so a captured graph advances it on every replay, and
+// parameters that start to receive gradients later -- unfrozen layers, train_reconstruct.py:657-660 -- get their own bias corrections,
+// exactly as torch.optim.Adam keeps one step count per parameter); lr is a float
 // argument or, if lr_dev is given, a device scalar (a learning-rate schedule then reaches a captured graph).
 #include "common.h"
 
@@ -21,15 +24,14 @@ struct AdamGrads { const float* g[ADAM_MAXT]; };
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(const long long* __restrict__ desc, const AdamGrads grads,
                                                          const int* __restrict__ chunks, float lr,
-                                                         const float* __restrict__ lr_dev, double beta1, double beta2, float eps, float wd,
-                                                         const float* __restrict__ step_dev) {
+                                                         const float* __restrict__ lr_dev, double beta1, double beta2, float eps, float wd) {
     const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
-    float* __restrict__ p = (float*)desc[4 * t];
+    float* __restrict__ p = (float*)desc[5 * t];
     const float* __restrict__ g = grads.g[t];
-    float* __restrict__ m = (float*)desc[4 * t + 1];
-    float* __restrict__ v = (float*)desc[4 * t + 2];
-    const long long n = desc[4 * t + 3];
-    const double step = (double)step_dev[0];
+    float* __restrict__ m = (float*)desc[5 * t + 1];
+    float* __restrict__ v = (float*)desc[5 * t + 2];
+    const long long n = desc[5 * t + 3];
+    const double step = (double)*(const float*)desc[5 * t + 4];
     const float bc1 = (float)(1.0 - pow(beta1, step));
     const float bc2s = (float)sqrt(1.0 - pow(beta2, step));
     const float step_size = (lr_dev ? lr_dev[0] : lr) / bc1;
@@ -63,14 +65,14 @@ extern "C" int uncr_adam_max_tensors(void) { return ADAM_MAXT; }
 
 extern "C" int uncr_adam_step(const long long* desc, const long long* grads_host, int n_tensors, const int* chunks, int n_chunks,
                               float lr, const float* lr_dev, double beta1, double beta2, float eps, float weight_decay,
-                              const float* step_dev, hipStream_t stream) {
-    if (!desc || !grads_host || !chunks || n_chunks <= 0 || !step_dev) return UNCR_EINVAL;
+                              hipStream_t stream) {
+    if (!desc || !grads_host || !chunks || n_chunks <= 0) return UNCR_EINVAL;
     if (n_tensors <= 0 || n_tensors > ADAM_MAXT) return UNCR_ESHAPE;
     if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.f)) return UNCR_EINVAL;
     AdamGrads gs;
     for (int i = 0; i < ADAM_MAXT; ++i) gs.g[i] = i < n_tensors ? (const float*)grads_host[i] : nullptr;
     hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, stream, desc, gs, chunks, lr, lr_dev, beta1, beta2, eps,
-                       weight_decay, step_dev);
+                       weight_decay);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -12,7 +12,6 @@ into per-(frame,channel) coefficients and the consuming kernel applies them in i
 """
 from __future__ import annotations
 
-import os
 import threading
 import weakref
 
@@ -120,9 +119,9 @@ class NormSpec:
 # side chains: latency-bound launches that only feed parameter gradients run on a second HIP stream next to the bandwidth-bound
 # kernels of the critical path (inside a captured step they become a parallel branch of the graph)
 # ------------------------------------------------------------------------------------------------
-# Opt-in (UNCR_SIDE_STREAM=1): measured neutral on MI355X inside the captured step (12.69 ms with, 12.70 ms without: the ~90 us of
-# parameter-gradient launches do not overlap usefully with the bandwidth-bound kernels next to them), so the default keeps one stream.
-_USE_SIDE = os.environ.get("UNCR_SIDE_STREAM", "0") == "1"
+# Opt-in (dev_options(side_stream=True)): measured neutral on MI355X inside the captured step (12.69 ms with, 12.70 ms without: the ~90 us
+# of parameter-gradient launches do not overlap usefully with the bandwidth-bound kernels next to them), so the default keeps one stream.
+_USE_SIDE = False
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 _SIDE_TLS = threading.local()
 
@@ -267,16 +266,48 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
     return NormFwd(A, B, mean, rstd, kind, groups, ub=ub, hb=hbt)
 
 
-_CENTRED_NORMBWD = os.environ.get("UNCR_RAW_NORMBWD", "0") != "1"     # development A/B switch
+# Development switches.  The product path never reads the process environment: these are module constants with the shipped values,
+# and tools / tests flip them for an A/B run through the explicit `dev_options(...)` context below.
+_CENTRED_NORMBWD = True       # False: raw norm backward dh = c1*du + c2*h + c3 instead of the centred form
 # fp16 two-part split in the dz GEMM of an MBConv backward, scaled per frame from the producers' magnitude bookkeeping
-# (UNCR_NO_H2_BWD=1: exact bf16 split there, no bookkeeping -- A/B runs)
-_H2_BWD = os.environ.get("UNCR_NO_H2_BWD", "0") != "1"
-_H2_WGRAD = os.environ.get("UNCR_NO_H2_WGRAD", "0") != "1"    # the dW2 weight-gradient products alone (A/B runs)
-_H2_DX = os.environ.get("UNCR_NO_H2_DX", "0") != "1"          # the dx GEMM (+ max |du1| in the depthwise backward) alone (A/B runs)
+# (False: exact bf16 split there, no bookkeeping)
+_H2_BWD = True
+_H2_WGRAD = True              # the dW2 weight-gradient products alone
+_H2_DX = True                 # the dx GEMM (+ max |du1| in the depthwise backward) alone
 # the same split in the forward GEMMs behind a norm (pw1 / pw2 of an MBConv), scaled per frame from the bounds the statistics
-# finalisation emits (UNCR_NO_H2_FWD=1: exact bf16 split -- A/B runs)
-_H2_FWD = os.environ.get("UNCR_NO_H2_FWD", "0") != "1"
+# finalisation emits (False: exact bf16 split)
+_H2_FWD = True
+_PREPACK = True               # False: every pack_wt call packs on its own (bisecting)
 _DW_VARIANT = 0      # uncr_dw_fwd / uncr_dw_bwd `variant`: 0 = automatic, 1 = LDS-tiled kernels for every width (tests)
+
+_DEV_OPTIONS = {"side_stream": "_USE_SIDE", "centred_normbwd": "_CENTRED_NORMBWD", "h2_bwd": "_H2_BWD", "h2_wgrad": "_H2_WGRAD",
+                "h2_dx": "_H2_DX", "h2_fwd": "_H2_FWD", "prepack": "_PREPACK", "fused_dx": "_FUSED_DX", "fused_ltae": "_FUSED_LTAE",
+                "dw_variant": "_DW_VARIANT"}
+
+
+class dev_options:
+    """`with engine.dev_options(h2_fwd=False, fused_dx=False): ...` -- flip development switches of the Python layer for the duration
+    of an A/B run or a test (tools/, tests/) and restore them afterwards.  Nothing here is read from the environment, and the
+    library below (include/uncr_hip.h) keeps no switches at all: a kernel variant follows from the arguments of each call."""
+
+    def __init__(self, **opts):
+        unknown = set(opts) - set(_DEV_OPTIONS)
+        if unknown:
+            raise KeyError(f"unknown development option(s) {sorted(unknown)}; known: {sorted(_DEV_OPTIONS)}")
+        self.opts, self.old = opts, {}
+
+    def __enter__(self):
+        g = globals()
+        for k, v in self.opts.items():
+            self.old[k] = g[_DEV_OPTIONS[k]]
+            g[_DEV_OPTIONS[k]] = v
+        return self
+
+    def __exit__(self, *exc):
+        g = globals()
+        for k, v in self.old.items():
+            g[_DEV_OPTIONS[k]] = v
+        return False
 
 
 @dataclass
@@ -400,7 +431,7 @@ def prepack(weights, owner=None) -> None:
     long as the module does and are never evicted: a captured HIP graph holds raw pointers into a plan's buffers, so a
     plan must not be freed while its model can still be replayed."""
     weights = [(w, bool(tr)) for w, tr in weights if w.is_contiguous()]
-    if not weights or os.environ.get("UNCR_NO_PREPACK"):      # env: development switch (bisecting)
+    if not weights or not _PREPACK:
         return
     key = tuple((w.data_ptr(), tr, w.shape[0], w.shape[1]) for w, tr in weights)
     plans = _PACK_PLANS
@@ -611,7 +642,7 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     return y, saved, party
 
 
-_FUSED_DX = os.environ.get("UNCR_NO_FUSED_DX", "0") != "1"     # A/B switch (development, tests)
+_FUSED_DX = True     # dev_options(fused_dx=False): pw1 backward as GEMM + element-wise pass (tests, A/B runs)
 
 _CONST_PLANES: Dict[tuple, Tuple[Tensor, Tensor]] = {}
 
@@ -963,7 +994,7 @@ def ltae_attention_forward(down: Tensor, dates: Optional[Tensor], pad: Optional[
     return att, saved
 
 
-_FUSED_LTAE = os.environ.get("UNCR_NO_FUSED_LTAE", "0") != "1"     # A/B switch (development, tests)
+_FUSED_LTAE = True     # dev_options(fused_ltae=False): the unfused L-TAE kernels (tests, A/B runs)
 
 
 def ltae_fused_ok(T: int, C: int, n_head: int, S: int) -> bool:

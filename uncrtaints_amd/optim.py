@@ -30,6 +30,23 @@ class FusedAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, capturable=on_gpu, **kw)
         self._uncr_tables = {}       # group index -> (key, desc, chunks, n_chunks, keep-alive)
         self._uncr_pinned: List[torch.Tensor] = []
+        self.state_epoch = 0         # bumped whenever the state tensors are replaced (load_state_dict): captured steps hold raw pointers
+
+    def load_state_dict(self, state_dict):
+        """torch's load_state_dict replaces every param_group entry with the checkpoint's -- a checkpoint of the reference (or of an
+        eager run) carries `lr` as a Python float.  A learning rate that lived on the device (graph mode: the captured kernel reads it,
+        ExponentialLR updates it in place) stays THAT tensor and receives the loaded value; the moments are new tensors, so the address
+        tables are dropped and `state_epoch` tells holders of captured steps (BaseModel._graph_step) to re-capture."""
+        dev_lrs = [g["lr"] if isinstance(g["lr"], torch.Tensor) and g["lr"].is_cuda else None for g in self.param_groups]
+        super().load_state_dict(state_dict)
+        for g, t in zip(self.param_groups, dev_lrs):
+            if t is not None:
+                t.fill_(float(g["lr"]))
+                g["lr"] = t
+                if "initial_lr" in g and not isinstance(g["initial_lr"], torch.Tensor):
+                    g["initial_lr"] = float(g["initial_lr"])
+        self._uncr_tables.clear()
+        self.state_epoch += 1
 
     # ------------------------------------------------------------------------------------------------------------------
     def _native_ok(self, group) -> bool:
@@ -70,9 +87,11 @@ class FusedAdam(torch.optim.Adam):
         return [self.state[p]["step"] for p in params]
 
     def _tables(self, gi, params):
-        """Device tables of a batch of at most uncr_adam_max_tensors() parameters: addresses of (param, exp_avg, exp_avg_sq) and the
-        chunk -> tensor map.  They change only when the state is re-created (first step, load_state_dict): built in an eager step."""
-        key = tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(), p.numel()) for p in params)
+        """Device tables of a batch of at most uncr_adam_max_tensors() parameters: addresses of (param, exp_avg, exp_avg_sq), the element
+        count, the address of the parameter's OWN step counter (torch.optim.Adam counts steps per parameter: a layer unfrozen at epoch k
+        starts its bias corrections at 1 while the others are at k * steps) and the chunk -> tensor map.  They change only when the state is re-created (first step, load_state_dict): built in an eager step."""
+        key = tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(), p.numel(),
+                     self.state[p]["step"].data_ptr()) for p in params)
         cached = self._uncr_tables.get(gi)
         if cached is not None and cached[0] == key:
             return cached[1], cached[2], cached[3]
@@ -109,8 +128,7 @@ class FusedAdam(torch.optim.Adam):
             if not params:
                 continue
             steps = self._init_state(group, params)
-            torch._foreach_add_(steps, 1.0)      # one launch; the kernel reads the first (they are all equal)
-            step = steps[0]
+            torch._foreach_add_(steps, 1.0)      # one launch; the kernel reads every tensor's own counter
             lr = group["lr"]
             lr_dev = lr if isinstance(lr, torch.Tensor) and lr.is_cuda else None
             if lr_dev is not None and lr_dev.dtype != torch.float32:
@@ -122,6 +140,8 @@ class FusedAdam(torch.optim.Adam):
                 desc, chunks, n_chunks = self._tables((gi, bi), batch)
                 grads = torch.tensor([p.grad.data_ptr() for p in batch], dtype=torch.int64)      # host: read by the launcher
                 hb.call("uncr_adam_step", desc, grads.data_ptr(), len(batch), chunks, n_chunks, 0.0 if lr_dev is not None else float(lr), lr_dev,
-                        float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), step,
+                        float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                         torch.cuda.current_stream().cuda_stream)
+            # the kernel wrote the parameters through raw pointers: tell autograd and the version-checked caches (engine._PACK_CACHE)
+            torch.autograd.graph.increment_version(params)
         return loss

@@ -24,7 +24,8 @@ class BaseModel(nn.Module):
         # Adam, ~300 kernel launches -- from ONE captured HIP graph (see _graph_step).  Adam then keeps its step count and its
         # learning rate on the device (capturable), so that ExponentialLR's per-epoch update reaches the captured kernels.
         self._use_graph = bool(getattr(config, "hip_graph", False))
-        self._graph = None
+        self._graphs = {}            # launch-list key -> captured step (a few shapes, e.g. the smaller last batch of an epoch); LRU
+        self._graph_cap = 4
         # base_model.py:48: torch.optim.Adam(params, lr).  FusedAdam IS that class (same state, checkpoints exchange with it) with the
         # update as one HIP launch over all parameters; on CPU parameters it runs torch's own step.
         from ...optim import FusedAdam
@@ -83,14 +84,42 @@ class BaseModel(nn.Module):
     # the launch list (another input shape, train/eval switch, freezing layers, a data-parallel wrapper) falls back to eager steps
     # and a fresh capture.
     def _graph_key(self):
+        # state_epoch: bumped by FusedAdam.load_state_dict -- a captured step holds raw pointers to the moments it was captured with
         return (tuple(self.real_A.shape), tuple(self.real_B.shape), None if self.dates is None else tuple(self.dates.shape),
-                self.netG.training, tuple(p.requires_grad for p in self.netG.parameters()))
+                self.netG.training, tuple(p.requires_grad for p in self.netG.parameters()),
+                getattr(self.optimizer_G, "state_epoch", 0))
+
+    def _graph_capable(self):
+        """BatchNorm2d(momentum=None) derives its update factor from num_batches_tracked on the HOST (a sync, illegal in a capture and
+        a constant in a replay): such models take eager steps."""
+        ok = getattr(self, "_graph_ok", None)
+        if ok is None:
+            ok = self._graph_ok = not any(isinstance(m, nn.BatchNorm2d) and m.momentum is None for m in self.netG.modules())
+        return ok
+
+    def _device_lr(self):
+        """The captured Adam kernel reads the learning rate from a device scalar (ExponentialLR then reaches the replays).  A
+        checkpoint written by the reference or by an eager run restores a Python float (torch's load_state_dict replaces the
+        param_group entries): FusedAdam.load_state_dict puts the value back into the device scalar; anything else that left a float
+        there (a user assignment) is moved onto the device here, BEFORE a capture could bake it in by value."""
+        for grp in self.optimizer_G.param_groups:
+            lr = grp["lr"]
+            if not (isinstance(lr, torch.Tensor) and lr.is_cuda and lr.dtype == torch.float32):
+                grp["lr"] = torch.tensor(float(lr), dtype=torch.float32, device=self.real_A.device)
+                self._graphs.clear()
 
     def _graph_step(self):
+        self._device_lr()
         key = self._graph_key()
-        g = self._graph
-        if g is None or g["key"] != key:
-            g = self._graph = dict(key=key, eager_left=2, graph=None)
+        if getattr(self.optimizer_G, "state_epoch", 0) != getattr(self, "_seen_state_epoch", 0):
+            self._seen_state_epoch = getattr(self.optimizer_G, "state_epoch", 0)
+            self._graphs.clear()           # every captured step points at the old exp_avg / exp_avg_sq buffers
+        g = self._graphs.pop(key, None)
+        if g is None:
+            g = dict(key=key, eager_left=2, graph=None)
+            while len(self._graphs) >= self._graph_cap:       # least recently used first (dicts keep insertion order)
+                self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[key] = g              # (re-)inserted last = most recently used
         agg = getattr(self.netG, "temporal_aggregator", None)
         if agg is not None and agg.step_counter is None:
             agg.step_counter = torch.zeros(1, dtype=torch.int64, device=self.real_A.device)
@@ -147,7 +176,8 @@ class BaseModel(nn.Module):
                 self.netG.variance = self.netG.variance.cpu()
 
     def optimize_parameters(self):
-        if self._use_graph and self.data_parallel is None and self.real_A is not None and self.real_A.is_cuda:
+        if self._use_graph and self.data_parallel is None and self.real_A is not None and self.real_A.is_cuda \
+                and self._graph_capable():
             return self._graph_step()
         return self._eager_step()
 
