@@ -11,6 +11,7 @@ GPU, fp32), plus `roofline` for the dominant kernel (HIP-event timed inside the 
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -83,6 +84,58 @@ def kernel_model(name, key):
     return (name, 0.0, 0.0, 0)
 
 
+def written_fraction(name, key):
+    """Share of a launch's algorithmic bytes that are WRITES (the rest are reads) -- picks the measured stream roof of that mix."""
+    if name == "uncr_pw_gemm":
+        bias_stride, N, Cin, Cout, P, pro, epi, in_dt, out_dt = key[:9]
+        bi, bo = (2.0 if in_dt else 4.0), (2.0 if out_dt else 4.0)
+        rd = Cin * (2 if pro == PRO_NORMBWD else 1) * bi + (Cout * bo if epi in (2, 3) else 0)
+        return Cout * bo / (rd + Cout * bo)
+    if name == "uncr_pw_gemm_dx":
+        N, Cin, Cout, P, act = key[:5]
+        return Cout / (2.0 * Cin + 4.0 * Cout)
+    if name == "uncr_residual_pool":
+        return 1.0 / 3.0
+    if name == "uncr_dw_fwd":
+        return 0.5
+    if name == "uncr_dw_bwd":
+        return 0.25
+    if name == "uncr_ew":
+        tensors = {0: 1, 1: 2, 2: 2, 3: 3, 4: 3, 5: 4, 6: 3, 7: 1, 8: 2, 9: 3}[key[0]]
+        return 0.0 if tensors == 1 else 1.0 / tensors
+    if name == "uncr_aggregate_fwd":
+        T = key[-8]
+        return 1.0 / (T + 1)
+    if name == "uncr_aggregate_bwd":
+        T = key[-8]
+        return T / (2.0 * T + 1)
+    return 0.0          # weight gradients: read-only streams
+
+
+_STREAM_ROOFS = None
+
+
+def stream_roof_gbs(wfrac):
+    """What a pure stream with this written share reaches on this part: piecewise-linear through the points of
+    profiles/r04_stream_roofs.json (tools/stream_roofs.py: float4 lanes, 1 GB per stream, best of plain / non-temporal and of two
+    grid sizes): read-only 7.0, 3r:1w 5.6, 2r:1w 5.8, copy 5.6, 1r:2w 5.4, write-only 5.9 TB/s.  None if the file is missing."""
+    global _STREAM_ROOFS
+    if _STREAM_ROOFS is None:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", "r04_stream_roofs.json")))["best_per_mode"]
+            w = {"read_only": 0.0, "3r_1w": 0.25, "2r_1w": 1.0 / 3.0, "copy_1r_1w": 0.5, "1r_2w": 2.0 / 3.0, "write_only": 1.0}
+            _STREAM_ROOFS = sorted((w[k], v["TBps_total"] * 1e3) for k, v in d.items() if k in w)
+        except (OSError, KeyError, ValueError):
+            _STREAM_ROOFS = []
+    pts = _STREAM_ROOFS
+    if len(pts) < 2:
+        return None
+    for (w0, r0), (w1, r1) in zip(pts, pts[1:]):
+        if w0 <= wfrac <= w1:
+            return r0 + (r1 - r0) * (wfrac - w0) / max(w1 - w0, 1e-9)
+    return pts[-1][1]
+
+
 PROFILED = ("uncr_pw_gemm", "uncr_pw_gemm_dx", "uncr_residual_pool", "uncr_pw_wgrad", "uncr_dw_fwd", "uncr_dw_bwd", "uncr_ew", "uncr_aggregate_fwd",
             "uncr_aggregate_bwd")
 
@@ -153,6 +206,82 @@ def cpu_baseline(T, H, W, budget_s=45.0):
             "k8": {"value": round(1.0 / med8, 4), "cores": min(8, cores), "sample": f"same, 1 warm-up + {n8} timed, median"}}
 
 
+class PowerSampler:
+    """Socket power and shader clock of this rank's GPU while the timed steps run, from `rocm-smi --showclocks --showpower` polled
+    by a background thread (host side only: the timed region is a run of graph replays, nothing here touches a stream).  MI355X
+    enforces a socket power cap (`rocm-smi --showmaxpower`: 1400 W); a kernel mix that reaches it is clocked down, and its kernels
+    are then bounded by energy per unit of work, not by the HBM or MFMA peaks (profiles/r04_power.json)."""
+
+    def __init__(self, device_index=0, period_s=0.25):
+        import threading
+        self.idx, self.period, self.samples, self._stop = device_index, period_s, [], False
+        self.cap = None
+        try:
+            m = re.findall(r"GPU\[%d\].*?Power \(W\):\s*([0-9.]+)" % device_index, self._smi("--showmaxpower"))
+            self.cap = float(m[0]) if m else None
+        except Exception:      # noqa: BLE001 -- no rocm-smi, no power object
+            self.cap = None
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _smi(*a):
+        import subprocess
+        return subprocess.run(["rocm-smi", *a], capture_output=True, text=True, timeout=10).stdout
+
+    def _run(self):
+        while not self._stop:
+            try:
+                o = self._smi("--showclocks", "--showpower")
+                sclk = re.findall(r"GPU\[%d\].*?sclk clock level.*?\((\d+)Mhz\)" % self.idx, o)
+                pw = re.findall(r"GPU\[%d\].*?Power \(W\):\s*([0-9.]+)" % self.idx, o)
+                if sclk and pw:
+                    self.samples.append((time.perf_counter(), int(sclk[0]), float(pw[0])))
+            except Exception:      # noqa: BLE001
+                pass
+            time.sleep(self.period)
+
+    def start(self):
+        self._th.start()
+
+    def stop(self):
+        self._stop = True
+
+    def summary(self, t0, t1):
+        s = [x for x in self.samples if t0 + 0.5 <= x[0] <= t1]      # the first half second: the governor is still settling
+        if not s:
+            return {"samples": 0, "power_cap_w": self.cap, "note": "no rocm-smi samples inside the timed region (too short, or no rocm-smi)"}
+        pw, ck = [x[2] for x in s], [x[1] for x in s]
+        return {"samples": len(s), "avg_power_w": round(sum(pw) / len(pw), 1), "max_power_w": max(pw), "power_cap_w": self.cap,
+                "avg_sclk_mhz": round(sum(ck) / len(ck)), "min_sclk_mhz": min(ck), "max_sclk_mhz_of_the_part": 2400,
+                "source": "rocm-smi --showclocks --showpower polled every %.2f s during the timed steps" % self.period}
+
+
+def bf16_leg(args):
+    """BASELINE config 3's per-GPU leg (bf16 activation storage, fp32 accumulate) measured by a second run of this script in its own
+    process (own memory pool and graph) and attached to the fp32 headline line as a compact sub-object: the fp32 fields stay the
+    headline, `dtype` of the sub-object is bf16.  A few seconds; any failure is reported in place of the numbers."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.abspath(__file__), "--act-dtype", "bf16", "--no-cpu-baseline", "--steps", str(min(args.steps, 200)),
+           "--warmup", str(args.warmup), "--batch-per-gpu", str(args.batch_per_gpu), "--T", str(args.T), "--size", str(args.size)]
+    if args.no_kernel_events:
+        cmd.append("--no-kernel-events")
+    if args.no_graph:
+        cmd.append("--no-graph")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:      # noqa: BLE001 -- the headline line must not die with its appendix
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+    out = {k: d.get(k) for k in ("dtype", "value", "unit", "ms_per_step", "steps", "step_hbm_roofline_frac")}
+    out["config"] = "the same workload with bf16 activation storage, fp32 statistics / weights / accumulation (BASELINE config 3, one GPU)"
+    if "roofline" in d:
+        out["roofline"] = {k: d["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "mean_launch_ms")}
+    if "ltae_stage" in d:
+        out["ltae_stage_roofline_frac"] = d["ltae_stage"].get("roofline_frac")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +297,9 @@ def main():
     ap.add_argument("--act-dtype", choices=("fp32", "bf16"), default="fp32",
                     help="activation storage: fp32 (default: the headline line, BASELINE config 2) or bf16 (BASELINE config 3: bf16 "
                          "activations, fp32 accumulate; reported as dtype bf16, never as the fp32 headline)")
+    ap.add_argument("--no-power", action="store_true", help="do not poll rocm-smi for power / clock during the timed steps")
+    ap.add_argument("--no-bf16-leg", action="store_true",
+                    help="skip the compact `bf16` sub-object (BASELINE config 3's per-GPU leg) the fp32 headline line carries at N = 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -388,6 +520,9 @@ def main():
     if want_events and not use_graph:
         prof = hb.EventProfiler(PROFILED)
         hb.set_profiler(prof)
+    power = PowerSampler(local_rank) if rank == 0 and not args.no_power else None
+    if power is not None:
+        power.start()
     fence()
     if dp is not None:
         dp.wait_ms()                        # drop the warm-up records
@@ -397,6 +532,10 @@ def main():
     host_dt = time.perf_counter() - t0      # host time to ENQUEUE the steps (no sync inside step())
     fence()
     dt = time.perf_counter() - t0
+    power_summary = None
+    if power is not None:
+        power.stop()
+        power_summary = power.summary(t0, t0 + dt)
     hb.set_profiler(None)
     coll_wait = dp.wait_ms() if dp is not None else []
     eager_ms = None
@@ -470,7 +609,8 @@ def main():
                                  prod=prod,
                                  bf16_pipe_util=(prod * flops / mean_ms / 1e9 / BF16_MFMA_PEAK_TF) if (prod and mean_ms > 0) else None,
                                  gbs=nbytes / mean_ms / 1e6 if mean_ms > 0 else 0.0,
-                                 tflops=flops / mean_ms / 1e9 if mean_ms > 0 else 0.0, bytes=nbytes, flops=flops))
+                                 tflops=flops / mean_ms / 1e9 if mean_ms > 0 else 0.0, bytes=nbytes, flops=flops,
+                                 wfrac=written_fraction(name, key)))
             rows.sort(key=lambda r: -r["total_ms"])
             tot = sum(r["total_ms"] for r in rows)
             top = rows[0]
@@ -487,6 +627,13 @@ def main():
             else:
                 res["roofline"] = {"bound": "hbm", "achieved": round(top["gbs"], 1), "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": None, "kernel": top["kernel"]}
+            # next to `frac` (of the 8 TB/s spec), never instead of it: the same rate against what a PURE stream of this kernel's
+            # read : write mix reaches on this part (tools/stream_roofs.py -> profiles/r04_stream_roofs.json)
+            sr = stream_roof_gbs(top["wfrac"])
+            if sr:
+                res["roofline"]["written_share_of_bytes"] = round(top["wfrac"], 3)
+                res["roofline"]["stream_roof_gbs_for_this_mix"] = round(sr, 1)
+                res["roofline"]["frac_of_stream_roof"] = round(top["gbs"] / sr, 4)
             # HBM bytes per launch from the PMC passes (tools/measure_traffic.sh -> profiles/<round>_traffic.json; rocprofv3
             # cannot run inside this process).  The file records the hash of the kernel sources it was measured on: the number
             # is attached only while the sources still hash to it (a stale figure is worse than null) and for a kernel that
@@ -511,6 +658,7 @@ def main():
             res["kernel_breakdown"] = [
                 dict(kernel=r["kernel"], launches_per_step=r["launches"] / prof_steps, mean_ms=round(r["mean_ms"], 4),
                      share=round(r["total_ms"] / max(tot, 1e-9), 4), gbs=round(r["gbs"], 1), tflops=round(r["tflops"], 2),
+                     frac_of_stream_roof=(round(r["gbs"] / stream_roof_gbs(r["wfrac"]), 3) if stream_roof_gbs(r["wfrac"]) else None),
                      # tflops = fp32-equivalent work; the exact-split GEMMs issue 6 bf16 MFMA products per fp32 MAC:
                      # bf16_pipe_util = 6 x tflops / 2500 TF = the share of the bf16 matrix pipe's dense peak really used
                      bf16_pipe_util=None if r["bf16_pipe_util"] is None else round(r["bf16_pipe_util"], 4))
@@ -553,6 +701,10 @@ def main():
                 res["eager_event_profiled_ms_per_step"] = round(eager_ms, 3)
                 res["roofline"]["source"] = ("eager re-run of the same steps with a HIP event pair around every launch "
                                              "(graph replays cannot be bracketed per kernel)")
+        if power_summary is not None:
+            res["power"] = power_summary
+        if world == 1 and not bf16 and not args.no_bf16_leg:
+            res["bf16"] = bf16_leg(args)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(T, H, H)
         print(json.dumps(res))

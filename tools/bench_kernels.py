@@ -88,10 +88,10 @@ def main():
             x = torch.randn(1, Cin, Pn, device=dev)
             Wt = E.pack_wt(torch.randn(Cout, Cin, device=dev) * 0.05, transpose=True)
             out = torch.empty(1, Cout, Pn, device=dev)
-            st = torch.zeros(4096 * 4, device=dev)
+            st = torch.zeros(4096 * 8, device=dev)
             fn = lambda: E.pw_gemm(x, Wt, 1, Cin, Cout, Pn, out=out, ek=(None, None, None, st))
             ms = timeit(fn, 10)
-            s = st.view(-1, 4).cpu(); s = s[s[:, 3] > 0]
+            s = st.view(-1, 8).cpu(); s = s[s[:, 3] > 0]
             tiles = s[:, 3].sum().item()
             print(f"tiles={nb} blocks={len(s)} wall {ms*1e3:.1f} us: prologue {s[:,0].mean():.0f}  loop+epilogues {s[:,1].mean():.0f} "
                   f"(per tile {(s[:,1] / s[:,3]).mean():.0f}, of which epilogue {(s[:,2] / s[:,3]).mean():.0f}) ticks; "

@@ -8,7 +8,7 @@ mkdir -p "$root/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- \
-    python "$root/bench.py" --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline "$@" > "$root/gpurun_out/${tag}_bench.json" 2> /tmp/prof_$tag.err </dev/null
+    python "$root/bench.py" --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-bf16-leg "$@" > "$root/gpurun_out/${tag}_bench.json" 2> /tmp/prof_$tag.err </dev/null
 f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" 2>/dev/null | head -1)
 if [ -n "$f" ]; then
     cp "$f" "$root/gpurun_out/${tag}_kernel_stats.csv"

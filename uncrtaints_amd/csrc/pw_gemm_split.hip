@@ -58,6 +58,15 @@ template <bool NT, typename TA> __device__ __forceinline__ void pws_st(TA* p, co
 #ifndef PWS_ABL
 #define PWS_ABL 0   // development ablations (tools/ablate_split.sh): 1 no stores, 2 no staging, 4 no activation loads, 8 no A reloads, 16 no MFMA
 #endif
+#ifndef PWS_PRIO
+#define PWS_PRIO 0   // experiment: 1 = s_setprio(1) around every k-step's MFMA groups, 2 = static priority for every second block
+#endif
+#ifndef PWS_A2SET
+#define PWS_A2SET 0   // experiment: two rolling A-fragment sets (one per k-step parity), each re-loaded for the SAME k-step of the next chunk
+#endif
+#ifndef PWS_LATE_LOAD
+#define PWS_LATE_LOAD 0   // experiment: the raw chunk request moves behind the chunk's second k-step
+#endif
 #define PWS_TP 128
 #define PWS_BUF 24576   // bytes per LDS stage: 3 parts x 32 ci x 128 px x 2 B (bf16 activations: 1 part, 8192 B)
 #ifndef PWS_A16_WPARTS
@@ -120,6 +129,10 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
     const int nkp = (nk + DEPTH - 1) / DEPTH * DEPTH;     // chunks computed per tile (padding chunks are all-zero)
 #ifdef PWS_STAMP
     const unsigned long long ts0 = __builtin_readcyclecounter();
+    unsigned long long tph[4] = {0, 0, 0, 0};     // k-step 0 | staging | request + barrier | k-step 1
+#define PWS_T(i) { const unsigned long long tn_ = __builtin_readcyclecounter(); tph[i] += tn_ - tl_; tl_ = tn_; }
+#else
+#define PWS_T(i)
 #endif
 
     // Every optional pointer is read branch-free (a null pointer reads a dummy location and the value is replaced by
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
             for (int r = 0; r < 4; ++r) {
                 float v = pws_get(pre[S][r], e);
                 if constexpr (PRO == PRO_AFFINE) v = fmaf(c0[r], v, c1[r]);
-                else if constexpr (PRO == PRO_AFFINE_GELU) v = c2[r] * gelu_f(fmaf(c0[r], v, c1[r]));
+                else if constexpr (PRO == PRO_AFFINE_GELU) v = (PWS_ABL & 64) ? c2[r] * fmaf(c0[r], v, c1[r]) : c2[r] * gelu_f(fmaf(c0[r], v, c1[r]));
                 else if constexpr (PRO == PRO_NORMBWD) {
                     if constexpr (BF) v = fmaf(c0[r], v, fmaf(c1[r], pws_get(pre2[PRE2 ? S : 0][r], e) - c3[r], c2[r]));
                     else v = fmaf(c0[r], v, fmaf(c1[r], pws_get(pre2[PRE2 ? S : 0][r], e), c2[r]));
@@ -256,6 +269,8 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
     const u32x4_t* wp = (const u32x4_t*)g.Wt + (size_t)(wn * CT) * PWS_NSLOT * 64 + lane;
     auto lda = [&](int ks, int ct, int part) { return wp[((size_t)(ks * NCT + ct) * PWS_NSLOT + (H2 ? 3 : 0) + part) * 64]; };
     u32x4_t ah[CT], am[CT], al[CT];
+    constexpr bool A2 = PWS_A2SET && H2 && (CT == 1 || PWS_A2SET > 1);
+    u32x4_t ah1[A2 ? CT : 1], al1[A2 ? CT : 1];   // A2: the fragments of the odd k-steps (ah / al serve the even ones)
     u32x4_t a2[BF ? 2 : 1][BF ? NW : 1][CT];      // bf16 activations: the A fragments of two consecutive k-steps
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, DEPTH - 1>;
@@ -271,6 +286,10 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
     } else if constexpr (H2) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); al[ct] = lda(0, ct, 1); }
+        if constexpr (A2) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) { ah1[ct] = lda(1, ct, 0); al1[ct] = lda(1, ct, 1); }
+        }
     } else {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
@@ -346,6 +365,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         for (int c = tid; c < COUTP; c += NT) hsc[c] = wtail[c] * isc;
         __syncthreads();
     }
+    if constexpr ((PWS_PRIO & 2) != 0) { if (((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1) __builtin_amdgcn_s_setprio(2); }
     float amx = 0.f;          // max |stored output| of this block (CT = 1 statistics / skip epilogues)
     constexpr bool AMAXK = CT == 1 && (EPI == 1 || EPI == 2 || EPI == 5);
     stage_chunk(0, 0, S0{});
@@ -400,7 +420,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
     };
 #define PWS_MF16(A, B)                                                                                        \
     _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) _Pragma("unroll") for (int e = 0; e < 4; ++e)           \
-        acc[e][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, A[ct]),              \
+        if (!(PWS_ABL & 16)) acc[e][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, A[ct]),              \
                                                             __builtin_bit_cast(f16x8_t, B[e]), acc[e][ct], 0, 0, 0)
     // fp16 two-part k-step: three products; the low B part is read at the top of its own k-step, everything else rolls
     auto kstep_h2 = [&](int ksn, const unsigned char* cb, const unsigned char* nb, auto roll) {
@@ -416,6 +436,25 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         PWS_MF16(ah, bl); PWS_SB();
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) if (ROLL) ah[ct] = lda(ksn, ct, 0);
+        if (ROLL) ldb(nb, 0, bh);
+        PWS_SB();
+#undef PWS_SB
+    };
+    // A2: as kstep_h2 with the fragment set of the k-step's parity, re-loaded for k-step `ksn` = this one + 2 (wrapping into the next
+    // tile) -- every weight request is then OLDER than the raw chunk request that follows it in the vmcnt queue when it is waited for
+    auto kstep_h2x = [&](u32x4_t (&xh)[A2 ? CT : 1], u32x4_t (&xl)[A2 ? CT : 1], int ksn, const unsigned char* cb, const unsigned char* nb, auto roll) {
+        constexpr bool ROLL = decltype(roll)::value;
+#define PWS_SB() __builtin_amdgcn_sched_barrier(0)
+        ldb(cb, 1, bl);
+        PWS_SB();
+        PWS_MF16(xh, bh); PWS_SB();
+        PWS_MF16(xl, bh); PWS_SB();
+#pragma unroll
+        for (int ct = 0; ct < (A2 ? CT : 0); ++ct) xl[ct] = lda(ksn, ct, 1);
+        PWS_SB();
+        PWS_MF16(xh, bl); PWS_SB();
+#pragma unroll
+        for (int ct = 0; ct < (A2 ? CT : 0); ++ct) xh[ct] = lda(ksn, ct, 0);
         if (ROLL) ldb(nb, 0, bh);
         PWS_SB();
 #undef PWS_SB
@@ -449,15 +488,29 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         const unsigned char* xb = &xs[par][0] + rd_off;
         const unsigned char* xn = &xs[par ^ 1][0] + rd_off;
         const int cn = c + 1 == nkp ? 0 : c + 1;                 // the next chunk of the stream (wraps into the next tile)
+#ifdef PWS_STAMP
+        unsigned long long tl_ = __builtin_readcyclecounter();
+#endif
+        if constexpr (PWS_PRIO & 1) __builtin_amdgcn_s_setprio(1);
         if constexpr (BF) kstep_a16(Q0{}, 2 * c + 2 >= nks ? 2 * c + 2 - nks : 2 * c + 2, xb + 4096);
+        else if constexpr (A2) kstep_h2x(ah, al, 2 * c + 2 >= nks ? 2 * c + 2 - nks : 2 * c + 2, xb, xb + 4096, Roll{});
         else if constexpr (H2) kstep_h2(2 * c + 1, xb, xb + 4096, Roll{});
         else kstep(2 * c + 1, xb, xb + 4096, Roll{});
+        if constexpr (PWS_PRIO & 1) __builtin_amdgcn_s_setprio(0);
+        PWS_T(0)
         if (!(PWS_ABL & 2)) stage_chunk(cn, par ^ 1, slot);
-        if (!(PWS_ABL & 4)) { load_chunk(lp, slot); advance(lp); }
+        PWS_T(1)
+        if constexpr (!PWS_LATE_LOAD) if (!(PWS_ABL & 4)) { load_chunk(lp, slot); advance(lp); }
         __syncthreads();
+        PWS_T(2)
+        if constexpr (PWS_PRIO & 1) __builtin_amdgcn_s_setprio(1);
         if constexpr (BF) kstep_a16(Q1{}, 2 * c + 3 >= nks ? 2 * c + 3 - nks : 2 * c + 3, xn);
+        else if constexpr (A2) kstep_h2x(ah1, al1, 2 * c + 3 >= nks ? 2 * c + 3 - nks : 2 * c + 3, xb + 4096, xn, roll_last);
         else if constexpr (H2) kstep_h2(2 * c + 2 == nks ? 0 : 2 * c + 2, xb + 4096, xn, roll_last);
         else kstep(2 * c + 2 == nks ? 0 : 2 * c + 2, xb + 4096, xn, roll_last);
+        if constexpr (PWS_PRIO & 1) __builtin_amdgcn_s_setprio(0);
+        if constexpr (PWS_LATE_LOAD) if (!(PWS_ABL & 4)) { load_chunk(lp, slot); advance(lp); }
+        PWS_T(3)
         par ^= 1;
     };
 
@@ -609,7 +662,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         if constexpr (!BF) {      // (bf16 activations: the rolling operand loads already wrapped into the next tile)
             // operands of the next tile's first k-step (its chunk 0 is already staged in xs[par])
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
+            for (int ct = 0; ct < (A2 ? 0 : CT); ++ct) {      // (A2: the tile's last two k-steps already requested them)
                 ah[ct] = lda(0, ct, 0);
                 if constexpr (H2) al[ct] = lda(0, ct, 1);
                 else { am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
@@ -646,8 +699,9 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
     __syncthreads();
     if (tid == 0 && g.e3 && EPI != 3) {   // development: per-block phase durations (cycles) -> e3
         const unsigned long long ts3 = __builtin_readcyclecounter();
-        float* o = const_cast<float*>(g.e3) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        float* o = const_cast<float*>(g.e3) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
         o[0] = (float)(ts1 - ts0); o[1] = (float)(ts2 - ts1); o[2] = (float)tepi; o[3] = (float)nt;
+        o[4] = (float)tph[0]; o[5] = (float)tph[1]; o[6] = (float)tph[2]; o[7] = (float)tph[3];
     }
 #endif
 }
@@ -797,7 +851,10 @@ int pw_split_blocks_per_frame(int N, int P) {
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
             ncu = 256;
-        slots = 2 * ncu;
+#ifndef PWS_BLOCKS_PER_CU
+#define PWS_BLOCKS_PER_CU 2
+#endif
+        slots = PWS_BLOCKS_PER_CU * ncu;
     }
     const int ntile = P / PWS_TP;
     int bpf = slots / N;
