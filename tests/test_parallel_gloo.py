@@ -129,3 +129,75 @@ def test_default_buckets_cover_uncrtaints_parameters():
     assert len(b) == 3
     assert sorted(n for x in b for n in x) == sorted(n for n, _ in m.named_parameters())
     assert b[0][0].startswith("out_block") or b[0][0].startswith("out_conv")
+
+
+class ToyUnused(Toy):
+    """One parameter of the middle bucket never receives a gradient (an unused / frozen-in-effect branch): that bucket's hook count
+    stays short of its size, no hook launches its all-reduce, and finish() has to pack (zeros for the missing gradient) and reduce."""
+
+    def __init__(self):
+        super().__init__()
+        self.temporal_encoder_unused = torch.nn.Parameter(torch.ones(5))
+
+
+def _worker4(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uncrtaints_amd.parallel import BucketedDataParallel
+    torch.manual_seed(200 + rank)
+    m = ToyUnused()
+    dp = BucketedDataParallel(m)
+    sizes = [b["n"] for b in dp.buckets]
+    g = torch.Generator().manual_seed(11)
+    X, Y = torch.randn(4 * world + 3, 6, generator=g), torch.randn(4 * world + 3, 2, generator=g)
+    # uneven shards: the last rank takes the remainder (a per-rank mean then differs from the global mean: the test compares with
+    # the mean of the per-shard gradients, which is what an averaging all-reduce defines)
+    lo = rank * 4
+    hi = lo + 4 if rank < world - 1 else X.shape[0]
+    launched_by_hooks = None
+    for step in range(2):
+        dp.zero_grad()
+        ((dp(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
+        if step == 0:
+            launched_by_hooks = [b["handle"] is not None for b in dp.buckets]
+        dp.finish()
+    grads = {n: (p.grad.numpy().copy() if p.grad is not None else None) for n, p in m.named_parameters()}
+    q.put((rank, grads, {n: p.detach().numpy().copy() for n, p in m.named_parameters()}, launched_by_hooks, sizes, (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_uneven_bucket_and_shards():
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the bucket that holds the gradient-less parameter was NOT launched from a hook (finish() reduced it); the others were
+    for _, _, _, launched, sizes, _ in res:
+        assert launched == [True, False, True], launched
+        assert sizes[1] == 3
+    g0 = res[0][1]
+    for r in range(1, world):
+        for n in g0:
+            assert torch.allclose(torch.from_numpy(res[r][1][n]), torch.from_numpy(g0[n]), atol=1e-7), (r, n)
+            assert (res[r][2][n] == res[0][2][n]).all(), n
+    assert (g0["temporal_encoder_unused"] == 0).all()           # zeros went through the all-reduce (torch-DDP semantics)
+    # reference: mean over ranks of the per-shard gradients, with rank 0's (broadcast) weights
+    g = torch.Generator().manual_seed(11)
+    X, Y = torch.randn(4 * world + 3, 6, generator=g), torch.randn(4 * world + 3, 2, generator=g)
+    acc = None
+    for r in range(world):
+        lo, hi = res[r][5]
+        m = ToyUnused()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in res[0][2].items()})
+        ((m(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
+        gs = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()}
+        acc = gs if acc is None else {n: acc[n] + gs[n] for n in gs}
+    for n in acc:
+        assert torch.allclose(acc[n] / world, torch.from_numpy(g0[n]), atol=1e-6), n

@@ -61,6 +61,9 @@ template <bool NT, typename TA> __device__ __forceinline__ void pws_st(TA* p, co
 #ifndef PWS_PRIO
 #define PWS_PRIO 0   // experiment: 1 = s_setprio(1) around every k-step's MFMA groups, 2 = static priority for every second block
 #endif
+#ifndef PWS_EPI_PIPE
+#define PWS_EPI_PIPE 0   // 1: double-buffered operand rows in the aux epilogues 2 / 3; 3: also in the skip epilogues 5 / 6
+#endif
 #ifndef PWS_A2SET
 #define PWS_A2SET 0   // experiment: two rolling A-fragment sets (one per k-step parity), each re-loaded for the SAME k-step of the next chunk
 #endif
@@ -539,13 +542,22 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         int nco = n * Cout;
         asm volatile("" : "+s"(nco));   // keep the 2 x 32 row bases from being hoisted out of the tile loop (SGPR spills)
         auto row_of = [&](int ct, int r) { return (wn * CT + ct) * 32 + (r & 3) + 8 * (r >> 2); };   // + 4*kg per lane
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            constexpr int RB = (EPI == 5 || EPI == 6) ? 4 : 8;     // rows per request batch (epi 5 reads three rows per output row)
-#pragma unroll
-            for (int rb = 0; rb < 16; rb += RB) {
-                float4 xa[(EPI == 2 || EPI == 3 || EPI == 4 || EPI == 5 || EPI == 6) ? RB : 1];
-                float4 xb[(EPI == 5 || EPI == 6) ? RB : 1], xc[(EPI == 5 || EPI == 6) ? RB : 1];
+        {
+#ifndef PWS_EPI_RB
+#define PWS_EPI_RB 8
+#endif
+            constexpr int RB = (EPI == 5 || EPI == 6) ? 4 : ((EPI == 2 || EPI == 3) ? PWS_EPI_RB : 8);     // rows per request batch (epi 5 reads three rows per output row)
+            constexpr bool AUX = EPI == 2 || EPI == 3 || EPI == 4 || EPI == 5 || EPI == 6;
+            constexpr int NBAT = CT * 16 / RB;                      // batches of the tile: (ct, rb) = (bi / (16 / RB), RB * (bi % (16 / RB)))
+            // PWS_EPI_PIPE: the operand rows of batch bi + 1 are requested BEFORE batch bi is transformed (two register sets), so the
+            // epilogue's VALU work (pass-B: GELU' on every element) runs under the next batch's HBM latency instead of behind it
+            constexpr bool PIPE = (PWS_EPI_PIPE != 0) && AUX && EPI != 4 && ((PWS_EPI_PIPE & 2) || EPI == 2 || EPI == 3);
+            constexpr int NSET = PIPE ? 2 : 1;
+            float4 xa[NSET][AUX ? RB : 1];
+            float4 xb[NSET][(EPI == 5 || EPI == 6) ? RB : 1], xc[NSET][(EPI == 5 || EPI == 6) ? RB : 1];
+            auto issue = [&](auto bic, auto setc) {
+                constexpr int bi = decltype(bic)::value, S = decltype(setc)::value;
+                constexpr int ct = bi / (16 / RB), rb = RB * (bi % (16 / RB));
                 if constexpr (EPI == 5 || EPI == 6) {      // skip + PreNorm backward: x, dy, and the producing block's h3 (statistics)
                     const TA* a3 = g.aux3 ? (const TA*)g.aux3 : (const TA*)g.aux2;
 #pragma unroll
@@ -553,31 +565,31 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                         const int rw = row_of(ct, rb + q);
                         const int rc = rw + 4 < Cout ? rw : (Cout > 8 ? Cout - 8 : 0);
                         const size_t o = (size_t)(nco + rc) * P + loff;
-                        xa[q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux + o);
-                        xb[q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux2 + o);
-                        xc[q] = ld4<TA, UNCR_NTG_AUX>(a3 + o);
+                        xa[S][q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux + o);
+                        xb[S][q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux2 + o);
+                        xc[S][q] = ld4<TA, UNCR_NTG_AUX>(a3 + o);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (EPI == 4) {      // accumulate: out += result (dense 3x3 as nine shifted 1x1 GEMMs)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int rw = row_of(ct, rb + q);
                         const int rc = rw + 4 < Cout ? rw : (Cout > 8 ? Cout - 8 : 0);
-                        xa[q] = ld4<TA>((const TA*)g.out + (size_t)(nco + rc) * P + loff);
+                        xa[S][q] = ld4<TA>((const TA*)g.out + (size_t)(nco + rc) * P + loff);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (EPI == 2 || EPI == 3) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int r = rb + q;
-                        const int rw = row_of(ct, r);            // rows past Cout (padded tiles) re-read the last valid row
+                    for (int q = 0; q < RB; ++q) {
+                        const int rw = row_of(ct, rb + q);            // rows past Cout (padded tiles) re-read the last valid row
                         const int rc = rw + 4 < Cout ? rw : (Cout > 8 ? Cout - 8 : 0);
-                        xa[q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux + (size_t)(nco + rc) * P + loff);
+                        xa[S][q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux + (size_t)(nco + rc) * P + loff);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+            };
+            auto transform = [&](auto bic, auto setc) {
+                constexpr int bi = decltype(bic)::value, S = decltype(setc)::value;
+                constexpr int ct = bi / (16 / RB), rb = RB * (bi % (16 / RB));
 #pragma unroll
                 for (int q = 0; q < RB; ++q) {
                     const int r = rb + q;
@@ -593,7 +605,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                     float s0 = 0.f, s1 = 0.f;
                     if constexpr (EPI == 3) {
                         // du2 = gelu'(A*h2 + B) * (S*dz + D): the SE / GELU backward applied to the fresh accumulator
-                        const float4 x = xa[q];
+                        const float4 x = xa[S][q];
                         const float eA = ecf[1][col], eB = ecf[2][col], eS = ecf[3][col], eD = ecf[4][col];
                         v.x = gelu_grad_f(fmaf(eA, x.x, eB)) * fmaf(eS, v.x, eD);
                         v.y = gelu_grad_f(fmaf(eA, x.y, eB)) * fmaf(eS, v.y, eD);
@@ -603,7 +615,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
                     } else if constexpr (EPI == 2) {
-                        const float4 x = xa[q];
+                        const float4 x = xa[S][q];
                         v = rnd4<TA>(v);
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
@@ -612,10 +624,10 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
                     } else if constexpr (EPI == 4) {
-                        v.x += xa[q].x; v.y += xa[q].y; v.z += xa[q].z; v.w += xa[q].w;
+                        v.x += xa[S][q].x; v.y += xa[S][q].y; v.z += xa[S][q].z; v.w += xa[S][q].w;
                     } else if constexpr (EPI == 5) {
                         // dx = dy + C1*da + C2*x + C3 (PreNorm backward + skip) on the fresh accumulator da
-                        const float4 x = xa[q], y = xb[q], h = xc[q];
+                        const float4 x = xa[S][q], y = xb[S][q], h = xc[S][q];
                         const float e1 = ecf[1][col], e2 = ecf[2][col], e3 = ecf[3][col], em = ecf[5][col];
                         v.x = y.x + fmaf(e1, v.x, fmaf(e2, x.x - em, e3));
                         v.y = y.y + fmaf(e1, v.y, fmaf(e2, x.y - em, e3));
@@ -626,7 +638,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                         s1 = v.x * h.x + v.y * h.y + v.z * h.z + v.w * h.w;
                     } else if constexpr (EPI == 6) {
                         // as 5, then the producing ConvLayer's ReLU backward: du0 = dx * [rA*c0 + rB > 0], aux3 = c0
-                        const float4 x = xa[q], y = xb[q], h = xc[q];
+                        const float4 x = xa[S][q], y = xb[S][q], h = xc[S][q];
                         const float e1 = ecf[1][col], e2 = ecf[2][col], e3 = ecf[3][col], em = ecf[5][col];
                         const float rA = ecf[4][col], rB = ecf[0][col];
                         v.x = fmaf(rA, h.x, rB) > 0.f ? y.x + fmaf(e1, v.x, fmaf(e2, x.x - em, e3)) : 0.f;
@@ -645,7 +657,26 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                         if (j == 31) { red[col][0] += s0; red[col][1] += s1; }   // this lane owns column col in the block
                     }
                 }
-            }
+            };
+            // compile-time walk over the batches (register sets are static after unrolling)
+            auto walk = [&](auto self, auto bic) -> void {
+                constexpr int bi = decltype(bic)::value;
+                if constexpr (bi < NBAT) {
+                    using Cur = std::integral_constant<int, PIPE ? (bi & 1) : 0>;
+                    using Nxt = std::integral_constant<int, PIPE ? ((bi + 1) & 1) : 0>;
+                    if constexpr (PIPE) {
+                        if constexpr (bi == 0) issue(std::integral_constant<int, 0>{}, Cur{});
+                        if constexpr (bi + 1 < NBAT) issue(std::integral_constant<int, bi + 1>{}, Nxt{});
+                    } else if constexpr (AUX) {
+                        issue(bic, Cur{});
+                    }
+                    if constexpr (AUX) __builtin_amdgcn_sched_barrier(0);
+                    transform(bic, Cur{});
+                    if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+                    self(self, std::integral_constant<int, bi + 1>{});
+                }
+            };
+            walk(walk, std::integral_constant<int, 0>{});
         }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {

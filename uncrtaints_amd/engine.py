@@ -1412,8 +1412,6 @@ def sdpa_rows_forward(q: Tensor, k: Tensor, v: Optional[Tensor], pad: Optional[T
     """q [m, dk] (or [q_rows, dk] shared by consecutive row groups), k [m, T, dk], v [m, T, dv], pad [m, T] int32.
     -> attention as returned (after dropout) [m, T], attn @ v [m, dv] or None, masked scaled scores [m, T] or None, saved"""
     m, T, dk = k.shape
-    if T > 64:
-        raise NotImplementedError("stand-alone attention rows are built for sequences of at most 64 dates")
     dev = k.device
     q, k = q.contiguous().float(), k.contiguous().float()
     dv = v.shape[-1] if v is not None else 0
