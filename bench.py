@@ -318,8 +318,16 @@ def main():
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     dist_info = {}
-    if world > 1:
+    # UNCR_BENCH_FORCE_DP=1 (development / tests): take the N > 1 code path -- process group, bucketed all-reduces, segmented graphs --
+    # with whatever world size the launcher set, including 1.  One rank over RCCL runs the real collective library and the
+    # capture / replay pattern of the multi-GPU step on a single-GPU box (tests/test_gpu_ddp.py).
+    dp_mode = world > 1 or os.environ.get("UNCR_BENCH_FORCE_DP") == "1"
+    if dp_mode:
         import datetime
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         # fail fast: a collective error or a lost rank must end the run, not hang it (the driver times the whole command)
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
         os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "0")
@@ -349,7 +357,7 @@ def main():
     model = build_model(device, seed=1, act_dtype=args.act_dtype)
     crit = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode="diag")
     dp = None
-    if world > 1:
+    if dp_mode:
         from uncrtaints_amd.parallel import BucketedDataParallel
         # with a captured forward/backward the collectives stay outside the graph: no launches from autograd hooks
         dp = BucketedDataParallel(model, seed=1, overlap=args.no_graph)
@@ -509,7 +517,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp_mode:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -539,7 +547,7 @@ def main():
     hb.set_profiler(None)
     coll_wait = dp.wait_ms() if dp is not None else []
     eager_ms = None
-    if world > 1:   # the max over ranks of the timed region, taken before anything else touches the stream
+    if dp_mode:   # the max over ranks of the timed region, taken before anything else touches the stream
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -568,7 +576,7 @@ def main():
     # the step is fwd + MGNLL + bwd, "optimizer step reported separately".  The timed step above INCLUDES the Adam
     # update (the number a training run sees); its own cost is measured here, eagerly, with HIP events on the current stream.
     opt_ms = None
-    if world == 1 and not args.no_kernel_events:      # (at N > 1 the update is its own captured graph behind the all-reduces)
+    if not dp_mode and not args.no_kernel_events:      # (at N > 1 the update is its own captured graph behind the all-reduces)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         opt.step(); fence()
         e0.record()
@@ -588,7 +596,7 @@ def main():
                                    f"B={B}/GPU, {H}x{H}, fwd+MGNLL+bwd+Adam, train mode (dropout on), "
                                    + ("bf16 activation storage / fp32 accumulate, statistics, weights and loss" if bf16 else "fp32"),
                        "global_batch": world * B, "T": T, "parallelism": f"dp{world}"},
-            "ranks": world, "collective_backend": (backend if world > 1 else None),
+            "ranks": world, "collective_backend": (backend if dp_mode else None),
             # N > 1: what travels (one fp32 bucket per backward segment, all-reduce AVG), on which devices, and how long the compute
             # stream stood still for it per step (HIP events around the waits in finish(): 0 = fully hidden behind the backward)
             "collective": (dict(dist_info, bucket_bytes=dp.bucket_bytes(), all_reduces_per_step=len(dp.buckets),
@@ -703,12 +711,12 @@ def main():
                                              "(graph replays cannot be bracketed per kernel)")
         if power_summary is not None:
             res["power"] = power_summary
-        if world == 1 and not bf16 and not args.no_bf16_leg:
+        if not dp_mode and not bf16 and not args.no_bf16_leg:
             res["bf16"] = bf16_leg(args)
-        if world == 1 and not args.no_cpu_baseline:
+        if not dp_mode and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(T, H, H)
         print(json.dumps(res))
-    if world > 1:
+    if dp_mode:
         dist.barrier()
         dist.destroy_process_group()
 

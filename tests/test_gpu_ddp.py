@@ -229,3 +229,37 @@ def test_bench_two_ranks_segmented_graphs_gloo(act):
     assert res["dtype"] == ("bf16" if act == "bf16" else "f32")
     import math
     assert math.isfinite(res["final_loss"])
+
+
+def test_bench_one_rank_over_rccl_segmented_graphs():
+    """The multi-GPU step of bench.py on the REAL collective library: one rank, backend "nccl" (= RCCL on ROCm).  A one-rank
+    all-reduce moves no data, but everything else is what runs at N = 8: RCCL communicator creation on the device, the four captured
+    segment graphs (capture_error_mode="thread_local" next to RCCL's watchdog thread), asynchronous all-reduces enqueued between
+    the replays, the waits in finish(), the fused Adam graph behind them.  (RCCL refuses two ranks on one device, so two ranks are
+    exercised over gloo above.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UNCR_BENCH_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    env.pop("UNCR_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--size", "64",
+           "--batch-per-gpu", "2", "--no-power"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["collective_backend"] == "nccl" and res["ranks"] == 1
+    assert "all-reduced" in res["launch_mode"] and "graph" in res["launch_mode"], res["launch_mode"]
+    col = res["collective"]
+    assert col["all_reduces_per_step"] == 3 and sum(col["bucket_bytes"]) == 4 * 570010 and col["wait_ms_per_step"] >= 0
+    import math
+    assert math.isfinite(res["final_loss"]) and res["value"] > 0
+    # the same seeds without the data-parallel wrapper: a one-rank average changes nothing, the loss after the same number of steps
+    # agrees (dropout streams are seeded alike: seed + rank with rank 0)
+    env2 = {k: v for k, v in env.items() if k != "UNCR_BENCH_FORCE_DP"}
+    r2 = subprocess.run(cmd + ["--no-cpu-baseline", "--no-bf16-leg", "--no-kernel-events"], capture_output=True, text=True, env=env2,
+                        timeout=900, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    res2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][-1])
+    assert abs(res2["final_loss"] - res["final_loss"]) <= 1e-4 * abs(res2["final_loss"]) + 1e-6, (res["final_loss"], res2["final_loss"])

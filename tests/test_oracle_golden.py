@@ -245,16 +245,17 @@ def test_oracle_ltae2d_vs_reference_rows_fixture(i):
     training = bool(g[pre + "training"])
     p = {}
     for k in g.files:
-        if k.startswith(pre + "state/"):
-            t = torch.from_numpy(g[k]).clone()
-            p["temporal_encoder." + k[len(pre + "state/"):]] = t
+        if k.startswith("ltae/state/"):
+            p["temporal_encoder." + k[len("ltae/state/"):]] = torch.from_numpy(g[k]).clone()
     nh, dk = p["temporal_encoder.attention_heads.Q"].shape
     cfg = orc.OracleConfig(n_head=nh, d_k=dk, d_model=256, ltae_dropout=0.0)
-    x = torch.from_numpy(g[pre + "x"]).clone().requires_grad_(True)
-    v, a = orc.ltae2d_values_attention(x, torch.from_numpy(g[pre + "dates"]), torch.from_numpy(g[pre + "pad"]), p, cfg, training)
+    x = torch.from_numpy(g["ltae/x"]).clone().requires_grad_(True)
+    v, a = orc.ltae2d_values_attention(x, torch.from_numpy(g["ltae/dates"]), torch.from_numpy(g["ltae/pad"]), p, cfg, training)
+    # (the fixture keeps the value MLP's BatchNorm bias well above zero: with dead post-ReLU GroupNorm groups out_norm's variance sits
+    # at eps and two correct fp32 evaluations of this module differ by 3e-4 -- measured while the fixture was designed)
     assert rel_err(v.detach().numpy(), g[pre + "out"]) < 2e-5
     assert rel_err(a.detach().numpy(), g[pre + "attn"]) < 2e-5
-    ((v * torch.from_numpy(g[pre + "gv"])).sum() + (a * torch.from_numpy(g[pre + "ga"])).sum()).backward()
+    ((v * torch.from_numpy(g["ltae/gv"])).sum() + (a * torch.from_numpy(g["ltae/ga"])).sum()).backward()
     assert rel_err(x.grad.numpy(), g[pre + "dx"]) < 1e-4
     if training:
         assert rel_err(p["temporal_encoder.mlp.1.running_mean"].numpy(), g[pre + "after/mlp.1.running_mean"]) < 2e-5

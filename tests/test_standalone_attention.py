@@ -262,25 +262,26 @@ def test_ltae2d_vs_reference_fixture(g19, i):
     from uncrtaints_amd.src.backbones.ltae import LTAE2d
     g, pre = g19, f"ltae{i}/"
     training = bool(g[pre + "training"])
-    state = {k[len(pre + "state/"):]: _t(g, k) for k in g.files if k.startswith(pre + "state/")}
+    state = {k[len("ltae/state/"):]: _t(g, k) for k in g.files if k.startswith("ltae/state/")}
     C = state["in_norm.weight"].numel()
     nh, dk = state["attention_heads.Q"].shape
     m = LTAE2d(in_channels=C, n_head=nh, d_k=dk, mlp=[256, C], dropout=0.0, d_model=256, return_att=True, use_dropout=False)
-    m.load_state_dict(state, strict=True)
+    m.load_state_dict(state, strict=True)      # (a 32 x 32 map, one sample with a padded date; the same weights and inputs in both modes)
     m = m.to(DEV).train(training)
-    x = dev(_t(g, pre + "x")).requires_grad_(True)
-    out, attn = m(x, batch_positions=dev(_t(g, pre + "dates")), pad_mask=dev(_t(g, pre + "pad")))
-    close(f"g19 LTAE2d[train={training}] values", out, _t(g, pre + "out"))
+    x = dev(_t(g, "ltae/x")).requires_grad_(True)
+    out, attn = m(x, batch_positions=dev(_t(g, "ltae/dates")), pad_mask=dev(_t(g, "ltae/pad")))
+    VT = 1e-4      # the plain contract (the fixture keeps out_norm's 8-value groups alive: see make_golden.py::case_attention_rows)
+    close(f"g19 LTAE2d[train={training}] values", out, _t(g, pre + "out"), tol=VT)
     close(f"g19 LTAE2d[train={training}] attn", attn, _t(g, pre + "attn"))
-    ((out * dev(_t(g, pre + "gv"))).sum() + (attn * dev(_t(g, pre + "ga"))).sum()).backward()
-    close("g19 LTAE2d dx", x.grad, _t(g, pre + "dx"))
+    ((out * dev(_t(g, "ltae/gv"))).sum() + (attn * dev(_t(g, "ltae/ga"))).sum()).backward()
+    close("g19 LTAE2d dx", x.grad, _t(g, pre + "dx"), tol=VT)
     for k, par in m.named_parameters():
         ref = _t(g, pre + "grad/" + k)
         if k == "attention_heads.fc1_k.bias" or (training and k in ("inconv.bias", "mlp.0.bias", "in_norm.bias")):
             sib = m.get_parameter(k.replace(".bias", ".weight")).grad       # zero gradients (see test_ltae2d_standalone)
             assert float(par.grad.abs().max()) < 1e-3 * float(sib.abs().max()), k
             continue
-        close(f"g19 LTAE2d grad[{k}]", par.grad, ref)
+        close(f"g19 LTAE2d grad[{k}]", par.grad, ref, tol=VT)
     if training:
         for k in ("mlp.1.running_mean", "mlp.1.running_var"):
             close("g19 LTAE2d " + k, m.state_dict()[k], _t(g, pre + "after/" + k))
