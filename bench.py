@@ -25,7 +25,7 @@ FP32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 / _f16 dense peak (what the split GEMMs really run on: 6, 3 or 2 products)
 
 PRO_NORMBWD = 3
-TRAFFIC_FILE = "r03_traffic.json"          # fp32 storage; bf16 storage: r03_traffic_bf16.json (tools/measure_traffic.sh <tag> [bf16])
+TRAFFIC_FILE = "r04_traffic.json"          # fp32 storage; bf16 storage: r04_traffic_bf16.json (tools/measure_traffic.sh <tag> [bf16])
 
 
 def kernel_model(name, key):
@@ -273,7 +273,7 @@ def bf16_leg(args):
         d = json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:      # noqa: BLE001 -- the headline line must not die with its appendix
         return {"error": f"{type(e).__name__}: {e}"[:300]}
-    out = {k: d.get(k) for k in ("dtype", "value", "unit", "ms_per_step", "steps", "step_hbm_roofline_frac")}
+    out = {k: d.get(k) for k in ("dtype", "value", "unit", "ms_per_step", "steps", "step_hbm_roofline_frac", "power")}
     out["config"] = "the same workload with bf16 activation storage, fp32 statistics / weights / accumulation (BASELINE config 3, one GPU)"
     if "roofline" in d:
         out["roofline"] = {k: d["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "mean_launch_ms")}

@@ -65,7 +65,7 @@ def main(out_path):
     idle = samples[-1] if samples else None
     t = lambda *s: torch.randn(*s, device=dev)
     amax = lambda x: x.abs().amax(dim=(1, 2)).view(N, 1).contiguous()
-    for data in ("random", "zero"):
+    for data in (() if "--bf16" in sys.argv else ("random", "zero")):
         z = (lambda x: x) if data == "random" else torch.zeros_like
         h2 = z(t(N, 256, P)); x = z(t(N, 128, P)); x2 = z(t(N, 128, P))
         W2 = E.pack_wt(t(128, 256) * 0.05, transpose=True); W1 = E.pack_wt(t(256, 128) * 0.05, transpose=True)
@@ -92,6 +92,41 @@ def main(out_path):
         loop(f"wgrad [128x256] [{data}]", lambda: E.pw_wgrad(x, d, N, 128, 256, P, pro_d=3, dk=dk1, d2=x2, pro_x=2, xk=(k2[0], k2[1], None),
                                                             d_amax=a45, d2_amax=a45, x_ub=ub2), 4.0 * N * P * 512)
         del h2, x, x2, d, d2, o128, o256
+    if "--bf16" in sys.argv:       # the same launches on bf16 activation storage (BASELINE config 3)
+        bf = torch.bfloat16
+        tb = lambda *s: torch.randn(*s, device=dev).to(bf)
+        h2, x, x2 = tb(N, 256, P), tb(N, 128, P), tb(N, 128, P)
+        W2 = E.pack_wt(t(128, 256) * 0.05, transpose=True); W1 = E.pack_wt(t(256, 128) * 0.05, transpose=True)
+        k2 = tuple(torch.rand(N * 256, device=dev) for _ in range(3)); k1 = tuple(t(N * 128) for _ in range(3))
+        ek = tuple(torch.rand(N * 256, device=dev) for _ in range(4))
+        o128, o256 = torch.empty(N, 128, P, device=dev, dtype=bf), torch.empty(N, 256, P, device=dev, dtype=bf)
+        loop("bf16 pw2 fwd", lambda: E.pw_gemm(h2, W2, N, 256, 128, P, pro=2, k=k2, epi=1, out=o128), 2.0 * N * P * 384)
+        loop("bf16 pw1 fwd", lambda: E.pw_gemm(x, W1, N, 128, 256, P, pro=1, k=k1, epi=1, out=o256), 2.0 * N * P * 384)
+        loop("bf16 dz + pass-B", lambda: E.pw_gemm(x, W1, N, 128, 256, P, pro=3, k=k1, x2=x2, epi=3, aux=h2, ek=ek, out=o256), 2.0 * N * P * 768)
+        d, d2 = tb(N, 256, P), tb(N, 256, P)
+        dk = tuple(t(N * 256) for _ in range(3))
+        W1k = E.pack_wt(t(256, 128) * 0.05, transpose=False)
+        c = tuple(t(N * 128) for _ in range(3))
+        part = torch.empty(N * 128, hb.query("uncr_pw_stat_slots", N, 128, P), 2, device=dev)
+        loop("bf16 dx", lambda: hb.call("uncr_pw_gemm_dx", d, d2, W1k, o128, dk[0], dk[1], dk[2], None, x, x2, x, c[0], c[1], c[2], None, None,
+                                        None, part, N, 256, 128, P, 1, None, None, 0, None, 0, E._stream()), 2.0 * N * P * 1024)
+        xk = (t(N * 128), t(N * 128), None)
+        loop("bf16 wgrad [256x128]", lambda: E.pw_wgrad(d, x, N, 256, 128, P, pro_d=3, dk=dk, d2=d2, pro_x=1, xk=xk), 2.0 * N * P * 640)
+        dk1 = tuple(v[:N * 128] for v in dk)
+        loop("bf16 wgrad [128x256]", lambda: E.pw_wgrad(x, d, N, 128, 256, P, pro_d=3, dk=dk1, d2=x2, pro_x=2, xk=(k2[0], k2[1], None)), 2.0 * N * P * 512)
+        C, H, W = 256, 256, 256
+        h1, hh2, du2 = tb(N, C, H, W), tb(N, C, H, W), tb(N, C, H, W)
+        o4d = torch.empty(N, C, H, W, device=dev, dtype=bf)
+        cA, cB, q1, q2, q3 = (t(N * C) for _ in range(5))
+        w9 = t(C, 9)
+        sf, sb = hb.query("uncr_dw_slots_fwd", H), hb.query("uncr_dw_slots_bwd", H)
+        partf, partb, dwp = torch.empty(N * C, sf, 2, device=dev), torch.empty(N * C, sb, 2, device=dev), torch.empty(N * C, sb, 9, device=dev)
+        loop("bf16 dw_fwd", lambda: hb.call("uncr_dw_fwd", h1, cA, cB, w9, o4d, partf, N, C, H, W, 1, 0, E._stream()), 4.0 * N * C * P)
+        loop("bf16 dw_bwd", lambda: hb.call("uncr_dw_bwd", du2, hh2, h1, q1, q2, q3, None, cA, cB, w9, o4d, partb, dwp, None, 0, N, C, H, W, 1, 0, None,
+                                            E._stream()), 8.0 * N * C * P)
+        stop = True
+        json.dump({"method": __doc__.strip(), "power_cap_w": float(cap[0]) if cap else None, "kernels": results}, open(out_path, "w"), indent=1)
+        return
     C, H, W = 256, 256, 256
     h1, hh2, du2, out = t(N, C, H, W), t(N, C, H, W), t(N, C, H, W), torch.empty(N, C, H, W, device=dev)
     cA, cB, q1, q2, q3 = (t(N * C) for _ in range(5))

@@ -3,7 +3,8 @@
 set -eu
 tag=$1
 cd "$(dirname "$0")/.."
-cp gpurun_out/${tag}_pytest_gpu.log profiles/${tag}_pytest_gpu.log
+grep -E "PASSED|FAILED|ERROR|passed|failed" gpurun_out/${tag}_pytest_gpu.log | sed -e 's/\x1b\[[0-9;]*m//g' > profiles/${tag}_pytest_gpu.log
+for f in parity stream_roofs power power_bf16; do [ -f gpurun_out/${tag}_$f.json ] && cp gpurun_out/${tag}_$f.json profiles/${tag}_$f.json; done
 cp gpurun_out/${tag}_traffic.json profiles/${tag}_traffic.json
 cp gpurun_out/${tag}_traffic_bf16.json profiles/${tag}_traffic_bf16.json
 cp gpurun_out/${tag}_pmc_FETCH_SIZE.csv gpurun_out/${tag}_pmc_WRITE_SIZE.csv profiles/

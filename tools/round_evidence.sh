@@ -6,7 +6,12 @@ set -u
 tag=${1:-rXX}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$root"; mkdir -p gpurun_out
-python -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${tag}_pytest_gpu.log
+# -s -v: the [parity] lines stay in the log; tools/parse_parity.py turns them into the tracked per-test margins
+python -m pytest tests -m gpu -s -v -p no:cacheprovider > gpurun_out/${tag}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${tag}_pytest_gpu.log
+python tools/parse_parity.py gpurun_out/${tag}_pytest_gpu.log gpurun_out/${tag}_parity.json | head -3
+python tools/stream_roofs.py gpurun_out/${tag}_stream_roofs.json > gpurun_out/${tag}_stream_roofs.log 2>&1; tail -2 gpurun_out/${tag}_stream_roofs.log
+python tools/clock_watch.py gpurun_out/${tag}_power.json > gpurun_out/${tag}_power.log 2>&1; tail -3 gpurun_out/${tag}_power.log
+python tools/clock_watch.py gpurun_out/${tag}_power_bf16.json --bf16 > gpurun_out/${tag}_power_bf16.log 2>&1; tail -3 gpurun_out/${tag}_power_bf16.log
 # PMC passes first: bench.py attaches roofline.traffic only from a file measured on the current kernel sources
 tools/measure_traffic.sh $tag > gpurun_out/${tag}_traffic.log 2>&1; tail -9 gpurun_out/${tag}_traffic.log
 tools/measure_traffic.sh $tag bf16 > gpurun_out/${tag}_traffic_bf16.log 2>&1; tail -9 gpurun_out/${tag}_traffic_bf16.log

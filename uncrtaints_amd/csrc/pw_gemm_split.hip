@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
     const unsigned long long ts2 = __builtin_readcyclecounter();
     __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
     __syncthreads();
-    if (tid == 0 && g.e3 && EPI != 3) {   // development: per-block phase durations (cycles) -> e3
+    if (tid == 0 && g.e3) {   // development: per-block phase durations (cycles) -> e3 (epi 3: overwrites its D coefficients at the very end)
         const unsigned long long ts3 = __builtin_readcyclecounter();
         float* o = const_cast<float*>(g.e3) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
         o[0] = (float)(ts1 - ts0); o[1] = (float)(ts2 - ts1); o[2] = (float)tepi; o[3] = (float)nt;
