@@ -140,6 +140,38 @@ __global__ __launch_bounds__(1024) void ltae_compose_kernel(
     }
 }
 
+// Cross-lane sums of the fused kernels without the LDS crossbar (ds_bpermute: ~2 issue slots + an LDS round trip per __shfl_xor; the
+// forward kernel makes 192 of them per thread, the backward 300).  For the model's 16 heads the NH lanes of a pixel are exactly one
+// DPP row: four full-rate v_add_f32_dpp give every lane the row sum; the sum over the wave's four pixels (lanes i, i+16, i+32, i+48)
+// takes gfx950's v_permlane16_swap / v_permlane32_swap (rows 1 <-> 0 and 3 <-> 2 of a copy, then the wave's halves) and two adds.
+// Other head counts keep the shuffle butterfly.  (The summation order differs from the butterfly's: last-bit differences.)
+__device__ __forceinline__ float lf_pixel_sum(float p, int NH) {            // over the pixel's NH lanes; every lane gets the sum
+    if (NH == 16) {                                                        // wave-uniform
+        p += dpp_mov<0xB1>(p);                 // quad_perm [1,0,3,2]
+        p += dpp_mov<0x4E>(p);                 // quad_perm [2,3,0,1]
+        p += dpp_mov<0x124>(p);                // row_ror:4
+        p += dpp_mov<0x128>(p);                // row_ror:8
+        return p;
+    }
+    for (int m = NH >> 1; m >= 1; m >>= 1) p += __shfl_xor(p, m, 64);
+    return p;
+}
+__device__ __forceinline__ float lf_wave_pixels_sum(float v, int NH) {      // over the wave's 64 / NH pixels (same lane within the pixel)
+    if (NH == 16) {
+        // Inline asm, not __builtin_amdgcn_permlane16_swap: with ROCm 7.2's hipcc the sum of the builtin's TWO results came out as
+        // v_add v, vdst, vdst (the second result replaced by the first; seen in the ISA, 100 % wrong weight gradients) -- the asm
+        // statement names both registers as read-write.  s_nop 1 = the two wait states the swap needs behind a VALU write of its
+        // operands (cdna_hip_programming.md T21).
+        float a = v, b = v;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));      // a = (r0, r0, r2, r2), b = (r1, r1, r3, r3)
+        float c = a + b, d = c;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c), "+v"(d));      // c = (lower, lower), d = (upper, upper)
+        return c + d;
+    }
+    for (int m = NH; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
 // ---- fused forward -----------------------------------------------------------------------------------------------------
 // thread = (pixel, GroupNorm group g) -- the number of groups equals the number of heads (ltae.py:191-194), so the NH lanes of a
 // pixel hold its NH groups in the first half of the kernel and its NH heads in the second.  Wave = 64 / NH pixels, block = 4 waves,
@@ -197,7 +229,7 @@ __global__ __launch_bounds__(256) void ltae_fused_fwd_kernel(LfArgs g) {
                 float p = 0.f;
 #pragma unroll
                 for (int j = 0; j < CG; ++j) p = fmaf(a[j], xv[t][j], p);
-                for (int m = NH >> 1; m >= 1; m >>= 1) p += __shfl_xor(p, m, 64);    // over the pixel's NH lanes
+                p = lf_pixel_sum(p, NH);                                              // over the pixel's NH lanes
                 if (lane_g == h) sc[t] = p;
             }
         }
@@ -259,7 +291,7 @@ __global__ __launch_bounds__(256) void ltae_fused_bwd_kernel(LfArgs g) {
                 float v = a[t] * (d[t] - dot);
                 if (g.pad && g.pad[b * T + t]) v = 0.f;          // a padded date's score is the constant -1e3
                 dsl[(pl * NH + h) * T + t] = v;
-                for (int m = NH; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);      // over the wave's pixels (same head)
+                v = lf_wave_pixels_sum(v, NH);                                    // over the wave's pixels (same head)
                 if ((threadIdx.x & 63) == lane_g) accB[(wv * NH + h) * T + t] = v;
             }
     }
@@ -295,8 +327,7 @@ __global__ __launch_bounds__(256) void ltae_fused_bwd_kernel(LfArgs g) {
             }
 #pragma unroll
         for (int j = 0; j < CG; ++j) {
-            float v = da[j];
-            for (int m = NH; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);          // over the wave's pixels (same group)
+            const float v = lf_wave_pixels_sum(da[j], NH);                       // over the wave's pixels (same group)
             if ((threadIdx.x & 63) == lane_g) accA[(wv * NH + h) * C + lane_g * CG + j] = v;
         }
     }
