@@ -6,7 +6,7 @@ GRBM_GUI_ACTIVE is summed over the 8 XCDs, so kernel_cycles = GRBM_GUI_ACTIVE / 
 and valu_issue_busy = (SQ_INSTS_VALU - SQ_INSTS_MFMA) * 4 / (1024 * kernel_cycles)."""
 import csv, json, sys, collections
 
-NAMES = [("dw_bwd_row_kernel<float>", "dw_bwd"), ("dw_fwd_row_kernel<float>", "dw_fwd"),
+NAMES = [("dw_bwd_row_kernel<float", "dw_bwd"), ("dw_fwd_row_kernel<float", "dw_fwd"),
          ("pw_gemm_split_kernel<2, 3, 3, 1, float, ", "pw_gemm[128->256,pro3,epi3] (dz)"),
          ("pw_gemm_split_kernel<2, 1, 1, 1, float, ", "pw_gemm[128->256,pro1,epi1] (pw1 fwd)"),
          ("pw_gemm_split_kernel<1, 2, 1, 2, float, ", "pw_gemm[256->128,pro2,epi1] (pw2 fwd)"),
