@@ -17,7 +17,7 @@ int uncr_debug_mfma_probe_bf16(float* out, int blocks, int iters, hipStream_t st
  * out[l*4 + j] = j-th value received (256 ints). */
 int uncr_debug_tr_b16_probe(const int* offs, int* out, hipStream_t stream);
 int uncr_debug_bf16split_probe(const float* A, const float* B, float* out, int K, int terms, hipStream_t stream);
-/* HBM stream roofs: mode 0 read-only, 1 write-only, 2 copy, 3 two reads : one write, 4 one read : two writes, 5 three reads :
+/* HBM stream roofs: mode 0 read-only, 1 write-only, 2 copy, 3 two reads : one write, 4 one read : two writes, 6-8 the GEMMs' tiled pattern, 5 three reads :
  * one write; float4 lanes, contiguous slab per block, nt = non-temporal accesses.  a, b, c are read, x, y written, n_floats each. */
 int uncr_debug_stream_probe(const float* a, const float* b, const float* c, float* x, float* y, long long n_floats,
                             int mode, int nt, int blocks, hipStream_t stream);

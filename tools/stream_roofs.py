@@ -11,7 +11,9 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from uncrtaints_amd import hip_backend as hb  # noqa: E402
 
 MODES = {0: ("read_only", 1, 0), 1: ("write_only", 0, 1), 2: ("copy_1r_1w", 1, 1), 3: ("2r_1w", 2, 1), 4: ("1r_2w", 1, 2),
-         5: ("3r_1w", 3, 1)}
+         5: ("3r_1w", 3, 1),
+         # the same bytes in the plane-tiled GEMMs' access pattern: 512-byte pieces of 256-row groups, 256 KB apart, persistent blocks
+         6: ("tiled512B_2r_1w", 2, 1), 7: ("tiled512B_2r_0w", 2, 0), 8: ("tiled512B_16r_1w", 2, 0.125)}
 
 
 def main(out_path):
@@ -20,9 +22,11 @@ def main(out_path):
     bufs = [torch.empty(n, device="cuda", dtype=torch.float32).normal_() for _ in range(5)]
     s = torch.cuda.current_stream().cuda_stream
     res = {"n_bytes_per_stream": n * 4, "method": __doc__.strip().splitlines()[-2].strip(), "cases": []}
-    for blocks in (2048, 8192):
+    for blocks in (512, 2048, 8192):
         for nt in (0, 1):
             for mode, (name, nr, nw) in MODES.items():
+                if (mode >= 6) != (blocks == 512):       # the tiled patterns run on the GEMMs' persistent grid (two blocks per CU)
+                    continue
                 def run():
                     rc = dev.fn["uncr_debug_stream_probe"](*[b.data_ptr() for b in bufs], n, mode, nt, blocks, s)
                     assert rc == 0, rc

@@ -167,9 +167,58 @@ __global__ __launch_bounds__(256) void stream_probe_kernel(const float4* __restr
     if constexpr (MODE == 0)
         if (keep.x + keep.y + keep.z + keep.w == 1.2345e-30f) x[0] = keep;
 }
+// the same traffic in the access pattern of the plane-tiled GEMMs: every stream is [rows][65536] fp32 (one row = one (frame, channel)
+// plane), a job = 256 rows x one 128-pixel tile, i.e. 512-BYTE pieces 256 KB apart; persistent blocks walk jobs b, b + G, ...
+// MODE 6: read two streams, write one (the dz GEMM's 2 : 1), MODE 7: read two, write none, MODE 8: 7 reads : 1 write (the dx GEMM's mix:
+// seven row groups read, one written)
+template <int MODE, bool NT>
+__global__ __launch_bounds__(256) void stream_tile_probe_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                float* __restrict__ x, int rows_total) {
+    constexpr int PP = 65536, TP = 128, RG = 256;
+    const int ntile = PP / TP, njob = (rows_total / RG) * ntile;
+    const int rsub = threadIdx.x >> 5, c4 = (threadIdx.x & 31) * 4;
+    float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int job = blockIdx.x; job < njob; job += gridDim.x) {
+        const int g = job / ntile, t = job % ntile;
+        const size_t base = (size_t)g * RG * PP + (size_t)t * TP + c4;
+#pragma unroll 1
+        for (int rr = 0; rr < RG / 8; rr += 4) {
+            float4 va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t o = base + (size_t)((rr + u) * 8 + rsub) * PP;
+                va[u] = ld4<float, NT>(a + o);
+                vb[u] = ld4<float, NT>(b + o);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t o = base + (size_t)((rr + u) * 8 + rsub) * PP;
+                float4 v = va[u];
+                v.x += vb[u].x; v.y += vb[u].y; v.z += vb[u].z; v.w += vb[u].w;
+                if (MODE == 6 || (MODE == 8 && ((rr + u) & 3) == 0 && (rsub & 1) == 0)) st4<float, NT>(x + o, v);      // mode 8: every 8th row
+                else { keep.x += v.x; keep.y += v.y; keep.z += v.z; keep.w += v.w; }
+            }
+        }
+    }
+    if (keep.x + keep.y + keep.z + keep.w == 1.2345e-30f) x[0] = keep.x;
+}
+
 extern "C" int uncr_debug_stream_probe(const float* a, const float* b, const float* c, float* x, float* y, long long n_floats,
                                        int mode, int nt, int blocks, hipStream_t stream) {
-    if (n_floats <= 0 || n_floats % 4 || blocks <= 0 || mode < 0 || mode > 5) return UNCR_ESHAPE;
+    if (n_floats <= 0 || n_floats % 4 || blocks <= 0 || mode < 0 || mode > 8) return UNCR_ESHAPE;
+    if (mode >= 6) {
+        if (n_floats % (65536LL * 256)) return UNCR_ESHAPE;
+        const int rows = (int)(n_floats / 65536);
+#define ST_LAUNCH(M)                                                                                                            \
+        case M:                                                                                                                 \
+            if (nt) hipLaunchKernelGGL((stream_tile_probe_kernel<M, true>), dim3(blocks), dim3(256), 0, stream, a, b, x, rows);   \
+            else hipLaunchKernelGGL((stream_tile_probe_kernel<M, false>), dim3(blocks), dim3(256), 0, stream, a, b, x, rows);    \
+            break;
+        switch (mode) { ST_LAUNCH(6) ST_LAUNCH(7) ST_LAUNCH(8) }
+#undef ST_LAUNCH
+        UNCR_LAUNCH_CHECK();
+        return UNCR_OK;
+    }
     const size_t n4 = (size_t)n_floats / 4;
 #define SP_LAUNCH(M)                                                                                                          \
     case M:                                                                                                                   \
