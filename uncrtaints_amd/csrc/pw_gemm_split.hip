@@ -35,6 +35,12 @@
 #ifndef UNCR_NTG_ST2
 #define UNCR_NTG_ST2 0     // stores of the 256-channel outputs only (268 MB at N=4: larger than any cache level)
 #endif
+#ifndef UNCR_NTG_ST3
+#define UNCR_NTG_ST3 1     // stores of the fused pass-B epilogue only (du2 of the dz GEMM: 268 MB at N = 4 in 512-byte pieces, one third of that
+                           // kernel's traffic).  Round 4: the stream probe in this access pattern moves a 2 : 1 mix at 5.0 TB/s with plain and
+                           // 5.8 TB/s with non-temporal accesses; on the dz kernel alone 194 -> 179-185 us, in the step -0.09 ms (4 of 4
+                           // interleaved pairs: 12.11 vs 12.20 ms).  The same hint on every 256-channel output (ST2) slows pw1 forward by 10 %.
+#endif
 #include <type_traits>
 #include <cstdlib>
 // four consecutive activation elements as loaded: fp32 storage keeps the float4, bf16 storage keeps the raw 8 bytes (half the
@@ -685,7 +691,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                 const int rw = row_of(ct, r);
                 const float4 v = make_float4(acc[0][ct][r], acc[1][ct][r], acc[2][ct][r], acc[3][ct][r]);
                 if (rw + 4 * kg < Cout && (!(PWS_ABL & 1) || v.x == 1.2345e-30f)) {
-                    pws_st<(UNCR_NTG_ST || (UNCR_NTG_ST2 && CT == 2)) && EPI != 4, TA>((TA*)g.out + (size_t)(nco + rw) * P + loff, v);
+                    pws_st<(UNCR_NTG_ST || (UNCR_NTG_ST2 && CT == 2) || (UNCR_NTG_ST3 && EPI == 3)) && EPI != 4, TA>((TA*)g.out + (size_t)(nco + rw) * P + loff, v);
                 }
             }
         }
