@@ -35,6 +35,13 @@
 #ifndef UNCR_NTG_ST2
 #define UNCR_NTG_ST2 0     // stores of the 256-channel outputs only (268 MB at N=4: larger than any cache level)
 #endif
+#ifndef UNCR_NTG_ST4
+#define UNCR_NTG_ST4 0     // experiment: stores of the 128-channel statistics epilogue (h3 of pw2 forward)
+#endif
+#ifndef UNCR_NTG_ST5
+#define UNCR_NTG_ST5 1     // stores of the skip epilogues (dx, 1/8 of that kernel's traffic): isolated 226 -> 212 us, in the step -0.09 ms (3 of 3
+                           // interleaved pairs, 11.89 vs 11.98 ms) -- round 4, same reasoning as ST3
+#endif
 #ifndef UNCR_NTG_ST3
 #define UNCR_NTG_ST3 1     // stores of the fused pass-B epilogue only (du2 of the dz GEMM: 268 MB at N = 4 in 512-byte pieces, one third of that
                            // kernel's traffic).  Round 4: the stream probe in this access pattern moves a 2 : 1 mix at 5.0 TB/s with plain and
@@ -691,7 +698,8 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                 const int rw = row_of(ct, r);
                 const float4 v = make_float4(acc[0][ct][r], acc[1][ct][r], acc[2][ct][r], acc[3][ct][r]);
                 if (rw + 4 * kg < Cout && (!(PWS_ABL & 1) || v.x == 1.2345e-30f)) {
-                    pws_st<(UNCR_NTG_ST || (UNCR_NTG_ST2 && CT == 2) || (UNCR_NTG_ST3 && EPI == 3)) && EPI != 4, TA>((TA*)g.out + (size_t)(nco + rw) * P + loff, v);
+                    pws_st<(UNCR_NTG_ST || (UNCR_NTG_ST2 && CT == 2) || (UNCR_NTG_ST3 && EPI == 3) || (UNCR_NTG_ST4 && CT == 1 && EPI == 1) ||
+                            (UNCR_NTG_ST5 && (EPI == 5 || EPI == 6))) && EPI != 4, TA>((TA*)g.out + (size_t)(nco + rw) * P + loff, v);
                 }
             }
         }
