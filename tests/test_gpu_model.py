@@ -2,6 +2,7 @@
 reference (tests/golden/make_golden.py) and (b) with the CPU oracle on fresh seeded inputs, including one
 BASELINE-size (256x256) case, plus size-independent properties."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -538,3 +539,39 @@ def test_reference_written_checkpoint_runs_on_the_hip_path(tmp_path):
     with torch.no_grad():
         out = m.netG(dev(torch.from_numpy(g["x"])), batch_positions=dev(torch.from_numpy(g["dates"])))
     close("reference_checkpoint/eval_out", out, torch.from_numpy(g["eval_out"]))
+
+
+def test_bench_line_contract_single_gpu():
+    """The driver-facing contract of bench.py at N = 1 on a short run: ONE JSON line with the metric fields, the `roofline` object (live
+    HIP-event time of the dominant kernel, its fraction of the 8 TB/s spec AND of the measured pure-stream rate of its read : write mix),
+    the `cpu_baseline` leg on a bounded sample, the power / clock sampling of the timed steps and the bf16-storage leg (BASELINE config
+    3's per-GPU figure) as a sub-object of the fp32 headline line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "60", "--warmup", "3", "--size", "128", "--batch-per-gpu", "2"]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("UNCR_BENCH")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 60 and d["dtype"] == "f32" and d["vs_baseline"] is None and d["value"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and 0.0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["unit"] in ("GB/s", "TFLOP/s") and "traffic" in rf
+    if rf["bound"] == "hbm":
+        assert 0.0 < rf["frac_of_stream_roof"] < 1.5 and 5000 < rf["stream_roof_gbs_for_this_mix"] < 7200
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    pw = d["power"]
+    assert pw["power_cap_w"] is None or pw["power_cap_w"] > 500
+    if pw["samples"]:
+        assert 100 < pw["avg_power_w"] < 1500 and 500 < pw["avg_sclk_mhz"] <= 2500
+    b = d["bf16"]
+    assert "error" not in b, b
+    assert b["dtype"] == "bf16" and b["value"] > 0 and b["ms_per_step"] > 0 and b["roofline"]["kernel"]
