@@ -228,6 +228,13 @@ int uncr_se_mlp_fwd(const float* pool_part, int NP, int N, int C, int R, int P, 
 int uncr_se_mlp_bwd(const float* G, const float* Wpw, int N, int Co, int C, int R, int P, const float* W1,
                     const float* W2, const float* s, const float* pooled, const float* hid_pre, float* ds_pre,
                     float* dhid_pre, float* dpool_px, float* dWpw, float* dW1, float* dW2, hipStream_t stream);
+/* dWpw / dW1 / dW2 all null: only the per-frame phase runs (ds_pre, dhid_pre, dpool_px); the weight gradients are then taken by
+ * uncr_mbconv_param_grads together with the depthwise weight gradient -- ONE launch for the parameter-gradient reductions of an MBConv
+ * backward that sit on no critical path (dw_part: uncr_dw_bwd's per-tile partials [N*Cdw][NPT][9] -> dwdw [Cdw][9], as
+ * uncr_dw_wgrad_reduce). */
+int uncr_mbconv_param_grads(const float* G, int N, int Co, int C, int R, const float* s, const float* pooled,
+                            const float* hid_pre, const float* ds_pre, const float* dhid_pre, float* dWpw, float* dW1,
+                            float* dW2, const float* dw_part, int Cdw, int NPT, float* dwdw, hipStream_t stream);
 
 /* ---- L-TAE low-resolution branch (uncrtaints.py:403-404 max-pool; ltae.py:197-239 LTAE2dtiny;
  *      positional_encoding.py:5-31; ltae.py:341-385,431-458 attention) ---- */

@@ -170,8 +170,78 @@ extern "C" int uncr_se_mlp_bwd(const float* G, const float* Wpw, int N, int Co, 
     hipLaunchKernelGGL(se_mlp_bwd_frame_kernel, dim3(N), dim3(1024), (size_t)C * (R + 1) * sizeof(float), stream, G, Wpw, Co, C, R, P,
                        W1, W2, s, hid_pre, ds_pre, dhid_pre, dpool_px);
     UNCR_LAUNCH_CHECK();
+    if (!dWpw && !dW1 && !dW2) return UNCR_OK;      // the weight gradients follow later, in uncr_mbconv_param_grads
     hipLaunchKernelGGL(se_wgrad_kernel, dim3(Co + R), dim3(256), 0, stream, G, N, Co, C, R, s, pooled, hid_pre,
                        ds_pre, dhid_pre, dWpw, dW1, dW2);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+// The parameter-gradient reductions of one MBConv backward that sit on no critical path, in ONE launch (round 4: were two, 5 us each
+// plus a launch boundary, six times per step): blocks [0, Co + R) = se_wgrad_kernel's (dW of pw2 from the per-frame products, the two
+// SE weight gradients), blocks [Co + R, Co + R + Cdw) = the depthwise weight gradient dWdw[c][tap] from dw_bwd's per-tile partials
+// (dwconv.hip::dw_wgrad_reduce_kernel's arithmetic: fp64, the same 7-slice fixed order).
+__global__ __launch_bounds__(256) void mbconv_param_grads_kernel(const float* __restrict__ G, int N, int Co, int C, int R,
+                                                                 const float* __restrict__ s, const float* __restrict__ pooled,
+                                                                 const float* __restrict__ hid_pre, const float* __restrict__ ds_pre,
+                                                                 const float* __restrict__ dhid_pre, float* __restrict__ dWpw,
+                                                                 float* __restrict__ dW1, float* __restrict__ dW2,
+                                                                 const float* __restrict__ dw_part, int Cdw, int NPT,
+                                                                 float* __restrict__ dwdw) {
+    const int b = blockIdx.x;
+    if (b < Co + R) {           // block-uniform
+        const int c = threadIdx.x;
+        if (c >= C) return;
+        if (b < Co) {
+            double a = 0.0;
+            for (int n = 0; n < N; ++n) a += (double)s[n * C + c] * (double)G[((size_t)n * Co + b) * C + c];
+            dWpw[b * C + c] = (float)a;
+        } else {
+            const int j = b - Co;
+            double a = 0.0, bb = 0.0;
+            for (int n = 0; n < N; ++n) {
+                a += (double)dhid_pre[n * R + j] * (double)pooled[n * C + c];
+                bb += (double)ds_pre[n * C + c] * (double)gelu_f(hid_pre[n * R + j]);
+            }
+            dW1[j * C + c] = (float)a;
+            dW2[c * R + j] = (float)bb;
+        }
+        return;
+    }
+    const int c = b - (Co + R), lane = threadIdx.x;
+    const int tap = lane % 9, sl = lane / 9;           // 7 slices x 9 taps = 63 lanes
+    __shared__ double comb[7][9];
+    if (lane < 63) {
+        const int cnt = N * NPT;
+        const int i1 = (cnt * (sl + 1)) / 7;
+        int i = (cnt * sl) / 7;
+        double acc = 0.0;
+        auto at = [&](int q) {
+            const int n = q / NPT, j = q - n * NPT;
+            return dw_part[(((size_t)n * Cdw + c) * NPT + j) * 9 + tap];
+        };
+        for (; i + 4 <= i1; i += 4) {
+            const float v0 = at(i), v1 = at(i + 1), v2 = at(i + 2), v3 = at(i + 3);
+            acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+        }
+        for (; i < i1; ++i) acc += (double)at(i);
+        comb[sl][tap] = acc;
+    }
+    __syncthreads();
+    if (lane < 9) {
+        double acc = 0.0;
+        for (int q = 0; q < 7; ++q) acc += comb[q][lane];
+        dwdw[c * 9 + lane] = (float)acc;
+    }
+}
+
+extern "C" int uncr_mbconv_param_grads(const float* G, int N, int Co, int C, int R, const float* s, const float* pooled,
+                                       const float* hid_pre, const float* ds_pre, const float* dhid_pre, float* dWpw, float* dW1,
+                                       float* dW2, const float* dw_part, int Cdw, int NPT, float* dwdw, hipStream_t stream) {
+    if (C > 256 || R > 64 || N <= 0 || Co <= 0 || Cdw <= 0 || NPT <= 0) return UNCR_ESHAPE;
+    if (!G || !s || !pooled || !hid_pre || !ds_pre || !dhid_pre || !dWpw || !dW1 || !dW2 || !dw_part || !dwdw) return UNCR_EINVAL;
+    hipLaunchKernelGGL(mbconv_param_grads_kernel, dim3(Co + R + Cdw), dim3(256), 0, stream, G, N, Co, C, R, s, pooled, hid_pre, ds_pre,
+                       dhid_pre, dWpw, dW1, dW2, dw_part, Cdw, NPT, dwdw);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -686,8 +686,10 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     ds_pre, dhid_pre, dpool = _f32((N, Ch), dev), _f32((N, R), dev), _f32((N * Ch,), dev)
     dW2, dse1, dse2 = _f32((C, Ch), dev), _f32((R, Ch), dev), _f32((Ch, R), dev)
     w2 = p["w2"].reshape(C, Ch).contiguous()
+    # (per-frame phase only: dpool is what the dz GEMM waits for; dW2 and the SE weight gradients are reduced further down, in one
+    # launch with the depthwise weight gradient -- uncr_mbconv_param_grads)
     hb.call("uncr_se_mlp_bwd", G, w2, N, C, Ch, R, P, p["se1"].contiguous(), p["se2"].contiguous(), sv["s"],
-            sv["pooled"], sv["hid_pre"], ds_pre, dhid_pre, dpool, dW2, dse1, dse2, _stream())
+            sv["pooled"], sv["hid_pre"], ds_pre, dhid_pre, dpool, None, None, None, _stream())
     g["w2"], g["se1"], g["se2"] = dW2.view_as(p["w2"]), dse1, dse2
 
     # dz = W2^T dh3 ; du2 = gelu'(u2) * (s*dz + dpool) (in place) with stats (sum du2, sum du2*h2)
@@ -716,8 +718,9 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     hb.call("uncr_dw_bwd", du2, h2, h1, b2.c1, b2.c2, b2.c3, b2.mu, n1.A, n1.B, wdw, du1, part1.buf, dw_part, n1.mean,
             n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, H, W, dt, _DW_VARIANT, du1_amax, _stream())
     dwdw = _f32((Ch, 9), dev)
-    with side_chain(dw_part):          # feeds a parameter gradient only: next to the pw1 weight-gradient GEMM
-        hb.call("uncr_dw_wgrad_reduce", dw_part, N, Ch, slots, dwdw, _stream())
+    with side_chain(dw_part):          # feeds parameter gradients only: next to the pw1 weight-gradient GEMM
+        hb.call("uncr_mbconv_param_grads", G, N, C, Ch, R, sv["s"], sv["pooled"], sv["hid_pre"], ds_pre, dhid_pre, dW2, dse1, dse2,
+                dw_part, Ch, slots, dwdw, _stream())
     g["wdw"] = dwdw.view_as(p["wdw"])
     b1 = norm_bwd(part1, N, Ch, P, n1, p["n1w"], centered=True)
     g["n1w"], g["n1b"] = b1.dgamma, b1.dbeta
