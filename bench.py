@@ -542,8 +542,22 @@ def main():
     dt = time.perf_counter() - t0
     power_summary = None
     if power is not None:
-        power.stop()
-        power_summary = power.summary(t0, t0 + dt)
+        if dt < 2.5:
+            # a short timed region (the driver's --steps 20 is a quarter of a second) holds no rocm-smi sample: the same step is
+            # replayed UNTIMED for about three more seconds for the power / clock reading only (not part of `value`)
+            n_extra = int(3.0 / max(dt / args.steps, 1e-4)) + 1
+            tp0 = time.perf_counter()
+            for _ in range(n_extra):
+                loss = step()
+            fence()
+            tp1 = time.perf_counter()
+            power.stop()
+            power_summary = power.summary(tp0, tp1)
+            power_summary["sampled_over"] = f"{n_extra} further untimed replays of the same step behind the timed region ({dt:.2f} s is shorter than the sampler's settling time)"
+        else:
+            power.stop()
+            power_summary = power.summary(t0, t0 + dt)
+            power_summary["sampled_over"] = "the timed steps"
     hb.set_profiler(None)
     coll_wait = dp.wait_ms() if dp is not None else []
     eager_ms = None
