@@ -541,21 +541,29 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     power_summary = None
+    # a short timed region (the driver's --steps 20 is a quarter of a second) holds no rocm-smi sample: the same step is replayed
+    # UNTIMED for about three more seconds for the power / clock reading only (not part of `value`).  Rank 0 decides, EVERY rank
+    # replays: the steps contain the gradient all-reduces.
+    n_extra = 0
+    if power is not None and dt < 2.5:
+        n_extra = int(3.0 / max(dt / args.steps, 1e-4)) + 1
+    if dp_mode:
+        ne = torch.tensor([n_extra], device=device, dtype=torch.int64)
+        dist.broadcast(ne, src=0)
+        n_extra = int(ne.item())
+    if n_extra:
+        tp0 = time.perf_counter()
+        for _ in range(n_extra):
+            loss = step()
+        fence()
+        tp1 = time.perf_counter()
     if power is not None:
-        if dt < 2.5:
-            # a short timed region (the driver's --steps 20 is a quarter of a second) holds no rocm-smi sample: the same step is
-            # replayed UNTIMED for about three more seconds for the power / clock reading only (not part of `value`)
-            n_extra = int(3.0 / max(dt / args.steps, 1e-4)) + 1
-            tp0 = time.perf_counter()
-            for _ in range(n_extra):
-                loss = step()
-            fence()
-            tp1 = time.perf_counter()
-            power.stop()
+        power.stop()
+        if n_extra:
             power_summary = power.summary(tp0, tp1)
-            power_summary["sampled_over"] = f"{n_extra} further untimed replays of the same step behind the timed region ({dt:.2f} s is shorter than the sampler's settling time)"
+            power_summary["sampled_over"] = (f"{n_extra} further untimed replays of the same step behind the timed region ({dt:.2f} s is "
+                                             "shorter than the sampler's settling time)")
         else:
-            power.stop()
             power_summary = power.summary(t0, t0 + dt)
             power_summary["sampled_over"] = "the timed steps"
     hb.set_profiler(None)

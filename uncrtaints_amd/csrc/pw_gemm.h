@@ -73,11 +73,23 @@ typedef float f32x2v_t __attribute__((ext_vector_type(2)));
 // (a, b) -> packed fp16 pairs {lo16 = a, hi16 = b}: hi parts and lo parts.  No clamp: every caller scales its operand from a rigorous
 // bound to at most 2^15 first (weights at pack time, activations per frame), so the conversion cannot overflow on finite data; an inf /
 // NaN input (or a frame whose bound is not finite: no scaling) gives inf / NaN parts and the result is NaN, as in fp32.
+#ifndef UNCR_SPLIT_MIX
+#define UNCR_SPLIT_MIX 1      // residuals a - h on v_fma_mix_f32 (the fp16 half is widened inside the FMA): 4 instead of 6 VALU instructions per pair
+#endif
 __device__ __forceinline__ void split2_f16_pair(float a, float b, unsigned& hi, unsigned& lo) {
     const f16x2_t h = __builtin_convertvector(f32x2v_t{a, b}, f16x2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+#if UNCR_SPLIT_MIX
+    // la = fma(float(h.lo), -1, a), lb = fma(float(h.hi), -1, b): exact (a - h needs no rounding), the same bits as the two-step form.
+    // hipcc does not select v_fma_mix_f32 for this pattern (it emits v_cvt_f32_f16 x 2 + v_sub x 2): inline asm.
+    float la, lb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hi), "v"(b));
+    const f16x2_t l = __builtin_convertvector(f32x2v_t{la, lb}, f16x2_t);
+#else
     const f32x2v_t hf = __builtin_convertvector(h, f32x2v_t);
     const f16x2_t l = __builtin_convertvector(f32x2v_t{a - hf.x, b - hf.y}, f16x2_t);
-    hi = __builtin_bit_cast(unsigned, h);
+#endif
     lo = __builtin_bit_cast(unsigned, l);
 }
 #define PWS_NSLOT 5      // packed weight slots per (k-step, co tile): bf16 h, m, l and fp16 h, l (scaled)

@@ -159,12 +159,16 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         const float* p1 = g.k1 ? g.k1 + (size_t)n * Cin : g.Wt;
         const float* p2 = g.k2 ? g.k2 + (size_t)n * Cin : g.Wt;
         const float* p3 = g.k3 ? g.k3 + (size_t)n * Cin : g.Wt;
-        for (int i = tid; i < Cin; i += NT) {
-            const float a = p0[i], b = p1[i], c = p2[i];
-            cf[0][i] = g.k0 ? a : 1.f;
-            cf[1][i] = g.k1 ? b : 0.f;
-            cf[2][i] = g.k2 ? c : (PRO == PRO_AFFINE_GELU ? 1.f : 0.f);
-            if constexpr (PRO == PRO_NORMBWD) { const float m = p3[i]; cf[3][i] = g.k3 ? m : 0.f; }
+        // rows Cin .. 255 (a chunk's padding rows when Cin is not a multiple of 32) get ZERO coefficients: every prologue is linear in
+        // them, so such a row stages zeros without a select per staged element (it re-reads channel 0, finite wherever that is)
+        for (int i = tid; i < 256; i += NT) {
+            const int ii = i < Cin ? i : 0;
+            const float a = p0[ii], b = p1[ii], c = p2[ii];
+            const bool in = i < Cin;
+            cf[0][i] = in ? (g.k0 ? a : 1.f) : 0.f;
+            cf[1][i] = in ? (g.k1 ? b : 0.f) : 0.f;
+            cf[2][i] = in ? (g.k2 ? c : (PRO == PRO_AFFINE_GELU ? 1.f : 0.f)) : 0.f;
+            if constexpr (PRO == PRO_NORMBWD) { const float m = p3[ii]; cf[3][i] = (in && g.k3) ? m : 0.f; }
         }
     }
     {
@@ -223,9 +227,10 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
             const int k = kc * PWS_KC + 4 * cig + r;
             const int kk = k < Cin ? k : 0;
             valid[r] = k < Cin;
-            if constexpr (PRO != PRO_NONE) { c0[r] = cf[0][kk]; c1[r] = cf[1][kk]; c2[r] = cf[2][kk]; }
+            const int kz = k & 255;          // (k < 256 whenever the chunk holds data; padding chunks of a DEPTH-padded tile wrap harmlessly)
+            if constexpr (PRO != PRO_NONE) { c0[r] = cf[0][kz]; c1[r] = cf[1][kz]; c2[r] = cf[2][kz]; }
             if constexpr (PRO == PRO_NORMBWD) {
-                c3[r] = cf[3][kk];
+                c3[r] = cf[3][kz];
                 if constexpr (!BF) {
                     // fp32 storage: centre the second operand in place right away, so that the means are dead before the
                     // register-hungry split section (the 256-channel variants spilled 120 B per lane with four live
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                     else v = fmaf(c0[r], v, fmaf(c1[r], pws_get(pre2[PRE2 ? S : 0][r], e), c2[r]));
                 }
                 else if constexpr (PRO == PRO_AFFINE_RELU) v = fmaxf(fmaf(c0[r], v, c1[r]), 0.f);
-                if (!valid[r]) v = 0.f;
+                if constexpr (PRO == PRO_NONE) { if (!valid[r]) v = 0.f; }
                 if constexpr (BF || H2) vv[r] = v;
                 else split3_bf16(v, hh[r], mm[r], ll[r]);
             }
