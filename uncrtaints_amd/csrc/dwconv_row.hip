@@ -59,7 +59,11 @@ __device__ __forceinline__ float4 gelu4(float A, float B, const float4& h) {
 }
 __device__ __forceinline__ void gelu_both(float A, float B, float h, float& gv, float& gd) {
     const float u = fmaf(A, h, B);
+#if UNCR_GELU_DIET && !defined(UNCR_EXACT_ERF)
+    const float cdf = fmaf(copysignf(0.5f, u), 1.0f - erfc_abs_f(u * 0.70710678118654752440f), 0.5f);      // no 1 + erf, no 0.5 *
+#else
     const float cdf = 0.5f * (1.0f + erf_f(u * 0.70710678118654752440f));
+#endif
     const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * u * u);
     gv = u * cdf;
     gd = fmaf(u, pdf, cdf);
@@ -88,7 +92,8 @@ __global__ __launch_bounds__(256) void dw_fwd_row_kernel(const T* __restrict__ i
     // raw prefetch ring: DEPTH rows in flight per wave (fp32: 2; bf16: 4 -- the same bytes in flight and the same registers)
     constexpr int DEPTH = sizeof(T) == 2 ? DWR_DEPTH_BF : 2;
     typedef typename raw4<T>::type RawT;
-    auto ldr = [&](int yy) { return ld4raw<T, (UNCR_NT != 0)>(src + (size_t)min(max(yy, 0), H - 1) * W); };
+    // rows outside the image are fetched through the reflect map itself (row H -> row H-2, a cache hit): no select in the row loop
+    auto ldr = [&](int yy) { return ld4raw<T, (UNCR_NT != 0)>(src + (size_t)min(max(reflect1(yy, H), 0), H - 1) * W); };
     auto ld = [&](int yy) { return widen4(ldr(yy)); };
 
     // 4-slot ring of g rows (row y lives in slot (y - y0) & 3), the row loop unrolled x4 so that every slot index is
@@ -106,11 +111,8 @@ __global__ __launch_bounds__(256) void dw_fwd_row_kernel(const T* __restrict__ i
             const int y = Y + s;
             constexpr int dummy = 0; (void)dummy;
             const int im = (s + 3) & 3, ic = s, ip = (s + 1) & 3;
-            // row y+1 (reflect at the bottom edge: row H -> row H-2 = the ring's row y-1)
-            const Row6 gnew = row6_reflect(gelu4(A, B, widen4(nx[s % DEPTH])));
-            const bool inside = y + 1 < H;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) gW[ip].v[k] = inside ? gnew.v[k] : gW[im].v[k];
+            // row y+1 (at the bottom edge the loader fetched row H-2 for row H)
+            gW[ip] = row6_reflect(gelu4(A, B, widen4(nx[s % DEPTH])));
             nx[s % DEPTH] = ldr(y + 1 + DEPTH);
             float o[4];
 #pragma unroll
@@ -175,21 +177,25 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     constexpr int DEPTH = sizeof(T) == 2 ? DWR_DEPTH_BF : 2;      // rows in flight per wave, see the forward kernel
     typedef typename raw4<T>::type RawT;
     struct Raw3 { RawT a, b, h; };
+    // du2 / h2 rows outside the image are clamped (their dh2 is zeroed through the coefficients), h1 rows go through the reflect
+    // map (row H -> row H-2, a cache hit): no per-value select in the row loop
     auto ldr = [&](int yy) {
         const size_t o = pb + (size_t)min(max(yy, 0), H - 1) * W;
-        return Raw3{ld4raw<T, (UNCR_NT != 0)>(du2 + o), ld4raw<T, (UNCR_NT != 0)>(h2 + o), ld4raw<T, (UNCR_NT != 0)>(h1 + o)};
+        const size_t oh = pb + (size_t)min(max(reflect1(yy, H), 0), H - 1) * W;
+        return Raw3{ld4raw<T, (UNCR_NT != 0)>(du2 + o), ld4raw<T, (UNCR_NT != 0)>(h2 + o), ld4raw<T, (UNCR_NT != 0)>(h1 + oh)};
     };
     auto wide = [&](const Raw3& r) { return Raw{widen4(r.a), widen4(r.b), widen4(r.h)}; };
     auto ld = [&](int yy) { return wide(ldr(yy)); };
-    auto dh2 = [&](const Raw& r, int yy) {   // zero outside the image
-        const float m = (yy >= 0 && yy < H) ? 1.f : 0.f;
+    auto dh2 = [&](const Raw& r, int yy) {   // zero outside the image: the (wave-uniform) coefficients are zeroed, not the values
+        const bool in_img = yy >= 0 && yy < H;
+        const float c1 = in_img ? C1 : 0.f, c2 = in_img ? C2 : 0.f, c3 = in_img ? C3 : 0.f;
 #if DWR_PK
-        const f32x2 lo = f2(m) * fma2(f2(C1), f2(r.a.x, r.a.y), fma2(f2(C2), f2(r.b.x, r.b.y) - f2(M2), f2(C3)));
-        const f32x2 hi = f2(m) * fma2(f2(C1), f2(r.a.z, r.a.w), fma2(f2(C2), f2(r.b.z, r.b.w) - f2(M2), f2(C3)));
+        const f32x2 lo = fma2(f2(c1), f2(r.a.x, r.a.y), fma2(f2(c2), f2(r.b.x, r.b.y) - f2(M2), f2(c3)));
+        const f32x2 hi = fma2(f2(c1), f2(r.a.z, r.a.w), fma2(f2(c2), f2(r.b.z, r.b.w) - f2(M2), f2(c3)));
         return make_float4(lo.x, lo.y, hi.x, hi.y);
 #endif
-        return make_float4(m * fmaf(C1, r.a.x, fmaf(C2, r.b.x - M2, C3)), m * fmaf(C1, r.a.y, fmaf(C2, r.b.y - M2, C3)),
-                           m * fmaf(C1, r.a.z, fmaf(C2, r.b.z - M2, C3)), m * fmaf(C1, r.a.w, fmaf(C2, r.b.w - M2, C3)));
+        return make_float4(fmaf(c1, r.a.x, fmaf(c2, r.b.x - M2, c3)), fmaf(c1, r.a.y, fmaf(c2, r.b.y - M2, c3)),
+                           fmaf(c1, r.a.z, fmaf(c2, r.b.z - M2, c3)), fmaf(c1, r.a.w, fmaf(c2, r.b.w - M2, c3)));
     };
 
     auto both4 = [&](const float4& h, float4& gv, float4& gd) {
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     {
         const Raw q = ld(y0 - 1);
         dW[3] = row6_zero(dh2(q, y0 - 1));
-        gW[3] = row6_reflect(gelu4(A1, B1, q.h));          // g1(y0-1); for y0 == 0 replaced below by g1(1)
+        gW[3] = row6_reflect(gelu4(A1, B1, q.h));          // g1(y0-1); for y0 == 0 the loader fetched row 1
         const Raw q0 = ld(y0);
         dW[0] = row6_zero(dh2(q0, y0));
         float4 gv;
@@ -222,10 +228,19 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) nx[d] = ldr(y0 + 1 + d);
-    const bool l0 = lane == 0, l63 = lane == 63;
+    // Padding COLUMNS folded back (reflect adjoint): column -1 lands on column 1 (lane 0, j = 1), column W on column W-2 (lane 63,
+    // j = 2).  Both are one more tap on a value the stencil already multiplies -- d(., 0) for j = 1, d(., W-1) for j = 2 -- so the
+    // fold is a per-lane weight: w[ty][2] + w[ty][0] on lane 0, w[ty][0] + w[ty][2] on lane 63, the plain weight elsewhere.
+    float w2e[3], w0e[3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+        w2e[ty] = wk[3 * ty + 2] + (lane == 0 ? wk[3 * ty] : 0.f);
+        w0e[ty] = wk[3 * ty] + (lane == 63 ? wk[3 * ty + 2] : 0.f);
+    }
+    auto wt = [&](int ty, int tx, int j) { return (j == 1 && tx == 2) ? w2e[ty] : (j == 2 && tx == 0) ? w0e[ty] : wk[3 * ty + tx]; };
 
     float s0 = 0.f, s1 = 0.f, gw[9];
-    float am = 0.f;
+    unsigned am = 0u;       // AMAX: max |du1| as bit patterns (non-negative floats order like integers; a NaN is the largest and stays)
 #pragma unroll
     for (int i = 0; i < 9; ++i) gw[i] = 0.f;
     for (int Y = y0; Y < y1; Y += 4) {                     // (y1 - y0) % 4 == 0 (launcher: H % 4 == 0)
@@ -238,11 +253,7 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
             float4 gvn;
             both4(cur.h, gvn, qW[ip]);
             hW[ip] = cur.h;
-            const Row6 gnew = row6_reflect(gvn);
-            const bool inside = y + 1 < H;                 // reflect: row H -> row H-2
-#pragma unroll
-            for (int k = 0; k < 6; ++k) gW[ip].v[k] = inside ? gnew.v[k] : gW[im].v[k];
-            if (s == 0 && y == 0) gW[im] = gW[ip];         // reflect: row -1 -> row 1 (wave-uniform, registers only)
+            gW[ip] = row6_reflect(gvn);                    // (row H: the loader fetched row H-2)
             nx[s % DEPTH] = ldr(y + 1 + DEPTH);
             const Row6 &dm = dW[im], &dc = dW[ic], &dp = dW[ip], &gm = gW[im], &gc = gW[ic], &gp = gW[ip];
 
@@ -258,29 +269,21 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
                 float a = 0.f;
 #pragma unroll
                 for (int tx = 0; tx < 3; ++tx) {
-                    a = fmaf(wk[tx], dp.v[j + 2 - tx], a);
-                    a = fmaf(wk[3 + tx], dc.v[j + 2 - tx], a);
-                    a = fmaf(wk[6 + tx], dm.v[j + 2 - tx], a);
+                    a = fmaf(wt(0, tx, j), dp.v[j + 2 - tx], a);
+                    a = fmaf(wt(1, tx, j), dc.v[j + 2 - tx], a);
+                    a = fmaf(wt(2, tx, j), dm.v[j + 2 - tx], a);
                 }
                 res[j] = a;
             }
-            if (ry0 || ry1) {   // wave-uniform and rare; arithmetic only: the padding rows folded back onto rows 1 / H-2
+            if (ry0 || ry1) {   // wave-uniform and rare; arithmetic only: the padding ROWS folded back onto rows 1 / H-2 (corners
+                                // included through the per-lane weights)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int tx = 0; tx < 3; ++tx) {
-                        res[j] = fmaf(f0 * wk[tx], dm.v[j + 2 - tx], res[j]);
-                        res[j] = fmaf(f1 * wk[6 + tx], dp.v[j + 2 - tx], res[j]);
+                        res[j] = fmaf(f0 * wt(0, tx, j), dm.v[j + 2 - tx], res[j]);
+                        res[j] = fmaf(f1 * wt(2, tx, j), dp.v[j + 2 - tx], res[j]);
                     }
-            }
-            // padding columns folded back onto columns 1 (lane 0, j = 1) and W-2 (lane 63, j = 2), corners included
-            {
-                float e0 = fmaf(wk[0], dp.v[1], fmaf(wk[3], dc.v[1], wk[6] * dm.v[1]));
-                e0 = fmaf(f0 * wk[0], dm.v[1], fmaf(f1 * wk[6], dp.v[1], e0));
-                float e1 = fmaf(wk[2], dp.v[4], fmaf(wk[5], dc.v[4], wk[8] * dm.v[4]));
-                e1 = fmaf(f0 * wk[2], dm.v[4], fmaf(f1 * wk[8], dp.v[4], e1));
-                res[1] += l0 ? e0 : 0.f;
-                res[2] += l63 ? e1 : 0.f;
             }
             float4 o = rnd4<T>(make_float4(pq[0] * res[0], pq[1] * res[1], pq[2] * res[2], pq[3] * res[3]));   // as stored
             float* po = (float*)&o;
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
                 const float dv = po[j];
                 s0 += dv;
                 s1 = fmaf(dv, ph[j] - M1, s1);
-                if constexpr (AMAX) am = fabsf(dv) > am || !(dv == dv) ? fabsf(dv) : am;      // (a NaN stays)
+                if constexpr (AMAX) am = max(am, __float_as_uint(dv) & 0x7FFFFFFFu);
                 // depthwise weight gradient: dh2 at (y, x) times g1 at the reflect-padded neighbours
                 const float dcj = dc.v[j + 1];
 #pragma unroll
@@ -311,10 +314,11 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
             const int sl = Y >> 4;                          // y0 is a multiple of 16
             float ra = 0.f;
             if constexpr (AMAX) {
-                ra = am;
+                unsigned ru = am;
 #pragma unroll
-                for (int sft = 32; sft >= 1; sft >>= 1) { const float o = __shfl_xor(ra, sft, 64); ra = o > ra || !(o == o) ? o : ra; }
-                am = 0.f;
+                for (int sft = 32; sft >= 1; sft >>= 1) ru = max(ru, (unsigned)__shfl_xor((int)ru, sft, 64));
+                ra = __uint_as_float(ru);
+                am = 0u;
             }
             if (lane == 63 && sl < slots) {
                 const size_t slot = (size_t)plane * slots + sl;

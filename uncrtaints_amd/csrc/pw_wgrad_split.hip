@@ -79,6 +79,9 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xs = smem;                           // [2][BUF]
+#ifdef WGS_STAMP
+    const unsigned long long ts0 = __builtin_readcyclecounter();       // development: per-block phase stamps, see the kernel's end
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -185,6 +188,9 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
         }
     };
 
+#ifdef WGS_STAMP
+    const unsigned long long ts1 = __builtin_readcyclecounter();       // coefficients + bounds done
+#endif
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -315,6 +321,9 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
 #undef WGS_SB
     }
 
+#ifdef WGS_STAMP
+    const unsigned long long ts2 = __builtin_readcyclecounter();       // chunk loop done
+#endif
     float* po = g.part + ((size_t)n * gridDim.x + blockIdx.x) * COP * CIP;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -328,6 +337,15 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
                 if constexpr (H2) v = v * rsc[co] * rsc[COP + ci];      // powers of two: exact
                 po[co * CIP + ci] = v;
             }
+#ifdef WGS_STAMP
+    __builtin_amdgcn_s_waitcnt(0);       // stores acknowledged
+    __syncthreads();
+    if (tid == 0) {   // (overwrites the first values of this block's partial: timing builds only)
+        const unsigned long long ts3 = __builtin_readcyclecounter();
+        po[0] = (float)(ts1 - ts0); po[1] = (float)(ts2 - ts1); po[2] = (float)(ts3 - ts2); po[3] = (float)nc;
+        po[4] = (float)(ts0 & 0xFFFFFF); po[5] = (float)(ts3 & 0xFFFFFF);
+    }
+#endif
 }
 
 static int wgs_ncu() {
