@@ -13,7 +13,10 @@ from uncrtaints_amd import hip_backend as hb  # noqa: E402
 MODES = {0: ("read_only", 1, 0), 1: ("write_only", 0, 1), 2: ("copy_1r_1w", 1, 1), 3: ("2r_1w", 2, 1), 4: ("1r_2w", 1, 2),
          5: ("3r_1w", 3, 1),
          # the same bytes in the plane-tiled GEMMs' access pattern: 512-byte pieces of 256-row groups, 256 KB apart, persistent blocks
-         6: ("tiled512B_2r_1w", 2, 1), 7: ("tiled512B_2r_0w", 2, 0), 8: ("tiled512B_16r_1w", 2, 0.125)}
+         6: ("tiled512B_2r_1w", 2, 1), 7: ("tiled512B_2r_0w", 2, 0), 8: ("tiled512B_16r_1w", 2, 0.125),
+         # the weight-gradient kernels' pattern: one 512-thread block per CU walks a pixel range of a 512-row frame, reading 128 / 256 /
+         # 512-byte pieces of every row per visit
+         9: ("rows128B_1r_0w", 1, 0), 10: ("rows256B_1r_0w", 1, 0), 11: ("rows512B_1r_0w", 1, 0)}
 
 
 def main(out_path):
@@ -22,10 +25,12 @@ def main(out_path):
     bufs = [torch.empty(n, device="cuda", dtype=torch.float32).normal_() for _ in range(5)]
     s = torch.cuda.current_stream().cuda_stream
     res = {"n_bytes_per_stream": n * 4, "method": __doc__.strip().splitlines()[-2].strip(), "cases": []}
-    for blocks in (512, 2048, 8192):
+    only = sys.argv[2].split(",") if len(sys.argv) > 2 else None       # optional: comma-separated mode names
+    for blocks in (256, 512, 2048, 8192):
         for nt in (0, 1):
             for mode, (name, nr, nw) in MODES.items():
-                if (mode >= 6) != (blocks == 512):       # the tiled patterns run on the GEMMs' persistent grid (two blocks per CU)
+                # the tiled patterns run on the GEMMs' persistent grid (two blocks per CU), the rows patterns on the weight gradient's (one)
+                if (blocks == 256) != (mode >= 9) or (mode in (6, 7, 8)) != (blocks == 512) or (only and name not in only):
                     continue
                 def run():
                     rc = dev.fn["uncr_debug_stream_probe"](*[b.data_ptr() for b in bufs], n, mode, nt, blocks, s)

@@ -203,9 +203,46 @@ __global__ __launch_bounds__(256) void stream_tile_probe_kernel(const float* __r
     if (keep.x + keep.y + keep.z + keep.w == 1.2345e-30f) x[0] = keep.x;
 }
 
+// the weight-gradient kernels' pattern, read only: one 512-thread block per CU owns a contiguous pixel range of a 512-row frame and
+// walks it in visits of PW pixels; a visit reads PW * 4 BYTES of every row (rows 256 KB apart), eight float4 per thread in flight.
+// PW = 32 is what pw_wgrad_split.hip does (128-byte pieces); 64 / 128 ask what wider pieces would buy.
+template <int PW, bool NT>
+__global__ __launch_bounds__(512, 1) void stream_rows_probe_kernel(const float* __restrict__ a, float* __restrict__ x, int frames) {
+    constexpr int PP = 65536, R = 512, TPR = PW / 4, RPI = 512 / TPR, NPIECE = R / RPI;
+    const int nbx = gridDim.x / frames, n = blockIdx.x / nbx, bx = blockIdx.x % nbx;
+    const int p0 = (int)((long long)bx * PP / nbx), p1 = (int)((long long)(bx + 1) * PP / nbx);
+    const int lrow = threadIdx.x / TPR, c4 = (threadIdx.x % TPR) * 4;
+    const float* base = a + ((size_t)n * R + lrow) * PP + c4;
+    float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = p0; p < p1; p += PW) {
+#pragma unroll 1
+        for (int i0 = 0; i0 < NPIECE; i0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld4<float, NT>(base + (size_t)((i0 + u) * RPI) * PP + p);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { keep.x += v[u].x; keep.y += v[u].y; keep.z += v[u].z; keep.w += v[u].w; }
+        }
+    }
+    if (keep.x + keep.y + keep.z + keep.w == 1.2345e-30f) x[0] = keep.x;
+}
+
 extern "C" int uncr_debug_stream_probe(const float* a, const float* b, const float* c, float* x, float* y, long long n_floats,
                                        int mode, int nt, int blocks, hipStream_t stream) {
-    if (n_floats <= 0 || n_floats % 4 || blocks <= 0 || mode < 0 || mode > 8) return UNCR_ESHAPE;
+    if (n_floats <= 0 || n_floats % 4 || blocks <= 0 || mode < 0 || mode > 11) return UNCR_ESHAPE;
+    if (mode >= 9) {      // rows pattern: frames of 512 rows x 65536, `blocks` a multiple of the frame count
+        const int frames = (int)(n_floats / (65536LL * 512));
+        if (frames < 1 || blocks % frames) return UNCR_ESHAPE;
+#define SR_LAUNCH(M, PW)                                                                                                      \
+        case M:                                                                                                               \
+            if (nt) hipLaunchKernelGGL((stream_rows_probe_kernel<PW, true>), dim3(blocks), dim3(512), 0, stream, a, x, frames);  \
+            else hipLaunchKernelGGL((stream_rows_probe_kernel<PW, false>), dim3(blocks), dim3(512), 0, stream, a, x, frames);   \
+            break;
+        switch (mode) { SR_LAUNCH(9, 32) SR_LAUNCH(10, 64) SR_LAUNCH(11, 128) }
+#undef SR_LAUNCH
+        UNCR_LAUNCH_CHECK();
+        return UNCR_OK;
+    }
     if (mode >= 6) {
         if (n_floats % (65536LL * 256)) return UNCR_ESHAPE;
         const int rows = (int)(n_floats / 65536);

@@ -23,6 +23,14 @@
 #include "pw_gemm.h"
 #include <type_traits>
 
+#ifndef WGS_PF
+#define WGS_PF 1       // raw chunks in flight per thread in the fp16-split kernel (1 | 2).  2 (254 VGPRs, no spill): 146 -> 138 us per
+                       // launch in isolation at N = 4, 390 -> 386 at N = 12, the training step unchanged (4 + 3 interleaved pairs)
+#endif
+#ifndef WGS_ABL
+#define WGS_ABL 0      // development ablations (timing only, results wrong): 1 no global loads after the first two chunks, 2 no MFMA,
+#endif                 // 4 no staging (prologue arithmetic, split, LDS writes) after the first chunk
+
 struct WgsArgs {
     const float* d;
     const float* d2;
@@ -146,22 +154,31 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
         }
     }
 
-    float4 dv[ND], dv2[D2 ? ND : 1], xv[NX];
-    auto load_piece = [&](int i, int ch) {   // i compile-time after unrolling; ch clamped by the caller
+    // raw chunks in flight (registers): PF sets (WGS_PF; the exact-split kernels have no registers left for a second one)
+    constexpr int PF = H2 ? WGS_PF : 1;
+    float4 dv[PF][ND], dv2[PF][D2 ? ND : 1], xv[PF][NX];
+    bool abl_first = true;
+    auto load_piece = [&](int i, int ch, int set = 0) {   // i, set compile-time after unrolling; ch clamped by the caller
+        if ((WGS_ABL & 1) && !abl_first) return;
         const size_t po = (size_t)(cbeg + ch) * 32;
         if (i < ND) {
-            dv[i] = ld_nt4(dbase + (size_t)(64 * i) * P + po);
-            if constexpr (D2) dv2[i] = ld_nt4(d2base + (size_t)(64 * i) * P + po);
+            dv[set][i] = ld_nt4(dbase + (size_t)(64 * i) * P + po);
+            if constexpr (D2) dv2[set][i] = ld_nt4(d2base + (size_t)(64 * i) * P + po);
         } else {
-            xv[i - ND] = ld_nt4(xbase + (size_t)(64 * (i - ND)) * P + po);
+            xv[set][i - ND] = ld_nt4(xbase + (size_t)(64 * (i - ND)) * P + po);
         }
     };
-    auto stage_piece = [&](int i, int buf) {
+    auto stage_piece = [&](int i, int buf, int set = 0) {
+        if ((WGS_ABL & 4) && !abl_first) return;
         const bool isd = i < ND;
         const int row = isd ? lrow + 64 * i : COP + lrow + 64 * (i - ND);
         const float c0 = k0[i], c1 = k1[i], c2 = k2[i];
-        const float4 v = isd ? dv[i] : xv[i - ND];
-        const float4 w = (isd && D2) ? dv2[D2 ? i : 0] : v;
+        float4 v = isd ? dv[set][i] : xv[set][i - ND];
+        float4 w = (isd && D2) ? dv2[set][D2 ? i : 0] : v;
+        if (WGS_ABL & 1) {      // keep the arithmetic inside the loop although its inputs no longer change
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+            asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(w.z), "+v"(w.w));
+        }
         unsigned char* b = xs + buf * BUF + st_off + (row - lrow) * 16;
         if constexpr (H2) {
             unsigned hh[2], ll[2];
@@ -212,8 +229,13 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
 #pragma unroll
     for (int i = 0; i < ND + NX; ++i) load_piece(i, 0);
 #pragma unroll
-    for (int i = 0; i < ND + NX; ++i) { stage_piece(i, 0); load_piece(i, nc > 1 ? 1 : 0); }
+    for (int i = 0; i < ND + NX; ++i) {
+        stage_piece(i, 0);
+        if constexpr (PF == 2) { load_piece(i, nc > 1 ? 1 : 0, 1); load_piece(i, nc > 2 ? 2 : nc - 1, 0); }
+        else load_piece(i, nc > 1 ? 1 : 0);
+    }
     __syncthreads();
+    abl_first = false;
 
     // rolling operands (ah, am, bh re-read in place after their last use) and double-buffered single-use ones
     u32x4_t ah[2], am[2], bh[2], al[2][2], bl[2][2], bm[2][2];
@@ -221,27 +243,29 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
         // parts: 0 = high, 1 = low.  Products per k-step: ah*bl, ah*bh, al*bh; two staging pieces ride behind each in k-step 0.
         ldop(0, 0, 0, aoff, ah); ldop(0, 0, 0, boff, bh); ldop(0, 0, 1, aoff, al[0]); ldop(0, 0, 1, boff, bl[0]);
 #define WGS_MFH(A, B)                                                                                            \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)                  \
+    if (!(WGS_ABL & 2)) _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)  \
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, A[a]),                    \
                                                            __builtin_bit_cast(f16x8_t, B[b]), acc[a][b], 0, 0, 0)
 #define WGS_SBH() __builtin_amdgcn_sched_barrier(0)
-        for (int c = 0; c < nc; ++c) {
-            const int cur = c & 1;
-            const int c2 = c + 2 < nc ? c + 2 : nc - 1;
+        // SET: the register set holding raw chunk c+1 (PF == 2: (c + 1) & 1, the loop is unrolled over chunk pairs so that it is static)
+        auto body = [&](int c, auto SETC) {
+            constexpr int SET = decltype(SETC)::value;
+            const int cur = PF == 2 ? (SET ^ 1) : (c & 1);
+            const int c2 = c + 1 + PF < nc ? c + 1 + PF : nc - 1;
             WGS_MFH(ah, bl[0]); WGS_SBH();
             ldop(cur, 1, 1, aoff, al[1]); ldop(cur, 1, 1, boff, bl[1]);
-            if (0 < ND + NX) { stage_piece(0, cur ^ 1); load_piece(0, c2); }
-            if (1 < ND + NX) { stage_piece(1, cur ^ 1); load_piece(1, c2); }
+            if (0 < ND + NX) { stage_piece(0, cur ^ 1, SET); load_piece(0, c2, SET); }
+            if (1 < ND + NX) { stage_piece(1, cur ^ 1, SET); load_piece(1, c2, SET); }
             WGS_SBH();
             WGS_MFH(ah, bh); WGS_SBH();
             ldop(cur, 1, 0, aoff, ah);
-            if (2 < ND + NX) { stage_piece(2, cur ^ 1); load_piece(2, c2); }
-            if (3 < ND + NX) { stage_piece(3, cur ^ 1); load_piece(3, c2); }
+            if (2 < ND + NX) { stage_piece(2, cur ^ 1, SET); load_piece(2, c2, SET); }
+            if (3 < ND + NX) { stage_piece(3, cur ^ 1, SET); load_piece(3, c2, SET); }
             WGS_SBH();
             WGS_MFH(al[0], bh); WGS_SBH();
             ldop(cur, 1, 0, boff, bh);
-            if (4 < ND + NX) { stage_piece(4, cur ^ 1); load_piece(4, c2); }
-            if (5 < ND + NX) { stage_piece(5, cur ^ 1); load_piece(5, c2); }
+            if (4 < ND + NX) { stage_piece(4, cur ^ 1, SET); load_piece(4, c2, SET); }
+            if (5 < ND + NX) { stage_piece(5, cur ^ 1, SET); load_piece(5, c2, SET); }
             WGS_SBH();
             __syncthreads();
             WGS_MFH(ah, bl[1]); WGS_SBH();
@@ -253,6 +277,14 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
             WGS_MFH(al[1], bh); WGS_SBH();
             ldop(cur ^ 1, 0, 0, boff, bh);
             WGS_SBH();
+        };
+        if constexpr (PF == 2) {
+            for (int c = 0; c < nc; c += 2) {
+                body(c, std::integral_constant<int, 1>{});
+                if (c + 1 < nc) body(c + 1, std::integral_constant<int, 0>{});
+            }
+        } else {
+            for (int c = 0; c < nc; ++c) body(c, std::integral_constant<int, 0>{});
         }
 #undef WGS_MFH
 #undef WGS_SBH
@@ -261,7 +293,7 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
     ldop(0, 0, 2, aoff, al[0]); ldop(0, 0, 2, boff, bl[0]); ldop(0, 0, 1, boff, bm[0]);
 
 #define WGS_MF(A, B)                                                                                             \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)                  \
+    if (!(WGS_ABL & 2)) _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)  \
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A[a]),                  \
                                                             __builtin_bit_cast(bf16x8_t, B[b]), acc[a][b], 0, 0, 0)
 #define WGS_SB() __builtin_amdgcn_sched_barrier(0)
