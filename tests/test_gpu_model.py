@@ -456,6 +456,8 @@ def test_backward_through_the_model_in_eval_mode():
     ("widths_64", dict(encoder_widths=[64], decoder_widths=[64] * 5)),
     ("widths_96", dict(encoder_widths=[96], decoder_widths=[96] * 2)),
     ("widths_32", dict(encoder_widths=[32], decoder_widths=[32] * 2)),
+    ("widths_256", dict(encoder_widths=[256], decoder_widths=[256] * 2)),      # hidden width 512: the grouped MBConv path, any-width SE
+    ("widths_192", dict(encoder_widths=[192], decoder_widths=[192] * 2, n_head=32)),      # hidden 384: four 96-channel groups under GroupNorm(4), three under BatchNorm
     ("two_decoder_blocks", dict(decoder_widths=[128] * 2)),
     ("n_head_4", dict(n_head=4)),                           # 32 channels per head: the unfused L-TAE kernels
     ("n_head_8", dict(n_head=8)),
@@ -507,7 +509,7 @@ def test_unsupported_head_split_raises():
     with pytest.raises(NotImplementedError):
         U.UNCRTAINTS(input_dim=15, d_model=512, use_v=True)       # value projections wider than the GEMM kernels
     with pytest.raises(NotImplementedError):
-        U.UNCRTAINTS(input_dim=15, encoder_widths=[256], decoder_widths=[256] * 2)
+        U.UNCRTAINTS(input_dim=15, encoder_widths=[512], decoder_widths=[512] * 2)
     from uncrtaints_amd import engine
     with pytest.raises(NotImplementedError):          # the weight pre-pack refuses what the kernels cannot take (no OOB packing)
         engine.prepack([(torch.randn(512, 128, device=DEV), True)])

@@ -5,7 +5,7 @@
 //         dWpw[co,c] = sum_n s[n,c] G[n,co,c]  follow without another pass over the activations.
 #include "common.h"
 
-// grid = N, block = 1024 (latency-bound: 16 waves for every phase).  C <= 256, R <= 64.  Dynamic LDS: W2 staged with coalesced reads
+// grid = N, block = 1024 (latency-bound: 16 waves for every phase).  C <= 256, R <= 64 (wider: the *_any kernels further down).  Dynamic LDS: W2 staged with coalesced reads
 // ([C][R + 1] floats) so that thread c's sequential dot product -- same order as a plain row walk -- reads LDS, not 64 scattered
 // cache lines per step.
 __global__ __launch_bounds__(1024) void se_mlp_fwd_kernel(const float2* __restrict__ pool_part, int NP, int C, int R,
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__
                                                        const float* __restrict__ ds_pre,
                                                        const float* __restrict__ dhid_pre, float* __restrict__ dWpw,
                                                        float* __restrict__ dW1, float* __restrict__ dW2) {
-    const int c = threadIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;      // grid.y = ceil(C / 256)
     if (c >= C) return;
     if ((int)blockIdx.x < Co) {
         const int co = blockIdx.x;
@@ -142,6 +142,80 @@ __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__
     }
 }
 
+// ---- any width (C > 256 or R > 64: MBConv blocks wider than 128 channels) ----
+// The same arithmetic without the staging that the 256-channel kernels are tuned around: grid = N, block = 256, channels and hidden
+// units walked in strides of the block, weights read from global memory, fp64 where the kernels above use it.  Dynamic LDS:
+// [C] + [R] floats.
+__global__ __launch_bounds__(256) void se_mlp_fwd_any_kernel(const float2* __restrict__ pool_part, int NP, int C, int R, int P,
+                                                             const float* __restrict__ W1, const float* __restrict__ W2,
+                                                             float* __restrict__ pooled, float* __restrict__ hid_pre,
+                                                             float* __restrict__ s) {
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    extern __shared__ float sm[];
+    float* sp = sm;          // [C]
+    float* sh = sm + C;      // [R]
+    for (int c = tid; c < C; c += 256) {
+        const float2* src = pool_part + ((size_t)n * C + c) * NP;
+        double a = 0.0;
+        for (int j = 0; j < NP; ++j) a += (double)src[j].x;
+        const float m = (float)(a / (double)P);
+        sp[c] = m;
+        pooled[n * C + c] = m;
+    }
+    __syncthreads();
+    for (int j = wv; j < R; j += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a = fmaf(W1[j * C + c], sp[c], a);
+        a = wave_sum(a);
+        if (lane == 0) {
+            hid_pre[n * R + j] = a;
+            sh[j] = gelu_f(a);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float a = 0.f;
+        for (int j = 0; j < R; ++j) a = fmaf(W2[c * R + j], sh[j], a);
+        s[n * C + c] = sigmoid_f(a);
+    }
+}
+
+__global__ __launch_bounds__(256) void se_mlp_bwd_frame_any_kernel(
+    const float* __restrict__ G, const float* __restrict__ Wpw, int Co, int C, int R, int P, const float* __restrict__ W1,
+    const float* __restrict__ W2, const float* __restrict__ s, const float* __restrict__ hid_pre, float* __restrict__ ds_pre,
+    float* __restrict__ dhid_pre, float* __restrict__ dpool_px) {
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    extern __shared__ float sm[];
+    float* sds = sm;         // [C]
+    float* sdh = sm + C;     // [R]
+    for (int c = tid; c < C; c += 256) {
+        const float* g = G + (size_t)n * Co * C + c;
+        double a = 0.0;
+        for (int co = 0; co < Co; ++co) a += (double)Wpw[co * C + c] * (double)g[(size_t)co * C];
+        const float sv = s[n * C + c];
+        const float d = (float)a * sv * (1.f - sv);
+        sds[c] = d;
+        ds_pre[n * C + c] = d;
+    }
+    __syncthreads();
+    for (int j = wv; j < R; j += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a = fmaf(W2[c * R + j], sds[c], a);
+        a = wave_sum(a);
+        if (lane == 0) {
+            const float d = a * gelu_grad_f(hid_pre[n * R + j]);
+            sdh[j] = d;
+            dhid_pre[n * R + j] = d;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float a = 0.f;
+        for (int j = 0; j < R; ++j) a = fmaf(W1[j * C + c], sdh[j], a);
+        dpool_px[n * C + c] = a / (float)P;
+    }
+}
+
 // dynamic LDS above 64 KB (C = 256 with R = 64: 66.6 KB) needs the opt-in; done once per process
 static void se_lds_optin() {
     static bool done = false;
@@ -153,7 +227,13 @@ static void se_lds_optin() {
 
 extern "C" int uncr_se_mlp_fwd(const float* pool_part, int NP, int N, int C, int R, int P, const float* W1,
                                const float* W2, float* pooled, float* hid_pre, float* s, hipStream_t stream) {
-    if (C > 256 || R > 64 || N <= 0) return UNCR_ESHAPE;
+    if (C <= 0 || R <= 0 || N <= 0 || (size_t)(C + R) * sizeof(float) > 64 * 1024) return UNCR_ESHAPE;
+    if (C > 256 || R > 64) {
+        hipLaunchKernelGGL(se_mlp_fwd_any_kernel, dim3(N), dim3(256), (size_t)(C + R) * sizeof(float), stream, (const float2*)pool_part,
+                           NP, C, R, P, W1, W2, pooled, hid_pre, s);
+        UNCR_LAUNCH_CHECK();
+        return UNCR_OK;
+    }
     se_lds_optin();
     hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(N), dim3(1024), (size_t)C * (R + 1) * sizeof(float), stream, (const float2*)pool_part,
                        NP, C, R, P, W1, W2, pooled, hid_pre, s);
@@ -165,13 +245,18 @@ extern "C" int uncr_se_mlp_bwd(const float* G, const float* Wpw, int N, int Co, 
                                const float* W1, const float* W2, const float* s, const float* pooled,
                                const float* hid_pre, float* ds_pre, float* dhid_pre, float* dpool_px, float* dWpw,
                                float* dW1, float* dW2, hipStream_t stream) {
-    if (C > 256 || R > 64 || N <= 0) return UNCR_ESHAPE;
-    se_lds_optin();
-    hipLaunchKernelGGL(se_mlp_bwd_frame_kernel, dim3(N), dim3(1024), (size_t)C * (R + 1) * sizeof(float), stream, G, Wpw, Co, C, R, P,
-                       W1, W2, s, hid_pre, ds_pre, dhid_pre, dpool_px);
+    if (C <= 0 || R <= 0 || N <= 0 || (size_t)(C + R) * sizeof(float) > 64 * 1024) return UNCR_ESHAPE;
+    if (C > 256 || R > 64) {
+        hipLaunchKernelGGL(se_mlp_bwd_frame_any_kernel, dim3(N), dim3(256), (size_t)(C + R) * sizeof(float), stream, G, Wpw, Co, C, R,
+                           P, W1, W2, s, hid_pre, ds_pre, dhid_pre, dpool_px);
+    } else {
+        se_lds_optin();
+        hipLaunchKernelGGL(se_mlp_bwd_frame_kernel, dim3(N), dim3(1024), (size_t)C * (R + 1) * sizeof(float), stream, G, Wpw, Co, C, R,
+                           P, W1, W2, s, hid_pre, ds_pre, dhid_pre, dpool_px);
+    }
     UNCR_LAUNCH_CHECK();
     if (!dWpw && !dW1 && !dW2) return UNCR_OK;      // the weight gradients follow later, in uncr_mbconv_param_grads
-    hipLaunchKernelGGL(se_wgrad_kernel, dim3(Co + R), dim3(256), 0, stream, G, N, Co, C, R, s, pooled, hid_pre,
+    hipLaunchKernelGGL(se_wgrad_kernel, dim3(Co + R, (C + 255) / 256), dim3(256), 0, stream, G, N, Co, C, R, s, pooled, hid_pre,
                        ds_pre, dhid_pre, dWpw, dW1, dW2);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
@@ -190,7 +275,7 @@ __global__ __launch_bounds__(256) void mbconv_param_grads_kernel(const float* __
                                                                  float* __restrict__ dwdw) {
     const int b = blockIdx.x;
     if (b < Co + R) {           // block-uniform
-        const int c = threadIdx.x;
+        const int c = blockIdx.y * 256 + threadIdx.x;  // grid.y = ceil(C / 256)
         if (c >= C) return;
         if (b < Co) {
             double a = 0.0;
@@ -208,6 +293,7 @@ __global__ __launch_bounds__(256) void mbconv_param_grads_kernel(const float* __
         }
         return;
     }
+    if (blockIdx.y) return;     // (the depthwise blocks serve every channel from row 0 of the grid)
     const int c = b - (Co + R), lane = threadIdx.x;
     const int tap = lane % 9, sl = lane / 9;           // 7 slices x 9 taps = 63 lanes
     __shared__ double comb[7][9];
@@ -238,9 +324,9 @@ __global__ __launch_bounds__(256) void mbconv_param_grads_kernel(const float* __
 extern "C" int uncr_mbconv_param_grads(const float* G, int N, int Co, int C, int R, const float* s, const float* pooled,
                                        const float* hid_pre, const float* ds_pre, const float* dhid_pre, float* dWpw, float* dW1,
                                        float* dW2, const float* dw_part, int Cdw, int NPT, float* dwdw, hipStream_t stream) {
-    if (C > 256 || R > 64 || N <= 0 || Co <= 0 || Cdw <= 0 || NPT <= 0) return UNCR_ESHAPE;
+    if (C <= 0 || R <= 0 || N <= 0 || Co <= 0 || Cdw <= 0 || NPT <= 0) return UNCR_ESHAPE;
     if (!G || !s || !pooled || !hid_pre || !ds_pre || !dhid_pre || !dWpw || !dW1 || !dW2 || !dw_part || !dwdw) return UNCR_EINVAL;
-    hipLaunchKernelGGL(mbconv_param_grads_kernel, dim3(Co + R + Cdw), dim3(256), 0, stream, G, N, Co, C, R, s, pooled, hid_pre, ds_pre,
+    hipLaunchKernelGGL(mbconv_param_grads_kernel, dim3(Co + R + Cdw, (C + 255) / 256), dim3(256), 0, stream, G, N, Co, C, R, s, pooled, hid_pre, ds_pre,
                        dhid_pre, dWpw, dW1, dW2, dw_part, Cdw, NPT, dwdw);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;

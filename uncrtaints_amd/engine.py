@@ -536,6 +536,19 @@ def pw_wgrad(d: Tensor, x: Tensor, N: int, Cd: int, Cx: int, P: int, *, pro_d: i
     import ctypes
     cop, cip = ctypes.c_int(), ctypes.c_int()
     if hb.lib().cdll.uncr_wgrad_shape(Cd, Cx, ctypes.byref(cop), ctypes.byref(cip)) < 0:
+        if Cd <= 256 and 128 < Cx <= 256 and not partials:
+            # no kernel holds a [256][256] product: two calls over halves of the x channels (contiguous copies; a slow path for the
+            # configurations wider than BASELINE's, e.g. the L-TAE input convolution behind a 256-wide encoder)
+            half, outs, rs = (Cx + 1) // 2, [], None
+            cutk = lambda t, o, n: None if t is None else t.view(N, Cx)[:, o:o + n].contiguous().view(-1)
+            for o, n in ((0, half), (half, Cx - half)):
+                xs = x.reshape(N, Cx, P)[:, o:o + n].contiguous()
+                x2s = None if x2 is None else x2.reshape(N, Cx, P)[:, o:o + n].contiguous()
+                dWp, r = pw_wgrad(d, xs, N, Cd, n, P, pro_d=pro_d, dk=dk, d2=d2, pro_x=pro_x, xk=tuple(cutk(t, o, n) for t in xk),
+                                  x2=x2s, per_frame=per_frame, rowsum=rowsum and rs is None)
+                outs.append(dWp)
+                rs = r if rs is None else rs
+            return torch.cat(outs, dim=-1).contiguous(), rs
         raise RuntimeError(f"weight-gradient shape ({Cd},{Cx}) not built")
     cop, cip = cop.value, cip.value
     if d.dtype != x.dtype:
@@ -582,6 +595,8 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     P = H * W
     Ch = p["w1"].shape[0]
     R = p["se1"].shape[0]
+    if Ch > 256:        # hidden width beyond the GEMM kernels' 256 channels: the hidden axis in groups (slow path, any expansion)
+        return _mbconv_forward_wide(x, p, spec, training, x_part, buffers or {}, want_out_stats, x_h3, pool)
     need = spec.needs_stats(training)
     buffers = buffers or {}
     dt = _dt(x)
@@ -644,6 +659,163 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
 
 _FUSED_DX = True     # dev_options(fused_dx=False): pw1 backward as GEMM + element-wise pass (tests, A/B runs)
 
+# ------------------------------------------------------------------------------------------------
+# MBConv with a hidden width beyond 256 channels (block width > 128 at the reference's expansion 2, uncrtaints.py:100-105): the GEMM,
+# weight-gradient and SE kernels are built for at most 256 channels per operand, so the HIDDEN axis is cut into groups of <= 128
+# channels that live in separate tensors.  Everything between the two pointwise convolutions is per channel (norm 1, GELU, depthwise
+# 3x3, norm 2, GELU, SE scale) and runs per group on the kernels of the fast path; pw1 is one GEMM per group, pw2 and the pw1 data
+# gradient are sums over the groups (first group stores, the others accumulate: epilogue 4) followed by a statistics pass, the SE MLP
+# sees the concatenated pooled vector.  A functional path for the wider configurations, not a tuned one: no fp16 operand split, no
+# fused dx epilogue, one extra pass over h3 / da for their statistics.
+# ------------------------------------------------------------------------------------------------
+_WIDE_GROUP = 128
+
+
+def _wide_groups(Ch: int, spec: NormSpec):
+    """[(offset, channels)] of the hidden axis.  GroupNorm groups must not straddle a cut: the step is the largest multiple of the norm
+    group's channel count that fits into _WIDE_GROUP."""
+    step = _WIDE_GROUP
+    if spec.kind == "group":
+        per = Ch // spec.groups
+        if Ch % spec.groups or per > _WIDE_GROUP:
+            raise NotImplementedError(f"MBConv hidden width {Ch} in {spec.groups} norm groups: a norm group of {Ch / spec.groups:g} "
+                                      f"channels does not fit the {_WIDE_GROUP}-channel groups of the wide path")
+        step = (_WIDE_GROUP // per) * per
+    return [(o, min(step, Ch - o)) for o in range(0, Ch, step)]
+
+
+def _wide_spec(spec: NormSpec, Ch: int, Cg: int) -> NormSpec:
+    """The hidden norms of one group of Cg channels."""
+    return NormSpec("group", Cg // (Ch // spec.groups)) if spec.kind == "group" else spec
+
+
+def _cut(t: Optional[Tensor], o: int, n: int) -> Optional[Tensor]:
+    return None if t is None else t[o:o + n]
+
+
+def _mbconv_forward_wide(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bool, x_part: Optional[Part],
+                         buffers: Dict[str, Tensor], want_out_stats: bool, x_h3: Optional[Tensor], pool: Optional[int]):
+    N, C, H, W = _check4(x)
+    P = H * W
+    Ch, R = p["w1"].shape[0], p["se1"].shape[0]
+    dt, dev = _dt(x), x.device
+    if dt != F32:
+        raise NotImplementedError("bf16 activations: MBConv blocks with more than 256 hidden channels are not built")
+    if C > 256:
+        raise NotImplementedError(f"MBConv width {C}: the GEMM kernels take at most 256 channels per operand")
+    need = spec.needs_stats(training)
+    groups = _wide_groups(Ch, spec)
+
+    def rm(i, o=None, n=None):
+        a, b = buffers.get(f"n{i}rm"), buffers.get(f"n{i}rv")
+        return (a, b) if o is None else (_cut(a, o, n), _cut(b, o, n))
+
+    if need and x_part is None:
+        x_part = stats_sq(x, N * C, P)
+    n0 = norm_fwd(x_part if need else None, N, C, P, spec, training, p["n0w"], p["n0b"], *rm(0))
+    w1, wdw, w2 = p["w1"].reshape(Ch, C), p["wdw"].reshape(Ch, 9), p["w2"].reshape(C, Ch)
+    slots = hb.query("uncr_dw_slots_fwd", H)
+    h1s, h2s, n1s, n2s, pools = [], [], [], [], []
+    for o, n in groups:
+        gs = _wide_spec(spec, Ch, n)
+        h1, part1 = pw_gemm(x, pack_wt(w1[o:o + n], transpose=True), N, C, n, P, pro=PRO_AFFINE, k=(n0.A, n0.B, None),
+                            epi=1 if need else 0)
+        n1 = norm_fwd(part1, N, n, P, gs, training, _cut(p["n1w"], o, n), _cut(p["n1b"], o, n), *rm(1, o, n))
+        h2 = _act((N, n, H, W), dev, dt)
+        part2 = Part(_f32((N * n, slots, 2), dev), slots) if need else None
+        hb.call("uncr_dw_fwd", h1, n1.A, n1.B, wdw[o:o + n].contiguous(), h2, part2.buf if part2 is not None else None, N, n, H, W,
+                dt, _DW_VARIANT, _stream())
+        n2 = norm_fwd(part2, N, n, P, gs, training, _cut(p["n2w"], o, n), _cut(p["n2b"], o, n), *rm(2, o, n))
+        _, pp = ew(EW_SE_POOL, h2, k=(n2.A, n2.B, None, None), want_part=True, planes=N * n, P=P)
+        h1s.append(h1); h2s.append(h2); n1s.append(n1); n2s.append(n2); pools.append(pp)
+    ps = pools[0].slots
+    ppool = torch.cat([q.buf.view(N, n, ps, 2) for q, (_, n) in zip(pools, groups)], dim=1).contiguous()     # [N][Ch][slots]
+    pooled, hid_pre, s = _f32((N, Ch), dev), _f32((N, R), dev), _f32((N * Ch,), dev)
+    hb.call("uncr_se_mlp_fwd", ppool, ps, N, Ch, R, P, p["se1"].contiguous(), p["se2"].contiguous(), pooled, hid_pre, s, _stream())
+    sg = [s.view(N, Ch)[:, o:o + n].contiguous().view(-1) for o, n in groups]
+
+    h3 = _act((N, C, H, W), dev, dt)
+    for i, (o, n) in enumerate(groups):      # h3 = sum over the groups of W2[:, group] gelu(norm2(h2 group)) * s
+        pw_gemm(h2s[i], pack_wt(w2[:, o:o + n].contiguous(), transpose=True), N, n, C, P, pro=PRO_AFFINE_GELU,
+                k=(n2s[i].A, n2s[i].B, sg[i]), epi=0 if i == 0 else 4, out=h3.view(N, C, P))
+    part3 = stats_sq(h3, N * C, P) if need else None
+    n3 = norm_fwd(part3, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))
+
+    y = _act((N, C, H, W), dev, dt)
+    _, party = ew(EW_RESIDUAL, x, b=h3, out=y, k=(n3.A, n3.B, None, None), want_part=want_out_stats, planes=N * C, P=P)
+    ypool = maxpool_forward(y, pool, pool) if pool is not None else None
+    saved = dict(wide=True, ypool=ypool, x=x, h1=h1s, h2=h2s, h3=h3, n0=n0, n1=n1s, n2=n2s, n3=n3, pooled=pooled, hid_pre=hid_pre,
+                 s=s, sg=sg, groups=groups, dims=(N, C, Ch, R, H, W), x_h3=x_h3)
+    return y, saved, party
+
+
+def _mbconv_backward_wide(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool, dy_part: Optional[Part]):
+    N, C, Ch, R, H, W = sv["dims"]
+    P = H * W
+    dev = dy.device
+    x, h3, n0, n3 = sv["x"], sv["h3"], sv["n0"], sv["n3"]
+    dt = _dt(x)
+    dy = cast(dy.contiguous(), dt)
+    groups = sv["groups"]
+    g: Dict[str, Tensor] = {}
+    part3 = dy_part if dy_part is not None else stats_aux(dy, h3, N * C, P)
+    b3 = norm_bwd(part3, N, C, P, n3, p["n3w"])
+    g["n3w"], g["n3b"] = b3.dgamma, b3.dbeta
+    k3 = b3.k
+    w1, wdw, w2 = p["w1"].reshape(Ch, C), p["wdw"].reshape(Ch, 9), p["w2"].reshape(C, Ch).contiguous()
+
+    # pw2: per-frame products dh3 (x) g2 per group, concatenated along the hidden axis for the SE backward
+    Gs = [pw_wgrad(dy, sv["h2"][i], N, C, n, P, pro_d=PRO_NORMBWD, dk=k3, d2=h3, pro_x=PRO_AFFINE_GELU,
+                   xk=(sv["n2"][i].A, sv["n2"][i].B, None), per_frame=True)[0] for i, (o, n) in enumerate(groups)]
+    G = torch.cat(Gs, dim=2).contiguous()            # [N][C][Ch]
+    ds_pre, dhid_pre, dpool = _f32((N, Ch), dev), _f32((N, R), dev), _f32((N * Ch,), dev)
+    dW2, dse1, dse2 = _f32((C, Ch), dev), _f32((R, Ch), dev), _f32((Ch, R), dev)
+    hb.call("uncr_se_mlp_bwd", G, w2, N, C, Ch, R, P, p["se1"].contiguous(), p["se2"].contiguous(), sv["s"], sv["pooled"],
+            sv["hid_pre"], ds_pre, dhid_pre, dpool, dW2, dse1, dse2, _stream())
+    g["w2"], g["se1"], g["se2"] = dW2.view_as(p["w2"]), dse1, dse2
+
+    slots = hb.query("uncr_dw_slots_bwd", H)
+    dW1 = _f32((Ch, C), dev)
+    dwdw = _f32((Ch, 9), dev)
+    n1w, n1b, n2w, n2b = (_f32((Ch,), dev) for _ in range(4))
+    da = _act((N, C, H, W), dev, dt)
+    for i, (o, n) in enumerate(groups):
+        h1, h2, n1, n2 = sv["h1"][i], sv["h2"][i], sv["n1"][i], sv["n2"][i]
+        dpg = dpool.view(N, Ch)[:, o:o + n].contiguous().view(-1)
+        # dz = W2[:, group]^T dh3 with the SE / GELU backward and its statistics in the epilogue
+        du2, part2 = pw_gemm(dy, pack_wt(w2[:, o:o + n].contiguous(), transpose=False), N, C, n, P, pro=PRO_NORMBWD, k=k3, x2=h3,
+                             epi=3, aux=h2, ek=(n2.A, n2.B, sv["sg"][i], dpg))
+        b2 = norm_bwd(part2, N, n, P, n2, _cut(p["n2w"], o, n))
+        n2w[o:o + n], n2b[o:o + n] = b2.dgamma, b2.dbeta
+        du1 = _act((N, n, H, W), dev, dt)
+        part1 = Part(_f32((N * n, slots, 2), dev), slots)
+        dw_part = _f32((N * n, slots, 9), dev)
+        hb.call("uncr_dw_bwd", du2, h2, h1, b2.c1, b2.c2, b2.c3, b2.mu, n1.A, n1.B, wdw[o:o + n].contiguous(), du1, part1.buf, dw_part,
+                n1.mean, n1.groups if n1.kind == NORM_GROUP else 0, N, n, H, W, dt, _DW_VARIANT, None, _stream())
+        dwg = _f32((n, 9), dev)
+        hb.call("uncr_dw_wgrad_reduce", dw_part, N, n, slots, dwg, _stream())
+        dwdw[o:o + n] = dwg
+        b1 = norm_bwd(part1, N, n, P, n1, _cut(p["n1w"], o, n), centered=True)
+        n1w[o:o + n], n1b[o:o + n] = b1.dgamma, b1.dbeta
+        dW1g, _ = pw_wgrad(du1, x, N, n, C, P, pro_d=PRO_NORMBWD, dk=b1.k, d2=h1, pro_x=PRO_AFFINE, xk=(n0.A, n0.B, None))
+        dW1[o:o + n] = dW1g
+        # da = sum over the groups of W1[group]^T dh1
+        pw_gemm(du1, pack_wt(w1[o:o + n], transpose=False), N, n, C, P, pro=PRO_NORMBWD, k=b1.k, x2=h1, epi=0 if i == 0 else 4,
+                out=da.view(N, C, P))
+    g["w1"], g["wdw"] = dW1.view_as(p["w1"]), dwdw.view_as(p["wdw"])
+    for key, val in (("n1w", n1w), ("n1b", n1b), ("n2w", n2w), ("n2b", n2b)):
+        g[key] = val if p[key] is not None else None
+    part0 = stats_aux(da, x, N * C, P)
+    b0 = norm_bwd(part0, N, C, P, n0, p["n0w"])
+    g["n0w"], g["n0b"] = b0.dgamma, b0.dbeta
+    dx, dx_part = None, None
+    if need_dx:
+        dx = _act((N, C, H, W), dev, dt)
+        x_h3 = sv.get("x_h3")
+        _, dx_part = ew(EW_PASSE, dy, b=da, c=x, aux=x_h3, out=dx, k=b0.k, want_part=x_h3 is not None, planes=N * C, P=P)
+    return dx, g, dx_part
+
+
 _CONST_PLANES: Dict[tuple, Tuple[Tensor, Tensor]] = {}
 
 
@@ -661,6 +833,8 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
                     dy_part: Optional[Part] = None):
     """-> dx, {param key: grad}, partials (sum dx, sum dx*h3_prev) for the producing block (or None).
     `dy_part` = (sum dy, sum dy*h3) partials if the kernel that produced dy already emitted them."""
+    if sv.get("wide"):
+        return _mbconv_backward_wide(dy, sv, p, need_dx, dy_part)
     N, C, Ch, R, H, W = sv["dims"]
     P = H * W
     dev = dy.device

@@ -104,8 +104,6 @@ class SE(nn.Module):
         )
 
     def forward(self, x):
-        if x.shape[1] > 256 or self.fc[0].weight.shape[0] > 64:
-            raise NotImplementedError("stand-alone SE is built for <= 256 channels and <= 64 hidden units")
         return _SEFn.apply(x, self.fc[0].weight, self.fc[2].weight)
 
 
@@ -456,9 +454,9 @@ class UNCRTAINTS(nn.Module):
                                       "for 2, 4, 6, 8, 16 or 32 channels per head")
         # d_model beyond 256 runs wherever the fused L-TAE kernels apply (use_v off: the d_model-wide projections are folded into one
         # [n_head, C] functional and never exist as activations, csrc/ltae_fused.hip); the unfused path's GEMMs end at 256 channels
-        if (d_model is not None and d_model > 256 and use_v) or max(list(encoder_widths) + list(decoder_widths)) > 128 and block_type == 'mbconv':
-            raise NotImplementedError("the GEMM kernels are built for at most 256 channels: MBConv widths <= 128 (hidden width = 2 x width), "
-                                      "d_model <= 256 with use_v")
+        # MBConv blocks wider than 128 channels (hidden width > 256) run with the hidden axis in groups (engine._mbconv_forward_wide)
+        if (d_model is not None and d_model > 256 and use_v) or max(list(encoder_widths) + list(decoder_widths)) > 256:
+            raise NotImplementedError("the GEMM kernels take at most 256 channels per operand: block widths <= 256, d_model <= 256 with use_v")
         if block_type not in ('mbconv', 'residual'):
             raise NotImplementedError(block_type)
         if use_v and (agg_mode != "att_group" or is_mono):
@@ -572,8 +570,9 @@ class UNCRTAINTS(nn.Module):
         for mod in self.modules():
             if isinstance(mod, MBConv):
                 f = mod.conv.fn
-                both(f[0].weight)
-                both(f[7].weight)
+                if f[0].weight.shape[0] <= 256:     # (wider hidden axis: engine's grouped path packs its own slices)
+                    both(f[0].weight)
+                    both(f[7].weight)
         both(self.in_conv.conv.conv[0].weight)
         if not self.is_mono:
             te = self.temporal_encoder
