@@ -28,9 +28,22 @@ PRO_NORMBWD = 3
 TRAFFIC_FILE = "r04c_traffic.json"         # fp32 storage; bf16 storage: r04c_traffic_bf16.json (tools/measure_traffic.sh <tag> [bf16])
 
 
+# entry points that are another profiled kernel plus a consumer-side BatchNorm finalisation (csrc/bn_inline.h): same byte model;
+# value = (the kernel they extend, leading int arguments to drop -- the partial-slot counts of the finalisation)
+ALIASES = {"uncr_dw_fwd_bn": ("uncr_dw_fwd", 1)}
+
+
+def _alias(name, key):
+    if name in ALIASES:
+        base, drop = ALIASES[name]
+        return base, tuple(key[drop:])
+    return name, key
+
+
 def kernel_model(name, key):
     """-> (label, algorithmic bytes, flops, bf16 MFMA products per fp32-equivalent MAC) of one launch from its int arguments
     (DESIGN.md section 4).  The last int of every profiled entry point is the activation storage code (0 fp32, 1 bf16)."""
+    name, key = _alias(name, key)
     if name == "uncr_pw_gemm":
         bias_stride, N, Cin, Cout, P, pro, epi, in_dt, out_dt = key[:9]      # (then the counts of the magnitude arrays)
         bi, bo = (2.0 if in_dt else 4.0), (2.0 if out_dt else 4.0)
@@ -86,6 +99,7 @@ def kernel_model(name, key):
 
 def written_fraction(name, key):
     """Share of a launch's algorithmic bytes that are WRITES (the rest are reads) -- picks the measured stream roof of that mix."""
+    name, key = _alias(name, key)
     if name == "uncr_pw_gemm":
         bias_stride, N, Cin, Cout, P, pro, epi, in_dt, out_dt = key[:9]
         bi, bo = (2.0 if in_dt else 4.0), (2.0 if out_dt else 4.0)
@@ -137,7 +151,7 @@ def stream_roof_gbs(wfrac):
 
 
 PROFILED = ("uncr_pw_gemm", "uncr_pw_gemm_dx", "uncr_residual_pool", "uncr_pw_wgrad", "uncr_dw_fwd", "uncr_dw_bwd", "uncr_ew", "uncr_aggregate_fwd",
-            "uncr_aggregate_bwd")
+            "uncr_aggregate_bwd") + tuple(ALIASES)
 
 
 def a_step_bytes(T, P=65536, bf16=False):
@@ -300,7 +314,17 @@ def main():
     ap.add_argument("--no-power", action="store_true", help="do not poll rocm-smi for power / clock during the timed steps")
     ap.add_argument("--no-bf16-leg", action="store_true",
                     help="skip the compact `bf16` sub-object (BASELINE config 3's per-GPU leg) the fp32 headline line carries at N = 1")
+    ap.add_argument("--dev-options", default="",
+                    help="development A/B runs only: engine.dev_options switches as k=v[,k=v...], e.g. bn_consumer=0 (the line then "
+                         "carries them under config.dev_options; the defaults are the shipped path)")
     args = ap.parse_args()
+    dev_opts = {}
+    if args.dev_options:
+        from uncrtaints_amd import engine as _engine
+        for kv in args.dev_options.split(","):
+            k, v = kv.split("=")
+            dev_opts[k] = int(v) if k == "dw_variant" else bool(int(v))
+        _engine.dev_options(**dev_opts).__enter__()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -617,7 +641,8 @@ def main():
             "config": {"workload": f"uncrtaints --input_t {T} --n_head 16 --block_type mbconv --covmode diag, "
                                    f"B={B}/GPU, {H}x{H}, fwd+MGNLL+bwd+Adam, train mode (dropout on), "
                                    + ("bf16 activation storage / fp32 accumulate, statistics, weights and loss" if bf16 else "fp32"),
-                       "global_batch": world * B, "T": T, "parallelism": f"dp{world}"},
+                       "global_batch": world * B, "T": T, "parallelism": f"dp{world}",
+                       **({"dev_options": dev_opts} if dev_opts else {})},
             "ranks": world, "collective_backend": (backend if dp_mode else None),
             # N > 1: what travels (one fp32 bucket per backward segment, all-reduce AVG), on which devices, and how long the compute
             # stream stood still for it per step (HIP events around the waits in finish(): 0 = fully hidden behind the backward)

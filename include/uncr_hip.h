@@ -210,6 +210,17 @@ int uncr_dw_slots_fwd(int H);
 int uncr_dw_slots_bwd(int H);
 int uncr_dw_fwd(const void* in, const float* cA, const float* cB, const float* w, void* out, float* part,
                 int N, int C, int H, int W, int act, int variant, hipStream_t stream);
+/* The same depthwise forward with the train-mode BatchNorm of its INPUT finalised inside the kernel (every wave reduces the
+ * N * fin_NP partial pairs of its own channel; csrc/bn_inline.h): replaces uncr_norm_finalize_fwd(kind = BATCH_TRAIN) + uncr_dw_fwd
+ * -- one dependent ~5 us launch less per MBConv block (nn.BatchNorm2d in train mode, utae.py:470-473 via uncrtaints.py:16-22,128).
+ * fin_part [N*C][fin_NP][2] = (sum, sum^2) partials of `in`; cA / cB [N*C], save_mean / save_rstd [C], ub / hb [N*C] (nullable, hb
+ * needs ub) are OUTPUTS with the meaning of uncr_norm_finalize_fwd; running_mean / running_var (both or neither) are updated in
+ * place.  Only where uncr_dw_fwd_bn_supported(H, W) (the row-streaming kernel). */
+int uncr_dw_fwd_bn_supported(int H, int W);
+int uncr_dw_fwd_bn(const void* in, const float* fin_part, int fin_NP, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps, float* cA, float* cB,
+                   float* save_mean, float* save_rstd, float* ub, float* hb, const float* w, void* out, float* part,
+                   int N, int C, int H, int W, int act, hipStream_t stream);
 int uncr_dw_bwd_emits_amax(int H, int W, int act, int variant);
 int uncr_dw_bwd(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
                 const float* k3, const float* kmu /* dh2 = k1*du2 + k2*(h2 - kmu) + k3; null: kmu = 0 */,

@@ -182,6 +182,49 @@ def _depthwise_fwd_bwd(E, orc, H, W, variant):
               (du1_ref * (h1.detach() - mfull)).sum(dim=(2, 3)).reshape(-1))
 
 
+@pytest.mark.parametrize("act", [0, 1])
+def test_depthwise_fwd_finalises_its_batchnorm_itself(E, act):
+    """uncr_dw_fwd_bn (csrc/bn_inline.h): the waves of the row-streaming depthwise kernel reduce the producer's (sum, sum^2) partials
+    of their own channel -- coefficients, saved statistics, running statistics, magnitude bounds and the convolution output must equal
+    uncr_norm_finalize_fwd(BATCH_TRAIN) + uncr_dw_fwd (the fp64 sums are taken in another order: last-bit differences only)."""
+    from uncrtaints_amd import hip_backend as hb
+    N, C, H, W = 3, 16, 72, 256
+    P = H * W
+    h1 = dev(rand(N, C, H, W, seed=1) * 2.0 + rand(1, C, 1, 1, seed=2) * 3.0)
+    if act:
+        h1 = E.cast(h1, 1)
+    gamma, beta = dev(rand(C, seed=3, scale=0.3, shift=1.0)), dev(rand(C, seed=4, scale=0.2))
+    w = dev(rand(C, 9, seed=5, scale=0.4))
+    part = E.stats_sq(h1, N * C, P)
+    slots = hb.query("uncr_dw_slots_fwd", H)
+    outs = []
+    for fused in (False, True):
+        rm, rv = dev(rand(C, seed=6, scale=0.1)), dev(rand(C, seed=7, scale=0.1, shift=1.0).abs())
+        A, B, ub, hbt = (torch.empty(N * C, device=DEV) for _ in range(4))
+        mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        h2 = torch.empty(N, C, H, W, device=DEV, dtype=h1.dtype)
+        p2 = torch.empty(N * C, slots, 2, device=DEV)
+        if fused:
+            hb.call("uncr_dw_fwd_bn", h1, part.buf, part.slots, gamma, beta, rm, rv, 0.1, 1e-5, A, B, mean, rstd, ub, hbt, w, h2, p2,
+                    N, C, H, W, act, E._stream())
+        else:
+            hb.call("uncr_norm_finalize_fwd", part.buf, part.slots, N, C, 4, P, 1, gamma, beta, rm, rv, 0.1, 1e-5, A, B, mean, rstd,
+                    ub, hbt, E._stream())
+            hb.call("uncr_dw_fwd", h1, A, B, w, h2, p2, N, C, H, W, act, 0, E._stream())
+        outs.append((A, B, mean, rstd, ub, hbt, rm, rv, h2.float(), p2))
+    names = ("A", "B", "mean", "rstd", "ub", "hb", "running_mean", "running_var", "h2", "part2")
+    for name, a, b in zip(names, *outs):
+        tol = 2e-2 if (act and name in ("h2", "part2")) else 1e-5      # bf16 storage: a last-bit change of A / B can flip a rounding
+        err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        print(f"[parity] dw_fwd_bn[act{act}]/{name}: {err:.2e}")
+        assert err <= tol, (name, err)
+    # and against torch's BatchNorm2d statistics themselves
+    x = h1.float()
+    m_ref, v_ref = x.mean(dim=(0, 2, 3)), x.var(dim=(0, 2, 3), unbiased=False)
+    assert float((outs[1][2] - m_ref).abs().max()) < 1e-5 * float(m_ref.abs().max())
+    assert float((outs[1][3] - (v_ref + 1e-5).rsqrt()).abs().max()) < 1e-5 * float((v_ref + 1e-5).rsqrt().max())
+
+
 def _mb_module(norm, seed):
     from uncrtaints_amd.src.backbones import uncrtaints as U
     from uncrtaints_amd.src.learning.weight_init import weight_init

@@ -237,6 +237,7 @@ def test_graph_mode_survives_an_optimizer_checkpoint_with_a_float_learning_rate(
 @pytest.mark.parametrize("B,T,H,W,special", [
     (1, 3, 256, 256, ""), (2, 2, 128, 64, ""),
     (1, 2, 80, 64, ""),            # overlapping adaptive-pool windows, 2.5x up-sampling
+    (1, 2, 96, 96, ""),            # 3x3 pooling windows, 3x up-sampling, W != 256 (LDS-tiled depthwise kernels)
     (1, 1, 64, 64, ""),            # a single date through the temporal attention
     (1, 12, 64, 64, ""),           # a long series
     (1, 2, 64, 512, ""),           # wide frames: 2x / 16x up-sampling, depthwise kernels for W != 256

@@ -9,6 +9,7 @@
 //           du1 = gelu'(A1*h1+B1) * dg1;                 stats (sum du1, sum du1*h1)
 //           dWdw[c,tap] partials = sum_p dh2[p] * g1[reflect(p+tap)]
 #include "common.h"
+#include "bn_inline.h"
 
 #define DW_TR_FWD 32
 #define DW_TR_BWD 16
@@ -281,7 +282,7 @@ extern "C" int uncr_dw_slots_bwd(int H) { return (H + DW_TR_BWD - 1) / DW_TR_BWD
 
 // dwconv_row.hip: streaming kernels for W == 256
 int dw_fwd_row_launch(const void* in, const float* cA, const float* cB, const float* w, void* out, float* part, int N,
-                      int C, int H, int slots, int act, hipStream_t stream);
+                      int C, int H, int slots, int act, const BnFin* fin, hipStream_t stream);
 int dw_bwd_row_launch(const void* du2, const void* h2, const void* h1, const float* k1, const float* k2,
                       const float* k3, const float* kmu, const float* cA1, const float* cB1, const float* w, void* du1, float* part,
                       float* dw_part, const float* mean1, int mean_groups, int N, int C, int H, int slots, int act,
@@ -306,11 +307,29 @@ extern "C" int uncr_dw_fwd(const void* in, const float* cA, const float* cB, con
                            float* part, int N, int C, int H, int W, int act, int variant, hipStream_t stream) {
     if (N <= 0 || C <= 0 || H < 2 || W < 4 || (W & 3) || W > 1024) return UNCR_ESHAPE;
     if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
-    if (variant == 0 && W == 256 && H >= 4 && (H & 3) == 0) return dw_fwd_row_launch(in, cA, cB, w, out, part, N, C, H, uncr_dw_slots_fwd(H), act, stream);
+    if (variant == 0 && W == 256 && H >= 4 && (H & 3) == 0) return dw_fwd_row_launch(in, cA, cB, w, out, part, N, C, H, uncr_dw_slots_fwd(H), act, nullptr, stream);
     const size_t lds = (size_t)(DW_TR_FWD + 2) * (W + 8) * sizeof(float);
     if (lds > 150 * 1024) return UNCR_ESHAPE;
     if (act == UNCR_BF16) return dw_fwd_tiled<bf16_t>(in, cA, cB, w, out, part, N, C, H, W, lds, stream);
     return dw_fwd_tiled<float>(in, cA, cB, w, out, part, N, C, H, W, lds, stream);
+}
+
+// The depthwise forward with the train-mode BatchNorm of its input finalised by the kernel itself (bn_inline.h): fin_part
+// [N*C][fin_NP] = the (sum, sum^2) partials the producer of `in` left; cA / cB / save_mean / save_rstd (/ ub / hb) are OUTPUTS
+// here, written for the backward; running statistics updated as by uncr_norm_finalize_fwd(kind = BATCH_TRAIN).  Only where the
+// row-streaming kernel runs (uncr_dw_fwd_bn_supported); other shapes: uncr_norm_finalize_fwd + uncr_dw_fwd.
+extern "C" int uncr_dw_fwd_bn_supported(int H, int W) { return (W == 256 && H >= 4 && (H & 3) == 0) ? 1 : 0; }
+extern "C" int uncr_dw_fwd_bn(const void* in, const float* fin_part, int fin_NP, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* cA, float* cB,
+                              float* save_mean, float* save_rstd, float* ub, float* hb, const float* w, void* out, float* part,
+                              int N, int C, int H, int W, int act, hipStream_t stream) {
+    if (N <= 0 || C <= 0 || !uncr_dw_fwd_bn_supported(H, W)) return UNCR_ESHAPE;
+    if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
+    if (!in || !fin_part || fin_NP <= 0 || !gamma || !beta || !cA || !cB || !save_mean || !save_rstd || !w || !out) return UNCR_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr) || (hb && !ub)) return UNCR_EINVAL;
+    const BnFin f{(const float2*)fin_part, fin_NP, N, gamma, beta, running_mean, running_var, momentum, eps, cA, cB, save_mean,
+                  save_rstd, ub, hb};
+    return dw_fwd_row_launch(in, cA, cB, w, out, part, N, C, H, uncr_dw_slots_fwd(H), act, &f, stream);
 }
 
 template <typename T>

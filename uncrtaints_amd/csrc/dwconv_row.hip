@@ -8,6 +8,7 @@
 #define UNCR_NT 1     // this file opts in to non-temporal accesses (see common.h): -0.3 ms per training step
 #endif
 #include "common.h"
+#include "bn_inline.h"
 #include <cstdlib>
 
 #define DWR_TR 64
@@ -75,7 +76,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void dw_fwd_row_kernel(const T* __restrict__ in, const float* __restrict__ cA,
                                                          const float* __restrict__ cB, const float* __restrict__ w,
                                                          T* __restrict__ out, float2* __restrict__ part, int C,
-                                                         int H, int planes, int slots) {
+                                                         int H, int planes, int slots, BnFin fin) {
     constexpr int W = 256;
     const int lane = threadIdx.x & 63;
     const int tiles = (H + DWR_TR - 1) / DWR_TR;
@@ -83,7 +84,14 @@ __global__ __launch_bounds__(256) void dw_fwd_row_kernel(const T* __restrict__ i
     if (wid >= planes * tiles) return;
     const int plane = wid / tiles, tile = wid - plane * tiles, c = plane % C;
     const int y0 = tile * DWR_TR, y1 = min(H, y0 + DWR_TR);
-    const float A = cA[plane], B = cB[plane];
+    float A, B;
+    if (fin.part) {      // the input's BatchNorm is finalised here, by every wave for its own channel (bn_inline.h)
+        const int n = plane / C;
+        bn_fin_wave(fin, n, c, C, H * W, tile == 0, tile == 0 && n == 0, A, B);
+    } else {
+        A = cA[plane];
+        B = cB[plane];
+    }
     float wk[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
@@ -335,10 +343,12 @@ __global__ __launch_bounds__(256) void dw_bwd_row_kernel(
 }
 
 int dw_fwd_row_launch(const void* in, const float* cA, const float* cB, const float* w, void* out, float* part, int N,
-                      int C, int H, int slots, int act, hipStream_t stream) {
+                      int C, int H, int slots, int act, const BnFin* fin, hipStream_t stream) {
     const int planes = N * C, tiles = (H + DWR_TR - 1) / DWR_TR;
+    BnFin f{};
+    if (fin) f = *fin;
     UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(dw_fwd_row_kernel<T>, dim3((planes * tiles + 3) / 4), dim3(256), 0, stream,
-                                                 (const T*)in, cA, cB, w, (T*)out, (float2*)part, C, H, planes, slots));
+                                                 (const T*)in, cA, cB, w, (T*)out, (float2*)part, C, H, planes, slots, f));
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -211,6 +211,9 @@ class NormFwd:
     sync_count: float = 0.0     # > 0: BatchNorm statistics were all-reduced over the data-parallel group (global count)
     ub: Optional[Tensor] = None  # [N*C] upper bounds on |A*h + B| per plane (range bookkeeping of the fp16 two-part GEMMs), or None
     hb: Optional[Tensor] = None  # [N*C] upper bounds on |h| itself (for the gradient GEMMs that read h through a norm backward)
+    # consumer-side finalisation (norm_fwd(defer=True)): nothing has been launched yet; the kernel that applies this norm fills A, B,
+    # mean, rstd (ub, hb) itself from (part.buf, part.slots, gamma, beta, running_mean, running_var, momentum, eps)
+    fin: Optional[tuple] = None
 
 
 _SYNC_BN = None      # process group for synchronised BatchNorm statistics (None: per-replica statistics, torch-DDP default)
@@ -232,10 +235,13 @@ def _all_reduce_sums(sums: Tensor) -> float:
 
 def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, training: bool, gamma: Tensor,
              beta: Tensor, running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None,
-             momentum: float = 0.1, eps: float = 1e-5, bound_part: Optional[Part] = None, want_hb: bool = False) -> NormFwd:
+             momentum: float = 0.1, eps: float = 1e-5, bound_part: Optional[Part] = None, want_hb: bool = False,
+             defer: bool = False) -> NormFwd:
     """bound_part: (sum h, sum h^2) partials of the tensor this norm is applied to (in train mode `part` itself; in BatchNorm eval
     mode they serve only this): the finalize kernel then also emits per-plane upper bounds on |A*h + B| (NormFwd.ub), with which
-    the consuming wide GEMM multiplies in two range-safe fp16 parts instead of the exact bf16 split (pw_gemm)."""
+    the consuming wide GEMM multiplies in two range-safe fp16 parts instead of the exact bf16 split (pw_gemm).
+    defer: the caller's next kernel can finalise a train-mode BatchNorm itself (csrc/bn_inline.h): where that applies nothing is
+    launched here and NormFwd.fin carries what that kernel needs (the caller MUST then run such a kernel); otherwise as usual."""
     kind = spec.code(training)
     groups = C if spec.kind == "instance" else spec.groups
     if gamma is None:                      # norm without affine parameters (InstanceNorm2d): gamma = 1, beta = 0
@@ -261,6 +267,9 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
         if part is bound_part:
             ub = _f32((N * C,), dev)
     hbt = _f32((N * C,), dev) if (ub is not None and want_hb) else None
+    if defer and _BN_CONSUMER and kind == NORM_BATCH_TRAIN and part is not None and (ub is None or part is bound_part):
+        return NormFwd(A, B, mean, rstd, kind, groups, ub=ub, hb=hbt,
+                       fin=(part.buf, part.slots, gamma, beta, running_mean, running_var, float(momentum), float(eps)))
     hb.call("uncr_norm_finalize_fwd", part.buf if part else None, part.slots if part else 0, N, C, groups, P,
             kind, gamma, beta, running_mean, running_var, float(momentum), float(eps), A, B, mean, rstd, ub, hbt, _stream())
     return NormFwd(A, B, mean, rstd, kind, groups, ub=ub, hb=hbt)
@@ -279,10 +288,13 @@ _H2_DX = True                 # the dx GEMM (+ max |du1| in the depthwise backwa
 _H2_FWD = True
 _PREPACK = True               # False: every pack_wt call packs on its own (bisecting)
 _DW_VARIANT = 0      # uncr_dw_fwd / uncr_dw_bwd `variant`: 0 = automatic, 1 = LDS-tiled kernels for every width (tests)
+# train-mode BatchNorm finalised by the kernel that applies it, where that kernel works on whole planes (csrc/bn_inline.h);
+# False: one uncr_norm_finalize_fwd launch per norm (A/B runs, bisecting)
+_BN_CONSUMER = True
 
 _DEV_OPTIONS = {"side_stream": "_USE_SIDE", "centred_normbwd": "_CENTRED_NORMBWD", "h2_bwd": "_H2_BWD", "h2_wgrad": "_H2_WGRAD",
                 "h2_dx": "_H2_DX", "h2_fwd": "_H2_FWD", "prepack": "_PREPACK", "fused_dx": "_FUSED_DX", "fused_ltae": "_FUSED_LTAE",
-                "dw_variant": "_DW_VARIANT"}
+                "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER"}
 
 
 class dev_options:
@@ -615,13 +627,18 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     h1, part1 = pw_gemm(x, W1t, N, C, Ch, P, pro=PRO_AFFINE, k=(n0.A, n0.B, None), epi=1 if need else 0, in_amax=n0.ub)
     # (hb: the bound on |h1| itself, for the backward's dx GEMM, which reads h1 through the norm-1 backward)
     n1 = norm_fwd(part1, N, Ch, P, spec, training, p["n1w"], p["n1b"], *rm(1),
-                  bound_part=part1 if (h2ok and _H2_BWD and part1 is not None) else None, want_hb=True)
+                  bound_part=part1 if (h2ok and _H2_BWD and part1 is not None) else None, want_hb=True,
+                  defer=_DW_VARIANT == 0 and hb.query("uncr_dw_fwd_bn_supported", H, W) == 1)
 
     h2 = _act((N, Ch, H, W), x.device, dt)
     slots = hb.query("uncr_dw_slots_fwd", H)
     part2 = Part(_f32((N * Ch, slots, 2), x.device), slots) if (need or h2ok) else None
-    hb.call("uncr_dw_fwd", h1, n1.A, n1.B, p["wdw"].reshape(Ch, 9).contiguous(), h2, part2.buf if part2 is not None else None,
-            N, Ch, H, W, dt, _DW_VARIANT, _stream())
+    if n1.fin is not None:      # train-mode BatchNorm 1 finalised by the depthwise kernel's waves themselves
+        hb.call("uncr_dw_fwd_bn", h1, *n1.fin, n1.A, n1.B, n1.mean, n1.rstd, n1.ub, n1.hb, p["wdw"].reshape(Ch, 9).contiguous(),
+                h2, part2.buf if part2 is not None else None, N, Ch, H, W, dt, _stream())
+    else:
+        hb.call("uncr_dw_fwd", h1, n1.A, n1.B, p["wdw"].reshape(Ch, 9).contiguous(), h2,
+                part2.buf if part2 is not None else None, N, Ch, H, W, dt, _DW_VARIANT, _stream())
     n2 = norm_fwd(part2 if need else None, N, Ch, P, spec, training, p["n2w"], p["n2b"], *rm(2),
                   bound_part=part2 if h2ok else None)
 
