@@ -292,7 +292,12 @@ _DW_VARIANT = 0      # uncr_dw_fwd / uncr_dw_bwd `variant`: 0 = automatic, 1 = L
 # False: one uncr_norm_finalize_fwd launch per norm (A/B runs, bisecting)
 _BN_CONSUMER = True
 
-_DEV_OPTIONS = {"side_stream": "_USE_SIDE", "centred_normbwd": "_CENTRED_NORMBWD", "h2_bwd": "_H2_BWD", "h2_wgrad": "_H2_WGRAD",
+# development (tools/ablate_ltae_stage.py): "record" keeps the L-TAE stage's results of the next forward / backward, "replay" hands
+# them back without launching anything -- the stage's cost inside the captured step = step time with it minus step time without it
+_LTAE_REPLAY = None
+_LTAE_STORE: Dict[str, tuple] = {}
+
+_DEV_OPTIONS = {"ltae_replay": "_LTAE_REPLAY", "side_stream": "_USE_SIDE", "centred_normbwd": "_CENTRED_NORMBWD", "h2_bwd": "_H2_BWD", "h2_wgrad": "_H2_WGRAD",
                 "h2_dx": "_H2_DX", "h2_fwd": "_H2_FWD", "prepack": "_PREPACK", "fused_dx": "_FUSED_DX", "fused_ltae": "_FUSED_LTAE",
                 "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER"}
 
@@ -1478,6 +1483,14 @@ def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor]
     values (use_v): dict(p=value-branch params, include_w, include_b, bn_buffers, p_drop, seed): the LTAE2d values are
     up-sampled and merged through include_v (uncrtaints.py:414-417)."""
     B, T = e.shape[:2]
+    if _LTAE_REPLAY == "replay":
+        g_, sv_, gp_, att_ = _LTAE_STORE["fwd"]
+        return g_.detach(), sv_, gp_, att_         # (a fresh alias: the caller hands it to autograd as a new output)
+    if _LTAE_REPLAY == "record":
+        with dev_options(ltae_replay=None):
+            _LTAE_STORE["fwd"] = ltae_stage_forward(e, dates, pad, p, denom, n_head, d_k, att_down, training, p_drop, seed, dmask,
+                                                    want_stats, mode, values, pooled)
+        return _LTAE_STORE["fwd"]
     if pooled is not None:
         down, idx = (v.view(B, T, e.shape[2], att_down, att_down) for v in pooled)
     else:
@@ -1535,6 +1548,12 @@ def _pool_scatter(ddown: Tensor, sv: dict, de: Tensor, e_h3: Optional[Tensor]) -
 
 def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int, d_k: int, e_h3: Optional[Tensor] = None):
     """-> (de, {param grads}, partials (sum de, sum de*h3) or None).  e_h3: h3 of the block that produced e."""
+    if _LTAE_REPLAY == "replay":
+        return _LTAE_STORE["bwd"]
+    if _LTAE_REPLAY == "record":
+        with dev_options(ltae_replay=None):
+            _LTAE_STORE["bwd"] = ltae_stage_backward(dg, sv, p, n_head, d_k, e_h3)
+        return _LTAE_STORE["bwd"]
     if "val" in sv:     # use_v: include_v -> (aggregation, values) -> attention
         dg0, dv, dWinc, dbinc = include_v_backward(dg, sv["inc"])
         de, datt = aggregate_backward(dg0, sv["agg"])
