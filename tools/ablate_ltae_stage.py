@@ -2,9 +2,10 @@
 step time of the full captured step minus step time of a captured step whose two stage calls launch nothing and hand back the
 results an earlier real step left behind (engine.dev_options(ltae_replay=...)): same tensors, same values downstream, no stage
 kernels -- compose, fused forward, aggregation forward | aggregation backward (+ fold reduce), fused backward, compose backward AND
-the pooled-gradient scatter + statistics pass.  Interleaved chunks of replays of the two graphs inside one process.
+the pooled-gradient scatter + statistics pass.  One process per variant (median of 5 x 200 graph replays); tools/ablate_ltae_stage.sh interleaves three pairs inside one GPU session
+and writes the JSON.
 
-    python tools/ablate_ltae_stage.py [out.json] [--act-dtype bf16]
+    python tools/ablate_ltae_stage.py [--ablated] [bf16]
 """
 import json
 import os
@@ -22,7 +23,6 @@ from uncrtaints_amd.src import losses
 
 
 def main():
-    out_path = next((a for a in sys.argv[1:] if a.endswith(".json")), None)
     act = "bf16" if "bf16" in sys.argv else "fp32"
     dev = torch.device("cuda", 0)
     B, T, H = 4, 3, 256
@@ -44,10 +44,16 @@ def main():
         opt.step()
         return loss
 
-    def capture():
+    def capture(record=False):
+        # every eager step before the capture runs on a side stream: an AccumulateGrad node bound to the default stream would pull
+        # that stream into the capture (and hipStreamEndCapture crashes on the unjoined fork)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            if record:
+                with E.dev_options(ltae_replay="record"):
+                    step()
+                E._LTAE_REPLAY = "replay"
             for _ in range(2):
                 step()
         torch.cuda.current_stream().wait_stream(side)
@@ -59,12 +65,8 @@ def main():
         torch.cuda.synchronize()
         return g
 
-    full = capture()
-    with E.dev_options(ltae_replay="record"):
-        step()
-    torch.cuda.synchronize()
-    with E.dev_options(ltae_replay="replay"):
-        ablated = capture()
+    ablate = "--ablated" in sys.argv
+    graph = capture(record=ablate)
 
     def timed(g, n):
         torch.cuda.synchronize()
@@ -74,25 +76,10 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
-    n = 200
-    timed(full, 50), timed(ablated, 50)
-    rows = [(timed(full, n), timed(ablated, n)) for _ in range(5)]
-    f = sorted(r[0] for r in rows)[2]
-    a = sorted(r[1] for r in rows)[2]
-    deltas = sorted(r[0] - r[1] for r in rows)
-    delta = deltas[2]
+    timed(graph, 50)
+    ms = sorted(timed(graph, 200) for _ in range(5))[2]
     a_bytes = (3 * T + 2) * 128 * H * H * (2 if act == "bf16" else 4) * B
-    res = {"act_dtype": act, "step_ms_full": round(f, 4), "step_ms_without_stage_kernels": round(a, 4),
-           "stage_ms_by_ablation_incl_scatter_stats": round(delta, 4), "pairs_ms": [[round(u, 4), round(v, 4)] for u, v in rows],
-           "algorithmic_bytes": a_bytes,
-           "roofline_frac_incl_scatter_stats": round(a_bytes / (delta * 1e-3) / 8e12, 4),
-           "method": "median of 5 interleaved chunks of 200 graph replays each: the captured step vs the same step whose two L-TAE stage "
-                     "calls launch nothing (engine.dev_options(ltae_replay='replay')); the difference contains the scatter + statistics "
-                     "pass that bench.py's sum-of-kernels figure attributes to the encoder (its roofline_frac_with_scatter_stats is the "
-                     "like-for-like number)"}
-    print(json.dumps(res))
-    if out_path:
-        json.dump(res, open(out_path, "w"), indent=1)
+    print(json.dumps({"act_dtype": act, "ablated": ablate, "step_ms": round(ms, 4), "algorithmic_bytes_of_the_stage": a_bytes}))
 
 
 if __name__ == "__main__":

@@ -1549,7 +1549,9 @@ def _pool_scatter(ddown: Tensor, sv: dict, de: Tensor, e_h3: Optional[Tensor]) -
 def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int, d_k: int, e_h3: Optional[Tensor] = None):
     """-> (de, {param grads}, partials (sum de, sum de*h3) or None).  e_h3: h3 of the block that produced e."""
     if _LTAE_REPLAY == "replay":
-        return _LTAE_STORE["bwd"]
+        de_, g_, part_ = _LTAE_STORE["bwd"]
+        # fresh aliases: autograd may then adopt a gradient as .grad instead of cloning it (7 copy nodes in the captured graph otherwise)
+        return de_.detach(), {k: v.detach() for k, v in g_.items()}, part_
     if _LTAE_REPLAY == "record":
         with dev_options(ltae_replay=None):
             _LTAE_STORE["bwd"] = ltae_stage_backward(dg, sv, p, n_head, d_k, e_h3)
