@@ -139,7 +139,8 @@ int uncr_pack_wt_batch(const long long* desc, int n_items, hipStream_t stream);
 int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, void* out, const float* k0,
                  const float* k1, const float* k2, const float* kmu /* PRO_NORMBWD: mean array or null */,
                  const float* bias, int bias_stride_n, const void* aux,
-                 const float* e0, const float* e1, const float* e2, const float* e3 /* epi 3 coefficients */,
+                 const float* e0, const float* e1, const float* e2, const float* e3 /* epi 3 coefficients; epi 9 (Cout > 64, pro NONE):
+                 out = relu(e0*(v + bias) + e1) per (frame, output channel) with (sum, sum^2) statistics of the result */,
                  float* part, int N, int Cin, int Cout, int P, int pro, int epi, int in_dt, int out_dt,
                  /* magnitude bookkeeping for the fp16 two-part split (all nullable / 0; Cout > 64, fp32 storage):
                   * amax_out [N][uncr_pw_stat_slots]: per-block max |stored output| (Cout <= 128 with epi 1 / 2);
@@ -164,7 +165,9 @@ int uncr_head_fwd(const void* y, const float* Wt, const float* bias, float* out,
  * c1..c3 come from uncr_norm_finalize_bwd on the sums uncr_prenorm_bwd_finish derives without a pass over da.
  * relu_a / relu_b [N*Cout] (both or neither; need xh3): x came out of a ConvLayer's norm + ReLU (in_conv, utae.py:453-520)
  * whose pre-norm output is xh3: the ReLU backward is applied here, out *= [relu_a*xh3 + relu_b > 0], and part gets the
- * statistics of the masked output for that norm's backward. */
+ * statistics of the masked output for that norm's backward.  relu_a alone (any non-null pointer, relu_b and xh3 null; part
+ * required): the mask is [x > 0] itself -- x IS the ReLU's output -- no third operand stream, part = (sum out, sum out*x)
+ * (in_conv without its pre-norm tensor, uncr_inconv_*). */
 int uncr_pw_gemm_dx_supported(int Cin, int Cout);
 int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt, void* out, const float* k0, const float* k1,
                     const float* k2, const float* kmu, const void* dy, const void* x, const void* xh3, const float* c1,
@@ -232,6 +235,24 @@ int uncr_dw_bwd(const void* du2, const void* h2, const void* h1, const float* k1
                                    uncr_dw_bwd_emits_amax(H, W, act, variant) */,
                 hipStream_t stream);
 int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw, hipStream_t stream);
+
+/* ---- in_conv = Conv2d(Cin -> Cout, k = 1, bias) + GroupNorm + ReLU (utae.py:453-520 as built at uncrtaints.py:310-314) without
+ *      its pre-norm tensor c0 = W x + b (csrc/inconv.hip): with Cin + 1 <= 16 the GroupNorm statistics of c0 are a quadratic form in
+ *      the frame's augmented second-moment matrix M~ = sum_p [x;1][x;1]^T, and so are the sums the backward needs.
+ *      forward : uncr_inconv_moments -> uncr_inconv_norm_from_moments -> uncr_pw_gemm(epi = 9, e0 = A, e1 = B) writes relu(norm(c0)).
+ *      backward: the consumer's uncr_pw_gemm_dx masks with [x > 0] (relu_a alone, no xh3) and leaves (sum du, .) partials;
+ *                R = uncr_pw_wgrad(du, x_in) per frame; uncr_inconv_bwd_finish -> dW, db, d gamma, d beta (fp64 algebra). ---- */
+int uncr_inconv_moment_blocks(int P);
+int uncr_inconv_moments(const float* x /* [N][Cin][P] fp32 */, int N, int Cin, int P,
+                        double* part /* [N][uncr_inconv_moment_blocks(P)][256] */, hipStream_t stream);
+int uncr_inconv_norm_from_moments(const double* part, int nblk, int N, int Cin, int Cout, int groups, const float* W /* [Cout][Cin] */,
+                                  const float* bias /* [Cout] or null */, const float* gamma, const float* beta, float eps, float* coefA,
+                                  float* coefB /* [N*Cout] */, float* save_mean, float* save_rstd /* [N*groups] */,
+                                  double* mom /* [N][256] out: the reduced M~ per frame, row-major 16 x 16 */, hipStream_t stream);
+int uncr_inconv_bwd_finish(const float* R /* [N][Cout][Cin] = sum_p du x^T */, const float* part /* [N*Cout][NP][2]: .x = sum_p du */,
+                           int NP, const double* mom, const float* W, const float* bias, const float* gamma, const float* save_mean,
+                           const float* save_rstd, int N, int Cin, int Cout, int groups, float* dW /* [Cout][Cin] */,
+                           float* db /* [Cout] or null */, float* dgamma, float* dbeta, hipStream_t stream);
 
 /* ---- squeeze-excite MLP (uncrtaints.py:82-97) ---- */
 int uncr_se_mlp_fwd(const float* pool_part, int NP, int N, int C, int R, int P, const float* W1,

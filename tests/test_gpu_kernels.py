@@ -311,12 +311,20 @@ def test_pad_aware_smart_forward():
     assert y2.shape == (B, T, 128, H, W)
 
 
-def test_inconv_fwd_bwd(orc):
+@pytest.mark.parametrize("moments,input_grad", [(True, False), (True, True), (False, True)])
+def test_inconv_fwd_bwd(orc, E, moments, input_grad):
+    """in_conv (Conv2d k=1 + GroupNorm + ReLU): the moment path (csrc/inconv.hip: no pre-norm tensor, statistics and parameter gradients
+    from the frames' second-moment matrices; with an input gradient the pre-norm tensor is recomputed in the backward) and the plain
+    path (GEMM -> finalize -> element-wise pass), both against the oracle."""
     from uncrtaints_amd.src.backbones.utae import ConvBlock
     from uncrtaints_amd.src.learning.weight_init import weight_init
     torch.manual_seed(0)
     blk = ConvBlock(nkernels=[15, 128], k=1, s=1, p=0, norm="group")
     blk.apply(weight_init)
+    with torch.no_grad():        # a non-trivial GroupNorm affine (weight_init leaves it at 1 / 0), one weight exactly 0
+        blk.conv.conv[1].weight.copy_(1.0 + 0.3 * torch.randn(128))
+        blk.conv.conv[1].bias.copy_(0.2 * torch.randn(128))
+        blk.conv.conv[1].weight[5] = 0.0
     B, T, H, W = 2, 3, 64, 64
     x = torch.rand(B, T, 15, H, W)
     gy = rand(B, T, 128, H, W, seed=2)
@@ -328,14 +336,49 @@ def test_inconv_fwd_bwd(orc):
     a0 = torch.relu(orc.group_norm(c0, 4, ps[2], ps[3])).view(B, T, 128, H, W)
     a0.backward(gy)
     bd = blk.to(DEV)
-    xd = dev(x).requires_grad_(True)
-    yd = bd.smart_forward(xd)
-    close("inconv_fwd", yd, a0)
-    yd.backward(dev(gy))
-    close("inconv_dx", xd.grad, xo.grad)
+    xd = dev(x).requires_grad_(input_grad)
+    tag = f"[moments={moments},dx={input_grad}]"
+    with E.dev_options(inconv_moments=moments):
+        yd = bd.smart_forward(xd)
+        close("inconv_fwd" + tag, yd, a0)
+        yd.backward(dev(gy))
+    if input_grad:
+        close("inconv_dx" + tag, xd.grad, xo.grad)
     for got, ref, name in zip((bd.conv.conv[0].weight, bd.conv.conv[0].bias, bd.conv.conv[1].weight,
                                bd.conv.conv[1].bias), ps, ("w", "b", "gn_w", "gn_b")):
-        close(f"inconv_grad[{name}]", got.grad, ref.grad)
+        close(f"inconv_grad[{name}]" + tag, got.grad, ref.grad)
+
+
+def test_inconv_moments_and_statistics(E):
+    """uncr_inconv_moments + uncr_inconv_norm_from_moments against the statistics of the materialised c0 = W x + b (fp64)."""
+    from uncrtaints_amd import hip_backend as hb
+    N, Cin, Cout, H, W, G = 3, 15, 128, 48, 64, 4
+    P = H * W
+    x = torch.rand(N, Cin, H, W) * torch.rand(1, Cin, 1, 1) + 0.3 * torch.rand(1, Cin, 1, 1)      # reflectance-like: positive, offset
+    w, b = rand(Cout, Cin, seed=1, scale=0.4), rand(Cout, seed=2, scale=0.3)
+    gamma, beta = rand(Cout, seed=3, scale=0.3, shift=1.0), rand(Cout, seed=4, scale=0.2)
+    c0 = torch.einsum("kc,nchw->nkhw", w.double(), x.double()) + b.double().view(1, Cout, 1, 1)
+    cg = c0.reshape(N, G, -1)
+    mean, var = cg.mean(dim=2), cg.var(dim=2, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    nblk = hb.query("uncr_inconv_moment_blocks", P)
+    mpart = torch.empty(N, nblk, 256, device=DEV, dtype=torch.float64)
+    xd = dev(x)
+    hb.call("uncr_inconv_moments", xd, N, Cin, P, mpart, E._stream())
+    M = mpart.sum(1).reshape(N, 16, 16).cpu()
+    xa = torch.cat([x.double().view(N, Cin, P), torch.ones(N, 1, P, dtype=torch.float64)], dim=1)
+    Mref = torch.einsum("nap,nbp->nab", xa, xa)
+    assert float((M - Mref).abs().max() / Mref.abs().max()) < 1e-12
+    A, B = torch.empty(N * Cout, device=DEV), torch.empty(N * Cout, device=DEV)
+    sm, sr = torch.empty(N * G, device=DEV), torch.empty(N * G, device=DEV)
+    mom = torch.empty(N, 256, device=DEV, dtype=torch.float64)
+    hb.call("uncr_inconv_norm_from_moments", mpart, nblk, N, Cin, Cout, G, dev(w), dev(b), dev(gamma), dev(beta), 1e-5, A, B, sm, sr,
+            mom, E._stream())
+    close("inconv_moments/mean", sm.view(N, G), mean.float(), tol=1e-6)
+    close("inconv_moments/rstd", sr.view(N, G), rstd.float(), tol=1e-6)
+    Aref = gamma.double().view(1, G, -1) * rstd.view(N, G, 1)
+    close("inconv_moments/A", A.view(N, G, -1), Aref.float(), tol=1e-6)
+    close("inconv_moments/B", B.view(N, G, -1), (beta.double().view(1, G, -1) - mean.view(N, G, 1) * Aref).float(), tol=1e-6)
 
 
 @pytest.mark.parametrize("T,padded,fused,heads", [(3, False, True, (16, 4)), (3, True, True, (16, 4)), (6, False, True, (16, 4)),

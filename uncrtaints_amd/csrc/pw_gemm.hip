@@ -521,7 +521,10 @@ extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, vo
     if (!in || !Wt || !out) return UNCR_EINVAL;
     if ((in_dt != UNCR_F32 && in_dt != UNCR_BF16) || (out_dt != UNCR_F32 && out_dt != UNCR_BF16)) return UNCR_EINVAL;
     if (pro == PRO_NORMBWD && !in2) return UNCR_EINVAL;
-    if (epi < 0 || epi > 4) return UNCR_EINVAL;
+    // epi 9: out = relu(e0*(v + bias) + e1) with (sum, sum^2) statistics -- a ConvLayer's norm + ReLU applied to the accumulator
+    // (wide kernels, no prologue; csrc/inconv.hip)
+    if (epi < 0 || (epi > 4 && epi != 9)) return UNCR_EINVAL;
+    if (epi == 9 && (!use_split(Cout) || pro != PRO_NONE || !e0 || !e1)) return UNCR_EINVAL;
     if (epi && epi != 4 && !part) return UNCR_EINVAL;
     if ((epi == 2 || epi == 3) && !aux) return UNCR_EINVAL;
     if (epi == 3 && (!e0 || !e1 || !e2 || !e3)) return UNCR_EINVAL;
@@ -606,11 +609,15 @@ extern "C" int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt,
     if (!in || !in2 || !Wt || !out || !dy || !x || !c1 || !c2 || !c3) return UNCR_EINVAL;
     if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
     if (xh3 && !part) return UNCR_EINVAL;
-    if ((relu_a || relu_b) && !(relu_a && relu_b && xh3)) return UNCR_EINVAL;
+    // ReLU of the ConvLayer that produced x: relu_a AND relu_b with xh3 = that layer's pre-norm tensor (mask relu_a*xh3 + relu_b > 0),
+    // or relu_a alone (any non-null pointer) WITHOUT xh3: the mask is [x > 0] itself and part (required) receives (sum out, sum out*x)
+    const bool relu_x = relu_a && !relu_b && !xh3;
+    if (relu_x && !part) return UNCR_EINVAL;
+    if (!relu_x && (relu_a || relu_b) && !(relu_a && relu_b && xh3)) return UNCR_EINVAL;
     if (!uncr_pw_gemm_dx_supported(Cin, Cout)) return UNCR_EINVAL;
     if (P % uncr_pw_tile_px(Cout)) return UNCR_ESHAPE;
-    PwArgs g{in, in2, Wt, out, k0, k1, k2, relu_b, x, c1, c2, c3, relu_a ? relu_a : c3, xh3 ? (float2*)part : nullptr,
-             0, Cin, Cout, P, PRO_NORMBWD, relu_a ? 6 : 5, dy, xh3};
+    PwArgs g{in, in2, Wt, out, k0, k1, k2, relu_x ? nullptr : relu_b, x, c1, c2, c3, (relu_a && !relu_x) ? relu_a : c3,
+             (xh3 || relu_x) ? (float2*)part : nullptr, 0, Cin, Cout, P, PRO_NORMBWD, relu_x ? 8 : (relu_a ? 6 : 5), dy, xh3};
     g.k3 = kmu;
     g.emu = cmu;
     g.amax_out = amax_out;

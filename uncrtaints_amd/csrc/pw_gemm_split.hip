@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
     __shared__ __attribute__((aligned(16))) unsigned char xs[2][NPA * 8192];
     __shared__ float cf[PRO == PRO_NORMBWD ? 4 : 3][256];      // [3]: the norm's mean (centred norm backward)
     __shared__ float red[COUTP][2];
-    __shared__ float ecf[(EPI == 5 || EPI == 6) ? 6 : (EPI == 3 ? 5 : 1)][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D ([5]: epi 5 / 6 mean)
+    __shared__ float ecf[(EPI == 5 || EPI == 6 || EPI == 8) ? 6 : (EPI == 3 ? 5 : (EPI == 9 ? 3 : 1))][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D ([5]: epi 5 / 6 / 8 mean); epi 9: A, B
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar: row addresses stay in SGPRs
@@ -182,11 +182,15 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                 const int ci = n * Cout + cc;
                 ecf[1][c] = g.e0[ci]; ecf[2][c] = g.e1[ci]; ecf[3][c] = g.e2[ci]; ecf[4][c] = g.e3[ci];
             }
-            if constexpr (EPI == 5 || EPI == 6) {
+            if constexpr (EPI == 5 || EPI == 6 || EPI == 8) {
                 const int ci = n * Cout + cc;
                 ecf[1][c] = g.e0[ci]; ecf[2][c] = g.e1[ci]; ecf[3][c] = g.e2[ci];
                 { const float m = (g.emu ? g.emu : g.e2)[ci]; ecf[5][c] = g.emu ? m : 0.f; }
                 if constexpr (EPI == 6) { ecf[0][c] = g.bias[ci]; ecf[4][c] = g.e3[ci]; }   // ReLU mask: e3*aux3 + bias > 0
+            }
+            if constexpr (EPI == 9) {      // out = relu(A*(v + bias) + B): a ConvLayer's norm + ReLU on the fresh accumulator
+                const int ci = n * Cout + cc;
+                ecf[1][c] = g.e0[ci]; ecf[2][c] = g.e1[ci];
             }
         }
     }
@@ -389,6 +393,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
     if constexpr ((PWS_PRIO & 2) != 0) { if (((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1) __builtin_amdgcn_s_setprio(2); }
     float amx = 0.f;          // max |stored output| of this block (CT = 1 statistics / skip epilogues)
     constexpr bool AMAXK = CT == 1 && (EPI == 1 || EPI == 2 || EPI == 5);
+    constexpr bool SKIP = EPI == 5 || EPI == 6 || EPI == 8;      // the skip + PreNorm-backward epilogues
     stage_chunk(0, 0, S0{});
     load_chunk(lp, S0{}); advance(lp);
     if constexpr (DEPTH == 2) { load_chunk(lp, S1{}); advance(lp); }
@@ -564,19 +569,19 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
 #ifndef PWS_EPI_RB
 #define PWS_EPI_RB 8
 #endif
-            constexpr int RB = (EPI == 5 || EPI == 6) ? 4 : ((EPI == 2 || EPI == 3) ? PWS_EPI_RB : 8);     // rows per request batch (epi 5 reads three rows per output row)
-            constexpr bool AUX = EPI == 2 || EPI == 3 || EPI == 4 || EPI == 5 || EPI == 6;
+            constexpr int RB = SKIP ? 4 : ((EPI == 2 || EPI == 3) ? PWS_EPI_RB : 8);     // rows per request batch (epi 5 reads three rows per output row)
+            constexpr bool AUX = EPI == 2 || EPI == 3 || EPI == 4 || SKIP;
             constexpr int NBAT = CT * 16 / RB;                      // batches of the tile: (ct, rb) = (bi / (16 / RB), RB * (bi % (16 / RB)))
             // PWS_EPI_PIPE: the operand rows of batch bi + 1 are requested BEFORE batch bi is transformed (two register sets), so the
             // epilogue's VALU work (pass-B: GELU' on every element) runs under the next batch's HBM latency instead of behind it
             constexpr bool PIPE = (PWS_EPI_PIPE != 0) && AUX && EPI != 4 && ((PWS_EPI_PIPE & 2) || EPI == 2 || EPI == 3);
             constexpr int NSET = PIPE ? 2 : 1;
             float4 xa[NSET][AUX ? RB : 1];
-            float4 xb[NSET][(EPI == 5 || EPI == 6) ? RB : 1], xc[NSET][(EPI == 5 || EPI == 6) ? RB : 1];
+            float4 xb[NSET][SKIP ? RB : 1], xc[NSET][(EPI == 5 || EPI == 6) ? RB : 1];
             auto issue = [&](auto bic, auto setc) {
                 constexpr int bi = decltype(bic)::value, S = decltype(setc)::value;
                 constexpr int ct = bi / (16 / RB), rb = RB * (bi % (16 / RB));
-                if constexpr (EPI == 5 || EPI == 6) {      // skip + PreNorm backward: x, dy, and the producing block's h3 (statistics)
+                if constexpr (SKIP) {      // skip + PreNorm backward: x, dy, and the producing block's h3 (statistics)
                     const TA* a3 = g.aux3 ? (const TA*)g.aux3 : (const TA*)g.aux2;
 #pragma unroll
                     for (int q = 0; q < RB; ++q) {
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                         const size_t o = (size_t)(nco + rc) * P + loff;
                         xa[S][q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux + o);
                         xb[S][q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux2 + o);
-                        xc[S][q] = ld4<TA, UNCR_NTG_AUX>(a3 + o);
+                        if constexpr (EPI != 8) xc[S][q] = ld4<TA, UNCR_NTG_AUX>(a3 + o);      // (epi 8 masks with x itself: no third stream)
                     }
                 }
                 if constexpr (EPI == 4) {      // accumulate: out += result (dense 3x3 as nine shifted 1x1 GEMMs)
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                 for (int q = 0; q < RB; ++q) {
                     const int r = rb + q;
                     const int col = row_of(ct, r) + 4 * kg;
-                    const float bb = EPI == 6 ? 0.f : ecf[0][col];
+                    const float bb = (EPI == 6 || EPI == 8) ? 0.f : ecf[0][col];
                     float4 v;
                     if constexpr (H2) {     // the weights' pack-time scale and the frame's operand scale leave here
                         const float hinv = hsc[col];
@@ -666,6 +671,25 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                         v = rnd4<TA>(v);
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * h.x + v.y * h.y + v.z * h.z + v.w * h.w;
+                    } else if constexpr (EPI == 8) {
+                        // as 6 with the mask taken from x itself: x = relu(.) of the producing ConvLayer, so [x > 0] IS its ReLU mask and
+                        // the layer's pre-norm tensor is not read (csrc/inconv.hip); statistics (sum du0, sum du0*x)
+                        const float4 x = xa[S][q], y = xb[S][q];
+                        const float e1 = ecf[1][col], e2 = ecf[2][col], e3 = ecf[3][col], em = ecf[5][col];
+                        v.x = x.x > 0.f ? y.x + fmaf(e1, v.x, fmaf(e2, x.x - em, e3)) : 0.f;
+                        v.y = x.y > 0.f ? y.y + fmaf(e1, v.y, fmaf(e2, x.y - em, e3)) : 0.f;
+                        v.z = x.z > 0.f ? y.z + fmaf(e1, v.z, fmaf(e2, x.z - em, e3)) : 0.f;
+                        v.w = x.w > 0.f ? y.w + fmaf(e1, v.w, fmaf(e2, x.w - em, e3)) : 0.f;
+                        v = rnd4<TA>(v);
+                        s0 = v.x + v.y + v.z + v.w;
+                        s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
+                    } else if constexpr (EPI == 9) {
+                        const float eA = ecf[1][col], eB = ecf[2][col];
+                        v.x = fmaxf(fmaf(eA, v.x, eB), 0.f); v.y = fmaxf(fmaf(eA, v.y, eB), 0.f);
+                        v.z = fmaxf(fmaf(eA, v.z, eB), 0.f); v.w = fmaxf(fmaf(eA, v.w, eB), 0.f);
+                        v = rnd4<TA>(v);
+                        s0 = v.x + v.y + v.z + v.w;
+                        s1 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
                     }
                     acc[0][ct][r] = v.x; acc[1][ct][r] = v.y; acc[2][ct][r] = v.z; acc[3][ct][r] = v.w;
                     if constexpr (AMAXK) amx = fmaxf(amx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
@@ -704,7 +728,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                 const float4 v = make_float4(acc[0][ct][r], acc[1][ct][r], acc[2][ct][r], acc[3][ct][r]);
                 if (rw + 4 * kg < Cout && (!(PWS_ABL & 1) || v.x == 1.2345e-30f)) {
                     pws_st<(UNCR_NTG_ST || (UNCR_NTG_ST2 && CT == 2) || (UNCR_NTG_ST3 && EPI == 3) || (UNCR_NTG_ST4 && CT == 1 && EPI == 1) ||
-                            (UNCR_NTG_ST5 && (EPI == 5 || EPI == 6))) && EPI != 4, TA>((TA*)g.out + (size_t)(nco + rw) * P + loff, v);
+                            (UNCR_NTG_ST5 && SKIP)) && EPI != 4, TA>((TA*)g.out + (size_t)(nco + rw) * P + loff, v);
                 }
             }
         }
@@ -727,7 +751,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
     if constexpr (EPI != 0 && EPI != 4) {
         // one statistics slot per block (its tiles were summed in a fixed order): G slots per frame instead of P/128
         __syncthreads();
-        if ((EPI != 5 && EPI != 6) || g.part)
+        if (!SKIP || g.part)
             for (int c = tid; c < COUTP; c += NT)
                 if (c < Cout) g.part[((size_t)n * Cout + c) * G + bx] = make_float2(red[c][0], red[c][1]);
     }
@@ -949,6 +973,17 @@ static int pws_launch_t(const PwArgs& g, int N, int cp, hipStream_t stream) {
             else
                 hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 6, 2, TA>), grid, dim3(256), 0, stream, g);
             break;
+        case 8:
+            if (cp != 128) return UNCR_EINVAL;
+            if (sizeof(TA) == 4 && g.h2 && g.in_amax && g.in2_amax && g.in_amax_n > 0 && g.in2_amax_n > 0)
+                hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 8, 2, float, true>), grid, dim3(256), 0, stream, g);
+            else
+                hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 8, 2, TA>), grid, dim3(256), 0, stream, g);
+            break;
+#endif
+#if PWS_PRO == 0
+        case 9:      // a ConvLayer's norm + ReLU on the accumulator (in_conv without its pre-norm tensor, csrc/inconv.hip)
+            pws_launch_epi<9, TA>(g, grid, cp, stream); break;
 #endif
         default: return UNCR_EINVAL;
     }

@@ -291,6 +291,9 @@ _DW_VARIANT = 0      # uncr_dw_fwd / uncr_dw_bwd `variant`: 0 = automatic, 1 = L
 # train-mode BatchNorm finalised by the kernel that applies it, where that kernel works on whole planes (csrc/bn_inline.h);
 # False: one uncr_norm_finalize_fwd launch per norm (A/B runs, bisecting)
 _BN_CONSUMER = True
+# in_conv (Conv2d k=1 + GroupNorm + ReLU on <= 15 input channels) without its pre-norm tensor: statistics and parameter gradients
+# from the frames' second-moment matrices (csrc/inconv.hip); False: GEMM -> finalize -> element-wise pass, c0 kept for the backward
+_INCONV_MOMENTS = True
 
 # development (tools/ablate_ltae_stage.py): "record" keeps the L-TAE stage's results of the next forward / backward, "replay" hands
 # them back without launching anything -- the stage's cost inside the captured step = step time with it minus step time without it
@@ -299,7 +302,7 @@ _LTAE_STORE: Dict[str, tuple] = {}
 
 _DEV_OPTIONS = {"ltae_replay": "_LTAE_REPLAY", "side_stream": "_USE_SIDE", "centred_normbwd": "_CENTRED_NORMBWD", "h2_bwd": "_H2_BWD", "h2_wgrad": "_H2_WGRAD",
                 "h2_dx": "_H2_DX", "h2_fwd": "_H2_FWD", "prepack": "_PREPACK", "fused_dx": "_FUSED_DX", "fused_ltae": "_FUSED_LTAE",
-                "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER"}
+                "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER", "inconv_moments": "_INCONV_MOMENTS"}
 
 
 class dev_options:
@@ -945,9 +948,9 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         relu = sv.get("x_relu")       # x = relu(A*c0 + B) of in_conv: its ReLU backward and norm statistics ride along
         ra = rb = None
         if relu is not None:
-            x_h3, ra, rb = relu
+            x_h3, ra, rb = relu       # (c0, A, B); or (None, A, None): the mask is [x > 0] itself, c0 was never stored (inconv_forward)
         dx_part = None
-        if x_h3 is not None:
+        if x_h3 is not None or relu is not None:
             slots = hb.query("uncr_pw_stat_slots", N, C, P)
             dx_part = Part(_f32((N * C, slots, 2), dev), slots, masked=relu is not None)
             if relu is None and dt == F32 and _H2_BWD:      # dx is the next backward's dy: leave its per-block maxima for that dz GEMM
@@ -1096,6 +1099,11 @@ def residual_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool 
 # in_conv: Conv2d(15->128,k1,bias) + GroupNorm(4) + ReLU   (utae.py:453-520, uncrtaints.py:310-314)
 # ------------------------------------------------------------------------------------------------
 
+def _inconv_moments_ok(x: Tensor, N: int, Cin: int, Cout: int, spec: NormSpec, gw) -> bool:
+    return (_INCONV_MOMENTS and _dt(x) == F32 and spec.kind == "group" and gw is not None and Cin + 1 <= 16 and 64 < Cout <= 256
+            and Cout % spec.groups == 0 and N <= 64)
+
+
 def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec: NormSpec, training: bool,
                    buffers: Optional[Dict[str, Tensor]] = None):
     N, Cin, H, W = _check4(x)
@@ -1104,6 +1112,23 @@ def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec
     buffers = buffers or {}
     need = spec.needs_stats(training)
     Wt = pack_wt(w.reshape(Cout, Cin), transpose=True)
+    if _inconv_moments_ok(x, N, Cin, Cout, spec, gw):
+        # c0 = W x + b is never written: its GroupNorm statistics are a quadratic form in the frame's 16 x 16 augmented moment matrix,
+        # and the GEMM's epilogue stores relu(A*c0 + B) straight from the accumulators (csrc/inconv.hip)
+        dev = x.device
+        G = spec.groups
+        nblk = hb.query("uncr_inconv_moment_blocks", P)
+        mpart = torch.empty((N, nblk, 256), device=dev, dtype=torch.float64)
+        hb.call("uncr_inconv_moments", x, N, Cin, P, mpart, _stream())
+        A, B = _f32((N * Cout,), dev), _f32((N * Cout,), dev)
+        mean, rstd = _f32((N * G,), dev), _f32((N * G,), dev)
+        mom = torch.empty((N, 256), device=dev, dtype=torch.float64)
+        w2d, bc = w.reshape(Cout, Cin).contiguous(), b.contiguous()
+        hb.call("uncr_inconv_norm_from_moments", mpart, nblk, N, Cin, Cout, G, w2d, bc, gw, gb, 1e-5, A, B, mean, rstd, mom, _stream())
+        nf = NormFwd(A, B, mean, rstd, NORM_GROUP, G)
+        a0, parta = pw_gemm(x, Wt, N, Cin, Cout, P, bias=bc, epi=9, ek=(A, B, None, None))
+        a0 = a0.view(N, Cout, H, W)
+        return a0, dict(x=x, c0=None, a0=a0, nf=nf, mom=mom, b=bc, dims=(N, Cin, Cout, H, W)), parta
     c0, part = pw_gemm(x, Wt, N, Cin, Cout, P, bias=b.contiguous(), epi=1 if need else 0)
     nf = norm_fwd(part, N, Cout, P, spec, training, gw, gb, buffers.get("rm"), buffers.get("rv"))
     a0 = _act((N, Cout, H, W), x.device, _dt(x))
@@ -1113,11 +1138,35 @@ def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec
 
 def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool, masked_part: Optional[Part] = None):
     """masked_part: da0 is already du0 = da0 * [relu mask] and these are its (sum du0, sum du0*c0) partials (the consumer's
-    backward GEMM applied the mask in its epilogue, uncr_pw_gemm_dx)."""
+    backward GEMM applied the mask in its epilogue, uncr_pw_gemm_dx).  Without c0 (inconv_forward's moment path) the second
+    component is not used: sum du0*c0 follows from the per-frame products R = sum_p du0 x^T."""
     N, Cin, Cout, H, W = sv["dims"]
     P = H * W
     nf, c0, x = sv["nf"], sv["c0"], sv["x"]
     da0 = cast(da0.contiguous(), _dt(x))
+    if c0 is None:
+        dev = da0.device
+        if masked_part is not None:
+            du0, part = da0, masked_part
+        else:           # the consumer did not apply the mask: [a0 > 0] is the ReLU's mask
+            one, zero = _const_planes(dev, N * Cout)
+            du0 = _act((N, Cout, H, W), dev, _dt(x))
+            _, part = ew(EW_RELU_BWD, da0, b=sv["a0"], out=du0, k=(one, zero, None, None), want_part=True, planes=N * Cout, P=P)
+        R, _ = pw_wgrad(du0, x, N, Cout, Cin, P, per_frame=True)            # [N, Cout, Cin] = sum_p du0 x^T
+        dW, db, dg, dbeta = _f32((Cout, Cin), dev), _f32((Cout,), dev), _f32((Cout,), dev), _f32((Cout,), dev)
+        w2d = w.reshape(Cout, Cin).contiguous()
+        hb.call("uncr_inconv_bwd_finish", R.contiguous(), part.buf, part.slots, sv["mom"], w2d, sv["b"], gw, nf.mean, nf.rstd, N, Cin,
+                Cout, nf.groups, dW, db, dg, dbeta, _stream())
+        dx = None
+        if need_dx:
+            # the gradient w.r.t. the model input needs c0 per pixel: recomputed (a training run's input carries no gradient)
+            Wt = pack_wt(w2d, transpose=True)
+            c0r, _ = pw_gemm(x, Wt, N, Cin, Cout, P, bias=sv["b"])
+            nb = norm_bwd(stats_aux(du0, c0r, N * Cout, P), N, Cout, P, nf, gw)
+            Wk = pack_wt(w2d, transpose=False)
+            dx, _ = pw_gemm(du0, Wk, N, Cout, Cin, P, pro=PRO_NORMBWD, k=nb.k, x2=c0r, out_dt=F32)
+            dx = dx.view(N, Cin, H, W)
+        return dx, dW.view_as(w), db, dg, dbeta
     if masked_part is not None:
         du0, part = da0, masked_part
     else:

@@ -61,7 +61,8 @@ class _ConvNormActFn(torch.autograd.Function):
         ctx.sv, ctx.layer = sv, layer
         ctx.params = (w, gw)
         a0._uncr_part = part
-        a0._uncr_relu = (sv["c0"], sv["nf"].A, sv["nf"].B)   # lets the consumer's backward apply this ReLU's mask
+        # lets the consumer's backward apply this ReLU's mask: from c0 (A*c0 + B > 0) or, where c0 was never stored, from a0 itself
+        a0._uncr_relu = (sv["c0"], sv["nf"].A, sv["nf"].B if sv["c0"] is not None else None)
         return a0
 
     @staticmethod
