@@ -243,8 +243,8 @@ int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw,
  *      backward: the consumer's uncr_pw_gemm_dx masks with [x > 0] (relu_a alone, no xh3) and leaves (sum du, .) partials;
  *                R = uncr_pw_wgrad(du, x_in) per frame; uncr_inconv_bwd_finish -> dW, db, d gamma, d beta (fp64 algebra). ---- */
 int uncr_inconv_moment_blocks(int P);
-int uncr_inconv_moments(const float* x /* [N][Cin][P] fp32 */, int N, int Cin, int P,
-                        double* part /* [N][uncr_inconv_moment_blocks(P)][256] */, hipStream_t stream);
+int uncr_inconv_moments(const void* x /* [N][Cin][P], storage `act` */, int N, int Cin, int P,
+                        double* part /* [N][uncr_inconv_moment_blocks(P)][256] */, int act, hipStream_t stream);
 int uncr_inconv_norm_from_moments(const double* part, int nblk, int N, int Cin, int Cout, int groups, const float* W /* [Cout][Cin] */,
                                   const float* bias /* [Cout] or null */, const float* gamma, const float* beta, float eps, float* coefA,
                                   float* coefB /* [N*Cout] */, float* save_mean, float* save_rstd /* [N*groups] */,

@@ -383,7 +383,12 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
     pad_mask = (x == cfg.pad_value).all(dim=-1).all(dim=-1).all(dim=-1)   # [B,T]
     bf = cfg.act_bf16
     f = _store(x.reshape(B * T, Cin, H, W), bf, grad=False)               # smart_forward, utae.py:422-450 (input gradient: fp32)
-    c0 = _store(conv1x1(f, p["in_conv.conv.conv.0.weight"], p["in_conv.conv.conv.0.bias"]), bf)
+    c0 = conv1x1(f, p["in_conv.conv.conv.0.weight"], p["in_conv.conv.conv.0.bias"])
+    # bf16 emulation: behind a GroupNorm the HIP path never stores the pre-norm tensor of in_conv (statistics and parameter gradients
+    # from the frames' second-moment matrices, csrc/inconv.hip: at most 15 input channels, 65 ... 256 output channels): no rounding of
+    # c0 or of its gradient there; the other configurations keep it in bf16
+    if not (cfg.encoder_norm == "group" and Cin + 1 <= 16 and 64 < c0.shape[1] <= 256):
+        c0 = _store(c0, bf)
     a0 = _store(torch.relu(_NormCtx(p, cfg.encoder_norm, training, update_running)(c0, "in_conv.conv.conv.1")), bf)   # utae.py:463-473
     e = a0
     for i in range(len(cfg.encoder_widths)):                              # one block per entry, uncrtaints.py:316-319, 399-400

@@ -364,7 +364,7 @@ def test_inconv_moments_and_statistics(E):
     nblk = hb.query("uncr_inconv_moment_blocks", P)
     mpart = torch.empty(N, nblk, 256, device=DEV, dtype=torch.float64)
     xd = dev(x)
-    hb.call("uncr_inconv_moments", xd, N, Cin, P, mpart, E._stream())
+    hb.call("uncr_inconv_moments", xd, N, Cin, P, mpart, 0, E._stream())
     M = mpart.sum(1).reshape(N, 16, 16).cpu()
     xa = torch.cat([x.double().view(N, Cin, P), torch.ones(N, 1, P, dtype=torch.float64)], dim=1)
     Mref = torch.einsum("nap,nbp->nab", xa, xa)

@@ -18,21 +18,26 @@
 #define ICM_LD (ICM_TP + 1) // row stride (floats): 16 rows of one pixel fall into 16 different banks
 #define ICM_A 16            // augmented channel count (Cin + 1 <= 16)
 
+__device__ __forceinline__ float icm_ld(const float* p) { return *p; }
+__device__ __forceinline__ float icm_ld(const bf16_t* p) { return __uint_as_float((unsigned)(*p) << 16); }
+
 // grid = (nblk, N), block = 256 = 16 x 16 entries (i, j) of the frame's augmented moment matrix; part[(n*nblk + b)*256 + i*16 + j]
-__global__ __launch_bounds__(256) void inconv_moments_kernel(const float* __restrict__ x, int Cin, int P, int px_per_block,
+// T: storage of x (fp32, or bf16: the moments of the values as stored)
+template <typename T>
+__global__ __launch_bounds__(256) void inconv_moments_kernel(const T* __restrict__ x, int Cin, int P, int px_per_block,
                                                              double* __restrict__ part) {
     __shared__ float xs[ICM_A][ICM_LD];
     const int tid = threadIdx.x, i = tid >> 4, j = tid & 15;
     const int n = blockIdx.y;
     const int p0 = blockIdx.x * px_per_block, p1 = min(P, p0 + px_per_block);
-    const float* xb = x + (size_t)n * Cin * P;
+    const T* xb = x + (size_t)n * Cin * P;
     double acc = 0.0;
     for (int t0 = p0; t0 < p1; t0 += ICM_TP) {
         const int np = min(ICM_TP, p1 - t0);
         __syncthreads();                        // the previous tile has been consumed
         for (int c = 0; c < ICM_A; ++c) {
             float v = 0.f;
-            if (tid < np) v = c < Cin ? xb[(size_t)c * P + t0 + tid] : (c == Cin ? 1.f : 0.f);
+            if (tid < np) v = c < Cin ? icm_ld(xb + (size_t)c * P + t0 + tid) : (c == Cin ? 1.f : 0.f);
             xs[c][tid] = v;                     // pixels past the range contribute zeros (also to the count)
         }
         __syncthreads();
@@ -48,12 +53,15 @@ extern "C" int uncr_inconv_moment_blocks(int P) {
     const int b = (P + 1023) / 1024;
     return b < 1 ? 1 : (b > 256 ? 256 : b);
 }
-extern "C" int uncr_inconv_moments(const float* x, int N, int Cin, int P, double* part, hipStream_t stream) {
+extern "C" int uncr_inconv_moments(const void* x, int N, int Cin, int P, double* part, int act, hipStream_t stream) {
     if (N <= 0 || Cin <= 0 || Cin + 1 > ICM_A || P <= 0) return UNCR_ESHAPE;
-    if (!x || !part) return UNCR_EINVAL;
+    if (!x || !part || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
     const int nblk = uncr_inconv_moment_blocks(P);
     const int ppb = ((P + nblk - 1) / nblk + ICM_TP - 1) / ICM_TP * ICM_TP;
-    hipLaunchKernelGGL(inconv_moments_kernel, dim3(nblk, N), dim3(256), 0, stream, x, Cin, P, ppb, part);
+    if (act == UNCR_BF16)
+        hipLaunchKernelGGL(inconv_moments_kernel<bf16_t>, dim3(nblk, N), dim3(256), 0, stream, (const bf16_t*)x, Cin, P, ppb, part);
+    else
+        hipLaunchKernelGGL(inconv_moments_kernel<float>, dim3(nblk, N), dim3(256), 0, stream, (const float*)x, Cin, P, ppb, part);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -1100,7 +1100,7 @@ def residual_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool 
 # ------------------------------------------------------------------------------------------------
 
 def _inconv_moments_ok(x: Tensor, N: int, Cin: int, Cout: int, spec: NormSpec, gw) -> bool:
-    return (_INCONV_MOMENTS and _dt(x) == F32 and spec.kind == "group" and gw is not None and Cin + 1 <= 16 and 64 < Cout <= 256
+    return (_INCONV_MOMENTS and spec.kind == "group" and gw is not None and Cin + 1 <= 16 and 64 < Cout <= 256
             and Cout % spec.groups == 0 and N <= 64)
 
 
@@ -1119,7 +1119,7 @@ def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec
         G = spec.groups
         nblk = hb.query("uncr_inconv_moment_blocks", P)
         mpart = torch.empty((N, nblk, 256), device=dev, dtype=torch.float64)
-        hb.call("uncr_inconv_moments", x, N, Cin, P, mpart, _stream())
+        hb.call("uncr_inconv_moments", x, N, Cin, P, mpart, _dt(x), _stream())
         A, B = _f32((N * Cout,), dev), _f32((N * Cout,), dev)
         mean, rstd = _f32((N * G,), dev), _f32((N * G,), dev)
         mom = torch.empty((N, 256), device=dev, dtype=torch.float64)

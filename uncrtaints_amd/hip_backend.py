@@ -115,6 +115,7 @@ class EventProfiler:
         self.scope = None          # while set (a tag), EVERY launch is timed and also listed in scope_records
         self.scope_records = []    # (tag, entry point, start event, end event)
         self.scope_exclude = set() # entry points left out of scope_ms()
+        self.tag = None            # optional callable (entry point, args) -> record name (variants one entry point's ints cannot tell apart)
 
     def scope_ms(self):
         """-> {tag: summed kernel milliseconds} of the launches made while a scope tag was set."""
@@ -178,7 +179,7 @@ def call(name: str, *args):
         e1.record()
         if name in _PROF.names:
             key = tuple(a for a, (typ, _) in zip(args, proto) if typ == "int")
-            _PROF.records.append((name, key, e0, e1))
+            _PROF.records.append((_PROF.tag(name, args) if _PROF.tag else name, key, e0, e1))
         if _PROF.scope is not None:
             _PROF.scope_records.append((_PROF.scope, name, e0, e1))
     else:
