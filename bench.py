@@ -25,7 +25,7 @@ FP32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 / _f16 dense peak (what the split GEMMs really run on: 6, 3 or 2 products)
 
 PRO_NORMBWD = 3
-TRAFFIC_FILE = "r04d_traffic.json"         # fp32 storage; bf16 storage: r04d_traffic_bf16.json (tools/measure_traffic.sh <tag> [bf16])
+TRAFFIC_FILE = "r04e_traffic.json"         # fp32 storage; bf16 storage: r04e_traffic_bf16.json (tools/measure_traffic.sh <tag> [bf16])
 
 
 # entry points that are another profiled kernel plus a consumer-side BatchNorm finalisation (csrc/bn_inline.h): same byte model;

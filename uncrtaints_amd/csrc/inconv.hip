@@ -14,39 +14,56 @@
 // per pixel again; the host layer then recomputes it with the plain GEMM (rare: the input of a training run has no gradient).
 #include "common.h"
 
-#define ICM_TP 256          // pixels per LDS tile
-#define ICM_LD (ICM_TP + 1) // row stride (floats): 16 rows of one pixel fall into 16 different banks
 #define ICM_A 16            // augmented channel count (Cin + 1 <= 16)
+typedef double icm_f64x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float icm_ld(const float* p) { return *p; }
-__device__ __forceinline__ float icm_ld(const bf16_t* p) { return __uint_as_float((unsigned)(*p) << 16); }
+__device__ __forceinline__ float icm_w(float v) { return v; }
+__device__ __forceinline__ float icm_w(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+template <typename T> struct icm_vec4;
+template <> struct icm_vec4<float> { typedef float4 type; };
+template <> struct icm_vec4<bf16_t> { typedef ushort4 type; };
 
-// grid = (nblk, N), block = 256 = 16 x 16 entries (i, j) of the frame's augmented moment matrix; part[(n*nblk + b)*256 + i*16 + j]
+// M~ = X~ X~^T is a 16 x 16 x (pixels) product with fp64 accumulation: exactly v_mfma_f64_16x16x4_f64 with A = B (the product is
+// symmetric, so one register feeds both operands: lane l holds channel l & 15 of pixel 4-group l >> 4).  No LDS tile: a lane loads four
+// consecutive pixels of its channel (one 16- / 8-byte load per 16 pixels of the wave), widens them to fp64 (exact) and issues four
+// MFMAs; the products of fp32 values are exact in fp64.  C/D layout of the f64 form: col = lane & 15, row = (lane >> 4) + 4*reg.
+// grid = (nblk, N), block = 256 (4 waves, the block's pixel range dealt to them in 16-pixel steps); part[(n*nblk + b)*256 + i*16 + j]
 // T: storage of x (fp32, or bf16: the moments of the values as stored)
 template <typename T>
 __global__ __launch_bounds__(256) void inconv_moments_kernel(const T* __restrict__ x, int Cin, int P, int px_per_block,
                                                              double* __restrict__ part) {
-    __shared__ float xs[ICM_A][ICM_LD];
-    const int tid = threadIdx.x, i = tid >> 4, j = tid & 15;
+    typedef typename icm_vec4<T>::type V4;
+    __shared__ double red[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
     const int n = blockIdx.y;
     const int p0 = blockIdx.x * px_per_block, p1 = min(P, p0 + px_per_block);
-    const T* xb = x + (size_t)n * Cin * P;
-    double acc = 0.0;
-    for (int t0 = p0; t0 < p1; t0 += ICM_TP) {
-        const int np = min(ICM_TP, p1 - t0);
-        __syncthreads();                        // the previous tile has been consumed
-        for (int c = 0; c < ICM_A; ++c) {
-            float v = 0.f;
-            if (tid < np) v = c < Cin ? icm_ld(xb + (size_t)c * P + t0 + tid) : (c == Cin ? 1.f : 0.f);
-            xs[c][tid] = v;                     // pixels past the range contribute zeros (also to the count)
+    const T* xb = x + ((size_t)n * Cin + (c < Cin ? c : 0)) * P;
+    icm_f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    // two 16-pixel steps per iteration on independent accumulators (an MFMA's dependent latency is 4 passes)
+    for (int s = p0 + 32 * wv; s < p1; s += 128) {
+        float v[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int px = s + 16 * h + 4 * q;
+            const bool in = px < p1;                 // (p1 and px are multiples of 4: a 4-group is inside or outside as a whole)
+            V4 raw = {};
+            if (in && c < Cin) raw = *(const V4*)(xb + px);
+            const float one = (in && c == Cin) ? 1.f : 0.f;
+            v[h][0] = c < Cin ? icm_w(raw.x) : one; v[h][1] = c < Cin ? icm_w(raw.y) : one;
+            v[h][2] = c < Cin ? icm_w(raw.z) : one; v[h][3] = c < Cin ? icm_w(raw.w) : one;
         }
-        __syncthreads();
-        const float* ri = xs[i];
-        const float* rj = xs[j];
-#pragma unroll 8
-        for (int p = 0; p < ICM_TP; ++p) acc = fma((double)ri[p], (double)rj[p], acc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double a0 = (double)v[0][e], a1 = (double)v[1][e];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+        }
     }
-    part[((size_t)n * gridDim.x + blockIdx.x) * 256 + tid] = acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv][(q + 4 * r) * 16 + c] = acc0[r] + acc1[r];
+    __syncthreads();
+    part[((size_t)n * gridDim.x + blockIdx.x) * 256 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
 extern "C" int uncr_inconv_moment_blocks(int P) {
@@ -57,7 +74,8 @@ extern "C" int uncr_inconv_moments(const void* x, int N, int Cin, int P, double*
     if (N <= 0 || Cin <= 0 || Cin + 1 > ICM_A || P <= 0) return UNCR_ESHAPE;
     if (!x || !part || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
     const int nblk = uncr_inconv_moment_blocks(P);
-    const int ppb = ((P + nblk - 1) / nblk + ICM_TP - 1) / ICM_TP * ICM_TP;
+    if (P % 4) return UNCR_ESHAPE;
+    const int ppb = ((P + nblk - 1) / nblk + 127) / 128 * 128;
     if (act == UNCR_BF16)
         hipLaunchKernelGGL(inconv_moments_kernel<bf16_t>, dim3(nblk, N), dim3(256), 0, stream, (const bf16_t*)x, Cin, P, ppb, part);
     else
@@ -76,8 +94,25 @@ __global__ __launch_bounds__(256) void inconv_norm_from_moments_kernel(
     __shared__ float sh_mean, sh_rstd;
     const int tid = threadIdx.x, n = blockIdx.x / G, g = blockIdx.x % G, Cg = Cout / G;
     {
+        // up to 32 loads in flight per thread (a plain loop serialises nblk L2 round trips), summed in block order
+        const double* src = part + (size_t)n * nblk * 256 + tid;
         double a = 0.0;
-        for (int b = 0; b < nblk; ++b) a += part[((size_t)n * nblk + b) * 256 + tid];
+        int b = 0;
+        for (; b + 32 <= nblk; b += 32) {
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = src[(size_t)(b + u) * 256];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) a += v[u];
+        }
+        for (; b + 8 <= nblk; b += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(b + u) * 256];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; b < nblk; ++b) a += src[(size_t)b * 256];
         M[tid] = a;
         if (g == 0) mom[(size_t)n * 256 + tid] = a;
     }
@@ -87,13 +122,17 @@ __global__ __launch_bounds__(256) void inconv_norm_from_moments_kernel(
         const int k = g * Cg + c;
         const float* w = W + (size_t)k * Cin;
         const double b = bias ? (double)bias[k] : 0.0;
+        double wr[ICM_A];                         // the weight row in registers (a loop over global memory re-reads it 15 x 15 times)
+#pragma unroll
+        for (int a = 0; a < ICM_A; ++a) wr[a] = a < Cin ? (double)w[a < Cin ? a : 0] : 0.0;
         double ws = 0.0, q = 0.0;
-        for (int a = 0; a < Cin; ++a) {
-            const double wa = (double)w[a];
-            ws += wa * M[a * 16 + Cin];
+#pragma unroll
+        for (int a = 0; a < ICM_A - 1; ++a) {     // (rows / columns past Cin multiply zero weights; M's augmented row is excluded below)
             double r = 0.0;
-            for (int e = 0; e < Cin; ++e) r += (double)w[e] * M[a * 16 + e];
-            q += wa * r;
+#pragma unroll
+            for (int e = 0; e < ICM_A - 1; ++e) r += wr[e] * (e < Cin ? M[a * 16 + e] : 0.0);
+            ws += wr[a] * (a < Cin ? M[a * 16 + Cin] : 0.0);
+            q += wr[a] * r;
         }
         t1s[c] = ws + b * Pn;
         t2s[c] = q + 2.0 * b * ws + b * b * Pn;
@@ -132,7 +171,12 @@ extern "C" int uncr_inconv_norm_from_moments(const double* part, int nblk, int N
     return UNCR_OK;
 }
 
-// grid = G, block = 512.  Dynamic LDS: S1, S2 [N][Cg] doubles, c2, c3, m-terms [N] doubles.
+// grid = G, block = 512.  Dynamic LDS: S1, S2 [N][Cg], c2, c3 [N], Mc [256], v2, v3 [16], mean, rstd [N] doubles.
+// The sums over frames are taken once per group, not once per output: with c2, c3 per (frame, group)
+//   Mc = sum_n c2[n] M~[n]  (16 x 16),  v2[a] = sum_n c2[n] mu[n] Sx[n][a],  v3[a] = sum_n c3[n] Sx[n][a]
+//   dW[k][a] = gamma[k] sum_n rstd[n] R[n][k][a] + sum_e W[k][e] Mc[e][a] + b[k] Mc[a][Cin] - v2[a] + v3[a]
+//   db[k]    = gamma[k] sum_n rstd[n] S1[n][k]   + sum_a W[k][a] Mc[a][Cin] + b[k] Mc[Cin][Cin] - v2[Cin] + v3[Cin]
+// (Sx[n][a] = M~[n][a][Cin], the pixel count = M~[n][Cin][Cin]: the augmented row serves the bias like a 16th input channel).
 __global__ __launch_bounds__(512) void inconv_bwd_finish_kernel(
     const float* __restrict__ R /* [N][Cout][Cin] */, const float2* __restrict__ part /* [N*Cout][NP]: .x = sum du */, int NP,
     const double* __restrict__ mom /* [N][256] */, const float* __restrict__ W, const float* __restrict__ bias,
@@ -144,11 +188,32 @@ __global__ __launch_bounds__(512) void inconv_bwd_finish_kernel(
     double* S2 = S1 + (size_t)N * Cg;      // [N][Cg]
     double* c2 = S2 + (size_t)N * Cg;      // [N]
     double* c3 = c2 + N;                   // [N]
+    double* Mc = c3 + N;                   // [256]
+    double* v2 = Mc + 256;                 // [16]
+    double* v3 = v2 + 16;                  // [16]
+    double* mus = v3 + 16;                 // [N] the group's mean / rstd per frame (read in every loop below)
+    double* rss = mus + N;                 // [N]
+    for (int n = tid; n < N; n += 512) { mus[n] = (double)save_mean[n * G + g]; rss[n] = (double)save_rstd[n * G + g]; }
     for (int q = tid; q < N * Cg; q += 512) {
         const int n = q / Cg, c = q - n * Cg, k = g * Cg + c;
         const float2* src = part + ((size_t)n * Cout + k) * NP;
         double s1 = 0.0;
-        for (int j = 0; j < NP; ++j) s1 += (double)src[j].x;
+        int j = 0;
+        for (; j + 16 <= NP; j += 16) {        // loads in flight in batches, summed in slot order
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = src[j + u].x;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s1 += (double)v[u];
+        }
+        for (; j + 4 <= NP; j += 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = src[j + u].x;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s1 += (double)v[u];
+        }
+        for (; j < NP; ++j) s1 += (double)src[j].x;
         const float* r = R + ((size_t)n * Cout + k) * Cin;
         const float* w = W + (size_t)k * Cin;
         double s2 = 0.0;
@@ -158,7 +223,7 @@ __global__ __launch_bounds__(512) void inconv_bwd_finish_kernel(
     }
     __syncthreads();
     for (int n = tid; n < N; n += 512) {
-        const double mu = (double)save_mean[n * G + g], r = (double)save_rstd[n * G + g];
+        const double mu = mus[n], r = rss[n];
         const double Mn = (double)Cg * mom[(size_t)n * 256 + Cin * 16 + Cin];
         double a = 0.0, b = 0.0;
         for (int c = 0; c < Cg; ++c) {
@@ -170,42 +235,63 @@ __global__ __launch_bounds__(512) void inconv_bwd_finish_kernel(
         c3[n] = -r * (a / Mn);
     }
     __syncthreads();
+    if (tid < 256) {
+        double a = 0.0;
+        for (int n = 0; n < N; ++n) a += c2[n] * mom[(size_t)n * 256 + tid];
+        Mc[tid] = a;
+    } else if (tid < 256 + 16) {
+        const int a = tid - 256;
+        double s2 = 0.0, s3 = 0.0;
+        for (int n = 0; n < N; ++n) {
+            const double sx = mom[(size_t)n * 256 + a * 16 + Cin];
+            s2 += c2[n] * mus[n] * sx;
+            s3 += c3[n] * sx;
+        }
+        v2[a] = s2;
+        v3[a] = s3;
+    }
+    __syncthreads();
     // d gamma, d beta, d bias: one thread per channel of the group
     for (int c = tid; c < Cg; c += 512) {
         const int k = g * Cg + c;
         const float* w = W + (size_t)k * Cin;
         const double b = bias ? (double)bias[k] : 0.0, gm = (double)gamma[k];
-        double dg = 0.0, dbt = 0.0, dbias = 0.0;
+        double dg = 0.0, dbt = 0.0, rs1 = 0.0;
         for (int n = 0; n < N; ++n) {
-            const double mu = (double)save_mean[n * G + g], r = (double)save_rstd[n * G + g];
-            const double* M = mom + (size_t)n * 256;
-            const double Pn = M[Cin * 16 + Cin];
+            const double mu = mus[n], r = rss[n];
             const double s1 = S1[n * Cg + c], s2 = S2[n * Cg + c];
             dg += r * (s2 - mu * s1);
             dbt += s1;
-            double T = b * Pn;                                      // sum_p c0[k]
-            for (int a = 0; a < Cin; ++a) T += (double)w[a] * M[a * 16 + Cin];
-            dbias += r * gm * s1 + c2[n] * (T - mu * Pn) + c3[n] * Pn;
+            rs1 += r * s1;
         }
+        double t = b * Mc[Cin * 16 + Cin];
+        for (int a = 0; a < Cin; ++a) t += (double)w[a] * Mc[a * 16 + Cin];
         dgamma[k] = (float)dg;
         dbeta[k] = (float)dbt;
-        if (db) db[k] = (float)dbias;
+        if (db) db[k] = (float)(gm * rs1 + t - v2[Cin] + v3[Cin]);
     }
     // d W[k][a]
     for (int q = tid; q < Cg * Cin; q += 512) {
         const int c = q / Cin, a = q - c * Cin, k = g * Cg + c;
         const float* w = W + (size_t)k * Cin;
         const double b = bias ? (double)bias[k] : 0.0, gm = (double)gamma[k];
-        double acc = 0.0;
-        for (int n = 0; n < N; ++n) {
-            const double mu = (double)save_mean[n * G + g], r = (double)save_rstd[n * G + g];
-            const double* M = mom + (size_t)n * 256;
-            const double Sxa = M[a * 16 + Cin];
-            double Q = b * Sxa;                                     // sum_p c0[k] * x[a]
-            for (int e = 0; e < Cin; ++e) Q += (double)w[e] * M[e * 16 + a];
-            acc += r * gm * (double)R[((size_t)n * Cout + k) * Cin + a] + c2[n] * (Q - mu * Sxa) + c3[n] * Sxa;
+        double rr = 0.0;
+        int n = 0;
+        for (; n + 4 <= N; n += 4) {
+            float rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rv[u] = R[((size_t)(n + u) * Cout + k) * Cin + a];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rr += rss[n + u] * (double)rv[u];
         }
-        dW[(size_t)k * Cin + a] = (float)acc;
+        for (; n < N; ++n) rr += rss[n] * (double)R[((size_t)n * Cout + k) * Cin + a];
+        float wv[ICM_A];
+#pragma unroll
+        for (int e = 0; e < ICM_A; ++e) wv[e] = w[e < Cin ? e : 0];
+        double t = b * Mc[a * 16 + Cin];
+#pragma unroll
+        for (int e = 0; e < ICM_A - 1; ++e) t += e < Cin ? (double)wv[e] * Mc[e * 16 + a] : 0.0;
+        dW[(size_t)k * Cin + a] = (float)(gm * rr + t - v2[a] + v3[a]);
     }
 }
 
@@ -214,7 +300,7 @@ extern "C" int uncr_inconv_bwd_finish(const float* R, const float* part, int NP,
                                       int groups, float* dW, float* db, float* dgamma, float* dbeta, hipStream_t stream) {
     if (N <= 0 || Cin <= 0 || Cin + 1 > ICM_A || Cout <= 0 || groups <= 0 || Cout % groups || NP <= 0) return UNCR_ESHAPE;
     if (!R || !part || !mom || !W || !gamma || !save_mean || !save_rstd || !dW || !dgamma || !dbeta) return UNCR_EINVAL;
-    const size_t lds = ((size_t)2 * N * (Cout / groups) + 2 * (size_t)N) * sizeof(double);
+    const size_t lds = ((size_t)2 * N * (Cout / groups) + 4 * (size_t)N + 256 + 32) * sizeof(double);
     if (lds > 60 * 1024) return UNCR_ESHAPE;
     hipLaunchKernelGGL(inconv_bwd_finish_kernel, dim3(groups), dim3(512), lds, stream, R, (const float2*)part, NP, mom, W, bias, gamma,
                        save_mean, save_rstd, N, Cin, Cout, groups, dW, db, dgamma, dbeta);
