@@ -66,6 +66,7 @@ typedef struct ihipStream_t* hipStream_t;
 /* stand-alone norm layers / SE (PreNorm uncrtaints.py:72-79, SE uncrtaints.py:82-97 called outside MBConv) */
 #define UNCR_EW_AFFINE 15          /* out = A*a + B, stats (sum out, sum out^2) */
 #define UNCR_EW_NORMBWD 16         /* out = C1*a + C2*(b - M) + C3 (M = k3 or 0) */
+#define UNCR_EW_SE_POOL4 17        /* SE_POOL, four chunks of a plane per block: the same partial slots and values (P % 4096 == 0) */
 
 int uncr_version(void);
 

@@ -51,6 +51,31 @@ def test_ew_stats_and_norm_finalize(E, orc):
     close("bn_eval_apply", y, orc.batch_norm(x, gam, bet, rm, rv, False))
 
 
+@pytest.mark.parametrize("act", ["fp32", "bf16"])
+def test_se_pool_four_chunks_per_block_is_bit_identical(E, act):
+    """uncr_ew op 17 (se_pool4_kernel: four loads in flight per lane) against op 7: the same partial slots, the same bits; and
+    both against gelu in fp64."""
+    N, C, H, W = 2, 24, 64, 128
+    P = H * W
+    x = rand(N, C, H, W, seed=5, scale=2.0, shift=-0.2)
+    xd = dev(x)
+    if act == "bf16":
+        xd = E.cast(xd, E.BF16)
+    A, B = dev(rand(N * C, seed=6, scale=0.7, shift=0.9)), dev(rand(N * C, seed=7))
+    p1 = E.ew(E.EW_SE_POOL, xd, k=(A, B, None, None), want_part=True, planes=N * C, P=P)[1]
+    p4 = E.ew(E.EW_SE_POOL4, xd, k=(A, B, None, None), want_part=True, planes=N * C, P=P)[1]
+    torch.cuda.synchronize()
+    assert p1.slots == p4.slots == P // 1024
+    assert torch.equal(p1.buf, p4.buf)
+    u = (A.double().view(N, C, 1, 1) * xd.double() + B.double().view(N, C, 1, 1))
+    want = (0.5 * u * (1.0 + torch.erf(u / math.sqrt(2.0)))).flatten(2).sum(-1).view(-1)
+    got = p4.buf[..., 0].double().sum(-1)
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-6
+    # a plane count / size the four-chunk kernel does not take falls back to the one-chunk kernel
+    y = dev(rand(1, 3, 32, 96, seed=8))
+    assert E.se_pool(y, A[:3], B[:3], 3, 32 * 96).slots == 3
+
+
 @pytest.mark.parametrize("Cin,Cout,pro", [(15, 128, 0), (128, 256, 1), (256, 128, 2), (128, 26, 0), (64, 256, 0),
                                            (256, 64, 0), (26, 128, 0), (128, 256, 3), (256, 128, 3), (128, 15, 3)])
 def test_pw_gemm(E, Cin, Cout, pro):

@@ -26,7 +26,7 @@ PRO_NONE, PRO_AFFINE, PRO_AFFINE_GELU, PRO_NORMBWD, PRO_AFFINE_RELU = 0, 1, 2, 3
 NORM_GROUP, NORM_BATCH_TRAIN, NORM_BATCH_EVAL = 0, 1, 2
 EW_STATS_SQ, EW_STATS_AUX, EW_AFFINE_RELU, EW_RESIDUAL, EW_PASSB, EW_PASSE, EW_RELU_BWD, EW_SE_POOL, \
     EW_HEAD_FWD, EW_HEAD_BWD = range(10)
-EW_AFFINE, EW_NORMBWD = 15, 16
+EW_AFFINE, EW_NORMBWD, EW_SE_POOL4 = 15, 16, 17
 
 Tensor = torch.Tensor
 
@@ -192,6 +192,12 @@ def ew(op: int, a: Tensor, *, b=None, c=None, aux=None, out: Optional[Tensor] = 
     return out, part
 
 
+def se_pool(h2: Tensor, A: Tensor, B: Tensor, planes: int, P: int) -> Part:
+    """Partials of sum_p gelu(A*h2 + B) per plane (SE squeeze, uncrtaints.py:82-97): P / 1024 slots per plane either way."""
+    op = EW_SE_POOL4 if (_SE_POOL4 and P % 4096 == 0 and _dt(h2) == BF16) else EW_SE_POOL
+    return ew(op, h2, k=(A, B, None, None), want_part=True, planes=planes, P=P)[1]
+
+
 def stats_sq(x: Tensor, planes: int, P: int) -> Part:
     return ew(EW_STATS_SQ, x, want_part=True, planes=planes, P=P)[1]
 
@@ -294,6 +300,10 @@ _BN_CONSUMER = True
 # in_conv (Conv2d k=1 + GroupNorm + ReLU on <= 15 input channels) without its pre-norm tensor: statistics and parameter gradients
 # from the frames' second-moment matrices (csrc/inconv.hip); False: GEMM -> finalize -> element-wise pass, c0 kept for the backward
 _INCONV_MOMENTS = True
+# SE pooling pass of the bf16-storage mode with four chunks of a plane per block (four 8-byte loads in flight per lane; bit-identical
+# partials): -16 ... -20 % on the kernel behind a producer (tools/bench_sepool.py), -0.03 ms on the bf16 step (3 of 3 interleaved
+# pairs).  fp32 storage keeps one chunk per block (the four-chunk kernel is 6-7 % SLOWER there).  False: one chunk per block everywhere
+_SE_POOL4 = True
 
 # development (tools/ablate_ltae_stage.py): "record" keeps the L-TAE stage's results of the next forward / backward, "replay" hands
 # them back without launching anything -- the stage's cost inside the captured step = step time with it minus step time without it
@@ -302,7 +312,7 @@ _LTAE_STORE: Dict[str, tuple] = {}
 
 _DEV_OPTIONS = {"ltae_replay": "_LTAE_REPLAY", "side_stream": "_USE_SIDE", "centred_normbwd": "_CENTRED_NORMBWD", "h2_bwd": "_H2_BWD", "h2_wgrad": "_H2_WGRAD",
                 "h2_dx": "_H2_DX", "h2_fwd": "_H2_FWD", "prepack": "_PREPACK", "fused_dx": "_FUSED_DX", "fused_ltae": "_FUSED_LTAE",
-                "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER", "inconv_moments": "_INCONV_MOMENTS"}
+                "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER", "inconv_moments": "_INCONV_MOMENTS", "se_pool4": "_SE_POOL4"}
 
 
 class dev_options:
@@ -650,7 +660,7 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     n2 = norm_fwd(part2 if need else None, N, Ch, P, spec, training, p["n2w"], p["n2b"], *rm(2),
                   bound_part=part2 if h2ok else None)
 
-    _, ppool = ew(EW_SE_POOL, h2, k=(n2.A, n2.B, None, None), want_part=True, planes=N * Ch, P=P)
+    ppool = se_pool(h2, n2.A, n2.B, N * Ch, P)
     pooled, hid_pre, s = _f32((N, Ch), x.device), _f32((N, R), x.device), _f32((N * Ch,), x.device)
     hb.call("uncr_se_mlp_fwd", ppool.buf, ppool.slots, N, Ch, R, P, p["se1"].contiguous(), p["se2"].contiguous(),
             pooled, hid_pre, s, _stream())
@@ -751,7 +761,7 @@ def _mbconv_forward_wide(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, traini
         hb.call("uncr_dw_fwd", h1, n1.A, n1.B, wdw[o:o + n].contiguous(), h2, part2.buf if part2 is not None else None, N, n, H, W,
                 dt, _DW_VARIANT, _stream())
         n2 = norm_fwd(part2, N, n, P, gs, training, _cut(p["n2w"], o, n), _cut(p["n2b"], o, n), *rm(2, o, n))
-        _, pp = ew(EW_SE_POOL, h2, k=(n2.A, n2.B, None, None), want_part=True, planes=N * n, P=P)
+        pp = se_pool(h2, n2.A, n2.B, N * n, P)
         h1s.append(h1); h2s.append(h2); n1s.append(n1); n2s.append(n2); pools.append(pp)
     ps = pools[0].slots
     ppool = torch.cat([q.buf.view(N, n, ps, 2) for q, (_, n) in zip(pools, groups)], dim=1).contiguous()     # [N][Ch][slots]
