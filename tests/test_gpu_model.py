@@ -175,6 +175,69 @@ def test_train_step_replayed_from_a_hip_graph_equals_eager_steps():
     assert far <= 0.01 * total
 
 
+def test_eval_forward_replayed_from_a_hip_graph_follows_the_weights():
+    """config.hip_graph in the reference's validation loop (train_reconstruct.py:302-309: eval mode, no_grad, set_input, forward,
+    get_loss_G, rescale): the first forward of a shape is eager, the second is captured, later ones replay.  Replays equal the eager
+    forward bit for bit on new inputs, keep doing so after training steps moved the weights and the BatchNorm running statistics
+    (the weight packing is part of the captured launch list), re-capture for another batch size, and hand out copies of the static
+    output."""
+    from types import SimpleNamespace
+    from uncrtaints_amd.src.backbones.base_model import BaseModel
+    g = load_golden("g6_trainseq")
+    meta = json.loads(str(g["meta"]))
+    cfg = SimpleNamespace(model="uncrtaints", use_sar=True, encoder_widths=[128], decoder_widths=[128] * 5,
+                          out_conv=[26], mean_nonLinearity=True, var_nonLinearity="softplus", agg_mode="att_group",
+                          encoder_norm="group", decoder_norm="batch", n_head=16, d_model=256, d_k=4, pad_value=0,
+                          padding_mode="reflect", positional_encoding=True, covmode="diag", scale_by=meta["scale_by"],
+                          separate_out=False, use_v=False, block_type="mbconv", pretrain=False, loss="MGNLL",
+                          lr=meta["lr"], gamma=0.5, device=DEV, chunk_size=None, hip_graph=True)
+    model = BaseModel(cfg)
+    model.netG.load_state_dict(_state(g), strict=True)
+    model.to(DEV)
+    x, y, dates = (torch.from_numpy(g[k]) for k in ("x", "y", "dates"))
+    gen = torch.Generator().manual_seed(11)
+
+    def batch(n):
+        return {"A": torch.rand(x[:n].shape, generator=gen), "B": y[:n], "dates": dates[:n], "masks": None}
+
+    def validate(b):
+        model.eval()
+        with torch.no_grad():
+            model.set_input(b)
+            model.forward()
+            kept = model.fake_B
+            model.get_loss_G()
+            loss = model.loss_G.item()
+            model.rescale()
+            want = model.netG(model.scale_by * b["A"].to(DEV), batch_positions=b["dates"].to(DEV))     # the eager forward
+        assert torch.equal(kept, want)
+        return kept, loss
+
+    n = x.shape[0]
+    outs = [validate(batch(n)) for _ in range(4)]          # eager, capture, replay, replay
+    eval_graphs = [v for k, v in model._graphs.items() if k[0] == "eval_forward"]
+    assert len(eval_graphs) == 1 and eval_graphs[0]["graph"] is not None
+    assert not torch.equal(outs[2][0], outs[3][0])         # copies of the static output, not views of it
+    # training moves the weights and the running statistics in place ...
+    model.train()
+    for _ in range(3):
+        model.set_input({"A": x, "B": y, "dates": dates, "masks": None})
+        model.optimize_parameters()
+    # ... and the SAME captured graph follows them
+    validate(batch(n))
+    assert [v for k, v in model._graphs.items() if k[0] == "eval_forward"][0] is eval_graphs[0]
+    # another batch size: eager, then its own capture
+    if n > 1:
+        for _ in range(3):
+            validate(batch(1))
+        assert sum(1 for k in model._graphs if k[0] == "eval_forward") == 2
+    # a forward with autograd on stays eager (and differentiable)
+    model.eval()
+    model.set_input(batch(n))
+    model.forward()
+    assert model.fake_B.requires_grad
+
+
 def test_graph_mode_survives_an_optimizer_checkpoint_with_a_float_learning_rate():
     """Resume in graph mode from a checkpoint whose optimizer state carries `lr` as a Python float (what the reference and an eager
     run save, model_utils.py:117-196): the captured step must keep reading the learning rate from the device -- the schedule has to

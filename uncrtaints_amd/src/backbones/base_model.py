@@ -25,7 +25,7 @@ class BaseModel(nn.Module):
         # learning rate on the device (capturable), so that ExponentialLR's per-epoch update reaches the captured kernels.
         self._use_graph = bool(getattr(config, "hip_graph", False))
         self._graphs = {}            # launch-list key -> captured step (a few shapes, e.g. the smaller last batch of an epoch); LRU
-        self._graph_cap = 4
+        self._graph_cap = 6          # e.g. train / eval shapes plus the smaller last batch of each loader
         # base_model.py:48: torch.optim.Adam(params, lr).  FusedAdam IS that class (same state, checkpoints exchange with it) with the
         # update as one HIP launch over all parameters; on CPU parameters it runs torch's own step.
         from ...optim import FusedAdam
@@ -39,6 +39,12 @@ class BaseModel(nn.Module):
         self.data_parallel = None      # set to a uncrtaints_amd.parallel.BucketedDataParallel(self.netG) for multi-GPU training
 
     def forward(self):
+        # config.hip_graph also covers the reference's validation / test loops (train_reconstruct.py:302-309 under the model.eval() of :692 / :734):
+        # `model.eval(); with torch.no_grad(): model.set_input(...); model.forward()` replays the eval-mode forward from a captured
+        # HIP graph (see _graph_forward); every other call -- the training forward, a forward with autograd on -- launches eagerly.
+        if (self._use_graph and not torch.is_grad_enabled() and not self.netG.training and self.real_A is not None
+                and self.real_A.is_cuda and not torch.cuda.is_current_stream_capturing()):
+            return self._graph_forward()
         self.fake_B = self.netG(self.real_A, batch_positions=self.dates)
         self.netG.variance = None
 
@@ -168,6 +174,52 @@ class BaseModel(nn.Module):
         self.rescale()          # new tensors: the static outputs stay untouched
         self.reset_input()
         self._export()
+
+    # ---- eval-mode forward from a captured HIP graph (config.hip_graph) ---------------------------------------------------------
+    # An eager eval forward is ~70 launches enqueued from Python; at B = 1 the GPU needs a fraction of the time the host takes to
+    # enqueue them.  The first forward of a given input shape runs eagerly, the second is captured, later ones copy the batch into
+    # the static input and replay.  What the replay reads through raw pointers -- parameters, BatchNorm running statistics -- is
+    # updated IN PLACE by training steps and by load_state_dict, so validation after further training replays the same graph on the
+    # new weights: the weight packing (engine.prepack / pack_wt) is part of the captured launch list (the version-keyed pack cache is
+    # emptied before the capture, so nothing packed earlier is baked in).  The key holds the parameters' addresses: a model moved or
+    # re-created is captured afresh.  `fake_B` is a copy of the static output (the caller may keep it across iterations).
+    def _graph_forward(self):
+        key = ("eval_forward", tuple(self.real_A.shape), self.real_A.dtype, None if self.dates is None else tuple(self.dates.shape),
+               tuple(p.data_ptr() for p in self.netG.parameters()))
+        g = self._graphs.pop(key, None)
+        if g is None:
+            g = dict(key=key, eager_left=1, graph=None)
+            while len(self._graphs) >= self._graph_cap:
+                self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[key] = g
+        if g["eager_left"] > 0:
+            g["eager_left"] -= 1
+            self.fake_B = self.netG(self.real_A, batch_positions=self.dates)
+            self.netG.variance = None
+            return
+        cur = torch.cuda.current_stream()
+        if g["graph"] is None:
+            if getattr(self, "_gstream", None) is None:
+                self._gstream = torch.cuda.Stream(device=self.real_A.device)
+            from ... import engine
+            self._gstream.wait_stream(cur)
+            with torch.cuda.stream(self._gstream):
+                g["A"] = self.real_A.clone()
+                g["dates"] = None if self.dates is None else self.dates.clone()
+                engine._PACK_CACHE.clear()
+                graph = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph, stream=self._gstream):
+                    g["out"] = self.netG(g["A"], batch_positions=g["dates"])
+            cur.wait_stream(self._gstream)
+            g["graph"] = graph
+        else:
+            g["A"].copy_(self.real_A)
+            if g["dates"] is not None:
+                g["dates"].copy_(self.dates)
+        g["graph"].replay()
+        self.fake_B = g["out"].clone()
+        self.netG.variance = None
 
     def _export(self):
         if self.netG.training and getattr(self.config, "export_to_host", False):
