@@ -41,6 +41,10 @@ def profile_tag(name, args):
     return name
 
 
+# activation tensors an uncr_ew launch streams (inputs + output), by op code (include/uncr_hip.h UNCR_EW_*)
+EW_TENSORS = {0: 1, 1: 2, 2: 2, 3: 3, 4: 3, 5: 4, 6: 3, 7: 1, 8: 2, 9: 3, 10: 3, 11: 2, 12: 3, 13: 2, 14: 3, 15: 2, 16: 3, 17: 1}
+
+
 def _alias(name, key):
     if name in ALIASES:
         base, drop = ALIASES[name]
@@ -55,11 +59,11 @@ def kernel_model(name, key):
     if name == "uncr_pw_gemm":
         bias_stride, N, Cin, Cout, P, pro, epi, in_dt, out_dt = key[:9]      # (then the counts of the magnitude arrays)
         bi, bo = (2.0 if in_dt else 4.0), (2.0 if out_dt else 4.0)
-        rd = Cin * (2 if pro == PRO_NORMBWD else 1) * bi + (Cout * bo if epi in (2, 3) else 0)
+        rd = Cin * (2 if pro == PRO_NORMBWD else 1) * bi + (Cout * bo if epi in (2, 3, 10) else 0)
         # products per fp32 MAC on the 16-bit matrix pipe: 2 with bf16 storage, 3 for the fp16 two-part forward GEMMs (norm prologue,
         # statistics epilogue: DESIGN 4.1b), 6 for the exact bf16 split
         # (the call carried magnitude bounds for its activation operand: their counts follow in the key)
-        h2 = (not in_dt) and pro in (1, 2) and epi in (0, 1) and len(key) > 9 and key[9] > 0
+        h2 = (not in_dt) and pro in (1, 2) and epi in (0, 1, 10) and len(key) > 9 and key[9] > 0
         # ... and for the dz GEMM of the MBConv backward when both magnitude arrays were passed
         h2 = h2 or ((not in_dt) and pro == PRO_NORMBWD and epi == 3 and len(key) > 10 and key[9] > 0 and key[10] > 0)
         return (f"pw_gemm[{Cin}->{Cout},pro{pro},epi{epi},N{N},P{P}]", N * P * (rd + Cout * bo), 2.0 * N * P * Cin * Cout,
@@ -90,9 +94,9 @@ def kernel_model(name, key):
         return (f"dw_bwd[N{N},C{C},{H}x{W}]", (2.0 if act else 4.0) * N * C * H * W * 4, 36.0 * N * C * H * W, 0)
     if name == "uncr_ew":
         op, planes, P, C, n_mean, act = key
-        tensors = {0: 1, 1: 2, 2: 2, 3: 3, 4: 3, 5: 4, 6: 3, 7: 1, 8: 2, 9: 3}[op]
+        tensors = EW_TENSORS[op]
         nbytes = (2.0 if act else 4.0) * planes * P * tensors
-        if op == 9:        # head backward: two fp32 inputs, output in the activation storage
+        if op in (9, 12, 14):        # head backward: two fp32 inputs, output in the activation storage
             nbytes = planes * P * (8.0 + (2.0 if act else 4.0))
         return (f"ew[op{op},planes{planes},P{P}]", nbytes, 0.0, 0)
     if name == "uncr_aggregate_fwd":
@@ -112,7 +116,7 @@ def written_fraction(name, key):
     if name == "uncr_pw_gemm":
         bias_stride, N, Cin, Cout, P, pro, epi, in_dt, out_dt = key[:9]
         bi, bo = (2.0 if in_dt else 4.0), (2.0 if out_dt else 4.0)
-        rd = Cin * (2 if pro == PRO_NORMBWD else 1) * bi + (Cout * bo if epi in (2, 3) else 0)
+        rd = Cin * (2 if pro == PRO_NORMBWD else 1) * bi + (Cout * bo if epi in (2, 3, 10) else 0)
         return Cout * bo / (rd + Cout * bo)
     if name in ("uncr_pw_gemm_dx", "uncr_pw_gemm_dx:relu_x"):
         N, Cin, Cout, P, act = key[:5]
@@ -124,7 +128,7 @@ def written_fraction(name, key):
     if name == "uncr_dw_bwd":
         return 0.25
     if name == "uncr_ew":
-        tensors = {0: 1, 1: 2, 2: 2, 3: 3, 4: 3, 5: 4, 6: 3, 7: 1, 8: 2, 9: 3}[key[0]]
+        tensors = EW_TENSORS[key[0]]
         return 0.0 if tensors == 1 else 1.0 / tensors
     if name == "uncr_aggregate_fwd":
         T = key[-8]

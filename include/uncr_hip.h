@@ -141,13 +141,15 @@ int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, void* out, co
                  const float* k1, const float* k2, const float* kmu /* PRO_NORMBWD: mean array or null */,
                  const float* bias, int bias_stride_n, const void* aux,
                  const float* e0, const float* e1, const float* e2, const float* e3 /* epi 3 coefficients; epi 9 (Cout > 64, pro NONE):
-                 out = relu(e0*(v + bias) + e1) per (frame, output channel) with (sum, sum^2) statistics of the result */,
+                 out = relu(e0*(v + bias) + e1) per (frame, output channel) with (sum, sum^2) statistics of the result; epi 10
+                 (64 < Cout <= 128, pro AFFINE_GELU): out = aux + e0*(v + bias) + e1 with the same statistics -- the closing
+                 BatchNorm of an eval-mode MBConv (running statistics) and its skip, uncrtaints.py:121-146, on the accumulator */,
                  float* part, int N, int Cin, int Cout, int P, int pro, int epi, int in_dt, int out_dt,
                  /* magnitude bookkeeping for the fp16 two-part split (all nullable / 0; Cout > 64, fp32 storage):
                   * amax_out [N][uncr_pw_stat_slots]: per-block max |stored output| (Cout <= 128 with epi 1 / 2);
                   * pro NORMBWD + epi 3 (Cout 256): in_amax [N][in_amax_n], in2_amax [N][in2_amax_n] = such arrays (or any
                   *   per-frame upper bounds) of the two prologue operands;
-                  * pro AFFINE / AFFINE_GELU + epi 0 / 1: in_amax [N][in_amax_n = Cin] = upper bounds on |k0*in + k1| per plane
+                  * pro AFFINE / AFFINE_GELU + epi 0 / 1 / 10: in_amax [N][in_amax_n = Cin] = upper bounds on |k0*in + k1| per plane
                   *   (uncr_norm_finalize_fwd's `ub` output), in2_amax unused.
                   * With the bounds given the GEMM multiplies in two fp16 parts scaled by a per-frame power of two derived from
                   * them; without, in the exact bf16 split */

@@ -32,6 +32,19 @@ def test_stream_roof_interpolation_and_written_share():
     assert b.written_fraction("uncr_pw_wgrad", (4, 256, 128, 65536, 64, 3, 1, 0)) == 0.0
     label, nbytes, flops, prod = b.kernel_model("uncr_pw_gemm_dx", (4, 256, 128, 65536, 0, 1, 1))
     assert nbytes == 4.0 * 4 * 65536 * (2 * 256 + 4 * 128) and prod == 3 and "pw_gemm_dx" in label
+    # every element-wise op code of include/uncr_hip.h has a byte model (the bf16 leg launches op 17, the four-chunk SE pooling pass)
+    import re
+    hdr = open(os.path.join(ROOT, "include", "uncr_hip.h")).read()
+    ops = sorted(int(v) for v in re.findall(r"#define UNCR_EW_\w+ (\d+)", hdr))
+    assert ops and set(ops) <= set(b.EW_TENSORS)
+    for op in ops:
+        label, nbytes, _, _ = b.kernel_model("uncr_ew", (op, 1024, 65536, 256, 0, 1))
+        assert nbytes > 0 and 0.0 <= b.written_fraction("uncr_ew", (op, 1024, 65536, 256, 0, 1)) <= 0.5
+    assert b.kernel_model("uncr_ew", (17, 1024, 65536, 256, 0, 1))[1] == 2.0 * 1024 * 65536
+    # eval-mode MBConv tail (epi 10): pw2 reads its 256 input rows and the 128 skip rows, writes 128
+    _, nb10, _, prod10 = b.kernel_model("uncr_pw_gemm", (0, 4, 256, 128, 65536, 2, 10, 0, 0, 256, 0))
+    assert nb10 == 4.0 * 4 * 65536 * (256 + 128 + 128) and prod10 == 3
+    assert abs(b.written_fraction("uncr_pw_gemm", (0, 4, 256, 128, 65536, 2, 10, 0, 0, 256, 0)) - 0.25) < 1e-9
 
 
 def test_power_sampler_parses_rocm_smi(monkeypatch):

@@ -523,8 +523,11 @@ extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, vo
     if (pro == PRO_NORMBWD && !in2) return UNCR_EINVAL;
     // epi 9: out = relu(e0*(v + bias) + e1) with (sum, sum^2) statistics -- a ConvLayer's norm + ReLU applied to the accumulator
     // (wide kernels, no prologue; csrc/inconv.hip)
-    if (epi < 0 || (epi > 4 && epi != 9)) return UNCR_EINVAL;
+    // epi 10: out = aux + e0*(v + bias) + e1 with (sum, sum^2) statistics -- an eval-mode MBConv's closing BatchNorm and skip applied
+    // to the accumulator of pw2 (wide kernels, 65..128 output channels, GELU prologue)
+    if (epi < 0 || (epi > 4 && epi != 9 && epi != 10)) return UNCR_EINVAL;
     if (epi == 9 && (!use_split(Cout) || pro != PRO_NONE || !e0 || !e1)) return UNCR_EINVAL;
+    if (epi == 10 && (!use_split(Cout) || pw_coutp(Cout) != 128 || pro != PRO_AFFINE_GELU || !e0 || !e1 || !aux)) return UNCR_EINVAL;
     if (epi && epi != 4 && !part) return UNCR_EINVAL;
     if ((epi == 2 || epi == 3) && !aux) return UNCR_EINVAL;
     if (epi == 3 && (!e0 || !e1 || !e2 || !e3)) return UNCR_EINVAL;

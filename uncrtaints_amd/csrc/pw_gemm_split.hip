@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
     __shared__ __attribute__((aligned(16))) unsigned char xs[2][NPA * 8192];
     __shared__ float cf[PRO == PRO_NORMBWD ? 4 : 3][256];      // [3]: the norm's mean (centred norm backward)
     __shared__ float red[COUTP][2];
-    __shared__ float ecf[(EPI == 5 || EPI == 6 || EPI == 8) ? 6 : (EPI == 3 ? 5 : (EPI == 9 ? 3 : 1))][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D ([5]: epi 5 / 6 / 8 mean); epi 9: A, B
+    __shared__ float ecf[(EPI == 5 || EPI == 6 || EPI == 8) ? 6 : (EPI == 3 ? 5 : ((EPI == 9 || EPI == 10) ? 3 : 1))][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D ([5]: epi 5 / 6 / 8 mean); epi 9 / 10: A, B
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar: row addresses stay in SGPRs
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                 { const float m = (g.emu ? g.emu : g.e2)[ci]; ecf[5][c] = g.emu ? m : 0.f; }
                 if constexpr (EPI == 6) { ecf[0][c] = g.bias[ci]; ecf[4][c] = g.e3[ci]; }   // ReLU mask: e3*aux3 + bias > 0
             }
-            if constexpr (EPI == 9) {      // out = relu(A*(v + bias) + B): a ConvLayer's norm + ReLU on the fresh accumulator
+            if constexpr (EPI == 9 || EPI == 10) {      // 9: out = relu(A*(v + bias) + B): a ConvLayer's norm + ReLU on the fresh accumulator; 10: out = aux + A*(v + bias) + B
                 const int ci = n * Cout + cc;
                 ecf[1][c] = g.e0[ci]; ecf[2][c] = g.e1[ci];
             }
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
 #define PWS_EPI_RB 8
 #endif
             constexpr int RB = SKIP ? 4 : ((EPI == 2 || EPI == 3) ? PWS_EPI_RB : 8);     // rows per request batch (epi 5 reads three rows per output row)
-            constexpr bool AUX = EPI == 2 || EPI == 3 || EPI == 4 || SKIP;
+            constexpr bool AUX = EPI == 2 || EPI == 3 || EPI == 4 || EPI == 10 || SKIP;
             constexpr int NBAT = CT * 16 / RB;                      // batches of the tile: (ct, rb) = (bi / (16 / RB), RB * (bi % (16 / RB)))
             // PWS_EPI_PIPE: the operand rows of batch bi + 1 are requested BEFORE batch bi is transformed (two register sets), so the
             // epilogue's VALU work (pass-B: GELU' on every element) runs under the next batch's HBM latency instead of behind it
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                         xa[S][q] = ld4<TA>((const TA*)g.out + (size_t)(nco + rc) * P + loff);
                     }
                 }
-                if constexpr (EPI == 2 || EPI == 3) {
+                if constexpr (EPI == 2 || EPI == 3 || EPI == 10) {
 #pragma unroll
                     for (int q = 0; q < RB; ++q) {
                         const int rw = row_of(ct, rb + q);            // rows past Cout (padded tiles) re-read the last valid row
@@ -643,6 +643,17 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
                     } else if constexpr (EPI == 1) {
+                        v = rnd4<TA>(v);
+                        s0 = v.x + v.y + v.z + v.w;
+                        s1 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                    } else if constexpr (EPI == 10) {
+                        // an eval-mode MBConv's closing BatchNorm (running statistics: a fixed affine map) and its skip on the fresh
+                        // accumulator: y = x + A*h3 + B (uncrtaints.py:145: x + self.conv(x)), the arithmetic of ew_kernel<EW_RESIDUAL>
+                        // on an h3 that is never stored; statistics of y as that kernel takes them
+                        const float4 x = xa[S][q];
+                        const float eA = ecf[1][col], eB = ecf[2][col];
+                        v.x = x.x + fmaf(eA, v.x, eB); v.y = x.y + fmaf(eA, v.y, eB);
+                        v.z = x.z + fmaf(eA, v.z, eB); v.w = x.w + fmaf(eA, v.w, eB);
                         v = rnd4<TA>(v);
                         s0 = v.x + v.y + v.z + v.w;
                         s1 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
@@ -901,7 +912,7 @@ static void pws_launch_epi(const PwArgs& g, dim3 grid, int cp, hipStream_t strea
     // (bf16 storage alike: depth 2 spills with the double-buffered A fragments)
 #if PWS_PRO == 1 || PWS_PRO == 2
     // forward GEMMs behind a norm prologue, fp32 storage: the fp16 two-part split (three products instead of six)
-    if constexpr ((EPI == 0 || EPI == 1) && sizeof(TA) == 4) {      // epi 0: the same GEMMs in eval mode behind a BatchNorm (running statistics)
+    if constexpr ((EPI == 0 || EPI == 1 || EPI == 10) && sizeof(TA) == 4) {      // epi 0: the same GEMMs in eval mode behind a BatchNorm (running statistics)
         if (g.h2 && g.in_amax && g.in_amax_n > 0) {
             if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, PWS_H2_DEPTH_CT2, TA, true>), grid, dim3(256), 0, stream, g);
             else hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 2, TA, true>), grid, dim3(256), 0, stream, g);
@@ -980,6 +991,11 @@ static int pws_launch_t(const PwArgs& g, int N, int cp, hipStream_t stream) {
             else
                 hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, 8, 2, TA>), grid, dim3(256), 0, stream, g);
             break;
+#endif
+#if PWS_PRO == 2
+        case 10:     // eval-mode MBConv tail: closing BatchNorm + skip on the accumulator of pw2 (256 -> <= 128 channels)
+            if (cp != 128) return UNCR_EINVAL;
+            pws_launch_epi<10, TA>(g, grid, cp, stream); break;
 #endif
 #if PWS_PRO == 0
         case 9:      // a ConvLayer's norm + ReLU on the accumulator (in_conv without its pre-norm tensor, csrc/inconv.hip)

@@ -304,6 +304,9 @@ _INCONV_MOMENTS = True
 # partials): -16 ... -20 % on the kernel behind a producer (tools/bench_sepool.py), -0.03 ms on the bf16 step (3 of 3 interleaved
 # pairs).  fp32 storage keeps one chunk per block (the four-chunk kernel is 6-7 % SLOWER there).  False: one chunk per block everywhere
 _SE_POOL4 = True
+# inference: an eval-mode MBConv's closing BatchNorm + skip in the epilogue of its pw2 GEMM (uncr_pw_gemm epi 10); False: GEMM, then the
+# element-wise residual pass (tests: the two are bit-identical in fp32 storage)
+_EVAL_TAIL = True
 
 # development (tools/ablate_ltae_stage.py): "record" keeps the L-TAE stage's results of the next forward / backward, "replay" hands
 # them back without launching anything -- the stage's cost inside the captured step = step time with it minus step time without it
@@ -312,7 +315,7 @@ _LTAE_STORE: Dict[str, tuple] = {}
 
 _DEV_OPTIONS = {"ltae_replay": "_LTAE_REPLAY", "side_stream": "_USE_SIDE", "centred_normbwd": "_CENTRED_NORMBWD", "h2_bwd": "_H2_BWD", "h2_wgrad": "_H2_WGRAD",
                 "h2_dx": "_H2_DX", "h2_fwd": "_H2_FWD", "prepack": "_PREPACK", "fused_dx": "_FUSED_DX", "fused_ltae": "_FUSED_LTAE",
-                "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER", "inconv_moments": "_INCONV_MOMENTS", "se_pool4": "_SE_POOL4"}
+                "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER", "inconv_moments": "_INCONV_MOMENTS", "se_pool4": "_SE_POOL4", "eval_tail": "_EVAL_TAIL"}
 
 
 class dev_options:
@@ -545,7 +548,7 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
         use_in = in_amax is not None and in2_amax is not None and _H2_BWD and epi == 3 and fp32_wide
         n1, n2 = (in_amax.shape[1], in2_amax.shape[1]) if use_in else (0, 0)
     else:
-        use_in = in_amax is not None and _H2_FWD and pro in (PRO_AFFINE, PRO_AFFINE_GELU) and epi in (0, 1) and fp32_wide
+        use_in = in_amax is not None and _H2_FWD and pro in (PRO_AFFINE, PRO_AFFINE_GELU) and epi in (0, 1, 10) and fp32_wide
         if use_in and in_amax.numel() != N * Cin:
             raise RuntimeError("pw_gemm: in_amax of an affine prologue must hold one bound per (frame, input channel)")
         n1, n2, in2_amax = (Cin if use_in else 0), 0, None
@@ -616,8 +619,10 @@ MB_KEYS = ("n0w", "n0b", "w1", "n1w", "n1b", "wdw", "n2w", "n2b", "se1", "se2", 
 
 def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bool,
                    x_part: Optional[Part] = None, buffers: Optional[Dict[str, Tensor]] = None,
-                   want_out_stats: bool = True, x_h3: Optional[Tensor] = None, pool: Optional[int] = None):
+                   want_out_stats: bool = True, x_h3: Optional[Tensor] = None, pool: Optional[int] = None,
+                   inference: bool = False):
     """x [N,C,H,W] -> y, saved-for-backward dict, partial stats of y (for the next PreNorm).
+    inference: no gradient will be asked of this call (the saved dict may then be empty).
     `buffers` holds BatchNorm running_mean/var tensors keyed n{0..3}rm / n{0..3}rv (updated in place).
     pool: also return AdaptiveMaxPool2d((pool, pool))(y) and its argmax as saved["ypool"] (last encoder block: the
     L-TAE stage's pooling, uncrtaints.py:403-404, taken inside the residual kernel where the shape allows)."""
@@ -666,6 +671,14 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
             pooled, hid_pre, s, _stream())
 
     W2t = pack_wt(p["w2"].reshape(C, Ch), transpose=True)
+    if (_EVAL_TAIL and inference and not need and pool is None and 64 < C <= 128
+            and spec.code(training) == NORM_BATCH_EVAL):
+        # inference (eval-mode BatchNorm, no autograd): norm 3 is a fixed affine map, so it and the skip ride on pw2's epilogue
+        # (uncr_pw_gemm epi 10: the element-wise residual kernel's arithmetic and statistics on an h3 that is never stored)
+        n3 = norm_fwd(None, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))
+        y, party = pw_gemm(h2, W2t, N, Ch, C, P, pro=PRO_AFFINE_GELU, k=(n2.A, n2.B, s), epi=10, aux=x,
+                           ek=(n3.A, n3.B, None, None), in_amax=n2.ub)
+        return y.view(N, C, H, W), dict(ypool=None, h3=None, dims=(N, C, Ch, R, H, W)), (party if want_out_stats else None)
     h3, part3 = pw_gemm(h2, W2t, N, Ch, C, P, pro=PRO_AFFINE_GELU, k=(n2.A, n2.B, s), epi=1 if need else 0, want_amax=True,
                         in_amax=n2.ub)
     n3 = norm_fwd(part3, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))

@@ -109,12 +109,15 @@ class SE(nn.Module):
 
 class _MBConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, module, *params):
+    def forward(ctx, x, module, inference, *params):
+        # inference: the caller ran with autograd off (torch.no_grad(): validation / test loops).  It cannot be read here -- grad mode
+        # is always off inside Function.forward, and needs_input_grad reports the parameters' requires_grad whatever the mode
         p = dict(zip(E.MB_KEYS, params))
         x = x.contiguous()
         y, sv, party = E.mbconv_forward(x, p, module._spec, module.training, getattr(x, "_uncr_part", None),
                                         module._bn_buffers(), want_out_stats=True,
-                                        x_h3=getattr(x, "_uncr_h3", None), pool=getattr(x, "_uncr_pool", None))
+                                        x_h3=getattr(x, "_uncr_h3", None), pool=getattr(x, "_uncr_pool", None),
+                                        inference=bool(inference))
         sv["x_relu"] = getattr(x, "_uncr_relu", None)     # x is in_conv's relu(norm(c0)): (c0, A, B)
         ctx.sv, ctx.p = sv, p
         ctx.versions = tuple(None if t is None else t._version for t in params)
@@ -139,7 +142,7 @@ class _MBConvFn(torch.autograd.Function):
         dx, g, dx_part = E.mbconv_backward(dy, ctx.sv, ctx.p, need_dx=ctx.needs_input_grad[0], dy_part=part)
         E.tag_part(dx, dx_part)
         # norms without affine parameters (InstanceNorm2d) were passed as None: no gradient slot for them
-        return (dx, None) + tuple(g[k] if ctx.needs_input_grad[2 + i] else None for i, k in enumerate(E.MB_KEYS))
+        return (dx, None, None) + tuple(g[k] if ctx.needs_input_grad[3 + i] else None for i, k in enumerate(E.MB_KEYS))
 
 
 class MBConv(TemporallySharedBlock):
@@ -185,7 +188,7 @@ class MBConv(TemporallySharedBlock):
                 f[6].fc[0].weight, f[6].fc[2].weight, f[7].weight, n3.weight, n3.bias)
 
     def forward(self, x):
-        y = _MBConvFn.apply(x, self, *self._params())
+        y = _MBConvFn.apply(x, self, not torch.is_grad_enabled(), *self._params())
         if self.training and not getattr(self, "_nbt_deferred", False):
             for m in self._norms():
                 if isinstance(m, nn.BatchNorm2d):
