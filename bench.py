@@ -25,7 +25,23 @@ FP32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 / _f16 dense peak (what the split GEMMs really run on: 6, 3 or 2 products)
 
 PRO_NORMBWD = 3
-TRAFFIC_FILE = "r04e_traffic.json"         # fp32 storage; bf16 storage: r04e_traffic_bf16.json (tools/measure_traffic.sh <tag> [bf16])
+def traffic_file(bf16=False):
+    """The newest profiles/<tag>_traffic[_bf16].json (tools/measure_traffic.sh <tag> [bf16]) that was measured on the present kernel
+    sources (its `_source_sha`), else the newest one (the caller then reports why the number is null)."""
+    import glob
+    from uncrtaints_amd.build import source_sha
+    suffix = "_traffic_bf16.json" if bf16 else "_traffic.json"
+    cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*" + suffix))
+                   if bf16 or not f.endswith("_traffic_bf16.json"))
+    sha = source_sha()
+    for f in reversed(cands):
+        try:
+            with open(f) as fh:
+                if json.load(fh).get("_source_sha") == sha:
+                    return os.path.basename(f)
+        except (OSError, ValueError):
+            continue
+    return os.path.basename(cands[-1]) if cands else "none_traffic.json"
 
 
 # entry points that are another profiled kernel plus a consumer-side BatchNorm finalisation (csrc/bn_inline.h): same byte model;
@@ -711,7 +727,7 @@ def main():
             res["roofline"]["algorithmic_bytes"] = int(top["bytes"])
             try:
                 from uncrtaints_amd.build import source_sha
-                tfile = TRAFFIC_FILE.replace(".json", "_bf16.json") if bf16 else TRAFFIC_FILE
+                tfile = traffic_file(bf16)
                 with open(os.path.join(ROOT, "profiles", tfile)) as fh:
                     trj = json.load(fh)
                 tr = trj.get(top["kernel"])

@@ -21,23 +21,7 @@ python bench.py > gpurun_out/${tag}_bench_fp32.json 2> gpurun_out/${tag}_bench_f
 python bench.py --no-cpu-baseline --act-dtype bf16 > gpurun_out/${tag}_bench_bf16.json 2> gpurun_out/${tag}_bench_bf16.err
 tools/profile_bench.sh ${tag}_fp32 > gpurun_out/${tag}_prof_fp32.log 2>&1
 tools/profile_bench.sh ${tag}_bf16 --act-dtype bf16 > gpurun_out/${tag}_prof_bf16.log 2>&1
-# launches per step: the same trace with twice the steps; the difference leaves the set-up launches (optimizer state, buffers) out
-STEPS=20 tools/profile_bench.sh ${tag}_fp32x2 > gpurun_out/${tag}_prof_fp32x2.log 2>&1
-python - <<PY
-import csv, json
-def load(f):
-    return {r["Name"]: (int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(f))}
-a, b = load("gpurun_out/${tag}_fp32_kernel_stats.csv"), load("gpurun_out/${tag}_fp32x2_kernel_stats.csv")
-per = {k: ((b[k][0] - a.get(k, (0, 0))[0]) / 10.0, (b[k][1] - a.get(k, (0, 0))[1]) / 10.0 / 1e3) for k in b}
-per = {k: v for k, v in per.items() if v[0] > 0}
-small = {k: v for k, v in per.items() if v[1] / v[0] < 30.0}
-out = {"launches_per_step": sum(v[0] for v in per.values()), "kernel_us_per_step": sum(v[1] for v in per.values()),
-       "launches_under_30us": sum(v[0] for v in small.values()), "us_in_launches_under_30us": sum(v[1] for v in small.values()),
-       "method": "rocprofv3 kernel stats of bench.py at 20 steps minus the same at 10 steps, divided by 10",
-       "per_kernel": {k: [round(v[0], 2), round(v[1], 1)] for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])}}
-json.dump(out, open("gpurun_out/${tag}_launches.json", "w"), indent=1)
-print("launches/step", out["launches_per_step"], "under 30 us:", out["launches_under_30us"], round(out["us_in_launches_under_30us"], 1), "us")
-PY
+tools/launch_count.sh $tag
 python - <<PY
 import json
 for f in ("gpurun_out/${tag}_bench_fp32.json", "gpurun_out/${tag}_bench_bf16.json"):
