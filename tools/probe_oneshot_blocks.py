@@ -1,0 +1,20 @@
+import sys, torch
+sys.path.insert(0, "/root/repo")
+from uncrtaints_amd import hip_backend as hb
+dev = hb.dev_lib()
+n = 1 << 28
+bufs = [torch.empty(n, device="cuda", dtype=torch.float32).normal_() for _ in range(5)]
+s = torch.cuda.current_stream().cuda_stream
+for mode, name in ((0, "read_only"), (3, "2r_1w")):
+    for nt in (0, 1):
+        for blocks in (2048, 8192, 16384, 65536, 262144):
+            def run():
+                rc = dev.fn["uncr_debug_stream_probe"](*[b.data_ptr() for b in bufs], n, mode, nt, blocks, s); assert rc == 0
+            for _ in range(3): run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): run()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            nb = (1 if mode == 0 else 3) * n * 4
+            print(f"{name} nt={nt} blocks={blocks}: {ms*1e3:.0f} us  {nb/ms/1e9:.2f} TB/s  (float4 per thread: {n/4/blocks/256:.0f})", flush=True)

@@ -174,6 +174,80 @@ __global__ __launch_bounds__(256) void pool_scatter_stats_kernel(const float* __
         if (threadIdx.x == 0) amax_out[(size_t)plane * gridDim.x + blockIdx.x] = fmaxf(fmaxf(mr[0], mr[1]), fmaxf(mr[2], mr[3]));
     }
 }
+// The same pass with CH chunks of a plane per block: every lane has its 2 * CH operand loads (and the CH window indices) in flight
+// before the first dependent instruction.  One 16-byte load per lane and stream in short-lived blocks reads at 4.0-5.5 TB/s on this
+// part, four at 6.5-7.1 (tools/probe_oneshot_blocks.py: the stream probe at 1 / 4 float4 per lane); the one-chunk kernel ran its
+// 805 MB at 4.0 TB/s.  The per-chunk arithmetic, the wave sums (DPP) and the in-order sum of the four waves are those of the
+// one-chunk kernel and block_sum2, the partial / maximum slots are the same ones: bit-identical results.  grid = (P / (CH * 1024), planes).
+// Measured at the step's shape (tools/bench_pool_scatter.py, de rewritten by a copy kernel before the call as the aggregation backward
+// leaves it): bf16 storage 153 -> 96 us with four chunks (8-byte loads: the one-chunk kernel is short of bytes in flight), fp32 storage
+// 200 -> 181 us with two, 191 us with four, 202 us with eight -- fp32 gains little, whatever bounds it there is not the loads in flight.
+#ifndef PSS_CH_F32
+#define PSS_CH_F32 2      // chunks per block, fp32 storage (0: the one-chunk kernel)
+#endif
+#ifndef PSS_CH_BF16
+#define PSS_CH_BF16 4     // chunks per block, bf16 storage
+#endif
+#ifndef PSS_NT
+#define PSS_NT 1      // non-temporal operand loads in the multi-chunk kernel
+#endif
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void pool_scatter_stats_multi_kernel(const float* __restrict__ dpool, const int* __restrict__ idx,
+                                                                       T* __restrict__ de, const T* __restrict__ h3,
+                                                                       float2* __restrict__ part, int H, int W, int OH, int OW,
+                                                                       float* __restrict__ amax_out) {
+    const int plane = blockIdx.y;
+    const int p0 = blockIdx.x * (CH * 1024) + threadIdx.x * 4;
+    const size_t off0 = (size_t)plane * H * W + p0;
+    float4 v[CH], hv[CH];
+    int k[CH];
+    size_t q[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        v[c] = ld4<T, PSS_NT != 0>(de + off0 + c * 1024);
+        hv[c] = ld4<T, PSS_NT != 0>(h3 + off0 + c * 1024);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int p = p0 + c * 1024;
+        const int y = p / W, x0 = p - y * W;
+        q[c] = (size_t)plane * OH * OW + (size_t)(y / (H / OH)) * OW + x0 / (W / OW);
+        k[c] = idx[q[c]] - p;
+    }
+    __shared__ float red[CH][4][2], mr[CH][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        if (k[c] >= 0 && k[c] < 4) {
+            const float d = dpool[q[c]];      // (selects, not a dynamic register index: that would put the operands in LDS)
+            v[c].x = k[c] == 0 ? v[c].x + d : v[c].x; v[c].y = k[c] == 1 ? v[c].y + d : v[c].y;
+            v[c].z = k[c] == 2 ? v[c].z + d : v[c].z; v[c].w = k[c] == 3 ? v[c].w + d : v[c].w;
+            v[c] = rnd4<T>(v[c]);
+            st4<T>(de + off0 + c * 1024, v[c]);
+        }
+        float s0 = (v[c].x + v[c].y) + (v[c].z + v[c].w);
+        float s1 = fmaf(v[c].x, hv[c].x, fmaf(v[c].y, hv[c].y, fmaf(v[c].z, hv[c].z, v[c].w * hv[c].w)));
+        s0 = wave_sum_dpp(s0);
+        s1 = wave_sum_dpp(s1);
+        if (lane == 63) { red[c][w][0] = s0; red[c][w][1] = s1; }
+        if (amax_out) {
+            float m = fmaxf(fmaxf(fabsf(v[c].x), fabsf(v[c].y)), fmaxf(fabsf(v[c].z), fabsf(v[c].w)));
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
+            if (lane == 0) mr[c][w] = m;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < CH) {
+        const int c = threadIdx.x;
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sa += red[c][i][0]; sb += red[c][i][1]; }
+        const size_t slot = (size_t)plane * (gridDim.x * CH) + blockIdx.x * CH + c;
+        part[slot] = make_float2(sa, sb);
+        if (amax_out) amax_out[slot] = fmaxf(fmaxf(mr[c][0], mr[c][1]), fmaxf(mr[c][2], mr[c][3]));
+    }
+}
 extern "C" int uncr_pool_scatter_stats_supported(int H, int W, int OH, int OW) {
     return (OH > 0 && OW > 0 && H % OH == 0 && W % OW == 0 && ((W / OW) & 3) == 0 && ((H * W) % 1024) == 0) ? 1 : 0;
 }
@@ -181,6 +255,22 @@ extern "C" int uncr_pool_scatter_stats(const float* dpool, const int* idx, void*
                                        int H, int W, int OH, int OW, int act, float* amax_out, hipStream_t stream) {
     if (planes <= 0 || !uncr_pool_scatter_stats_supported(H, W, OH, OW)) return UNCR_ESHAPE;
     if (!dpool || !idx || !de || !h3 || !part || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
+#if PSS_CH_F32 > 0
+    if (act == UNCR_F32 && (H * W) % (PSS_CH_F32 * 1024) == 0) {
+        hipLaunchKernelGGL((pool_scatter_stats_multi_kernel<float, PSS_CH_F32>), dim3(H * W / (PSS_CH_F32 * 1024), planes), dim3(256), 0,
+                           stream, dpool, idx, (float*)de, (const float*)h3, (float2*)part, H, W, OH, OW, amax_out);
+        UNCR_LAUNCH_CHECK();
+        return UNCR_OK;
+    }
+#endif
+#if PSS_CH_BF16 > 0
+    if (act == UNCR_BF16 && (H * W) % (PSS_CH_BF16 * 1024) == 0) {
+        hipLaunchKernelGGL((pool_scatter_stats_multi_kernel<bf16_t, PSS_CH_BF16>), dim3(H * W / (PSS_CH_BF16 * 1024), planes), dim3(256), 0,
+                           stream, dpool, idx, (bf16_t*)de, (const bf16_t*)h3, (float2*)part, H, W, OH, OW, amax_out);
+        UNCR_LAUNCH_CHECK();
+        return UNCR_OK;
+    }
+#endif
     UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(pool_scatter_stats_kernel<T>, dim3(H * W / 1024, planes), dim3(256), 0, stream,
                                                  dpool, idx, (T*)de, (const T*)h3, (float2*)part, H, W, OH, OW, amax_out));
     UNCR_LAUNCH_CHECK();
