@@ -192,8 +192,8 @@ class BaseModel(nn.Module):
             while len(self._graphs) >= self._graph_cap:
                 self._graphs.pop(next(iter(self._graphs)))
         self._graphs[key] = g
-        if g["eager_left"] > 0:
-            g["eager_left"] -= 1
+        if g["eager_left"] > 0 or g["graph"] is False:
+            g["eager_left"] = max(g["eager_left"] - 1, 0)
             self.fake_B = self.netG(self.real_A, batch_positions=self.dates)
             self.netG.variance = None
             return
@@ -209,10 +209,22 @@ class BaseModel(nn.Module):
                 engine._PACK_CACHE.clear()
                 graph = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(graph, stream=self._gstream):
-                    g["out"] = self.netG(g["A"], batch_positions=g["dates"])
+                try:
+                    with torch.cuda.graph(graph, stream=self._gstream):
+                        g["out"] = self.netG(g["A"], batch_positions=g["dates"])
+                except Exception as exc:      # noqa: BLE001 -- a model variant whose forward cannot be captured (a host sync in it)
+                    import warnings
+                    warnings.warn(f"config.hip_graph: the eval forward of this model could not be captured ({type(exc).__name__}: {exc}); "
+                                  "validation forwards of this shape launch eagerly")
+                    graph = False
             cur.wait_stream(self._gstream)
             g["graph"] = graph
+            if graph is False:
+                torch.cuda.synchronize()
+                g.pop("out", None)
+                self.fake_B = self.netG(self.real_A, batch_positions=self.dates)
+                self.netG.variance = None
+                return
         else:
             g["A"].copy_(self.real_A)
             if g["dates"] is not None:
