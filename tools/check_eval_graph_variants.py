@@ -1,4 +1,6 @@
-import sys, warnings; sys.path.insert(0, "/root/repo")
+"""config.hip_graph in the validation loop for the model variants: every eval forward must be captured and replay bit-identically to
+the eager forward (run on the GPU box)."""
+import sys, warnings; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from types import SimpleNamespace
 import torch
 from uncrtaints_amd.src.backbones.base_model import BaseModel

@@ -1,5 +1,7 @@
+"""The stream probe of libuncr_dev with one-shot blocks: read-only and 2r:1w streams over 1 GB with 2048 ... 262144 blocks, i.e. 128 ... 1
+float4 per lane and block lifetime (run on the GPU box; profiles/r04g_probe_oneshot_blocks.log)."""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from uncrtaints_amd import hip_backend as hb
 dev = hb.dev_lib()
 n = 1 << 28
