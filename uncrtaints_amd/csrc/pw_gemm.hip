@@ -21,12 +21,15 @@
 
 // PRE2 = false drops the second prefetch register set (PRO_NORMBWD unavailable): keeps the 32-wide
 // variant (16 prefetch float4 per lane) free of spills.
-template <int CT, int WN, int WM, bool PRE2, typename TI = float, typename TO = float>
-__global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
+// KCV: rows of the contraction axis per staged chunk (32; 16 halves the LDS image -- 32 KB per block at TP = 256 -- so that four blocks
+// instead of two share a CU: the head's 128 -> 26 GEMM has one wave per SIMD otherwise and waits for HBM at every chunk)
+template <int CT, int WN, int WM, bool PRE2, typename TI = float, typename TO = float, int KCV = 32>
+__global__ __launch_bounds__(64 * WN * WM, KCV == 32 ? 2 : 4) void pw_gemm_kernel(PwArgs g) {
     constexpr int NT = 64 * WN * WM;
     constexpr int TP = 128 * WM;
     constexpr int COUTP = 32 * CT * WN;
-    constexpr int KC = 32;
+    constexpr int KC = KCV;
+    constexpr int KS = KC / 2;                    // MFMA k-steps per chunk (32x32x2)
     constexpr int NL = (KC * TP / 4) / NT;        // float4 loads per thread per chunk
     constexpr int ROWS_PER_I = NT / (TP / 4);     // rows covered per load index
 
@@ -102,11 +105,11 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
             for (int r = 0; r < 16; ++r) acc[e][ct][r] = 0.f;
 
     const float* wbase = g.Wt + (size_t)(lane >> 5) * COUTP + wn * (CT * 32) + (lane & 31);
-    float afr[16][CT];
+    float afr[KS][CT];
 #pragma unroll
     for (int i = 0; i < NL; ++i) load_piece(i, 0);
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) afr[s][ct] = wbase[(size_t)(2 * s) * COUTP + ct * 32];
     __syncthreads();   // cf visible
@@ -116,7 +119,8 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
     for (int i = 0; i < NL; ++i) load_piece(i, nk > 1 ? 1 : 0);
     __syncthreads();
 
-    constexpr int SLOT = 16 / NL >= 1 ? 16 / NL : 1;   // MFMA k-steps between two staging pieces
+    constexpr int SLOT = KS / NL >= 1 ? KS / NL : 1;   // MFMA k-steps between two staging pieces
+    static_assert(NL <= KS, "every staging piece of the next chunk needs its own k-step");
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
         // successors are clamped instead of branched on: memory operations under (even uniform) branches make the
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
         // just-issued HBM prefetch at every staging slot.  The redundant work at the tail is harmless.
         const int k1 = kc + 1 < nk ? kc + 1 : nk - 1, k2 = kc + 2 < nk ? kc + 2 : nk - 1;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < KS; ++s) {
             const float4 b = *(const float4*)&xs[cur][2 * s + (lane >> 5)][wm * 128 + 4 * (lane & 31)];
             const float* pb = (const float*)&b;
 #pragma unroll
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(64 * WN * WM, 2) void pw_gemm_kernel(PwArgs g) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) afr[s][ct] = wbase[(size_t)(k1 * KC + 2 * s) * COUTP + ct * 32];
             // one staging piece of the next chunk every SLOT k-steps (NL pieces per chunk)
-            if constexpr (NL <= 16) {
+            if constexpr (NL <= KS) {
                 if (s % SLOT == SLOT - 1 && s / SLOT < NL) {
                     const int i = s / SLOT;
                     stage_piece(i, k1, cur ^ 1);
@@ -574,6 +578,9 @@ extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, vo
     return UNCR_OK;
 }
 
+#ifndef HEAD_KC
+#define HEAD_KC 16      // contraction rows per staged chunk of the head's <= 32-channel GEMM (32: two blocks per CU, one wave per SIMD)
+#endif
 // out_conv + output nonlinearities in one kernel (narrow fp32-MFMA GEMM, Cout <= 64): uncrtaints.py:432-445
 extern "C" int uncr_head_fwd(const void* y, const float* Wt, const float* bias, float* out, float* pre, int N, int Cin,
                              int Cout, int P, int n_mean, float scale, float eps, int var_mode, int in_dt,
@@ -590,8 +597,8 @@ extern "C" int uncr_head_fwd(const void* y, const float* Wt, const float* bias, 
         if (in_dt == UNCR_BF16) hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true, bf16_t, float>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((pw_gemm_kernel<1, 2, 2, true>), grid, dim3(256), 0, stream, g);
     } else {
-        if (in_dt == UNCR_BF16) hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false, bf16_t, float>), grid, dim3(128), 0, stream, g);
-        else hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false>), grid, dim3(128), 0, stream, g);
+        if (in_dt == UNCR_BF16) hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false, bf16_t, float, HEAD_KC>), grid, dim3(128), 0, stream, g);
+        else hipLaunchKernelGGL((pw_gemm_kernel<1, 1, 2, false, float, float, HEAD_KC>), grid, dim3(128), 0, stream, g);
     }
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
