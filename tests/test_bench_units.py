@@ -65,3 +65,22 @@ def test_power_sampler_parses_rocm_smi(monkeypatch):
     assert s["samples"] > 3 and s["avg_power_w"] == 900.0 and s["avg_sclk_mhz"] == 1999 and s["power_cap_w"] == 1400.0
     empty = b.PowerSampler(0, period_s=0.01).summary(0.0, 1.0)
     assert empty["samples"] == 0 and "note" in empty
+
+
+def test_traffic_file_follows_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py attaches PMC traffic only from a profiles/<tag>_traffic[_bf16].json measured on the present kernel sources: the newest
+    file whose `_source_sha` matches wins; without a match the newest file is named (and the line then reports traffic null)."""
+    import json
+    b = _bench()
+    from uncrtaints_amd import build
+    sha = build.source_sha()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    for tag, s_ in (("r01", "old"), ("r02", sha), ("r03", "other")):
+        (prof / f"{tag}_traffic.json").write_text(json.dumps({"_source_sha": s_}))
+        (prof / f"{tag}_traffic_bf16.json").write_text(json.dumps({"_source_sha": s_ if tag != "r02" else "stale"}))
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    assert b.traffic_file() == "r02_traffic.json"
+    assert b.traffic_file(True) == "r03_traffic_bf16.json"          # no bf16 file matches: the newest one is named
+    (prof / "r04_traffic_bf16.json").write_text(json.dumps({"_source_sha": sha}))
+    assert b.traffic_file(True) == "r04_traffic_bf16.json"
