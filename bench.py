@@ -179,6 +179,16 @@ def stream_roof_gbs(wfrac):
     return pts[-1][1]
 
 
+def stream_ratio(gbs, probe_gbs):
+    """A kernel's rate against the cold pure-stream probe of its read : write mix.  <= 1: a fraction of that roof.  > 1: the launch ran
+    above what a cold stream reaches, i.e. part of its operands came from the 256 MB Infinity Cache (its producer had just written
+    them) -- reported as cache-assisted with the ratio, never as a roofline fraction."""
+    r = gbs / probe_gbs
+    if r <= 1.0:
+        return {"frac_of_stream_roof": round(r, 4)}
+    return {"frac_of_stream_roof": None, "infinity_cache_assisted": True, "ratio_to_cold_stream_probe": round(r, 4)}
+
+
 PROFILED = ("uncr_pw_gemm", "uncr_pw_gemm_dx", "uncr_residual_pool", "uncr_pw_wgrad", "uncr_dw_fwd", "uncr_dw_bwd", "uncr_ew", "uncr_aggregate_fwd",
             "uncr_aggregate_bwd") + tuple(ALIASES)
 
@@ -296,7 +306,7 @@ class PowerSampler:
         pw, ck = [x[2] for x in s], [x[1] for x in s]
         return {"samples": len(s), "avg_power_w": round(sum(pw) / len(pw), 1), "max_power_w": max(pw), "power_cap_w": self.cap,
                 "avg_sclk_mhz": round(sum(ck) / len(ck)), "min_sclk_mhz": min(ck), "max_sclk_mhz_of_the_part": 2400,
-                "source": "rocm-smi --showclocks --showpower polled every %.2f s during the timed steps" % self.period}
+                "source": "rocm-smi --showclocks --showpower polled every %.2f s" % self.period}
 
 
 def bf16_leg(args):
@@ -323,6 +333,82 @@ def bf16_leg(args):
     if "ltae_stage" in d:
         out["ltae_stage_roofline_frac"] = d["ltae_stage"].get("roofline_frac")
     return out
+
+
+# ---- rank bookkeeping of the N > 1 launch (one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from torch.distributed.run).
+#      Plain functions so that a gloo world of 8 CPU processes can run them (tests/test_parallel_gloo.py): the first real 8-GPU run
+#      must not fail on plumbing.
+
+def rank_env(gpus_flag):
+    """(world, rank, local_rank) from the launcher's environment; --gpus N > 1 must agree with WORLD_SIZE."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if gpus_flag > 1 and world != gpus_flag:
+        raise SystemExit(f"--gpus {gpus_flag} needs torch.distributed.run with WORLD_SIZE={gpus_flag} (got {world})")
+    if not 0 <= rank < world:
+        raise SystemExit(f"RANK={rank} outside WORLD_SIZE={world}")
+    return world, rank, local_rank
+
+
+def check_roster(seen, world, backend):
+    """One rank per GPU: over RCCL every rank must sit on a different device (the gloo development mode shares cuda:0)."""
+    if len(seen) != world or any(s is None for s in seen):
+        raise SystemExit(f"device roster incomplete: {seen}")
+    if backend == "nccl" and len(set(seen)) != world:
+        raise SystemExit(f"{world} ranks but only {len(set(seen))} distinct devices: {seen}")
+
+
+def join_ranks(backend, rank, world, device, identity, device_name):
+    """Create the process group and return the `collective` header of the result line: every rank reports the device it sits on
+    (`identity`), rank bookkeeping is checked on every rank."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", str(rank))
+    os.environ.setdefault("WORLD_SIZE", str(world))
+    # fail fast: a collective error or a lost rank must end the run, not hang it (the driver times the whole command)
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+    os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "0")
+    tmo = datetime.timedelta(seconds=int(os.environ.get("UNCR_BENCH_COLL_TIMEOUT_S", "180")))
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=device, timeout=tmo)
+    else:
+        dist.init_process_group(backend, timeout=tmo)
+    if dist.get_world_size() != world or dist.get_rank() != rank:
+        raise SystemExit(f"process group disagrees with the environment: rank {dist.get_rank()}/{dist.get_world_size()} vs {rank}/{world}")
+    seen = [None] * world
+    dist.all_gather_object(seen, identity)
+    check_roster(seen, world, backend)
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:      # noqa: BLE001
+            ver = None
+    return {"devices": seen, "rccl_version": ver, "device_name": device_name}
+
+
+def max_over_ranks(dt, device):
+    """The timed region's length as the job sees it: the slowest rank's."""
+    import torch.distributed as dist
+    tt = torch.tensor([dt], device=device, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def job_value(world, batch_per_gpu, steps, dt):
+    """Whole-job samples/s: weak scaling, every rank processed batch_per_gpu samples per step."""
+    return world * batch_per_gpu * steps / dt
+
+
+def collective_object(dist_info, dp, coll_wait):
+    """N > 1: what travels (one fp32 bucket per backward segment, all-reduce AVG), on which devices, and how long the compute stream
+    stood still for it per step (HIP events around the waits in finish(): 0 = fully hidden behind the backward)."""
+    return dict(dist_info, bucket_bytes=dp.bucket_bytes(), all_reduces_per_step=len(dp.buckets),
+                wait_ms_per_step=round(sum(coll_wait) / max(len(coll_wait), 1), 4),
+                wait_ms_max=round(max(coll_wait), 4) if coll_wait else None)
 
 
 def main():
@@ -355,11 +441,7 @@ def main():
             dev_opts[k] = int(v) if k == "dw_variant" else bool(int(v))
         _engine.dev_options(**dev_opts).__enter__()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
+    world, rank, local_rank = rank_env(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # UNCR_BENCH_BACKEND=gloo: development switch to exercise the N > 1 code path on a single-GPU box (all ranks on
@@ -376,31 +458,9 @@ def main():
     # capture / replay pattern of the multi-GPU step on a single-GPU box (tests/test_gpu_ddp.py).
     dp_mode = world > 1 or os.environ.get("UNCR_BENCH_FORCE_DP") == "1"
     if dp_mode:
-        import datetime
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", str(rank))
-        os.environ.setdefault("WORLD_SIZE", str(world))
-        # fail fast: a collective error or a lost rank must end the run, not hang it (the driver times the whole command)
-        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
-        os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "0")
-        tmo = datetime.timedelta(seconds=int(os.environ.get("UNCR_BENCH_COLL_TIMEOUT_S", "180")))
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device, timeout=tmo)
-        else:
-            dist.init_process_group(backend, timeout=tmo)
-        # one rank per GPU: every rank reports the device it sits on, rank 0 checks that they are all different
         props = torch.cuda.get_device_properties(device)
         me = f"{os.uname().nodename}:{getattr(props, 'uuid', None) or getattr(props, 'pci_bus_id', None) or local_rank}:{local_rank}"
-        seen = [None] * world
-        dist.all_gather_object(seen, me)
-        if backend == "nccl" and len(set(seen)) != world:
-            raise SystemExit(f"{world} ranks but only {len(set(seen))} distinct devices: {seen}")
-        try:
-            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
-        except Exception:
-            ver = None
-        dist_info = {"devices": seen, "rccl_version": ver, "device_name": props.name}
+        dist_info = join_ranks(backend, rank, world, device if backend == "nccl" else None, me, props.name)
 
     from uncrtaints_amd import hip_backend as hb
     from uncrtaints_amd.src import losses
@@ -582,9 +642,10 @@ def main():
         prof = hb.EventProfiler(PROFILED)
         prof.tag = profile_tag
         hb.set_profiler(prof)
+    # the sampler (a thread forking rocm-smi every 0.25 s) never runs next to the timed region: in the eager / segmented modes the
+    # timed host loop enqueues launches and would compete with it.  It is started behind the timed steps, over ~3 s of UNTIMED
+    # replays of the same step
     power = PowerSampler(local_rank) if rank == 0 and not args.no_power else None
-    if power is not None:
-        power.start()
     fence()
     if dp is not None:
         dp.wait_ms()                        # drop the warm-up records
@@ -595,17 +656,18 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     power_summary = None
-    # a short timed region (the driver's --steps 20 is a quarter of a second) holds no rocm-smi sample: the same step is replayed
-    # UNTIMED for about three more seconds for the power / clock reading only (not part of `value`).  Rank 0 decides, EVERY rank
-    # replays: the steps contain the gradient all-reduces.
+    # power / clock reading: the same step replayed UNTIMED for about three more seconds (not part of `value`).  Rank 0 decides,
+    # EVERY rank replays: the steps contain the gradient all-reduces.
     n_extra = 0
-    if power is not None and dt < 2.5:
+    if power is not None:
         n_extra = int(3.0 / max(dt / args.steps, 1e-4)) + 1
     if dp_mode:
         ne = torch.tensor([n_extra], device=device, dtype=torch.int64)
         dist.broadcast(ne, src=0)
         n_extra = int(ne.item())
     if n_extra:
+        if power is not None:
+            power.start()
         tp0 = time.perf_counter()
         for _ in range(n_extra):
             loss = step()
@@ -613,20 +675,14 @@ def main():
         tp1 = time.perf_counter()
     if power is not None:
         power.stop()
-        if n_extra:
-            power_summary = power.summary(tp0, tp1)
-            power_summary["sampled_over"] = (f"{n_extra} further untimed replays of the same step behind the timed region ({dt:.2f} s is "
-                                             "shorter than the sampler's settling time)")
-        else:
-            power_summary = power.summary(t0, t0 + dt)
-            power_summary["sampled_over"] = "the timed steps"
+        power_summary = power.summary(tp0, tp1)
+        power_summary["sampled_over"] = f"{n_extra} further untimed replays of the same step behind the timed region"
+        power_summary["sampler_overlapped_timed_region"] = False
     hb.set_profiler(None)
     coll_wait = dp.wait_ms() if dp is not None else []
     eager_ms = None
     if dp_mode:   # the max over ranks of the timed region, taken before anything else touches the stream
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = max_over_ranks(dt, device)
     if use_graph and not args.no_kernel_events:
         # kernels inside a graph replay cannot be bracketed one by one: re-run the SAME steps eagerly with a HIP
         # event pair around every launch (same kernels, same shapes, same stream) for the roofline numbers.  Every
@@ -664,7 +720,7 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        value = world * B * args.steps / dt
+        value = job_value(world, B, args.steps, dt)
         res = {
             "metric": "samples/sec fwd+bwd (BxTx15x256x256, T=3)", "value": round(value, 3), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -677,9 +733,7 @@ def main():
             "ranks": world, "collective_backend": (backend if dp_mode else None),
             # N > 1: what travels (one fp32 bucket per backward segment, all-reduce AVG), on which devices, and how long the compute
             # stream stood still for it per step (HIP events around the waits in finish(): 0 = fully hidden behind the backward)
-            "collective": (dict(dist_info, bucket_bytes=dp.bucket_bytes(), all_reduces_per_step=len(dp.buckets),
-                                wait_ms_per_step=round(sum(coll_wait) / max(len(coll_wait), 1), 4),
-                                wait_ms_max=round(max(coll_wait), 4) if coll_wait else None) if dp is not None else None),
+            "collective": collective_object(dist_info, dp, coll_wait) if dp is not None else None,
             "final_loss": final_loss, "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
             "launch_mode": graph_note,
             "optimizer": {"kind": opt_kind, "included_in_step": True,
@@ -713,13 +767,38 @@ def main():
             else:
                 res["roofline"] = {"bound": "hbm", "achieved": round(top["gbs"], 1), "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": None, "kernel": top["kernel"]}
-            # next to `frac` (of the 8 TB/s spec), never instead of it: the same rate against what a PURE stream of this kernel's
-            # read : write mix reaches on this part (tools/stream_roofs.py -> profiles/r04_stream_roofs.json)
+            # What `frac` measures: algorithmic bytes over launch time.  The decoder's launches work on B frames (<= 268 MB per
+            # operand): a consumer finds part of what its producer just wrote in the 256 MB Infinity Cache, so their rate is
+            # cache-ASSISTED, not an HBM rate.  The encoder runs the same kernel on B*T frames (3x the bytes, nothing survives in the
+            # cache): that launch's rate is the HBM truth, reported next to `frac` as `hbm_truth_frac`.
+            by_label = {r["kernel"]: r for r in rows}
+
+            def twin_of(label):
+                m_ = re.search(r"N(\d+)", label)
+                if not m_:
+                    return None
+                n_ = int(m_.group(1))
+                for n2 in (n_ * T, n_ // T if n_ % T == 0 else 0):
+                    if n2 and n2 != n_:
+                        r2 = by_label.get(label[:m_.start()] + f"N{n2}" + label[m_.end():])
+                        if r2 is not None:
+                            return r2
+                return None
+            tw = twin_of(top["kernel"])
+            if tw is not None and res["roofline"]["bound"] == "hbm":
+                big = tw if tw["bytes"] > top["bytes"] else top
+                res["roofline"]["hbm_truth_frac"] = round(big["gbs"] / HBM_PEAK_GBS, 4)
+                res["roofline"]["hbm_truth_kernel"] = big["kernel"]
+                res["roofline"]["frac_is"] = ("algorithmic bytes / launch time of the dominant (B-frame) launch: Infinity-Cache-assisted; "
+                                              "hbm_truth_frac = the same kernel's B*T-frame launch, whose operands exceed the cache")
+            # the same rate against what a PURE stream of this kernel's read : write mix reaches from a COLD start on this part
+            # (tools/stream_roofs.py -> profiles/r04_stream_roofs.json).  A ratio above 1 is not "beyond a roof": it is the cache help
+            # described above, and is reported as such
             sr = stream_roof_gbs(top["wfrac"])
             if sr:
                 res["roofline"]["written_share_of_bytes"] = round(top["wfrac"], 3)
-                res["roofline"]["stream_roof_gbs_for_this_mix"] = round(sr, 1)
-                res["roofline"]["frac_of_stream_roof"] = round(top["gbs"] / sr, 4)
+                res["roofline"]["cold_stream_probe_gbs_for_this_mix"] = round(sr, 1)
+                res["roofline"].update(stream_ratio(top["gbs"], sr))
             # HBM bytes per launch from the PMC passes (tools/measure_traffic.sh -> profiles/<round>_traffic.json; rocprofv3
             # cannot run inside this process).  The file records the hash of the kernel sources it was measured on: the number
             # is attached only while the sources still hash to it (a stale figure is worse than null) and for a kernel that
@@ -744,7 +823,11 @@ def main():
             res["kernel_breakdown"] = [
                 dict(kernel=r["kernel"], launches_per_step=r["launches"] / prof_steps, mean_ms=round(r["mean_ms"], 4),
                      share=round(r["total_ms"] / max(tot, 1e-9), 4), gbs=round(r["gbs"], 1), tflops=round(r["tflops"], 2),
-                     frac_of_stream_roof=(round(r["gbs"] / stream_roof_gbs(r["wfrac"]), 3) if stream_roof_gbs(r["wfrac"]) else None),
+                     frac_of_8tbs=round(r["gbs"] / HBM_PEAK_GBS, 3),
+                     # the launch of the same kernel on the other frame count (decoder: B frames, cache-assisted; encoder: B*T frames)
+                     twin=(lambda t_: None if t_ is None else {"kernel": t_["kernel"], "gbs": round(t_["gbs"], 1),
+                                                               "frac_of_8tbs": round(t_["gbs"] / HBM_PEAK_GBS, 3)})(twin_of(r["kernel"])),
+                     **(stream_ratio(r["gbs"], stream_roof_gbs(r["wfrac"])) if stream_roof_gbs(r["wfrac"]) else {}),
                      # tflops = fp32-equivalent work; the exact-split GEMMs issue 6 bf16 MFMA products per fp32 MAC:
                      # bf16_pipe_util = 6 x tflops / 2500 TF = the share of the bf16 matrix pipe's dense peak really used
                      bf16_pipe_util=None if r["bf16_pipe_util"] is None else round(r["bf16_pipe_util"], 4))

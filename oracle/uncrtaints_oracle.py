@@ -66,6 +66,7 @@ class OracleConfig:
     # gradient in backward (straight-through).  The reference itself is fp32 only; this variant exists to separate the cost
     # inherent in bf16 storage from implementation error in the bf16 parity tests.
     act_bf16: bool = False
+    inconv_moments: bool = True     # bf16 emulation only: engine.dev_options(inconv_moments=...) of the path under test
 
     @property
     def covar_dim(self) -> int:   # uncrtaints.py:357-365
@@ -387,7 +388,12 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
     # bf16 emulation: behind a GroupNorm the HIP path never stores the pre-norm tensor of in_conv (statistics and parameter gradients
     # from the frames' second-moment matrices, csrc/inconv.hip: at most 15 input channels, 65 ... 256 output channels): no rounding of
     # c0 or of its gradient there; the other configurations keep it in bf16
-    if not (cfg.encoder_norm == "group" and Cin + 1 <= 16 and 64 < c0.shape[1] <= 256):
+    # (the same predicate as uncrtaints_amd.engine._inconv_moments_ok, limits of csrc/inconv.hip included: B*T frames <= 64, H*W % 4,
+    # [B*T][Cout / 4] partial pairs of a group within 60 KB; cfg.inconv_moments mirrors the engine's development switch)
+    Co, NF = c0.shape[1], B * T
+    moments = (cfg.inconv_moments and cfg.encoder_norm == "group" and Cin + 1 <= 16 and 64 < Co <= 256 and Co % 4 == 0 and NF <= 64
+               and (H * W) % 4 == 0 and (2 * NF * (Co // 4) + 4 * NF + 288) * 8 <= 60 * 1024)
+    if not moments:
         c0 = _store(c0, bf)
     a0 = _store(torch.relu(_NormCtx(p, cfg.encoder_norm, training, update_running)(c0, "in_conv.conv.conv.1")), bf)   # utae.py:463-473
     e = a0

@@ -87,24 +87,62 @@ def pool_branch(m, state, x, dates, cfg, training=True, tol=2e-5):
     return idx.reshape(n, c, cfg.att_down, cfg.att_down), flips
 
 
-def close_grad(name, got, ref32, truth64, tol=TOL, noise=8.0):
+NOISE = 2.0   # close_grad second clause: allowed multiple of the CPU fp32 evaluations' own (largest) distance from the fp64 truth
+
+
+class Fp32Draws:
+    """Further correct fp32 evaluations of the same gradients on the CPU, for close_grad's noise scale: `run()` performs one fp32
+    oracle evaluation and returns {name: gradient}; it is repeated with the oracle's spelled-out formulas (USE_ATEN = False: other
+    summation orders than ATen's kernels) and on one thread (ATen's reductions partition differently).  Evaluated lazily, on the
+    first gradient that needs the second clause, and cached -- a test whose gradients all sit within 1e-4 of the fp32 reference never
+    pays for them.  `extra`: evaluations that already exist (e.g. the reference-generated golden gradients of the fixture)."""
+
+    def __init__(self, run, extra=()):
+        self.run, self.extra, self.cache = run, list(extra), None
+
+    def get(self, key):
+        if self.cache is None:
+            from oracle import uncrtaints_oracle as orc
+            self.cache = []
+            nt = torch.get_num_threads()
+            try:
+                orc.USE_ATEN = False
+                self.cache.append(self.run())
+                orc.USE_ATEN = True
+                torch.set_num_threads(1)
+                self.cache.append(self.run())
+            finally:
+                orc.USE_ATEN = True
+                torch.set_num_threads(nt)
+        return [d[key] for d in self.extra + self.cache if key in d]
+
+
+def close_grad(name, got, ref32, truth64, tol=TOL, noise=NOISE, draws=None, key=None):
     """Gradient parity with ONE rule: within `tol` (1e-4) of the fp32 reference, or -- for cancellation-dominated sums, where two
-    correct fp32 evaluations differ by more than `tol` -- no further from the fp64 truth than max(tol, `noise` x the CPU fp32
-    path's own distance from it).  Both references are evaluated on the max-pool branch the implementation took
-    (`pool_branch`), so no kink allowance is needed.
-    Why `noise` = 8 (measured, tools/probe_h2_weight_error.py / tools/debug_h2_blocks.py): on the `weight_init` fixtures the whole
-    gradient moves with the absolute error of the head's variance pre-activation (MGNLL weights a pixel with 1 / var, var ~
-    exp(pre-activation) near the 1e-8 clamp), i.e. with the FORWARD rounding noise.  A GPU fp32 GEMM accumulates its K products one
-    after the other (6e-7 of max|out| per 128 -> 256 GEMM on this pipe, rocBLAS fp32 alike: tools/probe_bf16split.py), the CPU
-    oracle's blocked AVX sums sit 4-5 x lower; twelve GEMMs deep the forward noise is 3e-6 ... 5e-6 against the oracle's 1e-6
-    (contract: 1e-4), and the gradient noise follows in that ratio with a heavy tail over the hundred-odd parameters (seen: 0.7 x ...
-    5.7 x the CPU path's own distance, the same kernel set landing on either side depending on the fixture)."""
+    correct fp32 evaluations differ by more than `tol` -- no further from the fp64 truth than max(tol, `noise` x the distance of the
+    CPU fp32 evaluations from it).  Both references are evaluated on the max-pool branch the implementation took (`pool_branch`),
+    so no kink allowance is needed.
+    What the second clause measures (profiles/r05_parity_attribution.json, tools/parity_attribution.py, tools/forward_bias_probe.py):
+    on the `weight_init` fixtures MGNLL weights a pixel with (y - mu)^2 / var^2 and the smallest predicted variances are ~1e-7, so
+    every decoder gradient is dominated by a handful of pixels and moves with the forward rounding noise REALISED at those pixels --
+    one common factor per evaluation, a lottery.  The HIP path and the CPU path carry the same forward noise (3.3e-6 vs 3.1e-6 rms of
+    the output against an fp64 evaluation; both are the encoder's 3e-7 amplified by the temporal softmax and the decoder's batch
+    statistics), and over fresh inputs their worst gradient errors are distributed alike (six inputs: HIP 2.0 ... 6.8e-5, CPU
+    2.0 ... 8.2e-5); no single rounding source carries it (one-switch-at-a-time attribution: every "more exact" variant lands above
+    AND below the shipped path depending on the input).  ONE CPU evaluation is therefore a poor yardstick (its own error on the same
+    gradient ranges 9e-6 ... 5e-5 between ATen, the spelled-out formulas, one thread or eight, and the reference host): the scale
+    is the LARGEST distance among the available correct fp32 evaluations (`ref32`, plus `draws.get(key)`), and the allowed multiple
+    of it is `NOISE` = 2 (tests/test_parity_rule.py keeps TOL and NOISE from being raised)."""
     got = got.detach().double().cpu().numpy()
     ref32 = ref32.detach().double().cpu().numpy()
     truth64 = truth64.detach().cpu().numpy()
     assert got.shape == ref32.shape == truth64.shape, (name, got.shape, ref32.shape)
     assert np.isfinite(got).all(), f"{name}: non-finite values"
     e_ref, e_got, e_cpu = rel_err(got, ref32), rel_err(got, truth64), rel_err(ref32, truth64)
+    if not (e_ref < tol or e_got <= max(tol, noise * e_cpu)) and draws is not None:
+        for alt in draws.get(key):
+            alt = alt.detach().double().cpu().numpy() if isinstance(alt, torch.Tensor) else np.asarray(alt, dtype=np.float64)
+            e_cpu = max(e_cpu, rel_err(alt.reshape(truth64.shape), truth64))
     print(f"[parity] {name}: vs fp32 ref {e_ref:.3e}; vs fp64 truth: hip {e_got:.3e}, cpu-fp32 {e_cpu:.3e}")
     assert e_ref < tol or e_got <= max(tol, noise * e_cpu), \
         f"{name}: {e_ref:.3e} from the fp32 reference and {e_got:.3e} from fp64 truth (cpu fp32: {e_cpu:.3e})"

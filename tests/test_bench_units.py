@@ -47,6 +47,13 @@ def test_stream_roof_interpolation_and_written_share():
     assert abs(b.written_fraction("uncr_pw_gemm", (0, 4, 256, 128, 65536, 2, 10, 0, 0, 256, 0)) - 0.25) < 1e-9
 
 
+def test_stream_ratio_never_reports_a_fraction_above_one():
+    b = _bench()
+    assert b.stream_ratio(5000.0, 6000.0) == {"frac_of_stream_roof": round(5000.0 / 6000.0, 4)}
+    r = b.stream_ratio(6600.0, 6000.0)
+    assert r["frac_of_stream_roof"] is None and r["infinity_cache_assisted"] is True and r["ratio_to_cold_stream_probe"] == 1.1
+
+
 def test_power_sampler_parses_rocm_smi(monkeypatch):
     b = _bench()
     txt_max = "GPU[0]\t\t: Max Graphics Package Power (W): 1400.0\nGPU[1]\t\t: Max Graphics Package Power (W): 1400.0\n"

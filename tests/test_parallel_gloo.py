@@ -201,3 +201,94 @@ def test_four_ranks_uneven_bucket_and_shards():
         acc = gs if acc is None else {n: acc[n] + gs[n] for n in gs}
     for n in acc:
         assert torch.allclose(acc[n] / world, torch.from_numpy(g0[n]), atol=1e-6), n
+
+
+# ---- bench.py's rank bookkeeping on a world of 8 (the driver's `--gpus 8` launch, here eight gloo CPU processes) ----
+def _bench_mod():
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod_w8", os.path.join(root, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(m)
+    finally:
+        sys.argv = argv
+    return m
+
+
+def _bench_worker(rank, world, port, q):
+    # what torch.distributed.run sets for `--nproc-per-node 8`
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    b = _bench_mod()
+    w, r, lr = b.rank_env(world)
+    assert (w, r, lr) == (world, rank, rank)
+    info = b.join_ranks("gloo", r, w, None, f"node0:gpu-uuid-{lr}:{lr}", "cpu-stand-in")
+    assert info["devices"] == [f"node0:gpu-uuid-{i}:{i}" for i in range(world)]
+    b.check_roster(info["devices"], world, "nccl")          # eight distinct devices: what the RCCL launch requires
+    from uncrtaints_amd.parallel import BucketedDataParallel
+    torch.manual_seed(rank)
+    m = Toy()
+    dp = BucketedDataParallel(m)
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(4 * world, 6, generator=g), torch.randn(4 * world, 2, generator=g)
+    steps, B = 3, 4
+    for _ in range(steps):
+        dp.zero_grad()
+        ((dp(X[rank * B:(rank + 1) * B]) - Y[rank * B:(rank + 1) * B]) ** 2).mean().backward()
+        dp.finish()
+    # the job's time is the slowest rank's; the value is the whole job's samples per second (weak scaling)
+    dt = b.max_over_ranks(0.01 * (rank + 1), torch.device("cpu"))
+    assert abs(dt - 0.01 * world) < 1e-12
+    value = b.job_value(w, B, steps, dt)
+    assert abs(value - world * B * steps / (0.01 * world)) < 1e-9
+    coll = b.collective_object(info, dp, [0.0] * steps)
+    if rank == 0:
+        q.put({"collective": coll, "value": value, "grad0": m.in_conv.weight.grad.numpy().copy()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_rank_bookkeeping_world_8():
+    """bench.py's N > 1 plumbing on eight gloo ranks: environment parsing, the device roster (eight distinct devices), the
+    max-over-ranks clock, the weak-scaling arithmetic of `value`, the complete `collective` object, and bucketed all-reduces that
+    give every rank the gradient of the concatenated batch."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    c = res["collective"]
+    assert len(c["devices"]) == 8 and len(set(c["devices"])) == 8
+    for k in ("devices", "rccl_version", "device_name", "bucket_bytes", "all_reduces_per_step", "wait_ms_per_step", "wait_ms_max"):
+        assert k in c, k
+    assert c["all_reduces_per_step"] == 3 and len(c["bucket_bytes"]) == 3 and all(v > 0 for v in c["bucket_bytes"])
+    assert abs(res["value"] - 8 * 4 * 3 / 0.08) < 1e-6
+    # single-process reference on the concatenated batch (per-sample-mean loss: the rank average IS the global gradient)
+    torch.manual_seed(0)
+    m = Toy()
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(32, 6, generator=g), torch.randn(32, 2, generator=g)
+    ((m(X) - Y) ** 2).mean().backward()
+    assert torch.allclose(torch.from_numpy(res["grad0"]), m.in_conv.weight.grad, atol=1e-6)
+
+
+def test_bench_roster_rejects_shared_devices_and_bad_env(monkeypatch):
+    import pytest
+    b = _bench_mod()
+    with pytest.raises(SystemExit):
+        b.check_roster(["n:a:0", "n:a:0"], 2, "nccl")       # two RCCL ranks on one GPU
+    b.check_roster(["n:a:0", "n:a:0"], 2, "gloo")           # the single-GPU development mode may share it
+    with pytest.raises(SystemExit):
+        b.check_roster(["n:a:0", None], 2, "nccl")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "1")
+    with pytest.raises(SystemExit):
+        b.rank_env(8)                                       # --gpus 8 under a 4-rank launcher
+    assert b.rank_env(4)[:2] == (4, 1)

@@ -94,7 +94,7 @@ def test_oracle_variants_match_reference_fixture(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(VARIANTS))
 def test_hip_variants(name):
-    from gpu_util import close, close_grad, dev, is_zero_grad, pool_branch
+    from gpu_util import Fp32Draws, close, close_grad, dev, is_zero_grad, pool_branch
     from uncrtaints_amd.src.backbones import uncrtaints as U
     from uncrtaints_amd.src import losses
     g = load_golden("g2_variants")
@@ -122,6 +122,7 @@ def test_hip_variants(name):
     close(f"{name}/eval_vs_reference_slice", out_eval[:, 0, :, ::8, ::8], torch.from_numpy(g[f"{name}/eval_slice"]))
     close(f"{name}/train", out, ot)
     assert abs(l.item() - float(g[f"{name}/train_loss"])) < 1e-4 * abs(float(g[f"{name}/train_loss"]))
+    draws = Fp32Draws(lambda: _oracle(name, state, x, y, dates, pool_idx=pidx)[3])
     for k, v in m.named_parameters():
         if v.grad is None or k not in g64:
             continue
@@ -130,7 +131,7 @@ def test_hip_variants(name):
             continue
         if is_zero_grad(k, g64):
             continue
-        close_grad(f"{name}/grad[{k}]", v.grad, g32[k], g64[k])
+        close_grad(f"{name}/grad[{k}]", v.grad, g32[k], g64[k], draws=draws, key=k)
 
 
 @pytest.mark.gpu
@@ -213,7 +214,7 @@ def test_oracle_usev_matches_reference():
 
 @pytest.mark.gpu
 def test_hip_usev():
-    from gpu_util import close, close_grad, close_vs_truth, dev, pool_branch
+    from gpu_util import Fp32Draws, close, close_grad, close_vs_truth, dev, pool_branch
     from uncrtaints_amd.src.backbones import uncrtaints as U
     from uncrtaints_amd.src import losses
     g, state, x, y, dates = _usev_inputs()
@@ -243,11 +244,12 @@ def test_hip_usev():
     for k in g.files:
         if k.startswith("train/state/"):
             close("usev/" + k, sd[k[len("train/state/"):]], torch.from_numpy(g[k]), tol=1e-4)
+    draws = Fp32Draws(lambda: _usev_oracle(state, x, y, dates, pool_idx=pidx)[3])
     for k, v in m.named_parameters():
         if float(g64[k].abs().max()) < 1e-7:
             assert float(v.grad.abs().max()) < 1e-3 * max(float(x_.abs().max()) for x_ in g64.values()) , k
             continue
-        close_grad(f"usev/grad[{k}]", v.grad, g32[k], g64[k])
+        close_grad(f"usev/grad[{k}]", v.grad, g32[k], g64[k], draws=draws, key=k)
     # train-mode dropout on the values is stochastic and unbiased in expectation
     m.temporal_encoder.dropout.p = 0.2
     with torch.no_grad():
@@ -338,7 +340,7 @@ def test_hip_residual_blocks():
     # (ResidualConvBlock._last_relu) and its arg-max indices (UNCRTAINTS._last_pool_idx), after checking that the branch is a
     # correct evaluation (pool_branch; for the masks: the fp64 gradients on the pinned branch stay within the kink scale of the
     # free fp64 evaluation).  Then ONE rule: close_grad.
-    from gpu_util import close_grad, pool_branch
+    from gpu_util import Fp32Draws, close_grad, pool_branch
     masks = {}
     for name, blk in [(f"in_block.{i}", b) for i, b in enumerate(m.in_block)] + [(f"out_block.{i}", b) for i, b in enumerate(m.out_block)]:
         for i, (c, A, B) in enumerate(blk._last_relu, 1):
@@ -352,11 +354,12 @@ def test_hip_residual_blocks():
     # the branch is a correct one: the fp64 oracle's own masks differ from the HIP masks only where its pre-activation is tiny
     _, _, _, g64_free, _ = _res_oracle(state, x, y, dates, torch.float64, pidx, None)
     gmax = max(float(v.abs().max()) for v in g64.values())
+    draws = Fp32Draws(lambda: _res_oracle(state, x, y, dates, torch.float32, pidx, masks)[3])
     for k, v in m.named_parameters():
         if float(g64[k].abs().max()) < 1e-6:
             assert float(v.grad.abs().max()) < 1e-3 * gmax, k
             continue
-        close_grad(f"residual/grad[{k}]", v.grad, g32[k], g64[k])
+        close_grad(f"residual/grad[{k}]", v.grad, g32[k], g64[k], draws=draws, key=k)
         # pinning changed nothing beyond the kinks: the free fp64 evaluation stays within the kink scale of the pinned one
         assert rel_err(g64_free[k].numpy(), g64[k].numpy()) < 5e-2, k
     close_vs_truth("residual/dx_b0t0", xg.grad[0, 0], torch.from_numpy(g["train/dx_b0t0"]),

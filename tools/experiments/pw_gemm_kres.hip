@@ -1,5 +1,6 @@
-// EXPERIMENT (round 4) -- NOT part of the product library (uncrtaints_amd/build.py does not compile it; to try it: add the object
-// to the link and build pw_gemm.hip with -DUNCR_WITH_KRES, see tools/build_kres_variant.sh).  Result: bit-identical to the
+// EXPERIMENT (round 4), kept under tools/ for the record -- NOT part of the product library and no longer hooked into it (round 4
+// linked it behind `if (pw_kres_dz_applies(g, in_dt)) return pw_kres_dz_launch(g, N, stream);` in uncr_pw_gemm's PRO_NORMBWD case;
+// it includes "pw_gemm.h" from uncrtaints_amd/csrc).  Result: bit-identical to the
 // chunk-pipelined kernel and EXACTLY as fast (isolated 201-206 us vs 204-206 us, in the step 12.01 vs 12.02 ms, interleaved A/B) --
 // two structurally different kernels landing on the same time is the evidence that the dz GEMM is bound by its traffic (805 MB
 // with one third written: ablating all compute leaves 165 us = 4.9 TB/s, the plain-store rate of this access pattern) and not by the
@@ -23,7 +24,7 @@
 // -- the results are bit-identical (checked on MI355X in round 4 with the test that is now a comment at the end of this file).
 // LDS bytes of a staged chunk c (16 KB): part * 8192 + ((ks * 2 + kg) * 4 + e) * 512 + j * 16 + half * 8, pixel = 4 j + e, as in the
 // chunked kernel; weights Wp[ks][co tile][slot][lane] (slots 3, 4 = the scaled fp16 parts; tail = 1 / scale per output channel).
-#include "../pw_gemm.h"
+#include "../../uncrtaints_amd/csrc/pw_gemm.h"
 #include <type_traits>
 
 #ifndef KR_NT_LD

@@ -115,11 +115,6 @@ size_t pw_split_wt_floats(int rows_k, int cp);
 int pw_split_blocks_per_frame(int N, int P);
 int pw_pack_batch(const long long* desc, int n_items, hipStream_t stream);
 
-// pw_gemm_kres.hip: the dz GEMM of the model's MBConv backward (128 -> 256, fp32 storage, two-part fp16 route) with the whole
-// contraction axis of a tile resident in LDS and two 128-channel output passes
-bool pw_kres_dz_applies(const PwArgs& g, int act);
-int pw_kres_dz_launch(const PwArgs& g, int N, hipStream_t stream);
-
 // pw_wgrad_split.hip
 int pw_wgrad_split_nbx(int N, int P);
 bool pw_wgrad_split_supported(int Cd, int Cx, int pro_d, int pro_x, bool rowsum);

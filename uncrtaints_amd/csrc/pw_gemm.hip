@@ -552,9 +552,6 @@ extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, vo
             case PRO_AFFINE: return pw_split_launch_p1(g, N, cp, in_dt, stream);
             case PRO_AFFINE_GELU: return pw_split_launch_p2(g, N, cp, in_dt, stream);
             case PRO_NORMBWD:
-#ifdef UNCR_WITH_KRES      // experiments/pw_gemm_kres.hip (round 4: bit-identical, same speed -- not part of the product build)
-                if (pw_kres_dz_applies(g, in_dt)) return pw_kres_dz_launch(g, N, stream);
-#endif
                 return pw_split_launch_p3(g, N, cp, in_dt, stream);
             case PRO_AFFINE_RELU: return pw_split_launch_p4(g, N, cp, in_dt, stream);
             default: return UNCR_EINVAL;

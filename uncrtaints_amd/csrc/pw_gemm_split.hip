@@ -20,34 +20,14 @@
 //     A[co = lane&31][ci = 16 ks + 8 (lane>>5) + 0..7]); a wave's A load is one contiguous 1 KB read from L2.
 //     A parts are re-loaded for the next k-step right after their last use (no second register set).
 #include "pw_gemm.h"
-// non-temporal hints per access class, measured inside the training step (tools/ab_variants.sh, interleaved runs of one
-// session): activation loads -0.09 ms/step (4 of 4 rounds) -> ON; epilogue operand loads +0.15 ms and output stores +0.1 ms
-// (the next kernel re-reads them) -> OFF
-#ifndef UNCR_NTG_LD
-#define UNCR_NTG_LD 1
-#endif
-#ifndef UNCR_NTG_AUX
-#define UNCR_NTG_AUX 0
-#endif
-#ifndef UNCR_NTG_ST
-#define UNCR_NTG_ST 0
-#endif
-#ifndef UNCR_NTG_ST2
-#define UNCR_NTG_ST2 0     // stores of the 256-channel outputs only (268 MB at N=4: larger than any cache level)
-#endif
-#ifndef UNCR_NTG_ST4
-#define UNCR_NTG_ST4 0     // experiment: stores of the 128-channel statistics epilogue (h3 of pw2 forward)
-#endif
-#ifndef UNCR_NTG_ST5
-#define UNCR_NTG_ST5 1     // stores of the skip epilogues (dx, 1/8 of that kernel's traffic): isolated 226 -> 212 us, in the step -0.09 ms (3 of 3
-                           // interleaved pairs, 11.89 vs 11.98 ms) -- round 4, same reasoning as ST3
-#endif
-#ifndef UNCR_NTG_ST3
-#define UNCR_NTG_ST3 1     // stores of the fused pass-B epilogue only (du2 of the dz GEMM: 268 MB at N = 4 in 512-byte pieces, one third of that
-                           // kernel's traffic).  Round 4: the stream probe in this access pattern moves a 2 : 1 mix at 5.0 TB/s with plain and
-                           // 5.8 TB/s with non-temporal accesses; on the dz kernel alone 194 -> 179-185 us, in the step -0.09 ms (4 of 4
-                           // interleaved pairs: 12.11 vs 12.20 ms).  The same hint on every 256-channel output (ST2) slows pw1 forward by 10 %.
-#endif
+// Non-temporal hints per access class, each measured inside the training step with interleaved A/B runs (history: NOTES_next_round.md):
+//   * raw activation loads of the main loop: ON (-0.09 ms / step); not for the accumulate epilogue 4, which re-reads its own output
+//   * stores of the fused pass-B epilogue (du2 of the dz GEMM: 268 MB at N = 4, one third of that kernel's traffic): ON (-0.09 ms)
+//   * stores of the skip epilogues 5 / 6 / 8 (dx): ON (-0.09 ms)
+//   * every other store and the epilogue operand loads: plain (the next kernel re-reads them; the hint cost +0.1 ... +0.15 ms)
+#define PWS_NT_LOADS 1
+#define PWS_NT_STORE_PASSB 1
+#define PWS_NT_STORE_SKIP 1
 #include <type_traits>
 #include <cstdlib>
 // four consecutive activation elements as loaded: fp32 storage keeps the float4, bf16 storage keeps the raw 8 bytes (half the
@@ -69,26 +49,12 @@ __device__ __forceinline__ float pws_get(const uncr_u2& r, int e) {      // e is
 template <bool NT, typename TA> __device__ __forceinline__ void pws_st(TA* p, const float4& v) { st4<TA, NT>(p, v); }
 
 #ifndef PWS_ABL
-#define PWS_ABL 0   // development ablations (tools/ablate_split.sh): 1 no stores, 2 no staging, 4 no activation loads, 8 no A reloads, 16 no MFMA
-#endif
-#ifndef PWS_PRIO
-#define PWS_PRIO 0   // experiment: 1 = s_setprio(1) around every k-step's MFMA groups, 2 = static priority for every second block
-#endif
-#ifndef PWS_EPI_PIPE
-#define PWS_EPI_PIPE 0   // 1: double-buffered operand rows in the aux epilogues 2 / 3; 3: also in the skip epilogues 5 / 6
-#endif
-#ifndef PWS_A2SET
-#define PWS_A2SET 0   // experiment: two rolling A-fragment sets (one per k-step parity), each re-loaded for the SAME k-step of the next chunk
-#endif
-#ifndef PWS_LATE_LOAD
-#define PWS_LATE_LOAD 0   // experiment: the raw chunk request moves behind the chunk's second k-step
+#define PWS_ABL 0   // development ablations (tools/ablate_split.sh): 1 no stores, 2 no staging, 4 no activation loads, 8 no A reloads, 16 no MFMA, 32 no B reads, 64 no GELU
 #endif
 #define PWS_TP 128
 #define PWS_BUF 24576   // bytes per LDS stage: 3 parts x 32 ci x 128 px x 2 B (bf16 activations: 1 part, 8192 B)
-#ifndef PWS_A16_WPARTS
 #define PWS_A16_WPARTS 2   // bf16 activations: leading weight parts used (2 = 16 significant bits: the weights stay fp32-grade,
                            // the only rounding is the activations' bf16 storage; 1 product per part and k-step)
-#endif
 
 // DEPTH = chunks of raw activations in flight in registers (2 wherever the register budget allows: a chunk is
 // only ~1.3 us of MFMA work, one chunk of prefetch distance does not cover HBM latency under load).
@@ -106,18 +72,10 @@ template <bool NT, typename TA> __device__ __forceinline__ void pws_st(TA* p, co
 // its result is rounded ONCE to bf16 (one operand part instead of three); the weights keep their PWS_A16_WPARTS leading parts, so
 // a k-step is PWS_A16_WPARTS products instead of six and the kernel is purely stream-bound.  A fragments are double-buffered over
 // two k-steps (one k-step of MFMAs no longer covers an L2 round trip).
-#ifndef PWS_A16_DEPTH_CT2
-#define PWS_A16_DEPTH_CT2 1    // raw chunks in flight of the 256-channel bf16 variants (experiment knob)
-#endif
-#ifndef PWS_H2_DEPTH_CT2
-#define PWS_H2_DEPTH_CT2 1     // raw chunks in flight of the 256-channel fp16 two-part variant
-#endif
-#ifndef PWS_A16_OCC
-#define PWS_A16_OCC 2          // blocks per CU the bf16 variants are compiled for (experiment knob)
-#endif
+// The 256-channel (CT = 2) variants keep ONE raw chunk in flight (a second one spills in every storage mode); two blocks per CU.
 // H2 = true (fp32 storage, forward GEMMs behind a norm prologue): two fp16 parts per operand, three products (pw_gemm.h).
 template <int CT, int PRO, int EPI, int DEPTH, typename TA, bool H2 = false>
-__global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2) void pw_gemm_split_kernel(PwArgs g) {
+__global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     constexpr int NT = 256, WN = 4;
     constexpr bool BF = sizeof(TA) == 2;
     static_assert(!(H2 && BF), "the fp16 two-part split is for fp32 storage");
@@ -217,8 +175,8 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         for (int r = 0; r < 4; ++r) {
             const int k = p.c * PWS_KC + 4 * cig + r;
             const int kk = k < Cin ? k : 0;
-            pre[S][r] = pws_ld<UNCR_NTG_LD && EPI != 4, TA>(inb + (size_t)kk * P + px);
-            if constexpr (PRE2) pre2[S][r] = pws_ld<UNCR_NTG_LD && EPI != 4, TA>(in2b + (size_t)kk * P + px);
+            pre[S][r] = pws_ld<PWS_NT_LOADS && EPI != 4, TA>(inb + (size_t)kk * P + px);
+            if constexpr (PRE2) pre2[S][r] = pws_ld<PWS_NT_LOADS && EPI != 4, TA>(in2b + (size_t)kk * P + px);
         }
     };
     auto stage_chunk = [&](int kc, int buf, auto slot) {
@@ -231,7 +189,12 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
             const int k = kc * PWS_KC + 4 * cig + r;
             const int kk = k < Cin ? k : 0;
             valid[r] = k < Cin;
-            const int kz = k & 255;          // (k < 256 whenever the chunk holds data; padding chunks of a DEPTH-padded tile wrap harmlessly)
+            // k < 256 whenever the chunk holds data; the padding chunk of a DEPTH-padded tile (nkp - nk <= DEPTH - 1 = 1 chunk, k < 288) wraps onto
+            // rows 0..31 only where Cin = 256, and is never consumed as data there (nk = nkp for an even chunk count).
+            // Non-finite inputs: a padding row stages 0 * x[channel 0]; an inf / NaN in channel 0 therefore reaches every output channel --
+            // which a dense 1x1 convolution does with it anyway (every output depends on channel 0)
+            static_assert(DEPTH <= 2, "kz = k & 255 assumes at most one padding chunk per tile");
+            const int kz = k & 255;
             if constexpr (PRO != PRO_NONE) { c0[r] = cf[0][kz]; c1[r] = cf[1][kz]; c2[r] = cf[2][kz]; }
             if constexpr (PRO == PRO_NORMBWD) {
                 c3[r] = cf[3][kz];
@@ -294,8 +257,6 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
     const u32x4_t* wp = (const u32x4_t*)g.Wt + (size_t)(wn * CT) * PWS_NSLOT * 64 + lane;
     auto lda = [&](int ks, int ct, int part) { return wp[((size_t)(ks * NCT + ct) * PWS_NSLOT + (H2 ? 3 : 0) + part) * 64]; };
     u32x4_t ah[CT], am[CT], al[CT];
-    constexpr bool A2 = PWS_A2SET && H2 && (CT == 1 || PWS_A2SET > 1);
-    u32x4_t ah1[A2 ? CT : 1], al1[A2 ? CT : 1];   // A2: the fragments of the odd k-steps (ah / al serve the even ones)
     u32x4_t a2[BF ? 2 : 1][BF ? NW : 1][CT];      // bf16 activations: the A fragments of two consecutive k-steps
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, DEPTH - 1>;
@@ -311,10 +272,6 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
     } else if constexpr (H2) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); al[ct] = lda(0, ct, 1); }
-        if constexpr (A2) {
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) { ah1[ct] = lda(1, ct, 0); al1[ct] = lda(1, ct, 1); }
-        }
     } else {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) { ah[ct] = lda(0, ct, 0); am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
@@ -390,7 +347,6 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         for (int c = tid; c < COUTP; c += NT) hsc[c] = wtail[c] * isc;
         __syncthreads();
     }
-    if constexpr ((PWS_PRIO & 2) != 0) { if (((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1) __builtin_amdgcn_s_setprio(2); }
     float amx = 0.f;          // max |stored output| of this block (CT = 1 statistics / skip epilogues)
     constexpr bool AMAXK = CT == 1 && (EPI == 1 || EPI == 2 || EPI == 5);
     constexpr bool SKIP = EPI == 5 || EPI == 6 || EPI == 8;      // the skip + PreNorm-backward epilogues
@@ -466,25 +422,6 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         PWS_SB();
 #undef PWS_SB
     };
-    // A2: as kstep_h2 with the fragment set of the k-step's parity, re-loaded for k-step `ksn` = this one + 2 (wrapping into the next
-    // tile) -- every weight request is then OLDER than the raw chunk request that follows it in the vmcnt queue when it is waited for
-    auto kstep_h2x = [&](u32x4_t (&xh)[A2 ? CT : 1], u32x4_t (&xl)[A2 ? CT : 1], int ksn, const unsigned char* cb, const unsigned char* nb, auto roll) {
-        constexpr bool ROLL = decltype(roll)::value;
-#define PWS_SB() __builtin_amdgcn_sched_barrier(0)
-        ldb(cb, 1, bl);
-        PWS_SB();
-        PWS_MF16(xh, bh); PWS_SB();
-        PWS_MF16(xl, bh); PWS_SB();
-#pragma unroll
-        for (int ct = 0; ct < (A2 ? CT : 0); ++ct) xl[ct] = lda(ksn, ct, 1);
-        PWS_SB();
-        PWS_MF16(xh, bl); PWS_SB();
-#pragma unroll
-        for (int ct = 0; ct < (A2 ? CT : 0); ++ct) xh[ct] = lda(ksn, ct, 0);
-        if (ROLL) ldb(nb, 0, bh);
-        PWS_SB();
-#undef PWS_SB
-    };
     // bf16 activations: k-step with fragment set q (= its parity): NW products, then the set is re-loaded with the weights of
     // k-step `ksn` (two k-steps ahead, wrapping into the next tile) and bh with the next k-step's B operand
     auto kstep_a16 = [&](auto qc, int ksn, const unsigned char* nb) {
@@ -517,25 +454,18 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
 #ifdef PWS_STAMP
         unsigned long long tl_ = __builtin_readcyclecounter();
 #endif
-        if constexpr (PWS_PRIO & 1) __builtin_amdgcn_s_setprio(1);
         if constexpr (BF) kstep_a16(Q0{}, 2 * c + 2 >= nks ? 2 * c + 2 - nks : 2 * c + 2, xb + 4096);
-        else if constexpr (A2) kstep_h2x(ah, al, 2 * c + 2 >= nks ? 2 * c + 2 - nks : 2 * c + 2, xb, xb + 4096, Roll{});
         else if constexpr (H2) kstep_h2(2 * c + 1, xb, xb + 4096, Roll{});
         else kstep(2 * c + 1, xb, xb + 4096, Roll{});
-        if constexpr (PWS_PRIO & 1) __builtin_amdgcn_s_setprio(0);
         PWS_T(0)
         if (!(PWS_ABL & 2)) stage_chunk(cn, par ^ 1, slot);
         PWS_T(1)
-        if constexpr (!PWS_LATE_LOAD) if (!(PWS_ABL & 4)) { load_chunk(lp, slot); advance(lp); }
+        if (!(PWS_ABL & 4)) { load_chunk(lp, slot); advance(lp); }
         __syncthreads();
         PWS_T(2)
-        if constexpr (PWS_PRIO & 1) __builtin_amdgcn_s_setprio(1);
         if constexpr (BF) kstep_a16(Q1{}, 2 * c + 3 >= nks ? 2 * c + 3 - nks : 2 * c + 3, xn);
-        else if constexpr (A2) kstep_h2x(ah1, al1, 2 * c + 3 >= nks ? 2 * c + 3 - nks : 2 * c + 3, xb + 4096, xn, roll_last);
         else if constexpr (H2) kstep_h2(2 * c + 2 == nks ? 0 : 2 * c + 2, xb + 4096, xn, roll_last);
         else kstep(2 * c + 2 == nks ? 0 : 2 * c + 2, xb + 4096, xn, roll_last);
-        if constexpr (PWS_PRIO & 1) __builtin_amdgcn_s_setprio(0);
-        if constexpr (PWS_LATE_LOAD) if (!(PWS_ABL & 4)) { load_chunk(lp, slot); advance(lp); }
         PWS_T(3)
         par ^= 1;
     };
@@ -566,16 +496,10 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         asm volatile("" : "+s"(nco));   // keep the 2 x 32 row bases from being hoisted out of the tile loop (SGPR spills)
         auto row_of = [&](int ct, int r) { return (wn * CT + ct) * 32 + (r & 3) + 8 * (r >> 2); };   // + 4*kg per lane
         {
-#ifndef PWS_EPI_RB
-#define PWS_EPI_RB 8
-#endif
-            constexpr int RB = SKIP ? 4 : ((EPI == 2 || EPI == 3) ? PWS_EPI_RB : 8);     // rows per request batch (epi 5 reads three rows per output row)
+            constexpr int RB = SKIP ? 4 : 8;     // rows per request batch (the skip epilogues read three rows per output row)
             constexpr bool AUX = EPI == 2 || EPI == 3 || EPI == 4 || EPI == 10 || SKIP;
             constexpr int NBAT = CT * 16 / RB;                      // batches of the tile: (ct, rb) = (bi / (16 / RB), RB * (bi % (16 / RB)))
-            // PWS_EPI_PIPE: the operand rows of batch bi + 1 are requested BEFORE batch bi is transformed (two register sets), so the
-            // epilogue's VALU work (pass-B: GELU' on every element) runs under the next batch's HBM latency instead of behind it
-            constexpr bool PIPE = (PWS_EPI_PIPE != 0) && AUX && EPI != 4 && ((PWS_EPI_PIPE & 2) || EPI == 2 || EPI == 3);
-            constexpr int NSET = PIPE ? 2 : 1;
+            constexpr int NSET = 1;
             float4 xa[NSET][AUX ? RB : 1];
             float4 xb[NSET][SKIP ? RB : 1], xc[NSET][(EPI == 5 || EPI == 6) ? RB : 1];
             auto issue = [&](auto bic, auto setc) {
@@ -588,9 +512,9 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                         const int rw = row_of(ct, rb + q);
                         const int rc = rw + 4 < Cout ? rw : (Cout > 8 ? Cout - 8 : 0);
                         const size_t o = (size_t)(nco + rc) * P + loff;
-                        xa[S][q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux + o);
-                        xb[S][q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux2 + o);
-                        if constexpr (EPI != 8) xc[S][q] = ld4<TA, UNCR_NTG_AUX>(a3 + o);      // (epi 8 masks with x itself: no third stream)
+                        xa[S][q] = ld4<TA, false>((const TA*)g.aux + o);
+                        xb[S][q] = ld4<TA, false>((const TA*)g.aux2 + o);
+                        if constexpr (EPI != 8) xc[S][q] = ld4<TA, false>(a3 + o);      // (epi 8 masks with x itself: no third stream)
                     }
                 }
                 if constexpr (EPI == 4) {      // accumulate: out += result (dense 3x3 as nine shifted 1x1 GEMMs)
@@ -606,7 +530,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                     for (int q = 0; q < RB; ++q) {
                         const int rw = row_of(ct, rb + q);            // rows past Cout (padded tiles) re-read the last valid row
                         const int rc = rw + 4 < Cout ? rw : (Cout > 8 ? Cout - 8 : 0);
-                        xa[S][q] = ld4<TA, UNCR_NTG_AUX>((const TA*)g.aux + (size_t)(nco + rc) * P + loff);
+                        xa[S][q] = ld4<TA, false>((const TA*)g.aux + (size_t)(nco + rc) * P + loff);
                     }
                 }
             };
@@ -715,17 +639,12 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
             auto walk = [&](auto self, auto bic) -> void {
                 constexpr int bi = decltype(bic)::value;
                 if constexpr (bi < NBAT) {
-                    using Cur = std::integral_constant<int, PIPE ? (bi & 1) : 0>;
-                    using Nxt = std::integral_constant<int, PIPE ? ((bi + 1) & 1) : 0>;
-                    if constexpr (PIPE) {
-                        if constexpr (bi == 0) issue(std::integral_constant<int, 0>{}, Cur{});
-                        if constexpr (bi + 1 < NBAT) issue(std::integral_constant<int, bi + 1>{}, Nxt{});
-                    } else if constexpr (AUX) {
+                    using Cur = std::integral_constant<int, 0>;
+                    if constexpr (AUX) {
                         issue(bic, Cur{});
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (AUX) __builtin_amdgcn_sched_barrier(0);
                     transform(bic, Cur{});
-                    if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
                     self(self, std::integral_constant<int, bi + 1>{});
                 }
             };
@@ -738,8 +657,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
                 const int rw = row_of(ct, r);
                 const float4 v = make_float4(acc[0][ct][r], acc[1][ct][r], acc[2][ct][r], acc[3][ct][r]);
                 if (rw + 4 * kg < Cout && (!(PWS_ABL & 1) || v.x == 1.2345e-30f)) {
-                    pws_st<(UNCR_NTG_ST || (UNCR_NTG_ST2 && CT == 2) || (UNCR_NTG_ST3 && EPI == 3) || (UNCR_NTG_ST4 && CT == 1 && EPI == 1) ||
-                            (UNCR_NTG_ST5 && SKIP)) && EPI != 4, TA>((TA*)g.out + (size_t)(nco + rw) * P + loff, v);
+                    pws_st<(PWS_NT_STORE_PASSB && EPI == 3) || (PWS_NT_STORE_SKIP && SKIP), TA>((TA*)g.out + (size_t)(nco + rw) * P + loff, v);
                 }
             }
         }
@@ -747,7 +665,7 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 2 && CT == 1) ? PWS_A16_OCC : 2
         if constexpr (!BF) {      // (bf16 activations: the rolling operand loads already wrapped into the next tile)
             // operands of the next tile's first k-step (its chunk 0 is already staged in xs[par])
 #pragma unroll
-            for (int ct = 0; ct < (A2 ? 0 : CT); ++ct) {      // (A2: the tile's last two k-steps already requested them)
+            for (int ct = 0; ct < CT; ++ct) {
                 ah[ct] = lda(0, ct, 0);
                 if constexpr (H2) al[ct] = lda(0, ct, 1);
                 else { am[ct] = lda(0, ct, 1); al[ct] = lda(0, ct, 2); }
@@ -914,13 +832,13 @@ static void pws_launch_epi(const PwArgs& g, dim3 grid, int cp, hipStream_t strea
     // forward GEMMs behind a norm prologue, fp32 storage: the fp16 two-part split (three products instead of six)
     if constexpr ((EPI == 0 || EPI == 1 || EPI == 10) && sizeof(TA) == 4) {      // epi 0: the same GEMMs in eval mode behind a BatchNorm (running statistics)
         if (g.h2 && g.in_amax && g.in_amax_n > 0) {
-            if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, PWS_H2_DEPTH_CT2, TA, true>), grid, dim3(256), 0, stream, g);
+            if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, 1, TA, true>), grid, dim3(256), 0, stream, g);
             else hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 2, TA, true>), grid, dim3(256), 0, stream, g);
             return;
         }
     }
 #endif
-    if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, sizeof(TA) == 2 ? PWS_A16_DEPTH_CT2 : 1, TA>), grid, dim3(256), 0, stream, g);
+    if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, 1, TA>), grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 2, TA>), grid, dim3(256), 0, stream, g);
 }
 
@@ -936,10 +854,7 @@ int pw_split_blocks_per_frame(int N, int P) {
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
             ncu = 256;
-#ifndef PWS_BLOCKS_PER_CU
-#define PWS_BLOCKS_PER_CU 2
-#endif
-        slots = PWS_BLOCKS_PER_CU * ncu;
+        slots = 2 * ncu;
     }
     const int ntile = P / PWS_TP;
     int bpf = slots / N;

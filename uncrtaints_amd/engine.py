@@ -1122,9 +1122,14 @@ def residual_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool 
 # in_conv: Conv2d(15->128,k1,bias) + GroupNorm(4) + ReLU   (utae.py:453-520, uncrtaints.py:310-314)
 # ------------------------------------------------------------------------------------------------
 
-def _inconv_moments_ok(x: Tensor, N: int, Cin: int, Cout: int, spec: NormSpec, gw) -> bool:
-    return (_INCONV_MOMENTS and spec.kind == "group" and gw is not None and Cin + 1 <= 16 and 64 < Cout <= 256
-            and Cout % spec.groups == 0 and N <= 64)
+def _inconv_moments_ok(x: Tensor, N: int, Cin: int, Cout: int, spec: NormSpec, gw, P: int) -> bool:
+    """The moment path is taken in the FORWARD and leaves no c0 behind, so everything its backward needs is checked here: the limits
+    of uncr_inconv_moments (P % 4) and of uncr_inconv_bwd_finish, which holds [N][Cout / G] partial pairs of a group in 60 KB of LDS
+    (csrc/inconv.hip: (2 N Cg + 4 N + 288) doubles) -- at width 256 (Cg = 64) that is N = B*T <= 56; beyond it the generic path."""
+    if not (_INCONV_MOMENTS and spec.kind == "group" and gw is not None and Cin + 1 <= 16 and 64 < Cout <= 256
+            and Cout % spec.groups == 0 and N <= 64 and P % 4 == 0):
+        return False
+    return (2 * N * (Cout // spec.groups) + 4 * N + 288) * 8 <= 60 * 1024
 
 
 def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec: NormSpec, training: bool,
@@ -1135,7 +1140,7 @@ def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec
     buffers = buffers or {}
     need = spec.needs_stats(training)
     Wt = pack_wt(w.reshape(Cout, Cin), transpose=True)
-    if _inconv_moments_ok(x, N, Cin, Cout, spec, gw):
+    if _inconv_moments_ok(x, N, Cin, Cout, spec, gw, P):
         # c0 = W x + b is never written: its GroupNorm statistics are a quadratic form in the frame's 16 x 16 augmented moment matrix,
         # and the GEMM's epilogue stores relu(A*c0 + B) straight from the accumulators (csrc/inconv.hip)
         dev = x.device

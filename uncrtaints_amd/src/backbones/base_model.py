@@ -184,7 +184,14 @@ class BaseModel(nn.Module):
     # emptied before the capture, so nothing packed earlier is baked in).  The key holds the parameters' addresses: a model moved or
     # re-created is captured afresh.  `fake_B` is a copy of the static output (the caller may keep it across iterations).
     def _graph_forward(self):
-        key = ("eval_forward", tuple(self.real_A.shape), self.real_A.dtype, None if self.dates is None else tuple(self.dates.shape),
+        # everything that shapes the launch list: input / dates shapes and dtypes, the activation-storage mode, every sub-module's
+        # train / eval flag (a block left in train() mode takes batch statistics), the engine's development switches, and the
+        # parameters' addresses
+        from ... import engine
+        key = ("eval_forward", tuple(self.real_A.shape), self.real_A.dtype,
+               None if self.dates is None else (tuple(self.dates.shape), self.dates.dtype),
+               str(getattr(self.netG, "act_dtype", None)), tuple(m.training for m in self.netG.modules()),
+               tuple(getattr(engine, v) for v in engine._DEV_OPTIONS.values()),
                tuple(p.data_ptr() for p in self.netG.parameters()))
         g = self._graphs.pop(key, None)
         if g is None:
@@ -201,7 +208,6 @@ class BaseModel(nn.Module):
         if g["graph"] is None:
             if getattr(self, "_gstream", None) is None:
                 self._gstream = torch.cuda.Stream(device=self.real_A.device)
-            from ... import engine
             self._gstream.wait_stream(cur)
             with torch.cuda.stream(self._gstream):
                 g["A"] = self.real_A.clone()
