@@ -345,6 +345,22 @@ int uncr_aggregate_bwd(const void* dg, const void* e, const float* att, const in
                        unsigned long long seed, const long long* seed_dev, float p_drop, int shared_mask,
                        void* de, float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int AH,
                        int AW, int act /* storage of dg, e and de */, hipStream_t stream);
+/* The same backward in two passes, for the case where the statistics pass of the block that produced e follows anyway (autograd of
+ * uncrtaints.py:403-412: the gradient of e is the aggregator's de PLUS the max-pool's scatter of d(down)):
+ *   uncr_aggregate_bwd_datt: the attention's gradient alone (reads dg and e, writes nothing at full resolution);
+ *   uncr_aggregate_bwd_de:   de = a * dg + [pooled gradient dpool at the arg-max pidx of the OH x OW max-pool of e], written once,
+ *                            with the (sum de, sum de*h3) partials `part` ([B*T*C][P / 1024] float2) and per-block maxima `amax` of
+ *                            the producing block's norm-3 backward.  dpool / pidx, h3 / part and amax may be null (no scatter / no
+ *                            statistics).  Windows disjoint with a width that is a multiple of 4 (uncr_aggregate_bwd_de_supported). */
+int uncr_aggregate_bwd_datt(const void* dg, const void* e, const float* att, const int* pad, const float* dmask,
+                            unsigned long long seed, const long long* seed_dev, float p_drop, int shared_mask,
+                            float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int AH, int AW,
+                            int act, hipStream_t stream);
+int uncr_aggregate_bwd_de_supported(int H, int W, int OH, int OW);
+int uncr_aggregate_bwd_de(const void* dg, const float* att, const int* pad, const float* dmask, unsigned long long seed,
+                          const long long* seed_dev, float p_drop, int shared_mask, void* de, const float* dpool,
+                          const int* pidx, const void* h3, float* part, float* amax, int B, int T, int C, int NH, int H, int W,
+                          int AH, int AW, int OH, int OW, int act, hipStream_t stream);
 /* the aggregator's AvgPool branch (uncrtaints.py:197-204: feature map not larger than the attention map): the attention is
  * average-pooled with kernel = stride = k (= AW / H in the reference) to the feature map's size, no dropout; fp32.
  * Requires AH / k == H and AW / k == W.  datt [NH][B][T][AH][AW] (cells the pooling never reads get 0). */

@@ -665,6 +665,39 @@ def case_usev():
     print("g12_usev train loss", l.item(), "keys", len(out))
 
 
+def case_usev_modes():
+    """G20: UNCRTAINTS(use_v=True) with agg_mode 'att_mean' and 'mean' (uncrtaints.py:179-192,211-221 with 324-338,414-417): the weights
+    and inputs of g12_usev (loaded from that fixture: only results are stored here) -- eval / train outputs on a stride-8 grid with
+    checksums, the train loss, and a checksum of every parameter gradient."""
+    g12 = np.load(os.path.join(HERE, "g12_usev.npz"))
+    state = {k[len("state/"):]: torch.from_numpy(g12[k]).clone() for k in g12.files if k.startswith("state/")}
+    x, y, dates = (torch.from_numpy(g12[k]) for k in ("x", "y", "dates"))
+    out = {}
+    for mode in ("att_mean", "mean"):
+        m = uncrtaints.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus",
+                                  covmode="diag", scale_by=1.0, use_v=True, agg_mode=mode)
+        m.load_state_dict(state, strict=True)
+        m.temporal_aggregator.attn_dropout.p = 0.0
+        m.temporal_encoder.dropout.p = 0.0
+        m.eval()
+        with torch.no_grad():
+            oe = m(x, batch_positions=dates)
+        out[f"{mode}/eval_slice"] = oe[:, 0, :, ::8, ::8].numpy()
+        out[f"{mode}/eval_checksum"] = checksum(oe.numpy())
+        m.train()
+        ot = m(x, batch_positions=dates)
+        l, _ = crit("diag")(ot[:, :, :13], y, ot[:, :, 13:26])
+        l.backward()
+        out[f"{mode}/train_slice"] = ot.detach()[:, 0, :, ::8, ::8].numpy()
+        out[f"{mode}/train_checksum"] = checksum(ot.detach().numpy())
+        out[f"{mode}/train_loss"] = np.array(l.item())
+        for k, v in m.named_parameters():
+            if v.grad is not None:
+                out[f"{mode}/gradsum/{k}"] = checksum(v.grad.numpy())
+        print("g20_usev_modes", mode, "train loss", l.item())
+    np.savez_compressed(os.path.join(HERE, "g20_usev_modes.npz"), **out)
+
+
 def case_residual():
     """G13: UNCRTAINTS(block_type='residual'): ResidualConvBlock = 3 x (dense conv3x3 reflect + norm + ReLU) + skip
     (uncrtaints.py:24-69).  Small network (2 decoder blocks) to keep the fixture small."""
@@ -780,6 +813,8 @@ if __name__ == "__main__":
     case_attention_rows(); sys.exit(0)
   if "--only-usev" in sys.argv:
     case_usev(); sys.exit(0)
+  if "--only-usev-modes" in sys.argv:
+    case_usev_modes(); sys.exit(0)
   if "--only-residual" in sys.argv:
     case_residual(); sys.exit(0)
   if "--only-trainseq" not in sys.argv:
@@ -793,6 +828,7 @@ if __name__ == "__main__":
     case_aggpool()
     case_attention_rows()
     case_usev()
+    case_usev_modes()
     case_residual()
     case_posenc()
     case_ensemble()

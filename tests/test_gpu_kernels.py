@@ -945,6 +945,56 @@ def test_pool_scatter_fused_with_statistics(E, H, W, bf):
         assert torch.equal(amax, ref.float().view(planes, slots, 1024).abs().amax(dim=2))
 
 
+@pytest.mark.parametrize("H,W,bf,masked,padded", [(128, 128, False, False, False), (256, 256, False, True, True), (64, 128, True, True, False),
+                                                    (256, 256, True, False, True)])
+def test_aggregate_backward_in_two_passes(E, H, W, bf, masked, padded):
+    """uncr_aggregate_bwd_datt + uncr_aggregate_bwd_de against the one-pass backward followed by uncr_pool_scatter_stats: the attention
+    gradient is bit-identical; with fp32 storage de, the (sum de, sum de*h3) partials and the per-block maxima are bit-identical too
+    (bf16 storage: one rounding of a*dg + d(pooled) instead of two at the arg-max elements, so de may differ there by one bf16 ulp)."""
+    import uncrtaints_amd.hip_backend as hb
+    B, T, C, NH = 2, 3, 128, 16
+    dt = torch.bfloat16 if bf else torch.float32
+    e = dev(rand(B, T, C, H, W, seed=1)).to(dt)
+    att = dev(torch.softmax(rand(NH, B, T, 32, 32, seed=2), dim=2))
+    pad = torch.zeros(B, T, dtype=torch.int32)
+    if padded:
+        pad[B - 1, 0] = 1
+    dm = dev((torch.rand(NH * B, T, H, W, generator=torch.Generator().manual_seed(5)) > 0.1).float() / 0.9) if masked else None
+    g, sv, _ = E.aggregate_forward(e, att, dev(pad), True, 0.1, 1234, dm)
+    dg = dev(rand(B, C, H, W, seed=3)).to(dt)
+    h3 = dev(rand(B, T, C, H, W, seed=4)).to(dt)
+    down, idx = E.maxpool_forward(e.view(B * T, C, H, W), 32, 32)
+    ddown = dev(rand(B * T, C, 32 * 32, seed=6))
+    assert hb.query("uncr_aggregate_bwd_de_supported", H, W, 32, 32) == 1
+    assert hb.query("uncr_aggregate_bwd_de_supported", 64, 64, 32, 32) == 0        # 2-pixel windows
+    # reference: one pass, then scatter + statistics
+    de_ref, datt_ref = E.aggregate_backward(dg, sv)
+    slots = hb.query("uncr_ew_slots", H * W)
+    part_ref = torch.empty(B * T * C, slots, 2, device=DEV)
+    amax_ref = None if bf else torch.empty(B * T * C, slots, device=DEV)
+    hb.call("uncr_pool_scatter_stats", ddown, idx, de_ref, h3, part_ref, B * T * C, H, W, 32, 32, 1 if bf else 0, amax_ref, E._stream())
+    # two passes
+    datt = E.aggregate_backward_datt(dg, sv)
+    assert torch.equal(datt, datt_ref)
+    de, part = E.aggregate_backward_de(dg, sv, ddown, idx, 32, h3)
+    if not bf:
+        assert torch.equal(de, de_ref)
+        assert torch.equal(part.buf, part_ref)
+        assert torch.equal(part.amax.view(-1), amax_ref.view(-1))
+    else:
+        d = (de.float() - de_ref.float()).abs().view(B * T * C, H * W)
+        is_argmax = torch.zeros(B * T * C, H * W, dtype=torch.bool, device=DEV)
+        is_argmax.scatter_(1, idx.view(B * T * C, -1).long(), True)
+        assert float(d[~is_argmax].max()) == 0.0             # only arg-max elements can differ ...
+        # ... by the bf16 rounding of the product that the one-pass kernel stored before the scatter kernel added to it
+        assert float(d.max()) < 2 ** -7 * float(de_ref.float().abs().max())
+        close("two_pass/part", part.buf.double().sum(1), part_ref.double().sum(1), tol=2e-3)
+    # without the scatter and the statistics: plain de
+    de0, p0 = E.aggregate_backward_de(dg, sv, None, None, 32, None)
+    de_plain, _ = E.aggregate_backward(dg, sv)
+    assert p0 is None and torch.equal(de0, de_plain)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("norm", ["group", "batch", "instance"])
 @pytest.mark.parametrize("training", [True, False])

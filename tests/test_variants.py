@@ -257,6 +257,81 @@ def test_hip_usev():
     assert not torch.equal(a, b)
 
 
+# ---- use_v with agg_mode 'att_mean' / 'mean' (uncrtaints.py:179-192,211-221 with 324-338,414-417): fixture g20_usev_modes generated from
+#      the reference on g12_usev's weights and inputs ----
+def _usev_mode_oracle(mode, state, x, y, dates, dtype=torch.float32, pool_idx=None):
+    cfg = orc.OracleConfig(use_v=True, agg_mode=mode, attn_dropout=0.0, ltae_dropout=0.0)
+    cast = lambda v: v.clone().to(dtype) if v.dtype.is_floating_point else v.clone()
+    with torch.no_grad():
+        oe = orc.forward({k: cast(v) for k, v in state.items()}, x.to(dtype), dates.to(dtype), cfg, training=False)
+    pt = {k: (cast(v).requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else cast(v)) for k, v in state.items()}
+    ot = orc.forward(pt, x.to(dtype), dates.to(dtype), cfg, training=True, pool_idx=pool_idx)
+    loss = orc.loss_from_output(ot, y.to(dtype), cfg)
+    loss.backward()
+    return oe, ot.detach(), loss.item(), {k: v.grad for k, v in pt.items() if getattr(v, "grad", None) is not None}, cfg
+
+
+@pytest.mark.parametrize("mode", ["att_mean", "mean"])
+def test_oracle_usev_modes_match_reference_fixture(mode):
+    g = load_golden("g20_usev_modes")
+    _, state, x, y, dates = _usev_inputs()
+    oe, ot, loss, g32, _ = _usev_mode_oracle(mode, state, x, y, dates)
+    _, ot64, loss64, g64, _ = _usev_mode_oracle(mode, state, x, y, dates, torch.float64)
+    assert rel_err(oe[:, 0, :, ::8, ::8].numpy(), g[f"{mode}/eval_slice"]) < 5e-6
+    assert abs(checksum(oe.numpy())[1] - g[f"{mode}/eval_checksum"][1]) < 1e-5 * g[f"{mode}/eval_checksum"][1]
+    # train mode on the ill-conditioned weight_init weights: the reference's own fp32 result and the oracle's are held to the fp64
+    # evaluation (as for g12_usev)
+    e_ref = rel_err(g[f"{mode}/train_slice"], ot64[:, 0, :, ::8, ::8].numpy())
+    e_orc = rel_err(ot[:, 0, :, ::8, ::8].numpy(), ot64[:, 0, :, ::8, ::8].numpy())
+    assert e_orc < 2e-4 and e_orc < 3 * e_ref + 1e-6, (e_orc, e_ref)
+    assert abs(loss - float(g[f"{mode}/train_loss"])) < 1e-4 * abs(loss64)
+    checked = 0
+    for k, v64 in g64.items():
+        if float(v64.abs().max()) < 1e-7 or f"{mode}/gradsum/{k}" not in g.files:
+            continue
+        ref = g[f"{mode}/gradsum/{k}"]
+        assert abs(checksum(g32[k].numpy())[1] - ref[1]) < 2e-3 * abs(ref[1]), k          # sum of |gradient|
+        checked += 1
+    assert checked > 80
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["att_mean", "mean"])
+def test_hip_usev_modes(mode):
+    from gpu_util import Fp32Draws, close, close_grad, close_vs_truth, dev, pool_branch
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    from uncrtaints_amd.src import losses
+    g = load_golden("g20_usev_modes")
+    _, state, x, y, dates = _usev_inputs()
+    m = U.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag", scale_by=1.0,
+                     use_v=True, agg_mode=mode)
+    m.load_state_dict(state, strict=True)
+    m.temporal_aggregator.attn_dropout.p = 0.0
+    m.temporal_encoder.dropout.p = 0.0
+    m = m.to("cuda").eval()
+    with torch.no_grad():
+        out_eval = m(dev(x), batch_positions=dev(dates))
+    m.train()
+    out = m(dev(x), batch_positions=dev(dates))
+    l, _ = losses.MultiGaussianNLLLoss(reduction="mean", full=True, mode="diag")(out[:, :, :13], dev(y), out[:, :, 13:26])
+    l.backward()
+    cfg = orc.OracleConfig(use_v=True, agg_mode=mode, attn_dropout=0.0, ltae_dropout=0.0)
+    pidx, _ = pool_branch(m, state, x, dates, cfg)
+    oe, ot, loss_o, g32, _ = _usev_mode_oracle(mode, state, x, y, dates, pool_idx=pidx)
+    _, ot64, loss64, g64, _ = _usev_mode_oracle(mode, state, x, y, dates, torch.float64, pool_idx=pidx)
+    close(f"usev_{mode}/eval", out_eval, oe, tol=2e-5)
+    close(f"usev_{mode}/eval_vs_reference_slice", out_eval[:, 0, :, ::8, ::8], torch.from_numpy(g[f"{mode}/eval_slice"]), tol=2e-5)
+    close_vs_truth(f"usev_{mode}/train", out, ot, ot64, slack=4.0, cap=2e-4)
+    assert abs(l.item() - loss64) < 2e-4 * abs(loss64)
+    draws = Fp32Draws(lambda: _usev_mode_oracle(mode, state, x, y, dates, pool_idx=pidx)[3])
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    for k, v in m.named_parameters():
+        if float(g64[k].abs().max()) < 1e-7:
+            assert float(v.grad.abs().max()) < 1e-3 * gmax, k
+            continue
+        close_grad(f"usev_{mode}/grad[{k}]", v.grad, g32[k], g64[k], draws=draws, key=k)
+
+
 # ---- block_type='residual' (ResidualConvBlock: dense 3x3 convolutions): fixture g13_residual from the reference ----
 _RES_KW = dict(decoder_widths=[128, 128], block_type="residual")
 

@@ -29,6 +29,14 @@ struct AggArgs {
     float p_drop;          // > 0 with dmask == null: hash dropout
     int shared_mask;       // 1: one dropout mask per (b,t,pixel) shared by all heads ('att_mean' mode)
     int B, T, C, NH, H, W, AH, AW;
+    // backward pass 2 (BMODE 2): the pooled gradient and the arg-max of the 8x8 (OH x OW) max-pool that was taken from e, the h3 of the block
+    // that produced e, and that block's statistics / magnitude slots
+    const float* dpool = nullptr;   // [B*T*C][OH*OW] or null (no scatter)
+    const int* pidx = nullptr;      // [B*T*C][OH*OW] flat in-plane arg-max
+    const void* h3 = nullptr;       // [B][T][C][P] or null (no statistics)
+    float2* bpart = nullptr;        // [B*T*C][P / 1024] (sum de, sum de*h3)
+    float* amax = nullptr;          // [B*T*C][P / 1024] max |de| or null
+    int OH = 0, OW = 0;
 };
 
 struct Bilin {
@@ -46,6 +54,12 @@ __device__ __forceinline__ Bilin bilin_src(int dst, float scale, int in_size) {
     r.l1 = src - (float)r.i0;
     r.l0 = 1.f - r.l1;
     return r;
+}
+
+// a * b rounded on its own: the multiply carries no `contract` flag, so it cannot be fused into a following add
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
 }
 
 __device__ __forceinline__ float agg_keep(const AggArgs& g, int h, int b, int t, size_t p) {
@@ -72,7 +86,15 @@ __device__ __forceinline__ float agg_keep(const AggArgs& g, int h, int b, int t,
 // order; the block's four rows interpolate between the same two low-res rows, whose 2 x 32 cells the waves combine through LDS, again
 // in a fixed order.  Per (head, date) the block leaves 2 x AW partial cells in datt_up (re-used as [NH*B*T][tiles][2][AW]);
 // datt_fold_reduce_kernel adds the (at most four) tiles that touch a low-res row.  Deterministic; no atomics.
-template <bool BWD, int CH, bool STAGE, typename T, bool FOLD = false>
+// BMODE (backward): 0 = de and datt in one pass (reads dg, e; writes de): the general path.
+// Two-pass backward (round 5), for the case where the last encoder block's statistics pass follows anyway:
+//   1 = datt ONLY (reads dg, e; writes nothing at full resolution): a read-only stream;
+//   2 = de = a * dg + scatter(pooled gradient at the arg-max) written ONCE, with the (sum de, sum de*h3) partials and the per-block
+//       maxima the encoder block's backward needs, in the same pass (reads dg, h3; e is not touched).
+// One-pass + uncr_pool_scatter_stats moved (2T+1) + 2T planes per channel; the two passes move (T+1) + (2T+1): de is never re-read.
+// The statistics are those of uncr_pool_scatter_stats (per 1024-pixel chunk: (x+y)+(z+w), the fma chain, DPP wave sums, the four waves
+// in order), so with fp32 storage the partials are bit-identical to the old pair of launches.
+template <bool BWD, int CH, bool STAGE, typename T, bool FOLD = false, int BMODE = 0>
 __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
     extern __shared__ float att_s[];
     const int b = blockIdx.y;
@@ -86,7 +108,8 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
     for (int j = 0; j < 4; ++j) bx[j] = bilin_src(x0 + j, sx, g.AW);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
-    __shared__ float wred[4][256][2];   // per-wave statistics partials (forward), C <= 256
+    __shared__ float wred[BMODE == 2 ? 1 : 4][BMODE == 2 ? 1 : 256][2];   // per-wave statistics partials (forward), C <= 256
+    __shared__ float sred[2][BMODE == 2 ? 4 : 1][BMODE == 2 ? CH : 1][3];    // pass 2: per-wave (sum, sum*h3, max) of the CH planes of one (head, date)
     __shared__ float rowc[FOLD ? 2 : 1][4][32];      // FOLD: the four rows' cells, weighted for the two low-res rows
     // heads are split over blockIdx.z (more blocks in flight: the kernel is pure latency/bandwidth bound)
     const int hpb = (g.NH + gridDim.z - 1) / gridDim.z;
@@ -124,6 +147,74 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
                 keep[j] = agg_keep(g, h, b, t, (size_t)p0 + j);
                 a[j] = (by.l0 * top + by.l1 * bot) * keep[j];
             }
+            if constexpr (BWD && BMODE == 2) {
+                // pass 2: every load of this (head, date) -- the CH rows of h3 and the CH window indices -- is requested before the first
+                // dependent instruction (groups of at most 8 channels: 32 operand registers)
+                // Branch-free: a load under a per-lane branch costs an s_waitcnt vmcnt(0) at the join, and on gfx9 the stores share that counter --
+                // the first version (the pooled gradient read only by the lanes that hold an arg-max) waited for every earlier store of the
+                // block at each channel: 378 us for 940 MB, whatever the storage type.  The pooled value is read by every lane (the index
+                // and value tables are 6 MB, cache resident) and selected.
+                constexpr int GB = CH < 4 ? CH : 4;      // (eight rows in flight with bf16 storage: 169 VGPRs, 213 -> 265 us)
+                const unsigned cell = (unsigned)(y / (g.H / (g.OH > 0 ? g.OH : 1))) * (unsigned)g.OW + (unsigned)(x0 / (g.W / (g.OW > 0 ? g.OW : 1)));
+                const unsigned ncell = (unsigned)(g.OH * g.OW);
+                const int* pix = g.dpool ? g.pidx : (const int*)g.att;         // dummy readable locations when there is no scatter
+                const float* dpl = g.dpool ? g.dpool : g.att;
+                const bool scat = g.dpool != nullptr;
+#pragma unroll
+                for (int j0 = 0; j0 < CH; j0 += GB) {
+                    float4 hv[GB];
+                    int kk[GB];
+                    float dpv[GB];
+#pragma unroll
+                    for (int u = 0; u < GB; ++u) {
+                        const unsigned plane = (unsigned)((b * g.T + t) * g.C + h * CH + j0 + u);
+                        hv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (g.h3) hv[u] = ld_nt4t((const T*)g.h3 + (size_t)plane * P + p0);     // (kernel-uniform)
+                        const unsigned q = scat ? plane * ncell + cell : 0u;
+                        kk[u] = pix[q] - p0;            // the window's arg-max relative to this thread's four pixels
+                        dpv[u] = dpl[q];
+                    }
+#pragma unroll
+                    for (int u = 0; u < GB; ++u) {
+                        const int jc = j0 + u;
+                        const size_t eo = (((size_t)b * g.T + t) * g.C + h * CH + jc) * P + p0;
+                        const float4 dgv = acc[jc];
+                        // (products rounded on their own, not contracted with the pooled gradient's add: de then equals the one-pass kernel's
+                        // product + the scatter kernel's add bit for bit)
+                        float4 v = make_float4(mul_rounded(a[0], dgv.x), mul_rounded(a[1], dgv.y), mul_rounded(a[2], dgv.z), mul_rounded(a[3], dgv.w));
+                        const float dd = scat ? dpv[u] : 0.f;
+                        const int k = scat ? kk[u] : -1;
+                        v.x = k == 0 ? v.x + dd : v.x; v.y = k == 1 ? v.y + dd : v.y;
+                        v.z = k == 2 ? v.z + dd : v.z; v.w = k == 3 ? v.w + dd : v.w;
+                        v = rnd4<T>(v);
+                        st_nt4t((T*)g.de + eo, v);
+                        if (g.bpart) {
+                            float s0 = (v.x + v.y) + (v.z + v.w);
+                            float s1 = fmaf(v.x, hv[u].x, fmaf(v.y, hv[u].y, fmaf(v.z, hv[u].z, v.w * hv[u].w)));
+                            s0 = wave_sum_dpp(s0);
+                            s1 = wave_sum_dpp(s1);
+                            float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+                            if (g.amax) m = wave_max_dpp(m);
+                            if (lane == 63) { sred[t & 1][wv][jc][0] = s0; sred[t & 1][wv][jc][1] = s1; sred[t & 1][wv][jc][2] = m; }
+                        }
+                    }
+                }
+                if (g.bpart) {            // kernel-uniform: the CH planes of this (head, date), the four waves in order.  Two buffers by the
+                                          // date's parity: one barrier per date (a buffer is rewritten two barriers after it was read)
+                    __syncthreads();
+                    if (threadIdx.x < CH) {
+                        const int jc = threadIdx.x;
+                        const size_t slot = (((size_t)b * g.T + t) * g.C + h * CH + jc) * gridDim.x + blockIdx.x;
+                        float sa = 0.f, sb = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { sa += sred[t & 1][i][jc][0]; sb += sred[t & 1][i][jc][1]; }
+                        g.bpart[slot] = make_float2(sa, sb);
+                        if (g.amax) g.amax[slot] = fmaxf(fmaxf(sred[t & 1][0][jc][2], sred[t & 1][1][jc][2]),
+                                                         fmaxf(sred[t & 1][2][jc][2], sred[t & 1][3][jc][2]));
+                    }
+                }
+                continue;
+            }
             float d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int jc = 0; jc < CH; ++jc) {
@@ -136,7 +227,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
                     acc[jc].w = fmaf(a[3], ev.w, acc[jc].w);
                 } else {
                     const float4 dgv = acc[jc];
-                    st_nt4t((T*)g.de + eo, make_float4(a[0] * dgv.x, a[1] * dgv.y, a[2] * dgv.z, a[3] * dgv.w));
+                    if constexpr (BMODE == 0) st_nt4t((T*)g.de + eo, make_float4(a[0] * dgv.x, a[1] * dgv.y, a[2] * dgv.z, a[3] * dgv.w));
                     d[0] = fmaf(dgv.x, ev.x, d[0]);
                     d[1] = fmaf(dgv.y, ev.y, d[1]);
                     d[2] = fmaf(dgv.z, ev.z, d[2]);
@@ -287,20 +378,20 @@ static int agg_rows(int H, int W, int AH) {
 // the in-kernel adjoint of the up-sampling (aggregate_kernel FOLD) applies to the 8x up-sampling of 256-pixel rows
 static bool agg_fold(const AggArgs& g) { return g.W == 256 && g.W == 8 * g.AW && g.H == 8 * g.AH && g.AW == 32; }
 
-template <bool BWD, typename T>
+template <bool BWD, typename T, int BMODE = 0>
 static void agg_launch(const AggArgs& g, hipStream_t stream) {
     const int zs = g.NH <= 64 ? g.NH : (g.NH % 4 == 0 ? 4 : 1);      // one head per block: measured 4 % faster than four (more blocks in flight)
     const dim3 grid(g.H * g.W / AGG_PX, g.B, zs);
     const int nrows = agg_rows(g.H, g.W, g.AH);
     const size_t lds = (size_t)((g.NH + zs - 1) / zs) * g.T * nrows * g.AW * sizeof(float);
     const bool stage = lds <= 48 * 1024;
-    const bool fold = BWD && agg_fold(g);
+    const bool fold = BWD && BMODE != 2 && agg_fold(g);      // (pass 2 takes no attention gradient)
 #define AGG_GO(CHV)                                                                                              \
     do {                                                                                                         \
-        if (fold && stage) hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, true, T, BWD>), grid, dim3(256), lds, stream, g, nrows); \
-        else if (fold) hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, false, T, BWD>), grid, dim3(256), 0, stream, g, nrows);      \
-        else if (stage) hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, true, T>), grid, dim3(256), lds, stream, g, nrows); \
-        else hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, false, T>), grid, dim3(256), 0, stream, g, nrows);        \
+        if (fold && stage) hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, true, T, BWD && BMODE != 2, BMODE>), grid, dim3(256), lds, stream, g, nrows); \
+        else if (fold) hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, false, T, BWD && BMODE != 2, BMODE>), grid, dim3(256), 0, stream, g, nrows);      \
+        else if (stage) hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, true, T, false, BMODE>), grid, dim3(256), lds, stream, g, nrows); \
+        else hipLaunchKernelGGL((aggregate_kernel<BWD, CHV, false, T, false, BMODE>), grid, dim3(256), 0, stream, g, nrows);        \
     } while (0)
     switch (g.C / g.NH) {
         case 2: AGG_GO(2); break;
@@ -343,6 +434,49 @@ extern "C" int uncr_aggregate_bwd(const void* dg, const void* e, const float* at
     } else {
         hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(AH, NH * B * T), dim3(256), 0, stream, datt_up, datt, H, W, AH, AW);
     }
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+// Two-pass backward (see aggregate_kernel): pass 1 = the attention's gradient alone ...
+extern "C" int uncr_aggregate_bwd_datt(const void* dg, const void* e, const float* att, const int* pad, const float* dmask,
+                                       unsigned long long seed, const long long* seed_dev, float p_drop, int shared_mask,
+                                       float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int AH, int AW, int act,
+                                       hipStream_t stream) {
+    const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
+    if (rc) return rc;
+    if (!dg || !e || !att || !datt_up || !datt || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
+    AggArgs g{e, att, pad, dmask, nullptr, dg, nullptr, datt_up, nullptr, seed, seed_dev, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
+    UNCR_DISPATCH_ACT(act, T, (agg_launch<true, T, 1>(g, stream)));
+    UNCR_LAUNCH_CHECK();
+    if (agg_fold(g)) {
+        const long long n = (long long)NH * B * T * AH * AW;
+        hipLaunchKernelGGL(datt_fold_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, datt_up, datt, H, W, AH,
+                           AW, H * W / AGG_PX, n);
+    } else {
+        hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(AH, NH * B * T), dim3(256), 0, stream, datt_up, datt, H, W, AH, AW);
+    }
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+// ... pass 2 = de = a * dg (+ the pooled gradient at the arg-max of the OH x OW max-pool of e) with the producing block's statistics.
+// Windows as in uncr_pool_scatter_stats: disjoint, width a multiple of 4 (H % OH == 0, W % OW == 0, (W / OW) % 4 == 0).
+extern "C" int uncr_aggregate_bwd_de_supported(int H, int W, int OH, int OW) {
+    return (OH > 0 && OW > 0 && H % OH == 0 && W % OW == 0 && ((W / OW) & 3) == 0 && ((H * W) % AGG_PX) == 0) ? 1 : 0;
+}
+extern "C" int uncr_aggregate_bwd_de(const void* dg, const float* att, const int* pad, const float* dmask, unsigned long long seed,
+                                     const long long* seed_dev, float p_drop, int shared_mask, void* de, const float* dpool,
+                                     const int* pidx, const void* h3, float* part, float* amax, int B, int T, int C, int NH, int H, int W,
+                                     int AH, int AW, int OH, int OW, int act, hipStream_t stream) {
+    const int rc = agg_check(B, T, C, NH, H, W, AH, AW);
+    if (rc) return rc;
+    if (!dg || !att || !de || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
+    if ((dpool != nullptr) != (pidx != nullptr) || (part != nullptr) != (h3 != nullptr) || (amax && !part)) return UNCR_EINVAL;
+    if (dpool && !uncr_aggregate_bwd_de_supported(H, W, OH, OW)) return UNCR_ESHAPE;
+    if (dpool && (unsigned long long)B * T * C * OH * OW >= (1ull << 31)) return UNCR_ESHAPE;      // 32-bit cell offsets
+    AggArgs g{nullptr, att, pad, dmask, nullptr, dg, de, nullptr, nullptr, seed, seed_dev, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
+    g.dpool = dpool; g.pidx = pidx; g.h3 = h3; g.bpart = (float2*)part; g.amax = amax; g.OH = OH; g.OW = OW;
+    UNCR_DISPATCH_ACT(act, T, (agg_launch<true, T, 2>(g, stream)));
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -325,6 +325,17 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return v;
 }
 
+// max over the whole wave of NON-NEGATIVE values (the update_dpp fill for lanes without a source is 0); valid in lane 63 ONLY
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x124>(v));
+    v = fmaxf(v, dpp_mov<0x128>(v));
+    v = fmaxf(v, dpp_mov<0x142, 0xA, 0xF, false>(v));
+    v = fmaxf(v, dpp_mov<0x143, 0xC, 0xF, false>(v));
+    return v;
+}
+
 // Block-wide sum of two floats; result valid in thread 0.  `red` must hold >= 2*nwaves floats.
 template <int NTHREADS>
 __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {

@@ -315,7 +315,7 @@ _LTAE_STORE: Dict[str, tuple] = {}
 
 _DEV_OPTIONS = {"ltae_replay": "_LTAE_REPLAY", "side_stream": "_USE_SIDE", "centred_normbwd": "_CENTRED_NORMBWD", "h2_bwd": "_H2_BWD", "h2_wgrad": "_H2_WGRAD",
                 "h2_dx": "_H2_DX", "h2_fwd": "_H2_FWD", "prepack": "_PREPACK", "fused_dx": "_FUSED_DX", "fused_ltae": "_FUSED_LTAE",
-                "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER", "inconv_moments": "_INCONV_MOMENTS", "se_pool4": "_SE_POOL4", "eval_tail": "_EVAL_TAIL"}
+                "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER", "inconv_moments": "_INCONV_MOMENTS", "se_pool4": "_SE_POOL4", "eval_tail": "_EVAL_TAIL", "agg_two_pass": "_AGG_TWO_PASS"}
 
 
 class dev_options:
@@ -1422,6 +1422,44 @@ def aggregate_backward(dg: Tensor, sv: dict):
     return de, datt
 
 
+def aggregate_backward_datt(dg: Tensor, sv: dict) -> Tensor:
+    """Pass 1 of the two-pass backward (csrc/aggregate.hip): -> datt [nh,B,T,ah,aw]; nothing is written at full resolution."""
+    B, T, C, H, W, n_head, ah, aw = sv["dims"]
+    dev = dg.device
+    dt = _dt(sv["e"])
+    datt_up = _f32((n_head, B, T, H * W), dev)
+    datt = _f32((n_head, B, T, ah, aw), dev)
+    hb.call("uncr_aggregate_bwd_datt", cast(dg.contiguous(), dt), sv["e"], sv["att"], sv["pad"], sv["dmask"], sv["seed"], sv["seed_dev"],
+            sv["pd"], sv["shared"], datt_up, datt, B, T, C, n_head, H, W, ah, aw, dt, _stream())
+    return datt
+
+
+def aggregate_backward_de(dg: Tensor, sv: dict, ddown: Optional[Tensor], idx: Optional[Tensor], att_down: int,
+                          e_h3: Optional[Tensor]):
+    """Pass 2: de [B,T,C,H,W] = a * dg + the pooled gradient scattered to the arg-max, written once, with the (sum de, sum de*h3)
+    partials (and per-block maxima) of the block that produced e.  -> (de, Part or None)"""
+    B, T, C, H, W, n_head, ah, aw = sv["dims"]
+    dev = dg.device
+    dt = _dt(sv["e"])
+    de = _act((B, T, C, H, W), dev, dt)
+    part = None
+    if e_h3 is not None:
+        slots = hb.query("uncr_ew_slots", H * W)
+        part = Part(_f32((B * T * C, slots, 2), dev), slots)
+        if dt == F32 and _H2_BWD:
+            part.amax = _f32((B * T, C * slots), dev)     # per-block max |de|, one row per frame
+    hb.call("uncr_aggregate_bwd_de", cast(dg.contiguous(), dt), sv["att"], sv["pad"], sv["dmask"], sv["seed"], sv["seed_dev"], sv["pd"],
+            sv["shared"], de, ddown.contiguous() if ddown is not None else None, idx if ddown is not None else None, e_h3,
+            part.buf if part is not None else None, part.amax if part is not None else None, B, T, C, n_head, H, W, ah, aw,
+            att_down, att_down, dt, _stream())
+    return de, part
+
+
+# the aggregation backward in two passes (attention gradient | de + pooled-gradient scatter + the encoder block's statistics): de is written
+# once and never re-read; False: one pass + uncr_pool_scatter_stats (A/B runs, bisecting)
+_AGG_TWO_PASS = True
+
+
 def head_mean_attention(att: Tensor) -> Tensor:
     """'att_mean' (uncrtaints.py:180,212): average the attention over heads, then give every head that average."""
     NH = att.shape[0]
@@ -1592,8 +1630,8 @@ def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor]
     if values is None:
         g, sv_agg, gpart = aggregate_forward(e, w_att, pad, training, p_drop, seed, dmask, want_stats, shared)
         return g, dict(att=sv_att, agg=sv_agg, idx=idx, att_down=att_down, mode=mode), gpart, att
-    if mode != "att_group":
-        raise NotImplementedError("use_v is built for agg_mode='att_group'")
+    # use_v with any aggregation mode (uncrtaints.py:324-338,414-417): the aggregate takes the mode's weights (heads averaged for
+    # 'att_mean', uniform over the unpadded dates for 'mean'), the values always take the attention itself
     g0, sv_agg, _ = aggregate_forward(e, w_att, pad, training, p_drop, seed, dmask, False, shared)
     v, sv_val = ltae_values_forward(sv_att, pad, values["p"], n_head, training, values.get("bn_buffers"),
                                     values.get("p_drop", 0.0), values.get("seed", 0))
@@ -1637,15 +1675,34 @@ def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int,
         dg0, dv, dWinc, dbinc = include_v_backward(dg, sv["inc"])
         de, datt = aggregate_backward(dg0, sv["agg"])
         dy1, datt_v, gv = ltae_values_backward(dv.reshape(dv.shape[0], dv.shape[1], -1), sv["val"], sv["vp"], n_head)
-        hb.call("uncr_add", datt, datt_v, datt, datt.numel(), _stream())
+        vmode = sv.get("mode", "att_group")
+        if vmode == "mean":          # the aggregate's weights are constants: the attention is reached through the values alone
+            datt = datt_v.contiguous().view_as(datt)
+        else:
+            if vmode == "att_mean":
+                datt = head_mean_attention_backward(datt)
+            hb.call("uncr_add", datt, datt_v, datt, datt.numel(), _stream())
         ddown, g = ltae_attention_backward(datt, sv["att"], p, n_head, d_k, dy1_extra=dy1)
         part = _pool_scatter(ddown, sv, de, e_h3)
         g.update(gv)
         g["include_w"], g["include_b"] = dWinc, dbinc
         join_side()
         return de, g, part
-    de, datt = aggregate_backward(dg, sv["agg"])
     mode = sv.get("mode", "att_group")
+    agg = sv["agg"]
+    # (fp32 storage: 342 -> 304 us for the pair of full-resolution launches; bf16 storage keeps the one-pass kernel + the four-chunk
+    # scatter: its 8-byte rows leave the second pass short of bytes in flight, 214 -> 302 us)
+    if (_AGG_TWO_PASS and mode in ("att_group", "att_mean") and "pool_k" not in agg and e_h3 is not None and _dt(agg["e"]) == F32
+            and e_h3.numel() == agg["e"].numel() and e_h3.dtype == agg["e"].dtype and e_h3.is_contiguous()
+            and hb.query("uncr_aggregate_bwd_de_supported", agg["dims"][3], agg["dims"][4], sv["att_down"], sv["att_down"]) == 1):
+        datt = aggregate_backward_datt(dg, agg)
+        if mode == "att_mean":
+            datt = head_mean_attention_backward(datt)
+        ddown, g = ltae_attention_backward(datt, sv["att"], p, n_head, d_k)
+        de, part = aggregate_backward_de(dg, agg, ddown, sv["idx"], sv["att_down"], e_h3)
+        join_side()          # the attention's parameter-gradient chain ran next to the second pass
+        return de, g, part
+    de, datt = aggregate_backward(dg, sv["agg"])
     if mode == "mean":
         # the attention does not reach the output: no gradient to the temporal encoder (returned as zeros)
         g = {k: torch.zeros_like(v) for k, v in p.items()}

@@ -462,8 +462,8 @@ class UNCRTAINTS(nn.Module):
             raise NotImplementedError("the GEMM kernels take at most 256 channels per operand: block widths <= 256, d_model <= 256 with use_v")
         if block_type not in ('mbconv', 'residual'):
             raise NotImplementedError(block_type)
-        if use_v and (agg_mode != "att_group" or is_mono):
-            raise NotImplementedError("use_v is built for agg_mode='att_group' on image time series")
+        # use_v with is_mono: the reference builds neither a temporal encoder nor include_v then (uncrtaints.py:322-348) -- the flag is
+        # stored and has no effect, as there
         if agg_mode not in ("att_group", "att_mean", "mean"):
             raise NotImplementedError(f"agg_mode '{agg_mode}'")
         # padding_mode is stored and never used by the reference's UNCRTAINTS either (uncrtaints.py:299 is its only use: MBConv
