@@ -789,9 +789,11 @@ def main():
                 n_ = int(m_.group(1))
                 for n2 in (n_ * T, n_ // T if n_ % T == 0 else 0):
                     if n2 and n2 != n_:
-                        r2 = by_label.get(label[:m_.start()] + f"N{n2}" + label[m_.end():])
-                        if r2 is not None:
-                            return r2
+                        other = label[:m_.start()] + f"N{n2}" + label[m_.end():]
+                        # (the encoder's dx launch takes its ReLU mask from x itself: same kernel family, one operand stream less)
+                        for cand in (other, other + ",relu_x", other.replace(",relu_x", "")):
+                            if cand in by_label and cand != label:
+                                return by_label[cand]
                 return None
             tw = twin_of(top["kernel"])
             if tw is not None and res["roofline"]["bound"] == "hbm":

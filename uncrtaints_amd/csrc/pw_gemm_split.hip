@@ -839,7 +839,16 @@ static void pws_launch_epi(const PwArgs& g, dim3 grid, int cp, hipStream_t strea
     }
 #endif
     if (cp == 256) hipLaunchKernelGGL((pw_gemm_split_kernel<2, PWS_PRO, EPI, 1, TA>), grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 2, TA>), grid, dim3(256), 0, stream, g);
+    else {
+#if PWS_PRO == 0
+        // in_conv (epi 9, Cin <= 15): ONE chunk holds the whole contraction axis; with two chunks in flight the tile is padded to two
+        // (DEPTH-padding: the second is all zeros) and half of the staging and matrix work of this write-bound GEMM is spent on them
+        if constexpr (EPI == 9) {
+            if (g.Cin <= PWS_KC) { hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 1, TA>), grid, dim3(256), 0, stream, g); return; }
+        }
+#endif
+        hipLaunchKernelGGL((pw_gemm_split_kernel<1, PWS_PRO, EPI, 2, TA>), grid, dim3(256), 0, stream, g);
+    }
 }
 
 #define PWS_CAT2(a, b) a##b
