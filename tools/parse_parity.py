@@ -43,6 +43,10 @@ def main(log, out):
         "source": log, "tests_with_parity_lines": len(tests), "parity_lines": sum(v["lines"] for v in tests.values()),
         "lines_passing_only_on_the_fp64_clause": len(second),
         "worst_e_got_of_those": max((s["e_got"] for s in second), default=0.0),
+        # of those, the lines further than 1e-4 from the fp64 evaluation too: they pass on NOISE x the CPU evaluations' own distance
+        # (the printed cpu-fp32 figure is the largest distance among the fp32 evaluations that were needed to admit the line)
+        "lines_beyond_1e-4_of_fp64": sum(1 for s in second if s["e_got"] > 1e-4),
+        "worst_ratio_e_got_over_e_cpu_of_those_beyond_1e-4": max((s["ratio"] or 0.0 for s in second if s["e_got"] > 1e-4), default=0.0),
         "worst_ratio_e_got_over_e_cpu_of_those": max((s["ratio"] or 0.0 for s in second), default=0.0),
         "worst_e_got_overall": max((v["max_e_got"] for v in three), default=0.0),
         "second_clause_lines": sorted(second, key=lambda s: -(s["ratio"] or 0.0)),
