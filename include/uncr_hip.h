@@ -239,6 +239,46 @@ int uncr_dw_bwd(const void* du2, const void* h2, const void* h1, const float* k1
                 hipStream_t stream);
 int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw, hipStream_t stream);
 
+/* ---- any H x W (the reference takes any spatial size, uncrtaints.py:391-447).  For sizes outside the tuned tilings (H*W % 1024, W % 4)
+ *      the host layer keeps full-resolution tensors as dense planes of H*W pixels + a ZERO tail up to the stride Pc =
+ *      uncr_any_plane_stride(H, W) (0: the size needs none): flat kernels run over the whole stride, uncr_fix_* take the tail's share out
+ *      of the reductions and re-zero it, the 2-D kernels below read and write valid pixels only (csrc/anysize.hip).  fp32 storage. ---- */
+int uncr_any_plane_stride(int H, int W);
+int uncr_any_slots(void);          /* statistics slots per plane of uncr_dw_fwd_any / uncr_dw_bwd_any */
+int uncr_agg_any_slots(void);      /* ... of uncr_aggregate_any_fwd */
+int uncr_embed_tail(const float* src /* [planes][P] */, float* dst /* [planes][Pc] */, int planes, int P, int Pc, hipStream_t stream);
+int uncr_extract_tail(const float* src /* [planes][Pc] */, float* dst /* [planes][P] */, int planes, int P, int Pc, hipStream_t stream);
+/* t [planes][Pc] was written over its whole stride by a point-wise kernel fed with zero tails: every tail pixel of a plane holds one
+ * value v.  mode 0: part [planes][slots] = (sum t, sum t^2) partials lose (n v, n v^2), n = Pc - P; mode 1: (sum t, sum t*aux) with aux
+ * zero on the tail lose (n v, 0); mode 2 / part null: nothing.  Then the tail is zeroed. */
+int uncr_fix_tail(float* t, float* part, int slots, int planes, int P, int Pc, int mode, hipStream_t stream);
+int uncr_fix_sepool_tail(float* part, int slots, const float* cB /* [planes] */, int planes, int ntail, hipStream_t stream);
+int uncr_fix_wgrad_tail(float* G /* [N][Cd][Cx] */, int N, int Cd, int Cx, const float* c2, const float* c3, const float* mu /* [N*Cd], mu nullable */,
+                        const float* cB /* [N*Cx] */, int ntail, hipStream_t stream);
+int uncr_fix_rowsum_tail(float* rs /* [C] */, int N, int C, const float* c2, const float* c3, const float* mu /* [N*C], mu nullable */,
+                         int ntail, hipStream_t stream);
+/* depthwise 3x3 reflect (uncrtaints.py:130-131) with the meaning of uncr_dw_fwd / uncr_dw_bwd on dense H x W planes of stride Pc;
+ * part [N*C][uncr_any_slots()][2], dw_part [N*C][uncr_any_slots()][9] */
+int uncr_dw_fwd_any(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part, int N, int C, int H,
+                    int W, int Pc, hipStream_t stream);
+int uncr_dw_bwd_any(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2, const float* k3,
+                    const float* kmu, const float* cA1, const float* cB1, const float* w, float* du1, float* part, float* dw_part,
+                    const float* mean1, int mean_groups, int N, int C, int H, int W, int Pc, hipStream_t stream);
+/* adaptive max-pool (uncrtaints.py:403-404) on planes of stride pstride; idx = flat index inside the H x W image */
+int uncr_maxpool_fwd_strided(const float* in, float* out, int* idx, int planes, int H, int W, int pstride, int OH, int OW,
+                             hipStream_t stream);
+int uncr_maxpool_bwd_strided(const float* dout, const int* idx, float* din, int planes, int H, int W, int pstride, int OH, int OW,
+                             hipStream_t stream);
+/* temporal aggregation (uncrtaints.py:156-221) with the meaning of uncr_aggregate_fwd / _bwd on planes of stride Pc, any up-sampling
+ * ratio; part [B*C][uncr_agg_any_slots()][2]; datt_up: [NH*B*T][H*W] scratch */
+int uncr_aggregate_any_fwd(const float* e, const float* att, const int* pad, const float* dmask, unsigned long long seed,
+                           const long long* seed_dev, float p_drop, int shared_mask, float* out, float* part, int B, int T, int C,
+                           int NH, int H, int W, int Pc, int AH, int AW, hipStream_t stream);
+int uncr_aggregate_any_bwd(const float* dg, const float* e, const float* att, const int* pad, const float* dmask,
+                           unsigned long long seed, const long long* seed_dev, float p_drop, int shared_mask, float* de,
+                           float* datt_up, float* datt, int B, int T, int C, int NH, int H, int W, int Pc, int AH, int AW,
+                           hipStream_t stream);
+
 /* ---- in_conv = Conv2d(Cin -> Cout, k = 1, bias) + GroupNorm + ReLU (utae.py:453-520 as built at uncrtaints.py:310-314) without
  *      its pre-norm tensor c0 = W x + b (csrc/inconv.hip): with Cin + 1 <= 16 the GroupNorm statistics of c0 are a quadratic form in
  *      the frame's augmented second-moment matrix M~ = sum_p [x;1][x;1]^T, and so are the sums the backward needs.

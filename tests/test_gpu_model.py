@@ -309,6 +309,9 @@ def test_graph_mode_survives_an_optimizer_checkpoint_with_a_float_learning_rate(
     (1, 12, 64, 64, ""),           # a long series
     (1, 2, 64, 512, ""),           # wide frames: 2x / 16x up-sampling, depthwise kernels for W != 256
     (2, 3, 64, 64, "all_padded"),  # every date of sample 1 is padding (all-zero frames)
+    (1, 2, 100, 100, ""),          # any H x W (csrc/anysize.hip): H*W not a multiple of 1024 -- padded planes, tail corrections
+    (1, 2, 250, 250, ""),          # ... and W not a multiple of 4: the scalar 2-D kernels
+    (2, 2, 70, 90, ""),            # ... two samples, a non-square image
 ])
 def test_vs_oracle_fresh_inputs(B, T, H, W, special):
     """Fresh seeded inputs (incl. the BASELINE 256x256 size and shape / padding edge cases) against the CPU oracle,

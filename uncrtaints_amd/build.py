@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libuncr_hip.so")
 DEV_LIB = os.path.join(LIBDIR, "libuncr_dev.so")     # development probes (include/uncr_dev.h): never loaded by the product path
 # (source stem, extra flags, object stem); the split GEMM is compiled once per prologue kind (compile-time PRO)
-SOURCES = [(s, [], s) for s in ["norm", "ew", "pw_gemm", "pw_wgrad_split", "pw_wgrad_a16", "dwconv", "dwconv_row", "se", "ltae", "ltae_fused", "aggregate", "mgnll", "metrics", "conv3", "attn_rows", "optim", "inconv"]] + \
+SOURCES = [(s, [], s) for s in ["norm", "ew", "pw_gemm", "pw_wgrad_split", "pw_wgrad_a16", "dwconv", "dwconv_row", "se", "ltae", "ltae_fused", "aggregate", "mgnll", "metrics", "conv3", "attn_rows", "optim", "inconv", "anysize"]] + \
           [("pw_gemm_split", [f"-DPWS_PRO={p}"], f"pw_gemm_split_p{p}") for p in range(5)]
 # -fno-slp-vectorize: the SLP vectoriser packs neighbouring scalar FMAs into v_pk_fma_f32 and pays for it with
 # register-pair moves (depthwise row kernel: 370 vs 282 VALU instructions per row; whole step +1 %)

@@ -481,6 +481,125 @@ extern "C" int uncr_aggregate_bwd_de(const void* dg, const float* att, const int
     return UNCR_OK;
 }
 
+// ---- any H x W (csrc/anysize.hip): scalar variants on dense planes with a padded stride Pc -- one thread per pixel, valid pixels only,
+// no float4 rows, so any width and any up-sampling ratio; fp32 storage.  Same arithmetic as aggregate_kernel (bilin_src, agg_keep).
+#define AGGA_NB 8
+__global__ __launch_bounds__(256) void aggregate_any_fwd_kernel(AggArgs g, int Pc) {
+    const int plane = blockIdx.y, b = plane / g.C, c = plane - b * g.C, h = c / (g.C / g.NH);
+    const int P = g.H * g.W;
+    const float sy = (float)g.AH / (float)g.H, sx = (float)g.AW / (float)g.W;
+    float s0 = 0.f, s1 = 0.f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += AGGA_NB * 256) {
+        const int y = p / g.W, x = p - y * g.W;
+        const Bilin by = bilin_src(y, sy, g.AH), bx = bilin_src(x, sx, g.AW);
+        float acc = 0.f;
+        for (int t = 0; t < g.T; ++t) {
+            const float* ap = g.att + (((size_t)h * g.B + b) * g.T + t) * g.AH * g.AW;
+            const float top = bx.l0 * ap[by.i0 * g.AW + bx.i0] + bx.l1 * ap[by.i0 * g.AW + bx.i1];
+            const float bot = bx.l0 * ap[by.i1 * g.AW + bx.i0] + bx.l1 * ap[by.i1 * g.AW + bx.i1];
+            const float a = (by.l0 * top + by.l1 * bot) * agg_keep(g, h, b, t, (size_t)p);
+            acc = fmaf(a, ((const float*)g.e)[(((size_t)b * g.T + t) * g.C + c) * Pc + p], acc);
+        }
+        ((float*)g.out)[(size_t)plane * Pc + p] = acc;
+        s0 += acc;
+        s1 = fmaf(acc, acc, s1);
+    }
+    if (g.part) {
+        __shared__ float red[8];
+        block_sum2<256>(s0, s1, red);
+        if (threadIdx.x == 0) g.part[(size_t)plane * AGGA_NB + blockIdx.x] = make_float2(s0, s1);
+    }
+}
+// de[b,t,c,p] = a * dg[b,c,p]
+__global__ __launch_bounds__(256) void aggregate_any_de_kernel(AggArgs g, int Pc) {
+    const int plane = blockIdx.y, b = plane / g.C, c = plane - b * g.C, h = c / (g.C / g.NH);
+    const int P = g.H * g.W;
+    const float sy = (float)g.AH / (float)g.H, sx = (float)g.AW / (float)g.W;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += AGGA_NB * 256) {
+        const int y = p / g.W, x = p - y * g.W;
+        const Bilin by = bilin_src(y, sy, g.AH), bx = bilin_src(x, sx, g.AW);
+        const float dgv = ((const float*)g.dg)[(size_t)plane * Pc + p];
+        for (int t = 0; t < g.T; ++t) {
+            const float* ap = g.att + (((size_t)h * g.B + b) * g.T + t) * g.AH * g.AW;
+            const float top = bx.l0 * ap[by.i0 * g.AW + bx.i0] + bx.l1 * ap[by.i0 * g.AW + bx.i1];
+            const float bot = bx.l0 * ap[by.i1 * g.AW + bx.i0] + bx.l1 * ap[by.i1 * g.AW + bx.i1];
+            const float a = (by.l0 * top + by.l1 * bot) * agg_keep(g, h, b, t, (size_t)p);
+            ((float*)g.de)[(((size_t)b * g.T + t) * g.C + c) * Pc + p] = a * dgv;
+        }
+    }
+}
+// gradient w.r.t. the up-sampled attention, dense [NH*B*T][P]: keep * sum_{c in head} dg * e
+__global__ __launch_bounds__(256) void aggregate_any_dup_kernel(AggArgs g, int Pc) {
+    const int q = blockIdx.y, t = q % g.T, b = (q / g.T) % g.B, h = q / (g.T * g.B);
+    const int P = g.H * g.W, CH = g.C / g.NH;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += AGGA_NB * 256) {
+        float d = 0.f;
+        for (int jc = 0; jc < CH; ++jc) {
+            const int c = h * CH + jc;
+            d = fmaf(((const float*)g.dg)[((size_t)b * g.C + c) * Pc + p], ((const float*)g.e)[(((size_t)b * g.T + t) * g.C + c) * Pc + p], d);
+        }
+        g.datt_up[(size_t)q * P + p] = d * agg_keep(g, h, b, t, (size_t)p);
+    }
+}
+// adjoint of the bilinear up-sampling, any ratio: one thread per low-resolution cell gathers its footprint
+__global__ __launch_bounds__(256) void bilinear_adjoint_any_kernel(const float* __restrict__ dup, float* __restrict__ datt, int H, int W,
+                                                                   int AH, int AW) {
+    const int q = blockIdx.y;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= AH * AW) return;
+    const int ay = o / AW, ax = o - ay * AW;
+    const float sy = (float)AH / (float)H, sx = (float)AW / (float)W;
+    const int ylo = max(0, (int)floorf(((float)ay - 0.5f) / sy - 0.5f) - 1), yhi = min(H, (int)ceilf(((float)ay + 1.5f) / sy - 0.5f) + 2);
+    const int xlo = max(0, (int)floorf(((float)ax - 0.5f) / sx - 0.5f) - 1), xhi = min(W, (int)ceilf(((float)ax + 1.5f) / sx - 0.5f) + 2);
+    const float* src = dup + (size_t)q * H * W;
+    float s = 0.f;
+    for (int yy = ylo; yy < yhi; ++yy) {
+        const Bilin by = bilin_src(yy, sy, AH);
+        const float wy = (by.i0 == ay ? by.l0 : 0.f) + (by.i1 == ay ? by.l1 : 0.f);
+        if (wy == 0.f) continue;
+        float r = 0.f;
+        for (int xx = xlo; xx < xhi; ++xx) {
+            const Bilin bx = bilin_src(xx, sx, AW);
+            const float wx = (bx.i0 == ax ? bx.l0 : 0.f) + (bx.i1 == ax ? bx.l1 : 0.f);
+            if (wx != 0.f) r = fmaf(wx, src[(size_t)yy * W + xx], r);
+        }
+        s = fmaf(wy, r, s);
+    }
+    datt[(size_t)q * AH * AW + o] = s;
+}
+static int agg_any_check(int B, int T, int C, int NH, int H, int W, int AH, int AW, int Pc) {
+    if (B <= 0 || T <= 0 || NH <= 0 || C % NH || H < AH || W < AW || Pc < H * W) return UNCR_ESHAPE;
+    return UNCR_OK;
+}
+extern "C" int uncr_agg_any_slots(void) { return AGGA_NB; }
+extern "C" int uncr_aggregate_any_fwd(const float* e, const float* att, const int* pad, const float* dmask, unsigned long long seed,
+                                      const long long* seed_dev, float p_drop, int shared_mask, float* out, float* part, int B, int T,
+                                      int C, int NH, int H, int W, int Pc, int AH, int AW, hipStream_t stream) {
+    const int rc = agg_any_check(B, T, C, NH, H, W, AH, AW, Pc);
+    if (rc) return rc;
+    if (!e || !att || !out) return UNCR_EINVAL;
+    AggArgs g{e, att, pad, dmask, out, nullptr, nullptr, nullptr, (float2*)part, seed, seed_dev, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
+    hipLaunchKernelGGL(aggregate_any_fwd_kernel, dim3(AGGA_NB, B * C), dim3(256), 0, stream, g, Pc);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+extern "C" int uncr_aggregate_any_bwd(const float* dg, const float* e, const float* att, const int* pad, const float* dmask,
+                                      unsigned long long seed, const long long* seed_dev, float p_drop, int shared_mask, float* de,
+                                      float* datt_up /* [NH*B*T][H*W] scratch */, float* datt, int B, int T, int C, int NH, int H, int W,
+                                      int Pc, int AH, int AW, hipStream_t stream) {
+    const int rc = agg_any_check(B, T, C, NH, H, W, AH, AW, Pc);
+    if (rc) return rc;
+    if (!dg || !e || !att || !de || !datt_up || !datt) return UNCR_EINVAL;
+    AggArgs g{e, att, pad, dmask, nullptr, dg, de, datt_up, nullptr, seed, seed_dev, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
+    hipLaunchKernelGGL(aggregate_any_de_kernel, dim3(AGGA_NB, B * C), dim3(256), 0, stream, g, Pc);
+    UNCR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(aggregate_any_dup_kernel, dim3(AGGA_NB, NH * B * T), dim3(256), 0, stream, g, Pc);
+    UNCR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bilinear_adjoint_any_kernel, dim3((AH * AW + 255) / 256, NH * B * T), dim3(256), 0, stream, datt_up, datt, H, W,
+                       AH, AW);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
 
 // ---- the aggregator's AvgPool branch (uncrtaints.py:197-204): feature maps NOT larger than the attention map.  The attention is
 // average-pooled with kernel = stride = k = AW / H (nn.AvgPool2d(kernel_size=w // x.shape[-2])) down to the feature map's size and

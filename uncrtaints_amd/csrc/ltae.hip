@@ -9,14 +9,14 @@
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ in, float* __restrict__ out,
-                                                          int* __restrict__ idx, int H, int W, int OH, int OW) {
+                                                          int* __restrict__ idx, int H, int W, int OH, int OW, int pstride) {
     const int plane = blockIdx.y;
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= OH * OW) return;
     const int oy = o / OW, ox = o % OW;
     const int ys = (oy * H) / OH, ye = ((oy + 1) * H + OH - 1) / OH;
     const int xs = (ox * W) / OW, xe = ((ox + 1) * W + OW - 1) / OW;
-    const T* p = in + (size_t)plane * H * W;
+    const T* p = in + (size_t)plane * pstride;      // (pstride = H*W, or the padded plane stride of csrc/anysize.hip)
     float best = -INFINITY;
     int bi = ys * W + xs;
     if (((xe - xs) & 3) == 0 && (xs & 3) == 0 && (W & 3) == 0) {
@@ -537,7 +537,17 @@ extern "C" int uncr_maxpool_fwd(const void* in, float* out, int* idx, int planes
     if (planes <= 0 || H < OH || W < OW) return UNCR_ESHAPE;
     if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
     UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3((OH * OW + 255) / 256, planes), dim3(256), 0,
-                                                 stream, (const T*)in, out, idx, H, W, OH, OW));
+                                                 stream, (const T*)in, out, idx, H, W, OH, OW, H * W));
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+// the same on planes with a padded stride (csrc/anysize.hip: dense H*W pixels + a zero tail); idx stays the flat index inside the H x W image
+extern "C" int uncr_maxpool_fwd_strided(const float* in, float* out, int* idx, int planes, int H, int W, int pstride, int OH, int OW,
+                                        hipStream_t stream) {
+    if (planes <= 0 || H < OH || W < OW || pstride < H * W) return UNCR_ESHAPE;
+    if (!in || !out || !idx) return UNCR_EINVAL;
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3((OH * OW + 255) / 256, planes), dim3(256), 0, stream, in, out, idx, H, W, OH, OW,
+                       pstride);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -564,6 +574,16 @@ extern "C" int uncr_maxpool_bwd(const float* dout, const int* idx, void* din, in
     const int disjoint = (H % OH == 0) && (W % OW == 0);
     UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3((OH * OW + 255) / 256, planes), dim3(256), 0,
                                                  stream, dout, idx, (T*)din, H * W, OH * OW, disjoint));
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+extern "C" int uncr_maxpool_bwd_strided(const float* dout, const int* idx, float* din, int planes, int H, int W, int pstride, int OH,
+                                        int OW, hipStream_t stream) {
+    if (planes <= 0 || pstride < H * W) return UNCR_ESHAPE;
+    if (!dout || !idx || !din) return UNCR_EINVAL;
+    const int disjoint = (H % OH == 0) && (W % OW == 0);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3((OH * OW + 255) / 256, planes), dim3(256), 0, stream, dout, idx, din, pstride,
+                       OH * OW, disjoint);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

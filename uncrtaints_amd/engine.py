@@ -99,6 +99,112 @@ def claim_part(t: Tensor, attr: str = "_uncr_bpart") -> Optional["Part"]:
     return part
 
 
+# ------------------------------------------------------------------------------------------------
+# Any H x W (uncrtaints.py:391-447 takes any spatial size; csrc/anysize.hip).  For a size outside the tuned tilings the model keeps every
+# full-resolution tensor as [frames, C, 1, Pc]: dense planes of H*W pixels + a ZERO tail up to Pc = uncr_any_plane_stride(H, W).  The flat
+# kernels see planes of Pc pixels and run unchanged; while a `geom_scope` is active
+#   * every finalisation takes the TRUE pixel count (`_pcount`),
+#   * `fix_tail` behind a point-wise producer takes the tail's share out of its statistics and re-zeroes the tail,
+#   * the 2-D kernels (depthwise, max-pool, aggregation) run their any-size variants on (H, W, Pc).
+# The scope is entered by UNCRTAINTS.forward and re-entered by every backward from the geometry its forward saved.
+# ------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Geom:
+    H: int
+    W: int
+    Pc: int
+
+    @property
+    def P(self) -> int:
+        return self.H * self.W
+
+    @property
+    def ntail(self) -> int:
+        return self.Pc - self.H * self.W
+
+
+_GEOM: Optional[Geom] = None
+
+
+def plan_geom(H: int, W: int) -> Optional[Geom]:
+    """None when the tuned tilings take H x W as it is, else the padded-plane geometry."""
+    pc = hb.query("uncr_any_plane_stride", H, W)
+    if pc < 0:
+        raise RuntimeError(f"unsupported spatial size {H}x{W}")
+    if pc == 0:
+        return None
+    if H < 32 or W < 32:
+        raise RuntimeError(f"unsupported spatial size {H}x{W}: at least 32x32 (the L-TAE stage pools to 32x32)")
+    return Geom(H, W, pc)
+
+
+class geom_scope:
+    def __init__(self, geom: Optional[Geom]):
+        self.geom = geom
+
+    # Inside an any-size scope the GEMMs take the exact bf16 split: the magnitude bounds of the two-part fp16 route are maxima over
+    # statistics SLOTS, and fix_tail corrects a plane's first slot for a tail that lives in its last ones (the plane's SUM is what the
+    # normalisations need; a per-slot maximum would see one slot too small -- even negative -- and one too large).
+    _H2_FLAGS = ("_H2_FWD", "_H2_BWD", "_H2_DX", "_H2_WGRAD")
+
+    def __enter__(self):
+        global _GEOM
+        self.old, _GEOM = _GEOM, self.geom
+        self.h2 = None
+        if self.geom is not None:
+            gl = globals()
+            self.h2 = {k: gl[k] for k in self._H2_FLAGS}
+            for k in self._H2_FLAGS:
+                gl[k] = False
+        return self.geom
+
+    def __exit__(self, *exc):
+        global _GEOM
+        _GEOM = self.old
+        if self.h2 is not None:
+            globals().update(self.h2)
+        return False
+
+
+def current_geom() -> Optional[Geom]:
+    return _GEOM
+
+
+def _pcount(P: int) -> int:
+    """pixels of a plane that carry data: the image's H*W for a padded plane of the active geometry, else P itself"""
+    return _GEOM.P if (_GEOM is not None and P == _GEOM.Pc) else P
+
+
+def fix_tail(t: Tensor, part: Optional["Part"], mode: int, planes: int) -> None:
+    """Behind a point-wise producer (geometry active, t's planes have the padded stride): take the tail's share out of `part`
+    (mode 0: (sum, sum^2); 1: (sum, sum*aux) with aux zero on the tail; 2: none) and zero the tail."""
+    g = _GEOM
+    if g is None or t.numel() != planes * g.Pc:
+        return
+    if t.dtype != torch.float32:
+        raise NotImplementedError("any-size planes are built for fp32 storage")
+    hb.call("uncr_fix_tail", t, part.buf if part is not None else None, part.slots if part is not None else 0, planes, g.P, g.Pc,
+            mode if part is not None else 2, _stream())
+
+
+def embed_tail(x: Tensor, geom: Geom) -> Tensor:
+    """[planes..., H, W] dense fp32 -> [planes..., 1, Pc] with a zero tail"""
+    lead = tuple(x.shape[:-2])
+    planes = x.numel() // geom.P
+    out = _f32(lead + (1, geom.Pc), x.device)
+    hb.call("uncr_embed_tail", x.contiguous().float(), out, planes, geom.P, geom.Pc, _stream())
+    return out
+
+
+def extract_tail(x: Tensor, geom: Geom) -> Tensor:
+    """[planes..., 1, Pc] -> dense [planes..., H, W]"""
+    lead = tuple(x.shape[:-2])
+    planes = x.numel() // geom.Pc
+    out = _f32(lead + (geom.H, geom.W), x.device)
+    hb.call("uncr_extract_tail", x.contiguous(), out, planes, geom.P, geom.Pc, _stream())
+    return out
+
+
 @dataclass
 class NormSpec:
     kind: str        # 'group' | 'batch' | 'instance'
@@ -259,7 +365,7 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
     if kind == NORM_BATCH_TRAIN and _SYNC_BN is not None:
         sums = torch.empty((C, 2), device=dev, dtype=torch.float64)
         hb.call("uncr_bn_channel_sums", part.buf, part.slots, N, C, sums, _stream())
-        count = _all_reduce_sums(sums) * N * P
+        count = _all_reduce_sums(sums) * N * _pcount(P)
         ub = _f32((N * C,), dev) if (bound_part is part and _H2_FWD) else None
         hbt = _f32((N * C,), dev) if (ub is not None and want_hb) else None
         hb.call("uncr_bn_finalize_fwd_sums", sums, count, N, C, gamma, beta, running_mean, running_var, float(momentum),
@@ -276,7 +382,7 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
     if defer and _BN_CONSUMER and kind == NORM_BATCH_TRAIN and part is not None and (ub is None or part is bound_part):
         return NormFwd(A, B, mean, rstd, kind, groups, ub=ub, hb=hbt,
                        fin=(part.buf, part.slots, gamma, beta, running_mean, running_var, float(momentum), float(eps)))
-    hb.call("uncr_norm_finalize_fwd", part.buf if part else None, part.slots if part else 0, N, C, groups, P,
+    hb.call("uncr_norm_finalize_fwd", part.buf if part else None, part.slots if part else 0, N, C, groups, _pcount(P),
             kind, gamma, beta, running_mean, running_var, float(momentum), float(eps), A, B, mean, rstd, ub, hbt, _stream())
     return NormFwd(A, B, mean, rstd, kind, groups, ub=ub, hb=hbt)
 
@@ -375,7 +481,7 @@ def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor, cen
                 1 if centered else 0, _stream())
         return NormBwd(c1, c2, c3, dg, db, mu)
     scratch = _f32((2 * N * C,), dev) if nf.kind == NORM_GROUP else None
-    hb.call("uncr_norm_finalize_bwd", part.buf, part.slots, N, C, nf.groups, P, nf.kind, gamma, nf.mean, nf.rstd,
+    hb.call("uncr_norm_finalize_bwd", part.buf, part.slots, N, C, nf.groups, _pcount(P), nf.kind, gamma, nf.mean, nf.rstd,
             c1, c2, c3, mu, dg, db, scratch, 1 if centered else 0, _stream())
     return NormBwd(c1, c2, c3, dg, db, mu)
 
@@ -631,6 +737,8 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     Ch = p["w1"].shape[0]
     R = p["se1"].shape[0]
     if Ch > 256:        # hidden width beyond the GEMM kernels' 256 channels: the hidden axis in groups (slow path, any expansion)
+        if _GEOM is not None and P == _GEOM.Pc:
+            raise NotImplementedError("any-size planes with a hidden width beyond 256 channels are not built")
         return _mbconv_forward_wide(x, p, spec, training, x_part, buffers or {}, want_out_stats, x_h3, pool)
     need = spec.needs_stats(training)
     buffers = buffers or {}
@@ -647,16 +755,25 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     n0 = norm_fwd(x_part if need else None, N, C, P, spec, training, p["n0w"], p["n0b"], *rm(0),
                   bound_part=x_part if h2ok else None)
     W1t = pack_wt(p["w1"].reshape(Ch, C), transpose=True)
+    geom = _GEOM if (_GEOM is not None and P == _GEOM.Pc) else None      # padded planes of an any-size image (csrc/anysize.hip)
+    if geom is not None and dt != F32:
+        raise NotImplementedError("any-size planes are built for fp32 storage")
     h1, part1 = pw_gemm(x, W1t, N, C, Ch, P, pro=PRO_AFFINE, k=(n0.A, n0.B, None), epi=1 if need else 0, in_amax=n0.ub)
+    if geom is not None:
+        fix_tail(h1, part1, 0, N * Ch)
     # (hb: the bound on |h1| itself, for the backward's dx GEMM, which reads h1 through the norm-1 backward)
     n1 = norm_fwd(part1, N, Ch, P, spec, training, p["n1w"], p["n1b"], *rm(1),
                   bound_part=part1 if (h2ok and _H2_BWD and part1 is not None) else None, want_hb=True,
                   defer=_DW_VARIANT == 0 and hb.query("uncr_dw_fwd_bn_supported", H, W) == 1)
 
     h2 = _act((N, Ch, H, W), x.device, dt)
-    slots = hb.query("uncr_dw_slots_fwd", H)
+    slots = hb.query("uncr_dw_slots_fwd", H) if geom is None else hb.query("uncr_any_slots")
     part2 = Part(_f32((N * Ch, slots, 2), x.device), slots) if (need or h2ok) else None
-    if n1.fin is not None:      # train-mode BatchNorm 1 finalised by the depthwise kernel's waves themselves
+    if geom is not None:
+        hb.call("uncr_dw_fwd_any", h1, n1.A, n1.B, p["wdw"].reshape(Ch, 9).contiguous(), h2, part2.buf if part2 is not None else None,
+                N, Ch, geom.H, geom.W, geom.Pc, _stream())
+        fix_tail(h2, None, 2, N * Ch)          # (the kernel writes valid pixels only)
+    elif n1.fin is not None:      # train-mode BatchNorm 1 finalised by the depthwise kernel's waves themselves
         hb.call("uncr_dw_fwd_bn", h1, *n1.fin, n1.A, n1.B, n1.mean, n1.rstd, n1.ub, n1.hb, p["wdw"].reshape(Ch, 9).contiguous(),
                 h2, part2.buf if part2 is not None else None, N, Ch, H, W, dt, _stream())
     else:
@@ -666,8 +783,10 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
                   bound_part=part2 if h2ok else None)
 
     ppool = se_pool(h2, n2.A, n2.B, N * Ch, P)
+    if geom is not None:      # the pass summed gelu(A*0 + B) over the tail
+        hb.call("uncr_fix_sepool_tail", ppool.buf, ppool.slots, n2.B, N * Ch, geom.ntail, _stream())
     pooled, hid_pre, s = _f32((N, Ch), x.device), _f32((N, R), x.device), _f32((N * Ch,), x.device)
-    hb.call("uncr_se_mlp_fwd", ppool.buf, ppool.slots, N, Ch, R, P, p["se1"].contiguous(), p["se2"].contiguous(),
+    hb.call("uncr_se_mlp_fwd", ppool.buf, ppool.slots, N, Ch, R, _pcount(P), p["se1"].contiguous(), p["se2"].contiguous(),
             pooled, hid_pre, s, _stream())
 
     W2t = pack_wt(p["w2"].reshape(C, Ch), transpose=True)
@@ -678,9 +797,13 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
         n3 = norm_fwd(None, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))
         y, party = pw_gemm(h2, W2t, N, Ch, C, P, pro=PRO_AFFINE_GELU, k=(n2.A, n2.B, s), epi=10, aux=x,
                            ek=(n3.A, n3.B, None, None), in_amax=n2.ub)
+        if geom is not None:
+            fix_tail(y.view(N, C, H, W), party, 0, N * C)
         return y.view(N, C, H, W), dict(ypool=None, h3=None, dims=(N, C, Ch, R, H, W)), (party if want_out_stats else None)
     h3, part3 = pw_gemm(h2, W2t, N, Ch, C, P, pro=PRO_AFFINE_GELU, k=(n2.A, n2.B, s), epi=1 if need else 0, want_amax=True,
                         in_amax=n2.ub)
+    if geom is not None:
+        fix_tail(h3.view(N, C, H, W), part3, 0, N * C)
     n3 = norm_fwd(part3, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))
 
     y = _act((N, C, H, W), x.device, dt)
@@ -698,10 +821,12 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     else:
         _, party = ew(EW_RESIDUAL, x, b=h3, out=y, k=(n3.A, n3.B, None, None), want_part=want_out_stats, planes=N * C,
                       P=P)
+        if geom is not None:
+            fix_tail(y, party, 0, N * C)
         if pool is not None:
             ypool = maxpool_forward(y, pool, pool)
     saved = dict(ypool=ypool, x=x, h1=h1, h2=h2, h3=h3, n0=n0, n1=n1, n2=n2, n3=n3, pooled=pooled, hid_pre=hid_pre, s=s,
-                 dims=(N, C, Ch, R, H, W), x_h3=x_h3, part1f=part1, h3_amax=part3.amax if part3 is not None else None)
+                 dims=(N, C, Ch, R, H, W), x_h3=x_h3, part1f=part1, h3_amax=part3.amax if part3 is not None else None, geom=geom)
     return y, saved, party
 
 
@@ -885,6 +1010,10 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         return _mbconv_backward_wide(dy, sv, p, need_dx, dy_part)
     N, C, Ch, R, H, W = sv["dims"]
     P = H * W
+    geom = sv.get("geom")
+    if geom is not None and _GEOM != geom:        # (a backward entered outside the model's scope: re-enter the forward's geometry)
+        with geom_scope(geom):
+            return mbconv_backward(dy, sv, p, need_dx, dy_part)
     dev = dy.device
     x, h1, h2, h3 = sv["x"], sv["h1"], sv["h2"], sv["h3"]
     n0, n1, n2, n3 = sv["n0"], sv["n1"], sv["n2"], sv["n3"]
@@ -905,12 +1034,14 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     # (fp32 storage, magnitude bookkeeping at hand: two row-scaled fp16 parts, like the dz GEMM below)
     G, _ = pw_wgrad(dy, h2, N, C, Ch, P, pro_d=PRO_NORMBWD, dk=k3, d2=h3, pro_x=PRO_AFFINE_GELU,
                     xk=(n2.A, n2.B, None), per_frame=True, d_amax=dy_amax, d2_amax=sv.get("h3_amax"), x_ub=n2.ub)
+    if geom is not None:      # the tail (dy = h3 = h2 = 0 there) contributed n_tail * (c3 - c2*mu) (x) gelu(B2) to every frame's product
+        hb.call("uncr_fix_wgrad_tail", G, N, C, Ch, k3[1], k3[2], k3[3], n2.B, geom.ntail, _stream())
     ds_pre, dhid_pre, dpool = _f32((N, Ch), dev), _f32((N, R), dev), _f32((N * Ch,), dev)
     dW2, dse1, dse2 = _f32((C, Ch), dev), _f32((R, Ch), dev), _f32((Ch, R), dev)
     w2 = p["w2"].reshape(C, Ch).contiguous()
     # (per-frame phase only: dpool is what the dz GEMM waits for; dW2 and the SE weight gradients are reduced further down, in one
     # launch with the depthwise weight gradient -- uncr_mbconv_param_grads)
-    hb.call("uncr_se_mlp_bwd", G, w2, N, C, Ch, R, P, p["se1"].contiguous(), p["se2"].contiguous(), sv["s"],
+    hb.call("uncr_se_mlp_bwd", G, w2, N, C, Ch, R, _pcount(P), p["se1"].contiguous(), p["se2"].contiguous(), sv["s"],
             sv["pooled"], sv["hid_pre"], ds_pre, dhid_pre, dpool, None, None, None, _stream())
     g["w2"], g["se1"], g["se2"] = dW2.view_as(p["w2"]), dse1, dse2
 
@@ -921,12 +1052,14 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     # with the magnitude bookkeeping of dy's producer and of the forward pw2 GEMM at hand: two scaled fp16 parts (three products)
     du2, part2 = pw_gemm(dy, W2k, N, C, Ch, P, pro=PRO_NORMBWD, k=k3, x2=h3, epi=3, aux=h2,
                          ek=(n2.A, n2.B, sv["s"], dpool), in_amax=dy_amax, in2_amax=sv.get("h3_amax"))
+    if geom is not None:
+        fix_tail(du2.view(N, Ch, H, W), part2, 1, N * Ch)
     b2 = norm_bwd(part2, N, Ch, P, n2, p["n2w"])
     g["n2w"], g["n2b"] = b2.dgamma, b2.dbeta
 
     # depthwise backward
     du1 = _act((N, Ch, H, W), dev, dt)
-    slots = hb.query("uncr_dw_slots_bwd", H)
+    slots = hb.query("uncr_dw_slots_bwd", H) if geom is None else hb.query("uncr_any_slots")
     part1 = Part(_f32((N * Ch, slots, 2), dev), slots)
     dw_part = _f32((N * Ch, slots, 9), dev)
     wdw = p["wdw"].reshape(Ch, 9).contiguous()
@@ -935,10 +1068,15 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     # with the bound on |h1| at hand (NormFwd.hb), the row kernel also leaves max |du1| per slot: the two operands of the dx GEMM are
     # then bounded and it multiplies in two scaled fp16 parts
     du1_amax = None
-    if _H2_BWD and _H2_DX and n1.hb is not None and hb.query("uncr_dw_bwd_emits_amax", H, W, dt, _DW_VARIANT) == 1:
-        du1_amax = _f32((N, Ch * slots), dev)
-    hb.call("uncr_dw_bwd", du2, h2, h1, b2.c1, b2.c2, b2.c3, b2.mu, n1.A, n1.B, wdw, du1, part1.buf, dw_part, n1.mean,
-            n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, H, W, dt, _DW_VARIANT, du1_amax, _stream())
+    if geom is not None:
+        hb.call("uncr_dw_bwd_any", du2, h2, h1, b2.c1, b2.c2, b2.c3, b2.mu, n1.A, n1.B, wdw, du1, part1.buf, dw_part, n1.mean,
+                n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, geom.H, geom.W, geom.Pc, _stream())
+        fix_tail(du1, None, 2, N * Ch)
+    else:
+        if _H2_BWD and _H2_DX and n1.hb is not None and hb.query("uncr_dw_bwd_emits_amax", H, W, dt, _DW_VARIANT) == 1:
+            du1_amax = _f32((N, Ch * slots), dev)
+        hb.call("uncr_dw_bwd", du2, h2, h1, b2.c1, b2.c2, b2.c3, b2.mu, n1.A, n1.B, wdw, du1, part1.buf, dw_part, n1.mean,
+                n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, H, W, dt, _DW_VARIANT, du1_amax, _stream())
     dwdw = _f32((Ch, 9), dev)
     with side_chain(dw_part):          # feeds parameter gradients only: next to the pw1 weight-gradient GEMM
         hb.call("uncr_mbconv_param_grads", G, N, C, Ch, R, sv["s"], sv["pooled"], sv["hid_pre"], ds_pre, dhid_pre, dW2, dse1, dse2,
@@ -962,7 +1100,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         pf = sv.get("part1f")
         hb.call("uncr_prenorm_bwd_finish", wpart, nbx, cop, cip, p["w1"].reshape(Ch, C).contiguous(), part1.buf, part1.slots,
                 pf.buf if pf is not None else None, pf.slots if pf is not None else 0, k1[0], k1[1], k1[2],
-                k1[3] if pf is not None else None, n0.A, n0.B, part0.buf, dW1, N, Ch, C, P, _stream())
+                k1[3] if pf is not None else None, n0.A, n0.B, part0.buf, dW1, N, Ch, C, _pcount(P), _stream())
         g["w1"] = dW1.view_as(p["w1"])
         b0 = norm_bwd(part0, N, C, P, n0, p["n0w"])
         g["n0w"], g["n0b"] = b0.dgamma, b0.dbeta
@@ -982,10 +1120,14 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
                 dx_part.buf if dx_part is not None else None, N, Ch, C, P, dt,
                 dx_part.amax if dx_part is not None else None, du1_amax, du1_amax.shape[1] if du1_amax is not None else 0,
                 n1.hb if du1_amax is not None else None, Ch if du1_amax is not None else 0, _stream())
+        if geom is not None:
+            fix_tail(dx, dx_part, 1, N * C)
         join_side()
         return dx, g, dx_part
 
     # pw1: weight gradient and data gradient
+    if geom is not None:
+        raise NotImplementedError("any-size planes are built for the fused pw1 backward (block width a multiple of 32, <= 128 ... 256)")
     dW1, _ = pw_wgrad(du1, x, N, Ch, C, P, pro_d=PRO_NORMBWD, dk=k1, d2=h1, pro_x=PRO_AFFINE, xk=(n0.A, n0.B, None))
     g["w1"] = dW1.view_as(p["w1"])
     da, part0 = pw_gemm(du1, W1k, N, Ch, C, P, pro=PRO_NORMBWD, k=k1, x2=h1, epi=2, aux=x)
@@ -998,6 +1140,8 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         x_h3 = sv.get("x_h3")     # h3 of the block that produced x: emit its norm-3 backward statistics here
         _, dx_part = ew(EW_PASSE, dy, b=da, c=x, aux=x_h3, out=dx, k=b0.k,
                         want_part=x_h3 is not None, planes=N * C, P=P)
+        if geom is not None:
+            fix_tail(dx, dx_part, 1, N * C)
     join_side()
     return dx, g, dx_part
 
@@ -1129,6 +1273,8 @@ def _inconv_moments_ok(x: Tensor, N: int, Cin: int, Cout: int, spec: NormSpec, g
     if not (_INCONV_MOMENTS and spec.kind == "group" and gw is not None and Cin + 1 <= 16 and 64 < Cout <= 256
             and Cout % spec.groups == 0 and N <= 64 and P % 4 == 0):
         return False
+    if _GEOM is not None and P == _GEOM.Pc:       # any-size planes: the generic path (its tail corrections are plain statistics)
+        return False
     return (2 * N * (Cout // spec.groups) + 4 * N + 288) * 8 <= 60 * 1024
 
 
@@ -1157,11 +1303,16 @@ def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec
         a0, parta = pw_gemm(x, Wt, N, Cin, Cout, P, bias=bc, epi=9, ek=(A, B, None, None))
         a0 = a0.view(N, Cout, H, W)
         return a0, dict(x=x, c0=None, a0=a0, nf=nf, mom=mom, b=bc, dims=(N, Cin, Cout, H, W)), parta
+    geom = _GEOM if (_GEOM is not None and P == _GEOM.Pc) else None
     c0, part = pw_gemm(x, Wt, N, Cin, Cout, P, bias=b.contiguous(), epi=1 if need else 0)
+    if geom is not None:      # the tail holds the bias
+        fix_tail(c0.view(N, Cout, H, W), part, 0, N * Cout)
     nf = norm_fwd(part, N, Cout, P, spec, training, gw, gb, buffers.get("rm"), buffers.get("rv"))
     a0 = _act((N, Cout, H, W), x.device, _dt(x))
     _, parta = ew(EW_AFFINE_RELU, c0, out=a0, k=(nf.A, nf.B, None, None), want_part=True, planes=N * Cout, P=P)
-    return a0, dict(x=x, c0=c0, nf=nf, dims=(N, Cin, Cout, H, W)), parta
+    if geom is not None:
+        fix_tail(a0, parta, 0, N * Cout)
+    return a0, dict(x=x, c0=c0, nf=nf, dims=(N, Cin, Cout, H, W), geom=geom), parta
 
 
 def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool, masked_part: Optional[Part] = None):
@@ -1170,6 +1321,10 @@ def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool,
     component is not used: sum du0*c0 follows from the per-frame products R = sum_p du0 x^T."""
     N, Cin, Cout, H, W = sv["dims"]
     P = H * W
+    geom = sv.get("geom")
+    if geom is not None and _GEOM != geom:
+        with geom_scope(geom):
+            return inconv_backward(da0, sv, w, gw, need_dx, masked_part)
     nf, c0, x = sv["nf"], sv["c0"], sv["x"]
     da0 = cast(da0.contiguous(), _dt(x))
     if c0 is None:
@@ -1203,6 +1358,8 @@ def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool,
     nb = norm_bwd(part, N, Cout, P, nf, gw)
     kk = nb.k
     dW, db = pw_wgrad(du0, x, N, Cout, Cin, P, pro_d=PRO_NORMBWD, dk=kk, d2=c0, rowsum=True)
+    if geom is not None:      # the row sums ran over the tail, where the norm backward of (0, 0) is c3 - c2*mu (x is zero there: dW is clean)
+        hb.call("uncr_fix_rowsum_tail", db, N, Cout, kk[1], kk[2], kk[3], geom.ntail, _stream())
     dx = None
     if need_dx:
         Wk = pack_wt(w.reshape(Cout, Cin), transpose=False)   # [k=128][out=15]
@@ -1230,6 +1387,10 @@ def maxpool_forward(e: Tensor, OH: int, OW: int):
     lead = tuple(e.shape[:-2])
     down = _f32(lead + (OH, OW), e.device)
     idx = torch.empty(lead + (OH, OW), device=e.device, dtype=torch.int32)
+    g = _GEOM
+    if g is not None and H * W == g.Pc:       # padded planes of an any-size image: the window arithmetic of the true H x W
+        hb.call("uncr_maxpool_fwd_strided", e, down, idx, planes, g.H, g.W, g.Pc, OH, OW, _stream())
+        return down, idx
     hb.call("uncr_maxpool_fwd", e, down, idx, planes, H, W, OH, OW, _dt(e), _stream())
     return down, idx
 
@@ -1237,6 +1398,10 @@ def maxpool_forward(e: Tensor, OH: int, OW: int):
 def maxpool_backward_into(ddown: Tensor, idx: Tensor, de: Tensor, H: int, W: int, OH: int, OW: int):
     """de[plane][argmax] += ddown (in place on `de`)."""
     planes = ddown.numel() // (OH * OW)
+    g = _GEOM
+    if g is not None and H * W == g.Pc:
+        hb.call("uncr_maxpool_bwd_strided", ddown.contiguous(), idx, de, planes, g.H, g.W, g.Pc, OH, OW, _stream())
+        return
     hb.call("uncr_maxpool_bwd", ddown.contiguous(), idx, de, planes, H, W, OH, OW, _dt(de), _stream())
 
 
@@ -1374,6 +1539,26 @@ def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: b
     B, T, C, H, W = e.shape
     n_head, _, _, ah, aw = att.shape
     dev = e.device
+    geom = _GEOM if (_GEOM is not None and H * W == _GEOM.Pc) else None
+    if geom is not None:
+        # padded planes of an any-size image (csrc/anysize.hip): the scalar kernels on the true H x W (bilinear up-sampling of any ratio)
+        if _dt(e) != F32:
+            raise NotImplementedError("any-size planes are built for fp32 storage")
+        if geom.H < ah or geom.W < aw:
+            raise NotImplementedError(f"feature map {geom.H}x{geom.W} against a {ah}x{aw} attention map")
+        g = _f32((B, C, H, W), dev)
+        gpart = None
+        if want_stats:
+            slots = hb.query("uncr_agg_any_slots")
+            gpart = Part(_f32((B * C, slots, 2), dev), slots)
+        use_mask = dmask if training else None
+        pd = float(p_drop) if (training and dmask is None) else 0.0
+        seed_val, seed_dev = seed if isinstance(seed, tuple) else (seed, None)
+        hb.call("uncr_aggregate_any_fwd", e, att, pad, use_mask, seed_val, seed_dev, pd, 1 if shared_mask else 0, g,
+                gpart.buf if gpart else None, B, T, C, n_head, geom.H, geom.W, geom.Pc, ah, aw, _stream())
+        fix_tail(g, None, 2, B * C)
+        return g, dict(e=e, att=att, pad=pad, dmask=use_mask, pd=pd, seed=seed_val, seed_dev=seed_dev, shared=1 if shared_mask else 0,
+                       dims=(B, T, C, H, W, n_head, ah, aw), geom=geom), gpart
     if H <= aw and (H, W) != (ah, aw):
         # the reference's AvgPool branch (uncrtaints.py:197-204): the attention is pooled down to the feature map, no dropout.
         # (At equal size the pooling is the identity and the streaming kernel below serves it.)
@@ -1408,6 +1593,16 @@ def aggregate_backward(dg: Tensor, sv: dict):
     """-> de [B,T,C,H,W] (freshly written), datt [nh,B,T,ah,aw]"""
     B, T, C, H, W, n_head, ah, aw = sv["dims"]
     dev = dg.device
+    geom = sv.get("geom")
+    if geom is not None:
+        de = _f32((B, T, C, H, W), dev)
+        datt_up = _f32((n_head * B * T, geom.P), dev)
+        datt = _f32((n_head, B, T, ah, aw), dev)
+        hb.call("uncr_aggregate_any_bwd", dg.contiguous().float(), sv["e"], sv["att"], sv["pad"], sv["dmask"], sv["seed"], sv["seed_dev"],
+                sv["pd"], sv["shared"], de, datt_up, datt, B, T, C, n_head, geom.H, geom.W, geom.Pc, ah, aw, _stream())
+        with geom_scope(geom):
+            fix_tail(de.view(B * T, C, H, W), None, 2, B * T * C)
+        return de, datt
     if "pool_k" in sv:
         de, datt = _f32((B, T, C, H, W), dev), _f32((n_head, B, T, ah, aw), dev)
         hb.call("uncr_aggregate_pool_bwd", dg.contiguous().float(), sv["e"], sv["att"], sv["pad"], de, datt, B, T, C, n_head, H, W,
@@ -1617,7 +1812,8 @@ def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor]
         att, sv_att = ltae_attention_forward(down, dates, pad, p, denom, n_head, d_k)
     if mode == "att_group":
         w_att, shared = att, False
-        if e.shape[-2] <= att_down:      # feature map not larger than the attention map: the reference takes its AvgPool
+        true_h = _GEOM.H if (_GEOM is not None and e.shape[-2] * e.shape[-1] == _GEOM.Pc) else e.shape[-2]
+        if true_h <= att_down:      # feature map not larger than the attention map: the reference takes its AvgPool
             p_drop, dmask = 0.0, None    # branch (kernel 1 = identity at equal size), which has NO dropout (uncrtaints.py:197-204)
     elif mode == "att_mean":
         w_att, shared = head_mean_attention(att), True
@@ -1671,6 +1867,10 @@ def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int,
         with dev_options(ltae_replay=None):
             _LTAE_STORE["bwd"] = ltae_stage_backward(dg, sv, p, n_head, d_k, e_h3)
         return _LTAE_STORE["bwd"]
+    sgeom = sv["agg"].get("geom") if isinstance(sv.get("agg"), dict) else None
+    if sgeom is not None and _GEOM != sgeom:      # re-enter the forward's any-size geometry (csrc/anysize.hip)
+        with geom_scope(sgeom):
+            return ltae_stage_backward(dg, sv, p, n_head, d_k, e_h3)
     if "val" in sv:     # use_v: include_v -> (aggregation, values) -> attention
         dg0, dv, dWinc, dbinc = include_v_backward(dg, sv["inc"])
         de, datt = aggregate_backward(dg0, sv["agg"])
@@ -1692,7 +1892,8 @@ def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int,
     agg = sv["agg"]
     # (fp32 storage: 342 -> 304 us for the pair of full-resolution launches; bf16 storage keeps the one-pass kernel + the four-chunk
     # scatter: its 8-byte rows leave the second pass short of bytes in flight, 214 -> 302 us)
-    if (_AGG_TWO_PASS and mode in ("att_group", "att_mean") and "pool_k" not in agg and e_h3 is not None and _dt(agg["e"]) == F32
+    if (_AGG_TWO_PASS and mode in ("att_group", "att_mean") and "pool_k" not in agg and "geom" not in agg and e_h3 is not None
+            and _dt(agg["e"]) == F32
             and e_h3.numel() == agg["e"].numel() and e_h3.dtype == agg["e"].dtype and e_h3.is_contiguous()
             and hb.query("uncr_aggregate_bwd_de_supported", agg["dims"][3], agg["dims"][4], sv["att_down"], sv["att_down"]) == 1):
         datt = aggregate_backward_datt(dg, agg)

@@ -391,6 +391,30 @@ class _CastFn(torch.autograd.Function):
         return E.cast(g.contiguous(), E.F32), None
 
 
+class _EmbedFn(torch.autograd.Function):
+    """Any H x W (engine.Geom, csrc/anysize.hip): dense [planes..., H, W] -> padded planes [planes..., 1, Pc] with a zero tail."""
+
+    @staticmethod
+    def forward(ctx, x, geom):
+        ctx.geom = geom
+        return E.embed_tail(x, geom)
+
+    @staticmethod
+    def backward(ctx, g):
+        return E.extract_tail(g.contiguous().float(), ctx.geom), None
+
+
+class _ExtractFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, geom):
+        ctx.geom = geom
+        return E.extract_tail(x, geom)
+
+    @staticmethod
+    def backward(ctx, g):
+        return E.embed_tail(g, ctx.geom), None
+
+
 class _HeadFn(torch.autograd.Function):
     """out_conv (1x1 + bias) + mean/variance nonlinearities (uncrtaints.py:432-445)."""
 
@@ -612,6 +636,18 @@ class UNCRTAINTS(nn.Module):
         # between its blocks, so the statistics / masks that ride on the tensors survive in both directions
         b, t, _, h, w = input.shape
         x4 = input.view(b * t, input.shape[2], h, w)
+        # any H x W (uncrtaints.py:391-447): a size outside the tuned tilings runs on padded planes [frames, C, 1, Pc] (dense H*W pixels
+        # + a zero tail) inside a geometry scope; the output is cut back to [B, 1, C_out, H, W] at the end
+        geom = E.plan_geom(h, w)
+        if geom is not None:
+            if self.act_dtype == torch.bfloat16 or self.block_type != 'mbconv' or (self.use_v and not self.is_mono):
+                raise NotImplementedError(f"spatial size {h}x{w} (H*W not a multiple of 1024 or W not of 4) is built for fp32 storage, "
+                                          "block_type='mbconv', use_v=False")
+            x4 = _EmbedFn.apply(x4, geom)
+        with E.geom_scope(geom):
+            return self._forward_frames(x4, batch_positions, pad, b, t, h, w, geom)
+
+    def _forward_frames(self, x4, batch_positions, pad, b, t, h, w, geom):
         if self.act_dtype == torch.bfloat16:           # everything downstream allocates in the storage type of its input
             x4 = _CastFn.apply(x4, E.BF16)
         x4 = self.in_conv(x4)
@@ -657,8 +693,12 @@ class UNCRTAINTS(nn.Module):
         if not self.covmode:
             # mean only: plain conv + mean nonlinearity on all out_dims channels
             o = _HeadFnMeanOnly.apply(out, w_all, b_all, self)
+            if geom is not None:
+                o = _ExtractFn.apply(o, geom)
             return o.unsqueeze(1)[:, :, :self.mean_idx, ...]
         o = _HeadFn.apply(out, w_all, b_all, self)                         # [B, out_dims, H, W]
+        if geom is not None:
+            o = _ExtractFn.apply(o, geom)
         o = o.unsqueeze(1)
         if self.out_dims != self.vars_idx:
             o = o[:, :, :self.vars_idx, ...]
