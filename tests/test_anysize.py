@@ -1,0 +1,265 @@
+"""Any H x W (the reference takes any spatial size, uncrtaints.py:391-447): sizes outside the tuned tilings run on padded planes
+(csrc/anysize.hip, engine.Geom).  CPU: the geometry plan.  GPU: the scalar 2-D kernels and the tail corrections against torch, the whole
+model against the oracle in the configurations a user meets at odd sizes."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def test_plane_stride_plan():
+    """H*W % 1024 == 0 and W % 4 == 0 need nothing; everything else gets a stride that is the next multiple of 1024 pixels."""
+    import uncrtaints_amd.hip_backend as hb
+    q = lambda h, w: hb.query("uncr_any_plane_stride", h, w)
+    for h, w in ((256, 256), (64, 64), (96, 96), (80, 64), (128, 64), (64, 512)):
+        assert q(h, w) == 0, (h, w)
+    assert q(100, 100) == 10240 and q(250, 250) == 63488 and q(70, 90) == 7168 and q(33, 32) == 2048
+    assert q(256, 250) == 64512            # H*W is not the issue here: W % 4 is
+    assert q(0, 5) < 0
+    assert hb.query("uncr_any_slots") >= 1 and hb.query("uncr_agg_any_slots") >= 1
+
+
+pytestmark_gpu = pytest.mark.gpu
+
+
+def _geom(E, H, W):
+    g = E.plan_geom(H, W)
+    assert g is not None and g.Pc % 1024 == 0 and g.Pc >= H * W
+    return g
+
+
+def _padded(E, t, g):
+    return E.embed_tail(t.cuda(), g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(50, 50), (37, 90), (100, 33)])
+def test_depthwise_any_size_fwd_bwd_vs_torch(H, W):
+    """uncr_dw_fwd_any / uncr_dw_bwd_any = h2 = dw3x3_reflect(gelu(A*h1 + B)) and its full backward (norm-2 backward prologue, GELU',
+    adjoint of the reflect padding, depthwise weight gradient, centred statistics) against torch autograd in fp64."""
+    from gpu_util import close
+    import uncrtaints_amd.hip_backend as hb
+    from uncrtaints_amd import engine as E
+    N, C = 2, 8
+    g = _geom(E, H, W)
+    gen = torch.Generator().manual_seed(H * 1000 + W)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    h1, w = r(N, C, H, W), r(C, 1, 3, 3)
+    A, B = r(N * C), r(N * C)
+    h1p = _padded(E, h1, g)
+    slots = hb.query("uncr_any_slots")
+    h2p = torch.zeros(N, C, 1, g.Pc, device="cuda")
+    part = torch.empty(N * C, slots, 2, device="cuda")
+    hb.call("uncr_dw_fwd_any", h1p, A.cuda(), B.cuda(), w.reshape(C, 9).contiguous().cuda(), h2p, part, N, C, H, W, g.Pc, E._stream())
+    h1d = h1.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    u1 = A.view(N, C, 1, 1).double() * h1d + B.view(N, C, 1, 1).double()
+    h2 = F.conv2d(F.pad(F.gelu(u1), (1, 1, 1, 1), mode="reflect"), wd, groups=C)
+    close("dw_any/h2", E.extract_tail(h2p, g), h2.detach(), tol=2e-6)
+    close("dw_any/stats0", part.sum(1)[:, 0], h2.detach().sum(dim=(2, 3)).reshape(-1), tol=2e-5)
+    close("dw_any/stats1", part.sum(1)[:, 1], (h2.detach() ** 2).sum(dim=(2, 3)).reshape(-1), tol=2e-6)
+    assert float(h2p.view(N * C, g.Pc)[:, g.P:].abs().max()) == 0.0      # the kernel leaves the tail alone
+    # backward: dh2 = k1*du2 + k2*(h2 - kmu) + k3
+    du2 = r(N, C, H, W)
+    k1, k2, k3, kmu, mean1 = r(N * C), r(N * C) * 0.1, r(N * C) * 0.1, r(N * C), r(C)
+    dh2 = k1.view(N, C, 1, 1).double() * du2.double() + k2.view(N, C, 1, 1).double() * (h2.detach() - kmu.view(N, C, 1, 1).double()) \
+        + k3.view(N, C, 1, 1).double()
+    h2.backward(dh2)
+    du1p = torch.zeros(N, C, 1, g.Pc, device="cuda")
+    part1 = torch.empty(N * C, slots, 2, device="cuda")
+    dwp = torch.empty(N * C, slots, 9, device="cuda")
+    hb.call("uncr_dw_bwd_any", _padded(E, du2, g), E.embed_tail(h2.detach().float().cuda(), g), h1p, k1.cuda(), k2.cuda(), k3.cuda(), kmu.cuda(),
+            A.cuda(), B.cuda(), w.reshape(C, 9).contiguous().cuda(), du1p, part1, dwp, mean1.cuda(), 0, N, C, H, W, g.Pc, E._stream())
+    du1_ref = h1d.grad / A.view(N, C, 1, 1).double()          # d/d(u1) = d/d(h1) / A
+    close("dw_any/du1", E.extract_tail(du1p, g), du1_ref, tol=5e-6)
+    close("dw_any/dw", dwp.sum(1).view(N, C, 9).sum(0), wd.grad.reshape(C, 9), tol=5e-6)
+    close("dw_any/bstats0", part1.sum(1)[:, 0], du1_ref.sum(dim=(2, 3)).reshape(-1), tol=2e-5)
+    close("dw_any/bstats1", part1.sum(1)[:, 1], (du1_ref * (h1.double() - mean1.view(1, C, 1, 1).double())).sum(dim=(2, 3)).reshape(-1), tol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(100, 100), (70, 90), (250, 33)])
+def test_maxpool_and_aggregation_any_size_vs_oracle(H, W):
+    from gpu_util import close
+    from oracle import uncrtaints_oracle as orc
+    from uncrtaints_amd import engine as E
+    B, T, C, NH = 2, 3, 32, 16
+    g = _geom(E, H, W)
+    gen = torch.Generator().manual_seed(H + W)
+    e = torch.randn(B, T, C, H, W, generator=gen)
+    att = torch.softmax(torch.randn(NH, B, T, 32, 32, generator=gen), dim=2)
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[1, 0] = True
+    dm = (torch.rand(NH * B, T, H, W, generator=gen) > 0.1).float() / 0.9
+    dg = torch.randn(B, C, H, W, generator=gen)
+    ep = _padded(E, e, g)
+    with E.geom_scope(g):
+        down, idx = E.maxpool_forward(ep.view(B * T, C, 1, g.Pc), 32, 32)
+    ref, ridx = F.adaptive_max_pool2d(e.view(B * T, C, H, W), (32, 32), return_indices=True)
+    close("maxpool_any", down, ref)
+    assert torch.equal(idx.cpu().long(), ridx)
+    gd = torch.randn(B * T, C, 32, 32, generator=gen)
+    dep = torch.zeros(B * T, C, 1, g.Pc, device="cuda")
+    with E.geom_scope(g):
+        E.maxpool_backward_into(gd.cuda(), idx, dep, 1, g.Pc, 32, 32)
+    er = e.view(B * T, C, H, W).clone().requires_grad_(True)
+    F.adaptive_max_pool2d(er, (32, 32)).backward(gd)
+    close("maxpool_any_bwd", E.extract_tail(dep, g), er.grad)
+    # aggregation: forward, statistics, both gradients (explicit dropout mask, one padded date)
+    cfg = orc.OracleConfig(n_head=NH)
+    eo, ao = e.clone().requires_grad_(True), att.clone().requires_grad_(True)
+    go = orc.temporal_aggregate(eo, pad, ao, cfg, training=True, dropout_mask=dm)
+    go.backward(dg)
+    with E.geom_scope(g):
+        gp, sv, part = E.aggregate_forward(ep, att.cuda(), pad.to(torch.int32).cuda(), True, 0.1, 1234, dm.cuda())
+        de, datt = E.aggregate_backward(_padded(E, dg, g), sv)
+    close("agg_any/g", E.extract_tail(gp, g), go)
+    close("agg_any/stats0", part.buf.sum(1)[:, 0], go.detach().sum(dim=(2, 3)).reshape(-1), tol=2e-5)
+    close("agg_any/stats1", part.buf.sum(1)[:, 1], (go.detach() ** 2).sum(dim=(2, 3)).reshape(-1))
+    close("agg_any/de", E.extract_tail(de, g), eo.grad)
+    close("agg_any/datt", datt, ao.grad, tol=2e-5)
+    assert float(gp.view(B * C, g.Pc)[:, g.P:].abs().max()) == 0.0 and float(de.reshape(B * T * C, g.Pc)[:, g.P:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_tail_corrections():
+    """uncr_fix_tail / uncr_fix_sepool_tail / uncr_fix_wgrad_tail / uncr_fix_rowsum_tail: a flat kernel run over the whole stride of
+    zero-tailed planes + its correction equals the reduction over the image alone."""
+    from gpu_util import close
+    import uncrtaints_amd.hip_backend as hb
+    from uncrtaints_amd import engine as E
+    torch.manual_seed(0)
+    N, C, Ch, H, W = 2, 128, 256, 100, 100
+    g = _geom(E, H, W)
+    P, Pc = g.P, g.Pc
+    pad = lambda n, c: E.embed_tail(torch.randn(n, c, H, W).cuda(), g)
+    dy, h3, h2 = pad(N, C), pad(N, C), pad(N, Ch)
+    c1, c2, c3, mu = (torch.randn(N * C, device="cuda") for _ in range(4))
+    A2, B2 = torch.randn(N * Ch, device="cuda"), torch.randn(N * Ch, device="cuda")
+    val = lambda t, c: t.view(N, c, Pc)[..., :P].double()
+    dh = c1.view(N, C, 1).double() * val(dy, C) + c2.view(N, C, 1).double() * (val(h3, C) - mu.view(N, C, 1).double()) + c3.view(N, C, 1).double()
+    z = F.gelu(A2.view(N, Ch, 1).double() * val(h2, Ch) + B2.view(N, Ch, 1).double())
+    with E.geom_scope(g):
+        G, rs = E.pw_wgrad(dy, h2, N, C, Ch, Pc, pro_d=E.PRO_NORMBWD, dk=(c1, c2, c3, mu), d2=h3, pro_x=E.PRO_AFFINE_GELU, xk=(A2, B2, None),
+                           per_frame=True)
+        hb.call("uncr_fix_wgrad_tail", G, N, C, Ch, c2, c3, mu, B2, g.ntail, E._stream())
+        pp = E.se_pool(h2, A2, B2, N * Ch, Pc)
+        hb.call("uncr_fix_sepool_tail", pp.buf, pp.slots, B2, N * Ch, g.ntail, E._stream())
+        # a point-wise producer with statistics: y = A*h2 + B over the whole stride, then the fix
+        y = torch.empty_like(h2)
+        _, party = E.ew(E.EW_AFFINE, h2, out=y, k=(A2, B2, None, None), want_part=True, planes=N * Ch, P=Pc)
+        E.fix_tail(y, party, 0, N * Ch)
+        # row sums of a norm-backward operand
+        x15 = pad(N, 15)
+        dW, db = E.pw_wgrad(dy, x15, N, C, 15, Pc, pro_d=E.PRO_NORMBWD, dk=(c1, c2, c3, mu), d2=h3, rowsum=True)
+        hb.call("uncr_fix_rowsum_tail", db, N, C, c2, c3, mu, g.ntail, E._stream())
+    close("fix/G", G, torch.einsum("nop,nip->noi", dh, z), tol=2e-6)
+    close("fix/sepool", pp.buf.sum(1)[:, 0], z.sum(-1).reshape(-1), tol=2e-6)
+    yr = A2.view(N, Ch, 1).double() * val(h2, Ch) + B2.view(N, Ch, 1).double()
+    close("fix/y", y.view(N, Ch, Pc)[..., :P], yr, tol=2e-6)
+    assert float(y.view(N * Ch, Pc)[:, P:].abs().max()) == 0.0
+    close("fix/stats0", party.buf.sum(1)[:, 0], yr.sum(-1).reshape(-1), tol=2e-5)
+    close("fix/stats1", party.buf.sum(1)[:, 1], (yr ** 2).sum(-1).reshape(-1), tol=2e-6)
+    close("fix/rowsum", db, dh.sum(dim=(0, 2)), tol=2e-5)
+    close("fix/dW", dW, torch.einsum("nop,nip->oi", dh, val(x15, 15)), tol=2e-6)     # x is zero on the tail: nothing to correct
+
+
+def _model(**kw):
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    mk = dict(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag", scale_by=1.0)
+    mk.update(kw)
+    return U.UNCRTAINTS(**mk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,shape", [
+    ("att_mean", dict(agg_mode="att_mean"), (1, 3, 60, 72)),
+    ("mean", dict(agg_mode="mean"), (1, 2, 50, 50)),
+    ("iso", dict(covmode="iso", out_conv=[14]), (2, 2, 45, 47)),
+    ("separate_out", dict(separate_out=True), (1, 2, 66, 38)),
+    ("is_mono", dict(is_mono=True), (2, 1, 40, 50)),
+    ("batch_norm_encoder_two_blocks", dict(encoder_norm="batch", encoder_widths=[128, 128]), (2, 2, 34, 70)),
+])
+def test_model_variants_at_odd_sizes(name, kw, shape):
+    """Constructor variants at sizes outside the tuned tilings (odd widths included), one padded date where there are several: eval and
+    train forward, loss and every gradient against the oracle."""
+    from gpu_util import Fp32Draws, close, close_grad, dev, is_zero_grad, oracle_run, pool_branch
+    from oracle import uncrtaints_oracle as orc
+    from uncrtaints_amd.src import losses
+    B, T, H, W = shape
+    cfg = orc.OracleConfig(attn_dropout=0.0, **kw)
+    x, y, dates = orc.synthetic_batch(B, T, H, W, seed=7)
+    if T > 1:
+        x[B - 1, T - 1] = 0.0
+    torch.manual_seed(6)
+    m = _model(**kw)                       # the module's own (seeded) initialisation; the oracle reads the same state_dict keys
+    g_ = torch.Generator().manual_seed(16)
+    for mod in m.modules():                # running statistics and norm affines away from their defaults
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=g_))
+            mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g_))
+        if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.GroupNorm)) and mod.weight is not None:
+            mod.weight.data.copy_(1.0 + 0.3 * torch.randn(mod.weight.shape, generator=g_))
+            mod.bias.data.copy_(0.2 * torch.randn(mod.bias.shape, generator=g_))
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    if hasattr(m, "temporal_aggregator"):
+        m.temporal_aggregator.attn_dropout.p = 0.0
+    m = m.to("cuda").eval()
+    with torch.no_grad():
+        oe = m(dev(x), batch_positions=dev(dates))
+        ref_e = orc.forward({k: v.clone() for k, v in state.items()}, x, dates, cfg, training=False)
+    assert tuple(oe.shape) == tuple(ref_e.shape)
+    close(f"odd[{name}]/eval", oe, ref_e)
+    m.train()
+    out = m(dev(x), batch_positions=dev(dates))
+    cov = kw.get("covmode", "diag")
+    l, _ = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode=cov)(out[:, :, :13], dev(y), out[:, :, 13:m.vars_idx])
+    l.backward()
+    pidx, _ = pool_branch(m, state, x, dates, cfg) if name != "is_mono" else (None, 0)
+    out_o, loss_o, _, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx)
+    _, _, _, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64, pool_idx=pidx)
+    close(f"odd[{name}]/train", out, out_o)
+    assert abs(l.item() - loss_o.item()) < 1e-4 * abs(loss_o.item())
+    draws = Fp32Draws(lambda: oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx)[3])
+    for k, v in m.named_parameters():
+        if name == "mean" and k.startswith("temporal_encoder"):
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0      # the attention never reaches the output in this mode
+            continue
+        if v.grad is None or g64.get(k) is None or is_zero_grad(k, g64):
+            continue
+        close_grad(f"odd[{name}]/grad[{k}]", v.grad, g32[k], g64[k], draws=draws, key=k)
+
+
+@pytest.mark.gpu
+def test_odd_size_properties_and_refusals():
+    """Train-mode dropout on the hash stream at an odd size (shape, positivity, attention a distribution), a run at a friendly size right
+    after it (the geometry scope leaves nothing behind), and the configurations that refuse odd sizes."""
+    from gpu_util import dev
+    from oracle import uncrtaints_oracle as orc
+    from uncrtaints_amd import engine as E
+    cfg = orc.OracleConfig()
+    state = orc.init_params(cfg, seed=2)
+    m = _model()
+    m.load_state_dict(state, strict=True)
+    m = m.to("cuda").train()
+    x, _, dates = orc.synthetic_batch(1, 3, 75, 61, seed=3)
+    out = m(dev(x), batch_positions=dev(dates))
+    assert tuple(out.shape) == (1, 1, 26, 75, 61) and torch.isfinite(out).all()
+    assert (out[:, :, 13:] > 0).all() and (out[:, :, :13] >= 0).all() and (out[:, :, :13] <= 1).all()
+    att = m._last_attention
+    assert torch.allclose(att.sum(dim=2), torch.ones_like(att.sum(dim=2)), atol=1e-5)
+    out.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    assert E.current_geom() is None and E._H2_FWD and E._H2_BWD          # the scope restored the switches
+    x2, _, d2 = orc.synthetic_batch(1, 3, 64, 64, seed=3)
+    m.load_state_dict(state, strict=True)          # (the train step moved the running statistics)
+    m.eval()
+    with torch.no_grad():
+        o2 = m(dev(x2), batch_positions=dev(d2))
+        ref = orc.forward({k: v.clone() for k, v in state.items()}, x2, d2, cfg, training=False)
+    assert float((o2.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
+    with pytest.raises(NotImplementedError):
+        _model().to("cuda").set_act_dtype("bf16")(dev(x), batch_positions=dev(dates))
+    with pytest.raises(NotImplementedError):
+        _model(block_type="residual", decoder_widths=[128, 128]).to("cuda")(dev(x), batch_positions=dev(dates))
+    with pytest.raises(RuntimeError):
+        _model().to("cuda")(dev(x[..., :20, :20]), batch_positions=dev(dates))        # smaller than the 32 x 32 attention map
