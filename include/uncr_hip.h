@@ -259,11 +259,13 @@ int uncr_fix_rowsum_tail(float* rs /* [C] */, int N, int C, const float* c2, con
                          int ntail, hipStream_t stream);
 /* depthwise 3x3 reflect (uncrtaints.py:130-131) with the meaning of uncr_dw_fwd / uncr_dw_bwd on dense H x W planes of stride Pc;
  * part [N*C][uncr_any_slots()][2], dw_part [N*C][uncr_any_slots()][9] */
-int uncr_dw_fwd_any(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part, int N, int C, int H,
-                    int W, int Pc, hipStream_t stream);
+int uncr_dw_fwd_any(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part,
+                    float* scratch /* [N*C][Pc] floats: gelu(A*in + B), written here */, int N, int C, int H, int W, int Pc,
+                    hipStream_t stream);
 int uncr_dw_bwd_any(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2, const float* k3,
                     const float* kmu, const float* cA1, const float* cB1, const float* w, float* du1, float* part, float* dw_part,
-                    const float* mean1, int mean_groups, int N, int C, int H, int W, int Pc, hipStream_t stream);
+                    const float* mean1, int mean_groups, float* scratch /* [N*C][Pc] floats */, int N, int C, int H, int W, int Pc,
+                    hipStream_t stream);
 /* adaptive max-pool (uncrtaints.py:403-404) on planes of stride pstride; idx = flat index inside the H x W image */
 int uncr_maxpool_fwd_strided(const float* in, float* out, int* idx, int planes, int H, int W, int pstride, int OH, int OW,
                              hipStream_t stream);

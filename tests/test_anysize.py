@@ -49,7 +49,8 @@ def test_depthwise_any_size_fwd_bwd_vs_torch(H, W):
     slots = hb.query("uncr_any_slots")
     h2p = torch.zeros(N, C, 1, g.Pc, device="cuda")
     part = torch.empty(N * C, slots, 2, device="cuda")
-    hb.call("uncr_dw_fwd_any", h1p, A.cuda(), B.cuda(), w.reshape(C, 9).contiguous().cuda(), h2p, part, N, C, H, W, g.Pc, E._stream())
+    hb.call("uncr_dw_fwd_any", h1p, A.cuda(), B.cuda(), w.reshape(C, 9).contiguous().cuda(), h2p, part,
+            torch.empty(N, C, g.Pc, device="cuda"), N, C, H, W, g.Pc, E._stream())
     h1d = h1.double().requires_grad_(True)
     wd = w.double().requires_grad_(True)
     u1 = A.view(N, C, 1, 1).double() * h1d + B.view(N, C, 1, 1).double()
@@ -68,7 +69,8 @@ def test_depthwise_any_size_fwd_bwd_vs_torch(H, W):
     part1 = torch.empty(N * C, slots, 2, device="cuda")
     dwp = torch.empty(N * C, slots, 9, device="cuda")
     hb.call("uncr_dw_bwd_any", _padded(E, du2, g), E.embed_tail(h2.detach().float().cuda(), g), h1p, k1.cuda(), k2.cuda(), k3.cuda(), kmu.cuda(),
-            A.cuda(), B.cuda(), w.reshape(C, 9).contiguous().cuda(), du1p, part1, dwp, mean1.cuda(), 0, N, C, H, W, g.Pc, E._stream())
+            A.cuda(), B.cuda(), w.reshape(C, 9).contiguous().cuda(), du1p, part1, dwp, mean1.cuda(), 0, torch.empty(N, C, g.Pc, device="cuda"),
+            N, C, H, W, g.Pc, E._stream())
     du1_ref = h1d.grad / A.view(N, C, 1, 1).double()          # d/d(u1) = d/d(h1) / A
     close("dw_any/du1", E.extract_tail(du1p, g), du1_ref, tol=5e-6)
     close("dw_any/dw", dwp.sum(1).view(N, C, 9).sum(0), wd.grad.reshape(C, 9), tol=5e-6)

@@ -132,25 +132,33 @@ extern "C" int uncr_fix_rowsum_tail(float* rs, int N, int C, const float* c2, co
 // ---- depthwise 3x3, reflect padding, any H x W (uncrtaints.py:130-131): h2 = dw(gelu(A*h1 + B)), (sum h2, sum h2^2) per block ----
 __device__ __forceinline__ int refl(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
-__global__ __launch_bounds__(256) void dw_fwd_any_kernel(const float* __restrict__ in, const float* __restrict__ cA,
-                                                         const float* __restrict__ cB, const float* __restrict__ w,
+// g1 = gelu(A*h1 + B) over the whole stride (a flat float4 pass; the stencil then reads nine plain neighbours instead of evaluating nine
+// GELUs per output pixel: 474 -> ~100 us at 4 x 256 x 250 x 250)
+__global__ __launch_bounds__(256) void affine_gelu_any_kernel(const float* __restrict__ in, const float* __restrict__ cA,
+                                                              const float* __restrict__ cB, float* __restrict__ out, int Pc) {
+    const int plane = blockIdx.y;
+    const float A = cA[plane], B = cB[plane];
+    const size_t o = (size_t)plane * Pc + (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    const float4 v = *(const float4*)(in + o);
+    *(float4*)(out + o) = make_float4(gelu_f(fmaf(A, v.x, B)), gelu_f(fmaf(A, v.y, B)), gelu_f(fmaf(A, v.z, B)), gelu_f(fmaf(A, v.w, B)));
+}
+
+__global__ __launch_bounds__(256) void dw_fwd_any_kernel(const float* __restrict__ g1, const float* __restrict__ w,
                                                          float* __restrict__ out, float2* __restrict__ part, int C, int H, int W, int Pc) {
     const int plane = blockIdx.y, c = plane % C;
-    const float A = cA[plane], B = cB[plane];
     float wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
-    const float* ip = in + (size_t)plane * Pc;
+    const float* ip = g1 + (size_t)plane * Pc;
     float* op = out + (size_t)plane * Pc;
     float s0 = 0.f, s1 = 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += ANY_NB * 256) {
         const int y = i / W, x = i - y * W;
-        float acc = 0.f;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-                acc = fmaf(wk[ky * 3 + kx], gelu_f(fmaf(A, ip[refl(y + ky - 1, H) * W + refl(x + kx - 1, W)], B)), acc);
+        const int ym = refl(y - 1, H) * W, y0 = y * W, yp = refl(y + 1, H) * W, xm = refl(x - 1, W), xp = refl(x + 1, W);
+        float acc = wk[0] * ip[ym + xm];
+        acc = fmaf(wk[1], ip[ym + x], acc); acc = fmaf(wk[2], ip[ym + xp], acc);
+        acc = fmaf(wk[3], ip[y0 + xm], acc); acc = fmaf(wk[4], ip[y0 + x], acc); acc = fmaf(wk[5], ip[y0 + xp], acc);
+        acc = fmaf(wk[6], ip[yp + xm], acc); acc = fmaf(wk[7], ip[yp + x], acc); acc = fmaf(wk[8], ip[yp + xp], acc);
         op[i] = acc;
         s0 += acc;
         s1 = fmaf(acc, acc, s1);
@@ -161,62 +169,94 @@ __global__ __launch_bounds__(256) void dw_fwd_any_kernel(const float* __restrict
         if (threadIdx.x == 0) part[(size_t)plane * ANY_NB + blockIdx.x] = make_float2(s0, s1);
     }
 }
-extern "C" int uncr_dw_fwd_any(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part, int N, int C,
-                               int H, int W, int Pc, hipStream_t stream) {
-    if (N <= 0 || C <= 0 || H < 2 || W < 2 || Pc < H * W) return UNCR_ESHAPE;
-    if (!in || !cA || !cB || !w || !out) return UNCR_EINVAL;
-    hipLaunchKernelGGL(dw_fwd_any_kernel, dim3(ANY_NB, N * C), dim3(256), 0, stream, in, cA, cB, w, out, (float2*)part, C, H, W, Pc);
+extern "C" int uncr_dw_fwd_any(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part,
+                               float* scratch /* [N*C][Pc]: gelu(A*in + B) */, int N, int C, int H, int W, int Pc, hipStream_t stream) {
+    if (N <= 0 || C <= 0 || H < 2 || W < 2 || Pc < H * W || Pc % 1024) return UNCR_ESHAPE;
+    if (!in || !cA || !cB || !w || !out || !scratch) return UNCR_EINVAL;
+    hipLaunchKernelGGL(affine_gelu_any_kernel, dim3(Pc / 1024, N * C), dim3(256), 0, stream, in, cA, cB, scratch, Pc);
+    UNCR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dw_fwd_any_kernel, dim3(ANY_NB, N * C), dim3(256), 0, stream, scratch, w, out, (float2*)part, C, H, W, Pc);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
 
-// backward: dh2 = k1*du2 + k2*(h2 - kmu) + k3 (norm-2 backward), dg1 = adjoint of the reflect-padded stencil applied to dh2,
-// du1 = gelu'(A1*h1 + B1) * dg1; statistics (sum du1, sum du1*(h1 - mean1)) and the depthwise weight-gradient partials
-// dw_part[plane][block][tap] = sum_p dh2[p] * gelu(A1*h1 + B1)[reflected neighbour of p for that tap]
-__global__ __launch_bounds__(256) void dw_bwd_any_kernel(const float* __restrict__ du2, const float* __restrict__ h2,
-                                                         const float* __restrict__ h1, const float* __restrict__ k1,
-                                                         const float* __restrict__ k2, const float* __restrict__ k3,
-                                                         const float* __restrict__ kmu, const float* __restrict__ cA1,
-                                                         const float* __restrict__ cB1, const float* __restrict__ w,
-                                                         float* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
-                                                         const float* __restrict__ mean1, int mean_groups, int C, int H, int W, int Pc) {
-    const int plane = blockIdx.y, c = plane % C, n = plane / C;
+// backward: dh2 = k1*du2 + k2*(h2 - kmu) + k3 (norm-2 backward), then per INPUT pixel q and tap k the gathered sum
+//   t_k[q] = sum of dh2 over the outputs that read q through tap k (one output in the interior; up to four next to a reflecting border),
+// from which both results follow with ONE erf per pixel:  dg1[q] = sum_k w_k t_k[q],  du1 = gelu'(u1) * dg1,  and the depthwise weight
+// gradient  dW_k = sum_q gelu(u1)[q] * t_k[q];  statistics (sum du1, sum du1*(h1 - mean1)).
+// The outputs y' with refl(y' + d) == y for a row offset d = ky - 1:  y' = y - d;  y' = -y - d (reflection at row 0);
+// y' = 2H - 2 - y - d (reflection at row H-1) -- each only if it lies in [0, H) and really maps to y.
+__device__ __forceinline__ int refl_sources(int y, int d, int n, int (&src)[3]) {
+    int cnt = 0;
+    const int a = y - d, b = -y - d, c = 2 * n - 2 - y - d;
+    if (a >= 0 && a < n) src[cnt++] = a;
+    if (b >= 0 && b < n && b != a && refl(b + d, n) == y) src[cnt++] = b;
+    if (c >= 0 && c < n && c != a && c != b && refl(c + d, n) == y) src[cnt++] = c;
+    return cnt;
+}
+// dh2 = k1*du2 + k2*(h2 - kmu) + k3 over the whole stride (flat float4 pass; the gather below then reads one value per source)
+__global__ __launch_bounds__(256) void normbwd_any_kernel(const float* __restrict__ du2, const float* __restrict__ h2,
+                                                          const float* __restrict__ k1, const float* __restrict__ k2,
+                                                          const float* __restrict__ k3, const float* __restrict__ kmu,
+                                                          float* __restrict__ out, int Pc) {
+    const int plane = blockIdx.y;
     const float K1 = k1[plane], K2 = k2[plane], K3 = k3[plane], KM = kmu ? kmu[plane] : 0.f;
+    const size_t o = (size_t)plane * Pc + (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    const float4 a = *(const float4*)(du2 + o), b = *(const float4*)(h2 + o);
+    *(float4*)(out + o) = make_float4(fmaf(K1, a.x, fmaf(K2, b.x - KM, K3)), fmaf(K1, a.y, fmaf(K2, b.y - KM, K3)),
+                                      fmaf(K1, a.z, fmaf(K2, b.z - KM, K3)), fmaf(K1, a.w, fmaf(K2, b.w - KM, K3)));
+}
+__global__ __launch_bounds__(256) void dw_bwd_any_kernel(const float* __restrict__ dh2, const float* __restrict__ h1,
+                                                         const float* __restrict__ cA1, const float* __restrict__ cB1,
+                                                         const float* __restrict__ w, float* __restrict__ du1, float2* __restrict__ part,
+                                                         float* __restrict__ dw_part, const float* __restrict__ mean1, int mean_groups,
+                                                         int C, int H, int W, int Pc) {
+    const int plane = blockIdx.y, c = plane % C, n = plane / C;
     const float A1 = cA1[plane], B1 = cB1[plane];
     const float m1 = mean1 ? (mean_groups > 0 ? mean1[n * mean_groups + c / (C / mean_groups)] : mean1[c]) : 0.f;
     float wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
     const size_t base = (size_t)plane * Pc;
-    auto dh2 = [&](int yy, int xx) { const size_t o = base + (size_t)yy * W + xx; return fmaf(K1, du2[o], fmaf(K2, h2[o] - KM, K3)); };
+    const float* dp = dh2 + base;
     float s0 = 0.f, s1 = 0.f, gw[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) gw[k] = 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += ANY_NB * 256) {
         const int y = i / W, x = i - y * W;
-        // (a) this pixel as an INPUT of the forward stencil: every output (y', x') within one pixel that reads it through tap (ky, kx)
-        float dg = 0.f;
-        for (int yo = max(y - 1, 0); yo <= min(y + 1, H - 1); ++yo)
-            for (int xo = max(x - 1, 0); xo <= min(x + 1, W - 1); ++xo) {
-                const float d = dh2(yo, xo);
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-                        if (refl(yo + ky - 1, H) == y && refl(xo + kx - 1, W) == x) dg = fmaf(wk[ky * 3 + kx], d, dg);
-            }
         const float hv = h1[base + i];
-        const float v = gelu_grad_f(fmaf(A1, hv, B1)) * dg;
+        const float u = fmaf(A1, hv, B1);
+        const float gq = gelu_f(u);
+        float dg = 0.f;
+        if (y >= 2 && y < H - 2 && x >= 2 && x < W - 2) {
+            // interior: tap (ky, kx) of exactly one output, (y - ky + 1, x - kx + 1), reads this pixel
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float t = dp[(y - ky + 1) * W + (x - kx + 1)];
+                    dg = fmaf(wk[ky * 3 + kx], t, dg);
+                    gw[ky * 3 + kx] = fmaf(gq, t, gw[ky * 3 + kx]);
+                }
+        } else {
+            int ys[3][3], xs[3][3], ny[3], nx[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ny[k] = refl_sources(y, k - 1, H, ys[k]); nx[k] = refl_sources(x, k - 1, W, xs[k]); }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    float t = 0.f;
+                    for (int a = 0; a < ny[ky]; ++a)
+                        for (int b = 0; b < nx[kx]; ++b) t += dp[ys[ky][a] * W + xs[kx][b]];
+                    dg = fmaf(wk[ky * 3 + kx], t, dg);
+                    gw[ky * 3 + kx] = fmaf(gq, t, gw[ky * 3 + kx]);
+                }
+        }
+        const float v = gelu_grad_f(u) * dg;
         du1[base + i] = v;
         s0 += v;
         s1 = fmaf(v, hv - m1, s1);
-        // (b) this pixel as an OUTPUT: its dh2 against the nine (reflected) inputs
-        const float d0 = dh2(y, x);
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-                gw[ky * 3 + kx] = fmaf(d0, gelu_f(fmaf(A1, h1[base + (size_t)refl(y + ky - 1, H) * W + refl(x + kx - 1, W)], B1)), gw[ky * 3 + kx]);
     }
     __shared__ float red[8];
     block_sum2<256>(s0, s1, red);
@@ -234,12 +274,14 @@ __global__ __launch_bounds__(256) void dw_bwd_any_kernel(const float* __restrict
 }
 extern "C" int uncr_dw_bwd_any(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2, const float* k3,
                                const float* kmu, const float* cA1, const float* cB1, const float* w, float* du1, float* part,
-                               float* dw_part, const float* mean1, int mean_groups, int N, int C, int H, int W, int Pc,
-                               hipStream_t stream) {
-    if (N <= 0 || C <= 0 || H < 2 || W < 2 || Pc < H * W || (mean1 && mean_groups > 0 && C % mean_groups)) return UNCR_ESHAPE;
-    if (!du2 || !h2 || !h1 || !k1 || !k2 || !k3 || !cA1 || !cB1 || !w || !du1 || !part || !dw_part) return UNCR_EINVAL;
-    hipLaunchKernelGGL(dw_bwd_any_kernel, dim3(ANY_NB, N * C), dim3(256), 0, stream, du2, h2, h1, k1, k2, k3, kmu, cA1, cB1, w, du1,
-                       (float2*)part, dw_part, mean1, mean_groups, C, H, W, Pc);
+                               float* dw_part, const float* mean1, int mean_groups, float* scratch /* [N*C][Pc]: the norm-2 backward dh2 */,
+                               int N, int C, int H, int W, int Pc, hipStream_t stream) {
+    if (N <= 0 || C <= 0 || H < 2 || W < 2 || Pc < H * W || Pc % 1024 || (mean1 && mean_groups > 0 && C % mean_groups)) return UNCR_ESHAPE;
+    if (!du2 || !h2 || !h1 || !k1 || !k2 || !k3 || !cA1 || !cB1 || !w || !du1 || !part || !dw_part || !scratch) return UNCR_EINVAL;
+    hipLaunchKernelGGL(normbwd_any_kernel, dim3(Pc / 1024, N * C), dim3(256), 0, stream, du2, h2, k1, k2, k3, kmu, scratch, Pc);
+    UNCR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dw_bwd_any_kernel, dim3(ANY_NB, N * C), dim3(256), 0, stream, scratch, h1, cA1, cB1, w, du1, (float2*)part, dw_part,
+                       mean1, mean_groups, C, H, W, Pc);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -771,7 +771,7 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     part2 = Part(_f32((N * Ch, slots, 2), x.device), slots) if (need or h2ok) else None
     if geom is not None:
         hb.call("uncr_dw_fwd_any", h1, n1.A, n1.B, p["wdw"].reshape(Ch, 9).contiguous(), h2, part2.buf if part2 is not None else None,
-                N, Ch, geom.H, geom.W, geom.Pc, _stream())
+                _f32((N, Ch, geom.Pc), x.device), N, Ch, geom.H, geom.W, geom.Pc, _stream())
         fix_tail(h2, None, 2, N * Ch)          # (the kernel writes valid pixels only)
     elif n1.fin is not None:      # train-mode BatchNorm 1 finalised by the depthwise kernel's waves themselves
         hb.call("uncr_dw_fwd_bn", h1, *n1.fin, n1.A, n1.B, n1.mean, n1.rstd, n1.ub, n1.hb, p["wdw"].reshape(Ch, 9).contiguous(),
@@ -1070,7 +1070,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     du1_amax = None
     if geom is not None:
         hb.call("uncr_dw_bwd_any", du2, h2, h1, b2.c1, b2.c2, b2.c3, b2.mu, n1.A, n1.B, wdw, du1, part1.buf, dw_part, n1.mean,
-                n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, geom.H, geom.W, geom.Pc, _stream())
+                n1.groups if n1.kind == NORM_GROUP else 0, _f32((N, Ch, geom.Pc), dev), N, Ch, geom.H, geom.W, geom.Pc, _stream())
         fix_tail(du1, None, 2, N * Ch)
     else:
         if _H2_BWD and _H2_DX and n1.hb is not None and hb.query("uncr_dw_bwd_emits_amax", H, W, dt, _DW_VARIANT) == 1:
