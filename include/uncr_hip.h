@@ -430,6 +430,10 @@ int uncr_unpad2d_reflect_adjoint(const float* src, float* dst, int planes, int H
 int uncr_add_upsampled(const float* a, const float* z, float* out, float* part /* [planes][P/1024][2] or null */,
                        int planes, int H, int W, int AH, int AW, hipStream_t stream);
 int uncr_bilinear_adjoint(const float* src, float* dst, int planes, int H, int W, int AH, int AW, hipStream_t stream);
+/* the same pair on any-size planes (plane stride Pc >= H*W, tail written as zeros; part [planes][uncr_agg_any_slots()][2]) */
+int uncr_add_upsampled_any(const float* a, const float* z, float* out, float* part, int planes, int H, int W, int Pc, int AH, int AW,
+                           hipStream_t stream);
+int uncr_bilinear_adjoint_any(const float* src, float* dst, int planes, int H, int W, int Pc, int AH, int AW, hipStream_t stream);
 int uncr_add(const float* a, const float* b, float* out, long long n, hipStream_t stream);
 int uncr_dropout(const float* a, float* out, long long n, unsigned long long seed, const long long* seed_dev, float p,
                  hipStream_t stream);

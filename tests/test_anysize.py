@@ -180,6 +180,8 @@ def _model(**kw):
     ("separate_out", dict(separate_out=True), (1, 2, 66, 38)),
     ("is_mono", dict(is_mono=True), (2, 1, 40, 50)),
     ("batch_norm_encoder_two_blocks", dict(encoder_norm="batch", encoder_widths=[128, 128]), (2, 2, 34, 70)),
+    ("use_v", dict(use_v=True), (1, 2, 50, 46)),
+    ("use_v_att_mean", dict(use_v=True, agg_mode="att_mean"), (2, 2, 36, 41)),
 ])
 def test_model_variants_at_odd_sizes(name, kw, shape):
     """Constructor variants at sizes outside the tuned tilings (odd widths included), one padded date where there are several: eval and
@@ -188,7 +190,7 @@ def test_model_variants_at_odd_sizes(name, kw, shape):
     from oracle import uncrtaints_oracle as orc
     from uncrtaints_amd.src import losses
     B, T, H, W = shape
-    cfg = orc.OracleConfig(attn_dropout=0.0, **kw)
+    cfg = orc.OracleConfig(attn_dropout=0.0, ltae_dropout=0.0, **kw)
     x, y, dates = orc.synthetic_batch(B, T, H, W, seed=7)
     if T > 1:
         x[B - 1, T - 1] = 0.0
@@ -205,6 +207,8 @@ def test_model_variants_at_odd_sizes(name, kw, shape):
     state = {k: v.detach().clone() for k, v in m.state_dict().items()}
     if hasattr(m, "temporal_aggregator"):
         m.temporal_aggregator.attn_dropout.p = 0.0
+    if kw.get("use_v"):
+        m.temporal_encoder.dropout.p = 0.0
     m = m.to("cuda").eval()
     with torch.no_grad():
         oe = m(dev(x), batch_positions=dev(dates))

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void aggregate_any_dup_kernel(AggArgs g, int P
 }
 // adjoint of the bilinear up-sampling, any ratio: one thread per low-resolution cell gathers its footprint
 __global__ __launch_bounds__(256) void bilinear_adjoint_any_kernel(const float* __restrict__ dup, float* __restrict__ datt, int H, int W,
-                                                                   int AH, int AW) {
+                                                                   int AH, int AW, size_t stride /* of a source plane, >= H*W */) {
     const int q = blockIdx.y;
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= AH * AW) return;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void bilinear_adjoint_any_kernel(const float* 
     const float sy = (float)AH / (float)H, sx = (float)AW / (float)W;
     const int ylo = max(0, (int)floorf(((float)ay - 0.5f) / sy - 0.5f) - 1), yhi = min(H, (int)ceilf(((float)ay + 1.5f) / sy - 0.5f) + 2);
     const int xlo = max(0, (int)floorf(((float)ax - 0.5f) / sx - 0.5f) - 1), xhi = min(W, (int)ceilf(((float)ax + 1.5f) / sx - 0.5f) + 2);
-    const float* src = dup + (size_t)q * H * W;
+    const float* src = dup + (size_t)q * stride;
     float s = 0.f;
     for (int yy = ylo; yy < yhi; ++yy) {
         const Bilin by = bilin_src(yy, sy, AH);
@@ -596,7 +596,7 @@ extern "C" int uncr_aggregate_any_bwd(const float* dg, const float* e, const flo
     hipLaunchKernelGGL(aggregate_any_dup_kernel, dim3(AGGA_NB, NH * B * T), dim3(256), 0, stream, g, Pc);
     UNCR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bilinear_adjoint_any_kernel, dim3((AH * AW + 255) / 256, NH * B * T), dim3(256), 0, stream, datt_up, datt, H, W,
-                       AH, AW);
+                       AH, AW, (size_t)H * W);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -733,6 +733,52 @@ extern "C" int uncr_add_upsampled(const float* a, const float* z, float* out, fl
     if (!a || !z || !out) return UNCR_EINVAL;
     hipLaunchKernelGGL(add_upsampled_kernel, dim3(H * W / AGG_PX, planes), dim3(256), 0, stream, a, z, out,
                        (float2*)part, H, W, AH, AW);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+// use_v on any-size planes (plane stride Pc >= H*W, csrc/anysize.hip): the same sum with scalar accesses and AGGA_NB statistics
+// slots per plane; the tail [H*W, Pc) of `out` is written as zeros, as every consumer of a padded plane expects.
+__global__ __launch_bounds__(256) void add_upsampled_any_kernel(const float* __restrict__ a, const float* __restrict__ z,
+                                                                float* __restrict__ out, float2* __restrict__ part, int H, int W,
+                                                                int Pc, int AH, int AW) {
+    const int plane = blockIdx.y, P = H * W;
+    const float sy = (float)AH / (float)H, sx = (float)AW / (float)W;
+    const float* zp = z + (size_t)plane * AH * AW;
+    float s0 = 0.f, s1 = 0.f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < Pc; p += AGGA_NB * 256) {
+        float o = 0.f;
+        if (p < P) {
+            const int y = p / W, x = p - y * W;
+            const Bilin by = bilin_src(y, sy, AH), bx = bilin_src(x, sx, AW);
+            const float up = by.l0 * (bx.l0 * zp[by.i0 * AW + bx.i0] + bx.l1 * zp[by.i0 * AW + bx.i1]) +
+                             by.l1 * (bx.l0 * zp[by.i1 * AW + bx.i0] + bx.l1 * zp[by.i1 * AW + bx.i1]);
+            o = a[(size_t)plane * Pc + p] + up;
+        }
+        out[(size_t)plane * Pc + p] = o;
+        s0 += o;
+        s1 = fmaf(o, o, s1);
+    }
+    if (part) {
+        __shared__ float red[8];
+        block_sum2<256>(s0, s1, red);
+        if (threadIdx.x == 0) part[(size_t)plane * AGGA_NB + blockIdx.x] = make_float2(s0, s1);
+    }
+}
+extern "C" int uncr_add_upsampled_any(const float* a, const float* z, float* out, float* part, int planes, int H, int W, int Pc,
+                                      int AH, int AW, hipStream_t stream) {
+    if (planes <= 0 || H < AH || W < AW || Pc < H * W) return UNCR_ESHAPE;
+    if (!a || !z || !out) return UNCR_EINVAL;
+    hipLaunchKernelGGL(add_upsampled_any_kernel, dim3(AGGA_NB, planes), dim3(256), 0, stream, a, z, out, (float2*)part, H, W, Pc, AH,
+                       AW);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+extern "C" int uncr_bilinear_adjoint_any(const float* src, float* dst, int planes, int H, int W, int Pc, int AH, int AW,
+                                         hipStream_t stream) {
+    if (planes <= 0 || H < AH || W < AW || Pc < H * W) return UNCR_ESHAPE;
+    if (!src || !dst) return UNCR_EINVAL;
+    hipLaunchKernelGGL(bilinear_adjoint_any_kernel, dim3((AH * AW + 255) / 256, planes), dim3(256), 0, stream, src, dst, H, W, AH, AW,
+                       (size_t)Pc);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -1755,17 +1755,21 @@ def include_v_forward(gagg: Tensor, v: Tensor, w: Tensor, b: Tensor, want_stats:
     B, C, H, W = gagg.shape
     Cv, ah, aw = v.shape[1:]
     P, S = H * W, ah * aw
+    geom = _GEOM if (_GEOM is not None and P == _GEOM.Pc) else None        # padded planes of an any-size image: P = Pc, zero tails
     w2 = w.reshape(C, C + Cv)
     wa, wv = w2[:, :C].contiguous(), w2[:, C:].contiguous()
     z, _ = pw_gemm(v.reshape(B, Cv, S), pack_wt(wv, transpose=True), B, Cv, C, S, bias=b.contiguous())
-    t, _ = pw_gemm(gagg.view(B, C, P), pack_wt(wa, transpose=True), B, C, C, P)
+    t, _ = pw_gemm(gagg.view(B, C, P), pack_wt(wa, transpose=True), B, C, C, P)          # no bias: a zero tail stays zero
     out = _f32((B, C, H, W), gagg.device)
     part = None
     if want_stats:
-        slots = hb.query("uncr_agg_slots", P)
+        slots = hb.query("uncr_agg_any_slots") if geom is not None else hb.query("uncr_agg_slots", P)
         part = Part(_f32((B * C, slots, 2), gagg.device), slots)
-    hb.call("uncr_add_upsampled", t, z, out, part.buf if part else None, B * C, H, W, ah, aw, _stream())
-    return out, dict(g=gagg, v=v, wa=wa, wv=wv, dims=(B, C, Cv, H, W, ah, aw)), part
+    if geom is not None:
+        hb.call("uncr_add_upsampled_any", t, z, out, part.buf if part else None, B * C, geom.H, geom.W, geom.Pc, ah, aw, _stream())
+    else:
+        hb.call("uncr_add_upsampled", t, z, out, part.buf if part else None, B * C, H, W, ah, aw, _stream())
+    return out, dict(g=gagg, v=v, wa=wa, wv=wv, dims=(B, C, Cv, H, W, ah, aw), geom=geom), part
 
 
 def include_v_backward(dout: Tensor, sv: dict):
@@ -1774,7 +1778,11 @@ def include_v_backward(dout: Tensor, sv: dict):
     P, S = H * W, ah * aw
     dout = dout.contiguous()
     dz = _f32((B, C, S), dout.device)
-    hb.call("uncr_bilinear_adjoint", dout, dz, B * C, H, W, ah, aw, _stream())
+    if sv.get("geom") is not None:
+        gm = sv["geom"]
+        hb.call("uncr_bilinear_adjoint_any", dout, dz, B * C, gm.H, gm.W, gm.Pc, ah, aw, _stream())
+    else:
+        hb.call("uncr_bilinear_adjoint", dout, dz, B * C, H, W, ah, aw, _stream())
     dWa, db = pw_wgrad(dout.view(B, C, P), sv["g"].view(B, C, P), B, C, C, P, rowsum=True)     # db = sum dout (= sum dz)
     dWv, _ = pw_wgrad(dz, sv["v"].reshape(B, Cv, S), B, C, Cv, S)
     dg, _ = pw_gemm(dout.view(B, C, P), pack_wt(sv["wa"], transpose=False), B, C, C, P)
