@@ -423,6 +423,12 @@ int uncr_pad2d(const float* src, const float* src2, float* dst, const float* k0,
 int uncr_unpad2d(const float* src, float* dst, float* part /* [planes][H*W/1024][2] or null */, int planes, int H,
                  int W, hipStream_t stream);
 int uncr_unpad2d_reflect_adjoint(const float* src, float* dst, int planes, int H, int W, hipStream_t stream);
+/* the same three on the dense planes of an any-size image: plane stride Ps (a multiple of 1024 >= H*W) on the un-padded side, whose
+ * tail is never read and is written as zeros; part [planes][Ps/1024][2] */
+int uncr_pad2d_strided(const float* src, const float* src2, float* dst, const float* k0, const float* k1, const float* k2,
+                       const float* kmu, int pro, int mode, int planes, int H, int W, int Ps, hipStream_t stream);
+int uncr_unpad2d_strided(const float* src, float* dst, float* part, int planes, int H, int W, int Ps, hipStream_t stream);
+int uncr_unpad2d_reflect_adjoint_strided(const float* src, float* dst, int planes, int H, int W, int Ps, hipStream_t stream);
 
 /* ---- use_v variant (uncrtaints.py:324-338,414-417; LTAE2d ltae.py:10-141): pieces that are not already covered by the
  *      entry points above.  include_v(cat(g, up(v))) = Wa*g + up(Wv*v + b), so only uncr_add_upsampled touches full

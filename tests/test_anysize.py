@@ -236,6 +236,62 @@ def test_model_variants_at_odd_sizes(name, kw, shape):
 
 
 @pytest.mark.gpu
+def test_residual_blocks_at_an_odd_size():
+    """block_type='residual' (dense 3x3 convolutions as nine shifted GEMMs on reflect-padded planes, csrc/conv3.hip) on an image outside
+    the tuned tilings: only the padding / un-padding glue sees the dense planes' stride.  Gradients on the ReLU masks and the arg-max
+    branch the HIP forward took, as in test_variants.test_hip_residual_blocks."""
+    from gpu_util import Fp32Draws, close, close_grad, dev, pool_branch
+    from oracle import uncrtaints_oracle as orc
+    from uncrtaints_amd.src import losses
+    kw = dict(block_type="residual", decoder_widths=[128, 128])
+    B, T, H, W = 1, 2, 40, 50
+    cfg = orc.OracleConfig(attn_dropout=0.0, **kw)
+    x, y, dates = orc.synthetic_batch(B, T, H, W, seed=9)
+    torch.manual_seed(8)
+    m = _model(**kw)
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.temporal_aggregator.attn_dropout.p = 0.0
+    m = m.to("cuda").eval()
+    with torch.no_grad():
+        oe = m(dev(x), batch_positions=dev(dates))
+        ref_e = orc.forward({k: v.clone() for k, v in state.items()}, x, dates, cfg, training=False)
+    close("odd[residual]/eval", oe, ref_e, tol=2e-5)
+    m.train()
+    blocks = [(f"in_block.{i}", b) for i, b in enumerate(m.in_block)] + [(f"out_block.{i}", b) for i, b in enumerate(m.out_block)]
+    for _, blk in blocks:
+        blk.keep_relu_branch = True
+    out = m(dev(x), batch_positions=dev(dates))
+    l, _ = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode="diag")(out[:, :, :13], dev(y), out[:, :, 13:26])
+    l.backward()
+    masks = {}
+    for name, blk in blocks:
+        for i, (c, A, Bc) in enumerate(blk._last_relu, 1):
+            n, ch = c.shape[:2]
+            cv = c.reshape(n, ch, -1)[:, :, :H * W].reshape(n, ch, H, W)          # dense planes: the valid pixels
+            masks[f"{name}.conv{i}"] = ((A.view(n, ch, 1, 1) * cv + Bc.view(n, ch, 1, 1)) > 0).float().cpu()
+    pidx, _ = pool_branch(m, state, x, dates, cfg)
+
+    def run(dtype):
+        pt = {k: (v.clone().to(dtype).requires_grad_(True) if v.dtype.is_floating_point and "running" not in k
+                  else (v.clone().to(dtype) if v.dtype.is_floating_point else v.clone())) for k, v in state.items()}
+        ot = orc.forward(pt, x.to(dtype), dates.to(dtype), cfg, training=True, pool_idx=pidx, relu_masks=masks)
+        loss = orc.loss_from_output(ot, y.to(dtype), cfg)
+        loss.backward()
+        return ot.detach(), loss.item(), {k: v.grad for k, v in pt.items() if getattr(v, "grad", None) is not None}
+    ot, lo, g32 = run(torch.float32)
+    _, _, g64 = run(torch.float64)
+    close("odd[residual]/train", out, ot, tol=5e-5)
+    assert abs(l.item() - lo) < 1e-4 * abs(lo)
+    draws = Fp32Draws(lambda: run(torch.float32)[2])
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    for k, v in m.named_parameters():
+        if float(g64[k].abs().max()) < 1e-6:
+            assert float(v.grad.abs().max()) < 1e-3 * gmax, k
+            continue
+        close_grad(f"odd[residual]/grad[{k}]", v.grad, g32[k], g64[k], draws=draws, key=k)
+
+
+@pytest.mark.gpu
 def test_odd_size_properties_and_refusals():
     """Train-mode dropout on the hash stream at an odd size (shape, positivity, attention a distribution), a run at a friendly size right
     after it (the geometry scope leaves nothing behind), and the configurations that refuse odd sizes."""
@@ -265,7 +321,5 @@ def test_odd_size_properties_and_refusals():
     assert float((o2.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
     with pytest.raises(NotImplementedError):
         _model().to("cuda").set_act_dtype("bf16")(dev(x), batch_positions=dev(dates))
-    with pytest.raises(NotImplementedError):
-        _model(block_type="residual", decoder_widths=[128, 128]).to("cuda")(dev(x), batch_positions=dev(dates))
     with pytest.raises(RuntimeError):
         _model().to("cuda")(dev(x[..., :20, :20]), batch_positions=dev(dates))        # smaller than the 32 x 32 attention map

@@ -12,7 +12,8 @@
 __global__ __launch_bounds__(256) void pad2d_kernel(const float* __restrict__ src, const float* __restrict__ src2,
                                                     float* __restrict__ dst, const float* __restrict__ k0,
                                                     const float* __restrict__ k1, const float* __restrict__ k2,
-                                                    const float* __restrict__ kmu, int pro, int mode, int H, int W, int Sp) {
+                                                    const float* __restrict__ kmu, int pro, int mode, int H, int W, int Sp,
+                                                    int Ps /* source plane stride >= H*W */) {
     const int plane = blockIdx.y;
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= Sp) return;
@@ -23,7 +24,7 @@ __global__ __launch_bounds__(256) void pad2d_kernel(const float* __restrict__ sr
         const bool ring = y < 0 || y >= H || x < 0 || x >= W;
         if (!(ring && mode == 1)) {
             y = reflect1(y, H); x = reflect1(x, W);
-            const size_t o = (size_t)plane * H * W + (size_t)y * W + x;
+            const size_t o = (size_t)plane * Ps + (size_t)y * W + x;
             v = src[o];
             if (pro == PRO_AFFINE_RELU) v = fmaxf(fmaf(k0[plane], v, k1[plane]), 0.f);
             else if (pro == PRO_NORMBWD) v = fmaf(k0[plane], v, fmaf(k1[plane], src2[o] - (kmu ? kmu[plane] : 0.f), k2[plane]));
@@ -33,9 +34,10 @@ __global__ __launch_bounds__(256) void pad2d_kernel(const float* __restrict__ sr
     dst[(size_t)plane * Sp + q] = v;
 }
 
-// interior of a padded plane -> [planes][H][W], with (sum, sum^2) partials per 1024-pixel chunk
+// interior of a padded plane -> [planes][H][W] (plane stride Ps >= H*W, the tail written as zeros), with (sum, sum^2) partials per
+// 1024-pixel chunk
 __global__ __launch_bounds__(256) void unpad2d_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                      float2* __restrict__ part, int H, int W, int Sp) {
+                                                      float2* __restrict__ part, int H, int W, int Sp, int Ps) {
     const int plane = blockIdx.y;
     const int P = H * W, Wp = W + 2;
     float s0 = 0.f, s1 = 0.f;
@@ -45,9 +47,11 @@ __global__ __launch_bounds__(256) void unpad2d_kernel(const float* __restrict__ 
         if (p < P) {
             const int y = p / W, x = p % W;
             const float v = src[(size_t)plane * Sp + (size_t)(y + 1) * Wp + x + 1];
-            dst[(size_t)plane * P + p] = v;
+            dst[(size_t)plane * Ps + p] = v;
             s0 += v;
             s1 = fmaf(v, v, s1);
+        } else if (p < Ps) {
+            dst[(size_t)plane * Ps + p] = 0.f;
         }
     }
     if (part) {
@@ -61,10 +65,13 @@ __global__ __launch_bounds__(256) void unpad2d_kernel(const float* __restrict__ 
 // collects its own padded position plus the ring positions that mirror onto it (rows -1 -> 1, H -> H-2; same for
 // columns; corners through both).
 __global__ __launch_bounds__(256) void unpad2d_reflect_adjoint_kernel(const float* __restrict__ src,
-                                                                      float* __restrict__ dst, int H, int W, int Sp) {
+                                                                      float* __restrict__ dst, int H, int W, int Sp, int Ps) {
     const int plane = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= H * W) return;
+    if (p >= H * W) {
+        if (p < Ps) dst[(size_t)plane * Ps + p] = 0.f;
+        return;
+    }
     const int y = p / W, x = p % W, Wp = W + 2;
     const float* s = src + (size_t)plane * Sp;
     int ys[2] = {y + 1, -1}, xs[2] = {x + 1, -1};
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256) void unpad2d_reflect_adjoint_kernel(const floa
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             if (ys[i] >= 0 && xs[j] >= 0) a += s[(size_t)ys[i] * Wp + xs[j]];
-    dst[(size_t)plane * H * W + p] = a;
+    dst[(size_t)plane * Ps + p] = a;
 }
 
 extern "C" int uncr_conv3_plane_stride(int H, int W) {          // S_p: padded plane stride (floats)
@@ -88,22 +95,26 @@ extern "C" int uncr_conv3_plane_stride(int H, int W) {          // S_p: padded p
 }
 extern "C" int uncr_conv3_margin(int W) { return W + 3; }       // slack (floats) the caller keeps before and after the tensor
 
-extern "C" int uncr_pad2d(const float* src, const float* src2, float* dst, const float* k0, const float* k1,
-                          const float* k2, const float* kmu, int pro, int mode, int planes, int H, int W, hipStream_t stream) {
+static int pad2d_launch(const float* src, const float* src2, float* dst, const float* k0, const float* k1, const float* k2,
+                        const float* kmu, int pro, int mode, int planes, int H, int W, int Ps, hipStream_t stream) {
     const int Sp = uncr_conv3_plane_stride(H, W);
-    if (planes <= 0 || Sp <= 0 || mode < 0 || mode > 1) return UNCR_ESHAPE;
+    if (planes <= 0 || Sp <= 0 || mode < 0 || mode > 1 || Ps < H * W) return UNCR_ESHAPE;
     if (!src || !dst || (pro == PRO_NORMBWD && (!src2 || !k0 || !k1 || !k2)) ||
         ((pro == PRO_AFFINE_RELU || pro == PRO_AFFINE) && (!k0 || !k1)))
         return UNCR_EINVAL;
     hipLaunchKernelGGL(pad2d_kernel, dim3(Sp / 256, planes), dim3(256), 0, stream, src, src2, dst, k0, k1, k2, kmu, pro,
-                       mode, H, W, Sp);
+                       mode, H, W, Sp, Ps);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
+}
+extern "C" int uncr_pad2d(const float* src, const float* src2, float* dst, const float* k0, const float* k1,
+                          const float* k2, const float* kmu, int pro, int mode, int planes, int H, int W, hipStream_t stream) {
+    return pad2d_launch(src, src2, dst, k0, k1, k2, kmu, pro, mode, planes, H, W, H * W, stream);
 }
 extern "C" int uncr_unpad2d(const float* src, float* dst, float* part, int planes, int H, int W, hipStream_t stream) {
     const int Sp = uncr_conv3_plane_stride(H, W);
     if (planes <= 0 || Sp <= 0 || ((H * W) % 1024)) return UNCR_ESHAPE;
-    hipLaunchKernelGGL(unpad2d_kernel, dim3(H * W / 1024, planes), dim3(256), 0, stream, src, dst, (float2*)part, H, W, Sp);
+    hipLaunchKernelGGL(unpad2d_kernel, dim3(H * W / 1024, planes), dim3(256), 0, stream, src, dst, (float2*)part, H, W, Sp, H * W);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -111,7 +122,31 @@ extern "C" int uncr_unpad2d_reflect_adjoint(const float* src, float* dst, int pl
     const int Sp = uncr_conv3_plane_stride(H, W);
     if (planes <= 0 || Sp <= 0) return UNCR_ESHAPE;
     hipLaunchKernelGGL(unpad2d_reflect_adjoint_kernel, dim3((H * W + 255) / 256, planes), dim3(256), 0, stream, src,
-                       dst, H, W, Sp);
+                       dst, H, W, Sp, H * W);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+// ---- the same three on the dense planes of an any-size image (csrc/anysize.hip): plane stride Ps = a multiple of 1024 >= H*W; the
+// un-padded side's tail [H*W, Ps) is never read and is written as zeros; part [planes][Ps/1024][2] ----
+extern "C" int uncr_pad2d_strided(const float* src, const float* src2, float* dst, const float* k0, const float* k1,
+                                  const float* k2, const float* kmu, int pro, int mode, int planes, int H, int W, int Ps,
+                                  hipStream_t stream) {
+    return pad2d_launch(src, src2, dst, k0, k1, k2, kmu, pro, mode, planes, H, W, Ps, stream);
+}
+extern "C" int uncr_unpad2d_strided(const float* src, float* dst, float* part, int planes, int H, int W, int Ps, hipStream_t stream) {
+    const int Sp = uncr_conv3_plane_stride(H, W);
+    if (planes <= 0 || Sp <= 0 || Ps < H * W || (Ps % 1024)) return UNCR_ESHAPE;
+    if (!src || !dst) return UNCR_EINVAL;
+    hipLaunchKernelGGL(unpad2d_kernel, dim3(Ps / 1024, planes), dim3(256), 0, stream, src, dst, (float2*)part, H, W, Sp, Ps);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+extern "C" int uncr_unpad2d_reflect_adjoint_strided(const float* src, float* dst, int planes, int H, int W, int Ps,
+                                                    hipStream_t stream) {
+    const int Sp = uncr_conv3_plane_stride(H, W);
+    if (planes <= 0 || Sp <= 0 || Ps < H * W) return UNCR_ESHAPE;
+    if (!src || !dst) return UNCR_EINVAL;
+    hipLaunchKernelGGL(unpad2d_reflect_adjoint_kernel, dim3((Ps + 255) / 256, planes), dim3(256), 0, stream, src, dst, H, W, Sp, Ps);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

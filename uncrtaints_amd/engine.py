@@ -1158,8 +1158,9 @@ class _Padded:
     """[planes][S_p] padded planes inside a flat buffer with `margin` zero floats of slack on both sides, so that a
     tap's shifted view (flat[margin + off : ...]) stays inside the allocation."""
 
-    def __init__(self, N: int, C: int, H: int, W: int, dev):
+    def __init__(self, N: int, C: int, H: int, W: int, dev, geom=None):
         self.N, self.C, self.H, self.W = N, C, H, W
+        self.geom = geom          # any-size image: the un-padded side lives on dense planes of stride geom.Pc (csrc/anysize.hip)
         self.Sp = hb.query("uncr_conv3_plane_stride", H, W)
         self.margin = hb.query("uncr_conv3_margin", W)
         self.n = N * C * self.Sp
@@ -1182,12 +1183,16 @@ def conv3x3_forward(xp: _Padded, w: Tensor, b: Tensor, want_stats: bool):
     for i, (ky, kx, off) in enumerate(_taps(W)):
         pw_gemm(xp.view(off), pack_wt(wt[ky, kx], transpose=True), N, Ci, Co, xp.Sp, bias=b.contiguous() if i == 0 else None,
                 epi=0 if i == 0 else 4, out=outp.view().view(N, Co, xp.Sp))
-    c = _f32((N, Co, H, W), w.device)
+    g = xp.geom
+    c = _f32((N, Co, 1, g.Pc) if g is not None else (N, Co, H, W), w.device)
     part = None
     if want_stats:
-        slots = hb.query("uncr_ew_slots", H * W)
+        slots = hb.query("uncr_ew_slots", g.Pc if g is not None else H * W)
         part = Part(_f32((N * Co, slots, 2), w.device), slots)
-    hb.call("uncr_unpad2d", outp.view(), c, part.buf if part else None, N * Co, H, W, _stream())
+    if g is not None:
+        hb.call("uncr_unpad2d_strided", outp.view(), c, part.buf if part else None, N * Co, H, W, g.Pc, _stream())
+    else:
+        hb.call("uncr_unpad2d", outp.view(), c, part.buf if part else None, N * Co, H, W, _stream())
     return c, part
 
 
@@ -1197,9 +1202,14 @@ def conv3x3_backward(du: Tensor, c: Tensor, kk, xp: _Padded, w: Tensor, need_dx:
     N, Ci, H, W = xp.N, xp.C, xp.H, xp.W
     Co = w.shape[0]
     dev = w.device
-    dcp = _Padded(N, Co, H, W, dev)
-    hb.call("uncr_pad2d", du.contiguous(), c, dcp.view(), kk[0], kk[1], kk[2], kk[3] if len(kk) > 3 else None, PRO_NORMBWD, 1,
-            N * Co, H, W, _stream())
+    g = xp.geom
+    dcp = _Padded(N, Co, H, W, dev, g)
+    if g is not None:
+        hb.call("uncr_pad2d_strided", du.contiguous(), c, dcp.view(), kk[0], kk[1], kk[2], kk[3] if len(kk) > 3 else None, PRO_NORMBWD,
+                1, N * Co, H, W, g.Pc, _stream())
+    else:
+        hb.call("uncr_pad2d", du.contiguous(), c, dcp.view(), kk[0], kk[1], kk[2], kk[3] if len(kk) > 3 else None, PRO_NORMBWD, 1,
+                N * Co, H, W, _stream())
     dWt = []
     db = None
     for i, (ky, kx, off) in enumerate(_taps(W)):
@@ -1215,41 +1225,59 @@ def conv3x3_backward(du: Tensor, c: Tensor, kk, xp: _Padded, w: Tensor, need_dx:
         for i, (ky, kx, off) in enumerate(_taps(W)):
             pw_gemm(dcp.view(-off), pack_wt(wt[ky, kx], transpose=False), N, Co, Ci, xp.Sp, epi=0 if i == 0 else 4,
                     out=dxp.view().view(N, Ci, xp.Sp))
-        dx = _f32((N, Ci, H, W), dev)
-        hb.call("uncr_unpad2d_reflect_adjoint", dxp.view(), dx, N * Ci, H, W, _stream())
+        if g is not None:
+            dx = _f32((N, Ci, 1, g.Pc), dev)
+            hb.call("uncr_unpad2d_reflect_adjoint_strided", dxp.view(), dx, N * Ci, H, W, g.Pc, _stream())
+        else:
+            dx = _f32((N, Ci, H, W), dev)
+            hb.call("uncr_unpad2d_reflect_adjoint", dxp.view(), dx, N * Ci, H, W, _stream())
     return dx, dW, db
 
 
 def residual_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bool, buffers=None):
     """ResidualConvBlock.forward.  p: RES_KEYS; buffers: {rm1, rv1, ...} BatchNorm running statistics."""
     N, C, H, W = _check4(x)
-    P = H * W
+    P = H * W                 # pixels per stored plane (any-size: the padded count Pc; the finalisations divide by the true count)
+    geom = _GEOM if (_GEOM is not None and P == _GEOM.Pc) else None
+    if geom is not None:
+        if _dt(x) != F32:
+            raise NotImplementedError("any-size planes are built for fp32 storage")
+        H, W = geom.H, geom.W          # the 3x3 taps run on the true image; only the un-padded side has the dense planes' stride
     dev = x.device
-    sv = dict(x=x, xp=[], c=[], nf=[], dims=(N, C, H, W))
+    sv = dict(x=x, xp=[], c=[], nf=[], dims=(N, C, H, W), geom=geom)
     src, pro, k = x, PRO_NONE, (None, None)
     for i in (1, 2, 3):
-        xp = _Padded(N, C, H, W, dev)
-        hb.call("uncr_pad2d", src, None, xp.view(), k[0], k[1], None, None, pro, 0, N * C, H, W, _stream())
+        xp = _Padded(N, C, H, W, dev, geom)
+        if geom is not None:
+            hb.call("uncr_pad2d_strided", src, None, xp.view(), k[0], k[1], None, None, pro, 0, N * C, H, W, geom.Pc, _stream())
+        else:
+            hb.call("uncr_pad2d", src, None, xp.view(), k[0], k[1], None, None, pro, 0, N * C, H, W, _stream())
         c, part = conv3x3_forward(xp, p[f"w{i}"], p[f"b{i}"], spec.needs_stats(training))
         rm = buffers.get(f"rm{i}") if buffers else None
         rv = buffers.get(f"rv{i}") if buffers else None
         nf = norm_fwd(part, N, C, P, spec, training, p[f"g{i}"], p[f"be{i}"], rm, rv)
         sv["xp"].append(xp); sv["c"].append(c); sv["nf"].append(nf)
         src, pro, k = c, PRO_AFFINE_RELU, (nf.A, nf.B)
-    y = _f32((N, C, H, W), dev)
+    y = torch.empty_like(x)
     ew(EW_RESIDUAL_RELU, x, b=src, out=y, k=(k[0], k[1], None, None), planes=N * C, P=P)
+    if geom is not None:
+        fix_tail(y, None, 2, N * C)          # the tail holds relu(B): back to zero
     return y, sv
 
 
 def residual_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = True):
+    geom = sv.get("geom")
+    if geom is not None and _GEOM != geom:      # re-enter the forward's any-size geometry
+        with geom_scope(geom):
+            return residual_backward(dy, sv, p, need_dx)
     N, C, H, W = sv["dims"]
-    P = H * W
+    P = H * W if geom is None else geom.Pc
     dev = dy.device
     g: Dict[str, Tensor] = {}
     da = dy.contiguous()
     for i in (3, 2, 1):
         c, nf, xp = sv["c"][i - 1], sv["nf"][i - 1], sv["xp"][i - 1]
-        du = _f32((N, C, H, W), dev)
+        du = torch.empty_like(c)       # (a zero tail of `da` gives a zero tail here: the mask multiplies)
         _, part = ew(EW_RELU_BWD, da, b=c, out=du, k=(nf.A, nf.B, None, None), want_part=True, planes=N * C, P=P)
         nb = norm_bwd(part, N, C, P, nf, p[f"g{i}"])
         g[f"g{i}"], g[f"be{i}"] = nb.dgamma, nb.dbeta
@@ -1257,7 +1285,7 @@ def residual_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool 
                                                       need_dx or i > 1)
     dx = None
     if need_dx:
-        dx = _f32((N, C, H, W), dev)
+        dx = torch.empty_like(da)
         hb.call("uncr_add", dy.contiguous(), da, dx, dx.numel(), _stream())
     return dx, g
 

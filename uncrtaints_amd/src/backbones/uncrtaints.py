@@ -640,9 +640,8 @@ class UNCRTAINTS(nn.Module):
         # + a zero tail) inside a geometry scope; the output is cut back to [B, 1, C_out, H, W] at the end
         geom = E.plan_geom(h, w)
         if geom is not None:
-            if self.act_dtype == torch.bfloat16 or self.block_type != 'mbconv':
-                raise NotImplementedError(f"spatial size {h}x{w} (H*W not a multiple of 1024 or W not of 4) is built for fp32 storage, "
-                                          "block_type='mbconv'")
+            if self.act_dtype == torch.bfloat16:
+                raise NotImplementedError(f"spatial size {h}x{w} (H*W not a multiple of 1024 or W not of 4) is built for fp32 storage")
             x4 = _EmbedFn.apply(x4, geom)
         with E.geom_scope(geom):
             return self._forward_frames(x4, batch_positions, pad, b, t, h, w, geom)
