@@ -244,7 +244,7 @@ int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw,
  *      uncr_any_plane_stride(H, W) (0: the size needs none): flat kernels run over the whole stride, uncr_fix_* take the tail's share out
  *      of the reductions and re-zero it, the 2-D kernels below read and write valid pixels only (csrc/anysize.hip).  fp32 storage. ---- */
 int uncr_any_plane_stride(int H, int W);
-int uncr_any_slots(void);          /* statistics slots per plane of uncr_dw_fwd_any / uncr_dw_bwd_any */
+int uncr_dw_any_slots(int H, int W, int bwd); /* statistics slots (row bands) per plane of uncr_dw_fwd_any (bwd 0) / uncr_dw_bwd_any (1); -1: W too wide */
 int uncr_agg_any_slots(void);      /* ... of uncr_aggregate_any_fwd */
 int uncr_embed_tail(const float* src /* [planes][P] */, float* dst /* [planes][Pc] */, int planes, int P, int Pc, hipStream_t stream);
 int uncr_extract_tail(const float* src /* [planes][Pc] */, float* dst /* [planes][P] */, int planes, int P, int Pc, hipStream_t stream);
@@ -257,15 +257,14 @@ int uncr_fix_wgrad_tail(float* G /* [N][Cd][Cx] */, int N, int Cd, int Cx, const
                         const float* cB /* [N*Cx] */, int ntail, hipStream_t stream);
 int uncr_fix_rowsum_tail(float* rs /* [C] */, int N, int C, const float* c2, const float* c3, const float* mu /* [N*C], mu nullable */,
                          int ntail, hipStream_t stream);
-/* depthwise 3x3 reflect (uncrtaints.py:130-131) with the meaning of uncr_dw_fwd / uncr_dw_bwd on dense H x W planes of stride Pc;
- * part [N*C][uncr_any_slots()][2], dw_part [N*C][uncr_any_slots()][9] */
-int uncr_dw_fwd_any(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part,
-                    float* scratch /* [N*C][Pc] floats: gelu(A*in + B), written here */, int N, int C, int H, int W, int Pc,
-                    hipStream_t stream);
+/* depthwise 3x3 reflect (uncrtaints.py:130-131) with the meaning of uncr_dw_fwd / uncr_dw_bwd on dense H x W planes of stride Pc: row
+ * bands staged through LDS on the padded grid, any width up to 2558 (forward) / 1702 (backward), the zero tail of the result written too;
+ * part [N*C][uncr_dw_any_slots(H, W, bwd)][2], dw_part [N*C][uncr_dw_any_slots(H, W, 1)][9] */
+int uncr_dw_fwd_any(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part, int N, int C, int H,
+                    int W, int Pc, hipStream_t stream);
 int uncr_dw_bwd_any(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2, const float* k3,
                     const float* kmu, const float* cA1, const float* cB1, const float* w, float* du1, float* part, float* dw_part,
-                    const float* mean1, int mean_groups, float* scratch /* [N*C][Pc] floats */, int N, int C, int H, int W, int Pc,
-                    hipStream_t stream);
+                    const float* mean1, int mean_groups, int N, int C, int H, int W, int Pc, hipStream_t stream);
 /* adaptive max-pool (uncrtaints.py:403-404) on planes of stride pstride; idx = flat index inside the H x W image */
 int uncr_maxpool_fwd_strided(const float* in, float* out, int* idx, int planes, int H, int W, int pstride, int OH, int OW,
                              hipStream_t stream);

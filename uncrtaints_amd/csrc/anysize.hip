@@ -12,9 +12,7 @@
 // fp32 storage.  These are functional kernels for sizes outside the tuned tilings, not tuned ones; the tuned path is untouched.
 #include "common.h"
 
-#define ANY_NB 8      // blocks (= statistics slots) per plane of the scalar 2-D kernels
 
-extern "C" int uncr_any_slots(void) { return ANY_NB; }
 // plane stride of an H x W image: the next multiple of 1024 pixels (0: the tuned tilings take the size as it is)
 extern "C" int uncr_any_plane_stride(int H, int W) {
     const long long P = (long long)H * W;
@@ -129,159 +127,193 @@ extern "C" int uncr_fix_rowsum_tail(float* rs, int N, int C, const float* c2, co
     return UNCR_OK;
 }
 
-// ---- depthwise 3x3, reflect padding, any H x W (uncrtaints.py:130-131): h2 = dw(gelu(A*h1 + B)), (sum h2, sum h2^2) per block ----
-__device__ __forceinline__ int refl(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
-
-// g1 = gelu(A*h1 + B) over the whole stride (a flat float4 pass; the stencil then reads nine plain neighbours instead of evaluating nine
-// GELUs per output pixel: 474 -> ~100 us at 4 x 256 x 250 x 250)
-__global__ __launch_bounds__(256) void affine_gelu_any_kernel(const float* __restrict__ in, const float* __restrict__ cA,
-                                                              const float* __restrict__ cB, float* __restrict__ out, int Pc) {
-    const int plane = blockIdx.y;
-    const float A = cA[plane], B = cB[plane];
-    const size_t o = (size_t)plane * Pc + (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
-    const float4 v = *(const float4*)(in + o);
-    *(float4*)(out + o) = make_float4(gelu_f(fmaf(A, v.x, B)), gelu_f(fmaf(A, v.y, B)), gelu_f(fmaf(A, v.z, B)), gelu_f(fmaf(A, v.w, B)));
+// ---- depthwise 3x3, reflect padding, any H x W (uncrtaints.py:130-131) as ROW-BAND kernels: one 256-thread block owns TR consecutive
+// rows of one plane and stages them with their halo into an LDS tile ON THE PADDED GRID (the point-wise prologue applied on the way: one
+// GELU / one norm-backward per element, not nine), so the stencil loop reads LDS at constant offsets -- no reflection arithmetic, no
+// alignment assumptions, any width, no scratch tensor.  These kernels are VALU-bound, not latency-bound: what counts is instructions per
+// pixel (the first versions gathered nine reflected neighbours from global memory, then from LDS with a per-pixel border branch whose
+// 81 predicated reads every wave crossing a row end had to walk: 356 / 852 us, then 235 / 654 us at 4 x 256 x 250 x 250).
+#define DWB_LDS_FLOATS 10240
+// rows per band: the forward tile is (TR + 2) x (W + 2) (reflected halo), the backward tile (TR + 4) x (W + 4) (zero-extended, see below)
+static int dw_band_rows(int W, int bwd) {
+    if (W < 2) return 0;
+    const int tr = bwd ? DWB_LDS_FLOATS / (W + 4) - 4 : DWB_LDS_FLOATS / (W + 2) - 2;
+    return tr < 2 ? 0 : (tr > 32 ? 32 : tr);
 }
+// statistics slots (= row bands) per plane of uncr_dw_fwd_any (bwd = 0) / uncr_dw_bwd_any (bwd = 1); -1: width not supported
+extern "C" int uncr_dw_any_slots(int H, int W, int bwd) {
+    const int tr = dw_band_rows(W, bwd);
+    return (tr && H >= 2) ? (H + tr - 1) / tr : -1;
+}
+__device__ __forceinline__ int refl(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+// row of the flat index i in a grid of width 1 / inv: (int)((i + 0.5) * inv) is exact for i < 2^14 -- the quotient is at least
+// 0.5 / width from an integer and the fp32 rounding error of the product is below 2^14 * 2^-23
+__device__ __forceinline__ int row_of(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
 
-__global__ __launch_bounds__(256) void dw_fwd_any_kernel(const float* __restrict__ g1, const float* __restrict__ w,
-                                                         float* __restrict__ out, float2* __restrict__ part, int C, int H, int W, int Pc) {
+// forward: h2 = dw(gelu(A*h1 + B)), (sum h2, sum h2^2) per band; the last band also writes the plane's zero tail.
+// tile (r, c) = gelu(u1) at image (refl(y0 - 1 + r), refl(c - 1)), pitch W + 2
+__global__ __launch_bounds__(256) void dw_fwd_band_kernel(const float* __restrict__ in, const float* __restrict__ cA,
+                                                          const float* __restrict__ cB, const float* __restrict__ w,
+                                                          float* __restrict__ out, float2* __restrict__ part, int C, int H, int W, int Pc,
+                                                          int TR, float invW) {
+    extern __shared__ __attribute__((aligned(16))) float t[];
     const int plane = blockIdx.y, c = plane % C;
+    const int y0 = blockIdx.x * TR, rows = min(TR, H - y0), nrow = rows + 2, pitch = W + 2;
+    const float A = cA[plane], B = cB[plane];
+    const float* src = in + (size_t)plane * Pc;
+    const int n = nrow * W;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = row_of(i, invW), x = i - r * W;
+        t[r * pitch + 1 + x] = gelu_f(fmaf(A, src[refl(y0 - 1 + r, H) * W + x], B));
+    }
+    for (int i = threadIdx.x; i < 2 * nrow; i += 256) {                 // the two halo columns: column -1 = column 1, column W = W - 2
+        const int r = i >> 1, side = i & 1;
+        t[r * pitch + (side ? W + 1 : 0)] = gelu_f(fmaf(A, src[refl(y0 - 1 + r, H) * W + (side ? W - 2 : 1)], B));
+    }
     float wk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
-    const float* ip = g1 + (size_t)plane * Pc;
-    float* op = out + (size_t)plane * Pc;
+    __syncthreads();
+    float* dst = out + (size_t)plane * Pc + (size_t)y0 * W;
+    const int m = rows * W;
     float s0 = 0.f, s1 = 0.f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += ANY_NB * 256) {
-        const int y = i / W, x = i - y * W;
-        const int ym = refl(y - 1, H) * W, y0 = y * W, yp = refl(y + 1, H) * W, xm = refl(x - 1, W), xp = refl(x + 1, W);
-        float acc = wk[0] * ip[ym + xm];
-        acc = fmaf(wk[1], ip[ym + x], acc); acc = fmaf(wk[2], ip[ym + xp], acc);
-        acc = fmaf(wk[3], ip[y0 + xm], acc); acc = fmaf(wk[4], ip[y0 + x], acc); acc = fmaf(wk[5], ip[y0 + xp], acc);
-        acc = fmaf(wk[6], ip[yp + xm], acc); acc = fmaf(wk[7], ip[yp + x], acc); acc = fmaf(wk[8], ip[yp + xp], acc);
-        op[i] = acc;
+#pragma unroll 2
+    for (int j = threadIdx.x; j < m; j += 256) {
+        const int r = row_of(j, invW);
+        const float* tc = t + r * pitch + (j - r * W);                  // tile (r, x): the stencil's top-left corner
+        float acc = wk[0] * tc[0];
+        acc = fmaf(wk[1], tc[1], acc); acc = fmaf(wk[2], tc[2], acc);
+        acc = fmaf(wk[3], tc[pitch], acc); acc = fmaf(wk[4], tc[pitch + 1], acc); acc = fmaf(wk[5], tc[pitch + 2], acc);
+        acc = fmaf(wk[6], tc[2 * pitch], acc); acc = fmaf(wk[7], tc[2 * pitch + 1], acc); acc = fmaf(wk[8], tc[2 * pitch + 2], acc);
+        dst[j] = acc;
         s0 += acc;
         s1 = fmaf(acc, acc, s1);
     }
+    if (blockIdx.x == gridDim.x - 1)
+        for (int i = H * W + threadIdx.x; i < Pc; i += 256) out[(size_t)plane * Pc + i] = 0.f;
     if (part) {
         __shared__ float red[8];
         block_sum2<256>(s0, s1, red);
-        if (threadIdx.x == 0) part[(size_t)plane * ANY_NB + blockIdx.x] = make_float2(s0, s1);
+        if (threadIdx.x == 0) part[(size_t)plane * gridDim.x + blockIdx.x] = make_float2(s0, s1);
     }
 }
-extern "C" int uncr_dw_fwd_any(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part,
-                               float* scratch /* [N*C][Pc]: gelu(A*in + B) */, int N, int C, int H, int W, int Pc, hipStream_t stream) {
-    if (N <= 0 || C <= 0 || H < 2 || W < 2 || Pc < H * W || Pc % 1024) return UNCR_ESHAPE;
-    if (!in || !cA || !cB || !w || !out || !scratch) return UNCR_EINVAL;
-    hipLaunchKernelGGL(affine_gelu_any_kernel, dim3(Pc / 1024, N * C), dim3(256), 0, stream, in, cA, cB, scratch, Pc);
-    UNCR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dw_fwd_any_kernel, dim3(ANY_NB, N * C), dim3(256), 0, stream, scratch, w, out, (float2*)part, C, H, W, Pc);
+extern "C" int uncr_dw_fwd_any(const float* in, const float* cA, const float* cB, const float* w, float* out,
+                               float* part /* [N*C][uncr_dw_any_slots(H, W, 0)][2] or null */, int N, int C, int H, int W, int Pc,
+                               hipStream_t stream) {
+    const int tr = dw_band_rows(W, 0);
+    if (N <= 0 || C <= 0 || H < 2 || !tr || Pc < H * W || Pc % 1024) return UNCR_ESHAPE;
+    if (!in || !cA || !cB || !w || !out) return UNCR_EINVAL;
+    hipLaunchKernelGGL(dw_fwd_band_kernel, dim3((H + tr - 1) / tr, N * C), dim3(256), (size_t)(tr + 2) * (W + 2) * sizeof(float), stream,
+                       in, cA, cB, w, out, (float2*)part, C, H, W, Pc, tr, 1.0f / (float)W);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
 
-// backward: dh2 = k1*du2 + k2*(h2 - kmu) + k3 (norm-2 backward), then per INPUT pixel q and tap k the gathered sum
-//   t_k[q] = sum of dh2 over the outputs that read q through tap k (one output in the interior; up to four next to a reflecting border),
-// from which both results follow with ONE erf per pixel:  dg1[q] = sum_k w_k t_k[q],  du1 = gelu'(u1) * dg1,  and the depthwise weight
-// gradient  dW_k = sum_q gelu(u1)[q] * t_k[q];  statistics (sum du1, sum du1*(h1 - mean1)).
-// The outputs y' with refl(y' + d) == y for a row offset d = ky - 1:  y' = y - d;  y' = -y - d (reflection at row 0);
-// y' = 2H - 2 - y - d (reflection at row H-1) -- each only if it lies in [0, H) and really maps to y.
-__device__ __forceinline__ int refl_sources(int y, int d, int n, int (&src)[3]) {
-    int cnt = 0;
-    const int a = y - d, b = -y - d, c = 2 * n - 2 - y - d;
-    if (a >= 0 && a < n) src[cnt++] = a;
-    if (b >= 0 && b < n && b != a && refl(b + d, n) == y) src[cnt++] = b;
-    if (c >= 0 && c < n && c != a && c != b && refl(c + d, n) == y) src[cnt++] = c;
-    return cnt;
-}
-// dh2 = k1*du2 + k2*(h2 - kmu) + k3 over the whole stride (flat float4 pass; the gather below then reads one value per source)
-__global__ __launch_bounds__(256) void normbwd_any_kernel(const float* __restrict__ du2, const float* __restrict__ h2,
-                                                          const float* __restrict__ k1, const float* __restrict__ k2,
-                                                          const float* __restrict__ k3, const float* __restrict__ kmu,
-                                                          float* __restrict__ out, int Pc) {
-    const int plane = blockIdx.y;
-    const float K1 = k1[plane], K2 = k2[plane], K3 = k3[plane], KM = kmu ? kmu[plane] : 0.f;
-    const size_t o = (size_t)plane * Pc + (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
-    const float4 a = *(const float4*)(du2 + o), b = *(const float4*)(h2 + o);
-    *(float4*)(out + o) = make_float4(fmaf(K1, a.x, fmaf(K2, b.x - KM, K3)), fmaf(K1, a.y, fmaf(K2, b.y - KM, K3)),
-                                      fmaf(K1, a.z, fmaf(K2, b.z - KM, K3)), fmaf(K1, a.w, fmaf(K2, b.w - KM, K3)));
-}
-__global__ __launch_bounds__(256) void dw_bwd_any_kernel(const float* __restrict__ dh2, const float* __restrict__ h1,
-                                                         const float* __restrict__ cA1, const float* __restrict__ cB1,
-                                                         const float* __restrict__ w, float* __restrict__ du1, float2* __restrict__ part,
-                                                         float* __restrict__ dw_part, const float* __restrict__ mean1, int mean_groups,
-                                                         int C, int H, int W, int Pc) {
+// backward: with gp = the reflect-padded gelu(u1) on [-1, H] x [-1, W], the forward is a plain correlation  h2[q] = sum_k w_k gp[q + k - 1],
+// so the gradient on the padded grid is  dgp[p~] = sum_k w_k t_k[p~],  t_k[p~] = dh2z[p~ - k + 1]  (dh2z = the norm-2 backward
+// dh2 = k1*du2 + k2*(h2 - kmu) + k3 inside the image, ZERO outside), and the reflection folds the ring back:
+//   dg1[p] = sum of dgp over the padded positions that mirror onto p = {y, and -1 if y == 1, and H if y == H-2} x {x, -1 if x == 1, W if x == W-2}
+// -- one position in the interior, two along rows / columns 1 and H-2 / W-2, four at their crossings.  The same t_k give the depthwise
+// weight gradient  dW_k = sum_p gelu(u1)[p] * (sum over p's padded positions of t_k)  with ONE erf per pixel;  du1 = gelu'(u1) * dg1,
+// statistics (sum du1, sum du1*(h1 - mean1)).  tile (r, c) = dh2z at image (y0 - 2 + r, c - 2), pitch W + 4: every read of the loop is in
+// range without a test.
+__global__ __launch_bounds__(256) void dw_bwd_band_kernel(const float* __restrict__ du2, const float* __restrict__ h2,
+                                                          const float* __restrict__ h1, const float* __restrict__ k1,
+                                                          const float* __restrict__ k2, const float* __restrict__ k3,
+                                                          const float* __restrict__ kmu, const float* __restrict__ cA1,
+                                                          const float* __restrict__ cB1, const float* __restrict__ w,
+                                                          float* __restrict__ du1, float2* __restrict__ part, float* __restrict__ dw_part,
+                                                          const float* __restrict__ mean1, int mean_groups, int C, int H, int W, int Pc,
+                                                          int TR, float invW, float invP) {
+    extern __shared__ __attribute__((aligned(16))) float t[];
     const int plane = blockIdx.y, c = plane % C, n = plane / C;
+    const int y0 = blockIdx.x * TR, rows = min(TR, H - y0), nrow = rows + 4, pitch = W + 4;
+    const size_t base = (size_t)plane * Pc;
+    {
+        const float K1 = k1[plane], K2 = k2[plane], K3 = k3[plane], KM = kmu ? kmu[plane] : 0.f;
+        const float* pa = du2 + base;
+        const float* pb = h2 + base;
+        const int cnt = nrow * pitch;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            const int r = row_of(i, invP), yy = y0 - 2 + r, xx = i - r * pitch - 2;
+            const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int o = min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);          // (unconditional loads)
+            const float v = fmaf(K1, pa[o], fmaf(K2, pb[o] - KM, K3));
+            t[i] = inside ? v : 0.f;
+        }
+    }
     const float A1 = cA1[plane], B1 = cB1[plane];
     const float m1 = mean1 ? (mean_groups > 0 ? mean1[n * mean_groups + c / (C / mean_groups)] : mean1[c]) : 0.f;
-    float wk[9];
+    float wk[9], gw[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
-    const size_t base = (size_t)plane * Pc;
-    const float* dp = dh2 + base;
-    float s0 = 0.f, s1 = 0.f, gw[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) gw[k] = 0.f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += ANY_NB * 256) {
-        const int y = i / W, x = i - y * W;
-        const float hv = h1[base + i];
+    for (int k = 0; k < 9; ++k) { wk[k] = w[c * 9 + k]; gw[k] = 0.f; }
+    __syncthreads();
+    const float* hp = h1 + base + (size_t)y0 * W;
+    float* dst = du1 + base + (size_t)y0 * W;
+    const int m = rows * W;
+    float s0 = 0.f, s1 = 0.f;
+    for (int j = threadIdx.x; j < m; j += 256) {
+        const int r = row_of(j, invW), x = j - r * W, y = y0 + r;
+        const float hv = hp[j];
         const float u = fmaf(A1, hv, B1);
         const float gq = gelu_f(u);
+        // the padded positions that mirror onto (y, x): rows {y, e1y, e2y}[0 .. ny), columns likewise
+        const int ny = 1 + (y == 1) + (y == H - 2), nx = 1 + (x == 1) + (x == W - 2);
+        const int e1y = (y == 1) ? -1 : H, e1x = (x == 1) ? -1 : W;
+        float tk[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tk[k] = 0.f;
+        for (int a = 0; a < ny; ++a) {
+            const int ry = (a == 0 ? y : (a == 1 ? e1y : H)) - (y0 - 2);
+            for (int b = 0; b < nx; ++b) {
+                const int cx = (b == 0 ? x : (b == 1 ? e1x : W)) + 2;
+                const float* tc = t + ry * pitch + cx;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) tk[ky * 3 + kx] += tc[(1 - ky) * pitch + (1 - kx)];
+            }
+        }
         float dg = 0.f;
-        if (y >= 2 && y < H - 2 && x >= 2 && x < W - 2) {
-            // interior: tap (ky, kx) of exactly one output, (y - ky + 1, x - kx + 1), reads this pixel
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float t = dp[(y - ky + 1) * W + (x - kx + 1)];
-                    dg = fmaf(wk[ky * 3 + kx], t, dg);
-                    gw[ky * 3 + kx] = fmaf(gq, t, gw[ky * 3 + kx]);
-                }
-        } else {
-            int ys[3][3], xs[3][3], ny[3], nx[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { ny[k] = refl_sources(y, k - 1, H, ys[k]); nx[k] = refl_sources(x, k - 1, W, xs[k]); }
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    float t = 0.f;
-                    for (int a = 0; a < ny[ky]; ++a)
-                        for (int b = 0; b < nx[kx]; ++b) t += dp[ys[ky][a] * W + xs[kx][b]];
-                    dg = fmaf(wk[ky * 3 + kx], t, dg);
-                    gw[ky * 3 + kx] = fmaf(gq, t, gw[ky * 3 + kx]);
-                }
+        for (int k = 0; k < 9; ++k) {
+            dg = fmaf(wk[k], tk[k], dg);
+            gw[k] = fmaf(gq, tk[k], gw[k]);
         }
         const float v = gelu_grad_f(u) * dg;
-        du1[base + i] = v;
+        dst[j] = v;
         s0 += v;
         s1 = fmaf(v, hv - m1, s1);
     }
+    if (blockIdx.x == gridDim.x - 1)
+        for (int i = H * W + threadIdx.x; i < Pc; i += 256) du1[base + i] = 0.f;
     __shared__ float red[8];
+    const size_t slot = (size_t)plane * gridDim.x + blockIdx.x;
     block_sum2<256>(s0, s1, red);
-    if (threadIdx.x == 0) part[(size_t)plane * ANY_NB + blockIdx.x] = make_float2(s0, s1);
+    if (threadIdx.x == 0) part[slot] = make_float2(s0, s1);
 #pragma unroll
     for (int k = 0; k < 9; k += 2) {
         __syncthreads();
         float a = gw[k], b = k + 1 < 9 ? gw[k + 1] : 0.f;
         block_sum2<256>(a, b, red);
         if (threadIdx.x == 0) {
-            dw_part[((size_t)plane * ANY_NB + blockIdx.x) * 9 + k] = a;
-            if (k + 1 < 9) dw_part[((size_t)plane * ANY_NB + blockIdx.x) * 9 + k + 1] = b;
+            dw_part[slot * 9 + k] = a;
+            if (k + 1 < 9) dw_part[slot * 9 + k + 1] = b;
         }
     }
 }
 extern "C" int uncr_dw_bwd_any(const float* du2, const float* h2, const float* h1, const float* k1, const float* k2, const float* k3,
-                               const float* kmu, const float* cA1, const float* cB1, const float* w, float* du1, float* part,
-                               float* dw_part, const float* mean1, int mean_groups, float* scratch /* [N*C][Pc]: the norm-2 backward dh2 */,
-                               int N, int C, int H, int W, int Pc, hipStream_t stream) {
-    if (N <= 0 || C <= 0 || H < 2 || W < 2 || Pc < H * W || Pc % 1024 || (mean1 && mean_groups > 0 && C % mean_groups)) return UNCR_ESHAPE;
-    if (!du2 || !h2 || !h1 || !k1 || !k2 || !k3 || !cA1 || !cB1 || !w || !du1 || !part || !dw_part || !scratch) return UNCR_EINVAL;
-    hipLaunchKernelGGL(normbwd_any_kernel, dim3(Pc / 1024, N * C), dim3(256), 0, stream, du2, h2, k1, k2, k3, kmu, scratch, Pc);
-    UNCR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dw_bwd_any_kernel, dim3(ANY_NB, N * C), dim3(256), 0, stream, scratch, h1, cA1, cB1, w, du1, (float2*)part, dw_part,
-                       mean1, mean_groups, C, H, W, Pc);
+                               const float* kmu, const float* cA1, const float* cB1, const float* w, float* du1,
+                               float* part /* [N*C][slots][2] */, float* dw_part /* [N*C][slots][9], slots = uncr_dw_any_slots(H, W, 1) */,
+                               const float* mean1, int mean_groups, int N, int C, int H, int W, int Pc, hipStream_t stream) {
+    const int tr = dw_band_rows(W, 1);
+    if (N <= 0 || C <= 0 || H < 2 || !tr || Pc < H * W || Pc % 1024 || (mean1 && mean_groups > 0 && C % mean_groups)) return UNCR_ESHAPE;
+    if (!du2 || !h2 || !h1 || !k1 || !k2 || !k3 || !cA1 || !cB1 || !w || !du1 || !part || !dw_part) return UNCR_EINVAL;
+    hipLaunchKernelGGL(dw_bwd_band_kernel, dim3((H + tr - 1) / tr, N * C), dim3(256), (size_t)(tr + 4) * (W + 4) * sizeof(float), stream,
+                       du2, h2, h1, k1, k2, k3, kmu, cA1, cB1, w, du1, (float2*)part, dw_part, mean1, mean_groups, C, H, W, Pc, tr,
+                       1.0f / (float)W, 1.0f / (float)(W + 4));
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -170,6 +170,13 @@ def current_geom() -> Optional[Geom]:
     return _GEOM
 
 
+def _dw_any_slots(geom, bwd: bool) -> int:
+    slots = hb.query("uncr_dw_any_slots", geom.H, geom.W, 1 if bwd else 0)
+    if slots <= 0:
+        raise NotImplementedError(f"depthwise 3x3 on any-size planes: width {geom.W} is beyond the row-band kernels' 2558 (forward) / 1702 (backward)")
+    return slots
+
+
 def _pcount(P: int) -> int:
     """pixels of a plane that carry data: the image's H*W for a padded plane of the active geometry, else P itself"""
     return _GEOM.P if (_GEOM is not None and P == _GEOM.Pc) else P
@@ -767,12 +774,11 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
                   defer=_DW_VARIANT == 0 and hb.query("uncr_dw_fwd_bn_supported", H, W) == 1)
 
     h2 = _act((N, Ch, H, W), x.device, dt)
-    slots = hb.query("uncr_dw_slots_fwd", H) if geom is None else hb.query("uncr_any_slots")
+    slots = hb.query("uncr_dw_slots_fwd", H) if geom is None else _dw_any_slots(geom, False)
     part2 = Part(_f32((N * Ch, slots, 2), x.device), slots) if (need or h2ok) else None
     if geom is not None:
         hb.call("uncr_dw_fwd_any", h1, n1.A, n1.B, p["wdw"].reshape(Ch, 9).contiguous(), h2, part2.buf if part2 is not None else None,
-                _f32((N, Ch, geom.Pc), x.device), N, Ch, geom.H, geom.W, geom.Pc, _stream())
-        fix_tail(h2, None, 2, N * Ch)          # (the kernel writes valid pixels only)
+                N, Ch, geom.H, geom.W, geom.Pc, _stream())          # (writes the zero tail too)
     elif n1.fin is not None:      # train-mode BatchNorm 1 finalised by the depthwise kernel's waves themselves
         hb.call("uncr_dw_fwd_bn", h1, *n1.fin, n1.A, n1.B, n1.mean, n1.rstd, n1.ub, n1.hb, p["wdw"].reshape(Ch, 9).contiguous(),
                 h2, part2.buf if part2 is not None else None, N, Ch, H, W, dt, _stream())
@@ -1059,7 +1065,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
 
     # depthwise backward
     du1 = _act((N, Ch, H, W), dev, dt)
-    slots = hb.query("uncr_dw_slots_bwd", H) if geom is None else hb.query("uncr_any_slots")
+    slots = hb.query("uncr_dw_slots_bwd", H) if geom is None else _dw_any_slots(geom, True)
     part1 = Part(_f32((N * Ch, slots, 2), dev), slots)
     dw_part = _f32((N * Ch, slots, 9), dev)
     wdw = p["wdw"].reshape(Ch, 9).contiguous()
@@ -1070,8 +1076,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     du1_amax = None
     if geom is not None:
         hb.call("uncr_dw_bwd_any", du2, h2, h1, b2.c1, b2.c2, b2.c3, b2.mu, n1.A, n1.B, wdw, du1, part1.buf, dw_part, n1.mean,
-                n1.groups if n1.kind == NORM_GROUP else 0, _f32((N, Ch, geom.Pc), dev), N, Ch, geom.H, geom.W, geom.Pc, _stream())
-        fix_tail(du1, None, 2, N * Ch)
+                n1.groups if n1.kind == NORM_GROUP else 0, N, Ch, geom.H, geom.W, geom.Pc, _stream())
     else:
         if _H2_BWD and _H2_DX and n1.hb is not None and hb.query("uncr_dw_bwd_emits_amax", H, W, dt, _DW_VARIANT) == 1:
             du1_amax = _f32((N, Ch * slots), dev)
