@@ -300,10 +300,14 @@ def ltae_tiny_attention(down: Tensor, dates: Tensor, pad_mask: Tensor, p: Dict[s
 
 def ltae2d_values_attention(down: Tensor, dates: Tensor, pad_mask: Tensor, p: Dict[str, Tensor], cfg: OracleConfig,
                             training: bool, update_running: bool = True,
-                            v_dropout_mask: Optional[Tensor] = None):
+                            v_dropout_mask: Optional[Tensor] = None, relu_mask: Optional[Tensor] = None,
+                            taps: Optional[Dict[str, Tensor]] = None):
     """LTAE2d.forward + MultiHeadAttention + ScaledDotProductAttention (ltae.py:99-141, 266-307, 399-416), as built
     by UNCRTAINTS(use_v=True) (uncrtaints.py:324-336: mlp=[d_model, C], use_dropout=False, return_att=True).
-    down [B,T,C,h,w] -> (values [B,C,h,w], attention [n_head,B,T,h,w])."""
+    down [B,T,C,h,w] -> (values [B,C,h,w], attention [n_head,B,T,h,w]).
+    relu_mask (test infrastructure, like `pool_idx` of forward): 0/1 tensor [B*h*w, C] -- the branch of the value MLP's ReLU to
+    differentiate.  The GroupNorm behind it normalises C/n_head = 8 values per pixel; where a group is dead (all eight negative) its
+    rstd is 1/sqrt(eps) = 316, so ONE pre-activation within rounding of zero in such a group moves the gradients by ~316 / (n*C)."""
     B, T, C, h, w = down.shape
     nh, dk, n = cfg.n_head, cfg.d_k, B * h * w
     pre = "temporal_encoder."
@@ -320,12 +324,16 @@ def ltae2d_values_attention(down: Tensor, dates: Tensor, pad_mask: Tensor, p: Di
     dv = cfg.d_model // nh
     vh = y.view(n, T, nh, dv)                                                         # head h = channels h*dv..(h+1)*dv
     out = torch.einsum("hnt,nthd->nhd", attn, vh).reshape(n, cfg.d_model)             # heads concatenated
+    vh_cat = out
     out = out @ p[pre + "mlp.0.weight"].t() + p[pre + "mlp.0.bias"]                   # Linear(d_model -> C)
+    m1 = out
     # BatchNorm1d over the n = B*h*w samples == BatchNorm2d on [n, C, 1, 1]
     out = batch_norm(out.view(n, C, 1, 1), p[pre + "mlp.1.weight"], p[pre + "mlp.1.bias"],
                      p.get(pre + "mlp.1.running_mean"), p.get(pre + "mlp.1.running_var"), training,
                      update_running=update_running).view(n, C)
-    out = torch.relu(out)
+    out = torch.relu(out) if relu_mask is None else out * relu_mask.to(out.dtype)
+    if taps is not None:        # (debugging: intermediate tensors of the value branch, tools/debug_spike.py)
+        taps.update(val_y=y, val_vh=vh_cat, val_m1=m1, val_r=out)
     if training:
         if v_dropout_mask is not None:
             out = out * v_dropout_mask
@@ -374,7 +382,7 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
             taps: Optional[dict] = None, pool_idx: Optional[Tensor] = None,
             relu_masks: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """UNCRTAINTS.forward (uncrtaints.py:391-447).  x [B,T,Cin,H,W], dates [B,T] -> [B,1,13+covar,H,W].
-    relu_masks (test infrastructure): see residual_block.
+    relu_masks (test infrastructure): see residual_block; key "temporal_encoder.mlp": see ltae2d_values_attention.
     pool_idx (test infrastructure, not a reference argument): flat in-plane arg-max indices [B*T, C, 32, 32] that the max-pool
     is to take instead of its own.  The max-pool is a kink of the function: where the two largest values of a window differ by
     less than the forward error, two correct fp32 evaluations may select different elements and route the pooled gradient to
@@ -400,6 +408,7 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
     for i in range(len(cfg.encoder_widths)):                              # one block per entry, uncrtaints.py:316-319, 399-400
         e = _block(e, p, f"in_block.{i}", cfg.encoder_norm, training, update_running, taps, cfg, relu_masks)
     C = e.shape[1]
+    vals = None
     if cfg.is_mono:
         g, down, attn = e.view(B, T, C, H, W).squeeze(dim=1), None, None
     else:
@@ -408,9 +417,9 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
             down = down.view(B, T, C, cfg.att_down, cfg.att_down)
         else:
             down = F.adaptive_max_pool2d(e, (cfg.att_down, cfg.att_down)).view(B, T, C, cfg.att_down, cfg.att_down)
-        vals = None
         if cfg.use_v:
-            vals, attn = ltae2d_values_attention(down, dates, pad_mask, p, cfg, training, update_running)
+            vals, attn = ltae2d_values_attention(down, dates, pad_mask, p, cfg, training, update_running,
+                                                 relu_mask=relu_masks.get("temporal_encoder.mlp") if relu_masks else None, taps=taps)
         else:
             attn = ltae_tiny_attention(down, dates, pad_mask, p, cfg)
         g = _store(temporal_aggregate(e.view(B, T, C, H, W), pad_mask, attn, cfg, training, dropout_mask), bf)
@@ -419,6 +428,8 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
             g = conv1x1(torch.cat((g, up_v), dim=1), p["include_v.weight"], p["include_v.bias"])
     if taps is not None:
         taps.update(c0=c0, a0=a0, e=e, down=down, attn=attn, agg=g)
+        if vals is not None:
+            taps["vals"] = vals
     out = g
     for i in range(len(cfg.decoder_widths)):
         out = _block(out, p, f"out_block.{i}", cfg.decoder_norm, training, update_running, taps, cfg, relu_masks)

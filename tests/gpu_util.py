@@ -151,9 +151,9 @@ def close_grad(name, got, ref32, truth64, tol=TOL, noise=NOISE, draws=None, key=
     return e_ref, e_got, e_cpu
 
 
-def oracle_run(state, x, y, dates, cfg, dtype, training=True, pool_idx=None):
+def oracle_run(state, x, y, dates, cfg, dtype, training=True, pool_idx=None, relu_masks=None):
     """CPU oracle forward + MGNLL + backward in `dtype`; returns (out, loss, dx, {param grads}).
-    pool_idx: differentiate the max-pool branch these arg-max indices select (see oracle.forward)."""
+    pool_idx: differentiate the max-pool branch these arg-max indices select (see oracle.forward); relu_masks: likewise for ReLUs."""
     from oracle import uncrtaints_oracle as orc
     pt = {}
     for k, v in state.items():
@@ -163,7 +163,7 @@ def oracle_run(state, x, y, dates, cfg, dtype, training=True, pool_idx=None):
         else:
             pt[k] = v.clone()
     xg = x.to(dtype).clone().requires_grad_(True)
-    out = orc.forward(pt, xg, dates.to(dtype), cfg, training=training, pool_idx=pool_idx)
+    out = orc.forward(pt, xg, dates.to(dtype), cfg, training=training, pool_idx=pool_idx, relu_masks=relu_masks)
     loss = orc.loss_from_output(out, y.to(dtype), cfg)
     loss.backward()
     grads = {k: v.grad for k, v in pt.items() if isinstance(v, torch.Tensor) and v.requires_grad}
@@ -176,3 +176,20 @@ def is_zero_grad(name, grads64):
         return False
     sib = name.replace(".bias", ".weight")
     return sib in grads64 and grads64[name].abs().max() < 1e-6 * grads64[sib].abs().max()
+
+
+def value_relu_mask(model):
+    """{"temporal_encoder.mlp": 0/1 [B*S, C]}: the branch the value MLP's ReLU of a use_v model took in its last train-mode forward
+    (LTAE2d.keep_relu_branch must have been set before it).  Why this kink is pinned while the in_conv ReLUs are not: the GroupNorm
+    behind this ReLU normalises 8 values per pixel, and a dead group has rstd = 1 / sqrt(eps) = 316 -- one pre-activation within
+    rounding of zero there moves the encoder-side gradients by ~316 / (B*S*C), e.g. 3e-3 at B*S = 1024 (tools/debug_spike.py)."""
+    m1, A, B = model.temporal_encoder._last_relu
+    b, c, s = m1.shape
+    return {"temporal_encoder.mlp": relu_branch(m1, A.view(b, c, 1), B.view(b, c, 1)).permute(0, 2, 1).reshape(b * s, c).cpu()}
+
+
+def relu_branch(c, A, B):
+    """[A*c + B > 0] as the kernels decide it: they evaluate fmaf(A, c, B) -- ONE rounding -- so the sign is that of the exact value.
+    fp64 gives it (the product of two fp32 numbers is exact there and rounding a non-zero sum cannot cross zero); `A * c + B` in fp32
+    rounds the product first and flips elements with |u| ~ 1e-7 (one such element of 131072 moved a use_v gradient by 3.8e-3)."""
+    return ((A.double() * c.double() + B.double()) > 0).float()

@@ -191,13 +191,14 @@ def test_model_variants_at_odd_sizes(name, kw, shape):
     from uncrtaints_amd.src import losses
     B, T, H, W = shape
     cfg = orc.OracleConfig(attn_dropout=0.0, ltae_dropout=0.0, **kw)
-    # Input / initialisation seeds: 7 / 6, except where a padded date meets batch statistics that couple the frames (BatchNorm encoder,
-    # the value MLP of use_v): gradient then flows into the constant padded frame, and on about one input in seven the HIP path lands
-    # 20-30x further from fp64 than the CPU paths on the encoder-side gradients (seed 0 of both cases: 1.8e-4 / 3.8e-3), while on the
-    # neighbouring seeds HIP and CPU agree within 2x on every gradient; any change of rounding (libm erf / exp, another summation order in
-    # the depthwise statistics) moves the outlier to another input.  tools/odd_size_noise.py reproduces the table; NOTES_next_round.md
-    # has what is known.  This test is about the odd-size plumbing of each variant, so it runs on a neighbouring seed there.
-    s = {"batch_norm_encoder_two_blocks": 1, "use_v": 3}.get(name, 0)
+    # Input / initialisation seeds: 7 / 6, except for the batch-norm encoder.  There seed 7 is an input on which ONE cancelling
+    # gradient (out_block.4 BatchNorm-1 gamma) lands 4.3x further from fp64 on the HIP path (1.8e-4) than on the CPU paths, while on
+    # the seven neighbouring seeds HIP and CPU agree within 1.5x on every gradient, and any change of rounding (libm erf / exp,
+    # another summation order in the depthwise statistics) moves the outlier elsewhere (tools/odd_size_noise.py --affines).  The
+    # distribution over inputs is what tests/test_parity_rule.py holds the path to; this test is about the odd-size plumbing.
+    # (The use_v cases had a 3.8e-3 outlier on seed 7 that WAS a kink: one value-MLP ReLU with |u| = 9e-8 decided differently by
+    # `A*c + B` in fp32 and by the kernels' fmaf -- gpu_util.relu_branch now decides like the kernels, tools/debug_spike.py.)
+    s = {"batch_norm_encoder_two_blocks": 1}.get(name, 0)
     x, y, dates = orc.synthetic_batch(B, T, H, W, seed=7 + s)
     if T > 1:
         x[B - 1, T - 1] = 0.0
@@ -223,16 +224,22 @@ def test_model_variants_at_odd_sizes(name, kw, shape):
     assert tuple(oe.shape) == tuple(ref_e.shape)
     close(f"odd[{name}]/eval", oe, ref_e)
     m.train()
+    if kw.get("use_v"):
+        m.temporal_encoder.keep_relu_branch = True
     out = m(dev(x), batch_positions=dev(dates))
     cov = kw.get("covmode", "diag")
     l, _ = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode=cov)(out[:, :, :13], dev(y), out[:, :, 13:m.vars_idx])
     l.backward()
     pidx, _ = pool_branch(m, state, x, dates, cfg) if name != "is_mono" else (None, 0)
-    out_o, loss_o, _, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx)
-    _, _, _, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64, pool_idx=pidx)
+    vmask = None
+    if kw.get("use_v"):       # the value MLP's ReLU sits ahead of a GroupNorm over 8 values: a kink worth pinning (gpu_util.value_relu_mask)
+        from gpu_util import value_relu_mask
+        vmask = value_relu_mask(m)
+    out_o, loss_o, _, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx, relu_masks=vmask)
+    _, _, _, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64, pool_idx=pidx, relu_masks=vmask)
     close(f"odd[{name}]/train", out, out_o)
     assert abs(l.item() - loss_o.item()) < 1e-4 * abs(loss_o.item())
-    draws = Fp32Draws(lambda: oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx)[3])
+    draws = Fp32Draws(lambda: oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx, relu_masks=vmask)[3])
     for k, v in m.named_parameters():
         if name == "mean" and k.startswith("temporal_encoder"):
             assert v.grad is None or float(v.grad.abs().max()) == 0.0      # the attention never reaches the output in this mode
@@ -247,7 +254,7 @@ def test_residual_blocks_at_an_odd_size():
     """block_type='residual' (dense 3x3 convolutions as nine shifted GEMMs on reflect-padded planes, csrc/conv3.hip) on an image outside
     the tuned tilings: only the padding / un-padding glue sees the dense planes' stride.  Gradients on the ReLU masks and the arg-max
     branch the HIP forward took, as in test_variants.test_hip_residual_blocks."""
-    from gpu_util import Fp32Draws, close, close_grad, dev, pool_branch
+    from gpu_util import Fp32Draws, close, close_grad, dev, pool_branch, relu_branch
     from oracle import uncrtaints_oracle as orc
     from uncrtaints_amd.src import losses
     kw = dict(block_type="residual", decoder_widths=[128, 128])
@@ -275,7 +282,7 @@ def test_residual_blocks_at_an_odd_size():
         for i, (c, A, Bc) in enumerate(blk._last_relu, 1):
             n, ch = c.shape[:2]
             cv = c.reshape(n, ch, -1)[:, :, :H * W].reshape(n, ch, H, W)          # dense planes: the valid pixels
-            masks[f"{name}.conv{i}"] = ((A.view(n, ch, 1, 1) * cv + Bc.view(n, ch, 1, 1)) > 0).float().cpu()
+            masks[f"{name}.conv{i}"] = relu_branch(cv, A.view(n, ch, 1, 1), Bc.view(n, ch, 1, 1)).cpu()
     pidx, _ = pool_branch(m, state, x, dates, cfg)
 
     def run(dtype):

@@ -172,14 +172,14 @@ def _usev_inputs():
     return g, state, x, y, dates
 
 
-def _usev_oracle(state, x, y, dates, dtype=torch.float32, pool_idx=None):
+def _usev_oracle(state, x, y, dates, dtype=torch.float32, pool_idx=None, relu_masks=None):
     cfg = orc.OracleConfig(use_v=True, attn_dropout=0.0, ltae_dropout=0.0)
     cast = lambda v: v.clone().to(dtype) if v.dtype.is_floating_point else v.clone()
     with torch.no_grad():
         oe = orc.forward({k: cast(v) for k, v in state.items()}, x.to(dtype), dates.to(dtype), cfg, training=False)
     pt = {k: (cast(v).requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else cast(v))
           for k, v in state.items()}
-    ot = orc.forward(pt, x.to(dtype), dates.to(dtype), cfg, training=True, pool_idx=pool_idx)
+    ot = orc.forward(pt, x.to(dtype), dates.to(dtype), cfg, training=True, pool_idx=pool_idx, relu_masks=relu_masks)
     loss = orc.loss_from_output(ot, y.to(dtype), cfg)
     loss.backward()
     grads = {k: v.grad for k, v in pt.items() if getattr(v, "grad", None) is not None}
@@ -229,13 +229,17 @@ def test_hip_usev():
         out = m(dev(x), batch_positions=dev(dates))
     out_eval = out
     m.train()
+    m.temporal_encoder.keep_relu_branch = True
     out = m(dev(x), batch_positions=dev(dates))
     l, _ = losses.MultiGaussianNLLLoss(reduction="mean", full=True, mode="diag")(out[:, :, :13], dev(y), out[:, :, 13:26])
     l.backward()
-    # both oracle runs differentiate the max-pool branch the HIP forward took (gpu_util.pool_branch)
+    # both oracle runs differentiate the max-pool branch and the value-MLP ReLU branch the HIP forward took (gpu_util.pool_branch,
+    # gpu_util.value_relu_mask)
+    from gpu_util import value_relu_mask
     pidx, _ = pool_branch(m, state, x, dates, orc.OracleConfig(use_v=True, attn_dropout=0.0, ltae_dropout=0.0))
-    oe, ot, loss_o, g32, running = _usev_oracle(state, x, y, dates, pool_idx=pidx)
-    _, ot64, loss64, g64, _ = _usev_oracle(state, x, y, dates, torch.float64, pool_idx=pidx)
+    vmask = value_relu_mask(m)
+    oe, ot, loss_o, g32, running = _usev_oracle(state, x, y, dates, pool_idx=pidx, relu_masks=vmask)
+    _, ot64, loss64, g64, _ = _usev_oracle(state, x, y, dates, torch.float64, pool_idx=pidx, relu_masks=vmask)
     close("usev/eval", out_eval, oe, tol=2e-5)
     close("usev/eval_vs_reference", out_eval, torch.from_numpy(g["eval/out"]), tol=2e-5)
     close_vs_truth("usev/train", out, torch.from_numpy(g["train/out"]), ot64, alt32=ot, slack=4.0, cap=2e-4)
@@ -244,7 +248,7 @@ def test_hip_usev():
     for k in g.files:
         if k.startswith("train/state/"):
             close("usev/" + k, sd[k[len("train/state/"):]], torch.from_numpy(g[k]), tol=1e-4)
-    draws = Fp32Draws(lambda: _usev_oracle(state, x, y, dates, pool_idx=pidx)[3])
+    draws = Fp32Draws(lambda: _usev_oracle(state, x, y, dates, pool_idx=pidx, relu_masks=vmask)[3])
     for k, v in m.named_parameters():
         if float(g64[k].abs().max()) < 1e-7:
             assert float(v.grad.abs().max()) < 1e-3 * max(float(x_.abs().max()) for x_ in g64.values()) , k
@@ -259,13 +263,13 @@ def test_hip_usev():
 
 # ---- use_v with agg_mode 'att_mean' / 'mean' (uncrtaints.py:179-192,211-221 with 324-338,414-417): fixture g20_usev_modes generated from
 #      the reference on g12_usev's weights and inputs ----
-def _usev_mode_oracle(mode, state, x, y, dates, dtype=torch.float32, pool_idx=None):
+def _usev_mode_oracle(mode, state, x, y, dates, dtype=torch.float32, pool_idx=None, relu_masks=None):
     cfg = orc.OracleConfig(use_v=True, agg_mode=mode, attn_dropout=0.0, ltae_dropout=0.0)
     cast = lambda v: v.clone().to(dtype) if v.dtype.is_floating_point else v.clone()
     with torch.no_grad():
         oe = orc.forward({k: cast(v) for k, v in state.items()}, x.to(dtype), dates.to(dtype), cfg, training=False)
     pt = {k: (cast(v).requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else cast(v)) for k, v in state.items()}
-    ot = orc.forward(pt, x.to(dtype), dates.to(dtype), cfg, training=True, pool_idx=pool_idx)
+    ot = orc.forward(pt, x.to(dtype), dates.to(dtype), cfg, training=True, pool_idx=pool_idx, relu_masks=relu_masks)
     loss = orc.loss_from_output(ot, y.to(dtype), cfg)
     loss.backward()
     return oe, ot.detach(), loss.item(), {k: v.grad for k, v in pt.items() if getattr(v, "grad", None) is not None}, cfg
@@ -312,18 +316,21 @@ def test_hip_usev_modes(mode):
     with torch.no_grad():
         out_eval = m(dev(x), batch_positions=dev(dates))
     m.train()
+    m.temporal_encoder.keep_relu_branch = True
     out = m(dev(x), batch_positions=dev(dates))
     l, _ = losses.MultiGaussianNLLLoss(reduction="mean", full=True, mode="diag")(out[:, :, :13], dev(y), out[:, :, 13:26])
     l.backward()
+    from gpu_util import value_relu_mask
     cfg = orc.OracleConfig(use_v=True, agg_mode=mode, attn_dropout=0.0, ltae_dropout=0.0)
     pidx, _ = pool_branch(m, state, x, dates, cfg)
-    oe, ot, loss_o, g32, _ = _usev_mode_oracle(mode, state, x, y, dates, pool_idx=pidx)
-    _, ot64, loss64, g64, _ = _usev_mode_oracle(mode, state, x, y, dates, torch.float64, pool_idx=pidx)
+    vmask = value_relu_mask(m)
+    oe, ot, loss_o, g32, _ = _usev_mode_oracle(mode, state, x, y, dates, pool_idx=pidx, relu_masks=vmask)
+    _, ot64, loss64, g64, _ = _usev_mode_oracle(mode, state, x, y, dates, torch.float64, pool_idx=pidx, relu_masks=vmask)
     close(f"usev_{mode}/eval", out_eval, oe, tol=2e-5)
     close(f"usev_{mode}/eval_vs_reference_slice", out_eval[:, 0, :, ::8, ::8], torch.from_numpy(g[f"{mode}/eval_slice"]), tol=2e-5)
     close_vs_truth(f"usev_{mode}/train", out, ot, ot64, slack=4.0, cap=2e-4)
     assert abs(l.item() - loss64) < 2e-4 * abs(loss64)
-    draws = Fp32Draws(lambda: _usev_mode_oracle(mode, state, x, y, dates, pool_idx=pidx)[3])
+    draws = Fp32Draws(lambda: _usev_mode_oracle(mode, state, x, y, dates, pool_idx=pidx, relu_masks=vmask)[3])
     gmax = max(float(v.abs().max()) for v in g64.values())
     for k, v in m.named_parameters():
         if float(g64[k].abs().max()) < 1e-7:
@@ -415,13 +422,12 @@ def test_hip_residual_blocks():
     # (ResidualConvBlock._last_relu) and its arg-max indices (UNCRTAINTS._last_pool_idx), after checking that the branch is a
     # correct evaluation (pool_branch; for the masks: the fp64 gradients on the pinned branch stay within the kink scale of the
     # free fp64 evaluation).  Then ONE rule: close_grad.
-    from gpu_util import Fp32Draws, close_grad, pool_branch
+    from gpu_util import Fp32Draws, close_grad, pool_branch, relu_branch
     masks = {}
     for name, blk in [(f"in_block.{i}", b) for i, b in enumerate(m.in_block)] + [(f"out_block.{i}", b) for i, b in enumerate(m.out_block)]:
         for i, (c, A, B) in enumerate(blk._last_relu, 1):
             n, ch = c.shape[:2]
-            u = A.view(n, ch, 1, 1) * c + B.view(n, ch, 1, 1)
-            masks[f"{name}.conv{i}"] = (u > 0).float().cpu()
+            masks[f"{name}.conv{i}"] = relu_branch(c, A.view(n, ch, 1, 1), B.view(n, ch, 1, 1)).cpu()
     cfg = orc.OracleConfig(block_type="residual", decoder_widths=[128, 128], attn_dropout=0.0)
     pidx, pflips = pool_branch(m, state, x, dates, cfg)
     _, _, _, g32, _ = _res_oracle(state, x, y, dates, torch.float32, pidx, masks)

@@ -44,16 +44,21 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
     m.temporal_aggregator.attn_dropout.p = 0.0
     if kw.get("use_v"):
         m.temporal_encoder.dropout.p = 0.0
+        m.temporal_encoder.keep_relu_branch = "--free-relu" not in sys.argv
     m = m.to("cuda").train()
     out = m(dev(x), batch_positions=dev(dates))
     l, _ = losses.MultiGaussianNLLLoss(reduction="mean", eps=1e-8, full=True, mode="diag")(out[:, :, :13], dev(y), out[:, :, 13:26])
     l.backward()
     pidx, _ = pool_branch(m, state, x, dates, cfg)
-    _, _, _, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx)
+    vm = None
+    if kw.get("use_v") and "--free-relu" not in sys.argv:
+        from gpu_util import value_relu_mask
+        vm = value_relu_mask(m)
+    _, _, _, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx, relu_masks=vm)
     orc.USE_ATEN = False
-    _, _, _, g32b, _ = oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx)
+    _, _, _, g32b, _ = oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx, relu_masks=vm)
     orc.USE_ATEN = True
-    _, _, _, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64, pool_idx=pidx)
+    _, _, _, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64, pool_idx=pidx, relu_masks=vm)
     rows = []
     for k, v in m.named_parameters():
         if v.grad is None or g64.get(k) is None or is_zero_grad(k, g64):

@@ -361,6 +361,11 @@ class _StageFn(torch.autograd.Function):
                                                  pooled=getattr(e4, "_uncr_pooled", None))
         if ctx.use_v and net.training:
             te.mlp[1].num_batches_tracked += 1
+        if ctx.use_v and getattr(te, "keep_relu_branch", False):
+            # parity tests differentiate the oracle on the branch the value MLP's ReLU took here (like `_last_pool_idx`): its
+            # pre-norm input [B, C, S] and the BatchNorm coefficients per (b, c), from which the mask [A*m + B > 0] follows
+            nf = sv["val"]["nf"]
+            te._last_relu = (sv["val"]["m1"], nf.A, nf.B)
         ctx.sv, ctx.p, ctx.te = sv, p, te
         net._last_attention = att
         net._last_pool_idx = sv["idx"]        # arg-max of the 32x32 max-pool (flat in-plane index per (frame, channel, cell))
