@@ -305,7 +305,7 @@ def ltae2d_values_attention(down: Tensor, dates: Tensor, pad_mask: Tensor, p: Di
     """LTAE2d.forward + MultiHeadAttention + ScaledDotProductAttention (ltae.py:99-141, 266-307, 399-416), as built
     by UNCRTAINTS(use_v=True) (uncrtaints.py:324-336: mlp=[d_model, C], use_dropout=False, return_att=True).
     down [B,T,C,h,w] -> (values [B,C,h,w], attention [n_head,B,T,h,w]).
-    relu_mask (test infrastructure, like `pool_idx` of forward): 0/1 tensor [B*h*w, C] -- the branch of the value MLP's ReLU to
+    relu_mask (test infrastructure, like `pool_idx` of forward): 0/1 tensor [B*h*w, C] -- the branch of the value MLP's (last) ReLU to
     differentiate.  The GroupNorm behind it normalises C/n_head = 8 values per pixel; where a group is dead (all eight negative) its
     rstd is 1/sqrt(eps) = 316, so ONE pre-activation within rounding of zero in such a group moves the gradients by ~316 / (n*C)."""
     B, T, C, h, w = down.shape
@@ -325,13 +325,19 @@ def ltae2d_values_attention(down: Tensor, dates: Tensor, pad_mask: Tensor, p: Di
     vh = y.view(n, T, nh, dv)                                                         # head h = channels h*dv..(h+1)*dv
     out = torch.einsum("hnt,nthd->nhd", attn, vh).reshape(n, cfg.d_model)             # heads concatenated
     vh_cat = out
-    out = out @ p[pre + "mlp.0.weight"].t() + p[pre + "mlp.0.bias"]                   # Linear(d_model -> C)
-    m1 = out
+    # the MLP: Linear + BatchNorm1d + ReLU per layer (ltae.py:75-84; UNCRTAINTS builds one layer, LTAE2d on its own any number);
     # BatchNorm1d over the n = B*h*w samples == BatchNorm2d on [n, C, 1, 1]
-    out = batch_norm(out.view(n, C, 1, 1), p[pre + "mlp.1.weight"], p[pre + "mlp.1.bias"],
-                     p.get(pre + "mlp.1.running_mean"), p.get(pre + "mlp.1.running_var"), training,
-                     update_running=update_running).view(n, C)
-    out = torch.relu(out) if relu_mask is None else out * relu_mask.to(out.dtype)
+    li, m1 = 0, None
+    while pre + f"mlp.{3 * li}.weight" in p:
+        wk, bk = pre + f"mlp.{3 * li}", pre + f"mlp.{3 * li + 1}"
+        last = pre + f"mlp.{3 * li + 3}.weight" not in p
+        out = out @ p[wk + ".weight"].t() + p[wk + ".bias"]
+        m1 = out
+        Cv = out.shape[1]
+        out = batch_norm(out.view(n, Cv, 1, 1), p[bk + ".weight"], p[bk + ".bias"], p.get(bk + ".running_mean"),
+                         p.get(bk + ".running_var"), training, update_running=update_running).view(n, Cv)
+        out = torch.relu(out) if (relu_mask is None or not last) else out * relu_mask.to(out.dtype)
+        li += 1
     if taps is not None:        # (debugging: intermediate tensors of the value branch, tools/debug_spike.py)
         taps.update(val_y=y, val_vh=vh_cat, val_m1=m1, val_r=out)
     if training:
@@ -340,7 +346,7 @@ def ltae2d_values_attention(down: Tensor, dates: Tensor, pad_mask: Tensor, p: Di
         elif cfg.ltae_dropout > 0:
             out = F.dropout(out, cfg.ltae_dropout, training=True)
     out = group_norm(out, nh, p[pre + "out_norm.weight"], p[pre + "out_norm.bias"])    # per sample, C/nh channels per group
-    v = out.view(B, h, w, C).permute(0, 3, 1, 2)
+    v = out.view(B, h, w, out.shape[1]).permute(0, 3, 1, 2)
     return v, attn.view(nh, B, h, w, T).permute(0, 1, 4, 2, 3)
 
 

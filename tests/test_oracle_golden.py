@@ -259,3 +259,36 @@ def test_oracle_ltae2d_vs_reference_rows_fixture(i):
     assert rel_err(x.grad.numpy(), g[pre + "dx"]) < 1e-4
     if training:
         assert rel_err(p["temporal_encoder.mlp.1.running_mean"].numpy(), g[pre + "after/mlp.1.running_mean"]) < 2e-5
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_oracle_ltae2d_two_layer_mlp_vs_reference_fixture(i):
+    """G21 (reference LTAE2d with mlp=[256, 128, 64], ltae.py:75-84, eval and train, a padded date): outputs, attention, input
+    gradient, every parameter gradient, both BatchNorm1d layers' running statistics."""
+    import torch
+    from oracle import uncrtaints_oracle as orc
+    g, pre = load_golden("g21_ltae2d_deep"), f"run{i}/"
+    training = bool(g[pre + "training"])
+    p = {"temporal_encoder." + k[len("state/"):]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith("state/")}
+    for k, v in p.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    nh, dk = p["temporal_encoder.attention_heads.Q"].shape
+    cfg = orc.OracleConfig(n_head=nh, d_k=dk, d_model=256, ltae_dropout=0.0)
+    x = torch.from_numpy(g["x"]).clone().requires_grad_(True)
+    v, a = orc.ltae2d_values_attention(x, torch.from_numpy(g["dates"]), torch.from_numpy(g["pad"]), p, cfg, training)
+    assert tuple(v.shape) == tuple(g[pre + "out"].shape)
+    assert rel_err(v.detach().numpy(), g[pre + "out"]) < 2e-5
+    assert rel_err(a.detach().numpy(), g[pre + "attn"]) < 2e-5
+    ((v * torch.from_numpy(g["gv"])).sum() + (a * torch.from_numpy(g["ga"])).sum()).backward()
+    assert rel_err(x.grad.numpy(), g[pre + "dx"]) < 1e-4
+    for k in g.files:
+        if k.startswith(pre + "grad/"):
+            name = k[len(pre + "grad/"):]
+            ref = g[k]
+            mine = p["temporal_encoder." + name].grad
+            if name.endswith(".bias") and np.abs(ref).max() < 1e-3 * np.abs(g[pre + "grad/" + name.replace(".bias", ".weight")]).max():
+                continue        # mathematically zero gradients (a bias ahead of a norm / of the softmax): rounding noise on both sides
+            assert rel_err(mine.numpy(), ref) < 2e-4, name
+        if training and k.startswith(pre + "after/"):
+            assert rel_err(p["temporal_encoder." + k[len(pre + "after/"):]].detach().numpy(), g[k]) < 2e-5, k

@@ -285,3 +285,41 @@ def test_ltae2d_vs_reference_fixture(g19, i):
     if training:
         for k in ("mlp.1.running_mean", "mlp.1.running_var"):
             close("g19 LTAE2d " + k, m.state_dict()[k], _t(g, pre + "after/" + k))
+
+
+# ---- a value MLP with more than one layer (ltae.py:75-84): fixture g21_ltae2d_deep written by the reference's LTAE2d(mlp=[256, 128, 64]) ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", [0, 1])
+def test_ltae2d_two_layer_mlp_vs_reference_fixture(i):
+    from conftest import load_golden
+    from uncrtaints_amd.src.backbones.ltae import LTAE2d
+    g, pre = load_golden("g21_ltae2d_deep"), f"run{i}/"
+    training = bool(g[pre + "training"])
+    state = {k[len("state/"):]: _t(g, k) for k in g.files if k.startswith("state/")}
+    C = state["in_norm.weight"].numel()
+    nh, dk = state["attention_heads.Q"].shape
+    mlp = [int(v) for v in g["mlp"]]
+    m = LTAE2d(in_channels=C, n_head=nh, d_k=dk, mlp=mlp, dropout=0.0, d_model=256, return_att=True, use_dropout=False)
+    assert list(m.state_dict().keys()) == [k[len("state/"):] for k in g.files if k.startswith("state/")]      # the reference's keys, in order
+    m.load_state_dict(state, strict=True)
+    m = m.to(DEV).train(training)
+    x = dev(_t(g, "x")).requires_grad_(True)
+    out, attn = m(x, batch_positions=dev(_t(g, "dates")), pad_mask=dev(_t(g, "pad")))
+    assert tuple(out.shape) == tuple(g[pre + "out"].shape)
+    VT = 1e-4
+    close(f"g21 LTAE2d[train={training}] values", out, _t(g, pre + "out"), tol=VT)
+    close(f"g21 LTAE2d[train={training}] attn", attn, _t(g, pre + "attn"))
+    ((out * dev(_t(g, "gv"))).sum() + (attn * dev(_t(g, "ga"))).sum()).backward()
+    close("g21 LTAE2d dx", x.grad, _t(g, pre + "dx"), tol=VT)
+    for k, par in m.named_parameters():
+        ref = _t(g, pre + "grad/" + k)
+        if k.endswith(".bias") and k != "out_norm.bias":
+            sib_ref = _t(g, pre + "grad/" + k.replace(".bias", ".weight"))
+            if float(ref.abs().max()) < 1e-3 * float(sib_ref.abs().max()):      # zero gradients (a bias ahead of a norm / the softmax)
+                assert float(par.grad.abs().max()) < 1e-3 * float(m.get_parameter(k.replace(".bias", ".weight")).grad.abs().max()), k
+                continue
+        close(f"g21 LTAE2d grad[{k}]", par.grad, ref, tol=VT)
+    if training:
+        for k in g.files:
+            if k.startswith(pre + "after/"):
+                close("g21 LTAE2d " + k, m.state_dict()[k[len(pre + "after/"):]], _t(g, k))

@@ -1716,25 +1716,42 @@ def mean_mode_weights(pad: Optional[Tensor], n_head: int, B: int, T: int, ah: in
     return out
 
 
+def _value_layers(p: Dict[str, Tensor]):
+    """[(W, b, bn_w, bn_b), ...]: the value MLP's layers out of its parameter dict (keys of layer i > 0 carry the index)"""
+    out, i = [], 0
+    while ("mlp_w" + ("" if i == 0 else str(i))) in p:
+        sfx = "" if i == 0 else str(i)
+        out.append((p["mlp_w" + sfx], p["mlp_b" + sfx], p["bn_w" + sfx], p["bn_b" + sfx], sfx))
+        i += 1
+    return out
+
+
 def ltae_values_forward(sv_att: dict, pad: Optional[Tensor], p: Dict[str, Tensor], n_head: int, training: bool,
                         bn_buffers, p_drop: float, seed):
-    """LTAE2d values (ltae.py:122-133): attention-weighted sum over T of the projected features (per head), Linear +
-    BatchNorm1d + ReLU, dropout, GroupNorm.  -> v [B,C,S] (C = mlp[-1]), saved.
-    p: mlp_w [C,D], mlp_b, bn_w, bn_b, on_w, on_b.  The attention-weighted sum IS the temporal aggregation at the
-    attention's own resolution, so it runs on the aggregate kernels."""
+    """LTAE2d values (ltae.py:122-133): attention-weighted sum over T of the projected features (per head), (Linear +
+    BatchNorm1d + ReLU) per MLP layer, dropout, GroupNorm.  -> v [B,C,S] (C = mlp[-1]), saved.
+    p: mlp_w [C,D], mlp_b, bn_w, bn_b (further layers: mlp_w1, ...), on_w, on_b; bn_buffers: (running_mean, running_var) of the one
+    layer, or a list of such pairs.  The attention-weighted sum IS the temporal aggregation at the attention's own resolution, so it
+    runs on the aggregate kernels."""
     B, T, Cin, S, D, HK = sv_att["dims"]
     att, y1 = sv_att["att"], sv_att["y1"]
     ah, aw = att.shape[-2:]
     dev = y1.device
-    C = p["mlp_w"].shape[0]
     vh, sv_agg, _ = aggregate_forward(y1.view(B, T, D, ah, aw), att, pad, False, 0.0, 0, None, want_stats=False)
-    Wm = pack_wt(p["mlp_w"], transpose=True)
-    m1, part = pw_gemm(vh.view(B, D, S), Wm, B, D, C, S, bias=p["mlp_b"].contiguous(), epi=1)
     spec = NormSpec("batch", 1)
-    rm, rv = bn_buffers if bn_buffers is not None else (None, None)
-    nf = norm_fwd(part, B, C, S, spec, training, p["bn_w"], p["bn_b"], rm, rv)
-    r = _f32((B, C, S), dev)
-    ew(EW_AFFINE_RELU, m1, out=r, k=(nf.A, nf.B, None, None), want_part=False, planes=B * C, P=S)
+    if bn_buffers is None or (isinstance(bn_buffers, tuple) and len(bn_buffers) == 2 and not isinstance(bn_buffers[0], tuple)):
+        bn_buffers = [bn_buffers]
+    layers, src, Cprev = [], vh.view(B, D, S), D
+    for li, (w, b, bw, bb, _) in enumerate(_value_layers(p)):
+        C = w.shape[0]
+        m1, part = pw_gemm(src, pack_wt(w, transpose=True), B, Cprev, C, S, bias=b.contiguous(), epi=1)
+        rm, rv = bn_buffers[li] if (li < len(bn_buffers) and bn_buffers[li] is not None) else (None, None)
+        nf = norm_fwd(part, B, C, S, spec, training, bw, bb, rm, rv)
+        r = _f32((B, C, S), dev)
+        ew(EW_AFFINE_RELU, m1, out=r, k=(nf.A, nf.B, None, None), want_part=False, planes=B * C, P=S)
+        layers.append(dict(x=src, m1=m1, nf=nf, r=r, dims=(Cprev, C)))
+        src, Cprev = r, C
+    C, r = Cprev, src
     pd = float(p_drop) if training else 0.0
     seed_val, seed_dev = seed if isinstance(seed, tuple) else (seed, None)
     rd = r
@@ -1743,8 +1760,9 @@ def ltae_values_forward(sv_att: dict, pad: Optional[Tensor], p: Dict[str, Tensor
         hb.call("uncr_dropout", r, rd, r.numel(), seed_val, seed_dev, pd, _stream())
     v, mean, rstd = _f32((B, C, S), dev), _f32((B, n_head, S), dev), _f32((B, n_head, S), dev)
     hb.call("uncr_ltae_gn_fwd", rd, p["on_w"], p["on_b"], 1e-5, v, mean, rstd, B, 1, C, n_head, S, _stream())
-    saved = dict(agg=sv_agg, vh=vh, m1=m1, nf=nf, r=r, rd=rd, gn=(mean, rstd), pd=pd, seed=seed_val, seed_dev=seed_dev,
-                 dims=(B, T, C, S, D))
+    last = layers[-1]
+    saved = dict(agg=sv_agg, vh=vh, layers=layers, m1=last["m1"], nf=last["nf"], r=r, rd=rd, gn=(mean, rstd), pd=pd, seed=seed_val,
+                 seed_dev=seed_dev, dims=(B, T, C, S, D))
     return v, saved
 
 
@@ -1767,18 +1785,22 @@ def ltae_values_backward(dv: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int
     if sv["pd"] > 0.0:
         dr = _f32((B, C, S), dev)
         hb.call("uncr_dropout", drd, dr, drd.numel(), sv["seed"], sv["seed_dev"], sv["pd"], _stream())
-    nf, m1 = sv["nf"], sv["m1"]
-    du = _f32((B, C, S), dev)
-    _, part = ew(EW_RELU_BWD, dr, b=m1, out=du, k=(nf.A, nf.B, None, None), want_part=True, planes=B * C, P=S)
-    nb = norm_bwd(part, B, C, S, nf, p["bn_w"])
-    g["bn_w"], g["bn_b"] = nb.dgamma, nb.dbeta
-    kk = nb.k
-    dWm, dbm = pw_wgrad(du, sv["vh"].view(B, D, S), B, C, D, S, pro_d=PRO_NORMBWD, dk=kk, d2=m1, rowsum=True)
-    g["mlp_w"], g["mlp_b"] = dWm, dbm
-    Wmk = pack_wt(p["mlp_w"], transpose=False)                # [k=C][out=D]
-    dvh, _ = pw_gemm(du, Wmk, B, C, D, S, pro=PRO_NORMBWD, k=kk, x2=m1)
+    vl = _value_layers(p)
+    for li in range(len(vl) - 1, -1, -1):            # the MLP's layers back to front: dr is the gradient behind layer li's ReLU
+        w, _, bw, _, sfx = vl[li]
+        lay = sv["layers"][li]
+        Cx, Cl = lay["dims"]
+        nf, m1 = lay["nf"], lay["m1"]
+        du = _f32((B, Cl, S), dev)
+        _, part = ew(EW_RELU_BWD, dr, b=m1, out=du, k=(nf.A, nf.B, None, None), want_part=True, planes=B * Cl, P=S)
+        nb = norm_bwd(part, B, Cl, S, nf, bw)
+        g["bn_w" + sfx], g["bn_b" + sfx] = nb.dgamma, nb.dbeta
+        kk = nb.k
+        dWm, dbm = pw_wgrad(du, lay["x"].reshape(B, Cx, S), B, Cl, Cx, S, pro_d=PRO_NORMBWD, dk=kk, d2=m1, rowsum=True)
+        g["mlp_w" + sfx], g["mlp_b" + sfx] = dWm, dbm
+        dr, _ = pw_gemm(du, pack_wt(w, transpose=False), B, Cl, Cx, S, pro=PRO_NORMBWD, k=kk, x2=m1)      # W as [k = Cl][out = Cx]
     ah, aw = sv["agg"]["dims"][6:8]
-    dy1, datt = aggregate_backward(dvh.view(B, D, ah, aw), sv["agg"])
+    dy1, datt = aggregate_backward(dr.view(B, D, ah, aw), sv["agg"])
     return dy1.view(B * T, D, S), datt, g
 
 

@@ -134,13 +134,30 @@ def _ltae_params(m):
 
 
 _LTAE_KEYS = ("in_norm_w", "in_norm_b", "inconv_w", "inconv_b", "fc_w", "fc_b", "Q")
-# value branch of LTAE2d (use_v): Linear(d_model -> C), BatchNorm1d(C), out GroupNorm(C)
-_LTAEV_KEYS = ("mlp_w", "mlp_b", "bn_w", "bn_b", "on_w", "on_b")
+# value branch of LTAE2d (use_v): Linear(d_model -> C), BatchNorm1d(C) [, further Linear + BatchNorm1d layers: keys with the layer's
+# index appended], out GroupNorm(C)
+_LTAEV_KEYS = ("mlp_w", "mlp_b", "bn_w", "bn_b", "on_w", "on_b")          # one layer: what UNCRTAINTS(use_v=True) builds
+
+
+def _ltaev_keys(n_layers: int):
+    ks = ["mlp_w", "mlp_b", "bn_w", "bn_b"]
+    for i in range(1, n_layers):
+        ks += [f"mlp_w{i}", f"mlp_b{i}", f"bn_w{i}", f"bn_b{i}"]
+    return tuple(ks + ["on_w", "on_b"])
+
+
+def _mlp_layers(m):
+    """[(Linear, BatchNorm1d), ...] of the nn.Sequential(Linear, BatchNorm1d, ReLU, ...) the reference builds (ltae.py:75-84)"""
+    return [(m.mlp[3 * i], m.mlp[3 * i + 1]) for i in range(len(m.mlp) // 3)]
 
 
 def _ltae_value_params(m):
-    return dict(mlp_w=m.mlp[0].weight, mlp_b=m.mlp[0].bias, bn_w=m.mlp[1].weight, bn_b=m.mlp[1].bias,
-                on_w=m.out_norm.weight, on_b=m.out_norm.bias)
+    out = {}
+    for i, (lin, bn) in enumerate(_mlp_layers(m)):
+        sfx = "" if i == 0 else str(i)
+        out.update({"mlp_w" + sfx: lin.weight, "mlp_b" + sfx: lin.bias, "bn_w" + sfx: bn.weight, "bn_b" + sfx: bn.bias})
+    out.update(on_w=m.out_norm.weight, on_b=m.out_norm.bias)
+    return out
 
 
 class _LTAEAttnFn(torch.autograd.Function):
@@ -234,7 +251,9 @@ class _LTAE2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dates, pad, module, *params):
         nk = len(_LTAE_KEYS)
-        p, vp = dict(zip(_LTAE_KEYS, params[:nk])), dict(zip(_LTAEV_KEYS, params[nk:]))
+        layers = _mlp_layers(module)
+        vkeys = _ltaev_keys(len(layers))
+        p, vp = dict(zip(_LTAE_KEYS, params[:nk])), dict(zip(vkeys, params[nk:]))
         te = module
         denom = te.positional_encoder.denom_on(x.device) if te.positional_encoder is not None else None
         B, T, C, h, w = x.shape
@@ -247,12 +266,14 @@ class _LTAE2dFn(torch.autograd.Function):
         if pa > 0.0:                            # MultiHeadAttention(use_dropout=True): dropout on the attention before the values
             att_d = torch.empty_like(att)
             E.hb.call("uncr_dropout", att, att_d, att.numel(), seed, None, pa, E._stream())
-        bn = te.mlp[1]
-        v, sv_val = E.ltae_values_forward(dict(sv_att, att=att_d), pad, vp, nh, te.training, (bn.running_mean, bn.running_var),
-                                          float(te.dropout.p), seed ^ 0x5bd1e995)
-        if te.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+        v, sv_val = E.ltae_values_forward(dict(sv_att, att=att_d), pad, vp, nh, te.training,
+                                          [(bn.running_mean, bn.running_var) for _, bn in layers], float(te.dropout.p), seed ^ 0x5bd1e995)
+        if te.training:
+            for _, bn in layers:
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
         ctx.sv = (sv_att, sv_val, p, vp, nh, dk, pa, seed)
+        ctx.vkeys = vkeys
         return v.view(B, -1, h, w), att_d
 
     @staticmethod
@@ -269,12 +290,12 @@ class _LTAE2dFn(torch.autograd.Function):
         ddown, g = E.ltae_attention_backward(dsum, sv_att, p, nh, dk, dy1_extra=dy1)
         g.update(gv)
         ddown = ddown.view(sv_att["down"].shape) if ctx.needs_input_grad[0] else None
-        return (ddown, None, None, None) + tuple(g[k] for k in _LTAE_KEYS) + tuple(g[k] for k in _LTAEV_KEYS)
+        return (ddown, None, None, None) + tuple(g[k] for k in _LTAE_KEYS) + tuple(g[k] for k in ctx.vkeys)
 
 
 class LTAE2d(nn.Module):
-    """ltae.py:10-141: the attention of LTAE2dtiny plus the values (attention-weighted projected features -> Linear +
-    BatchNorm1d + ReLU -> dropout -> GroupNorm).  UNCRTAINTS(use_v=True) runs it fused with the max-pool and the aggregation; a
+    """ltae.py:10-141: the attention of LTAE2dtiny plus the values (attention-weighted projected features -> (Linear +
+    BatchNorm1d + ReLU) per mlp layer -> dropout -> GroupNorm).  UNCRTAINTS(use_v=True) runs it fused with the max-pool and the aggregation; a
     stand-alone call goes through _LTAE2dFn."""
 
     def __init__(self, in_channels=128, n_head=16, d_k=4, mlp=[256, 128], dropout=0.2, d_model=256, T=1000,
@@ -285,8 +306,10 @@ class LTAE2d(nn.Module):
         mlp = copy.deepcopy(mlp)
         self.return_att = return_att
         self.n_head = n_head
-        if len(mlp) != 2:
-            raise NotImplementedError("LTAE2d is built for a one-layer MLP (mlp=[d_model, C])")
+        if len(mlp) < 2:
+            raise ValueError("mlp needs at least [d_model, C]")
+        if max(mlp) > 256:
+            raise NotImplementedError("the GEMM kernels take at most 256 channels per operand: every mlp width <= 256")
         if d_model is not None:
             self.d_model = d_model
             self.inconv = nn.Conv1d(in_channels, d_model, 1)
@@ -299,7 +322,10 @@ class LTAE2d(nn.Module):
         self.attention_heads = MultiHeadAttention(n_head=n_head, d_k=d_k, d_in=self.d_model, use_dropout=use_dropout)
         self.in_norm = nn.GroupNorm(num_groups=n_head, num_channels=self.in_channels)
         self.out_norm = nn.GroupNorm(num_groups=n_head, num_channels=mlp[-1])
-        self.mlp = nn.Sequential(nn.Linear(mlp[0], mlp[1]), nn.BatchNorm1d(mlp[1]), nn.ReLU())
+        layers = []
+        for i in range(len(mlp) - 1):                      # ltae.py:75-84
+            layers += [nn.Linear(mlp[i], mlp[i + 1]), nn.BatchNorm1d(mlp[i + 1]), nn.ReLU()]
+        self.mlp = nn.Sequential(*layers)
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x, batch_positions=None, pad_mask=None, return_comp=False):
@@ -309,5 +335,6 @@ class LTAE2d(nn.Module):
             raise ValueError("batch_positions (dates) are required when positional_encoding=True")
         pad = pad_mask.to(torch.int32).contiguous() if pad_mask is not None else None
         p, vp = _ltae_params(self), _ltae_value_params(self)
-        out, attn = _LTAE2dFn.apply(x, batch_positions, pad, self, *([p[k] for k in _LTAE_KEYS] + [vp[k] for k in _LTAEV_KEYS]))
+        out, attn = _LTAE2dFn.apply(x, batch_positions, pad, self,
+                                    *([p[k] for k in _LTAE_KEYS] + [vp[k] for k in _ltaev_keys(len(_mlp_layers(self)))]))
         return (out, attn) if self.return_att else out
