@@ -130,14 +130,20 @@ extern "C" int uncr_fix_rowsum_tail(float* rs, int N, int C, const float* c2, co
 // ---- depthwise 3x3, reflect padding, any H x W (uncrtaints.py:130-131) as ROW-BAND kernels: one 256-thread block owns TR consecutive
 // rows of one plane and stages them with their halo into an LDS tile ON THE PADDED GRID (the point-wise prologue applied on the way: one
 // GELU / one norm-backward per element, not nine), so the stencil loop reads LDS at constant offsets -- no reflection arithmetic, no
-// alignment assumptions, any width, no scratch tensor.  These kernels are VALU-bound, not latency-bound: what counts is instructions per
-// pixel (the first versions gathered nine reflected neighbours from global memory, then from LDS with a per-pixel border branch whose
+// alignment assumptions, any width, no scratch tensor.  What counts is instructions per
+// pixel and blocks per CU (the first versions gathered nine reflected neighbours from global memory, then from LDS with a per-pixel border branch whose
 // 81 predicated reads every wave crossing a row end had to walk: 356 / 852 us, then 235 / 654 us at 4 x 256 x 250 x 250).
-#define DWB_LDS_FLOATS 10240
-// rows per band: the forward tile is (TR + 2) x (W + 2) (reflected halo), the backward tile (TR + 4) x (W + 4) (zero-extended, see below)
+// rows per band: the forward tile is (TR + 2) x (W + 2) (reflected halo), the backward tile (TR + 4) x (W + 4) (zero-extended, see below).
+// A 20 KB tile (eight blocks = 32 waves per CU) beats a 40 KB one by 25 % at W = 250 (425 -> 320 us backward): the two phases of a block
+// (stage, stencil) overlap only across blocks.  Wider images take a larger tile to keep at least eight rows per band, up to 62.5 KB.
 static int dw_band_rows(int W, int bwd) {
     if (W < 2) return 0;
-    const int tr = bwd ? DWB_LDS_FLOATS / (W + 4) - 4 : DWB_LDS_FLOATS / (W + 2) - 2;
+    const int budgets[3] = {5120, 10240, 16000};          // floats; 16000 < 2^14 keeps row_of exact
+    int tr = 0;
+    for (int i = 0; i < 3; ++i) {
+        tr = bwd ? budgets[i] / (W + 4) - 4 : budgets[i] / (W + 2) - 2;
+        if (tr >= 8) break;
+    }
     return tr < 2 ? 0 : (tr > 32 ? 32 : tr);
 }
 // statistics slots (= row bands) per plane of uncr_dw_fwd_any (bwd = 0) / uncr_dw_bwd_any (bwd = 1); -1: width not supported
@@ -263,17 +269,24 @@ __global__ __launch_bounds__(256) void dw_bwd_band_kernel(const float* __restric
         const int ny = 1 + (y == 1) + (y == H - 2), nx = 1 + (x == 1) + (x == W - 2);
         const int e1y = (y == 1) ? -1 : H, e1x = (x == 1) ? -1 : W;
         float tk[9];
+        {
+            const float* tc = t + (r + 2) * pitch + x + 2;              // the pixel's own padded position: all an interior lane needs
 #pragma unroll
-        for (int k = 0; k < 9; ++k) tk[k] = 0.f;
-        for (int a = 0; a < ny; ++a) {
-            const int ry = (a == 0 ? y : (a == 1 ? e1y : H)) - (y0 - 2);
-            for (int b = 0; b < nx; ++b) {
-                const int cx = (b == 0 ? x : (b == 1 ? e1x : W)) + 2;
-                const float* tc = t + ry * pitch + cx;
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) tk[ky * 3 + kx] = tc[(1 - ky) * pitch + (1 - kx)];
+        }
+        if (ny + nx > 2) {                                              // the mirrored positions (rows / columns 1 and H-2 / W-2 only)
+            for (int a = 0; a < ny; ++a) {
+                const int ry = (a == 0 ? y : (a == 1 ? e1y : H)) - (y0 - 2);
+                for (int b = (a == 0 ? 1 : 0); b < nx; ++b) {
+                    const int cx = (b == 0 ? x : (b == 1 ? e1x : W)) + 2;
+                    const float* tc = t + ry * pitch + cx;
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) tk[ky * 3 + kx] += tc[(1 - ky) * pitch + (1 - kx)];
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) tk[ky * 3 + kx] += tc[(1 - ky) * pitch + (1 - kx)];
+                }
             }
         }
         float dg = 0.f;

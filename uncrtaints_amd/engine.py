@@ -173,7 +173,7 @@ def current_geom() -> Optional[Geom]:
 def _dw_any_slots(geom, bwd: bool) -> int:
     slots = hb.query("uncr_dw_any_slots", geom.H, geom.W, 1 if bwd else 0)
     if slots <= 0:
-        raise NotImplementedError(f"depthwise 3x3 on any-size planes: width {geom.W} is beyond the row-band kernels' 2558 (forward) / 1702 (backward)")
+        raise NotImplementedError(f"depthwise 3x3 on any-size planes: width {geom.W} is beyond the row-band kernels' 3998 (forward) / 2662 (backward)")
     return slots
 
 
