@@ -307,10 +307,11 @@ def test_graph_mode_survives_an_optimizer_checkpoint_with_a_float_learning_rate(
     (1, 2, 96, 96, ""),            # 3x3 pooling windows, 3x up-sampling, W != 256 (LDS-tiled depthwise kernels)
     (1, 1, 64, 64, ""),            # a single date through the temporal attention
     (1, 12, 64, 64, ""),           # a long series
+    (1, 20, 64, 64, ""),           # ... beyond the fused L-TAE kernels' 16 dates: the stand-alone attention kernels
     (1, 2, 64, 512, ""),           # wide frames: 2x / 16x up-sampling, depthwise kernels for W != 256
     (2, 3, 64, 64, "all_padded"),  # every date of sample 1 is padding (all-zero frames)
     (1, 2, 100, 100, ""),          # any H x W (csrc/anysize.hip): H*W not a multiple of 1024 -- padded planes, tail corrections
-    (1, 2, 250, 250, ""),          # ... and W not a multiple of 4: the scalar 2-D kernels
+    (1, 2, 250, 250, ""),          # ... and W not a multiple of 4: the row-band / scalar 2-D kernels
     (2, 2, 70, 90, ""),            # ... two samples, a non-square image
 ])
 def test_vs_oracle_fresh_inputs(B, T, H, W, special):
