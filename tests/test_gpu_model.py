@@ -310,6 +310,7 @@ def test_graph_mode_survives_an_optimizer_checkpoint_with_a_float_learning_rate(
     (1, 20, 64, 64, ""),           # ... beyond the fused L-TAE kernels' 16 dates: the stand-alone attention kernels
     (1, 2, 64, 512, ""),           # wide frames: 2x / 16x up-sampling, depthwise kernels for W != 256
     (2, 3, 64, 64, "all_padded"),  # every date of sample 1 is padding (all-zero frames)
+    (22, 3, 32, 32, ""),           # 66 frames (beyond in_conv's moment path: its generic path), a map no larger than the attention's
     (1, 2, 100, 100, ""),          # any H x W (csrc/anysize.hip): H*W not a multiple of 1024 -- padded planes, tail corrections
     (1, 2, 250, 250, ""),          # ... and W not a multiple of 4: the row-band / scalar 2-D kernels
     (2, 2, 70, 90, ""),            # ... two samples, a non-square image
