@@ -255,10 +255,13 @@ int uncr_fix_tail(float* t, float* part, int slots, int planes, int P, int Pc, i
 int uncr_fix_sepool_tail(float* part, int slots, const float* cB /* [planes] */, int planes, int ntail, hipStream_t stream);
 int uncr_fix_wgrad_tail(float* G /* [N][Cd][Cx] */, int N, int Cd, int Cx, const float* c2, const float* c3, const float* mu /* [N*Cd], mu nullable */,
                         const float* cB /* [N*Cx] */, int ntail, hipStream_t stream);
+/* ... a product summed over the frames whose x operand is A*x + B (B on the tail): dW [Cd][Cx] loses n_tail * sum_n (c3 - c2*mu)[n,co] * B[n,ci] */
+int uncr_fix_wgrad_tail_affine(float* dW, int N, int Cd, int Cx, const float* c2, const float* c3, const float* mu, const float* cB,
+                               int ntail, hipStream_t stream);
 int uncr_fix_rowsum_tail(float* rs /* [C] */, int N, int C, const float* c2, const float* c3, const float* mu /* [N*C], mu nullable */,
                          int ntail, hipStream_t stream);
 /* depthwise 3x3 reflect (uncrtaints.py:130-131) with the meaning of uncr_dw_fwd / uncr_dw_bwd on dense H x W planes of stride Pc: row
- * bands staged through LDS on the padded grid, any width up to 3998 (forward) / 2662 (backward), the zero tail of the result written too;
+ * bands staged through LDS on the padded grid, any width up to 3998 (forward) / 2281 (backward), the zero tail of the result written too;
  * part [N*C][uncr_dw_any_slots(H, W, bwd)][2], dw_part [N*C][uncr_dw_any_slots(H, W, 1)][9] */
 int uncr_dw_fwd_any(const float* in, const float* cA, const float* cB, const float* w, float* out, float* part, int N, int C, int H,
                     int W, int Pc, hipStream_t stream);

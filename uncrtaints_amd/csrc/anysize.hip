@@ -108,6 +108,31 @@ extern "C" int uncr_fix_wgrad_tail(float* G, int N, int Cd, int Cx, const float*
     return UNCR_OK;
 }
 
+// the same for a product summed over the frames whose x operand has an AFFINE prologue (pw1's weight gradient on the unfused path:
+// dW1[co][ci] = sum_{n,p} dh[n,co,p] * (A*x + B)[n,ci,p]): the tail contributed n_tail * sum_n (c3 - c2*mu)[n,co] * B[n,ci]
+__global__ __launch_bounds__(256) void fix_wgrad_tail_affine_kernel(float* __restrict__ dW, int N, int Cd, int Cx,
+                                                                    const float* __restrict__ c2, const float* __restrict__ c3,
+                                                                    const float* __restrict__ mu, const float* __restrict__ cB,
+                                                                    float ntail) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cd * Cx) return;
+    const int co = i / Cx, ci = i - co * Cx;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n)
+        acc = fmaf(fmaf(-c2[n * Cd + co], mu ? mu[n * Cd + co] : 0.f, c3[n * Cd + co]), cB[n * Cx + ci], acc);
+    dW[i] -= ntail * acc;
+}
+extern "C" int uncr_fix_wgrad_tail_affine(float* dW, int N, int Cd, int Cx, const float* c2, const float* c3, const float* mu,
+                                          const float* cB, int ntail, hipStream_t stream) {
+    if (N <= 0 || Cd <= 0 || Cx <= 0 || ntail < 0) return UNCR_ESHAPE;
+    if (!dW || !c2 || !c3 || !cB) return UNCR_EINVAL;
+    if (ntail == 0) return UNCR_OK;
+    hipLaunchKernelGGL(fix_wgrad_tail_affine_kernel, dim3((Cd * Cx + 255) / 256), dim3(256), 0, stream, dW, N, Cd, Cx, c2, c3, mu, cB,
+                       (float)ntail);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
 // row sums db[co] = sum_{n,p} (c1*d + c2*(d2 - mu) + c3) over a stride whose tail holds d = d2 = 0
 __global__ __launch_bounds__(256) void fix_rowsum_tail_kernel(float* __restrict__ rs, int N, int C, const float* __restrict__ c2,
                                                               const float* __restrict__ c3, const float* __restrict__ mu, float ntail) {
@@ -133,7 +158,7 @@ extern "C" int uncr_fix_rowsum_tail(float* rs, int N, int C, const float* c2, co
 // alignment assumptions, any width, no scratch tensor.  What counts is instructions per
 // pixel and blocks per CU (the first versions gathered nine reflected neighbours from global memory, then from LDS with a per-pixel border branch whose
 // 81 predicated reads every wave crossing a row end had to walk: 356 / 852 us, then 235 / 654 us at 4 x 256 x 250 x 250).
-// rows per band: the forward tile is (TR + 2) x (W + 2) (reflected halo), the backward tile (TR + 4) x (W + 4) (zero-extended, see below).
+// rows per band: the forward tile is (TR + 2) x (W + 2) (reflected halo), the backward tile (TR + 5) x (W + 4) (zero-extended, see below).
 // A 20 KB tile (eight blocks = 32 waves per CU) beats a 40 KB one by 25 % at W = 250 (425 -> 320 us backward): the two phases of a block
 // (stage, stencil) overlap only across blocks.  Wider images take a larger tile to keep at least eight rows per band, up to 62.5 KB.
 static int dw_band_rows(int W, int bwd) {
@@ -141,7 +166,7 @@ static int dw_band_rows(int W, int bwd) {
     const int budgets[3] = {5120, 10240, 16000};          // floats; 16000 < 2^14 keeps row_of exact
     int tr = 0;
     for (int i = 0; i < 3; ++i) {
-        tr = bwd ? budgets[i] / (W + 4) - 4 : budgets[i] / (W + 2) - 2;
+        tr = bwd ? budgets[i] / (W + 4) - 5 : budgets[i] / (W + 2) - 2;
         if (tr >= 8) break;
     }
     return tr < 2 ? 0 : (tr > 32 ? 32 : tr);
@@ -222,8 +247,8 @@ extern "C" int uncr_dw_fwd_any(const float* in, const float* cA, const float* cB
 //   dg1[p] = sum of dgp over the padded positions that mirror onto p = {y, and -1 if y == 1, and H if y == H-2} x {x, -1 if x == 1, W if x == W-2}
 // -- one position in the interior, two along rows / columns 1 and H-2 / W-2, four at their crossings.  The same t_k give the depthwise
 // weight gradient  dW_k = sum_p gelu(u1)[p] * (sum over p's padded positions of t_k)  with ONE erf per pixel;  du1 = gelu'(u1) * dg1,
-// statistics (sum du1, sum du1*(h1 - mean1)).  tile (r, c) = dh2z at image (y0 - 2 + r, c - 2), pitch W + 4: every read of the loop is in
-// range without a test.
+// statistics (sum du1, sum du1*(h1 - mean1)).  tile (r, c) = dh2z at image (y0 - 2 + r, c - 2), rows y0 - 2 ... y0 + rows + 2 (row H - 2 may be a
+// band's last row, and its mirrored position H reads rows H - 1 ... H + 1), pitch W + 4: every read of the loop is in range without a test.
 __global__ __launch_bounds__(256) void dw_bwd_band_kernel(const float* __restrict__ du2, const float* __restrict__ h2,
                                                           const float* __restrict__ h1, const float* __restrict__ k1,
                                                           const float* __restrict__ k2, const float* __restrict__ k3,
@@ -234,7 +259,7 @@ __global__ __launch_bounds__(256) void dw_bwd_band_kernel(const float* __restric
                                                           int TR, float invW, float invP) {
     extern __shared__ __attribute__((aligned(16))) float t[];
     const int plane = blockIdx.y, c = plane % C, n = plane / C;
-    const int y0 = blockIdx.x * TR, rows = min(TR, H - y0), nrow = rows + 4, pitch = W + 4;
+    const int y0 = blockIdx.x * TR, rows = min(TR, H - y0), nrow = rows + 5, pitch = W + 4;
     const size_t base = (size_t)plane * Pc;
     {
         const float K1 = k1[plane], K2 = k2[plane], K3 = k3[plane], KM = kmu ? kmu[plane] : 0.f;
@@ -324,7 +349,7 @@ extern "C" int uncr_dw_bwd_any(const float* du2, const float* h2, const float* h
     const int tr = dw_band_rows(W, 1);
     if (N <= 0 || C <= 0 || H < 2 || !tr || Pc < H * W || Pc % 1024 || (mean1 && mean_groups > 0 && C % mean_groups)) return UNCR_ESHAPE;
     if (!du2 || !h2 || !h1 || !k1 || !k2 || !k3 || !cA1 || !cB1 || !w || !du1 || !part || !dw_part) return UNCR_EINVAL;
-    hipLaunchKernelGGL(dw_bwd_band_kernel, dim3((H + tr - 1) / tr, N * C), dim3(256), (size_t)(tr + 4) * (W + 4) * sizeof(float), stream,
+    hipLaunchKernelGGL(dw_bwd_band_kernel, dim3((H + tr - 1) / tr, N * C), dim3(256), (size_t)(tr + 5) * (W + 4) * sizeof(float), stream,
                        du2, h2, h1, k1, k2, k3, kmu, cA1, cB1, w, du1, (float2*)part, dw_part, mean1, mean_groups, C, H, W, Pc, tr,
                        1.0f / (float)W, 1.0f / (float)(W + 4));
     UNCR_LAUNCH_CHECK();

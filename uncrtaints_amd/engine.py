@@ -173,7 +173,7 @@ def current_geom() -> Optional[Geom]:
 def _dw_any_slots(geom, bwd: bool) -> int:
     slots = hb.query("uncr_dw_any_slots", geom.H, geom.W, 1 if bwd else 0)
     if slots <= 0:
-        raise NotImplementedError(f"depthwise 3x3 on any-size planes: width {geom.W} is beyond the row-band kernels' 3998 (forward) / 2662 (backward)")
+        raise NotImplementedError(f"depthwise 3x3 on any-size planes: width {geom.W} is beyond the row-band kernels' 3998 (forward) / 2281 (backward)")
     return slots
 
 
@@ -1130,12 +1130,14 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         join_side()
         return dx, g, dx_part
 
-    # pw1: weight gradient and data gradient
-    if geom is not None:
-        raise NotImplementedError("any-size planes are built for the fused pw1 backward (block width a multiple of 32, <= 128 ... 256)")
+    # pw1: weight gradient and data gradient (block widths the fused backward does not take, e.g. 64)
     dW1, _ = pw_wgrad(du1, x, N, Ch, C, P, pro_d=PRO_NORMBWD, dk=k1, d2=h1, pro_x=PRO_AFFINE, xk=(n0.A, n0.B, None))
+    if geom is not None:      # the tail (du1 = h1 = x = 0 there) contributed n_tail * sum_n (c3 - c2*mu)[n, co] * B0[n, ci]
+        hb.call("uncr_fix_wgrad_tail_affine", dW1, N, Ch, C, k1[1], k1[2], k1[3], n0.B, geom.ntail, _stream())
     g["w1"] = dW1.view_as(p["w1"])
     da, part0 = pw_gemm(du1, W1k, N, Ch, C, P, pro=PRO_NORMBWD, k=k1, x2=h1, epi=2, aux=x)
+    if geom is not None:
+        fix_tail(da, part0, 1, N * C)
     b0 = norm_bwd(part0, N, C, P, n0, p["n0w"])
     g["n0w"], g["n0b"] = b0.dgamma, b0.dbeta
 
