@@ -313,7 +313,10 @@ def ltae2d_values_attention(down: Tensor, dates: Tensor, pad_mask: Tensor, p: Di
     pre = "temporal_encoder."
     x = down.permute(0, 3, 4, 2, 1).reshape(n, C, T)
     x = group_norm(x, nh, p[pre + "in_norm.weight"], p[pre + "in_norm.bias"])
-    y = torch.einsum("oc,nct->nto", p[pre + "inconv.weight"][:, :, 0], x) + p[pre + "inconv.bias"]      # [n,T,d_model]
+    if pre + "inconv.weight" in p:
+        y = torch.einsum("oc,nct->nto", p[pre + "inconv.weight"][:, :, 0], x) + p[pre + "inconv.bias"]  # [n,T,d_model]
+    else:                                                                  # LTAE2d(d_model=None): no input projection, ltae.py:49-54
+        y = x.permute(0, 2, 1)
     if cfg.positional_encoding:
         pe = positional_table(dates, cfg.d_model // nh, cfg.T_period, nh)
         y = y + pe[:, None, :, :].expand(B, h * w, T, cfg.d_model).reshape(n, T, cfg.d_model)
