@@ -686,6 +686,7 @@ def test_mgnll_none_reduction_backward(orc):
 
 
 def test_positional_table_and_ensemble(E):
+    from oracle.uncrtaints_oracle import ensemble_combine as orc_ensemble
     from uncrtaints_amd.src.backbones.positional_encoding import PositionalEncoder
     g = load_golden("g7_posenc")
     pe = PositionalEncoder(16, T=1000, repeat=16)
@@ -696,6 +697,14 @@ def test_positional_table_and_ensemble(E):
         m, v = E.ensemble_combine(mu, var, mode)
         close(f"ens_mean[{mode}]", m, torch.from_numpy(g8["mean_ens"]).float(), tol=1e-6)
         close(f"ens_var[{mode}]", v, torch.from_numpy(g8[key]).float(), tol=2e-5)
+    # isotropic members (one variance channel): 'both' broadcasts it over the bands, 'aleatoric' = the mean of the members' variances
+    # keeps their one channel, as numpy does in ensemble_reconstruct.py:116-133
+    viso = var[:, :1].contiguous()
+    for mode in ("both", "aleatoric", "epistemic"):
+        m, v = E.ensemble_combine(mu, viso, mode)
+        mo, vo = orc_ensemble(mu.cpu().double(), viso.cpu().double(), mode)
+        assert tuple(v.shape) == tuple(vo.shape), (mode, tuple(v.shape), tuple(vo.shape))
+        close(f"ens_iso_var[{mode}]", v, vo, tol=2e-5)
 
 
 def test_eltlosses_gnll_l1_l2():

@@ -2225,8 +2225,11 @@ def ensemble_combine(means: Tensor, variances: Optional[Tensor], mode: str = "bo
     """means/variances [M, ...] -> (mean_ens, var_ens) (ensemble_reconstruct.py:116-133)."""
     M = means.shape[0]
     n = means[0].numel()
+    narrow = []
     if variances is not None and variances.shape != means.shape:
         # isotropic members carry one variance channel: broadcast it over the bands like the reference's numpy code does
+        if variances.dim() == means.dim():
+            narrow = [d - 1 for d in range(1, means.dim()) if variances.shape[d] == 1 and means.shape[d] != 1]
         try:
             variances = variances.expand_as(means)
         except RuntimeError:
@@ -2236,4 +2239,7 @@ def ensemble_combine(means: Tensor, variances: Optional[Tensor], mode: str = "bo
     code = {"both": 0, "aleatoric": 1, "epistemic": 2}[mode]
     hb.call("uncr_ensemble_combine", means.contiguous(), variances.contiguous() if variances is not None else None, M,
             n, code, mu, v, _stream())
+    if mode == "aleatoric":        # the mean of the members' variances keeps THEIR shape (one channel for isotropic members)
+        for d in narrow:
+            v = v.narrow(d, 0, 1)
     return mu, v
