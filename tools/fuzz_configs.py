@@ -18,15 +18,18 @@ from oracle import uncrtaints_oracle as orc
 from uncrtaints_amd.src import losses
 from uncrtaints_amd.src.backbones import uncrtaints as U
 
-WIDE = "--wide" in sys.argv
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-for a in sys.argv[3:]:                      # --dev=h2_fwd=0,eval_tail=0 : engine.dev_options for an A/B of one case
+_MAIN = __name__ == "__main__"
+WIDE = _MAIN and "--wide" in sys.argv
+n_cases = int(sys.argv[1]) if _MAIN and len(sys.argv) > 1 else 30
+first = int(sys.argv[2]) if _MAIN and len(sys.argv) > 2 else 0
+for a in (sys.argv[3:] if _MAIN else ()):                      # --dev=h2_fwd=0,eval_tail=0 : engine.dev_options for an A/B of one case
     if a.startswith("--dev="):
         from uncrtaints_amd import engine as _E
         _E.dev_options(**{kv.split("=")[0]: bool(int(kv.split("=")[1])) for kv in a[6:].split(",")}).__enter__()
-bad = 0
-for case in range(first, first + n_cases):
+def run_case(case, overrides=()):
+    """-> (outside the contract?, refused?): one random case, printed as a line"""
+    bad = 0
+    refused = False
     rnd = random.Random(case)
     kw = {}
     if rnd.random() < 0.4:
@@ -76,7 +79,7 @@ for case in range(first, first + n_cases):
     T = 1 if mono else rnd.choice([1, 2, 3, 5] + ([8] if WIDE else []))
     H, W = rnd.choice([(64, 64), (96, 96), (33, 47), (50, 46), (72, 60), (40, 100), (128, 32), (37, 37)]
                       + ([(65, 33), (32, 32), (64, 128), (97, 129), (34, 257)] if WIDE else [(32, 64)]))
-    for a in sys.argv[3:]:                  # --kw="..." / --shape=B,T,H,W / --pad=0|1 override what the seed drew (A/B runs of one case)
+    for a in overrides:                     # --kw="..." / --shape=B,T,H,W / --pad=0|1 override what the seed drew (A/B runs of one case)
         if a.startswith("--kw="):
             kw = eval("dict(" + a[5:] + ")")
         if a.startswith("--shape="):
@@ -139,9 +142,15 @@ for case in range(first, first + n_cases):
         for eh, ec, k in sorted(viol, reverse=True)[:10]:
             print(f"      {eh:.2e} cpu {ec:.2e} {k}")
     except NotImplementedError as exc:
+        refused = True
         print(f"{tag}: refused -- {str(exc)[:110]}", flush=True)
     except Exception as exc:
         bad += 1
         print(f"{tag}: {type(exc).__name__}: {str(exc)[:200]}  <<<<<<", flush=True)
         traceback.print_exc(limit=3)
-print("cases outside the contract:", bad)
+    return bool(bad), refused
+
+
+if __name__ == "__main__":
+    total = sum(run_case(c, sys.argv[3:])[0] for c in range(first, first + n_cases))
+    print("cases outside the contract:", total)
