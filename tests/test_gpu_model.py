@@ -537,6 +537,8 @@ def test_backward_through_the_model_in_eval_mode():
     ("n_head_4", dict(n_head=4)),                           # 32 channels per head: the unfused L-TAE kernels
     ("n_head_8", dict(n_head=8)),
     ("n_head_32", dict(n_head=32)),
+    ("widths_96_n_head_8", dict(encoder_widths=[96], decoder_widths=[96], n_head=8)),      # 12 channels per head: the scalar aggregation kernels
+    ("widths_192_n_head_8", dict(encoder_widths=[192], decoder_widths=[192], n_head=8)),   # 24
     ("scale_by_10", dict(scale_by=10.0)),                   # the README training configuration: eps = 1e-3 on the variance
     ("no_positional_encoding", dict(positional_encoding=False)),
     ("d_model_128", dict(d_model=128)),

@@ -1575,6 +1575,13 @@ def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: b
     n_head, _, _, ah, aw = att.shape
     dev = e.device
     geom = _GEOM if (_GEOM is not None and H * W == _GEOM.Pc) else None
+    odd_heads = None
+    if geom is None and C % n_head == 0 and C // n_head not in (2, 4, 6, 8, 16, 32) and not (H <= aw and (H, W) != (ah, aw)):
+        # channels per head outside the streaming kernels' list (e.g. 96 channels in 8 heads): the scalar kernels below take any count;
+        # a dense plane is a padded plane without a tail
+        if _dt(e) != F32:
+            raise NotImplementedError(f"{C // n_head} channels per head (other than 2, 4, 6, 8, 16, 32) are built for fp32 storage")
+        geom = odd_heads = Geom(H, W, H * W)
     if geom is not None:
         # padded planes of an any-size image (csrc/anysize.hip): the scalar kernels on the true H x W (bilinear up-sampling of any ratio)
         if _dt(e) != F32:
@@ -1591,9 +1598,14 @@ def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: b
         seed_val, seed_dev = seed if isinstance(seed, tuple) else (seed, None)
         hb.call("uncr_aggregate_any_fwd", e, att, pad, use_mask, seed_val, seed_dev, pd, 1 if shared_mask else 0, g,
                 gpart.buf if gpart else None, B, T, C, n_head, geom.H, geom.W, geom.Pc, ah, aw, _stream())
-        fix_tail(g, None, 2, B * C)
-        return g, dict(e=e, att=att, pad=pad, dmask=use_mask, pd=pd, seed=seed_val, seed_dev=seed_dev, shared=1 if shared_mask else 0,
-                       dims=(B, T, C, H, W, n_head, ah, aw), geom=geom), gpart
+        sv = dict(e=e, att=att, pad=pad, dmask=use_mask, pd=pd, seed=seed_val, seed_dev=seed_dev, shared=1 if shared_mask else 0,
+                  dims=(B, T, C, H, W, n_head, ah, aw))
+        if odd_heads is not None:
+            sv["any"] = odd_heads              # (no geometry scope to re-enter, no tail to zero)
+        else:
+            fix_tail(g, None, 2, B * C)
+            sv["geom"] = geom
+        return g, sv, gpart
     if H <= aw and (H, W) != (ah, aw):
         # the reference's AvgPool branch (uncrtaints.py:197-204): the attention is pooled down to the feature map, no dropout.
         # (At equal size the pooling is the identity and the streaming kernel below serves it.)
@@ -1628,15 +1640,16 @@ def aggregate_backward(dg: Tensor, sv: dict):
     """-> de [B,T,C,H,W] (freshly written), datt [nh,B,T,ah,aw]"""
     B, T, C, H, W, n_head, ah, aw = sv["dims"]
     dev = dg.device
-    geom = sv.get("geom")
+    geom = sv.get("geom") or sv.get("any")
     if geom is not None:
         de = _f32((B, T, C, H, W), dev)
         datt_up = _f32((n_head * B * T, geom.P), dev)
         datt = _f32((n_head, B, T, ah, aw), dev)
         hb.call("uncr_aggregate_any_bwd", dg.contiguous().float(), sv["e"], sv["att"], sv["pad"], sv["dmask"], sv["seed"], sv["seed_dev"],
                 sv["pd"], sv["shared"], de, datt_up, datt, B, T, C, n_head, geom.H, geom.W, geom.Pc, ah, aw, _stream())
-        with geom_scope(geom):
-            fix_tail(de.view(B * T, C, H, W), None, 2, B * T * C)
+        if "geom" in sv:
+            with geom_scope(geom):
+                fix_tail(de.view(B * T, C, H, W), None, 2, B * T * C)
         return de, datt
     if "pool_k" in sv:
         de, datt = _f32((B, T, C, H, W), dev), _f32((n_head, B, T, ah, aw), dev)
@@ -1957,7 +1970,7 @@ def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int,
     agg = sv["agg"]
     # (fp32 storage: 342 -> 304 us for the pair of full-resolution launches; bf16 storage keeps the one-pass kernel + the four-chunk
     # scatter: its 8-byte rows leave the second pass short of bytes in flight, 214 -> 302 us)
-    if (_AGG_TWO_PASS and mode in ("att_group", "att_mean") and "pool_k" not in agg and "geom" not in agg and e_h3 is not None
+    if (_AGG_TWO_PASS and mode in ("att_group", "att_mean") and "pool_k" not in agg and "geom" not in agg and "any" not in agg and e_h3 is not None
             and _dt(agg["e"]) == F32
             and e_h3.numel() == agg["e"].numel() and e_h3.dtype == agg["e"].dtype and e_h3.is_contiguous()
             and hb.query("uncr_aggregate_bwd_de_supported", agg["dims"][3], agg["dims"][4], sv["att_down"], sv["att_down"]) == 1):

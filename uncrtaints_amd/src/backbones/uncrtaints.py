@@ -481,9 +481,10 @@ class UNCRTAINTS(nn.Module):
             assert encoder_widths[-1] == decoder_widths[-1]
         else:
             decoder_widths = encoder_widths
-        if not is_mono and (encoder_widths[-1] % n_head or encoder_widths[-1] // n_head not in (2, 4, 6, 8, 16, 32)):
-            raise NotImplementedError(f"encoder width {encoder_widths[-1]} with n_head={n_head}: the L-TAE / aggregation kernels are built "
-                                      "for 2, 4, 6, 8, 16 or 32 channels per head")
+        if not is_mono and (encoder_widths[-1] % n_head or encoder_widths[-1] // n_head > 32):
+            # (2, 4, 6, 8, 16 or 32 channels per head take the streaming aggregation kernels, other counts the scalar ones)
+            raise NotImplementedError(f"encoder width {encoder_widths[-1]} with n_head={n_head}: the L-TAE kernels take at most 32 channels "
+                                      "per head, and the width must divide into the heads (uncrtaints.py:206)")
         # d_model beyond 256 runs wherever the fused L-TAE kernels apply (use_v off: the d_model-wide projections are folded into one
         # [n_head, C] functional and never exist as activations, csrc/ltae_fused.hip); the unfused path's GEMMs end at 256 channels
         # MBConv blocks wider than 128 channels (hidden width > 256) run with the hidden axis in groups (engine._mbconv_forward_wide)
