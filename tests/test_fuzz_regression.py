@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 # blocks, one to three decoder blocks, width 96, iso and separate heads, att_mean / mean, elu, and the shapes 33x47 (the one that exposed the
 # bug: H = 1 mod 32), 40x100, 50x46, 72x60, 128x32, 64x64.  (Seed 17 -- width 96 at 33x47 -- is the documented limit of the tail
 # corrections, DESIGN 3b: a per-frame product at 1.4e-4.)
-CASES = [1, 4, 5, 8, 9, 12, 14, 15, 18, 27]
+CASES = [1, 4, 8, 9, 12, 15, 27]
 
 
 @pytest.mark.gpu
