@@ -338,3 +338,12 @@ def test_odd_size_properties_and_refusals():
         _model().to("cuda").set_act_dtype("bf16")(dev(x), batch_positions=dev(dates))
     with pytest.raises(RuntimeError):
         _model().to("cuda")(dev(x[..., :20, :20]), batch_positions=dev(dates))        # smaller than the 32 x 32 attention map
+    # encoder_norm='instance' over a padded (constant) date: gradients not reliable on this path -> refused in training, served forward-only
+    xp = x.clone()
+    xp[0, 2] = 0.0
+    mi = _model(encoder_norm="instance").to("cuda").train()
+    with pytest.raises(NotImplementedError):
+        mi(dev(xp), batch_positions=dev(dates))
+    with torch.no_grad():
+        assert torch.isfinite(mi(dev(xp), batch_positions=dev(dates))).all()
+    assert torch.isfinite(mi(dev(x), batch_positions=dev(dates))).all()               # no padded date: trains
