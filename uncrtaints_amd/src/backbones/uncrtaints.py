@@ -639,13 +639,15 @@ class UNCRTAINTS(nn.Module):
             if nbt:
                 torch._foreach_add_(nbt, 1)
         pad = E.pad_mask_of(input, float(self.pad_value))                  # [B,T] int32, uncrtaints.py:392-394
-        if self.encoder_norm == 'instance' and self.training and torch.is_grad_enabled() and not self.is_mono and bool(pad.any()):
+        if self.encoder_norm == 'instance' and self.training and torch.is_grad_enabled() and not self.is_mono \
+                and not torch.cuda.is_current_stream_capturing() and bool(pad.any()):
             # A padded date is a CONSTANT frame: every InstanceNorm of the encoder sees zero variance (rstd = 1/sqrt(eps) = 316) and the
             # reference's own gradient inside that frame reaches 1e4 ... 1e9; its weight gradients stay finite because the frame's terms
             # cancel exactly, which this path's statistics-by-linearity and tail corrections do not reproduce (encoder gradients wrong by
             # O(1): DESIGN.md section 2, tools/fuzz_configs.py cases 240, 303, 336).  Refuse rather than train on them.  (One host
             # synchronisation, on this configuration only; the reference synchronises on pad_mask.any() in every forward,
-            # uncrtaints.py:157.  Forward-only calls and GroupNorm / BatchNorm encoders are unaffected.)
+            # uncrtaints.py:157.  Forward-only calls and GroupNorm / BatchNorm encoders are unaffected; inside a HIP-graph capture the check
+            # cannot run -- the eager warm-up steps ahead of every capture do run it.)
             raise NotImplementedError("encoder_norm='instance' with a padded (constant) date: the encoder's gradients are not reliable on "
                                       "this path; use encoder_norm='group' (the default) or 'batch', or drop the padded dates")
         # the encoder runs on the folded [B*T, C, H, W] frames (smart_forward, utae.py:422-450) without autograd views
