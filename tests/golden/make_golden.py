@@ -507,6 +507,43 @@ def case_ltae2d_deep():
     print("g21_ltae2d_deep", len(out), "arrays")
 
 
+def case_ltae2d_nomodel():
+    """G22: the reference LTAE2d without its input projection (d_model=None, ltae.py:49-54: the attention and the values work on the
+    in_channels themselves), eval and train, a padded date -- small: 64 channels, 8 heads."""
+    from src.backbones import ltae as R
+    out = {}
+    gen = torch.Generator().manual_seed(22)
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    C, nh, dk, B, T, hw, mlp = 64, 8, 4, 1, 2, 32, [64, 32]
+    torch.manual_seed(220)
+    mod = R.LTAE2d(in_channels=C, n_head=nh, d_k=dk, mlp=mlp, dropout=0.0, d_model=None, return_att=True, use_dropout=False)
+    with torch.no_grad():
+        mod.in_norm.weight.copy_(1.0 + 0.3 * rn(C)); mod.in_norm.bias.copy_(0.2 * rn(C))
+        mod.out_norm.weight.copy_(1.0 + 0.3 * rn(mlp[-1])); mod.out_norm.bias.copy_(0.2 * rn(mlp[-1]))
+        mod.mlp[1].weight.copy_(1.0 + 0.3 * rn(mlp[1])); mod.mlp[1].bias.copy_(1.5 + 0.2 * rn(mlp[1]))
+        mod.mlp[1].running_mean.copy_(0.1 * rn(mlp[1])); mod.mlp[1].running_var.copy_(0.5 + torch.rand(mlp[1], generator=gen))
+        mod.attention_heads.fc1_k.bias.copy_(0.3 * rn(nh * dk))
+    state0 = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    x0 = rn(B, T, C, hw, hw)
+    dates = torch.sort(torch.randint(1400, 1800, (B, T), generator=gen), dim=1).values.float()
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    gv, ga = rn(B, mlp[-1], hw, hw), rn(nh, B, T, hw, hw)
+    out.update({"mlp": np.array(mlp), "x": x0.numpy(), "dates": dates.numpy(), "pad": pad.numpy(), "gv": gv.numpy(), "ga": ga.numpy()})
+    out.update({f"state/{k}": v.numpy() for k, v in state0.items()})
+    for i, training in enumerate((False, True)):
+        mod.load_state_dict(state0)
+        mod.zero_grad()
+        mod.train(training)
+        x = x0.clone().requires_grad_(True)
+        o, a = mod(x, batch_positions=dates, pad_mask=pad)
+        ((o * gv).sum() + (a * ga).sum()).backward()
+        out.update({f"run{i}/training": np.array(training), f"run{i}/out": o.detach().numpy(), f"run{i}/attn": a.detach().numpy(),
+                    f"run{i}/dx": x.grad.numpy()})
+        out.update({f"run{i}/grad/{k}": p.grad.numpy().copy() for k, p in mod.named_parameters() if p.grad is not None})
+    np.savez_compressed(os.path.join(HERE, "g22_ltae2d_nomodel.npz"), **out)
+    print("g22_ltae2d_nomodel", len(out), "arrays")
+
+
 def case_posenc():
     pe = PositionalEncoder(256 // 16, T=1000, repeat=16)
     dates = torch.tensor([[1400., 1433., 1799.], [0., 1., 1000.]])
@@ -854,6 +891,8 @@ if __name__ == "__main__":
     case_attention_rows(); sys.exit(0)
   if "--only-ltae2d-deep" in sys.argv:
     case_ltae2d_deep(); sys.exit(0)
+  if "--only-ltae2d-nomodel" in sys.argv:
+    case_ltae2d_nomodel(); sys.exit(0)
   if "--only-usev" in sys.argv:
     case_usev(); sys.exit(0)
   if "--only-usev-modes" in sys.argv:
@@ -871,6 +910,7 @@ if __name__ == "__main__":
     case_aggpool()
     case_attention_rows()
     case_ltae2d_deep()
+    case_ltae2d_nomodel()
     case_usev()
     case_usev_modes()
     case_residual()

@@ -292,3 +292,32 @@ def test_oracle_ltae2d_two_layer_mlp_vs_reference_fixture(i):
             assert rel_err(mine.numpy(), ref) < 2e-4, name
         if training and k.startswith(pre + "after/"):
             assert rel_err(p["temporal_encoder." + k[len(pre + "after/"):]].detach().numpy(), g[k]) < 2e-5, k
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_oracle_ltae2d_without_input_projection_vs_reference_fixture(i):
+    """G22 (reference LTAE2d(d_model=None), ltae.py:49-54: attention and values on the input channels themselves), eval and train."""
+    import torch
+    from oracle import uncrtaints_oracle as orc
+    g, pre = load_golden("g22_ltae2d_nomodel"), f"run{i}/"
+    training = bool(g[pre + "training"])
+    p = {"temporal_encoder." + k[len("state/"):]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith("state/")}
+    assert "temporal_encoder.inconv.weight" not in p
+    for k, v in p.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    nh, dk = p["temporal_encoder.attention_heads.Q"].shape
+    C = p["temporal_encoder.in_norm.weight"].numel()
+    cfg = orc.OracleConfig(n_head=nh, d_k=dk, d_model=C, ltae_dropout=0.0)
+    x = torch.from_numpy(g["x"]).clone().requires_grad_(True)
+    v, a = orc.ltae2d_values_attention(x, torch.from_numpy(g["dates"]), torch.from_numpy(g["pad"]), p, cfg, training)
+    assert rel_err(v.detach().numpy(), g[pre + "out"]) < 2e-5
+    assert rel_err(a.detach().numpy(), g[pre + "attn"]) < 2e-5
+    ((v * torch.from_numpy(g["gv"])).sum() + (a * torch.from_numpy(g["ga"])).sum()).backward()
+    assert rel_err(x.grad.numpy(), g[pre + "dx"]) < 1e-4
+    for k in g.files:
+        if k.startswith(pre + "grad/"):
+            name, ref = k[len(pre + "grad/"):], g[k]
+            if name.endswith(".bias") and np.abs(ref).max() < 1e-3 * np.abs(g[pre + "grad/" + name.replace(".bias", ".weight")]).max():
+                continue        # mathematically zero gradients: rounding noise on both sides
+            assert rel_err(p["temporal_encoder." + name].grad.numpy(), ref) < 2e-4, name

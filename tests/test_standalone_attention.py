@@ -323,3 +323,35 @@ def test_ltae2d_two_layer_mlp_vs_reference_fixture(i):
         for k in g.files:
             if k.startswith(pre + "after/"):
                 close("g21 LTAE2d " + k, m.state_dict()[k[len(pre + "after/"):]], _t(g, k))
+
+
+# ---- LTAE2d without its input projection (d_model=None, ltae.py:49-54): fixture g22_ltae2d_nomodel written by the reference ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", [0, 1])
+def test_ltae2d_without_input_projection_vs_reference_fixture(i):
+    from conftest import load_golden
+    from uncrtaints_amd.src.backbones.ltae import LTAE2d
+    g, pre = load_golden("g22_ltae2d_nomodel"), f"run{i}/"
+    training = bool(g[pre + "training"])
+    state = {k[len("state/"):]: _t(g, k) for k in g.files if k.startswith("state/")}
+    C = state["in_norm.weight"].numel()
+    nh, dk = state["attention_heads.Q"].shape
+    m = LTAE2d(in_channels=C, n_head=nh, d_k=dk, mlp=[int(v) for v in g["mlp"]], dropout=0.0, d_model=None, return_att=True, use_dropout=False)
+    assert list(m.state_dict().keys()) == [k[len("state/"):] for k in g.files if k.startswith("state/")]
+    m.load_state_dict(state, strict=True)
+    m = m.to(DEV).train(training)
+    x = dev(_t(g, "x")).requires_grad_(True)
+    out, attn = m(x, batch_positions=dev(_t(g, "dates")), pad_mask=dev(_t(g, "pad")))
+    VT = 1e-4
+    close(f"g22 LTAE2d[train={training}] values", out, _t(g, pre + "out"), tol=VT)
+    close(f"g22 LTAE2d[train={training}] attn", attn, _t(g, pre + "attn"))
+    ((out * dev(_t(g, "gv"))).sum() + (attn * dev(_t(g, "ga"))).sum()).backward()
+    close("g22 LTAE2d dx", x.grad, _t(g, pre + "dx"), tol=VT)
+    for k, par in m.named_parameters():
+        ref = _t(g, pre + "grad/" + k)
+        if k.endswith(".bias") and k != "out_norm.bias":
+            sib_ref = _t(g, pre + "grad/" + k.replace(".bias", ".weight"))
+            if float(ref.abs().max()) < 1e-3 * float(sib_ref.abs().max()):
+                assert float(par.grad.abs().max()) < 1e-3 * float(m.get_parameter(k.replace(".bias", ".weight")).grad.abs().max()), k
+                continue
+        close(f"g22 LTAE2d grad[{k}]", par.grad, ref, tol=VT)
