@@ -97,8 +97,13 @@ class Fp32Draws:
     first gradient that needs the second clause, and cached -- a test whose gradients all sit within 1e-4 of the fp32 reference never
     pays for them.  `extra`: evaluations that already exist (e.g. the reference-generated golden gradients of the fixture)."""
 
+    N_RUNS = 2        # further evaluations `get` performs: spelled-out formulas, one thread.  Frozen (tests/test_parity_rule.py):
+    MAX_EXTRA = 2     # every evaluation added here widens close_grad's allowance monotonically; `extra` holds at most the fixture's
+                      # golden gradient (the reference host's evaluation) and this host's first fp32 run
+
     def __init__(self, run, extra=()):
         self.run, self.extra, self.cache = run, list(extra), None
+        assert len(self.extra) <= self.MAX_EXTRA, "Fp32Draws: `extra` takes the golden gradient and the first fp32 run, nothing else"
 
     def get(self, key):
         if self.cache is None:
@@ -111,6 +116,7 @@ class Fp32Draws:
                 orc.USE_ATEN = True
                 torch.set_num_threads(1)
                 self.cache.append(self.run())
+                assert len(self.cache) == self.N_RUNS
             finally:
                 orc.USE_ATEN = True
                 torch.set_num_threads(nt)

@@ -32,6 +32,39 @@ def test_tolerance_and_noise_multiple_are_not_raised():
                 assert "noise=" not in m.group(1) and "tol=" not in m.group(1), (f, m.group(0))
 
 
+def test_the_set_of_fp32_draws_is_frozen():
+    """close_grad's scale is the LARGEST distance among the fp32 evaluations at hand, so every further evaluation widens the allowance
+    monotonically.  The set is therefore fixed: this host's first fp32 run (`ref32`), two more by `Fp32Draws.get` (spelled-out
+    formulas, one thread) and at most two pre-existing ones in `extra` (the fixture's golden gradient = the reference host's run, and
+    the first fp32 run itself); nothing else, at no call site."""
+    import ast
+    import os
+    assert Fp32Draws.N_RUNS == 2 and Fp32Draws.MAX_EXTRA == 2
+    src = inspect.getsource(Fp32Draws.get)
+    assert src.count("self.run()") == Fp32Draws.N_RUNS, "Fp32Draws.get performs exactly two further evaluations"
+    with pytest.raises(AssertionError):
+        Fp32Draws(lambda: {}, extra=[{}, {}, {}])
+    # close_grad reads nothing but ref32 and draws.get(key) into its scale
+    csrc = inspect.getsource(close_grad)
+    assert csrc.count("e_cpu = max(") == 1 and "draws.get(key)" in csrc
+    here = os.path.dirname(os.path.abspath(__file__))
+    sites = 0
+    for f in sorted(os.listdir(here)):
+        if not f.endswith(".py") or f in ("test_parity_rule.py", "gpu_util.py"):
+            continue
+        tree = ast.parse(open(os.path.join(here, f)).read())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Call) and getattr(node.func, "id", getattr(node.func, "attr", None)) == "Fp32Draws":
+                sites += 1
+                assert len(node.args) == 1, (f, node.lineno)
+                for kw in node.keywords:
+                    assert kw.arg == "extra", (f, node.lineno, kw.arg)
+                    # `extra` is a literal list of at most two entries (optionally `[...] if cond else []`)
+                    val = kw.value.body if isinstance(kw.value, ast.IfExp) else kw.value
+                    assert isinstance(val, ast.List) and len(val.elts) <= Fp32Draws.MAX_EXTRA, (f, node.lineno)
+    assert sites >= 5
+
+
 def _t(v):
     return torch.tensor(v, dtype=torch.float64)
 

@@ -40,17 +40,21 @@ def run(N, shape):
         fn()
     e0.record(); part, nbx, cop, cip = fn(); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3
-    s = part.view(N * nbx, -1)[:, :6].cpu()
-    tot = (s[:, 0] + s[:, 1] + s[:, 2])
-    start = s[:, 4]; end = s[:, 5]
-    span = ((end - start.min()) % (1 << 24)).max()
-    tick = float(span) / us if us > 0 else 0.0
-    f = lambda v: f"{v.mean() / tick:.1f}/{v.max() / tick:.1f}"
-    print(f"wgrad [{shape}] N={N}: {us:.1f} us, {N * nbx} blocks x {s[:, 3].mean():.0f} chunks; us mean/max: prologue {f(s[:, 0])} loop {f(s[:, 1])} "
-          f"epilogue {f(s[:, 2])} block total {f(tot)}; first-to-last start {float(((start - start.min()) % (1 << 24)).max()) / tick:.1f} us; "
-          f"per chunk {float((s[:, 1] / s[:, 3]).mean()) / tick * 1e3:.0f} ns")
+    # s_memtime ticks at the constant 100 MHz reference clock: 0.01 us per tick (check: block total ~ kernel time)
+    s = part.view(N * nbx, -1)[:, :8].cpu().double() * 0.01
+    tot = s[:, 0] + s[:, 6] + s[:, 1] + s[:, 2]
+    f = lambda v: f"{v.mean():.1f}/{v.max():.1f}"
+    xcc = (s[:, 7] * 100).round().long()
+    spread = []
+    for x in range(8):      # the counters of different XCDs need not agree: start spread inside each XCD
+        st = (s[xcc == x, 4] * 100) % (1 << 24)
+        if st.numel():
+            spread.append(float(st.max() - st.min()) * 0.01)
+    print(f"wgrad [{shape}] N={N}: {us:.1f} us, {N * nbx} blocks x {s[:, 3].mean() * 100:.0f} chunks; us mean/max: coefficients {f(s[:, 0])} "
+          f"first chunk {f(s[:, 6])} loop {f(s[:, 1])} epilogue {f(s[:, 2])} block total {f(tot)}; start spread inside an XCD "
+          f"{max(spread) if spread else -1:.1f} us; per chunk {float((s[:, 1] / s[:, 3]).mean()) * 10:.0f} ns", flush=True)
 
 
 for shape in ("256x128", "128x256"):
-    for N in (2, 4, 12):
+    for N in (2, 4, 8, 12):
         run(N, shape)

@@ -148,6 +148,10 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
                 a[j] = (by.l0 * top + by.l1 * bot) * keep[j];
             }
             if constexpr (BWD && BMODE == 2) {
+                // statistics buffer of this (head, date): the parity of a counter that runs over the block's (head, date) pairs -- the date's
+                // parity alone meets itself between the last date of a head and date 0 of the next when T is odd and a block owns
+                // several heads (n_head > 64): waves 1-3 then rewrote the buffer wave 0 was still reducing
+                const int sb_ = ((h - h_beg) * g.T + t) & 1;
                 // pass 2: every load of this (head, date) -- the CH rows of h3 and the CH window indices -- is requested before the first
                 // dependent instruction (groups of at most 8 channels: 32 operand registers)
                 // Branch-free: a load under a per-lane branch costs an s_waitcnt vmcnt(0) at the join, and on gfx9 the stores share that counter --
@@ -195,22 +199,22 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
                             s1 = wave_sum_dpp(s1);
                             float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
                             if (g.amax) m = wave_max_dpp(m);
-                            if (lane == 63) { sred[t & 1][wv][jc][0] = s0; sred[t & 1][wv][jc][1] = s1; sred[t & 1][wv][jc][2] = m; }
+                            if (lane == 63) { sred[sb_][wv][jc][0] = s0; sred[sb_][wv][jc][1] = s1; sred[sb_][wv][jc][2] = m; }
                         }
                     }
                 }
                 if (g.bpart) {            // kernel-uniform: the CH planes of this (head, date), the four waves in order.  Two buffers by the
-                                          // date's parity: one barrier per date (a buffer is rewritten two barriers after it was read)
+                                          // pair counter's parity: one barrier per date (a buffer is rewritten two barriers after it was read)
                     __syncthreads();
                     if (threadIdx.x < CH) {
                         const int jc = threadIdx.x;
                         const size_t slot = (((size_t)b * g.T + t) * g.C + h * CH + jc) * gridDim.x + blockIdx.x;
                         float sa = 0.f, sb = 0.f;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { sa += sred[t & 1][i][jc][0]; sb += sred[t & 1][i][jc][1]; }
+                        for (int i = 0; i < 4; ++i) { sa += sred[sb_][i][jc][0]; sb += sred[sb_][i][jc][1]; }
                         g.bpart[slot] = make_float2(sa, sb);
-                        if (g.amax) g.amax[slot] = fmaxf(fmaxf(sred[t & 1][0][jc][2], sred[t & 1][1][jc][2]),
-                                                         fmaxf(sred[t & 1][2][jc][2], sred[t & 1][3][jc][2]));
+                        if (g.amax) g.amax[slot] = fmaxf(fmaxf(sred[sb_][0][jc][2], sred[sb_][1][jc][2]),
+                                                         fmaxf(sred[sb_][2][jc][2], sred[sb_][3][jc][2]));
                     }
                 }
                 continue;

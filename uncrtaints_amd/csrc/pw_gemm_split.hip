@@ -51,6 +51,9 @@ template <bool NT, typename TA> __device__ __forceinline__ void pws_st(TA* p, co
 #ifndef PWS_ABL
 #define PWS_ABL 0   // development ablations (tools/ablate_split.sh): 1 no stores, 2 no staging, 4 no activation loads, 8 no A reloads, 16 no MFMA, 32 no B reads, 64 no GELU
 #endif
+#ifndef PWS_MAP
+#define PWS_MAP 0
+#endif
 #define PWS_TP 128
 #define PWS_BUF 24576   // bytes per LDS stage: 3 parts x 32 ci x 128 px x 2 B (bf16 activations: 1 part, 8192 B)
 #define PWS_A16_WPARTS 2   // bf16 activations: leading weight parts used (2 = 16 significant bits: the weights stay fp32-grade,
@@ -154,7 +157,15 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     }
 
     // staging ownership: rows 4*cig .. 4*cig+3 of the chunk, pixels 4*sj .. 4*sj+3 of the tile
+#if PWS_MAP
+    // lane bits [2:0] = low pixel-quad bits, [3] = which 8-byte half of the 16-byte operand slot, [5:4] = high pixel-quad bits: the 16
+    // consecutive lanes that one ds_write_b64 cycle serves then fill 128 CONTIGUOUS bytes (8 slots x 2 halves) -- with the plain
+    // mapping (16 lanes = 16 slots, one half each: stride 16 B) lanes s and s + 8 meet on the same banks ((a / 4) mod 32 for
+    // 8-byte writes), a 2-way conflict on every staging write.  Global loads keep whole 128-byte lines per 8 lanes.
+    const int sj = (lane & 7) | ((lane >> 4) << 3), cig = 2 * wn + ((lane >> 3) & 1);
+#else
     const int sj = tid & 31, cig = tid >> 5;
+#endif
     const TA* inb = (const TA*)g.in + (size_t)n * Cin * P + 4 * sj;
     const TA* in2b = g.in2 ? (const TA*)g.in2 + (size_t)n * Cin * P + 4 * sj : inb;
     // LDS byte offset of this thread's 8-B half-slot for (part 0, e 0): ks = cig>>2, kg = (cig>>1)&1, half = cig&1

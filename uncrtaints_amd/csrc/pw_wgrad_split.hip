@@ -27,6 +27,12 @@
 #define WGS_PF 1       // raw chunks in flight per thread in the fp16-split kernel (1 | 2).  2 (254 VGPRs, no spill): 146 -> 138 us per
                        // launch in isolation at N = 4, 390 -> 386 at N = 12, the training step unchanged (4 + 3 interleaved pairs)
 #endif
+#ifndef WGS_ODD
+#define WGS_ODD 0
+#endif
+#ifndef WGS_ROT
+#define WGS_ROT 0
+#endif
 #ifndef WGS_ABL
 #define WGS_ABL 0      // development ablations (timing only, results wrong): 1 no global loads after the first two chunks, 2 no MFMA,
 #endif                 // 4 no staging (prologue arithmetic, split, LDS writes) after the first chunk
@@ -99,6 +105,18 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
     const int nch = P / 32;
     const int cbeg = (int)((long long)blockIdx.x * nch / gridDim.x), cend = (int)((long long)(blockIdx.x + 1) * nch / gridDim.x);
     const int nc = cend - cbeg;
+#if WGS_ROT
+    // the block starts WGS_ROT * blockIdx.x chunks into its range and wraps: concurrent blocks of a launch then do not request the same low
+    // address bits at the same time (their ranges start P / gridDim.x pixels apart: a power of two at N = 4)
+#if WGS_ROT == 99      // spread: the blocks of a frame start evenly distributed over their ranges
+    const int rot0 = (int)(((long long)blockIdx.x * nc / gridDim.x + n) % nc);
+#else
+    const int rot0 = (int)((unsigned)(blockIdx.x * WGS_ROT + n * 3) % (unsigned)nc);
+#endif
+#define WGS_CH(ch) ((ch) + rot0 < nc ? (ch) + rot0 : (ch) + rot0 - nc)
+#else
+#define WGS_CH(ch) (ch)
+#endif
 
     // loader mapping: piece i covers rows (tid>>3) + 64*i, float4 column c4 = tid & 7 of the 32-pixel chunk
     const int lrow = tid >> 3, c4 = tid & 7;
@@ -160,7 +178,7 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
     bool abl_first = true;
     auto load_piece = [&](int i, int ch, int set = 0) {   // i, set compile-time after unrolling; ch clamped by the caller
         if ((WGS_ABL & 1) && !abl_first) return;
-        const size_t po = (size_t)(cbeg + ch) * 32;
+        const size_t po = (size_t)(cbeg + WGS_CH(ch)) * 32;
         if (i < ND) {
             dv[set][i] = ld_nt4(dbase + (size_t)(64 * i) * P + po);
             if constexpr (D2) dv2[set][i] = ld_nt4(d2base + (size_t)(64 * i) * P + po);
@@ -235,6 +253,9 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
         else load_piece(i, nc > 1 ? 1 : 0);
     }
     __syncthreads();
+#ifdef WGS_STAMP
+    const unsigned long long ts1b = __builtin_readcyclecounter();      // first chunk staged (HBM latency of the block's first loads)
+#endif
     abl_first = false;
 
     // rolling operands (ah, am, bh re-read in place after their last use) and double-buffered single-use ones
@@ -374,8 +395,9 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
     __syncthreads();
     if (tid == 0) {   // (overwrites the first values of this block's partial: timing builds only)
         const unsigned long long ts3 = __builtin_readcyclecounter();
-        po[0] = (float)(ts1 - ts0); po[1] = (float)(ts2 - ts1); po[2] = (float)(ts3 - ts2); po[3] = (float)nc;
-        po[4] = (float)(ts0 & 0xFFFFFF); po[5] = (float)(ts3 & 0xFFFFFF);
+        po[0] = (float)(ts1 - ts0); po[1] = (float)(ts2 - ts1b); po[2] = (float)(ts3 - ts2); po[3] = (float)nc;
+        po[4] = (float)(ts0 & 0xFFFFFF); po[5] = (float)(ts3 & 0xFFFFFF); po[6] = (float)(ts1b - ts1);
+        po[7] = (float)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF);      // HW_REG_XCC_ID[3:0]
     }
 #endif
 }
@@ -396,6 +418,9 @@ int pw_wgrad_split_nbx(int N, int P) {
     int g = wgs_ncu() / N;
     if (g < 1) g = 1;
     if (g > P / 32) g = P / 32;
+#if WGS_ODD
+    if (g > 1 && (g & (g - 1)) == 0) g -= WGS_ODD;      // ranges that do not start a power of two apart
+#endif
     return g;
 }
 
