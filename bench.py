@@ -109,7 +109,7 @@ def kernel_model(name, key):
         N, C, H, W, act = key[-6:-1]
         return (f"dw_bwd[N{N},C{C},{H}x{W}]", (2.0 if act else 4.0) * N * C * H * W * 4, 36.0 * N * C * H * W, 0)
     if name == "uncr_ew":
-        op, planes, P, C, n_mean, act = key
+        op, planes, P, C, n_mean, act = key[:6]      # (then the valid-pixel count of padded planes)
         tensors = EW_TENSORS[op]
         nbytes = (2.0 if act else 4.0) * planes * P * tensors
         if op in (9, 12, 14):        # head backward: two fp32 inputs, output in the activation storage

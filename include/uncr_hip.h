@@ -110,9 +110,15 @@ int uncr_ew_slots(int P);
 /* act: storage of a, b, c, aux and out (the HEAD_* and RESIDUAL_RELU ops exist for fp32 only) */
 int uncr_ew(int op, const void* a, const void* b, const void* c, const void* aux, void* out,
             const float* k0, const float* k1, const float* k2, const float* k3, float* part, int planes, int P,
-            int C, int n_mean, float scale, float eps, int act, hipStream_t stream);
+            int C, int n_mean, float scale, float eps, int act,
+            int Pv /* pixels of a plane that carry data: P, or fewer on the padded planes of an any-size image (fp32): the rest is a
+                      zero tail on input, written as zeros, and left out of the statistics */,
+            hipStream_t stream);
 /* per-plane totals (fp64 accumulation, fixed order) of a [planes][slots] (sum0, sum1) partial array; either output may be null */
 int uncr_part_sums(const float* part, int slots, int planes, float* out0, float* out1, hipStream_t stream);
+/* out[n*C + c] = scale * mean of the statistics set of plane (n, c): groups > 0: mean [N*groups] (GroupNorm / InstanceNorm), 0: [C]
+ * (BatchNorm) -- per-plane pivots for the centred backward statistics and the centred weight-gradient products */
+int uncr_plane_means(const float* mean, int N, int C, int groups, float scale, float* out, hipStream_t stream);
 /* dst = src converted between the storage types (model input -> bf16 activations; bf16 input gradient -> fp32) */
 int uncr_cast(const void* src, void* dst, long long n, int src_dt, int dst_dt, hipStream_t stream);
 
@@ -154,6 +160,9 @@ int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, void* out, co
                   * With the bounds given the GEMM multiplies in two fp16 parts scaled by a per-frame power of two derived from
                   * them; without, in the exact bf16 split */
                  float* amax_out, const float* in_amax, int in_amax_n, const float* in2_amax, int in2_amax_n,
+                 int Pv /* pixels of a plane that carry data: P, or fewer on the padded planes of an any-size image (fp32 storage) --
+                           the statistics then leave out every pixel tile (uncr_pw_tile_px) that reaches beyond Pv; uncr_fix_tail
+                           behind the launch adds the boundary tile's valid pixels and zeroes the tail */,
                  hipStream_t stream);
 /* out_conv (Conv2d k=1 + bias, uncrtaints.py:432-440) with the output nonlinearities (uncrtaints.py:441-445) in the GEMM
  * epilogue, Cout <= 64: channel < |n_mean| -> n_mean > 0 ? scale*sigmoid : identity; the others -> var_mode 0 softplus(beta 1,
@@ -175,12 +184,15 @@ int uncr_pw_gemm_dx_supported(int Cin, int Cout);
 int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt, void* out, const float* k0, const float* k1,
                     const float* k2, const float* kmu, const void* dy, const void* x, const void* xh3, const float* c1,
                     const float* c2, const float* c3, const float* cmu /* out = dy + c1*da + c2*(x - cmu) + c3 */,
-                    const float* relu_a, const float* relu_b, float* part, int N, int Cin, int Cout, int P, int act,
+                    const float* relu_a, const float* relu_b,
+                    const float* relu_mu /* nullable [N*Cout], with relu_a AND relu_b: part = (sum out, sum out*(xh3 - relu_mu)), the
+                    centred statistics of that norm's backward (uncr_norm_finalize_bwd centered = 1) */,
+                    float* part, int N, int Cin, int Cout, int P, int act,
                     float* amax_out /* [N][uncr_pw_stat_slots] per-block max |out| or null (relu_a == null only) */,
                     const float* in_amax, int in_amax_n, const float* in2_amax, int in2_amax_n /* both or neither, fp32 storage:
                     bounds on |in| and |in2| per frame ([N][n]: per-block maxima or per-plane bounds, e.g. uncr_dw_bwd's amax_out and
                     uncr_norm_finalize_fwd's hb) -- the operand is then staged as two scaled fp16 parts, as in uncr_pw_gemm */,
-                    hipStream_t stream);
+                    int Pv /* as in uncr_pw_gemm */, hipStream_t stream);
 /* wpart [N*nbx][COP][CIP] = the per-block partials of the per-frame products R[n] = sum_p du1n*x (uncr_pw_wgrad with the raw x,
  * its reduction is done here); part_b / part_f = the (sum du1, .) and (sum h1, .) partials [N*Ch][NPB|NPF][2] (part_f may be
  * null: no c2 term); c1..c3 [N*Ch] = norm-1 backward coefficients; A0, B0 [N*C] = PreNorm forward coefficients.
@@ -190,7 +202,8 @@ int uncr_prenorm_bwd_finish(const float* wpart, int nbx, int COP, int CIP, const
                             const float* part_f, int NPF, const float* c1, const float* c2, const float* c3,
                             const float* cmu /* null: raw form; else part_f is required */, const float* A0,
                             const float* B0, float* part0, float* dW1, int N, int Ch /* % 4 == 0 */, int C /* % 32 == 0 */,
-                            int P, hipStream_t stream);
+                            int P, const float* xmu /* nullable [N*C]: wpart holds products with x - xmu (a per-plane pivot, e.g. the
+                            norm's mean); part0's second component is then the CENTRED sum da*(x - xmu) */, hipStream_t stream);
 int uncr_wgrad_shape(int Cd, int Cx, int* cop, int* cip);
 /* act: storage of d, d2, x.  bf16: the two wide shapes (256 x 128, 128 x 256) run one bf16 x bf16 product per MAC with fp32
  * accumulation (P % 64 == 0), every other shape the fp32 MFMA kernels.
@@ -204,7 +217,14 @@ int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const void* x2, 
                   float* part /* [N*NBX][COP][CIP] */, float* rs_part, int N, int Cd, int Cx, int P,
                   int NBX /* blocks (partials) per frame, from uncr_wgrad_nbx */, int pro_d, int pro_x, int act,
                   const float* d_amax, int d_amax_n, const float* d2_amax, int d2_amax_n, const float* x_ub,
+                  int Pv /* pixels of a plane that carry data: P, or fewer on the padded planes of an any-size image (fp32 storage) --
+                            the kernel then sums the whole 32-pixel chunks below Pv and uncr_wgrad_boundary adds the last Pv % 32 */,
                   hipStream_t stream);
+/* the last Pv % 32 pixels of every frame, added to the frame's first partial (and first row-sum partial) of a uncr_pw_wgrad launch with
+ * the same operands, prologues and NBX; a no-op when Pv % 32 == 0 */
+int uncr_wgrad_boundary(const float* d, const float* d2, const float* x, const float* dk0, const float* dk1, const float* dk2,
+                        const float* dkmu, const float* xk0, const float* xk1, const float* xk2, float* part, float* rs_part, int N,
+                        int Cd, int Cx, int P, int Pv, int NBX, int pro_d, int pro_x, hipStream_t stream);
 int uncr_wgrad_nbx(int N, int Cd, int Cx, int P, int pro_d, int pro_x, int rowsum, int act);
 int uncr_wgrad_reduce(const float* part, int n_out, int nblk_per_out, int COP, int CIP, int Cout, int Cin,
                       float* out, hipStream_t stream);
@@ -241,25 +261,19 @@ int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw,
 
 /* ---- any H x W (the reference takes any spatial size, uncrtaints.py:391-447).  For sizes outside the tuned tilings (H*W % 1024, W % 4)
  *      the host layer keeps full-resolution tensors as dense planes of H*W pixels + a ZERO tail up to the stride Pc =
- *      uncr_any_plane_stride(H, W) (0: the size needs none): flat kernels run over the whole stride, uncr_fix_* take the tail's share out
- *      of the reductions and re-zero it, the 2-D kernels below read and write valid pixels only (csrc/anysize.hip).  fp32 storage. ---- */
+ *      uncr_any_plane_stride(H, W) (0: the size needs none): flat kernels take the valid pixel count (Pv) next to the stride and keep the tail out
+ *      of every reduction (uncr_ew, uncr_pw_gemm + uncr_fix_tail, uncr_pw_wgrad + uncr_wgrad_boundary), the 2-D kernels below read and write valid pixels only (csrc/anysize.hip).  fp32 storage. ---- */
 int uncr_any_plane_stride(int H, int W);
 int uncr_dw_any_slots(int H, int W, int bwd); /* statistics slots (row bands) per plane of uncr_dw_fwd_any (bwd 0) / uncr_dw_bwd_any (1); -1: W too wide */
 int uncr_agg_any_slots(void);      /* ... of uncr_aggregate_any_fwd */
 int uncr_embed_tail(const float* src /* [planes][P] */, float* dst /* [planes][Pc] */, int planes, int P, int Pc, hipStream_t stream);
 int uncr_extract_tail(const float* src /* [planes][Pc] */, float* dst /* [planes][P] */, int planes, int P, int Pc, hipStream_t stream);
-/* t [planes][Pc] was written over its whole stride by a point-wise kernel fed with zero tails: every tail pixel of a plane holds one
- * value v.  mode 0: part [planes][slots] = (sum t, sum t^2) partials lose (n v, n v^2), n = Pc - P; mode 1: (sum t, sum t*aux) with aux
- * zero on the tail lose (n v, 0); mode 2 / part null: nothing.  Then the tail is zeroed. */
-int uncr_fix_tail(float* t, float* part, int slots, int planes, int P, int Pc, int mode, hipStream_t stream);
-int uncr_fix_sepool_tail(float* part, int slots, const float* cB /* [planes] */, int planes, int ntail, hipStream_t stream);
-int uncr_fix_wgrad_tail(float* G /* [N][Cd][Cx] */, int N, int Cd, int Cx, const float* c2, const float* c3, const float* mu /* [N*Cd], mu nullable */,
-                        const float* cB /* [N*Cx] */, int ntail, hipStream_t stream);
-/* ... a product summed over the frames whose x operand is A*x + B (B on the tail): dW [Cd][Cx] loses n_tail * sum_n (c3 - c2*mu)[n,co] * B[n,ci] */
-int uncr_fix_wgrad_tail_affine(float* dW, int N, int Cd, int Cx, const float* c2, const float* c3, const float* mu, const float* cB,
-                               int ntail, hipStream_t stream);
-int uncr_fix_rowsum_tail(float* rs /* [C] */, int N, int C, const float* c2, const float* c3, const float* mu /* [N*C], mu nullable */,
-                         int ntail, hipStream_t stream);
+/* t [planes][Pc] is the output of a pointwise GEMM launched with Pv = P < Pc: its statistics left out every `unit`-pixel tile that
+ * reaches into the tail.  Adds the valid pixels [P / unit * unit, P) of the boundary tile to the slot of the block that owned it --
+ * mode 0: (sum t, sum t^2); mode 1: (sum t, sum t*aux), aux [planes][Pc]; mode 2 / part null: nothing -- and zeroes the tail. */
+int uncr_fix_tail(float* t, const float* aux, float* part, int slots, int planes, int P, int Pc, int mode,
+                  int unit /* uncr_pw_tile_px(Cout) of the producing GEMM */,
+                  const float* pivot /* nullable [planes], mode 1: the second component is sum t*(aux - pivot) */, hipStream_t stream);
 /* depthwise 3x3 reflect (uncrtaints.py:130-131) with the meaning of uncr_dw_fwd / uncr_dw_bwd on dense H x W planes of stride Pc: row
  * bands staged through LDS on the padded grid, any width up to 3998 (forward) / 2281 (backward), the zero tail of the result written too;
  * part [N*C][uncr_dw_any_slots(H, W, bwd)][2], dw_part [N*C][uncr_dw_any_slots(H, W, 1)][9] */

@@ -1,11 +1,12 @@
 // Any H x W (the reference takes any spatial size, uncrtaints.py:391-447; the streaming kernels of this library tile a plane in
 // 1024-pixel / 128-pixel pieces of float4 lanes).  For sizes those tilings do not fit, the engine keeps every full-resolution tensor as
 // DENSE planes of H*W pixels followed by a ZERO TAIL up to the next multiple of 1024 (plane stride Pc):
-//   * the flat kernels (pointwise GEMMs, weight gradients, element-wise passes, SE pooling) run over the whole stride unchanged.  With
-//     zero inputs every tail pixel of a plane holds the same value f(0) after a point-wise kernel, so `uncr_fix_tail` behind the
-//     producer reads that value, takes n_tail * f(0) (and n_tail * f(0)^2) out of the plane's statistics slot and zeroes the tail;
-//     `uncr_fix_sepool_tail`, `uncr_fix_wgrad_tail` and `uncr_fix_rowsum_tail` are the analytic corrections of the three reductions
-//     whose tail term is not a plain statistic (SE pooling of gelu(B), the dW2 products, in_conv's bias gradient);
+//   * the flat kernels (pointwise GEMMs, weight gradients, element-wise passes, SE pooling) take the valid pixel count next to the
+//     stride and keep the tail OUT of every reduction: the element-wise family writes its tail as zeros and takes its statistics over
+//     valid pixels (ew.hip), the weight-gradient kernels sum whole 32-pixel chunks below the count and `uncr_wgrad_boundary` adds the
+//     rest, the pointwise GEMMs leave tiles that reach into the tail out of their statistics and `uncr_fix_tail` behind them adds
+//     the boundary tile's valid pixels and zeroes the tail (which holds f(0) until then).  Nothing is subtracted after the fact
+//     (rounds 5's analytic corrections took a coherent n_tail * f(0) term out of an fp32 sum whose valid terms cancel);
 //   * the 2-D kernels get scalar any-width variants that read and write valid pixels only: depthwise 3x3 forward / backward here, the
 //     adaptive max-pool with a plane stride in ltae.hip, the temporal aggregation in aggregate.hip;
 //   * `uncr_embed_tail` / `uncr_extract_tail` convert between the caller's dense tensors and the padded planes.
@@ -44,110 +45,47 @@ extern "C" int uncr_extract_tail(const float* src, float* dst, int planes, int P
     return UNCR_OK;
 }
 
-// mode 0: part = (sum t, sum t^2): both components lose the tail's share; mode 1: part = (sum t, sum t*aux) with aux zero on the tail:
-// the first component only; mode 2 (or part == null): zero the tail, no statistics.  One block per plane.
-__global__ __launch_bounds__(256) void fix_tail_kernel(float* __restrict__ t, float2* __restrict__ part, int slots, int P, int Pc,
-                                                       int mode) {
+// Behind a pointwise GEMM on padded planes (uncr_pw_gemm / uncr_pw_gemm_dx with Pv < P): the GEMM's statistics epilogue left out every
+// `unit`-pixel tile that reaches into the tail, so the BOUNDARY tile's valid pixels [P / unit * unit, P) are summed here -- from the
+// stored values, at most unit - 1 terms per plane, fp64 -- and added to the slot of the block that owned that tile; then the tail
+// (which holds the GEMM's f(0)) is zeroed.  mode 0: (sum t, sum t^2); mode 1: (sum t, sum t*aux); mode 2 (or part == null): zero the
+// tail only.  One block per plane.  Nothing is ever subtracted: a plane's statistics see its valid pixels only.
+__global__ __launch_bounds__(256) void fix_tail_kernel(float* __restrict__ t, const float* __restrict__ aux, float2* __restrict__ part,
+                                                       int slots, int P, int Pc, int mode, int unit, const float* __restrict__ pivot) {
     float* p = t + (size_t)blockIdx.x * Pc;
-    if (threadIdx.x == 0 && part && mode < 2 && P < Pc) {
-        const float v = p[P];                      // every tail pixel of the plane holds this value
-        const float n = (float)(Pc - P);
-        float2 s = part[(size_t)blockIdx.x * slots];
-        s.x -= n * v;
-        if (mode == 0) s.y -= n * v * v;
-        part[(size_t)blockIdx.x * slots] = s;
+    if (part && mode < 2) {
+        const int u0 = P / unit * unit;
+        const float* q = (mode == 1 && aux) ? aux + (size_t)blockIdx.x * Pc : p;
+        const double piv = (mode == 1 && pivot) ? (double)pivot[blockIdx.x] : 0.0;      // centred cross statistics: sum t*(aux - pivot)
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = u0 + threadIdx.x; i < P; i += 256) {
+            const double v = (double)p[i];
+            s0 += v;
+            s1 += v * ((double)q[i] - piv);
+        }
+        __shared__ double red[2][256];
+        red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+        __syncthreads();
+        for (int w = 128; w >= 1; w >>= 1) {
+            if (threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && u0 < P) {
+            const size_t slot = (size_t)blockIdx.x * slots + (size_t)((u0 / unit) % slots);
+            float2 s = part[slot];
+            s.x = (float)((double)s.x + red[0][0]);
+            s.y = (float)((double)s.y + red[1][0]);
+            part[slot] = s;
+        }
     }
-    __syncthreads();
     for (int i = P + threadIdx.x; i < Pc; i += 256) p[i] = 0.f;
 }
-extern "C" int uncr_fix_tail(float* t, float* part, int slots, int planes, int P, int Pc, int mode, hipStream_t stream) {
-    if (planes <= 0 || P <= 0 || Pc < P || (part && slots <= 0) || mode < 0 || mode > 2) return UNCR_ESHAPE;
+extern "C" int uncr_fix_tail(float* t, const float* aux, float* part, int slots, int planes, int P, int Pc, int mode, int unit,
+                             const float* pivot, hipStream_t stream) {
+    if (planes <= 0 || P <= 0 || Pc < P || (part && (slots <= 0 || unit <= 0)) || mode < 0 || mode > 2) return UNCR_ESHAPE;
     if (!t) return UNCR_EINVAL;
     if (Pc == P) return UNCR_OK;
-    hipLaunchKernelGGL(fix_tail_kernel, dim3(planes), dim3(256), 0, stream, t, (float2*)part, slots, P, Pc, mode);
-    UNCR_LAUNCH_CHECK();
-    return UNCR_OK;
-}
-
-// SE pooling partials (sum_p gelu(A*h2 + B), .) over a plane whose tail holds h2 = 0: take n_tail * gelu(B) out again
-__global__ __launch_bounds__(256) void fix_sepool_tail_kernel(float2* __restrict__ part, int slots, const float* __restrict__ cB,
-                                                              int planes, float ntail) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < planes) part[(size_t)i * slots].x -= ntail * gelu_f(cB[i]);      // the pass evaluated gelu(fma(A, 0, B)) = gelu(B) there
-}
-extern "C" int uncr_fix_sepool_tail(float* part, int slots, const float* cB, int planes, int ntail, hipStream_t stream) {
-    if (planes <= 0 || slots <= 0 || ntail < 0) return UNCR_ESHAPE;
-    if (!part || !cB) return UNCR_EINVAL;
-    if (ntail == 0) return UNCR_OK;
-    hipLaunchKernelGGL(fix_sepool_tail_kernel, dim3((planes + 255) / 256), dim3(256), 0, stream, (float2*)part, slots, cB, planes,
-                       (float)ntail);
-    UNCR_LAUNCH_CHECK();
-    return UNCR_OK;
-}
-
-// per-frame products G[n][co][ci] = sum_p dh[n,co,p] * z[n,ci,p] with dh = c1*dy + c2*(h3 - mu) + c3 and z = gelu(A*h2 + B), taken over a
-// stride whose tail holds dy = h3 = h2 = 0: the tail contributed n_tail * (c3 - c2*mu)[n,co] * gelu(B)[n,ci]
-__global__ __launch_bounds__(256) void fix_wgrad_tail_kernel(float* __restrict__ G, int Cd, int Cx, const float* __restrict__ c2,
-                                                             const float* __restrict__ c3, const float* __restrict__ mu,
-                                                             const float* __restrict__ cB, float ntail) {
-    const int n = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= Cd * Cx) return;
-    const int co = i / Cx, ci = i - co * Cx;
-    const float kap = fmaf(-c2[n * Cd + co], mu ? mu[n * Cd + co] : 0.f, c3[n * Cd + co]);
-    G[((size_t)n * Cd + co) * Cx + ci] -= ntail * kap * gelu_f(cB[n * Cx + ci]);
-}
-extern "C" int uncr_fix_wgrad_tail(float* G, int N, int Cd, int Cx, const float* c2, const float* c3, const float* mu, const float* cB,
-                                   int ntail, hipStream_t stream) {
-    if (N <= 0 || Cd <= 0 || Cx <= 0 || ntail < 0) return UNCR_ESHAPE;
-    if (!G || !c2 || !c3 || !cB) return UNCR_EINVAL;
-    if (ntail == 0) return UNCR_OK;
-    hipLaunchKernelGGL(fix_wgrad_tail_kernel, dim3((Cd * Cx + 255) / 256, N), dim3(256), 0, stream, G, Cd, Cx, c2, c3, mu, cB,
-                       (float)ntail);
-    UNCR_LAUNCH_CHECK();
-    return UNCR_OK;
-}
-
-// the same for a product summed over the frames whose x operand has an AFFINE prologue (pw1's weight gradient on the unfused path:
-// dW1[co][ci] = sum_{n,p} dh[n,co,p] * (A*x + B)[n,ci,p]): the tail contributed n_tail * sum_n (c3 - c2*mu)[n,co] * B[n,ci]
-__global__ __launch_bounds__(256) void fix_wgrad_tail_affine_kernel(float* __restrict__ dW, int N, int Cd, int Cx,
-                                                                    const float* __restrict__ c2, const float* __restrict__ c3,
-                                                                    const float* __restrict__ mu, const float* __restrict__ cB,
-                                                                    float ntail) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= Cd * Cx) return;
-    const int co = i / Cx, ci = i - co * Cx;
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n)
-        acc = fmaf(fmaf(-c2[n * Cd + co], mu ? mu[n * Cd + co] : 0.f, c3[n * Cd + co]), cB[n * Cx + ci], acc);
-    dW[i] -= ntail * acc;
-}
-extern "C" int uncr_fix_wgrad_tail_affine(float* dW, int N, int Cd, int Cx, const float* c2, const float* c3, const float* mu,
-                                          const float* cB, int ntail, hipStream_t stream) {
-    if (N <= 0 || Cd <= 0 || Cx <= 0 || ntail < 0) return UNCR_ESHAPE;
-    if (!dW || !c2 || !c3 || !cB) return UNCR_EINVAL;
-    if (ntail == 0) return UNCR_OK;
-    hipLaunchKernelGGL(fix_wgrad_tail_affine_kernel, dim3((Cd * Cx + 255) / 256), dim3(256), 0, stream, dW, N, Cd, Cx, c2, c3, mu, cB,
-                       (float)ntail);
-    UNCR_LAUNCH_CHECK();
-    return UNCR_OK;
-}
-
-// row sums db[co] = sum_{n,p} (c1*d + c2*(d2 - mu) + c3) over a stride whose tail holds d = d2 = 0
-__global__ __launch_bounds__(256) void fix_rowsum_tail_kernel(float* __restrict__ rs, int N, int C, const float* __restrict__ c2,
-                                                              const float* __restrict__ c3, const float* __restrict__ mu, float ntail) {
-    const int co = blockIdx.x * 256 + threadIdx.x;
-    if (co >= C) return;
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s += fmaf(-c2[n * C + co], mu ? mu[n * C + co] : 0.f, c3[n * C + co]);
-    rs[co] -= ntail * s;
-}
-extern "C" int uncr_fix_rowsum_tail(float* rs, int N, int C, const float* c2, const float* c3, const float* mu, int ntail,
-                                    hipStream_t stream) {
-    if (N <= 0 || C <= 0 || ntail < 0) return UNCR_ESHAPE;
-    if (!rs || !c2 || !c3) return UNCR_EINVAL;
-    if (ntail == 0) return UNCR_OK;
-    hipLaunchKernelGGL(fix_rowsum_tail_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, rs, N, C, c2, c3, mu, (float)ntail);
+    hipLaunchKernelGGL(fix_tail_kernel, dim3(planes), dim3(256), 0, stream, t, aux, (float2*)part, slots, P, Pc, mode, unit > 0 ? unit : 1, pivot);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -14,7 +14,7 @@ enum : int {
     EW_RESIDUAL = 3,     // out = a + A*b + B;                stats (sum out, sum out^2)   a=x, b=h3
     EW_PASSB = 4,        // out = gelu'(A*b + B) * (S*a + D); stats (sum out, sum out*b)   a=dz, b=h2
     EW_PASSE = 5,        // out = a + C1*b + C2*(c - M) + C3; stats (sum out, sum out*aux) a=dy, b=da, c=x (M = k3 or 0)
-    EW_RELU_BWD = 6,     // out = a * [A*b + B > 0];          stats (sum out, sum out*b)   a=d(a0), b=c0
+    EW_RELU_BWD = 6,     // out = a * [A*b + B > 0];          stats (sum out, sum out*(b - M))   a=d(a0), b=c0, M = k2 or 0
     EW_SE_POOL = 7,      // stats only: (sum gelu(A*a + B), 0)
     EW_HEAD_FWD = 8,     // out = c < n_mean ? scale*sigmoid(a) : softplus(a)+eps   (per-plane channel test)
     EW_HEAD_BWD = 9,     // out = a * f'(b)   a = d(out), b = pre-activation
@@ -44,6 +44,8 @@ struct EwArgs {
     const float* k3;
     float2* part;        // optional [N*C][NP]
     int P;
+    int Pv;              // pixels of a plane that carry data (P: all of them).  Pv < P = padded planes of an any-size image (anysize.hip):
+                         // pixels Pv .. P-1 hold zeros on input and are written as zeros; the statistics run over the first Pv pixels
     int C;               // channels per frame (HEAD ops)
     int n_mean;          // HEAD: number of mean channels
     float scale;         // HEAD: scale_by
@@ -59,6 +61,14 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
     float4 vo;
     float* o = (float*)&vo;
     const float* pa = (const float*)&va;
+    // padded planes: this thread's pixels from `nval` on belong to the zero tail (kernel-uniform test first: the dense sizes pay one
+    // scalar compare).  A point-wise result f(0) there is put back to zero BEFORE the statistics are taken from it.
+    const bool padded = g.Pv < g.P;
+    const int nval = g.Pv - (int)(blockIdx.x * EW_CHUNK + threadIdx.x * 4);
+#define EW_ZERO_TAIL()                                                         \
+    if (padded && nval < 4) {                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) o[i] = i < nval ? o[i] : 0.f; \
+    }
     if constexpr (OP == EW_STATS_SQ) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s0 += pa[i]; s1 += pa[i] * pa[i]; }
@@ -71,6 +81,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         const float A = g.k0[plane], B = g.k1[plane];
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = fmaxf(fmaf(A, pa[i], B), 0.f);
+        EW_ZERO_TAIL()
         vo = rnd4<T>(vo);       // statistics of the values as stored
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s0 += o[i]; s1 += o[i] * o[i]; }
@@ -78,6 +89,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         const float A = g.k0[plane], B = g.k1[plane];
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = fmaf(A, pa[i], B);
+        EW_ZERO_TAIL()
         vo = rnd4<T>(vo);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s0 += o[i]; s1 += o[i] * o[i]; }
@@ -88,12 +100,14 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         const float* pb = (const float*)&vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = fmaf(C1, pa[i], fmaf(C2, pb[i] - M, C3));
+        EW_ZERO_TAIL()
     } else if constexpr (OP == EW_RESIDUAL) {
         const float A = g.k0[plane], B = g.k1[plane];
         const float4 vb = ld_nt4t((const T*)g.b + off);
         const float* pb = (const float*)&vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = pa[i] + fmaf(A, pb[i], B);
+        EW_ZERO_TAIL()
         vo = rnd4<T>(vo);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s0 += o[i]; s1 += o[i] * o[i]; }
@@ -103,6 +117,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         const float* pb = (const float*)&vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = pa[i] + fmaxf(fmaf(A, pb[i], B), 0.f);
+        EW_ZERO_TAIL()
     } else if constexpr (OP == EW_PASSB) {
         const float A = g.k0[plane], B = g.k1[plane], S = g.k2[plane], D = g.k3[plane];
         const float4 vb = ld_nt4t((const T*)g.b + off);
@@ -112,6 +127,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
             const f32x2 r = gelu_grad_f2(fma2(f2(A), f2(pb[i], pb[i + 1]), f2(B))) * fma2(f2(S), f2(pa[i], pa[i + 1]), f2(D));
             o[i] = r.x; o[i + 1] = r.y;
         }
+        EW_ZERO_TAIL()
         vo = rnd4<T>(vo);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s0 += o[i]; s1 += o[i] * pb[i]; }
@@ -124,6 +140,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         const float* pc = (const float*)&vc;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = pa[i] + fmaf(C1, pb[i], fmaf(C2, pc[i] - M, C3));
+        EW_ZERO_TAIL()
         vo = rnd4<T>(vo);
         if (g.part) {
             const float4 vx = ld_nt4t((const T*)g.aux + off);
@@ -133,12 +150,13 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         }
     } else if constexpr (OP == EW_RELU_BWD) {
         const float A = g.k0[plane], B = g.k1[plane];
+        const float M = g.k2 ? g.k2[plane] : 0.f;      // pivot of the second statistic (the norm's mean: centred norm backward)
         const float4 vb = ld_nt4t((const T*)g.b + off);
         const float* pb = (const float*)&vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             o[i] = fmaf(A, pb[i], B) > 0.f ? pa[i] : 0.f;      // a is already a stored value: nothing to round
-            s0 += o[i]; s1 += o[i] * pb[i];
+            s0 += o[i]; s1 += o[i] * (pb[i] - M);
         }
     } else if constexpr (OP == EW_SE_POOL) {
         const float A = g.k0[plane], B = g.k1[plane];
@@ -148,8 +166,13 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs g) {
         for (int i = 0; i < 4; i += 2) {
             const f32x2 u = fma2(f2(A), f2(pa[i], pa[i + 1]), f2(B));
             const f32x2 hu = f2(0.5f) * u, pe = f2(1.0f) + erf_f2(u * f2(0.70710678118654752440f));
-            s0 = fmaf(hu.x, pe.x, s0);
-            s0 = fmaf(hu.y, pe.y, s0);
+            if (padded && nval < 4) {         // a tail pixel would add gelu(B)
+                if (i < nval) s0 = fmaf(hu.x, pe.x, s0);
+                if (i + 1 < nval) s0 = fmaf(hu.y, pe.y, s0);
+            } else {
+                s0 = fmaf(hu.x, pe.x, s0);
+                s0 = fmaf(hu.y, pe.y, s0);
+            }
         }
     } else if constexpr (ew_is_head_fwd(OP)) {
         // n_mean > 0: first n_mean channels get scale*sigmoid; n_mean < 0: first |n_mean| channels identity
@@ -283,13 +306,14 @@ extern "C" int uncr_part_sums(const float* part, int slots, int planes, float* o
 
 extern "C" int uncr_ew(int op, const void* a, const void* b, const void* c, const void* aux, void* out,
                        const float* k0, const float* k1, const float* k2, const float* k3, float* part, int planes,
-                       int P, int C, int n_mean, float scale, float eps, int act, hipStream_t stream) {
-    if (planes <= 0 || P <= 0 || (P % EW_CHUNK) != 0) return UNCR_ESHAPE;
+                       int P, int C, int n_mean, float scale, float eps, int act, int Pv, hipStream_t stream) {
+    if (planes <= 0 || P <= 0 || (P % EW_CHUNK) != 0 || Pv <= 0 || Pv > P) return UNCR_ESHAPE;
+    if (Pv < P && (act != UNCR_F32 || op == EW_SE_POOL4)) return UNCR_EINVAL;      // padded planes: fp32 storage, one chunk per block
     if (!a || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
     // HEAD_FWD* / RESIDUAL_RELU exist for fp32 storage only; HEAD_BWD*: a, b are fp32 (model output side), `act` is the storage
     // of the OUTPUT (the gradient w.r.t. the head's pre-activation, an activation gradient)
     if (act == UNCR_BF16 && (ew_is_head_fwd(op) || op == EW_RESIDUAL_RELU)) return UNCR_EINVAL;
-    EwArgs g{a, b, c, aux, out, k0, k1, k2, k3, (float2*)part, P, C, n_mean, scale, eps};
+    EwArgs g{a, b, c, aux, out, k0, k1, k2, k3, (float2*)part, P, Pv, C, n_mean, scale, eps};
     dim3 grid(P / EW_CHUNK, planes), blk(256);
 #define EW_CASE(OPV)                                                                                       \
     case OPV:                                                                                              \

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(
     }
     __shared__ double red[8];
     __shared__ float sh_mean, sh_rstd;
+    __shared__ int sh_flat;
     s = wave_sum_d(s);
     ss = wave_sum_d(ss);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -47,6 +48,17 @@ __global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(
         const double mean = S / M;
         double var = SS / M - mean * mean;
         if (var < 0) var = 0;
+        // InstanceNorm (one plane per statistics set) over a CONSTANT plane -- a zero-padded date behind in_conv: every plane of that
+        // frame holds its channel's bias, and every later plane of the frame a constant again: exact arithmetic (and the reference,
+        // whose Welford mean of a constant is that constant, uncrtaints.py:16-22) gives (h - mean) * rstd = 0 there, so the frame's
+        // activations are zero and it contributes nothing to any weight gradient.  The raw moments of fp32 slot sums cannot tell
+        // var = 0 from var ~ 1e-6 mean^2, and A*h + B with a rounded B would leave 1e-6-sized activations behind, which the frame's
+        // gradient (amplified by rstd = 1/sqrt(eps) = 316 per norm) turns into O(1) errors of the encoder's weight gradients.  A plane
+        // whose variance is below the resolution of its statistics (2^-17 mean^2) is therefore TREATED as constant: var = 0 and the
+        // coefficients of the exact result, A = 0, B = beta.
+        const bool flat = Cg == 1 && var <= ldexp(mean * mean, -17);
+        if (flat) var = 0;
+        sh_flat = flat ? 1 : 0;
         sh_mean = (float)mean;
         sh_rstd = (float)(1.0 / sqrt(var + (double)eps));
         save_mean[n * G + g] = sh_mean;
@@ -55,8 +67,8 @@ __global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(
     __syncthreads();
     for (int c = threadIdx.x; c < Cg; c += 256) {
         const int ch = g * Cg + c;
-        const float a = gamma[ch] * sh_rstd;
-        const float b = beta[ch] - sh_mean * a;
+        const float a = sh_flat ? 0.f : gamma[ch] * sh_rstd;
+        const float b = sh_flat ? beta[ch] : beta[ch] - sh_mean * a;
         coefA[n * C + ch] = a;
         coefB[n * C + ch] = b;
         if (ub) ub[n * C + ch] = fmaf(fabsf(a), sqrtf(__uint_as_float(smax[c])), fabsf(b));
@@ -278,7 +290,8 @@ __global__ __launch_bounds__(1024) void prenorm_bwd_finish_kernel(
     const float* __restrict__ wpart, int nbx, int COP, int CIP, const float* __restrict__ W1,
     const float2* __restrict__ part_b, int NPB, const float2* __restrict__ part_f, int NPF, const float* __restrict__ c1,
     const float* __restrict__ c2, const float* __restrict__ c3, const float* __restrict__ cmu, const float* __restrict__ A0,
-    const float* __restrict__ B0, float2* __restrict__ part0, float* __restrict__ dW1, int N, int Ch, int C, int P) {
+    const float* __restrict__ B0, float2* __restrict__ part0, float* __restrict__ dW1, int N, int Ch, int C, int P,
+    const float* __restrict__ xmu) {
     // four frames per round: their loads are all in flight before the round's first barrier
     __shared__ double comb[4][8][128];
     __shared__ double sS[4][4];
@@ -333,7 +346,12 @@ __global__ __launch_bounds__(1024) void prenorm_bwd_finish_kernel(
 #pragma unroll
             for (int q = 0; q < 8; ++q) r += comb[f][q][e];
             const double R = (double)(float)r, S = sS[f][kk];
-            dwt[f][e] = (double)A0[n * C + c] * R + (double)B0[n * C + c] * S;
+            // xmu: the products were taken on x - m (m = xmu[n, c], the plane's pivot): R holds Rc = sum du1n*(x - m), and
+            // A0*(Rc + m*S) + B0*S = A0*Rc + (A0*m + B0)*S has no cancellation between two separately rounded sums when the
+            // plane sits many standard deviations from zero (or is constant: InstanceNorm over a padded date); the statistics'
+            // second component is then the centred sum da*(x - m)
+            const double m = xmu ? (double)xmu[n * C + c] : 0.0;
+            dwt[f][e] = (double)A0[n * C + c] * R + ((double)A0[n * C + c] * m + (double)B0[n * C + c]) * S;
             red[f][0][e] = w * S;
             red[f][1][e] = w * R;
         }
@@ -359,14 +377,14 @@ __global__ __launch_bounds__(1024) void prenorm_bwd_finish_kernel(
 extern "C" int uncr_prenorm_bwd_finish(const float* wpart, int nbx, int COP, int CIP, const float* W1, const float* part_b,
                                        int NPB, const float* part_f, int NPF, const float* c1, const float* c2,
                                        const float* c3, const float* cmu, const float* A0, const float* B0, float* part0,
-                                       float* dW1, int N, int Ch, int C, int P, hipStream_t stream) {
+                                       float* dW1, int N, int Ch, int C, int P, const float* xmu, hipStream_t stream) {
     if (N <= 0 || Ch <= 0 || (Ch & 3) || C <= 0 || (C & 31) || P <= 0 || nbx <= 0 || COP < Ch || CIP < C) return UNCR_ESHAPE;
     if (!wpart || !W1 || !part_b || NPB <= 0 || !c1 || !c2 || !c3 || !A0 || !B0 || !part0 || !dW1) return UNCR_EINVAL;
     if (part_f && NPF <= 0) return UNCR_EINVAL;
     if (cmu && !part_f) return UNCR_EINVAL;      // the centred form needs sum h1
     hipLaunchKernelGGL(prenorm_bwd_finish_kernel, dim3(C / 32, Ch / 4), dim3(1024), 0, stream, wpart, nbx, COP, CIP, W1,
                        (const float2*)part_b, NPB, (const float2*)part_f, NPF, c1, c2, c3, cmu, A0, B0, (float2*)part0, dW1, N, Ch,
-                       C, P);
+                       C, P, xmu);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -524,6 +542,24 @@ extern "C" int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, i
     } else {
         return UNCR_EINVAL;
     }
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+// out[n*C + c] = scale * mean of the statistics set plane (n, c) belongs to: groups > 0: mean [N*groups] (GroupNorm; groups == C:
+// InstanceNorm), groups == 0: mean [C] (BatchNorm).  The per-plane pivots of the centred backward statistics and of the centred
+// weight-gradient products where no per-plane array exists yet.
+__global__ __launch_bounds__(256) void plane_means_kernel(const float* __restrict__ mean, int N, int C, int groups, float scale,
+                                                          float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    out[i] = scale * (groups > 0 ? mean[n * groups + c / (C / groups)] : mean[c]);
+}
+extern "C" int uncr_plane_means(const float* mean, int N, int C, int groups, float scale, float* out, hipStream_t stream) {
+    if (N <= 0 || C <= 0 || groups < 0 || (groups > 0 && C % groups)) return UNCR_ESHAPE;
+    if (!mean || !out) return UNCR_EINVAL;
+    hipLaunchKernelGGL(plane_means_kernel, dim3((N * C + 255) / 256), dim3(256), 0, stream, mean, N, C, groups, scale, out);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -44,6 +44,11 @@ struct PwArgs {
     const float* in_amax = nullptr;
     const float* in2_amax = nullptr;
     int in_amax_n = 0, in2_amax_n = 0;
+    // padded planes of an any-size image (anysize.hip): pixels Pv .. P-1 of every plane are a tail that carries no data.  The statistics
+    // epilogues leave out every pixel tile that reaches into it (uncr_fix_tail behind the launch adds the boundary tile's valid pixels
+    // and zeroes the tail); 0 = P: dense planes
+    int Pv = 0;
+    const float* rmu = nullptr;   // epi 6: per-(n, co) pivot of the statistics' second component, sum out*(aux3 - rmu) (the norm's mean); null: 0
     const float* emu = nullptr;   // epi 5 / 6: mean of the PreNorm per (n, co): out = dy + e0*v + e1*(x - emu) + e2; null: 0
 };
 
@@ -121,7 +126,7 @@ bool pw_wgrad_split_supported(int Cd, int Cx, int pro_d, int pro_x, bool rowsum)
 int pw_wgrad_split_launch(const float* d, const float* d2, const float* x, const float* dk0, const float* dk1,
                           const float* dk2, const float* dkmu, const float* xk0, const float* xk1, const float* xk2, float* part,
                           int N, int Cd, int Cx, int P, int nbx, int pro_x, const float* d_amax, int d_amax_n,
-                          const float* d2_amax, int d2_amax_n, const float* x_ub, hipStream_t stream);
+                          const float* d2_amax, int d2_amax_n, const float* x_ub, int Pv, hipStream_t stream);
 
 // pw_wgrad_a16.hip: the same weight gradients from bf16 operands (one bf16 x bf16 product per MAC, fp32 accumulation)
 int pw_wgrad_a16_nbx(int N, int P);

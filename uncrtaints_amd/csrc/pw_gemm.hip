@@ -219,6 +219,7 @@ __global__ __launch_bounds__(64 * WN * WM, KCV == 32 ? 2 : 4) void pw_gemm_kerne
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                 for (int m = 0; m < WM; ++m) { s0 += red[m][c][0]; s1 += red[m][c][1]; }
+                if (g.Pv > 0 && px0 + TP > g.Pv) s0 = s1 = 0.f;      // a tile that reaches into an any-size plane's tail: uncr_fix_tail
                 g.part[((size_t)n * Cout + c) * gridDim.x + blockIdx.x] = make_float2(s0, s1);
             }
         }
@@ -245,6 +246,8 @@ struct WgArgs {
     int Cd, Cx, P, PXB;
     int pro_d, pro_x;
     const float* dk3 = nullptr;     // PRO_NORMBWD on d: the norm's mean per (n, co) (centred form), null: 0
+    int Pv = 0;                     // > 0: padded planes of an any-size image -- only the whole 32-pixel chunks below Pv are summed here
+                                    // (uncr_wgrad_boundary adds the last Pv % 32 pixels); 0: all P
 };
 
 __device__ __forceinline__ float4 apply_pro(int pro, float4 v, const float4& v2, float c0, float c1, float c2, float c3 = 0.f) {
@@ -286,7 +289,8 @@ __global__ __launch_bounds__(64 * WCO * WCI, 2) void pw_wgrad_kernel(WgArgs g) {
     const int n = blockIdx.y;
     const int P = g.P, Cd = g.Cd, Cx = g.Cx;
     const int pbeg = blockIdx.x * g.PXB;
-    const int nchunks = g.PXB / KP;
+    const int pend = g.Pv > 0 ? min(pbeg + g.PXB, g.Pv / KP * KP) : pbeg + g.PXB;
+    const int nchunks = pend > pbeg ? (pend - pbeg) / KP : 0;      // (0: a block that lies in the tail writes a zero partial)
     const int pro_d = g.pro_d, pro_x = g.pro_x;
 
     f32x16 acc[MT][NTL];
@@ -519,8 +523,10 @@ extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, vo
                             const void* aux,
                             const float* e0, const float* e1, const float* e2, const float* e3, float* part, int N,
                             int Cin, int Cout, int P, int pro, int epi, int in_dt, int out_dt, float* amax_out,
-                            const float* in_amax, int in_amax_n, const float* in2_amax, int in2_amax_n, hipStream_t stream) {
-    if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
+                            const float* in_amax, int in_amax_n, const float* in2_amax, int in2_amax_n, int Pv,
+                            hipStream_t stream) {
+    if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256 || Pv <= 0 || Pv > P) return UNCR_ESHAPE;
+    if (Pv < P && (in_dt != UNCR_F32 || out_dt != UNCR_F32)) return UNCR_EINVAL;      // padded planes: fp32 storage
     if ((in_amax && in_amax_n <= 0) || (in2_amax && in2_amax_n <= 0)) return UNCR_EINVAL;
     if (!in || !Wt || !out) return UNCR_EINVAL;
     if ((in_dt != UNCR_F32 && in_dt != UNCR_BF16) || (out_dt != UNCR_F32 && out_dt != UNCR_BF16)) return UNCR_EINVAL;
@@ -544,6 +550,7 @@ extern "C" int uncr_pw_gemm(const void* in, const void* in2, const float* Wt, vo
     g.amax_out = amax_out;
     g.in_amax = in_amax; g.in_amax_n = in_amax_n;
     g.in2_amax = in2_amax; g.in2_amax_n = in2_amax_n;
+    g.Pv = Pv < P ? Pv : 0;
     const int cp = pw_coutp(Cout);
     if (use_split(Cout)) {
         if (in_dt != out_dt) return UNCR_EINVAL;      // the wide kernels have one storage type for all activation operands
@@ -609,10 +616,11 @@ extern "C" int uncr_pw_gemm_dx_supported(int Cin, int Cout) { return (use_split(
 extern "C" int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt, void* out, const float* k0,
                                const float* k1, const float* k2, const float* kmu, const void* dy, const void* x,
                                const void* xh3, const float* c1, const float* c2, const float* c3, const float* cmu,
-                               const float* relu_a, const float* relu_b, float* part, int N, int Cin, int Cout, int P,
+                               const float* relu_a, const float* relu_b, const float* relu_mu, float* part, int N, int Cin, int Cout, int P,
                                int act, float* amax_out, const float* in_amax, int in_amax_n, const float* in2_amax,
-                               int in2_amax_n, hipStream_t stream) {
-    if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256) return UNCR_ESHAPE;
+                               int in2_amax_n, int Pv, hipStream_t stream) {
+    if (N <= 0 || Cin <= 0 || Cin > 256 || Cout <= 0 || Cout > 256 || Pv <= 0 || Pv > P) return UNCR_ESHAPE;
+    if (Pv < P && act != UNCR_F32) return UNCR_EINVAL;
     if (!in || !in2 || !Wt || !out || !dy || !x || !c1 || !c2 || !c3) return UNCR_EINVAL;
     if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
     if (xh3 && !part) return UNCR_EINVAL;
@@ -627,12 +635,14 @@ extern "C" int uncr_pw_gemm_dx(const void* in, const void* in2, const float* Wt,
              (xh3 || relu_x) ? (float2*)part : nullptr, 0, Cin, Cout, P, PRO_NORMBWD, relu_x ? 8 : (relu_a ? 6 : 5), dy, xh3};
     g.k3 = kmu;
     g.emu = cmu;
+    g.rmu = (relu_a && relu_b) ? relu_mu : nullptr;
     g.amax_out = amax_out;
     if ((in_amax && in_amax_n <= 0) || (in2_amax && in2_amax_n <= 0)) return UNCR_EINVAL;
     // both operand bounds given (fp32 storage): two scaled fp16 parts, as the dz GEMM
     g.h2 = in_amax != nullptr && in2_amax != nullptr;
     g.in_amax = in_amax; g.in_amax_n = in_amax_n;
     g.in2_amax = in2_amax; g.in2_amax_n = in2_amax_n;
+    g.Pv = Pv < P ? Pv : 0;
     return pw_split_launch_p3(g, N, pw_coutp(Cout), act, stream);
 }
 
@@ -670,10 +680,12 @@ extern "C" int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const
                              const float* dk1, const float* dk2, const float* dkmu, const float* xk0, const float* xk1,
                              const float* xk2, float* part, float* rs_part, int N, int Cd, int Cx, int P, int NBX,
                              int pro_d, int pro_x, int act, const float* d_amax, int d_amax_n, const float* d2_amax,
-                             int d2_amax_n, const float* x_ub, hipStream_t stream) {
+                             int d2_amax_n, const float* x_ub, int Pv, hipStream_t stream) {
     int cop, cip;
     const int shp = wg_shape(Cd, Cx, &cop, &cip);
-    if (shp < 0 || N <= 0 || NBX <= 0) return UNCR_ESHAPE;
+    if (shp < 0 || N <= 0 || NBX <= 0 || Pv <= 0 || Pv > P) return UNCR_ESHAPE;
+    if (Pv < P && act != UNCR_F32) return UNCR_EINVAL;      // padded planes: fp32 storage
+    const int pv = Pv < P ? Pv : 0;
     if (!d || !x || !part || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
     if (pro_d == PRO_NORMBWD && !d2) return UNCR_EINVAL;
     if (pro_x == PRO_NORMBWD) return UNCR_EINVAL;   // norm-backward form is only built for the D operand
@@ -684,13 +696,14 @@ extern "C" int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const
     if (act == UNCR_F32 && pw_wgrad_split_supported(Cd, Cx, pro_d, pro_x, rs_part != nullptr)) {
         if (!dk0 || !dk1 || !dk2 || !xk0 || !xk1) return UNCR_EINVAL;
         return pw_wgrad_split_launch((const float*)d, (const float*)d2, (const float*)x, dk0, dk1, dk2, dkmu, xk0, xk1, xk2, part, N,
-                                     Cd, Cx, P, NBX, pro_x, d_amax, d_amax_n, d2_amax, d2_amax_n, x_ub, stream);
+                                     Cd, Cx, P, NBX, pro_x, d_amax, d_amax_n, d2_amax, d2_amax_n, x_ub, pv, stream);
     }
     if (P % NBX) return UNCR_ESHAPE;
     const int PXB = P / NBX;
     if (PXB % 32) return UNCR_ESHAPE;
     WgArgs g{d, d2, x, x2, dk0, dk1, dk2, xk0, xk1, xk2, part, rs_part, Cd, Cx, P, PXB, pro_d, pro_x};
     g.dk3 = pro_d == PRO_NORMBWD ? dkmu : nullptr;
+    g.Pv = pv;
     dim3 grid(P / PXB, N);
     const size_t lds = (size_t)((cop + cip) * 36 + 4 * cop + 3 * cip) * sizeof(float);
     // bf16 operands on the fp32-MFMA kernels: every shape the two bf16-product kernels above do not take
@@ -719,6 +732,55 @@ extern "C" int uncr_pw_wgrad(const void* d, const void* d2, const void* x, const
 #undef WG_LAUNCH_AB
 #undef WG_LAUNCH_T
     }
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+// Padded planes of an any-size image (anysize.hip): the weight-gradient kernels sum the whole 32-pixel chunks below Pv; the last
+// Pv % 32 pixels of every frame are added here, into the frame's FIRST partial (and its first row-sum partial): plain fp32 products of
+// the same prologues, at most 31 terms per entry.  One thread per (co, ci); the operand rows come from L1 / L2.
+__global__ __launch_bounds__(256) void wgrad_boundary_kernel(WgArgs g, int nbx, int COP, int CIP) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.Cd * g.Cx) return;
+    const int co = i / g.Cx, ci = i - co * g.Cx;
+    const int p0 = g.Pv / 32 * 32, np = g.Pv - p0;
+    const float* dr = (const float*)g.d + ((size_t)n * g.Cd + co) * g.P + p0;
+    const float* d2r = g.d2 ? (const float*)g.d2 + ((size_t)n * g.Cd + co) * g.P + p0 : dr;
+    const float* xr = (const float*)g.x + ((size_t)n * g.Cx + ci) * g.P + p0;
+    const int di = n * g.Cd + co, xi = n * g.Cx + ci;
+    const float d0 = g.dk0 ? g.dk0[di] : 1.f, d1 = g.dk1 ? g.dk1[di] : 0.f, dmu = g.dk3 ? g.dk3[di] : 0.f;
+    const float dc2 = g.dk2 ? g.dk2[di] : (g.pro_d == PRO_AFFINE_GELU ? 1.f : 0.f);
+    const float x0 = g.xk0 ? g.xk0[xi] : 1.f, x1 = g.xk1 ? g.xk1[xi] : 0.f;
+    const float xc2 = g.xk2 ? g.xk2[xi] : (g.pro_x == PRO_AFFINE_GELU ? 1.f : 0.f);
+    auto pro = [](int kind, float v, float v2, float c0, float c1, float c2, float c3) -> float {
+        if (kind == PRO_AFFINE) return fmaf(c0, v, c1);
+        if (kind == PRO_AFFINE_GELU) return c2 * gelu_f(fmaf(c0, v, c1));
+        if (kind == PRO_NORMBWD) return fmaf(c0, v, fmaf(c1, v2 - c3, c2));
+        if (kind == PRO_AFFINE_RELU) return fmaxf(fmaf(c0, v, c1), 0.f);
+        return v;
+    };
+    float acc = 0.f, rs = 0.f;
+    for (int p = 0; p < np; ++p) {
+        const float a = pro(g.pro_d, dr[p], d2r[p], d0, d1, dc2, dmu);
+        acc = fmaf(a, pro(g.pro_x, xr[p], 0.f, x0, x1, xc2, 0.f), acc);
+        rs += a;
+    }
+    g.part[((size_t)n * nbx * COP + co) * CIP + ci] += acc;
+    if (g.rs_part && ci == 0) g.rs_part[(size_t)n * nbx * COP + co] += rs;
+}
+extern "C" int uncr_wgrad_boundary(const float* d, const float* d2, const float* x, const float* dk0, const float* dk1,
+                                   const float* dk2, const float* dkmu, const float* xk0, const float* xk1, const float* xk2,
+                                   float* part, float* rs_part, int N, int Cd, int Cx, int P, int Pv, int NBX, int pro_d, int pro_x,
+                                   hipStream_t stream) {
+    int cop, cip;
+    if (wg_shape(Cd, Cx, &cop, &cip) < 0 || N <= 0 || NBX <= 0 || Pv <= 0 || Pv > P) return UNCR_ESHAPE;
+    if (!d || !x || !part || (pro_d == PRO_NORMBWD && !d2) || pro_x == PRO_NORMBWD) return UNCR_EINVAL;
+    if (Pv % 32 == 0) return UNCR_OK;
+    WgArgs g{d, d2, x, nullptr, dk0, dk1, dk2, xk0, xk1, xk2, part, rs_part, Cd, Cx, P, 0, pro_d, pro_x};
+    g.dk3 = pro_d == PRO_NORMBWD ? dkmu : nullptr;
+    g.Pv = Pv;
+    hipLaunchKernelGGL(wgrad_boundary_kernel, dim3((Cd * Cx + 255) / 256, N), dim3(256), 0, stream, g, NBX, cop, cip);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

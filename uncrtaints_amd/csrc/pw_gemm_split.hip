@@ -52,7 +52,7 @@ template <bool NT, typename TA> __device__ __forceinline__ void pws_st(TA* p, co
 #define PWS_ABL 0   // development ablations (tools/ablate_split.sh): 1 no stores, 2 no staging, 4 no activation loads, 8 no A reloads, 16 no MFMA, 32 no B reads, 64 no GELU
 #endif
 #ifndef PWS_MAP
-#define PWS_MAP 0
+#define PWS_MAP 1
 #endif
 #define PWS_TP 128
 #define PWS_BUF 24576   // bytes per LDS stage: 3 parts x 32 ci x 128 px x 2 B (bf16 activations: 1 part, 8192 B)
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char xs[2][NPA * 8192];
     __shared__ float cf[PRO == PRO_NORMBWD ? 4 : 3][256];      // [3]: the norm's mean (centred norm backward)
     __shared__ float red[COUTP][2];
-    __shared__ float ecf[(EPI == 5 || EPI == 6 || EPI == 8) ? 6 : (EPI == 3 ? 5 : ((EPI == 9 || EPI == 10) ? 3 : 1))][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D ([5]: epi 5 / 6 / 8 mean); epi 9 / 10: A, B
+    __shared__ float ecf[EPI == 6 ? 7 : ((EPI == 5 || EPI == 8) ? 6 : (EPI == 3 ? 5 : ((EPI == 9 || EPI == 10) ? 3 : 1)))][COUTP];   // epilogue per-channel scalars: bias, then the epi-3 A, B, S, D ([5]: epi 5 / 6 / 8 mean); epi 9 / 10: A, B
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index as a scalar: row addresses stay in SGPRs
@@ -147,7 +147,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                 const int ci = n * Cout + cc;
                 ecf[1][c] = g.e0[ci]; ecf[2][c] = g.e1[ci]; ecf[3][c] = g.e2[ci];
                 { const float m = (g.emu ? g.emu : g.e2)[ci]; ecf[5][c] = g.emu ? m : 0.f; }
-                if constexpr (EPI == 6) { ecf[0][c] = g.bias[ci]; ecf[4][c] = g.e3[ci]; }   // ReLU mask: e3*aux3 + bias > 0
+                if constexpr (EPI == 6) {      // ReLU mask: e3*aux3 + bias > 0; [6]: the pivot of sum out*(aux3 - pivot)
+                    ecf[0][c] = g.bias[ci]; ecf[4][c] = g.e3[ci];
+                    const float m = (g.rmu ? g.rmu : g.e3)[ci];
+                    ecf[6][c] = g.rmu ? m : 0.f;
+                }
             }
             if constexpr (EPI == 9 || EPI == 10) {      // 9: out = relu(A*(v + bias) + B): a ConvLayer's norm + ReLU on the fresh accumulator; 10: out = aux + A*(v + bias) + B
                 const int ci = n * Cout + cc;
@@ -501,6 +505,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         // pass 1: bias / fused backward transform in place in the accumulators + statistics (aux loads in batches)
         // pass 2: float4 row stores, fire and forget; the next tile's chunks and weights were requested before them
         const int tile = bx + ti * G;
+        const bool tile_ok = g.Pv <= 0 || (tile + 1) * PWS_TP <= g.Pv;      // (any-size planes: no statistics from a tile that reaches into the tail)
         // address of (row, lane) = uniform row base (SGPR arithmetic) + one per-lane element offset
         const int loff = 4 * kg * P + tile * PWS_TP + 4 * j;
         int nco = n * Cout;
@@ -616,7 +621,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                         v.w = fmaf(rA, h.w, rB) > 0.f ? y.w + fmaf(e1, v.w, fmaf(e2, x.w - em, e3)) : 0.f;
                         v = rnd4<TA>(v);
                         s0 = v.x + v.y + v.z + v.w;
-                        s1 = v.x * h.x + v.y * h.y + v.z * h.z + v.w * h.w;
+                        const float rm = ecf[EPI == 6 ? 6 : 0][col];
+                        s1 = v.x * (h.x - rm) + v.y * (h.y - rm) + v.z * (h.z - rm) + v.w * (h.w - rm);
                     } else if constexpr (EPI == 8) {
                         // as 6 with the mask taken from x itself: x = relu(.) of the producing ConvLayer, so [x > 0] IS its ReLU mask and
                         // the layer's pre-norm tensor is not read (csrc/inconv.hip); statistics (sum du0, sum du0*x)
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
                     if constexpr (EPI != 0 && EPI != 4) {
                         s0 = half_wave_sum_dpp(s0);
                         s1 = half_wave_sum_dpp(s1);
-                        if (j == 31) { red[col][0] += s0; red[col][1] += s1; }   // this lane owns column col in the block
+                        if (j == 31 && tile_ok) { red[col][0] += s0; red[col][1] += s1; }   // this lane owns column col in the block
                     }
                 }
             };

@@ -80,8 +80,12 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_a16_kernel(WgaArgs g) {
     }
 
     u32x4_t dv[ND], dv2[ND], xv[NX];
+    // consecutive blocks of a frame start 5 chunks further into their ranges and wrap (pw_wgrad_split.hip, WGS_ROT: un-rotated blocks,
+    // whose ranges start a power of two apart, request the same low address bits at every moment)
+    const int rot0 = nc > 0 ? (int)((unsigned)(blockIdx.x * 5 + n * 3) % (unsigned)nc) : 0;
     auto load_piece = [&](int i, int ch) {   // i compile-time after unrolling; ch clamped by the caller
-        const size_t po = (size_t)(cbeg + ch) * 64;
+        const int cr = ch + rot0 < nc ? ch + rot0 : ch + rot0 - nc;
+        const size_t po = (size_t)(cbeg + cr) * 64;
         if (i < ND) {
             dv[i] = __builtin_nontemporal_load((const u32x4_t*)(dbase + (size_t)(64 * i) * P + po));
             dv2[i] = __builtin_nontemporal_load((const u32x4_t*)(d2base + (size_t)(64 * i) * P + po));

@@ -27,11 +27,12 @@
 #define WGS_PF 1       // raw chunks in flight per thread in the fp16-split kernel (1 | 2).  2 (254 VGPRs, no spill): 146 -> 138 us per
                        // launch in isolation at N = 4, 390 -> 386 at N = 12, the training step unchanged (4 + 3 interleaved pairs)
 #endif
-#ifndef WGS_ODD
-#define WGS_ODD 0
-#endif
 #ifndef WGS_ROT
-#define WGS_ROT 0
+#define WGS_ROT 5      // chunks by which consecutive blocks of a frame are rotated inside their pixel ranges (0: every block starts at its
+                       // range's first chunk).  The ranges start P / gridDim.x pixels apart -- 4 KB per row at N = 4 -- so un-rotated
+                       // blocks request the same low address bits at every moment.  Measured inside the training step, 9 interleaved
+                       // pairs (profiles/r06_ab_wgrot2.log): 11.11 -> 10.93 ms with 5, 10.96 with 7, 10.95 with an even spread; in
+                       // isolation on cold operands N = 4 does not move and N = 8 gains 11 % (r06_time_wgrad2.log)
 #endif
 #ifndef WGS_ABL
 #define WGS_ABL 0      // development ablations (timing only, results wrong): 1 no global loads after the first two chunks, 2 no MFMA,
@@ -50,6 +51,7 @@ struct WgsArgs {
     const float* d_amax; int d_amax_n;
     const float* d2_amax; int d2_amax_n;
     const float* x_ub;
+    int Pv;            // > 0: padded planes of an any-size image -- the whole 32-pixel chunks below Pv only (uncr_wgrad_boundary adds the rest)
 };
 
 // power of two bringing `bound` to [2^13, 2^14); 1 for a zero / non-finite bound (inf / NaN then propagate as in fp32)
@@ -102,21 +104,12 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
     const int wco = wv / WCI, wci = wv % WCI;
     const int n = blockIdx.y;
     const int P = g.P;
-    const int nch = P / 32;
+    const int nch = (g.Pv > 0 ? g.Pv : P) / 32;
     const int cbeg = (int)((long long)blockIdx.x * nch / gridDim.x), cend = (int)((long long)(blockIdx.x + 1) * nch / gridDim.x);
     const int nc = cend - cbeg;
-#if WGS_ROT
-    // the block starts WGS_ROT * blockIdx.x chunks into its range and wraps: concurrent blocks of a launch then do not request the same low
-    // address bits at the same time (their ranges start P / gridDim.x pixels apart: a power of two at N = 4)
-#if WGS_ROT == 99      // spread: the blocks of a frame start evenly distributed over their ranges
-    const int rot0 = (int)(((long long)blockIdx.x * nc / gridDim.x + n) % nc);
-#else
-    const int rot0 = (int)((unsigned)(blockIdx.x * WGS_ROT + n * 3) % (unsigned)nc);
-#endif
-#define WGS_CH(ch) ((ch) + rot0 < nc ? (ch) + rot0 : (ch) + rot0 - nc)
-#else
-#define WGS_CH(ch) (ch)
-#endif
+    // the block starts rot0 chunks into its range and wraps around (see WGS_ROT)
+    const int rot0 = nc > 0 ? (int)((unsigned)(blockIdx.x * WGS_ROT + n * 3) % (unsigned)nc) : 0;
+    auto rot_chunk = [&](int ch) { const int c = ch < 0 ? 0 : ch; return c + rot0 < nc ? c + rot0 : (c + rot0 < 2 * nc ? c + rot0 - nc : 0); };
 
     // loader mapping: piece i covers rows (tid>>3) + 64*i, float4 column c4 = tid & 7 of the 32-pixel chunk
     const int lrow = tid >> 3, c4 = tid & 7;
@@ -178,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_split_kernel(WgsArgs g) {
     bool abl_first = true;
     auto load_piece = [&](int i, int ch, int set = 0) {   // i, set compile-time after unrolling; ch clamped by the caller
         if ((WGS_ABL & 1) && !abl_first) return;
-        const size_t po = (size_t)(cbeg + WGS_CH(ch)) * 32;
+        const size_t po = (size_t)(cbeg + rot_chunk(ch)) * 32;
         if (i < ND) {
             dv[set][i] = ld_nt4(dbase + (size_t)(64 * i) * P + po);
             if constexpr (D2) dv2[set][i] = ld_nt4(d2base + (size_t)(64 * i) * P + po);
@@ -418,9 +411,6 @@ int pw_wgrad_split_nbx(int N, int P) {
     int g = wgs_ncu() / N;
     if (g < 1) g = 1;
     if (g > P / 32) g = P / 32;
-#if WGS_ODD
-    if (g > 1 && (g & (g - 1)) == 0) g -= WGS_ODD;      // ranges that do not start a power of two apart
-#endif
     return g;
 }
 
@@ -450,9 +440,9 @@ static int wgs_launch(const WgsArgs& g, dim3 grid, hipStream_t stream) {
 int pw_wgrad_split_launch(const float* d, const float* d2, const float* x, const float* dk0, const float* dk1,
                           const float* dk2, const float* dkmu, const float* xk0, const float* xk1, const float* xk2, float* part,
                           int N, int Cd, int Cx, int P, int nbx, int pro_x, const float* d_amax, int d_amax_n,
-                          const float* d2_amax, int d2_amax_n, const float* x_ub, hipStream_t stream) {
+                          const float* d2_amax, int d2_amax_n, const float* x_ub, int Pv, hipStream_t stream) {
     if (P % 32 || nbx < 1 || nbx > P / 32) return UNCR_ESHAPE;
-    WgsArgs g{d, d2, x, dk0, dk1, dk2, xk0, xk1, xk2, part, Cd, Cx, P, dkmu, d_amax, d_amax_n, d2_amax, d2_amax_n, x_ub};
+    WgsArgs g{d, d2, x, dk0, dk1, dk2, xk0, xk1, xk2, part, Cd, Cx, P, dkmu, d_amax, d_amax_n, d2_amax, d2_amax_n, x_ub, Pv};
     dim3 grid(nbx, N);
     // every bound at hand (and the shape the bounds are derived for): two fp16 parts, three products
     if (Cd == 128 && pro_x == PRO_AFFINE_GELU && d_amax && d_amax_n > 0 && d2_amax && d2_amax_n > 0 && x_ub)

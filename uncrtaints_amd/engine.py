@@ -81,6 +81,7 @@ class Part:
     masked: bool = False     # backward partials of a gradient that already carries the producer's ReLU mask (in_conv)
     amax: Optional[Tensor] = None   # [N][n] upper bounds on |value| per frame (per-block maxima of the producer), or None
     owner: tuple = ()        # (data_ptr, _version) of the tensor these partials describe (hand-offs between autograd nodes)
+    centered: bool = False   # backward partials whose second component is sum du*(h - mean) (the producer was given the norm's mean)
 
 
 def tag_part(t: Tensor, part: Optional["Part"], attr: str = "_uncr_bpart") -> None:
@@ -123,51 +124,50 @@ class Geom:
         return self.Pc - self.H * self.W
 
 
-_GEOM: Optional[Geom] = None
+# The active geometry lives in thread-local storage: autograd runs a device's backward on its own thread, and two models of
+# different sizes (train 256 x 256, validate 250 x 250; two streams) may be in flight in one process.  Every backward re-enters the
+# geometry its forward saved; nothing else about the scope is global (the kernels' variants follow from the arguments of each call).
+_GEOM_TLS = threading.local()
+
+
+def _geom() -> Optional[Geom]:
+    return getattr(_GEOM_TLS, "geom", None)
 
 
 def plan_geom(H: int, W: int) -> Optional[Geom]:
     """None when the tuned tilings take H x W as it is, else the padded-plane geometry."""
     pc = hb.query("uncr_any_plane_stride", H, W)
     if pc < 0:
-        raise RuntimeError(f"unsupported spatial size {H}x{W}")
+        raise NotImplementedError(f"unsupported spatial size {H}x{W}")
     if pc == 0:
         return None
-    if H < 32 or W < 32:
-        raise RuntimeError(f"unsupported spatial size {H}x{W}: at least 32x32 (the L-TAE stage pools to 32x32)")
     return Geom(H, W, pc)
 
 
 class geom_scope:
+    """`with geom_scope(geom):` -- the calls inside (on this thread) treat planes of geom.Pc pixels as padded planes of an H x W image."""
+
     def __init__(self, geom: Optional[Geom]):
         self.geom = geom
 
-    # Inside an any-size scope the GEMMs take the exact bf16 split: the magnitude bounds of the two-part fp16 route are maxima over
-    # statistics SLOTS, and fix_tail corrects a plane's first slot for a tail that lives in its last ones (the plane's SUM is what the
-    # normalisations need; a per-slot maximum would see one slot too small -- even negative -- and one too large).
-    _H2_FLAGS = ("_H2_FWD", "_H2_BWD", "_H2_DX", "_H2_WGRAD")
-
     def __enter__(self):
-        global _GEOM
-        self.old, _GEOM = _GEOM, self.geom
-        self.h2 = None
-        if self.geom is not None:
-            gl = globals()
-            self.h2 = {k: gl[k] for k in self._H2_FLAGS}
-            for k in self._H2_FLAGS:
-                gl[k] = False
+        self.old = _geom()
+        _GEOM_TLS.geom = self.geom
         return self.geom
 
     def __exit__(self, *exc):
-        global _GEOM
-        _GEOM = self.old
-        if self.h2 is not None:
-            globals().update(self.h2)
+        _GEOM_TLS.geom = self.old
         return False
 
 
 def current_geom() -> Optional[Geom]:
-    return _GEOM
+    return _geom()
+
+
+def _geom_for(P: int) -> Optional[Geom]:
+    """the active geometry if planes of P pixels are its padded planes, else None"""
+    g = _geom()
+    return g if (g is not None and P == g.Pc) else None
 
 
 def _dw_any_slots(geom, bwd: bool) -> int:
@@ -179,19 +179,23 @@ def _dw_any_slots(geom, bwd: bool) -> int:
 
 def _pcount(P: int) -> int:
     """pixels of a plane that carry data: the image's H*W for a padded plane of the active geometry, else P itself"""
-    return _GEOM.P if (_GEOM is not None and P == _GEOM.Pc) else P
+    g = _geom()
+    return g.P if (g is not None and P == g.Pc) else P
 
 
-def fix_tail(t: Tensor, part: Optional["Part"], mode: int, planes: int) -> None:
-    """Behind a point-wise producer (geometry active, t's planes have the padded stride): take the tail's share out of `part`
-    (mode 0: (sum, sum^2); 1: (sum, sum*aux) with aux zero on the tail; 2: none) and zero the tail."""
-    g = _GEOM
+def fix_tail(t: Tensor, part: Optional["Part"], mode: int, planes: int, unit: int = 1, aux: Optional[Tensor] = None,
+             pivot: Optional[Tensor] = None) -> None:
+    """Behind a pointwise GEMM on padded planes (geometry active, t's planes have the padded stride): add the valid pixels of the
+    boundary `unit`-pixel tile -- which the GEMM's statistics epilogue left out, like every tile that reaches into the tail -- to
+    `part` (mode 0: (sum, sum^2); 1: (sum, sum*aux); 2: none) and zero the tail."""
+    g = _geom()
     if g is None or t.numel() != planes * g.Pc:
         return
     if t.dtype != torch.float32:
         raise NotImplementedError("any-size planes are built for fp32 storage")
-    hb.call("uncr_fix_tail", t, part.buf if part is not None else None, part.slots if part is not None else 0, planes, g.P, g.Pc,
-            mode if part is not None else 2, _stream())
+    hb.call("uncr_fix_tail", t, aux if (part is not None and mode == 1) else None, part.buf if part is not None else None,
+            part.slots if part is not None else 0, planes, g.P, g.Pc, mode if part is not None else 2, unit,
+            pivot if (part is not None and mode == 1) else None, _stream())
 
 
 def embed_tail(x: Tensor, geom: Geom) -> Tensor:
@@ -301,7 +305,7 @@ def ew(op: int, a: Tensor, *, b=None, c=None, aux=None, out: Optional[Tensor] = 
         slots = hb.query("uncr_ew_slots", P)
         part = Part(_f32((planes, slots, 2), a.device), slots)
     hb.call("uncr_ew", op, a, b, c, aux, out, k[0], k[1], k[2], k[3], part.buf if part else None, planes, P, C,
-            n_mean, float(scale), float(eps), _dt(out if out is not None else a), _stream())
+            n_mean, float(scale), float(eps), _dt(out if out is not None else a), _pcount(P), _stream())
     return out, part
 
 
@@ -471,6 +475,13 @@ class NormBwd:
         return (self.c1, self.c2, self.c3, self.mu)
 
 
+def plane_means(nf: NormFwd, N: int, C: int, scale: float = 1.0) -> Tensor:
+    """[N*C]: scale * the mean of the statistics set each plane belongs to (pivots of centred statistics / products)"""
+    out = _f32((N * C,), nf.mean.device)
+    hb.call("uncr_plane_means", nf.mean, N, C, nf.groups if nf.kind == NORM_GROUP else 0, float(scale), out, _stream())
+    return out
+
+
 def norm_bwd(part: Part, N: int, C: int, P: int, nf: NormFwd, gamma: Tensor, centered: bool = False) -> NormBwd:
     """centered: the partials' second component is sum du*(h - mean) (producer was given nf.mean)."""
     if gamma is None:
@@ -637,8 +648,10 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
             x2: Optional[Tensor] = None, bias: Optional[Tensor] = None, bias_per_frame: bool = False, epi: int = 0,
             aux: Optional[Tensor] = None, out: Optional[Tensor] = None,
             ek=(None, None, None, None), out_dt: Optional[int] = None, want_amax: bool = False,
-            in_amax: Optional[Tensor] = None, in2_amax: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Part]]:
-    """out_dt: storage of the output (default: that of the input; the narrow Cout <= 64 kernels write fp32 only).
+            in_amax: Optional[Tensor] = None, in2_amax: Optional[Tensor] = None, dense: bool = False) -> Tuple[Tensor, Optional[Part]]:
+    """dense: the planes are NOT padded planes of the active any-size geometry whatever their pixel count (the dense 3x3 convolution's
+    padded grids, which may happen to have the geometry's stride).
+    out_dt: storage of the output (default: that of the input; the narrow Cout <= 64 kernels write fp32 only).
     want_amax (epi 1 / 2, 64 < Cout <= 128, fp32): the returned Part carries per-block maxima of |out| ([N][slots]).
     in_amax / in2_amax ([N][n] each): magnitude bounds of the two NORMBWD operands; with both, the epi-3 GEMM of an MBConv backward
     multiplies in two scaled fp16 parts (three products) instead of the exact bf16 split (six).
@@ -668,15 +681,20 @@ def pw_gemm(x: Tensor, Wt: Tensor, N: int, Cin: int, Cout: int, P: int, *, pro: 
     hb.call("uncr_pw_gemm", x, x2, Wt, out, k[0], k[1], k[2], k[3] if len(k) > 3 else None, bias,
             Cout if bias_per_frame else 0, aux,
             ek[0], ek[1], ek[2], ek[3], part.buf if part else None, N, Cin, Cout, P, pro, epi, _dt(x), _dt(out),
-            amax, in_amax if use_in else None, n1, in2_amax if use_in else None, n2, _stream())
+            amax, in_amax if use_in else None, n1, in2_amax if use_in else None, n2, P if dense else _pcount(P), _stream())
+    if not dense and _geom_for(P) is not None and epi != 4 and not (epi == 0 and pro == PRO_NONE and bias is None):
+        # padded planes of an any-size image: the statistics left out the tiles that reach into the tail, which holds f(0) now
+        # (a plain product of zero columns without a bias leaves zeros: nothing to do then)
+        fix_tail(out, part, 1 if epi in (2, 3) else (0 if part is not None else 2), N * Cout, hb.query("uncr_pw_tile_px", Cout), aux)
     return out, part
 
 
 def pw_wgrad(d: Tensor, x: Tensor, N: int, Cd: int, Cx: int, P: int, *, pro_d: int = PRO_NONE, dk=(None, None, None),
              d2: Optional[Tensor] = None, pro_x: int = PRO_NONE, xk=(None, None, None), x2: Optional[Tensor] = None,
              per_frame: bool = False, rowsum: bool = False, partials: bool = False, d_amax: Optional[Tensor] = None,
-             d2_amax: Optional[Tensor] = None, x_ub: Optional[Tensor] = None):
+             d2_amax: Optional[Tensor] = None, x_ub: Optional[Tensor] = None, dense: bool = False):
     """dW[co,ci] = sum_{n,p} fD(d)[n,co,p] * fX(x)[n,ci,p]  (-> [Cd,Cx], or [N,Cd,Cx] if per_frame);
+    dense: as in pw_gemm.
     optionally also rowsum[co] = sum_{n,p} fD(d).  partials: the per-block partials themselves, (part [N*nbx, cop, cip], nbx, cop,
     cip), for a consumer that reduces them on the way (uncr_prenorm_bwd_finish)."""
     import ctypes
@@ -691,12 +709,13 @@ def pw_wgrad(d: Tensor, x: Tensor, N: int, Cd: int, Cx: int, P: int, *, pro_d: i
                 xs = x.reshape(N, Cx, P)[:, o:o + n].contiguous()
                 x2s = None if x2 is None else x2.reshape(N, Cx, P)[:, o:o + n].contiguous()
                 dWp, r = pw_wgrad(d, xs, N, Cd, n, P, pro_d=pro_d, dk=dk, d2=d2, pro_x=pro_x, xk=tuple(cutk(t, o, n) for t in xk),
-                                  x2=x2s, per_frame=per_frame, rowsum=rowsum and rs is None)
+                                  x2=x2s, per_frame=per_frame, rowsum=rowsum and rs is None, dense=dense)
                 outs.append(dWp)
                 rs = r if rs is None else rs
             return torch.cat(outs, dim=-1).contiguous(), rs
         raise RuntimeError(f"weight-gradient shape ({Cd},{Cx}) not built")
     cop, cip = cop.value, cip.value
+    Pv = P if dense else _pcount(P)
     if d.dtype != x.dtype:
         raise RuntimeError("pw_wgrad: both operands must have the same storage type")
     act = _dt(d)
@@ -711,7 +730,10 @@ def pw_wgrad(d: Tensor, x: Tensor, N: int, Cd: int, Cx: int, P: int, *, pro_d: i
         d_amax = d2_amax = x_ub = None          # the row-scaled fp16 split needs every bound; the exact split otherwise
     hb.call("uncr_pw_wgrad", d, d2, x, x2, dk[0], dk[1], dk[2], dk[3] if len(dk) > 3 else None, xk[0], xk[1], xk[2], part,
             rs_part, N, Cd, Cx, P, nbx, pro_d, pro_x, act, d_amax, d_amax.numel() // N if d_amax is not None else 0, d2_amax,
-            d2_amax.numel() // N if d2_amax is not None else 0, x_ub, _stream())
+            d2_amax.numel() // N if d2_amax is not None else 0, x_ub, Pv, _stream())
+    if Pv != P:      # padded planes: the kernel summed the whole 32-pixel chunks below the image's pixel count; the rest here
+        hb.call("uncr_wgrad_boundary", d, d2, x, dk[0], dk[1], dk[2], dk[3] if len(dk) > 3 else None, xk[0], xk[1], xk[2], part, rs_part,
+                N, Cd, Cx, P, Pv, nbx, pro_d, pro_x, _stream())
     if partials:
         return part, nbx, cop, cip
     n_out = N if per_frame else 1
@@ -744,7 +766,7 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     Ch = p["w1"].shape[0]
     R = p["se1"].shape[0]
     if Ch > 256:        # hidden width beyond the GEMM kernels' 256 channels: the hidden axis in groups (slow path, any expansion)
-        if _GEOM is not None and P == _GEOM.Pc:
+        if _geom_for(P) is not None:
             raise NotImplementedError("any-size planes with a hidden width beyond 256 channels are not built")
         return _mbconv_forward_wide(x, p, spec, training, x_part, buffers or {}, want_out_stats, x_h3, pool)
     need = spec.needs_stats(training)
@@ -762,12 +784,10 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     n0 = norm_fwd(x_part if need else None, N, C, P, spec, training, p["n0w"], p["n0b"], *rm(0),
                   bound_part=x_part if h2ok else None)
     W1t = pack_wt(p["w1"].reshape(Ch, C), transpose=True)
-    geom = _GEOM if (_GEOM is not None and P == _GEOM.Pc) else None      # padded planes of an any-size image (csrc/anysize.hip)
+    geom = _geom_for(P)      # padded planes of an any-size image (csrc/anysize.hip)
     if geom is not None and dt != F32:
         raise NotImplementedError("any-size planes are built for fp32 storage")
     h1, part1 = pw_gemm(x, W1t, N, C, Ch, P, pro=PRO_AFFINE, k=(n0.A, n0.B, None), epi=1 if need else 0, in_amax=n0.ub)
-    if geom is not None:
-        fix_tail(h1, part1, 0, N * Ch)
     # (hb: the bound on |h1| itself, for the backward's dx GEMM, which reads h1 through the norm-1 backward)
     n1 = norm_fwd(part1, N, Ch, P, spec, training, p["n1w"], p["n1b"], *rm(1),
                   bound_part=part1 if (h2ok and _H2_BWD and part1 is not None) else None, want_hb=True,
@@ -789,8 +809,6 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
                   bound_part=part2 if h2ok else None)
 
     ppool = se_pool(h2, n2.A, n2.B, N * Ch, P)
-    if geom is not None:      # the pass summed gelu(A*0 + B) over the tail
-        hb.call("uncr_fix_sepool_tail", ppool.buf, ppool.slots, n2.B, N * Ch, geom.ntail, _stream())
     pooled, hid_pre, s = _f32((N, Ch), x.device), _f32((N, R), x.device), _f32((N * Ch,), x.device)
     hb.call("uncr_se_mlp_fwd", ppool.buf, ppool.slots, N, Ch, R, _pcount(P), p["se1"].contiguous(), p["se2"].contiguous(),
             pooled, hid_pre, s, _stream())
@@ -803,13 +821,9 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
         n3 = norm_fwd(None, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))
         y, party = pw_gemm(h2, W2t, N, Ch, C, P, pro=PRO_AFFINE_GELU, k=(n2.A, n2.B, s), epi=10, aux=x,
                            ek=(n3.A, n3.B, None, None), in_amax=n2.ub)
-        if geom is not None:
-            fix_tail(y.view(N, C, H, W), party, 0, N * C)
         return y.view(N, C, H, W), dict(ypool=None, h3=None, dims=(N, C, Ch, R, H, W)), (party if want_out_stats else None)
     h3, part3 = pw_gemm(h2, W2t, N, Ch, C, P, pro=PRO_AFFINE_GELU, k=(n2.A, n2.B, s), epi=1 if need else 0, want_amax=True,
                         in_amax=n2.ub)
-    if geom is not None:
-        fix_tail(h3.view(N, C, H, W), part3, 0, N * C)
     n3 = norm_fwd(part3, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))
 
     y = _act((N, C, H, W), x.device, dt)
@@ -827,8 +841,6 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     else:
         _, party = ew(EW_RESIDUAL, x, b=h3, out=y, k=(n3.A, n3.B, None, None), want_part=want_out_stats, planes=N * C,
                       P=P)
-        if geom is not None:
-            fix_tail(y, party, 0, N * C)
         if pool is not None:
             ypool = maxpool_forward(y, pool, pool)
     saved = dict(ypool=ypool, x=x, h1=h1, h2=h2, h3=h3, n0=n0, n1=n1, n2=n2, n3=n3, pooled=pooled, hid_pre=hid_pre, s=s,
@@ -1017,7 +1029,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     N, C, Ch, R, H, W = sv["dims"]
     P = H * W
     geom = sv.get("geom")
-    if geom is not None and _GEOM != geom:        # (a backward entered outside the model's scope: re-enter the forward's geometry)
+    if geom is not None and _geom() != geom:        # (a backward entered outside the model's scope: re-enter the forward's geometry)
         with geom_scope(geom):
             return mbconv_backward(dy, sv, p, need_dx, dy_part)
     dev = dy.device
@@ -1040,8 +1052,6 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     # (fp32 storage, magnitude bookkeeping at hand: two row-scaled fp16 parts, like the dz GEMM below)
     G, _ = pw_wgrad(dy, h2, N, C, Ch, P, pro_d=PRO_NORMBWD, dk=k3, d2=h3, pro_x=PRO_AFFINE_GELU,
                     xk=(n2.A, n2.B, None), per_frame=True, d_amax=dy_amax, d2_amax=sv.get("h3_amax"), x_ub=n2.ub)
-    if geom is not None:      # the tail (dy = h3 = h2 = 0 there) contributed n_tail * (c3 - c2*mu) (x) gelu(B2) to every frame's product
-        hb.call("uncr_fix_wgrad_tail", G, N, C, Ch, k3[1], k3[2], k3[3], n2.B, geom.ntail, _stream())
     ds_pre, dhid_pre, dpool = _f32((N, Ch), dev), _f32((N, R), dev), _f32((N * Ch,), dev)
     dW2, dse1, dse2 = _f32((C, Ch), dev), _f32((R, Ch), dev), _f32((Ch, R), dev)
     w2 = p["w2"].reshape(C, Ch).contiguous()
@@ -1058,8 +1068,6 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
     # with the magnitude bookkeeping of dy's producer and of the forward pw2 GEMM at hand: two scaled fp16 parts (three products)
     du2, part2 = pw_gemm(dy, W2k, N, C, Ch, P, pro=PRO_NORMBWD, k=k3, x2=h3, epi=3, aux=h2,
                          ek=(n2.A, n2.B, sv["s"], dpool), in_amax=dy_amax, in2_amax=sv.get("h3_amax"))
-    if geom is not None:
-        fix_tail(du2.view(N, Ch, H, W), part2, 1, N * Ch)
     b2 = norm_bwd(part2, N, Ch, P, n2, p["n2w"])
     g["n2w"], g["n2b"] = b2.dgamma, b2.dbeta
 
@@ -1098,46 +1106,48 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         # that exist already (uncr_prenorm_bwd_finish).  The PreNorm backward coefficients are therefore known before the
         # data GEMM, whose epilogue writes dx = dy + c1*da + c2*x + c3 (and the producing block's norm-3 statistics).
         one, zero = _const_planes(dev, N * C)
+        # InstanceNorm (one group per plane): the products are taken on x - mean, so that a plane far from zero -- or a CONSTANT one, a
+        # zero-padded date -- leaves no difference of two separately rounded sums behind (uncr_prenorm_bwd_finish, xmu)
+        xmu = negmu = None
+        if n0.kind == NORM_GROUP and n0.groups == C and n0.mean.numel() == N * C:
+            xmu, negmu = n0.mean, plane_means(n0, N, C, -1.0)
         wpart, nbx, cop, cip = pw_wgrad(du1, x, N, Ch, C, P, pro_d=PRO_NORMBWD, dk=k1, d2=h1, pro_x=PRO_AFFINE,
-                                        xk=(one, zero, None), partials=True)
+                                        xk=(one, zero if negmu is None else negmu, None), partials=True)
         part0 = Part(_f32((N * C, Ch // 2, 2), dev), Ch // 2)
         dW1 = _f32((Ch, C), dev)
         pf = sv.get("part1f")
         hb.call("uncr_prenorm_bwd_finish", wpart, nbx, cop, cip, p["w1"].reshape(Ch, C).contiguous(), part1.buf, part1.slots,
                 pf.buf if pf is not None else None, pf.slots if pf is not None else 0, k1[0], k1[1], k1[2],
-                k1[3] if pf is not None else None, n0.A, n0.B, part0.buf, dW1, N, Ch, C, _pcount(P), _stream())
+                k1[3] if pf is not None else None, n0.A, n0.B, part0.buf, dW1, N, Ch, C, _pcount(P), xmu, _stream())
         g["w1"] = dW1.view_as(p["w1"])
-        b0 = norm_bwd(part0, N, C, P, n0, p["n0w"])
+        b0 = norm_bwd(part0, N, C, P, n0, p["n0w"], centered=xmu is not None)
         g["n0w"], g["n0b"] = b0.dgamma, b0.dbeta
         dx = _act((N, C, H, W), dev, dt)
         x_h3 = sv.get("x_h3")
         relu = sv.get("x_relu")       # x = relu(A*c0 + B) of in_conv: its ReLU backward and norm statistics ride along
-        ra = rb = None
+        ra = rb = rmu = None
         if relu is not None:
-            x_h3, ra, rb = relu       # (c0, A, B); or (None, A, None): the mask is [x > 0] itself, c0 was never stored (inconv_forward)
+            x_h3, ra, rb = relu[:3]   # (c0, A, B, mean per plane); or (None, A, None): the mask is [x > 0] itself, c0 was never stored (inconv_forward)
+            rmu = relu[3] if (len(relu) > 3 and rb is not None) else None
         dx_part = None
         if x_h3 is not None or relu is not None:
             slots = hb.query("uncr_pw_stat_slots", N, C, P)
-            dx_part = Part(_f32((N * C, slots, 2), dev), slots, masked=relu is not None)
+            dx_part = Part(_f32((N * C, slots, 2), dev), slots, masked=relu is not None, centered=rmu is not None)
             if relu is None and dt == F32 and _H2_BWD:      # dx is the next backward's dy: leave its per-block maxima for that dz GEMM
                 dx_part.amax = _f32((N, slots), dev)
-        hb.call("uncr_pw_gemm_dx", du1, h1, W1k, dx, k1[0], k1[1], k1[2], k1[3], dy, x, x_h3, b0.c1, b0.c2, b0.c3, b0.mu, ra, rb,
+        hb.call("uncr_pw_gemm_dx", du1, h1, W1k, dx, k1[0], k1[1], k1[2], k1[3], dy, x, x_h3, b0.c1, b0.c2, b0.c3, b0.mu, ra, rb, rmu,
                 dx_part.buf if dx_part is not None else None, N, Ch, C, P, dt,
                 dx_part.amax if dx_part is not None else None, du1_amax, du1_amax.shape[1] if du1_amax is not None else 0,
-                n1.hb if du1_amax is not None else None, Ch if du1_amax is not None else 0, _stream())
-        if geom is not None:
-            fix_tail(dx, dx_part, 1, N * C)
+                n1.hb if du1_amax is not None else None, Ch if du1_amax is not None else 0, _pcount(P), _stream())
+        if geom is not None:      # (statistics partner: the producing block's h3, or x itself where the mask is [x > 0])
+            fix_tail(dx, dx_part, 1, N * C, hb.query("uncr_pw_tile_px", C), x_h3 if x_h3 is not None else x, rmu)
         join_side()
         return dx, g, dx_part
 
     # pw1: weight gradient and data gradient (block widths the fused backward does not take, e.g. 64)
     dW1, _ = pw_wgrad(du1, x, N, Ch, C, P, pro_d=PRO_NORMBWD, dk=k1, d2=h1, pro_x=PRO_AFFINE, xk=(n0.A, n0.B, None))
-    if geom is not None:      # the tail (du1 = h1 = x = 0 there) contributed n_tail * sum_n (c3 - c2*mu)[n, co] * B0[n, ci]
-        hb.call("uncr_fix_wgrad_tail_affine", dW1, N, Ch, C, k1[1], k1[2], k1[3], n0.B, geom.ntail, _stream())
     g["w1"] = dW1.view_as(p["w1"])
     da, part0 = pw_gemm(du1, W1k, N, Ch, C, P, pro=PRO_NORMBWD, k=k1, x2=h1, epi=2, aux=x)
-    if geom is not None:
-        fix_tail(da, part0, 1, N * C)
     b0 = norm_bwd(part0, N, C, P, n0, p["n0w"])
     g["n0w"], g["n0b"] = b0.dgamma, b0.dbeta
 
@@ -1147,8 +1157,6 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         x_h3 = sv.get("x_h3")     # h3 of the block that produced x: emit its norm-3 backward statistics here
         _, dx_part = ew(EW_PASSE, dy, b=da, c=x, aux=x_h3, out=dx, k=b0.k,
                         want_part=x_h3 is not None, planes=N * C, P=P)
-        if geom is not None:
-            fix_tail(dx, dx_part, 1, N * C)
     join_side()
     return dx, g, dx_part
 
@@ -1189,7 +1197,7 @@ def conv3x3_forward(xp: _Padded, w: Tensor, b: Tensor, want_stats: bool):
     outp = _Padded(N, Co, H, W, w.device)
     for i, (ky, kx, off) in enumerate(_taps(W)):
         pw_gemm(xp.view(off), pack_wt(wt[ky, kx], transpose=True), N, Ci, Co, xp.Sp, bias=b.contiguous() if i == 0 else None,
-                epi=0 if i == 0 else 4, out=outp.view().view(N, Co, xp.Sp))
+                epi=0 if i == 0 else 4, out=outp.view().view(N, Co, xp.Sp), dense=True)
     g = xp.geom
     c = _f32((N, Co, 1, g.Pc) if g is not None else (N, Co, H, W), w.device)
     part = None
@@ -1220,7 +1228,7 @@ def conv3x3_backward(du: Tensor, c: Tensor, kk, xp: _Padded, w: Tensor, need_dx:
     dWt = []
     db = None
     for i, (ky, kx, off) in enumerate(_taps(W)):
-        dW_t, rs = pw_wgrad(dcp.view().view(N, Co, xp.Sp), xp.view(off).view(N, Ci, xp.Sp), N, Co, Ci, xp.Sp, rowsum=(i == 0))
+        dW_t, rs = pw_wgrad(dcp.view().view(N, Co, xp.Sp), xp.view(off).view(N, Ci, xp.Sp), N, Co, Ci, xp.Sp, rowsum=(i == 0), dense=True)
         dWt.append(dW_t)
         if i == 0:
             db = rs
@@ -1231,7 +1239,7 @@ def conv3x3_backward(du: Tensor, c: Tensor, kk, xp: _Padded, w: Tensor, need_dx:
         dxp = _Padded(N, Ci, H, W, dev)
         for i, (ky, kx, off) in enumerate(_taps(W)):
             pw_gemm(dcp.view(-off), pack_wt(wt[ky, kx], transpose=False), N, Co, Ci, xp.Sp, epi=0 if i == 0 else 4,
-                    out=dxp.view().view(N, Ci, xp.Sp))
+                    out=dxp.view().view(N, Ci, xp.Sp), dense=True)
         if g is not None:
             dx = _f32((N, Ci, 1, g.Pc), dev)
             hb.call("uncr_unpad2d_reflect_adjoint_strided", dxp.view(), dx, N * Ci, H, W, g.Pc, _stream())
@@ -1245,7 +1253,7 @@ def residual_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: 
     """ResidualConvBlock.forward.  p: RES_KEYS; buffers: {rm1, rv1, ...} BatchNorm running statistics."""
     N, C, H, W = _check4(x)
     P = H * W                 # pixels per stored plane (any-size: the padded count Pc; the finalisations divide by the true count)
-    geom = _GEOM if (_GEOM is not None and P == _GEOM.Pc) else None
+    geom = _geom_for(P)
     if geom is not None:
         if _dt(x) != F32:
             raise NotImplementedError("any-size planes are built for fp32 storage")
@@ -1267,14 +1275,12 @@ def residual_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: 
         src, pro, k = c, PRO_AFFINE_RELU, (nf.A, nf.B)
     y = torch.empty_like(x)
     ew(EW_RESIDUAL_RELU, x, b=src, out=y, k=(k[0], k[1], None, None), planes=N * C, P=P)
-    if geom is not None:
-        fix_tail(y, None, 2, N * C)          # the tail holds relu(B): back to zero
     return y, sv
 
 
 def residual_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = True):
     geom = sv.get("geom")
-    if geom is not None and _GEOM != geom:      # re-enter the forward's any-size geometry
+    if geom is not None and _geom() != geom:      # re-enter the forward's any-size geometry
         with geom_scope(geom):
             return residual_backward(dy, sv, p, need_dx)
     N, C, H, W = sv["dims"]
@@ -1285,8 +1291,8 @@ def residual_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool 
     for i in (3, 2, 1):
         c, nf, xp = sv["c"][i - 1], sv["nf"][i - 1], sv["xp"][i - 1]
         du = torch.empty_like(c)       # (a zero tail of `da` gives a zero tail here: the mask multiplies)
-        _, part = ew(EW_RELU_BWD, da, b=c, out=du, k=(nf.A, nf.B, None, None), want_part=True, planes=N * C, P=P)
-        nb = norm_bwd(part, N, C, P, nf, p[f"g{i}"])
+        _, part = ew(EW_RELU_BWD, da, b=c, out=du, k=(nf.A, nf.B, plane_means(nf, N, C), None), want_part=True, planes=N * C, P=P)
+        nb = norm_bwd(part, N, C, P, nf, p[f"g{i}"], centered=True)
         g[f"g{i}"], g[f"be{i}"] = nb.dgamma, nb.dbeta
         da, g[f"w{i}"], g[f"b{i}"] = conv3x3_backward(du, c, nb.k, xp, p[f"w{i}"],
                                                       need_dx or i > 1)
@@ -1308,7 +1314,7 @@ def _inconv_moments_ok(x: Tensor, N: int, Cin: int, Cout: int, spec: NormSpec, g
     if not (_INCONV_MOMENTS and spec.kind == "group" and gw is not None and Cin + 1 <= 16 and 64 < Cout <= 256
             and Cout % spec.groups == 0 and N <= 64 and P % 4 == 0):
         return False
-    if _GEOM is not None and P == _GEOM.Pc:       # any-size planes: the generic path (its tail corrections are plain statistics)
+    if _geom_for(P) is not None:       # any-size planes: the generic path (its tail corrections are plain statistics)
         return False
     return (2 * N * (Cout // spec.groups) + 4 * N + 288) * 8 <= 60 * 1024
 
@@ -1338,16 +1344,15 @@ def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec
         a0, parta = pw_gemm(x, Wt, N, Cin, Cout, P, bias=bc, epi=9, ek=(A, B, None, None))
         a0 = a0.view(N, Cout, H, W)
         return a0, dict(x=x, c0=None, a0=a0, nf=nf, mom=mom, b=bc, dims=(N, Cin, Cout, H, W)), parta
-    geom = _GEOM if (_GEOM is not None and P == _GEOM.Pc) else None
+    geom = _geom_for(P)
     c0, part = pw_gemm(x, Wt, N, Cin, Cout, P, bias=b.contiguous(), epi=1 if need else 0)
-    if geom is not None:      # the tail holds the bias
-        fix_tail(c0.view(N, Cout, H, W), part, 0, N * Cout)
     nf = norm_fwd(part, N, Cout, P, spec, training, gw, gb, buffers.get("rm"), buffers.get("rv"))
     a0 = _act((N, Cout, H, W), x.device, _dt(x))
     _, parta = ew(EW_AFFINE_RELU, c0, out=a0, k=(nf.A, nf.B, None, None), want_part=True, planes=N * Cout, P=P)
-    if geom is not None:
-        fix_tail(a0, parta, 0, N * Cout)
-    return a0, dict(x=x, c0=c0, nf=nf, dims=(N, Cin, Cout, H, W), geom=geom), parta
+    # per-plane means of the norm: pivots of the backward's second statistic, sum du0*(c0 - mean) -- c0 = W x + b of non-negative
+    # inputs sits several standard deviations from zero, and the raw sum du0*c0 - mean*sum du0 cancels in fp32 slots
+    mu = plane_means(nf, N, Cout) if (need and training) else None
+    return a0, dict(x=x, c0=c0, nf=nf, mu=mu, dims=(N, Cin, Cout, H, W), geom=geom), parta
 
 
 def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool, masked_part: Optional[Part] = None):
@@ -1357,7 +1362,7 @@ def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool,
     N, Cin, Cout, H, W = sv["dims"]
     P = H * W
     geom = sv.get("geom")
-    if geom is not None and _GEOM != geom:
+    if geom is not None and _geom() != geom:
         with geom_scope(geom):
             return inconv_backward(da0, sv, w, gw, need_dx, masked_part)
     nf, c0, x = sv["nf"], sv["c0"], sv["x"]
@@ -1389,12 +1394,11 @@ def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool,
         du0, part = da0, masked_part
     else:
         du0 = _act((N, Cout, H, W), da0.device, _dt(x))
-        _, part = ew(EW_RELU_BWD, da0, b=c0, out=du0, k=(nf.A, nf.B, None, None), want_part=True, planes=N * Cout, P=P)
-    nb = norm_bwd(part, N, Cout, P, nf, gw)
+        _, part = ew(EW_RELU_BWD, da0, b=c0, out=du0, k=(nf.A, nf.B, sv.get("mu"), None), want_part=True, planes=N * Cout, P=P)
+        part.centered = sv.get("mu") is not None
+    nb = norm_bwd(part, N, Cout, P, nf, gw, centered=part.centered)
     kk = nb.k
     dW, db = pw_wgrad(du0, x, N, Cout, Cin, P, pro_d=PRO_NORMBWD, dk=kk, d2=c0, rowsum=True)
-    if geom is not None:      # the row sums ran over the tail, where the norm backward of (0, 0) is c3 - c2*mu (x is zero there: dW is clean)
-        hb.call("uncr_fix_rowsum_tail", db, N, Cout, kk[1], kk[2], kk[3], geom.ntail, _stream())
     dx = None
     if need_dx:
         Wk = pack_wt(w.reshape(Cout, Cin), transpose=False)   # [k=128][out=15]
@@ -1422,8 +1426,8 @@ def maxpool_forward(e: Tensor, OH: int, OW: int):
     lead = tuple(e.shape[:-2])
     down = _f32(lead + (OH, OW), e.device)
     idx = torch.empty(lead + (OH, OW), device=e.device, dtype=torch.int32)
-    g = _GEOM
-    if g is not None and H * W == g.Pc:       # padded planes of an any-size image: the window arithmetic of the true H x W
+    g = _geom_for(H * W)
+    if g is not None:       # padded planes of an any-size image: the window arithmetic of the true H x W
         hb.call("uncr_maxpool_fwd_strided", e, down, idx, planes, g.H, g.W, g.Pc, OH, OW, _stream())
         return down, idx
     hb.call("uncr_maxpool_fwd", e, down, idx, planes, H, W, OH, OW, _dt(e), _stream())
@@ -1433,8 +1437,8 @@ def maxpool_forward(e: Tensor, OH: int, OW: int):
 def maxpool_backward_into(ddown: Tensor, idx: Tensor, de: Tensor, H: int, W: int, OH: int, OW: int):
     """de[plane][argmax] += ddown (in place on `de`)."""
     planes = ddown.numel() // (OH * OW)
-    g = _GEOM
-    if g is not None and H * W == g.Pc:
+    g = _geom_for(H * W)
+    if g is not None:
         hb.call("uncr_maxpool_bwd_strided", ddown.contiguous(), idx, de, planes, g.H, g.W, g.Pc, OH, OW, _stream())
         return
     hb.call("uncr_maxpool_bwd", ddown.contiguous(), idx, de, planes, H, W, OH, OW, _dt(de), _stream())
@@ -1574,7 +1578,7 @@ def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: b
     B, T, C, H, W = e.shape
     n_head, _, _, ah, aw = att.shape
     dev = e.device
-    geom = _GEOM if (_GEOM is not None and H * W == _GEOM.Pc) else None
+    geom = _geom_for(H * W)
     odd_heads = None
     if geom is None and C % n_head == 0 and C // n_head not in (2, 4, 6, 8, 16, 32) and not (H <= aw and (H, W) != (ah, aw)):
         # channels per head outside the streaming kernels' list (e.g. 96 channels in 8 heads): the scalar kernels below take any count;
@@ -1807,8 +1811,8 @@ def ltae_values_backward(dv: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int
         Cx, Cl = lay["dims"]
         nf, m1 = lay["nf"], lay["m1"]
         du = _f32((B, Cl, S), dev)
-        _, part = ew(EW_RELU_BWD, dr, b=m1, out=du, k=(nf.A, nf.B, None, None), want_part=True, planes=B * Cl, P=S)
-        nb = norm_bwd(part, B, Cl, S, nf, bw)
+        _, part = ew(EW_RELU_BWD, dr, b=m1, out=du, k=(nf.A, nf.B, plane_means(nf, B, Cl), None), want_part=True, planes=B * Cl, P=S)
+        nb = norm_bwd(part, B, Cl, S, nf, bw, centered=True)
         g["bn_w" + sfx], g["bn_b" + sfx] = nb.dgamma, nb.dbeta
         kk = nb.k
         dWm, dbm = pw_wgrad(du, lay["x"].reshape(B, Cx, S), B, Cl, Cx, S, pro_d=PRO_NORMBWD, dk=kk, d2=m1, rowsum=True)
@@ -1825,7 +1829,7 @@ def include_v_forward(gagg: Tensor, v: Tensor, w: Tensor, b: Tensor, want_stats:
     B, C, H, W = gagg.shape
     Cv, ah, aw = v.shape[1:]
     P, S = H * W, ah * aw
-    geom = _GEOM if (_GEOM is not None and P == _GEOM.Pc) else None        # padded planes of an any-size image: P = Pc, zero tails
+    geom = _geom_for(P)        # padded planes of an any-size image: P = Pc, zero tails
     w2 = w.reshape(C, C + Cv)
     wa, wv = w2[:, :C].contiguous(), w2[:, C:].contiguous()
     z, _ = pw_gemm(v.reshape(B, Cv, S), pack_wt(wv, transpose=True), B, Cv, C, S, bias=b.contiguous())
@@ -1890,7 +1894,8 @@ def ltae_stage_forward(e: Tensor, dates: Optional[Tensor], pad: Optional[Tensor]
         att, sv_att = ltae_attention_forward(down, dates, pad, p, denom, n_head, d_k)
     if mode == "att_group":
         w_att, shared = att, False
-        true_h = _GEOM.H if (_GEOM is not None and e.shape[-2] * e.shape[-1] == _GEOM.Pc) else e.shape[-2]
+        sg = _geom_for(e.shape[-2] * e.shape[-1])
+        true_h = sg.H if sg is not None else e.shape[-2]
         if true_h <= att_down:      # feature map not larger than the attention map: the reference takes its AvgPool
             p_drop, dmask = 0.0, None    # branch (kernel 1 = identity at equal size), which has NO dropout (uncrtaints.py:197-204)
     elif mode == "att_mean":
@@ -1946,7 +1951,7 @@ def ltae_stage_backward(dg: Tensor, sv: dict, p: Dict[str, Tensor], n_head: int,
             _LTAE_STORE["bwd"] = ltae_stage_backward(dg, sv, p, n_head, d_k, e_h3)
         return _LTAE_STORE["bwd"]
     sgeom = sv["agg"].get("geom") if isinstance(sv.get("agg"), dict) else None
-    if sgeom is not None and _GEOM != sgeom:      # re-enter the forward's any-size geometry (csrc/anysize.hip)
+    if sgeom is not None and _geom() != sgeom:      # re-enter the forward's any-size geometry (csrc/anysize.hip)
         with geom_scope(sgeom):
             return ltae_stage_backward(dg, sv, p, n_head, d_k, e_h3)
     if "val" in sv:     # use_v: include_v -> (aggregation, values) -> attention

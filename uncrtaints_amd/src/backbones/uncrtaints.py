@@ -639,17 +639,6 @@ class UNCRTAINTS(nn.Module):
             if nbt:
                 torch._foreach_add_(nbt, 1)
         pad = E.pad_mask_of(input, float(self.pad_value))                  # [B,T] int32, uncrtaints.py:392-394
-        if self.encoder_norm == 'instance' and self.training and torch.is_grad_enabled() and not self.is_mono \
-                and not torch.cuda.is_current_stream_capturing() and bool(pad.any()):
-            # A padded date is a CONSTANT frame: every InstanceNorm of the encoder sees zero variance (rstd = 1/sqrt(eps) = 316) and the
-            # reference's own gradient inside that frame reaches 1e4 ... 1e9; its weight gradients stay finite because the frame's terms
-            # cancel exactly, which this path's statistics-by-linearity and tail corrections do not reproduce (encoder gradients wrong by
-            # O(1): DESIGN.md section 2, tools/fuzz_configs.py cases 240, 303, 336).  Refuse rather than train on them.  (One host
-            # synchronisation, on this configuration only; the reference synchronises on pad_mask.any() in every forward,
-            # uncrtaints.py:157.  Forward-only calls and GroupNorm / BatchNorm encoders are unaffected; inside a HIP-graph capture the check
-            # cannot run -- the eager warm-up steps ahead of every capture do run it.)
-            raise NotImplementedError("encoder_norm='instance' with a padded (constant) date: the encoder's gradients are not reliable on "
-                                      "this path; use encoder_norm='group' (the default) or 'batch', or drop the padded dates")
         # the encoder runs on the folded [B*T, C, H, W] frames (smart_forward, utae.py:422-450) without autograd views
         # between its blocks, so the statistics / masks that ride on the tensors survive in both directions
         b, t, _, h, w = input.shape
@@ -657,6 +646,8 @@ class UNCRTAINTS(nn.Module):
         # any H x W (uncrtaints.py:391-447): a size outside the tuned tilings runs on padded planes [frames, C, 1, Pc] (dense H*W pixels
         # + a zero tail) inside a geometry scope; the output is cut back to [B, 1, C_out, H, W] at the end
         geom = E.plan_geom(h, w)
+        if not self.is_mono and (h < 32 or w < 32):
+            raise NotImplementedError(f"spatial size {h}x{w}: at least 32x32 (the L-TAE stage pools to 32x32)")
         if geom is not None:
             if self.act_dtype == torch.bfloat16:
                 raise NotImplementedError(f"spatial size {h}x{w} (H*W not a multiple of 1024 or W not of 4) is built for fp32 storage")

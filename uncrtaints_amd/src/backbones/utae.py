@@ -62,7 +62,7 @@ class _ConvNormActFn(torch.autograd.Function):
         ctx.params = (w, gw)
         a0._uncr_part = part
         # lets the consumer's backward apply this ReLU's mask: from c0 (A*c0 + B > 0) or, where c0 was never stored, from a0 itself
-        a0._uncr_relu = (sv["c0"], sv["nf"].A, sv["nf"].B if sv["c0"] is not None else None)
+        a0._uncr_relu = (sv["c0"], sv["nf"].A, sv["nf"].B if sv["c0"] is not None else None, sv.get("mu"))
         return a0
 
     @staticmethod
