@@ -103,6 +103,24 @@ class _RoundBf16(torch.autograd.Function):
         return (g.to(torch.bfloat16).to(g.dtype) if ctx.bwd else g), None, None
 
 
+class _ContiguousGrad(torch.autograd.Function):
+    """Identity whose gradient is made contiguous, placed behind F.instance_norm.  ATen's CPU batch-norm backward (which serves
+    instance_norm on the [1, N*C, H, W] view) mis-reads a gradient with expanded / permuted strides -- what the einsum of this file's
+    'att_mean' aggregation (one head-averaged map for all channels) hands back through the residual connection for B = 1: the
+    encoder's weight gradients then come out ORTHOGONAL to the true ones while the forward values and the gradient's values at the
+    encoder output are right.  Found in round 6 (tools/debug_instance_pad.py: finite differences of the HIP forward and the reference's
+    own modules agree with the HIP gradients; the reference's `x * attn[:, :, None]` form produces a dense gradient and is not
+    affected).  Rounds 4-5 had read the symptom as a defect of the HIP path under `encoder_norm='instance'` with a padded date."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.contiguous()
+
+
 def _store(x: Tensor, on: bool, grad: bool = True) -> Tensor:
     """A tensor the HIP path keeps in bf16 (or rounds ahead of the matrix pipe).  grad: its gradient is a bf16 tensor too (a stored
     activation gradient, or a gradient-GEMM operand)."""
@@ -197,7 +215,7 @@ class _NormCtx:
 
     def __call__(self, x: Tensor, prefix: str) -> Tensor:
         if self.kind == "instance":        # nn.InstanceNorm2d defaults: no affine, instance statistics in train and eval
-            return F.instance_norm(x, eps=1e-5)
+            return _ContiguousGrad.apply(F.instance_norm(x, eps=1e-5))      # (a dense gradient for ATen's backward: see the class)
         w, b = self.p[prefix + ".weight"], self.p[prefix + ".bias"]
         if self.kind == "group":
             return group_norm(x, 4, w, b)
@@ -451,7 +469,13 @@ def forward(p: Dict[str, Tensor], x: Tensor, dates: Tensor, cfg: OracleConfig, t
                                       p["out_conv_var_1.conv.conv.0.bias"])), dim=1)
         o = o.unsqueeze(1)
     else:
-        o = conv1x1(out, p["out_conv.conv.conv.0.weight"], p["out_conv.conv.conv.0.bias"]).unsqueeze(1)
+        # out_conv = ConvBlock(norm='none', last_relu=False) over [decoder_widths[0]] + out_conv (uncrtaints.py:381): Conv2d k=1 at the
+        # even Sequential indices, a ReLU behind every convolution but the last (utae.py:476-494)
+        i = 0
+        while f"out_conv.conv.conv.{i + 2}.weight" in p:
+            out = _store(torch.relu(conv1x1(out, p[f"out_conv.conv.conv.{i}.weight"], p[f"out_conv.conv.conv.{i}.bias"])), bf)
+            i += 2
+        o = conv1x1(out, p[f"out_conv.conv.conv.{i}.weight"], p[f"out_conv.conv.conv.{i}.bias"]).unsqueeze(1)
     o = _ground(o, bf)       # the gradient of the head's pre-activation is an activation gradient: stored like the decoder's
     if taps is not None:
         taps["pre_head"] = o

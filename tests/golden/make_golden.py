@@ -864,7 +864,100 @@ def case_variants():
     np.savez_compressed(os.path.join(HERE, "g2_variants.npz"), **out)
 
 
+def case_outconv_layers():
+    """G23: out_conv with several layers (`--out_conv "[32,26]"`, parse_args.py:30): ConvBlock(norm='none', last_relu=False) puts a ReLU
+    behind every 1x1 convolution but the last (utae.py:476-494, uncrtaints.py:381).  Body weights from g1_diag_t3, the two out_conv
+    layers freshly drawn; eval output, train output, loss, every gradient."""
+    base = np.load(os.path.join(HERE, "g1_diag_t3.npz"))
+    state = {k[len("state/"):]: torch.from_numpy(base[k]) for k in base.files if k.startswith("state/")}
+    x, y, dates = (torch.from_numpy(base[k]) for k in ("x", "y", "dates"))
+    torch.manual_seed(23)
+    m = uncrtaints.UNCRTAINTS(input_dim=15, out_conv=[32, 26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag", scale_by=1.0)
+    sd = m.state_dict()
+    new = {k: v.clone() for k, v in sd.items() if k.startswith("out_conv.")}
+    sd.update({k: v for k, v in state.items() if not k.startswith("out_conv.")})
+    m.load_state_dict(sd, strict=True)
+    m.temporal_aggregator.attn_dropout.p = 0.0
+    out = {f"state/{k}": v.numpy() for k, v in new.items()}
+    m.eval()
+    with torch.no_grad():
+        oe = m(x, batch_positions=dates)
+    m.train()
+    ot = m(x, batch_positions=dates)
+    l, _ = crit("diag")(ot[:, :, :13], y, ot[:, :, 13:26])
+    l.backward()
+    out["eval_out"], out["train_out"], out["train_loss"] = oe.numpy(), ot.detach().numpy(), np.array(l.item())
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            if k.startswith("out_conv.") or k.startswith("out_block.4") or k.startswith("in_conv"):
+                out[f"grad/{k}"] = v.grad.numpy()
+            out[f"gradsum/{k}"] = checksum(v.grad.numpy())
+    print("outconv layers", [k for k in new], "train loss", l.item())
+    np.savez_compressed(os.path.join(HERE, "g23_outconv_layers.npz"), **out)
+
+
+def case_small_input():
+    """G24: an input below 32 x 32 (16 x 16): AdaptiveMaxPool2d((32, 32)) pools UP (uncrtaints.py:403-404) and the aggregator takes its
+    AvgPool2d(32 // 16) branch, which has no dropout (uncrtaints.py:197-204).  Weights of g1_diag_t3; one padded date in the second sample."""
+    base = np.load(os.path.join(HERE, "g1_diag_t3.npz"))
+    state = {k[len("state/"):]: torch.from_numpy(base[k]) for k in base.files if k.startswith("state/")}
+    x, y, dates = synth(2, 3, 16, 16, seed=24)
+    x[1, 2] = 0.0
+    torch.manual_seed(0)
+    m = uncrtaints.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag", scale_by=1.0)
+    m.load_state_dict(state, strict=True)
+    out = dict(x=x.numpy(), y=y.numpy(), dates=dates.numpy())
+    m.eval()
+    with torch.no_grad():
+        oe = m(x, batch_positions=dates)
+    m.train()                      # (attn_dropout stays at its default 0.1: the small-map branch applies none)
+    ot = m(x, batch_positions=dates)
+    l, _ = crit("diag")(ot[:, :, :13], y, ot[:, :, 13:26])
+    l.backward()
+    out["eval_out"], out["train_out"], out["train_loss"] = oe.numpy(), ot.detach().numpy(), np.array(l.item())
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            out[f"gradsum/{k}"] = checksum(v.grad.numpy())
+            if k.startswith("temporal_encoder") or k.startswith("in_conv") or k.startswith("out_conv"):
+                out[f"grad/{k}"] = v.grad.numpy()
+    print("small input train loss", l.item())
+    np.savez_compressed(os.path.join(HERE, "g24_small_input.npz"), **out)
+
+
+def case_instance_attmean():
+    """G25: encoder_norm='instance' + agg_mode='att_mean', B = 1, T = 3 with a zero-padded last date, 64 x 64, default initialisation.
+    The combination on which (a) ATen's CPU batch-norm backward mis-reads the strided gradient an einsum-form aggregation hands back
+    (the oracle's encoder gradients were orthogonal to these before round 6) and (b) a constant frame meets InstanceNorm
+    (uncrtaints.py:16-22): every plane of the padded frame is exactly zero behind in_conv's norm."""
+    torch.manual_seed(25)
+    m = uncrtaints.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag", scale_by=1.0,
+                              encoder_norm="instance", agg_mode="att_mean", decoder_widths=[128])
+    m.temporal_aggregator.attn_dropout.p = 0.0
+    x, y, dates = synth(1, 3, 64, 64, seed=25)
+    x[0, 2] = 0.0
+    out = {f"state/{k}": v.numpy().copy() for k, v in m.state_dict().items()}
+    out.update(x=x.numpy(), y=y.numpy(), dates=dates.numpy())
+    m.train()
+    ot = m(x, batch_positions=dates)
+    l, _ = crit("diag")(ot[:, :, :13], y, ot[:, :, 13:26])
+    l.backward()
+    out["train_out"], out["train_loss"] = ot.detach().numpy(), np.array(l.item())
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            out[f"gradsum/{k}"] = checksum(v.grad.numpy())
+            if k.startswith("in_block") or k.startswith("in_conv"):
+                out[f"grad/{k}"] = v.grad.numpy()
+    print("instance + att_mean train loss", l.item())
+    np.savez_compressed(os.path.join(HERE, "g25_instance_attmean.npz"), **out)
+
+
 if __name__ == "__main__":
+  if "--only-instance-attmean" in sys.argv:
+    case_instance_attmean(); sys.exit(0)
+  if "--only-small-input" in sys.argv:
+    case_small_input(); sys.exit(0)
+  if "--only-outconv-layers" in sys.argv:
+    case_outconv_layers(); sys.exit(0)
   if "--skip-model" not in sys.argv:
     case_model("g1_diag_t3", "diag", 2, 3, 64, 64, seed=1, full_grads=True)
     case_model("g1_diag_t3_pad", "diag", 2, 3, 64, 64, seed=1, full_grads=False, pad_last=True, save_state=False, taps=False)
@@ -918,4 +1011,7 @@ if __name__ == "__main__":
     case_ensemble()
     case_weightinit()
     case_refcheckpoint()
+    case_outconv_layers()
+    case_small_input()
+    case_instance_attmean()
   case_trainseq()

@@ -1196,7 +1196,7 @@ def test_scaled_fp16_two_part_dx_gemm(E, gscale):
                     ("exact bf16", (None, 0, None, 0))):
         out, part = torch.empty(N, C, P, device=DEV), torch.empty(N * C, slots, 2, device=DEV)
         hb.call("uncr_pw_gemm_dx", dev(du1), dev(h1), W1k, out, dev(k[0]), dev(k[1]), dev(k[2]), dev(k[3]), dev(dy), dev(x), dev(xh3),
-                dev(c[0]), dev(c[1]), dev(c[2]), dev(c[3]), None, None, part, N, Ch, C, P, 0, None, *b, E._stream())
+                dev(c[0]), dev(c[1]), dev(c[2]), dev(c[3]), None, None, None, part, N, Ch, C, P, 0, None, *b, P, E._stream())
         o = out.cpu().double()
         errs[name] = max(float((o[n] - truth[n]).abs().max() / truth[n].abs().max()) for n in range(N))
         sm = part.view(N * C, -1, 2).double().sum(1).cpu()

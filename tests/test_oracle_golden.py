@@ -321,3 +321,87 @@ def test_oracle_ltae2d_without_input_projection_vs_reference_fixture(i):
             if name.endswith(".bias") and np.abs(ref).max() < 1e-3 * np.abs(g[pre + "grad/" + name.replace(".bias", ".weight")]).max():
                 continue        # mathematically zero gradients: rounding noise on both sides
             assert rel_err(p["temporal_encoder." + name].grad.numpy(), ref) < 2e-4, name
+
+
+def _g23():
+    base, g = load_golden("g1_diag_t3"), load_golden("g23_outconv_layers")
+    state = {k: v for k, v in _state(base).items() if not k.startswith("out_conv.")}
+    state.update(_state(g))
+    x, y, dates = (torch.from_numpy(base[k]) for k in ("x", "y", "dates"))
+    return g, state, x, y, dates, orc.OracleConfig(out_conv=[32, 26], attn_dropout=0.0)
+
+
+def test_oracle_multi_layer_out_conv_vs_reference_fixture():
+    """g23: `--out_conv "[32,26]"` (parse_args.py:30) = Conv2d 128->32, ReLU, Conv2d 32->26 (utae.py:476-494, uncrtaints.py:381)."""
+    g, state, x, y, dates, cfg = _g23()
+    with torch.no_grad():
+        oe = orc.forward({k: v.clone() for k, v in state.items()}, x, dates, cfg, training=False)
+    assert rel_err(oe.numpy(), g["eval_out"]) < TOL
+    pt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in state.items()}
+    ot = orc.forward(pt, x, dates, cfg, training=True)
+    loss = orc.loss_from_output(ot, y, cfg)
+    loss.backward()
+    assert rel_err(ot.detach().numpy(), g["train_out"]) < TOL
+    assert abs(loss.item() - float(g["train_loss"])) < TOL * abs(float(g["train_loss"]))
+    class _Sub:          # the fixture's gradient entries, split by tolerance
+        def __init__(self, keys):
+            self.files = keys
+
+        def __getitem__(self, k):
+            return g[k]
+
+    got = {k: v.grad.numpy() for k, v in pt.items() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None}
+    gk = [k for k in g.files if k.startswith("grad/") or k.startswith("gradsum/")]
+    # in_conv's gradient on these ill-conditioned `weight_init` weights is the noise-dominated one: two CPU fp32 evaluations of the same
+    # graph -- the reference's modules on the fixture host, this restatement here -- sit 2.5e-4 apart on it
+    noisy = [k for k in gk if k.split("/", 1)[1].startswith("in_conv.")]
+    rep = compare_param_grads(got, _Sub([k for k in gk if k not in noisy]), tol=2e-4)
+    rep += compare_param_grads(got, _Sub(noisy), tol=5e-4)
+    assert len(rep) >= 90
+
+
+def test_oracle_small_input_vs_reference_fixture():
+    """g24: a 16 x 16 input -- AdaptiveMaxPool2d((32, 32)) pools UP (uncrtaints.py:403-404), the aggregator takes AvgPool2d(2) without
+    dropout (uncrtaints.py:197-204); written by the reference in train mode with its default attention dropout of 0.1."""
+    base, g = load_golden("g1_diag_t3"), load_golden("g24_small_input")
+    state = _state(base)
+    x, y, dates = (torch.from_numpy(g[k]) for k in ("x", "y", "dates"))
+    cfg = orc.OracleConfig()
+    with torch.no_grad():
+        oe = orc.forward({k: v.clone() for k, v in state.items()}, x, dates, cfg, training=False)
+    assert rel_err(oe.numpy(), g["eval_out"]) < TOL
+    pt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in state.items()}
+    ot = orc.forward(pt, x, dates, cfg, training=True)
+    loss = orc.loss_from_output(ot, y, cfg)
+    loss.backward()
+    assert rel_err(ot.detach().numpy(), g["train_out"]) < TOL
+    assert abs(loss.item() - float(g["train_loss"])) < 1e-4 * abs(float(g["train_loss"]))
+    got = {k: v.grad.numpy() for k, v in pt.items() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None}
+    rep = compare_param_grads(got, g, tol=1e-3)
+    assert len(rep) >= 90
+
+
+def test_oracle_instance_norm_att_mean_vs_reference_fixture():
+    """g25, written by the reference: encoder_norm='instance' + agg_mode='att_mean', B = 1, a padded date.  Before round 6 the oracle's
+    encoder gradients were ORTHOGONAL to the reference's here (ATen's CPU batch-norm backward on the strided gradient of the einsum-form
+    aggregation, oracle._ContiguousGrad) while every forward value agreed -- which rounds 4-5 read as a defect of the HIP path."""
+    g = load_golden("g25_instance_attmean")
+    state = _state(g)
+    x, y, dates = (torch.from_numpy(g[k]) for k in ("x", "y", "dates"))
+    cfg = orc.OracleConfig(encoder_norm="instance", agg_mode="att_mean", decoder_widths=[128], attn_dropout=0.0)
+    pt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in state.items()}
+    ot = orc.forward(pt, x, dates, cfg, training=True)
+    loss = orc.loss_from_output(ot, y, cfg)
+    loss.backward()
+    assert rel_err(ot.detach().numpy(), g["train_out"]) < TOL
+    assert abs(loss.item() - float(g["train_loss"])) < TOL * abs(float(g["train_loss"]))
+    got = {k: v.grad.numpy() for k, v in pt.items() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None}
+
+    class _Sub:      # without in_conv's bias: a shift in front of an InstanceNorm, mathematically zero, rounding noise x rstd = 316 on both sides
+        files = [k for k in g.files if (k.startswith("grad/") or k.startswith("gradsum/")) and not k.endswith("in_conv.conv.conv.0.bias")]
+
+        def __getitem__(self, k):
+            return g[k]
+
+    rep = compare_param_grads(got, _Sub(), tol=2e-4)
+    assert len(rep) >= 30

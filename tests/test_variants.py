@@ -135,6 +135,138 @@ def test_hip_variants(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["fixture", "odd"])
+def test_hip_multi_layer_out_conv(shape):
+    """`--out_conv "[32,26]"` (parse_args.py:30): Conv2d 128->32 + ReLU + Conv2d 32->26 with the output nonlinearities in the last
+    GEMM's epilogue (utae.py:476-494, uncrtaints.py:381); fixture g23 written by the reference.  'odd': the same model at 50 x 46
+    (padded planes) against the oracle."""
+    from gpu_util import Fp32Draws, close, close_grad, dev, is_zero_grad, oracle_run, pool_branch
+    from uncrtaints_amd.src import losses
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    base, g = load_golden("g1_diag_t3"), load_golden("g23_outconv_layers")
+    state = {k[6:]: torch.from_numpy(base[k]) for k in base.files if k.startswith("state/") and not k.startswith("state/out_conv.")}
+    state.update({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("state/")})
+    if shape == "fixture":
+        x, y, dates = (torch.from_numpy(base[k]) for k in ("x", "y", "dates"))
+    else:
+        x, y, dates = orc.synthetic_batch(1, 2, 50, 46, seed=23)
+    cfg = orc.OracleConfig(out_conv=[32, 26], attn_dropout=0.0)
+    m = U.UNCRTAINTS(input_dim=15, out_conv=[32, 26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag", scale_by=1.0)
+    m.load_state_dict(state, strict=True)
+    m.temporal_aggregator.attn_dropout.p = 0.0
+    m = m.to("cuda").eval()
+    with torch.no_grad():
+        oe = m(dev(x), batch_positions=dev(dates))
+    m.train()
+    out = m(dev(x), batch_positions=dev(dates))
+    l, _ = losses.MultiGaussianNLLLoss(reduction="mean", full=True, mode="diag")(out[:, :, :13], dev(y), out[:, :, 13:26])
+    l.backward()
+    pidx, _ = pool_branch(m, state, x, dates, cfg)
+    ot, lo, _, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx)
+    _, _, _, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64, pool_idx=pidx)
+    if shape == "fixture":
+        close("outconv2/eval vs reference", oe, torch.from_numpy(g["eval_out"]))
+        close("outconv2/train vs reference", out, torch.from_numpy(g["train_out"]))
+        assert abs(l.item() - float(g["train_loss"])) < 1e-4 * abs(float(g["train_loss"]))
+    close(f"outconv2[{shape}]/train", out, ot)
+    assert abs(l.item() - lo.item()) < 1e-4 * abs(lo.item())
+    draws = Fp32Draws(lambda: oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx)[3])
+    n = 0
+    for k, v in m.named_parameters():
+        if is_zero_grad(k, g64):
+            continue
+        close_grad(f"outconv2[{shape}]/grad[{k}]", v.grad, g32[k], g64[k], draws=draws, key=k)
+        n += 1
+    assert n > 80 and m.out_conv.conv.conv[0].weight.grad is not None and m.out_conv.conv.conv[2].weight.grad is not None
+
+
+@pytest.mark.gpu
+def test_hip_small_input_vs_reference_fixture():
+    """g24, written by the reference: a 16 x 16 input.  AdaptiveMaxPool2d((32, 32)) pools UP (uncrtaints.py:403-404; four cells share a
+    source pixel, the pooled gradient accumulates), the aggregator takes its AvgPool2d(32 // 16) branch without dropout
+    (uncrtaints.py:197-204); one padded date.  The planes are padded 256 -> 1024 pixels: a 75 % tail."""
+    from gpu_util import Fp32Draws, close, close_grad, dev, is_zero_grad, oracle_run, pool_branch
+    from uncrtaints_amd.src import losses
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    base, g = load_golden("g1_diag_t3"), load_golden("g24_small_input")
+    state = {k[6:]: torch.from_numpy(base[k]) for k in base.files if k.startswith("state/")}
+    x, y, dates = (torch.from_numpy(g[k]) for k in ("x", "y", "dates"))
+    cfg = orc.OracleConfig()
+    m = U.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag", scale_by=1.0)
+    m.load_state_dict(state, strict=True)
+    m = m.to("cuda").eval()
+    with torch.no_grad():
+        oe = m(dev(x), batch_positions=dev(dates))
+    close("small/eval vs reference", oe, torch.from_numpy(g["eval_out"]))
+    m.train()
+    out = m(dev(x), batch_positions=dev(dates))
+    l, _ = losses.MultiGaussianNLLLoss(reduction="mean", full=True, mode="diag")(out[:, :, :13], dev(y), out[:, :, 13:26])
+    l.backward()
+    close("small/train vs reference", out, torch.from_numpy(g["train_out"]))
+    assert abs(l.item() - float(g["train_loss"])) < 1e-4 * abs(float(g["train_loss"]))
+    pidx, _ = pool_branch(m, state, x, dates, cfg)
+    _, _, _, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx)
+    _, _, _, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64, pool_idx=pidx)
+    draws = Fp32Draws(lambda: oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx)[3])
+    n = 0
+    for k, v in m.named_parameters():
+        if is_zero_grad(k, g64):
+            continue
+        close_grad(f"small/grad[{k}]", v.grad, g32[k], g64[k], draws=draws, key=k)
+        n += 1
+    assert n > 80
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["fixture", "odd"])
+def test_hip_instance_norm_att_mean_with_a_padded_date(shape):
+    """g25, written by the reference: encoder_norm='instance' + agg_mode='att_mean', B = 1, a zero-padded date, in TRAINING.  Round 5
+    refused this configuration ("gradients not reliable"): the HIP gradients were right, the CPU oracle's were not (ATen's CPU
+    batch-norm backward on a strided gradient, oracle._ContiguousGrad); finite differences of the HIP forward settled it
+    (tools/debug_instance_pad.py --fd).  Every plane of the padded frame is constant: the InstanceNorm finalisation treats a plane whose
+    variance is below the resolution of its statistics as constant (A = 0, B = beta: the exact result), so the frame is exactly zero
+    behind every norm, as in the reference.  'odd': the same model at 40 x 100 (padded planes) against the oracle."""
+    from gpu_util import Fp32Draws, close, close_grad, dev, is_zero_grad, oracle_run, pool_branch
+    from uncrtaints_amd.src import losses
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    g = load_golden("g25_instance_attmean")
+    state = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("state/")}
+    kw = dict(encoder_norm="instance", agg_mode="att_mean", decoder_widths=[128])
+    if shape == "fixture":
+        x, y, dates = (torch.from_numpy(g[k]) for k in ("x", "y", "dates"))
+    else:
+        x, y, dates = orc.synthetic_batch(1, 2, 40, 100, seed=25)
+        x[0, 1] = 0.0
+    cfg = orc.OracleConfig(attn_dropout=0.0, **kw)
+    m = U.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag", scale_by=1.0, **kw)
+    m.load_state_dict(state, strict=True)
+    m.temporal_aggregator.attn_dropout.p = 0.0
+    m = m.to("cuda").train()
+    m.keep_boundaries = True
+    out = m(dev(x), batch_positions=dev(dates))
+    l, _ = losses.MultiGaussianNLLLoss(reduction="mean", full=True, mode="diag")(out[:, :, :13], dev(y), out[:, :, 13:26])
+    l.backward()
+    e = m._boundary_enc                       # the encoder output on the folded frames: the padded one is exactly zero
+    assert float(e.reshape(e.shape[0], -1)[-1].abs().max()) == 0.0
+    if shape == "fixture":
+        close("instance_attmean/train vs reference", out, torch.from_numpy(g["train_out"]))
+        assert abs(l.item() - float(g["train_loss"])) < 1e-4 * abs(float(g["train_loss"]))
+    pidx, _ = pool_branch(m, state, x, dates, cfg)
+    ot, lo, _, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx)
+    _, _, _, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64, pool_idx=pidx)
+    close(f"instance_attmean[{shape}]/train", out, ot)
+    draws = Fp32Draws(lambda: oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx)[3],
+                      extra=[{k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad/")}] if shape == "fixture" else [])
+    n = 0
+    for k, v in m.named_parameters():
+        if is_zero_grad(k, g64) or k == "in_conv.conv.conv.0.bias":      # (a shift in front of an InstanceNorm: zero, noise x 316 everywhere)
+            continue
+        close_grad(f"instance_attmean[{shape}]/grad[{k}]", v.grad, g32[k], g64[k], draws=draws, key=k)
+        n += 1
+    assert n > 40
+
+
+@pytest.mark.gpu
 def test_iso_ensemble_inference_config5():
     """BASELINE config 5: five iso members, inference only, mixture-moment combine
     (ensemble_reconstruct.py:116-133) -- HIP members + HIP combine against the oracle."""

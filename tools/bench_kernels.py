@@ -136,8 +136,8 @@ def main():
         slots = hb.query("uncr_pw_stat_slots", N, 128, P)
         part = torch.empty(N * 128, slots, 2, device=dev)
         for _ in range(3):
-            hb.call("uncr_pw_gemm_dx", d, d2, W1k, dx, dk[0], dk[1], dk[2], None, dy, xx, xh3, c[0], c[1], c[2], None, None, None, part,
-                    N, 256, 128, P, act, None, None if bf else amax(d), 0 if bf else 1, None if bf else amax(d2), 0 if bf else 1, E._stream())
+            hb.call("uncr_pw_gemm_dx", d, d2, W1k, dx, dk[0], dk[1], dk[2], None, dy, xx, xh3, c[0], c[1], c[2], None, None, None, None, part,
+                    N, 256, 128, P, act, None, None if bf else amax(d), 0 if bf else 1, None if bf else amax(d2), 0 if bf else 1, P, E._stream())
         # the depthwise kernels
         C, H, W = 256, 256, 256
         t4 = lambda *s: torch.randn(*s, device=dev).to(adt)
@@ -158,7 +158,7 @@ def main():
         Wt = E.pack_wt(W, transpose=True); out = torch.empty(N, Cout, P, device=dev)
         from uncrtaints_amd import hip_backend as hb
         for flags, name in [(0, "full")]:
-            fn = lambda: hb.call("uncr_pw_gemm", x, None, Wt, out, None, None, None, None, None, 0, None, None, None, None, None, None, N, Cin, Cout, P, 0, flags, 0, 0, None, None, 0, None, 0, E._stream())
+            fn = lambda: hb.call("uncr_pw_gemm", x, None, Wt, out, None, None, None, None, None, 0, None, None, None, None, None, None, N, Cin, Cout, P, 0, flags, 0, 0, None, None, 0, None, 0, P, E._stream())
             ms = timeit(fn, iters)
             print(f"{name:28s}: {ms*1e3:.1f} us  {2.0*N*P*Cin*Cout/ms/1e9:.1f} TF")
     elif what == "mfma":

@@ -72,7 +72,7 @@ def main():
         part = torch.empty(N * 128, slots, 2, device=dev)
         ad, ad2 = amax(d), amax(d2)
         ms = timeit(lambda: hb.call("uncr_pw_gemm_dx", d, d2, W1k, o128, dk[0], dk[1], dk[2], None, dy, xx, xh3, c[0], c[1], c[2], None, None,
-                                    None, part, N, 256, 128, P, 0, None, ad, 1, ad2, 1, E._stream()), iters)
+                                    None, None, part, N, 256, 128, P, 0, None, ad, 1, ad2, 1, P, E._stream()), iters)
         res["dx [256->128, normbwd + skip]"] = (ms, 4.0 * N * P * (2 * 256 + 4 * 128))
     tag = os.path.basename(os.environ.get("UNCR_HIP_LIB", "base"))
     for name, (ms, by) in res.items():

@@ -85,7 +85,7 @@ def main(out_path):
         c = tuple(t(N * 128) for _ in range(3))
         part = torch.empty(N * 128, hb.query("uncr_pw_stat_slots", N, 128, P), 2, device=dev)
         loop(f"dx [{data}]", lambda: hb.call("uncr_pw_gemm_dx", d, d2, W1k, o128, dk[0], dk[1], dk[2], None, x, x2, x, c[0], c[1], c[2], None, None,
-                                             None, part, N, 256, 128, P, 0, None, a45, 1, a45, 1, E._stream()), 4.0 * N * P * 1024)
+                                             None, None, part, N, 256, 128, P, 0, None, a45, 1, a45, 1, P, E._stream()), 4.0 * N * P * 1024)
         xk = (t(N * 128), t(N * 128), None)
         loop(f"wgrad [256x128] [{data}]", lambda: E.pw_wgrad(d, x, N, 256, 128, P, pro_d=3, dk=dk, d2=d2, pro_x=1, xk=xk), 4.0 * N * P * 640)
         dk1 = tuple(v[:N * 128] for v in dk)
@@ -109,7 +109,7 @@ def main(out_path):
         c = tuple(t(N * 128) for _ in range(3))
         part = torch.empty(N * 128, hb.query("uncr_pw_stat_slots", N, 128, P), 2, device=dev)
         loop("bf16 dx", lambda: hb.call("uncr_pw_gemm_dx", d, d2, W1k, o128, dk[0], dk[1], dk[2], None, x, x2, x, c[0], c[1], c[2], None, None,
-                                        None, part, N, 256, 128, P, 1, None, None, 0, None, 0, E._stream()), 2.0 * N * P * 1024)
+                                        None, None, part, N, 256, 128, P, 1, None, None, 0, None, 0, P, E._stream()), 2.0 * N * P * 1024)
         xk = (t(N * 128), t(N * 128), None)
         loop("bf16 wgrad [256x128]", lambda: E.pw_wgrad(d, x, N, 256, 128, P, pro_d=3, dk=dk, d2=d2, pro_x=1, xk=xk), 2.0 * N * P * 640)
         dk1 = tuple(v[:N * 128] for v in dk)

@@ -424,6 +424,10 @@ _SE_POOL4 = True
 # inference: an eval-mode MBConv's closing BatchNorm + skip in the epilogue of its pw2 GEMM (uncr_pw_gemm epi 10); False: GEMM, then the
 # element-wise residual pass (tests: the two are bit-identical in fp32 storage)
 _EVAL_TAIL = True
+# InstanceNorm PreNorm: pw1's weight-gradient products on x - mean (False: raw x, bisecting)
+_CENTRED_PW1 = True
+# in_conv's backward statistics centred on the norm's mean (False: raw sum du0*c0, bisecting)
+_CENTRED_INCONV = True
 
 # development (tools/ablate_ltae_stage.py): "record" keeps the L-TAE stage's results of the next forward / backward, "replay" hands
 # them back without launching anything -- the stage's cost inside the captured step = step time with it minus step time without it
@@ -432,7 +436,8 @@ _LTAE_STORE: Dict[str, tuple] = {}
 
 _DEV_OPTIONS = {"ltae_replay": "_LTAE_REPLAY", "side_stream": "_USE_SIDE", "centred_normbwd": "_CENTRED_NORMBWD", "h2_bwd": "_H2_BWD", "h2_wgrad": "_H2_WGRAD",
                 "h2_dx": "_H2_DX", "h2_fwd": "_H2_FWD", "prepack": "_PREPACK", "fused_dx": "_FUSED_DX", "fused_ltae": "_FUSED_LTAE",
-                "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER", "inconv_moments": "_INCONV_MOMENTS", "se_pool4": "_SE_POOL4", "eval_tail": "_EVAL_TAIL", "agg_two_pass": "_AGG_TWO_PASS"}
+                "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER", "inconv_moments": "_INCONV_MOMENTS", "se_pool4": "_SE_POOL4", "eval_tail": "_EVAL_TAIL", "agg_two_pass": "_AGG_TWO_PASS",
+                "centred_pw1": "_CENTRED_PW1", "centred_inconv": "_CENTRED_INCONV"}
 
 
 class dev_options:
@@ -1109,7 +1114,7 @@ def mbconv_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool = 
         # InstanceNorm (one group per plane): the products are taken on x - mean, so that a plane far from zero -- or a CONSTANT one, a
         # zero-padded date -- leaves no difference of two separately rounded sums behind (uncr_prenorm_bwd_finish, xmu)
         xmu = negmu = None
-        if n0.kind == NORM_GROUP and n0.groups == C and n0.mean.numel() == N * C:
+        if _CENTRED_PW1 and n0.kind == NORM_GROUP and n0.groups == C and n0.mean.numel() == N * C:
             xmu, negmu = n0.mean, plane_means(n0, N, C, -1.0)
         wpart, nbx, cop, cip = pw_wgrad(du1, x, N, Ch, C, P, pro_d=PRO_NORMBWD, dk=k1, d2=h1, pro_x=PRO_AFFINE,
                                         xk=(one, zero if negmu is None else negmu, None), partials=True)
@@ -1351,7 +1356,7 @@ def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec
     _, parta = ew(EW_AFFINE_RELU, c0, out=a0, k=(nf.A, nf.B, None, None), want_part=True, planes=N * Cout, P=P)
     # per-plane means of the norm: pivots of the backward's second statistic, sum du0*(c0 - mean) -- c0 = W x + b of non-negative
     # inputs sits several standard deviations from zero, and the raw sum du0*c0 - mean*sum du0 cancels in fp32 slots
-    mu = plane_means(nf, N, Cout) if (need and training) else None
+    mu = plane_means(nf, N, Cout) if (need and training and _CENTRED_INCONV) else None
     return a0, dict(x=x, c0=c0, nf=nf, mu=mu, dims=(N, Cin, Cout, H, W), geom=geom), parta
 
 
@@ -1590,6 +1595,15 @@ def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: b
         # padded planes of an any-size image (csrc/anysize.hip): the scalar kernels on the true H x W (bilinear up-sampling of any ratio)
         if _dt(e) != F32:
             raise NotImplementedError("any-size planes are built for fp32 storage")
+        if odd_heads is None and geom.H <= aw and (geom.H, geom.W) != (ah, aw):
+            # a feature map not larger than the attention map (inputs below 32 x 32: uncrtaints.py:403-404 pools UP to 32 x 32 and the
+            # aggregator takes its AvgPool2d(w // H) branch, uncrtaints.py:197-204): a few hundred pixels per plane -- through the dense
+            # kernels of that branch on extracted planes, the result embedded again
+            with geom_scope(None):
+                gd, svd, _ = aggregate_forward(extract_tail(e, geom), att, pad, training, p_drop, seed, dmask, False, shared_mask)
+            g = embed_tail(gd, geom)
+            gpart = stats_sq(g, B * C, geom.Pc) if want_stats else None
+            return g, dict(small=svd, geom=geom, dims=(B, T, C, H, W, n_head, ah, aw)), gpart
         if geom.H < ah or geom.W < aw:
             raise NotImplementedError(f"feature map {geom.H}x{geom.W} against a {ah}x{aw} attention map")
         g = _f32((B, C, H, W), dev)
@@ -1645,6 +1659,10 @@ def aggregate_backward(dg: Tensor, sv: dict):
     B, T, C, H, W, n_head, ah, aw = sv["dims"]
     dev = dg.device
     geom = sv.get("geom") or sv.get("any")
+    if "small" in sv:         # the AvgPool branch of a padded-plane feature map: dense kernels on extracted planes (aggregate_forward)
+        with geom_scope(None):
+            ded, datt = aggregate_backward(extract_tail(dg.contiguous().float(), geom), sv["small"])
+        return embed_tail(ded, geom), datt
     if geom is not None:
         de = _f32((B, T, C, H, W), dev)
         datt_up = _f32((n_head * B * T, geom.P), dev)

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from ... import engine as E
 from .ltae import LTAE2d, LTAE2dtiny, _LTAE_KEYS, _LTAEV_KEYS, _ltae_params, _ltae_value_params
-from .utae import ConvBlock, ConvLayer, TemporallySharedBlock
+from .utae import ConvBlock, ConvLayer, TemporallySharedBlock, _ConvBiasReluFn
 
 S2_BANDS = 13
 
@@ -589,6 +589,8 @@ class UNCRTAINTS(nn.Module):
                 raise NotImplementedError("bf16 activations are built for block_type='mbconv' without use_v")
             if self.out_dims > 64:
                 raise NotImplementedError("bf16 activations: out_conv wider than 64 channels is not built")
+            if len(self.out_widths) > 1:
+                raise NotImplementedError("bf16 activations: a multi-layer out_conv is built for fp32 storage")
         self.act_dtype = dtype
         return self
 
@@ -615,7 +617,9 @@ class UNCRTAINTS(nn.Module):
                 both(p["inconv_w"])
                 both(p["fc_w"])
         if not self.separate_out:
-            both(self.out_conv.conv.conv[0].weight)
+            for mod in self.out_conv.conv.conv:
+                if isinstance(mod, nn.Conv2d):
+                    both(mod.weight)
         return out
 
     def forward(self, input, batch_positions=None):
@@ -646,8 +650,6 @@ class UNCRTAINTS(nn.Module):
         # any H x W (uncrtaints.py:391-447): a size outside the tuned tilings runs on padded planes [frames, C, 1, Pc] (dense H*W pixels
         # + a zero tail) inside a geometry scope; the output is cut back to [B, 1, C_out, H, W] at the end
         geom = E.plan_geom(h, w)
-        if not self.is_mono and (h < 32 or w < 32):
-            raise NotImplementedError(f"spatial size {h}x{w}: at least 32x32 (the L-TAE stage pools to 32x32)")
         if geom is not None:
             if self.act_dtype == torch.bfloat16:
                 raise NotImplementedError(f"spatial size {h}x{w} (H*W not a multiple of 1024 or W not of 4) is built for fp32 storage")
@@ -696,7 +698,12 @@ class UNCRTAINTS(nn.Module):
             else:
                 w_all, b_all = cm.weight, cm.bias
         else:
-            conv = self.out_conv.conv.conv[0]
+            # out_conv with several layers (`--out_conv "[32,13]"`, parse_args.py:30): Conv2d + ReLU for every layer but the last
+            # (utae.py:476-494 with norm='none', last_relu=False); the last one carries the output nonlinearities in its epilogue
+            convs = [mod for mod in self.out_conv.conv.conv if isinstance(mod, nn.Conv2d)]
+            for cl in convs[:-1]:
+                out = _ConvBiasReluFn.apply(out, cl.weight, cl.bias)
+            conv = convs[-1]
             w_all, b_all = conv.weight, conv.bias
         if not self.covmode:
             # mean only: plain conv + mean nonlinearity on all out_dims channels

@@ -105,6 +105,39 @@ class _ConvBiasFn(torch.autograd.Function):
         return dx, dW.view_as(w), db
 
 
+class _ConvBiasReluFn(torch.autograd.Function):
+    """Conv2d(k=1, bias) + ReLU without a norm: the inner layers of a multi-layer out_conv (`--out_conv "[32,13]"`, utae.py:453-497 with
+    norm='none', last_relu=False: a ReLU behind every convolution but the last)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        N, C, H, W = E._check4(x)
+        Co = w.shape[0]
+        pre, _ = E.pw_gemm(x, E.pack_wt(w.reshape(Co, C), transpose=True), N, C, Co, H * W, bias=b.contiguous())
+        one, zero = E._const_planes(x.device, N * Co)
+        out = torch.empty_like(pre)
+        E.ew(E.EW_AFFINE_RELU, pre, out=out, k=(one, zero, None, None), planes=N * Co, P=H * W)
+        ctx.save_for_backward(x, w, pre)
+        return out.view(N, Co, H, W)
+
+    @staticmethod
+    def backward(ctx, do):
+        x, w, pre = ctx.saved_tensors
+        N, C, H, W = x.shape
+        Co = w.shape[0]
+        one, zero = E._const_planes(x.device, N * Co)
+        do = E.cast(do.contiguous(), E._dt(pre))
+        dpre = torch.empty_like(pre)
+        E.ew(E.EW_RELU_BWD, do, b=pre, out=dpre, k=(one, zero, None, None), planes=N * Co, P=H * W)
+        dW, db = E.pw_wgrad(dpre, x, N, Co, C, H * W, rowsum=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, _ = E.pw_gemm(dpre, E.pack_wt(w.reshape(Co, C), transpose=False), N, Co, C, H * W)
+            dx = dx.view(N, C, H, W)
+        return dx, dW.view_as(w), db
+
+
 class ConvLayer(nn.Module):
     def __init__(self, nkernels, norm="batch", k=3, s=1, p=1, n_groups=4, last_relu=True, padding_mode="reflect"):
         super().__init__()
@@ -146,19 +179,29 @@ class ConvLayer(nn.Module):
         return {}
 
     def forward(self, input):
-        if self._k != 1 or self._s != 1 or self._p != 0 or self._nconv != 1:
-            raise NotImplementedError("HIP ConvLayer is built for single 1x1 convolutions (the UNCRTAINTS in_conv / "
-                                      "out_conv configuration)")
-        conv = self.conv[0]
-        if self._norm in ("group", "batch", "instance") and self._last_relu:
-            nrm = self.conv[1]
-            out = _ConvNormActFn.apply(input, conv.weight, conv.bias, nrm.weight, nrm.bias, self)
-            if isinstance(nrm, nn.BatchNorm2d) and self.training:
-                nrm.num_batches_tracked += 1
-            return out
-        if self._norm in (None, "none") and not self._last_relu:
-            return _ConvBiasFn.apply(input, conv.weight, conv.bias)
-        raise NotImplementedError(f"ConvLayer(norm={self._norm}, last_relu={self._last_relu}) is not built")
+        if self._k != 1 or self._s != 1 or self._p != 0:
+            raise NotImplementedError("HIP ConvLayer is built for 1x1 convolutions (the UNCRTAINTS in_conv / out_conv configuration)")
+        mods = list(self.conv)
+        out, i = input, 0
+        while i < len(mods):                     # Conv2d [norm] [ReLU] groups, as the constructor laid them out (utae.py:476-494)
+            conv = mods[i]
+            nrm = mods[i + 1] if (i + 1 < len(mods) and not isinstance(mods[i + 1], (nn.ReLU, nn.Conv2d))) else None
+            j = i + 1 + (nrm is not None)
+            relu = j < len(mods) and isinstance(mods[j], nn.ReLU)
+            i = j + (1 if relu else 0)
+            if nrm is not None and relu:
+                if self._nconv != 1:
+                    raise NotImplementedError("HIP ConvLayer: a normalised 1x1 convolution is built as a single layer (in_conv)")
+                out = _ConvNormActFn.apply(out, conv.weight, conv.bias, nrm.weight, nrm.bias, self)
+                if isinstance(nrm, nn.BatchNorm2d) and self.training:
+                    nrm.num_batches_tracked += 1
+            elif nrm is None and relu:
+                out = _ConvBiasReluFn.apply(out, conv.weight, conv.bias)
+            elif nrm is None:
+                out = _ConvBiasFn.apply(out, conv.weight, conv.bias)
+            else:
+                raise NotImplementedError(f"ConvLayer(norm={self._norm}, last_relu={self._last_relu}): a norm without a ReLU is not built")
+        return out
 
 
 class ConvBlock(TemporallySharedBlock):
