@@ -202,20 +202,26 @@ def _model(**kw):
 ])
 def test_model_variants_at_odd_sizes(name, kw, shape):
     """Constructor variants at sizes outside the tuned tilings (odd widths included), one padded date where there are several: eval and
-    train forward, loss and every gradient against the oracle."""
+    train forward, loss and every gradient against the oracle.  Input / initialisation seeds 7 / 6 for every variant."""
+    _variant_at_odd_size(name, kw, shape, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [5, 6, 8, 9, 10, 11, 12])
+def test_batch_norm_encoder_at_odd_size_over_seeds(seed):
+    """Round 5 ran `batch_norm_encoder_two_blocks` on seed 8 because on seed 7 one cancelling gradient landed at 1.8e-4 (4.3 x the CPU
+    paths).  With the tail out of every reduction the variant runs on seed 7 above and on its neighbours here."""
+    _variant_at_odd_size("batch_norm_encoder_two_blocks", dict(encoder_norm="batch", encoder_widths=[128, 128]), (2, 2, 34, 70), seed - 7)
+
+
+def _variant_at_odd_size(name, kw, shape, s):
     from gpu_util import Fp32Draws, close, close_grad, dev, is_zero_grad, oracle_run, pool_branch
     from oracle import uncrtaints_oracle as orc
     from uncrtaints_amd.src import losses
     B, T, H, W = shape
     cfg = orc.OracleConfig(attn_dropout=0.0, ltae_dropout=0.0, **kw)
-    # Input / initialisation seeds: 7 / 6, except for the batch-norm encoder.  There seed 7 is an input on which ONE cancelling
-    # gradient (out_block.4 BatchNorm-1 gamma) lands 4.3x further from fp64 on the HIP path (1.8e-4) than on the CPU paths, while on
-    # the seven neighbouring seeds HIP and CPU agree within 1.5x on every gradient, and any change of rounding (libm erf / exp,
-    # another summation order in the depthwise statistics) moves the outlier elsewhere (tools/odd_size_noise.py --affines).  The
-    # distribution over inputs is what tests/test_parity_rule.py holds the path to; this test is about the odd-size plumbing.
     # (The use_v cases had a 3.8e-3 outlier on seed 7 that WAS a kink: one value-MLP ReLU with |u| = 9e-8 decided differently by
-    # `A*c + B` in fp32 and by the kernels' fmaf -- gpu_util.relu_branch now decides like the kernels, tools/debug_spike.py.)
-    s = {"batch_norm_encoder_two_blocks": 1}.get(name, 0)
+    # `A*c + B` in fp32 and by the kernels' fmaf -- gpu_util.relu_branch decides like the kernels, tools/debug_spike.py.)
     x, y, dates = orc.synthetic_batch(B, T, H, W, seed=7 + s)
     if T > 1:
         x[B - 1, T - 1] = 0.0
@@ -352,8 +358,8 @@ def test_odd_size_properties_and_refusals():
     assert float((o2.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
     with pytest.raises(NotImplementedError):
         _model().to("cuda").set_act_dtype("bf16")(dev(x), batch_positions=dev(dates))
-    with pytest.raises(NotImplementedError):
-        _model().to("cuda")(dev(x[..., :20, :20]), batch_positions=dev(dates))        # smaller than the 32 x 32 attention map
+    with pytest.raises(ValueError):       # 20 x 20: AvgPool2d(32 // 20 = 1) leaves the 32 x 32 map as it is -- the reference fails on the
+        _model().to("cuda")(dev(x[..., :20, :20]), batch_positions=dev(dates))        # product too (uncrtaints.py:197-204); 16 x 16 runs: g24
     # encoder_norm='instance' over a padded (constant) date trains (round 5 refused it: tests/test_variants.py::test_hip_instance_norm_att_mean...)
     xp = x.clone()
     xp[0, 2] = 0.0

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
 
     __shared__ float wred[BMODE == 2 ? 1 : 4][BMODE == 2 ? 1 : 256][2];   // per-wave statistics partials (forward), C <= 256
     __shared__ float sred[2][BMODE == 2 ? 4 : 1][BMODE == 2 ? CH : 1][3];    // pass 2: per-wave (sum, sum*h3, max) of the CH planes of one (head, date)
-    __shared__ float rowc[FOLD ? 2 : 1][4][32];      // FOLD: the four rows' cells, weighted for the two low-res rows
+    __shared__ float rowc[FOLD ? 2 : 1][FOLD ? 2 : 1][4][32];      // FOLD: [pair parity][low-res row][wave][cell]: the four rows' cells, weighted for the two low-res rows
     // heads are split over blockIdx.z (more blocks in flight: the kernel is pure latency/bandwidth bound)
     const int hpb = (g.NH + gridDim.z - 1) / gridDim.z;
     const int h_beg = blockIdx.z * hpb, h_end = min(g.NH, h_beg + hpb);
@@ -258,16 +258,18 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs g, int nrows) {
                 const float from_left = __shfl(vp, (lane + 63) & 63, 64), from_r1 = __shfl(v0, (lane + 1) & 63, 64),
                             from_r2 = __shfl(vm, (lane + 2) & 63, 64);
                 const float cell = (((lane > 0 ? from_left : 0.f) + v0) + from_r1) + (lane < 62 ? from_r2 : 0.f);
-                __syncthreads();                 // the previous date's cells have been read
+                // two buffers by the parity of the block's (head, date) counter: ONE barrier per pair (a buffer is rewritten two barriers
+                // after it was read; round 5 had a second barrier in front of the writes: 96 instead of 48 per block at 16 heads x 3 dates)
+                const int rp = ((h - h_beg) * g.T + t) & 1;
                 if ((lane & 1) == 0) {
-                    rowc[0][wv][f] = by.l0 * cell;
-                    rowc[1][wv][f] = by.l1 * cell;
+                    rowc[rp][0][wv][f] = by.l0 * cell;
+                    rowc[rp][1][wv][f] = by.l1 * cell;
                 }
                 __syncthreads();
                 if (threadIdx.x < 64) {
                     const int r = threadIdx.x >> 5, a = threadIdx.x & 31;
                     g.datt_up[((((size_t)h * g.B + b) * g.T + t) * gridDim.x + blockIdx.x) * 2 * g.AW + r * g.AW + a] =
-                        ((rowc[r][0][a] + rowc[r][1][a]) + rowc[r][2][a]) + rowc[r][3][a];
+                        ((rowc[rp][r][0][a] + rowc[rp][r][1][a]) + rowc[rp][r][2][a]) + rowc[rp][r][3][a];
                 }
             }
         }

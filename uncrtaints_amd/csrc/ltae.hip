@@ -534,7 +534,7 @@ extern "C" int uncr_pad_mask(const float* x, int NF, long long frame_elems, floa
 
 extern "C" int uncr_maxpool_fwd(const void* in, float* out, int* idx, int planes, int H, int W, int OH, int OW, int act,
                                 hipStream_t stream) {
-    if (planes <= 0 || H < OH || W < OW) return UNCR_ESHAPE;
+    if (planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return UNCR_ESHAPE;      // (H < OH pools UP: every window holds >= 1 element)
     if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
     UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3((OH * OW + 255) / 256, planes), dim3(256), 0,
                                                  stream, (const T*)in, out, idx, H, W, OH, OW, H * W));
@@ -544,7 +544,7 @@ extern "C" int uncr_maxpool_fwd(const void* in, float* out, int* idx, int planes
 // the same on planes with a padded stride (csrc/anysize.hip: dense H*W pixels + a zero tail); idx stays the flat index inside the H x W image
 extern "C" int uncr_maxpool_fwd_strided(const float* in, float* out, int* idx, int planes, int H, int W, int pstride, int OH, int OW,
                                         hipStream_t stream) {
-    if (planes <= 0 || H < OH || W < OW || pstride < H * W) return UNCR_ESHAPE;
+    if (planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || pstride < H * W) return UNCR_ESHAPE;
     if (!in || !out || !idx) return UNCR_EINVAL;
     hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3((OH * OW + 255) / 256, planes), dim3(256), 0, stream, in, out, idx, H, W, OH, OW,
                        pstride);
