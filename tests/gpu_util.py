@@ -33,7 +33,7 @@ def rand(*shape, seed=0, scale=1.0, shift=0.0):
 def close_vs_truth(name, got, ref32, truth64, tol=TOL, slack=4.0, alt32=None, kink_frac=0.0, cap=None):
     # kink_frac > 0: tensors downstream of the 8x8 max-pool (activation / input gradients).  A near-tie inside a
     # pooling window can pick a different arg-max under a 1e-6 forward difference; the gradient then lands on the
-    # neighbouring pixel -- a kink of the function, not an arithmetic error (verified with tools/debug_argmax.py on
+    # neighbouring pixel -- a kink of the function, not an arithmetic error (verified in round 3 with a stage-by-stage arg-max debugger, since removed, on
     # g1_iso_t6: 2 of 786 432 cells have fp64 top-2 gaps of 3e-7 and flip on HIP and on CPU fp32 alike; one flipped
     # cell perturbs ~1e-3 of a frame's input gradient through the 3x3 adjoint).  Those tensors pass if at most
     # `kink_frac` of their elements deviate by more than `tol` (relative to the tensor's max).
@@ -192,6 +192,31 @@ def value_relu_mask(model):
     m1, A, B = model.temporal_encoder._last_relu
     b, c, s = m1.shape
     return {"temporal_encoder.mlp": relu_branch(m1, A.view(b, c, 1), B.view(b, c, 1)).permute(0, 2, 1).reshape(b * s, c).cpu()}
+
+
+def inconv_relu_mask(m, state, x, dates, cfg, training=True, tol=2e-6):
+    """{"in_conv": 0/1 [B*T, C, H, W]}: the branch in_conv's ReLU took in the HIP model's last forward (m.keep_boundaries must have been
+    set before it), after checking against the fp64 oracle that every element decided differently has a pre-activation within `tol` of
+    max|u| of zero (a genuine near-tie, not an arithmetic error).  -> (masks, number of elements decided differently)"""
+    from oracle import uncrtaints_oracle as orc
+    from uncrtaints_amd import engine as E
+    a0 = m._boundary_a0.detach()
+    B, T, _, H, W = x.shape
+    geom = E.plan_geom(H, W)
+    if geom is not None:
+        a0 = E.extract_tail(a0.float(), geom)
+    mask = (a0.float() > 0).float().cpu().reshape(B * T, -1, H, W)
+    pt = {k: (v.double().clone() if v.dtype.is_floating_point else v.clone()) for k, v in state.items()}
+    p64 = pt
+    with torch.no_grad():
+        c0 = orc.conv1x1(x.double().reshape(B * T, -1, H, W), p64["in_conv.conv.conv.0.weight"], p64["in_conv.conv.conv.0.bias"])
+        u0 = orc._NormCtx(p64, cfg.encoder_norm, training, False)(c0, "in_conv.conv.conv.1")
+    diff = mask.double() != (u0 > 0).double()
+    flips = int(diff.sum())
+    gap = float(u0[diff].abs().max() / u0.abs().max()) if flips else 0.0
+    assert gap <= tol, f"in_conv's ReLU decided an element with |u| = {gap:.2e} of max|u| the other way"
+    print(f"[parity] in_conv ReLU branch: {flips} of {mask.numel()} elements decided differently from the fp64 oracle (largest |u| {gap:.1e} of max|u|)")
+    return {"in_conv": mask}, flips
 
 
 def relu_branch(c, A, B):

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 
 from conftest import rel_err
-from gpu_util import dev, is_zero_grad, oracle_run, pool_branch, value_relu_mask
+from gpu_util import dev, inconv_relu_mask, is_zero_grad, oracle_run, pool_branch, value_relu_mask
 from oracle import uncrtaints_oracle as orc
 from uncrtaints_amd.src import losses
 from uncrtaints_amd.src.backbones import uncrtaints as U
@@ -112,6 +112,7 @@ def run_case(case, overrides=()):
             m.temporal_encoder.dropout.p = 0.0
             m.temporal_encoder.keep_relu_branch = True
         m = m.to("cuda").eval()
+        m.keep_boundaries = True
         with torch.no_grad():
             oe = m(dev(x), batch_positions=dev(dates))
             re_ = orc.forward({k: v.clone() for k, v in state.items()}, x, dates, cfg, training=False)
@@ -123,6 +124,9 @@ def run_case(case, overrides=()):
         l.backward()
         pidx = None if mono else pool_branch(m, state, x, dates, cfg)[0]
         vm = value_relu_mask(m) if kw.get("use_v") else None
+        if "--pin-inconv" in sys.argv:        # in_conv's ReLU on the branch the HIP forward took (gpu_util.inconv_relu_mask)
+            im, _ = inconv_relu_mask(m, state, x, dates, cfg)
+            vm = {**(vm or {}), **im}
         ot, lo, _, g32, _ = oracle_run(state, x, y, dates, cfg, torch.float32, pool_idx=pidx, relu_masks=vm)
         _, _, _, g64, _ = oracle_run(state, x, y, dates, cfg, torch.float64, pool_idx=pidx, relu_masks=vm)
         e_train = rel_err(out.detach().cpu().numpy(), ot.numpy())

@@ -40,8 +40,11 @@ def run(N, shape):
         fn()
     e0.record(); part, nbx, cop, cip = fn(); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3
-    # s_memtime ticks at the constant 100 MHz reference clock: 0.01 us per tick (check: block total ~ kernel time)
-    s = part.view(N * nbx, -1)[:, :8].cpu().double() * 0.01
+    raw = part.view(N * nbx, -1)[:, :8].cpu().double()
+    rtot = raw[:, 0] + raw[:, 6] + raw[:, 1] + raw[:, 2]
+    # the counter runs at the shader clock: every block lives for the whole kernel, so mean block total = the kernel's event time
+    s = raw * (us / float(rtot.mean()))
+    s[:, 3], s[:, 7], s[:, 4] = raw[:, 3] * 0.01, raw[:, 7] * 0.01, raw[:, 4] * 0.01
     tot = s[:, 0] + s[:, 6] + s[:, 1] + s[:, 2]
     f = lambda v: f"{v.mean():.1f}/{v.max():.1f}"
     xcc = (s[:, 7] * 100).round().long()

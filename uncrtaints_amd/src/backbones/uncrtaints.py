@@ -661,6 +661,8 @@ class UNCRTAINTS(nn.Module):
         if self.act_dtype == torch.bfloat16:           # everything downstream allocates in the storage type of its input
             x4 = _CastFn.apply(x4, E.BF16)
         x4 = self.in_conv(x4)
+        if self.keep_boundaries:
+            self._boundary_a0 = x4          # in_conv's relu(norm(c0)): parity tests read the branch its ReLU took from it (a0 > 0)
         pooled = None
         for li, layer in enumerate(self.in_block):
             if li == len(self.in_block) - 1 and not self.is_mono and h % 32 == 0 and w % 32 == 0:
