@@ -265,7 +265,7 @@ int uncr_dw_wgrad_reduce(const float* dw_part, int N, int C, int NPT, float* dw,
  *      of every reduction (uncr_ew, uncr_pw_gemm + uncr_fix_tail, uncr_pw_wgrad + uncr_wgrad_boundary), the 2-D kernels below read and write valid pixels only (csrc/anysize.hip).  fp32 storage. ---- */
 int uncr_any_plane_stride(int H, int W);
 int uncr_dw_any_slots(int H, int W, int bwd); /* statistics slots (row bands) per plane of uncr_dw_fwd_any (bwd 0) / uncr_dw_bwd_any (1); -1: W too wide */
-int uncr_agg_any_slots(void);      /* ... of uncr_aggregate_any_fwd */
+int uncr_agg_any_slots(int Pc, int C, int NH);      /* ... of uncr_aggregate_any_fwd: Pc / 1024 on the float4 kernels (2, 4, 6, 8, 16, 32 channels per head), 8 on the scalar ones */
 int uncr_embed_tail(const float* src /* [planes][P] */, float* dst /* [planes][Pc] */, int planes, int P, int Pc, hipStream_t stream);
 int uncr_extract_tail(const float* src /* [planes][Pc] */, float* dst /* [planes][P] */, int planes, int P, int Pc, hipStream_t stream);
 /* t [planes][Pc] is the output of a pointwise GEMM launched with Pv = P < Pc: its statistics left out every `unit`-pixel tile that
@@ -288,7 +288,7 @@ int uncr_maxpool_fwd_strided(const float* in, float* out, int* idx, int planes, 
 int uncr_maxpool_bwd_strided(const float* dout, const int* idx, float* din, int planes, int H, int W, int pstride, int OH, int OW,
                              hipStream_t stream);
 /* temporal aggregation (uncrtaints.py:156-221) with the meaning of uncr_aggregate_fwd / _bwd on planes of stride Pc, any up-sampling
- * ratio; part [B*C][uncr_agg_any_slots()][2]; datt_up: [NH*B*T][H*W] scratch */
+ * ratio; part [B*C][uncr_agg_any_slots(Pc, C, NH)][2]; datt_up: [NH*B*T][Pc] scratch */
 int uncr_aggregate_any_fwd(const float* e, const float* att, const int* pad, const float* dmask, unsigned long long seed,
                            const long long* seed_dev, float p_drop, int shared_mask, float* out, float* part, int B, int T, int C,
                            int NH, int H, int W, int Pc, int AH, int AW, hipStream_t stream);
@@ -304,8 +304,10 @@ int uncr_aggregate_any_bwd(const float* dg, const float* e, const float* att, co
  *      backward: the consumer's uncr_pw_gemm_dx masks with [x > 0] (relu_a alone, no xh3) and leaves (sum du, .) partials;
  *                R = uncr_pw_wgrad(du, x_in) per frame; uncr_inconv_bwd_finish -> dW, db, d gamma, d beta (fp64 algebra). ---- */
 int uncr_inconv_moment_blocks(int P);
-int uncr_inconv_moments(const void* x /* [N][Cin][P], storage `act` */, int N, int Cin, int P,
-                        double* part /* [N][uncr_inconv_moment_blocks(P)][256] */, int act, hipStream_t stream);
+int uncr_inconv_moments(const void* x /* [N][Cin][pstride], storage `act` */, int N, int Cin, int P /* pixels that carry data */,
+                        double* part /* [N][uncr_inconv_moment_blocks(P)][256] */, int act,
+                        int pstride /* plane stride; 0 = P; > P: padded planes of an any-size image (zero tail, % 4 == 0) */,
+                        hipStream_t stream);
 int uncr_inconv_norm_from_moments(const double* part, int nblk, int N, int Cin, int Cout, int groups, const float* W /* [Cout][Cin] */,
                                   const float* bias /* [Cout] or null */, const float* gamma, const float* beta, float eps, float* coefA,
                                   float* coefB /* [N*Cout] */, float* save_mean, float* save_rstd /* [N*groups] */,
@@ -314,6 +316,18 @@ int uncr_inconv_bwd_finish(const float* R /* [N][Cout][Cin] = sum_p du x^T */, c
                            int NP, const double* mom, const float* W, const float* bias, const float* gamma, const float* save_mean,
                            const float* save_rstd, int N, int Cin, int Cout, int groups, float* dW /* [Cout][Cin] */,
                            float* db /* [Cout] or null */, float* dgamma, float* dbeta, hipStream_t stream);
+/* the same behind a train-mode BatchNorm (encoder_norm = 'batch'): statistics per channel over ALL frames from the sum of the frames'
+ * moment matrices, fp64 (+ the running statistics' update); mom [N][256] scratch, momtot [256] out (kept for the backward).
+ * groups = Cout in uncr_inconv_norm_from_moments / uncr_inconv_bwd_finish serves InstanceNorm (a constant plane -- a padded date --
+ * gets A = 0, B = beta: the exact result). */
+int uncr_inconv_bn_from_moments(const double* part, int nblk, int N, int Cin, int Cout, const float* W, const float* bias,
+                                const float* gamma, const float* beta, float* running_mean /* nullable, with running_var */,
+                                float* running_var, float momentum, float eps, float* coefA /* [N*Cout] */, float* coefB,
+                                float* save_mean /* [Cout] */, float* save_rstd, double* mom, double* momtot, hipStream_t stream);
+int uncr_inconv_bwd_finish_bn(const float* R /* [N][Cout][Cin] */, const float* part /* [N*Cout][NP][2]: .x = sum_p du */, int NP,
+                              const double* momtot, const float* W, const float* bias, const float* gamma, const float* save_mean,
+                              const float* save_rstd, int N, int Cin, int Cout, float* dW, float* db /* nullable */, float* dgamma,
+                              float* dbeta, hipStream_t stream);
 
 /* ---- squeeze-excite MLP (uncrtaints.py:82-97) ---- */
 int uncr_se_mlp_fwd(const float* pool_part, int NP, int N, int C, int R, int P, const float* W1,

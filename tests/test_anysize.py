@@ -211,7 +211,8 @@ def test_model_variants_at_odd_sizes(name, kw, shape):
     "ONE gradient (out_block.4 BatchNorm-1 gamma, a cancelling sum) sits 1.11e-4 from fp64 against an allowance of max(1e-4, 3 x 3.39e-5) = "
     "1.02e-4; on this input the CPU paths' own error is 10 x their usual 3e-6.  Round 5: 1.8e-4 (4.3 x) with the tail subtracted after the "
     "fact, and the test ran on seed 8 instead; round 6 (tail out of every reduction): 1.11e-4 (3.3 x).  Recorded, not steered around: "
-    "profiles/r06_pytest_gpu.log"))), 8, 9, 10, 11, 12])
+    "profiles/r06_pytest_gpu.log.  Later in round 6 in_conv's BatchNorm statistics moved to fp64 moment matrices (csrc/inconv.hip) and the line "
+    "has passed on the build's boxes since; the mark stays non-strict because the margin is a hair either way"))), 8, 9, 10, 11, 12])
 def test_batch_norm_encoder_at_odd_size_over_seeds(seed):
     """`encoder_norm='batch'`, two encoder blocks, 34 x 70, one padded date, over eight input / initialisation seeds.  On seven of them every
     gradient sits at the CPU paths' level (2e-6 ... 1.3e-5 from fp64 on the worst line); seed 7 is the recorded miss above."""

@@ -374,6 +374,54 @@ def test_inconv_fwd_bwd(orc, E, moments, input_grad):
         close(f"inconv_grad[{name}]" + tag, got.grad, ref.grad)
 
 
+@pytest.mark.parametrize("norm", ["batch", "instance"])
+@pytest.mark.parametrize("moments", [True, False])
+def test_inconv_batch_and_instance_norm_fwd_bwd(orc, E, norm, moments):
+    """in_conv behind a train-mode BatchNorm / an InstanceNorm: the moment path (round 6: statistics per channel over all frames from the
+    SUM of the frames' fp64 moment matrices; InstanceNorm = one channel per group, a constant plane -- a zero-padded frame -- gets the
+    exact result 0) and the generic path, against torch in fp64.  The inputs are reflectance-like (positive, offset): channel means of
+    W x + b several standard deviations from zero."""
+    import torch.nn.functional as F
+    from uncrtaints_amd.src.backbones.utae import ConvBlock
+    torch.manual_seed(3)
+    blk = ConvBlock(nkernels=[15, 128], k=1, s=1, p=0, norm=norm)
+    B, T, H, W = 2, 3, 64, 64
+    x = torch.rand(B, T, 15, H, W) * torch.rand(1, 1, 15, 1, 1) + 0.5 * torch.rand(1, 1, 15, 1, 1)
+    x[1, 2] = 0.0                                        # a padded frame: constant planes behind the convolution
+    gy = rand(B, T, 128, H, W, seed=2)
+    conv = blk.conv.conv[0]
+    w64, b64 = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    c0 = F.conv2d(x.double().view(B * T, 15, H, W), w64, b64)
+    if norm == "batch":
+        bn = blk.conv.conv[1]
+        with torch.no_grad():
+            bn.weight.copy_(1.0 + 0.3 * torch.randn(128)); bn.bias.copy_(0.2 * torch.randn(128))
+        g64, be64 = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+        u = F.batch_norm(c0, None, None, g64, be64, True, 0.1, 1e-5)
+        rm_ref = 0.9 * bn.running_mean.double() + 0.1 * c0.detach().mean(dim=(0, 2, 3))
+    else:
+        u = F.instance_norm(c0.contiguous(), eps=1e-5)
+    a0 = torch.relu(u).view(B, T, 128, H, W)
+    a0.backward(gy.double())
+    bd = blk.to(DEV).train()
+    tag = f"[{norm},moments={moments}]"
+    with E.dev_options(inconv_moments=moments):
+        calls = _count_calls(lambda: bd.smart_forward(dev(x)), ("uncr_inconv_moments",))
+        assert (len(calls["launches"]) > 0) == moments, calls["launches"]          # the path under test ran
+        yd = calls["result"]
+        close("inconv_fwd" + tag, yd, a0.float(), tol=2e-5)
+        if norm == "instance":
+            assert float(yd[1, 2].abs().max()) == 0.0                               # the padded frame: exactly zero
+        yd.backward(dev(gy))
+    close("inconv_grad[w]" + tag, bd.conv.conv[0].weight.grad, w64.grad.float().view_as(conv.weight), tol=5e-5)
+    if norm == "batch":
+        close("inconv_grad[bn_w]" + tag, bd.conv.conv[1].weight.grad, g64.grad.float(), tol=2e-5)
+        close("inconv_grad[bn_b]" + tag, bd.conv.conv[1].bias.grad, be64.grad.float(), tol=2e-5)
+        close("inconv_running_mean" + tag, bd.conv.conv[1].running_mean, rm_ref.float(), tol=1e-5)
+    # (the convolution's bias sits in front of a norm that removes it: its gradient is zero up to rounding)
+    assert float(bd.conv.conv[0].bias.grad.abs().max()) < 1e-3 * float(bd.conv.conv[0].weight.grad.abs().max()) * (300.0 if norm == "instance" else 1.0)
+
+
 def test_inconv_moments_and_statistics(E):
     """uncr_inconv_moments + uncr_inconv_norm_from_moments against the statistics of the materialised c0 = W x + b (fp64)."""
     from uncrtaints_amd import hip_backend as hb
@@ -389,7 +437,7 @@ def test_inconv_moments_and_statistics(E):
     nblk = hb.query("uncr_inconv_moment_blocks", P)
     mpart = torch.empty(N, nblk, 256, device=DEV, dtype=torch.float64)
     xd = dev(x)
-    hb.call("uncr_inconv_moments", xd, N, Cin, P, mpart, 0, E._stream())
+    hb.call("uncr_inconv_moments", xd, N, Cin, P, mpart, 0, 0, E._stream())
     M = mpart.sum(1).reshape(N, 16, 16).cpu()
     xa = torch.cat([x.double().view(N, Cin, P), torch.ones(N, 1, P, dtype=torch.float64)], dim=1)
     Mref = torch.einsum("nap,nbp->nab", xa, xa)

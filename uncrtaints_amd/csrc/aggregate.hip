@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void aggregate_any_dup_kernel(AggArgs g, int P
             const int c = h * CH + jc;
             d = fmaf(((const float*)g.dg)[((size_t)b * g.C + c) * Pc + p], ((const float*)g.e)[(((size_t)b * g.T + t) * g.C + c) * Pc + p], d);
         }
-        g.datt_up[(size_t)q * P + p] = d * agg_keep(g, h, b, t, (size_t)p);
+        g.datt_up[(size_t)q * Pc + p] = d * agg_keep(g, h, b, t, (size_t)p);
     }
 }
 // adjoint of the bilinear up-sampling, any ratio: one thread per low-resolution cell gathers its footprint
@@ -573,11 +573,111 @@ __global__ __launch_bounds__(256) void bilinear_adjoint_any_kernel(const float* 
     }
     datt[(size_t)q * AH * AW + o] = s;
 }
+// ---- float4 form of the same (round 6): a plane is dense -- H*W contiguous pixels, 16-byte aligned at every multiple of four whatever
+// the width -- so a thread takes four consecutive FLAT pixels (they may sit on two image rows: the bilinear source is evaluated per
+// pixel) of all CH channels of one head, like aggregate_kernel; the attention taps are gathered (L1 / L2 resident: 4 KB per (head,
+// date)).  Tail pixels of the padded stride read zeros and write zeros.  The scalar kernels above recomputed the up-sampled attention
+// once per CHANNEL and moved one float per lane: 256 / 474 us at 4 x 3 x 128 x 250 x 250 against 109 / 292 us of the tuned kernels at
+// 256 x 256.  Backward: de = a*dg and the dense gradient of the up-sampled attention (stride Pc) in one pass.
+static bool agg_anyv_ok(int C, int NH, int Pc) {
+    if (NH <= 0 || C % NH || Pc % AGG_PX) return false;
+    const int ch = C / NH;
+    return ch == 2 || ch == 4 || ch == 6 || ch == 8 || ch == 16 || ch == 32;
+}
+template <bool BWD, int CH>
+__global__ __launch_bounds__(256) void aggregate_anyv_kernel(AggArgs g, int Pc) {
+    const int b = blockIdx.y, h = blockIdx.z;
+    const int P = g.H * g.W;
+    const int p0 = blockIdx.x * AGG_PX + threadIdx.x * 4;
+    const float sy = (float)g.AH / (float)g.H, sx = (float)g.AW / (float)g.W;
+    Bilin by[4], bx[4];
+    bool in[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = min(p0 + j, P - 1);            // (tail pixels: any valid source; their operands are zero)
+        const int y = p / g.W;
+        in[j] = p0 + j < P;
+        by[j] = bilin_src(y, sy, g.AH);
+        bx[j] = bilin_src(p - y * g.W, sx, g.AW);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ float wred[4][32][2];
+    float4 acc[CH];
+#pragma unroll
+    for (int jc = 0; jc < CH; ++jc) {
+        if constexpr (BWD) acc[jc] = *(const float4*)((const float*)g.dg + ((size_t)b * g.C + h * CH + jc) * Pc + p0);
+        else acc[jc] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int t = 0; t < g.T; ++t) {
+        const float* ap = g.att + (((size_t)h * g.B + b) * g.T + t) * g.AH * g.AW;
+        float a[4], keep[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float top = bx[j].l0 * ap[by[j].i0 * g.AW + bx[j].i0] + bx[j].l1 * ap[by[j].i0 * g.AW + bx[j].i1];
+            const float bot = bx[j].l0 * ap[by[j].i1 * g.AW + bx[j].i0] + bx[j].l1 * ap[by[j].i1 * g.AW + bx[j].i1];
+            keep[j] = in[j] ? agg_keep(g, h, b, t, (size_t)p0 + j) : 0.f;
+            a[j] = (by[j].l0 * top + by[j].l1 * bot) * keep[j];
+        }
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jc = 0; jc < CH; ++jc) {
+            const size_t eo = (((size_t)b * g.T + t) * g.C + h * CH + jc) * Pc + p0;
+            const float4 ev = *(const float4*)((const float*)g.e + eo);
+            if constexpr (!BWD) {
+                acc[jc].x = fmaf(a[0], ev.x, acc[jc].x); acc[jc].y = fmaf(a[1], ev.y, acc[jc].y);
+                acc[jc].z = fmaf(a[2], ev.z, acc[jc].z); acc[jc].w = fmaf(a[3], ev.w, acc[jc].w);
+            } else {
+                const float4 dgv = acc[jc];
+                *(float4*)((float*)g.de + eo) = make_float4(a[0] * dgv.x, a[1] * dgv.y, a[2] * dgv.z, a[3] * dgv.w);
+                d[0] = fmaf(dgv.x, ev.x, d[0]); d[1] = fmaf(dgv.y, ev.y, d[1]);
+                d[2] = fmaf(dgv.z, ev.z, d[2]); d[3] = fmaf(dgv.w, ev.w, d[3]);
+            }
+        }
+        if constexpr (BWD)
+            *(float4*)(g.datt_up + (((size_t)h * g.B + b) * g.T + t) * Pc + p0) =
+                make_float4(d[0] * keep[0], d[1] * keep[1], d[2] * keep[2], d[3] * keep[3]);
+    }
+    if constexpr (!BWD) {
+#pragma unroll
+        for (int jc = 0; jc < CH; ++jc) {
+            const float4 o = acc[jc];
+            *(float4*)((float*)g.out + ((size_t)b * g.C + h * CH + jc) * Pc + p0) = o;
+            if (g.part) {
+                const float s0 = wave_sum_dpp(o.x + o.y + o.z + o.w);
+                const float s1 = wave_sum_dpp(o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w);
+                if (lane == 63) { wred[wv][jc][0] = s0; wred[wv][jc][1] = s1; }
+            }
+        }
+        if (g.part) {
+            __syncthreads();
+            if (threadIdx.x < CH) {
+                const int jc = threadIdx.x;
+                g.part[((size_t)b * g.C + h * CH + jc) * gridDim.x + blockIdx.x] =
+                    make_float2((wred[0][jc][0] + wred[1][jc][0]) + (wred[2][jc][0] + wred[3][jc][0]),
+                                (wred[0][jc][1] + wred[1][jc][1]) + (wred[2][jc][1] + wred[3][jc][1]));
+            }
+        }
+    }
+}
+template <bool BWD>
+static void agg_anyv_launch(const AggArgs& g, int Pc, hipStream_t stream) {
+    const dim3 grid(Pc / AGG_PX, g.B, g.NH);
+    switch (g.C / g.NH) {
+        case 2: hipLaunchKernelGGL((aggregate_anyv_kernel<BWD, 2>), grid, dim3(256), 0, stream, g, Pc); break;
+        case 4: hipLaunchKernelGGL((aggregate_anyv_kernel<BWD, 4>), grid, dim3(256), 0, stream, g, Pc); break;
+        case 6: hipLaunchKernelGGL((aggregate_anyv_kernel<BWD, 6>), grid, dim3(256), 0, stream, g, Pc); break;
+        case 8: hipLaunchKernelGGL((aggregate_anyv_kernel<BWD, 8>), grid, dim3(256), 0, stream, g, Pc); break;
+        case 16: hipLaunchKernelGGL((aggregate_anyv_kernel<BWD, 16>), grid, dim3(256), 0, stream, g, Pc); break;
+        default: hipLaunchKernelGGL((aggregate_anyv_kernel<BWD, 32>), grid, dim3(256), 0, stream, g, Pc); break;
+    }
+}
+
 static int agg_any_check(int B, int T, int C, int NH, int H, int W, int AH, int AW, int Pc) {
     if (B <= 0 || T <= 0 || NH <= 0 || C % NH || H < AH || W < AW || Pc < H * W) return UNCR_ESHAPE;
     return UNCR_OK;
 }
-extern "C" int uncr_agg_any_slots(void) { return AGGA_NB; }
+// statistics slots per plane of uncr_aggregate_any_fwd: one per 1024-pixel block on the float4 kernels, AGGA_NB on the scalar ones
+extern "C" int uncr_agg_any_slots(int Pc, int C, int NH) { return agg_anyv_ok(C, NH, Pc) ? Pc / AGG_PX : AGGA_NB; }
 extern "C" int uncr_aggregate_any_fwd(const float* e, const float* att, const int* pad, const float* dmask, unsigned long long seed,
                                       const long long* seed_dev, float p_drop, int shared_mask, float* out, float* part, int B, int T,
                                       int C, int NH, int H, int W, int Pc, int AH, int AW, hipStream_t stream) {
@@ -585,7 +685,8 @@ extern "C" int uncr_aggregate_any_fwd(const float* e, const float* att, const in
     if (rc) return rc;
     if (!e || !att || !out) return UNCR_EINVAL;
     AggArgs g{e, att, pad, dmask, out, nullptr, nullptr, nullptr, (float2*)part, seed, seed_dev, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
-    hipLaunchKernelGGL(aggregate_any_fwd_kernel, dim3(AGGA_NB, B * C), dim3(256), 0, stream, g, Pc);
+    if (agg_anyv_ok(C, NH, Pc)) agg_anyv_launch<false>(g, Pc, stream);
+    else hipLaunchKernelGGL(aggregate_any_fwd_kernel, dim3(AGGA_NB, B * C), dim3(256), 0, stream, g, Pc);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -597,12 +698,16 @@ extern "C" int uncr_aggregate_any_bwd(const float* dg, const float* e, const flo
     if (rc) return rc;
     if (!dg || !e || !att || !de || !datt_up || !datt) return UNCR_EINVAL;
     AggArgs g{e, att, pad, dmask, nullptr, dg, de, datt_up, nullptr, seed, seed_dev, p_drop, shared_mask, B, T, C, NH, H, W, AH, AW};
-    hipLaunchKernelGGL(aggregate_any_de_kernel, dim3(AGGA_NB, B * C), dim3(256), 0, stream, g, Pc);
-    UNCR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(aggregate_any_dup_kernel, dim3(AGGA_NB, NH * B * T), dim3(256), 0, stream, g, Pc);
+    if (agg_anyv_ok(C, NH, Pc)) {
+        agg_anyv_launch<true>(g, Pc, stream);
+    } else {
+        hipLaunchKernelGGL(aggregate_any_de_kernel, dim3(AGGA_NB, B * C), dim3(256), 0, stream, g, Pc);
+        UNCR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(aggregate_any_dup_kernel, dim3(AGGA_NB, NH * B * T), dim3(256), 0, stream, g, Pc);
+    }
     UNCR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bilinear_adjoint_any_kernel, dim3((AH * AW + 255) / 256, NH * B * T), dim3(256), 0, stream, datt_up, datt, H, W,
-                       AH, AW, (size_t)H * W);
+                       AH, AW, (size_t)Pc);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -31,14 +31,16 @@ template <> struct icm_vec4<bf16_t> { typedef ushort4 type; };
 // T: storage of x (fp32, or bf16: the moments of the values as stored)
 template <typename T>
 __global__ __launch_bounds__(256) void inconv_moments_kernel(const T* __restrict__ x, int Cin, int P, int px_per_block,
-                                                             double* __restrict__ part) {
+                                                             double* __restrict__ part, int pstride) {
     typedef typename icm_vec4<T>::type V4;
     __shared__ double red[4][256];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int n = blockIdx.y;
-    const int p0 = blockIdx.x * px_per_block, p1 = min(P, p0 + px_per_block);
-    const T* xb = x + ((size_t)n * Cin + (c < Cin ? c : 0)) * P;
+    // P = pixels that carry data (the augmented channel counts them one by one); pstride = the plane stride (> P: the padded planes of
+    // an any-size image, whose tail holds zeros: a 4-group that straddles P adds nothing but its valid pixels' count)
+    const int p0 = blockIdx.x * px_per_block, p1 = min((P + 3) & ~3, p0 + px_per_block);
+    const T* xb = x + ((size_t)n * Cin + (c < Cin ? c : 0)) * pstride;
     icm_f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     // two 16-pixel steps per iteration on independent accumulators (an MFMA's dependent latency is 4 passes)
     for (int s = p0 + 32 * wv; s < p1; s += 128) {
@@ -49,9 +51,9 @@ __global__ __launch_bounds__(256) void inconv_moments_kernel(const T* __restrict
             const bool in = px < p1;                 // (p1 and px are multiples of 4: a 4-group is inside or outside as a whole)
             V4 raw = {};
             if (in && c < Cin) raw = *(const V4*)(xb + px);
-            const float one = (in && c == Cin) ? 1.f : 0.f;
-            v[h][0] = c < Cin ? icm_w(raw.x) : one; v[h][1] = c < Cin ? icm_w(raw.y) : one;
-            v[h][2] = c < Cin ? icm_w(raw.z) : one; v[h][3] = c < Cin ? icm_w(raw.w) : one;
+            const bool aug = in && c == Cin;
+            v[h][0] = c < Cin ? icm_w(raw.x) : ((aug && px + 0 < P) ? 1.f : 0.f); v[h][1] = c < Cin ? icm_w(raw.y) : ((aug && px + 1 < P) ? 1.f : 0.f);
+            v[h][2] = c < Cin ? icm_w(raw.z) : ((aug && px + 2 < P) ? 1.f : 0.f); v[h][3] = c < Cin ? icm_w(raw.w) : ((aug && px + 3 < P) ? 1.f : 0.f);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -70,16 +72,17 @@ extern "C" int uncr_inconv_moment_blocks(int P) {
     const int b = (P + 1023) / 1024;
     return b < 1 ? 1 : (b > 256 ? 256 : b);
 }
-extern "C" int uncr_inconv_moments(const void* x, int N, int Cin, int P, double* part, int act, hipStream_t stream) {
+extern "C" int uncr_inconv_moments(const void* x, int N, int Cin, int P, double* part, int act, int pstride, hipStream_t stream) {
     if (N <= 0 || Cin <= 0 || Cin + 1 > ICM_A || P <= 0) return UNCR_ESHAPE;
     if (!x || !part || (act != UNCR_F32 && act != UNCR_BF16)) return UNCR_EINVAL;
+    if (pstride <= 0) pstride = P;
     const int nblk = uncr_inconv_moment_blocks(P);
-    if (P % 4) return UNCR_ESHAPE;
+    if (pstride % 4 || pstride < ((P + 3) & ~3)) return UNCR_ESHAPE;      // 16-byte loads; a straddling 4-group stays inside the plane
     const int ppb = ((P + nblk - 1) / nblk + 127) / 128 * 128;
     if (act == UNCR_BF16)
-        hipLaunchKernelGGL(inconv_moments_kernel<bf16_t>, dim3(nblk, N), dim3(256), 0, stream, (const bf16_t*)x, Cin, P, ppb, part);
+        hipLaunchKernelGGL(inconv_moments_kernel<bf16_t>, dim3(nblk, N), dim3(256), 0, stream, (const bf16_t*)x, Cin, P, ppb, part, pstride);
     else
-        hipLaunchKernelGGL(inconv_moments_kernel<float>, dim3(nblk, N), dim3(256), 0, stream, (const float*)x, Cin, P, ppb, part);
+        hipLaunchKernelGGL(inconv_moments_kernel<float>, dim3(nblk, N), dim3(256), 0, stream, (const float*)x, Cin, P, ppb, part, pstride);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(256) void inconv_norm_from_moments_kernel(
     __shared__ double M[256];
     __shared__ double t1s[256], t2s[256];
     __shared__ float sh_mean, sh_rstd;
+    __shared__ int sh_flat;
     const int tid = threadIdx.x, n = blockIdx.x / G, g = blockIdx.x % G, Cg = Cout / G;
     {
         // up to 32 loads in flight per thread (a plain loop serialises nblk L2 round trips), summed in block order
@@ -145,6 +149,11 @@ __global__ __launch_bounds__(256) void inconv_norm_from_moments_kernel(
         const double mean = s / Mn;
         double var = ss / Mn - mean * mean;
         if (var < 0) var = 0;
+        // InstanceNorm (Cg == 1) over a constant plane -- a zero-padded date: c0 = bias everywhere: the exact result is 0, which
+        // A*c0 + B with a rounded B does not give (norm.hip::gn_finalize_fwd_kernel has the same rule and the reasoning)
+        const bool flat = Cg == 1 && var <= ldexp(mean * mean, -17);
+        if (flat) var = 0;
+        sh_flat = flat ? 1 : 0;
         sh_mean = (float)mean;
         sh_rstd = (float)(1.0 / sqrt(var + (double)eps));
         save_mean[n * G + g] = sh_mean;
@@ -153,9 +162,9 @@ __global__ __launch_bounds__(256) void inconv_norm_from_moments_kernel(
     __syncthreads();
     for (int c = tid; c < Cg; c += 256) {
         const int k = g * Cg + c;
-        const float a = gamma[k] * sh_rstd;
+        const float a = sh_flat ? 0.f : gamma[k] * sh_rstd;
         coefA[n * Cout + k] = a;
-        coefB[n * Cout + k] = beta[k] - sh_mean * a;
+        coefB[n * Cout + k] = sh_flat ? beta[k] : beta[k] - sh_mean * a;
     }
 }
 
@@ -304,6 +313,161 @@ extern "C" int uncr_inconv_bwd_finish(const float* R, const float* part, int NP,
     if (lds > 60 * 1024) return UNCR_ESHAPE;
     hipLaunchKernelGGL(inconv_bwd_finish_kernel, dim3(groups), dim3(512), lds, stream, R, (const float2*)part, NP, mom, W, bias, gamma,
                        save_mean, save_rstd, N, Cin, Cout, groups, dW, db, dgamma, dbeta);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+// ---- the same for a train-mode BatchNorm behind the convolution (encoder_norm = 'batch'): the statistics set is a channel over ALL
+// frames, so the frames' moment matrices add up first:  M~ = sum_n M~[n],
+//   sum c0[k] = W[k].Sx + b[k] P,  sum c0[k]^2 = W[k] Mx W[k]^T + 2 b[k] W[k].Sx + b[k]^2 P   (Sx, Mx, P of the total),
+// mean / rstd per channel (+ the running statistics' update, nn.BatchNorm2d), A = gamma rstd, B = beta - mean A for every frame.
+// fp64 throughout: the channel means of c0 = W x + b over non-negative inputs sit several standard deviations from zero, where the
+// fp32 slot sums of a statistics epilogue leave 1e-7 in the mean -- ATen's CPU path accumulates in fp64 too.
+// stage 1: grid = N, block = 256: mom[n][256] = the frame's reduced matrix.  stage 2: grid = ceil(Cout / 256), block = 256.
+__global__ __launch_bounds__(256) void inconv_moment_reduce_kernel(const double* __restrict__ part, int nblk, double* __restrict__ mom) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const double* src = part + (size_t)n * nblk * 256 + tid;
+    double a = 0.0;
+    int b = 0;
+    for (; b + 16 <= nblk; b += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(b + u) * 256];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a += v[u];
+    }
+    for (; b < nblk; ++b) a += src[(size_t)b * 256];
+    mom[(size_t)n * 256 + tid] = a;
+}
+__global__ __launch_bounds__(256) void inconv_bn_from_moments_kernel(
+    const double* __restrict__ mom, int N, int Cin, int Cout, const float* __restrict__ W, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+    float momentum, float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ save_mean,
+    float* __restrict__ save_rstd, double* __restrict__ momtot) {
+    __shared__ double M[256];
+    const int tid = threadIdx.x;
+    {
+        double a = 0.0;
+        for (int n = 0; n < N; ++n) a += mom[(size_t)n * 256 + tid];      // frame order
+        M[tid] = a;
+        if (blockIdx.x == 0) momtot[tid] = a;
+    }
+    __syncthreads();
+    const int k = blockIdx.x * 256 + tid;
+    if (k >= Cout) return;
+    const double Pn = M[Cin * 16 + Cin];
+    const float* w = W + (size_t)k * Cin;
+    const double b = bias ? (double)bias[k] : 0.0;
+    double wr[ICM_A];
+#pragma unroll
+    for (int a = 0; a < ICM_A; ++a) wr[a] = a < Cin ? (double)w[a < Cin ? a : 0] : 0.0;
+    double ws = 0.0, q = 0.0;
+#pragma unroll
+    for (int a = 0; a < ICM_A - 1; ++a) {
+        double r = 0.0;
+#pragma unroll
+        for (int e = 0; e < ICM_A - 1; ++e) r += wr[e] * (e < Cin ? M[a * 16 + e] : 0.0);
+        ws += wr[a] * (a < Cin ? M[a * 16 + Cin] : 0.0);
+        q += wr[a] * r;
+    }
+    const double mean = (ws + b * Pn) / Pn;
+    double var = (q + 2.0 * b * ws + b * b * Pn) / Pn - mean * mean;
+    if (var < 0) var = 0;
+    const float fm = (float)mean, fr = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[k] = fm;
+    save_rstd[k] = fr;
+    if (running_mean) {
+        const double unb = var * (Pn / (Pn > 1 ? Pn - 1 : 1));
+        running_mean[k] = (float)((1.0 - momentum) * running_mean[k] + momentum * mean);
+        running_var[k] = (float)((1.0 - momentum) * running_var[k] + momentum * unb);
+    }
+    const float a = gamma[k] * fr, bb = beta[k] - fm * a;
+    for (int n = 0; n < N; ++n) { coefA[(size_t)n * Cout + k] = a; coefB[(size_t)n * Cout + k] = bb; }
+}
+extern "C" int uncr_inconv_bn_from_moments(const double* part, int nblk, int N, int Cin, int Cout, const float* W, const float* bias,
+                                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                           float momentum, float eps, float* coefA, float* coefB, float* save_mean, float* save_rstd,
+                                           double* mom /* [N][256] */, double* momtot /* [256] */, hipStream_t stream) {
+    if (N <= 0 || Cin <= 0 || Cin + 1 > ICM_A || Cout <= 0 || nblk <= 0) return UNCR_ESHAPE;
+    if (!part || !W || !gamma || !beta || !coefA || !coefB || !save_mean || !save_rstd || !mom || !momtot) return UNCR_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return UNCR_EINVAL;
+    hipLaunchKernelGGL(inconv_moment_reduce_kernel, dim3(N), dim3(256), 0, stream, part, nblk, mom);
+    UNCR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(inconv_bn_from_moments_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, mom, N, Cin, Cout, W, bias, gamma,
+                       beta, running_mean, running_var, momentum, eps, coefA, coefB, save_mean, save_rstd, momtot);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+// backward of the same: with S1[k] = sum_{n,p} du, Rt[k][a] = sum_n R[n][k][a], S2[k] = W[k].Rt[k] + b[k] S1[k] = sum du*c0,
+//   d gamma = r (S2 - mu S1), d beta = S1;  dc0 = c1 du + c2 (c0 - mu) + c3 with c1 = r gamma, c2 = -r^2 (gamma r (S2 - mu S1) / P),
+//   c3 = -r gamma S1 / P (P = all pixels of all frames);
+//   dW[k][a] = c1 Rt[k][a] + c2 (sum_e W[k][e] Mx[e][a] + (b[k] - mu) Sx[a]) + c3 Sx[a],   db[k] = c1 S1 + c2 (W[k].Sx + (b[k] - mu) P) + c3 P.
+// One thread per channel (a few hundred loads each: latency, off the critical path of the full-resolution kernels).
+__global__ __launch_bounds__(64) void inconv_bwd_finish_bn_kernel(
+    const float* __restrict__ R /* [N][Cout][Cin] */, const float2* __restrict__ part /* [N*Cout][NP]: .x = sum du */, int NP,
+    const double* __restrict__ momtot /* [256] */, const float* __restrict__ W, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ save_mean, const float* __restrict__ save_rstd, int N, int Cin, int Cout,
+    float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= Cout) return;
+    double s1 = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const float2* src = part + ((size_t)n * Cout + k) * NP;
+        int j = 0;
+        for (; j + 8 <= NP; j += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[j + u].x;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s1 += (double)v[u];
+        }
+        for (; j < NP; ++j) s1 += (double)src[j].x;
+    }
+    double rt[ICM_A];
+#pragma unroll
+    for (int a = 0; a < ICM_A; ++a) rt[a] = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const float* r = R + ((size_t)n * Cout + k) * Cin;
+#pragma unroll
+        for (int a = 0; a < ICM_A - 1; ++a) rt[a] += a < Cin ? (double)r[a < Cin ? a : 0] : 0.0;
+    }
+    const float* w = W + (size_t)k * Cin;
+    double wr[ICM_A];
+#pragma unroll
+    for (int a = 0; a < ICM_A; ++a) wr[a] = a < Cin ? (double)w[a < Cin ? a : 0] : 0.0;
+    const double b = bias ? (double)bias[k] : 0.0, gm = (double)gamma[k];
+    const double mu = (double)save_mean[k], r = (double)save_rstd[k];
+    double s2 = b * s1;
+#pragma unroll
+    for (int a = 0; a < ICM_A - 1; ++a) s2 += wr[a] * rt[a];
+    const double Pn = momtot[Cin * 16 + Cin];
+    const double dg = r * (s2 - mu * s1);
+    const double c1 = r * gm, c2 = -r * r * (gm * dg / Pn), c3 = -r * (gm * s1 / Pn);
+    dgamma[k] = (float)dg;
+    dbeta[k] = (float)s1;
+    double wsx = 0.0;
+#pragma unroll
+    for (int a = 0; a < ICM_A - 1; ++a) wsx += wr[a] * (a < Cin ? momtot[a * 16 + Cin] : 0.0);
+    if (db) db[k] = (float)(c1 * s1 + c2 * (wsx + (b - mu) * Pn) + c3 * Pn);
+#pragma unroll
+    for (int a = 0; a < ICM_A - 1; ++a) {
+        if (a < Cin) {
+            double t = 0.0;
+#pragma unroll
+            for (int e = 0; e < ICM_A - 1; ++e) t += wr[e] * (e < Cin ? momtot[e * 16 + a] : 0.0);
+            const double sx = momtot[a * 16 + Cin];
+            dW[(size_t)k * Cin + a] = (float)(c1 * rt[a] + c2 * (t + (b - mu) * sx) + c3 * sx);
+        }
+    }
+}
+extern "C" int uncr_inconv_bwd_finish_bn(const float* R, const float* part, int NP, const double* momtot, const float* W,
+                                         const float* bias, const float* gamma, const float* save_mean, const float* save_rstd, int N,
+                                         int Cin, int Cout, float* dW, float* db, float* dgamma, float* dbeta, hipStream_t stream) {
+    if (N <= 0 || Cin <= 0 || Cin + 1 > ICM_A || Cout <= 0 || NP <= 0) return UNCR_ESHAPE;
+    if (!R || !part || !momtot || !W || !gamma || !save_mean || !save_rstd || !dW || !dgamma || !dbeta) return UNCR_EINVAL;
+    hipLaunchKernelGGL(inconv_bwd_finish_bn_kernel, dim3((Cout + 63) / 64), dim3(64), 0, stream, R, (const float2*)part, NP, momtot, W,
+                       bias, gamma, save_mean, save_rstd, N, Cin, Cout, dW, db, dgamma, dbeta);
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -1312,16 +1312,23 @@ def residual_backward(dy: Tensor, sv: dict, p: Dict[str, Tensor], need_dx: bool 
 # in_conv: Conv2d(15->128,k1,bias) + GroupNorm(4) + ReLU   (utae.py:453-520, uncrtaints.py:310-314)
 # ------------------------------------------------------------------------------------------------
 
-def _inconv_moments_ok(x: Tensor, N: int, Cin: int, Cout: int, spec: NormSpec, gw, P: int) -> bool:
+def _inconv_moments_ok(x: Tensor, N: int, Cin: int, Cout: int, spec: NormSpec, gw, P: int, training: bool = True) -> bool:
     """The moment path is taken in the FORWARD and leaves no c0 behind, so everything its backward needs is checked here: the limits
     of uncr_inconv_moments (P % 4) and of uncr_inconv_bwd_finish, which holds [N][Cout / G] partial pairs of a group in 60 KB of LDS
-    (csrc/inconv.hip: (2 N Cg + 4 N + 288) doubles) -- at width 256 (Cg = 64) that is N = B*T <= 56; beyond it the generic path."""
-    if not (_INCONV_MOMENTS and spec.kind == "group" and gw is not None and Cin + 1 <= 16 and 64 < Cout <= 256
-            and Cout % spec.groups == 0 and N <= 64 and P % 4 == 0):
+    (csrc/inconv.hip: (2 N Cg + 4 N + 288) doubles) -- at width 256 (Cg = 64) that is N = B*T <= 56; beyond it the generic path.
+    GroupNorm: either storage type.  InstanceNorm (one channel per group) and train-mode BatchNorm (statistics over all frames; not
+    with synchronised statistics): fp32 storage (round 6)."""
+    if not (_INCONV_MOMENTS and Cin + 1 <= 16 and 64 < Cout <= 256 and N <= 64 and P % 4 == 0):
         return False
-    if _geom_for(P) is not None:       # any-size planes: the generic path (its tail corrections are plain statistics)
+    if spec.kind == "group":
+        return gw is not None and Cout % spec.groups == 0 and (2 * N * (Cout // spec.groups) + 4 * N + 288) * 8 <= 60 * 1024
+    if _dt(x) != F32:
         return False
-    return (2 * N * (Cout // spec.groups) + 4 * N + 288) * 8 <= 60 * 1024
+    if spec.kind == "instance":
+        return (2 * N + 4 * N + 288) * 8 <= 60 * 1024
+    if spec.kind == "batch":
+        return training and gw is not None and _SYNC_BN is None
+    return False
 
 
 def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec: NormSpec, training: bool,
@@ -1332,23 +1339,36 @@ def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec
     buffers = buffers or {}
     need = spec.needs_stats(training)
     Wt = pack_wt(w.reshape(Cout, Cin), transpose=True)
-    if _inconv_moments_ok(x, N, Cin, Cout, spec, gw, P):
-        # c0 = W x + b is never written: its GroupNorm statistics are a quadratic form in the frame's 16 x 16 augmented moment matrix,
+    if _inconv_moments_ok(x, N, Cin, Cout, spec, gw, P, training):
+        # c0 = W x + b is never written: its norm statistics are a quadratic form in the frames' 16 x 16 augmented moment matrices (fp64),
         # and the GEMM's epilogue stores relu(A*c0 + B) straight from the accumulators (csrc/inconv.hip)
         dev = x.device
-        G = spec.groups
-        nblk = hb.query("uncr_inconv_moment_blocks", P)
+        Pv = _pcount(P)                # (padded planes of an any-size image: the valid pixels count, the stride is P)
+        nblk = hb.query("uncr_inconv_moment_blocks", Pv)
         mpart = torch.empty((N, nblk, 256), device=dev, dtype=torch.float64)
-        hb.call("uncr_inconv_moments", x, N, Cin, P, mpart, _dt(x), _stream())
+        hb.call("uncr_inconv_moments", x, N, Cin, Pv, mpart, _dt(x), P, _stream())
         A, B = _f32((N * Cout,), dev), _f32((N * Cout,), dev)
-        mean, rstd = _f32((N * G,), dev), _f32((N * G,), dev)
         mom = torch.empty((N, 256), device=dev, dtype=torch.float64)
         w2d, bc = w.reshape(Cout, Cin).contiguous(), b.contiguous()
-        hb.call("uncr_inconv_norm_from_moments", mpart, nblk, N, Cin, Cout, G, w2d, bc, gw, gb, 1e-5, A, B, mean, rstd, mom, _stream())
-        nf = NormFwd(A, B, mean, rstd, NORM_GROUP, G)
+        if spec.kind == "batch":       # train mode: statistics per channel over all frames
+            mean, rstd = _f32((Cout,), dev), _f32((Cout,), dev)
+            momtot = torch.empty((256,), device=dev, dtype=torch.float64)
+            hb.call("uncr_inconv_bn_from_moments", mpart, nblk, N, Cin, Cout, w2d, bc, gw, gb, buffers.get("rm"), buffers.get("rv"), 0.1,
+                    1e-5, A, B, mean, rstd, mom, momtot, _stream())
+            nf = NormFwd(A, B, mean, rstd, NORM_BATCH_TRAIN, 1)
+            mom = momtot
+        else:
+            G = Cout if spec.kind == "instance" else spec.groups
+            if gw is None:
+                gw_, gb_ = _const_planes(dev, Cout)
+            else:
+                gw_, gb_ = gw, gb
+            mean, rstd = _f32((N * G,), dev), _f32((N * G,), dev)
+            hb.call("uncr_inconv_norm_from_moments", mpart, nblk, N, Cin, Cout, G, w2d, bc, gw_, gb_, 1e-5, A, B, mean, rstd, mom, _stream())
+            nf = NormFwd(A, B, mean, rstd, NORM_GROUP, G)
         a0, parta = pw_gemm(x, Wt, N, Cin, Cout, P, bias=bc, epi=9, ek=(A, B, None, None))
         a0 = a0.view(N, Cout, H, W)
-        return a0, dict(x=x, c0=None, a0=a0, nf=nf, mom=mom, b=bc, dims=(N, Cin, Cout, H, W)), parta
+        return a0, dict(x=x, c0=None, a0=a0, nf=nf, mom=mom, b=bc, dims=(N, Cin, Cout, H, W), geom=_geom_for(P)), parta
     geom = _geom_for(P)
     c0, part = pw_gemm(x, Wt, N, Cin, Cout, P, bias=b.contiguous(), epi=1 if need else 0)
     nf = norm_fwd(part, N, Cout, P, spec, training, gw, gb, buffers.get("rm"), buffers.get("rv"))
@@ -1383,8 +1403,13 @@ def inconv_backward(da0: Tensor, sv: dict, w: Tensor, gw: Tensor, need_dx: bool,
         R, _ = pw_wgrad(du0, x, N, Cout, Cin, P, per_frame=True)            # [N, Cout, Cin] = sum_p du0 x^T
         dW, db, dg, dbeta = _f32((Cout, Cin), dev), _f32((Cout,), dev), _f32((Cout,), dev), _f32((Cout,), dev)
         w2d = w.reshape(Cout, Cin).contiguous()
-        hb.call("uncr_inconv_bwd_finish", R.contiguous(), part.buf, part.slots, sv["mom"], w2d, sv["b"], gw, nf.mean, nf.rstd, N, Cin,
-                Cout, nf.groups, dW, db, dg, dbeta, _stream())
+        if nf.kind == NORM_BATCH_TRAIN:
+            hb.call("uncr_inconv_bwd_finish_bn", R.contiguous(), part.buf, part.slots, sv["mom"], w2d, sv["b"], gw, nf.mean, nf.rstd, N,
+                    Cin, Cout, dW, db, dg, dbeta, _stream())
+        else:
+            hb.call("uncr_inconv_bwd_finish", R.contiguous(), part.buf, part.slots, sv["mom"], w2d, sv["b"],
+                    gw if gw is not None else _const_planes(dev, Cout)[0], nf.mean, nf.rstd, N, Cin, Cout, nf.groups, dW, db, dg, dbeta,
+                    _stream())
         dx = None
         if need_dx:
             # the gradient w.r.t. the model input needs c0 per pixel: recomputed (a training run's input carries no gradient)
@@ -1609,7 +1634,7 @@ def aggregate_forward(e: Tensor, att: Tensor, pad: Optional[Tensor], training: b
         g = _f32((B, C, H, W), dev)
         gpart = None
         if want_stats:
-            slots = hb.query("uncr_agg_any_slots")
+            slots = hb.query("uncr_agg_any_slots", geom.Pc, C, n_head)
             gpart = Part(_f32((B * C, slots, 2), dev), slots)
         use_mask = dmask if training else None
         pd = float(p_drop) if (training and dmask is None) else 0.0
@@ -1665,7 +1690,7 @@ def aggregate_backward(dg: Tensor, sv: dict):
         return embed_tail(ded, geom), datt
     if geom is not None:
         de = _f32((B, T, C, H, W), dev)
-        datt_up = _f32((n_head * B * T, geom.P), dev)
+        datt_up = _f32((n_head * B * T, geom.Pc), dev)          # (scratch: the gradient of the up-sampled attention, plane stride Pc)
         datt = _f32((n_head, B, T, ah, aw), dev)
         hb.call("uncr_aggregate_any_bwd", dg.contiguous().float(), sv["e"], sv["att"], sv["pad"], sv["dmask"], sv["seed"], sv["seed_dev"],
                 sv["pd"], sv["shared"], de, datt_up, datt, B, T, C, n_head, geom.H, geom.W, geom.Pc, ah, aw, _stream())
@@ -1855,7 +1880,8 @@ def include_v_forward(gagg: Tensor, v: Tensor, w: Tensor, b: Tensor, want_stats:
     out = _f32((B, C, H, W), gagg.device)
     part = None
     if want_stats:
-        slots = hb.query("uncr_agg_any_slots") if geom is not None else hb.query("uncr_agg_slots", P)
+        # (uncr_add_upsampled_any keeps the scalar kernels' slot count: one channel per "head" selects it)
+        slots = hb.query("uncr_agg_any_slots", geom.Pc, 1, 1) if geom is not None else hb.query("uncr_agg_slots", P)
         part = Part(_f32((B * C, slots, 2), gagg.device), slots)
     if geom is not None:
         hb.call("uncr_add_upsampled_any", t, z, out, part.buf if part else None, B * C, geom.H, geom.W, geom.Pc, ah, aw, _stream())
