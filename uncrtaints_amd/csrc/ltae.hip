@@ -557,9 +557,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_rows_kernel(const float* __re
     for (int x = threadIdx.x; x < W; x += 256) {
         float best = -INFINITY;
         int br = ys;
-        for (int y = ys; y < ye; ++y) {
-            const float v = p[(size_t)y * W + x];
-            if (v > best || v != v) { best = v; br = y; }
+        for (int y = ys; y < ye; y += 4) {          // four rows in flight (a load per iteration waited for its own latency: 8 round trips)
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p[(size_t)min(y + u, ye - 1) * W + x];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (y + u < ye && (v[u] > best || v[u] != v[u])) { best = v[u]; br = y + u; }
         }
         cmax[x] = best;
         crow[x] = br;

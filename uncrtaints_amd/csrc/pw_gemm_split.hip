@@ -54,6 +54,9 @@ template <bool NT, typename TA> __device__ __forceinline__ void pws_st(TA* p, co
 #ifndef PWS_MAP
 #define PWS_MAP 1
 #endif
+#ifndef PWS_TROT
+#define PWS_TROT 0      // tile-order rotation per frame (development knob: see tile_of)
+#endif
 #define PWS_TP 128
 #define PWS_BUF 24576   // bytes per LDS stage: 3 parts x 32 ci x 128 px x 2 B (bf16 activations: 1 part, 8192 B)
 #define PWS_A16_WPARTS 2   // bf16 activations: leading weight parts used (2 = 16 significant bits: the weights stay fp32-grade,
@@ -179,7 +182,15 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
     // last tile for the loads (re-reads, never consumed) -- no branches around memory operations.
     struct Pos { int c, ti; };
     auto advance = [&](Pos& p) { const bool wrap = p.c + 1 == nkp; p.c = wrap ? 0 : p.c + 1; p.ti += wrap ? 1 : 0; };
-    auto tile_px = [&](int ti) { return (bx + (ti < nt ? ti : nt - 1) * G) * PWS_TP; };
+#if PWS_TROT
+    // the frames of a launch walk their tiles in rotated order (frame n starts at its block's (n mod nt)-th tile): without it the
+    // blocks (bx, 0 ... N-1) request addresses that differ in the frame bits only, at every moment
+    const int trot = nt > 0 ? (int)((unsigned)(n * PWS_TROT) % (unsigned)nt) : 0;
+#else
+    const int trot = 0;
+#endif
+    auto tile_of = [&](int ti) { const int t = ti + trot; return bx + (t < nt ? t : t - nt) * G; };
+    auto tile_px = [&](int ti) { return tile_of(ti < nt ? ti : nt - 1) * PWS_TP; };
 
     Raw pre[DEPTH][4], pre2[PRE2 ? DEPTH : 1][4];
     // rows past Cin re-read row 0 (branch-free; they are zeroed at staging)
@@ -504,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_split_kernel(PwArgs g) {
         // ---- tile epilogue (same accumulator layout as the fp32 kernel) ----
         // pass 1: bias / fused backward transform in place in the accumulators + statistics (aux loads in batches)
         // pass 2: float4 row stores, fire and forget; the next tile's chunks and weights were requested before them
-        const int tile = bx + ti * G;
+        const int tile = tile_of(ti);
         const bool tile_ok = g.Pv <= 0 || (tile + 1) * PWS_TP <= g.Pv;      // (any-size planes: no statistics from a tile that reaches into the tail)
         // address of (row, lane) = uniform row base (SGPR arithmetic) + one per-lane element offset
         const int loff = 4 * kg * P + tile * PWS_TP + 4 * j;
