@@ -119,6 +119,13 @@ int uncr_part_sums(const float* part, int slots, int planes, float* out0, float*
 /* out[n*C + c] = scale * mean of the statistics set of plane (n, c): groups > 0: mean [N*groups] (GroupNorm / InstanceNorm), 0: [C]
  * (BatchNorm) -- per-plane pivots for the centred backward statistics and the centred weight-gradient products */
 int uncr_plane_means(const float* mean, int N, int C, int groups, float scale, float* out, hipStream_t stream);
+/* InstanceNorm2d (groups == C) behind uncr_norm_finalize_fwd: every plane whose raw-moment variance is below 2^-6 mean^2 gets mean,
+ * rstd, A, B (and the bounds ub / hb, nullable) recomputed from the tensor itself about its mean -- (sum h, sum h^2) of fp32 slot sums
+ * resolve a variance to ~1e-7 mean^2 only (uncrtaints.py:16-22 InstanceNorm2d behind an un-normalised tensor, e.g. the decoder's
+ * first PreNorm behind an eval-mode BatchNorm encoder).  x: [N*C] planes of P valid elements, `stride` elements apart; act: storage */
+int uncr_instance_repair(const void* x, int N, int C, int P, long long stride, const float* gamma, const float* beta, float eps,
+                         float* coefA, float* coefB, float* save_mean, float* save_rstd, float* ub, float* hb, int act,
+                         hipStream_t stream);
 /* dst = src converted between the storage types (model input -> bf16 activations; bf16 input gradient -> fp32) */
 int uncr_cast(const void* src, void* dst, long long n, int src_dt, int dst_dt, hipStream_t stream);
 

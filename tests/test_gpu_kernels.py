@@ -1096,6 +1096,39 @@ def nn_identity():
 
 
 @pytest.mark.gpu
+def test_instance_norm_of_planes_far_from_zero():
+    """InstanceNorm2d (uncrtaints.py:16-22) on planes whose mean is 5 ... 1000 sigma from zero: (sum h, sum h^2) of fp32 slot sums
+    resolve the variance to ~1e-7 mean^2 only, so those planes' statistics are recomputed about the mean (uncr_instance_repair;
+    tools/fuzz_configs.py cases 542 / 743: a decoder under decoder_norm='instance' behind an eval-mode BatchNorm encoder).  A constant
+    plane still comes out as exactly zero (the flat-plane rule); a plane 1e-5 of its mean wide is data (the raw moments call it flat)."""
+    from uncrtaints_amd import engine as E
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    torch.manual_seed(11)
+    N, C, H, W = 2, 64, 32, 64
+    x = torch.randn(N, C, H, W) * 0.3
+    ratios = torch.tensor([0.0, 5.0, 50.0, 500.0, 1000.0, -120.0, 9.0, 7.0])
+    x += (0.3 * ratios).repeat(C // 8).view(1, C, 1, 1)
+    x[1, 3] = 4.25                                   # a constant plane
+    x[1, 5] = 7.0 + 7e-5 * torch.randn(H, W)         # sigma / mean = 1e-5: far below the raw moments' resolution, yet data
+    ref = torch.nn.functional.instance_norm(x.double(), eps=1e-5)
+    m = U.PreNorm(C, nn_identity(), "instance").to("cuda").eval()
+    with torch.no_grad():
+        y = m(x.cuda()).cpu()
+        with E.dev_options(instance_repair=False):
+            y_raw = m(x.cuda()).cpu()
+    assert torch.count_nonzero(y[1, 3]) == 0
+    err = lambda a: float((a.double() - ref).abs().max() / ref.abs().max())
+    keep = torch.ones(N, C, dtype=torch.bool)
+    keep[1, 5] = False                               # (the narrow plane is limited by A*h + B in fp32: checked on its own below)
+    assert err(torch.where(keep.view(N, C, 1, 1), y, ref.float())) < 5e-5      # (A*h + B in fp32 at 1000 sigma: ~2e-5)
+    assert err(torch.where(keep.view(N, C, 1, 1), y_raw, ref.float())) > 1e-3          # the raw moments lose these planes
+    # sigma = 1e-5 mean (sigma^2 << eps: rstd = 316, values ~0.02): B = beta - mean*A is rounded at 2^-24 * 7 * 316 = 1.3e-4, a common
+    # shift of the plane; its spread is the reference's
+    assert float((y[1, 5].double() - ref[1, 5]).abs().max()) < 3e-4
+    assert abs(float(y[1, 5].std()) / float(ref[1, 5].std()) - 1.0) < 1e-3 and float(y_raw[1, 5].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
 def test_standalone_se_matches_torch():
     """SE called on its own (uncrtaints.py:82-97) against the same arithmetic in torch on the CPU."""
     from uncrtaints_amd.src.backbones import uncrtaints as U

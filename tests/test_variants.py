@@ -267,6 +267,48 @@ def test_hip_instance_norm_att_mean_with_a_padded_date(shape):
 
 
 @pytest.mark.gpu
+def test_hip_instance_decoder_behind_an_eval_batchnorm_encoder():
+    """decoder_norm='instance' behind encoder_norm='batch' in EVAL mode (running statistics that do not fit the data, as after a short
+    training run): the aggregate reaches the decoder's first PreNorm with planes up to ~100 sigma from zero, where raw fp32 moments
+    resolve the variance to 1e-3 (tools/fuzz_configs.py cases 542 / 743 / 526: eval output at 1.0-1.7e-4).  Those planes' statistics
+    are recomputed about the mean (uncr_instance_repair): the eval output sits with the CPU fp32 path again."""
+    from conftest import rel_err
+    from gpu_util import dev
+    from uncrtaints_amd import engine as E
+    from uncrtaints_amd.src.backbones import uncrtaints as U
+    kw = dict(encoder_norm="batch", decoder_norm="instance", decoder_widths=[128, 128])
+    cfg = orc.OracleConfig(attn_dropout=0.0, **kw)
+    x, _, dates = orc.synthetic_batch(2, 2, 96, 96, seed=843)
+    torch.manual_seed(743)
+    m = U.UNCRTAINTS(input_dim=15, out_conv=[26], out_nonlin_mean=True, out_nonlin_var="softplus", covmode="diag", scale_by=1.0, **kw)
+    g_ = torch.Generator().manual_seed(1743)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=g_))
+            mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g_))
+        if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.GroupNorm)) and mod.weight is not None:
+            mod.weight.data.copy_(1.0 + 0.3 * torch.randn(mod.weight.shape, generator=g_))
+            mod.bias.data.copy_(0.2 * torch.randn(mod.bias.shape, generator=g_))
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to("cuda").eval()
+    taps = {}
+    with torch.no_grad():
+        out = m(dev(x), batch_positions=dev(dates)).cpu()
+        with E.dev_options(instance_repair=False):
+            out_raw = m(dev(x), batch_positions=dev(dates)).cpu()
+        r64 = orc.forward({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in state.items()}, x.double(), dates.double(),
+                          cfg, training=False, taps=taps)
+        r32 = orc.forward({k: v.clone() for k, v in state.items()}, x, dates, cfg, training=False)
+    agg = taps["agg"].reshape(-1, 96 * 96)
+    worst = float((agg.mean(1).abs() / agg.std(1)).max())
+    e_hip, e_raw, e_cpu = (rel_err(t.numpy(), r64.numpy()) for t in (out, out_raw, r32))
+    print(f"[parity] instance decoder behind eval BatchNorm: planes up to {worst:.0f} sigma from zero; eval output vs fp64: hip {e_hip:.2e} "
+          f"(raw moments {e_raw:.2e}), cpu fp32 {e_cpu:.2e}")
+    assert worst > 30.0            # the case is what it claims to be
+    assert e_hip < max(3e-5, 3.0 * e_cpu)
+
+
+@pytest.mark.gpu
 def test_iso_ensemble_inference_config5():
     """BASELINE config 5: five iso members, inference only, mixture-moment combine
     (ensemble_reconstruct.py:116-133) -- HIP members + HIP combine against the oracle."""

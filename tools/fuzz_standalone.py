@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from conftest import rel_err
+from gpu_util import relu_branch
 from oracle import uncrtaints_oracle as orc
 from uncrtaints_amd.src import losses
 from uncrtaints_amd.src.backbones.ltae import LTAE2d
@@ -76,9 +77,16 @@ for case in range(first, first + n_cases):
         gv, ga = torch.randn(Bq, mlp[-1], 32, 32, generator=g), torch.randn(nh, Bq, T, 32, 32, generator=g)
         training = rnd.random() < 0.7
         m = m.cuda().train(training)
+        m.keep_relu_branch = True
         xh = dev(x).requires_grad_(True)
         o, a = m(xh, batch_positions=dev(dates), pad_mask=dev(pad))
         ((o * dev(gv)).sum() + (a * dev(ga)).sum()).backward()
+        # the last ReLU sits in front of a GroupNorm over C/nh values per pixel: differentiate the oracle on the branch the HIP forward took
+        # (gpu_util.value_relu_mask: one pre-activation within rounding of zero in a dead group moves every gradient by ~316 / (n*C))
+        m1_, A_, B_ = m._last_relu
+        b_, c_, s_ = m1_.shape
+        rmask = relu_branch(m1_, A_.view(-1, c_, 1) if A_.numel() == b_ * c_ else A_.view(1, c_, 1),
+                            B_.view(-1, c_, 1) if B_.numel() == b_ * c_ else B_.view(1, c_, 1)).permute(0, 2, 1).reshape(b_ * s_, c_).cpu()
         res = {}
         for dt_ in (torch.float32, torch.float64):
             p = {"temporal_encoder." + k: (v.clone().to(dt_) if v.dtype.is_floating_point else v.clone()) for k, v in state.items()}
@@ -87,7 +95,7 @@ for case in range(first, first + n_cases):
                     v.requires_grad_(True)
             cfg = orc.OracleConfig(n_head=nh, d_k=dk, d_model=d_in, ltae_dropout=0.0, positional_encoding=m.positional_encoder is not None)
             xo = x.detach().clone().to(dt_).requires_grad_(True)
-            vo, ao = orc.ltae2d_values_attention(xo, dates.to(dt_), pad, p, cfg, training)
+            vo, ao = orc.ltae2d_values_attention(xo, dates.to(dt_), pad, p, cfg, training, relu_mask=rmask)
             ((vo * gv.to(dt_)).sum() + (ao * ga.to(dt_)).sum()).backward()
             res[dt_] = (vo.detach().double(), ao.detach().double(), xo.grad.double(), {k[len("temporal_encoder."):]: v.grad.double() for k, v in p.items() if getattr(v, "grad", None) is not None})
         t = res[torch.float64]

@@ -524,6 +524,93 @@ extern "C" int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, i
     return UNCR_OK;
 }
 
+// ---- InstanceNorm statistics of an ill-conditioned plane, recomputed about its mean --------------------------------------------
+// (sum h, sum h^2) from fp32 slot sums resolve a plane's variance to ~1e-7 mean^2: enough while |mean| is a few sigma, not behind an
+// encoder whose eval-mode BatchNorm leaves planes 100 sigma from zero (tools/fuzz_configs.py cases 542 / 743 / 526: the decoder's first
+// PreNorm under decoder_norm='instance', eval output at 1.0-1.7e-4 where the CPU path sits at 1e-5).  One block per plane: a plane
+// whose raw-moment variance is above 2^-6 mean^2 keeps its statistics (the block reads two floats and leaves); otherwise the block
+// re-reads the plane and takes sum (h - m0), sum (h - m0)^2 about the raw mean m0 (no cancellation) with min and max, and rewrites
+// mean, rstd, A, B (and the bounds, now tight: A*h + B is monotone in h).  The flat-plane rule of gn_finalize_fwd_kernel applies to
+// the recomputed variance with the threshold of THAT resolution: a constant plane gives exactly 0, anything above 2^-34 mean^2 is data.
+template <typename T>
+__global__ __launch_bounds__(256) void instance_repair_kernel(const T* __restrict__ x, int C, int P, size_t stride,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float eps, float* __restrict__ coefA, float* __restrict__ coefB,
+                                                              float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                              float* __restrict__ ub, float* __restrict__ hb) {
+    const int pl = blockIdx.x;
+    const float m0 = save_mean[pl], r0 = save_rstd[pl];
+    const double var0 = 1.0 / ((double)r0 * (double)r0) - (double)eps;
+    if (var0 > ldexp((double)m0 * (double)m0, -6)) return;             // block-uniform: well-conditioned, nothing to do
+    const T* src = x + (size_t)pl * stride;
+    float s1 = 0.f, s2 = 0.f, mn = INFINITY, mx = -INFINITY;
+    const int P4 = P & ~3;
+    for (int i = threadIdx.x * 4; i < P4; i += 1024) {
+        const float4 v = widen4(ld4raw<T>(src + i));
+        const float d0 = v.x - m0, d1 = v.y - m0, d2 = v.z - m0, d3 = v.w - m0;
+        s1 += (d0 + d1) + (d2 + d3);
+        s2 = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, s2))));
+        mn = fminf(fminf(mn, fminf(v.x, v.y)), fminf(v.z, v.w));
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    for (int i = P4 + threadIdx.x; i < P; i += 256) {
+        const float v = ld1<T>(src + i), d = v - m0;
+        s1 += d;
+        s2 = fmaf(d, d, s2);
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    double S1 = wave_sum_d((double)s1), S2 = wave_sum_d((double)s2);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, m, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    }
+    __shared__ double red[8];
+    __shared__ float redm[8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[2 * w] = S1; red[2 * w + 1] = S2; redm[2 * w] = mn; redm[2 * w + 1] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S1 = S2 = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            S1 += red[2 * i]; S2 += red[2 * i + 1];
+            mn = fminf(mn, redm[2 * i]); mx = fmaxf(mx, redm[2 * i + 1]);
+        }
+        const double e1 = S1 / (double)P;
+        const double mean = (double)m0 + e1;
+        double var = S2 / (double)P - e1 * e1;
+        if (var < 0) var = 0;
+        const bool flat = var <= ldexp(mean * mean, -34);
+        if (flat) var = 0;
+        const float fm = (float)mean, fr = (float)(1.0 / sqrt(var + (double)eps));
+        save_mean[pl] = fm;
+        save_rstd[pl] = fr;
+        const int ch = pl % C;
+        const float a = flat ? 0.f : gamma[ch] * fr;
+        const float b = flat ? beta[ch] : beta[ch] - fm * a;
+        coefA[pl] = a;
+        coefB[pl] = b;
+        const float hmax = fmaxf(fabsf(mn), fabsf(mx));
+        // |A*h + B| over [mn, mx] peaks at an end point; the slack covers a consumer that rounds A*h before adding B
+        if (ub) ub[pl] = fmaxf(fabsf(fmaf(a, mn, b)), fabsf(fmaf(a, mx, b))) + ldexpf(fmaf(fabsf(a), hmax, fabsf(b)), -21);
+        if (hb) hb[pl] = hmax;
+    }
+}
+
+/* InstanceNorm2d behind uncr_norm_finalize_fwd (groups == C): planes whose raw-moment variance is below 2^-6 mean^2 get their
+ * statistics, coefficients and bounds recomputed from the tensor itself, centred on the mean (see instance_repair_kernel) */
+extern "C" int uncr_instance_repair(const void* x, int N, int C, int P, long long stride, const float* gamma, const float* beta,
+                                    float eps, float* coefA, float* coefB, float* save_mean, float* save_rstd, float* ub,
+                                    float* hb, int act, hipStream_t stream) {
+    if (N <= 0 || C <= 0 || P <= 0 || stride < P || (stride & 3)) return UNCR_ESHAPE;
+    if (!x || !gamma || !beta || !coefA || !coefB || !save_mean || !save_rstd || (hb && !ub)) return UNCR_EINVAL;
+    UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(instance_repair_kernel<T>, dim3(N * C), dim3(256), 0, stream, (const T*)x, C, P,
+                                                  (size_t)stride, gamma, beta, eps, coefA, coefB, save_mean, save_rstd, ub, hb));
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
 extern "C" int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                                       const float* gamma, const float* save_mean, const float* save_rstd, float* c1,
                                       float* c2, float* c3, float* cmu, float* dgamma, float* dbeta, float* scratch,

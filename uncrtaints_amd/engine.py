@@ -359,12 +359,15 @@ def _all_reduce_sums(sums: Tensor) -> float:
 def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, training: bool, gamma: Tensor,
              beta: Tensor, running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None,
              momentum: float = 0.1, eps: float = 1e-5, bound_part: Optional[Part] = None, want_hb: bool = False,
-             defer: bool = False) -> NormFwd:
+             defer: bool = False, src: Optional[Tensor] = None) -> NormFwd:
     """bound_part: (sum h, sum h^2) partials of the tensor this norm is applied to (in train mode `part` itself; in BatchNorm eval
     mode they serve only this): the finalize kernel then also emits per-plane upper bounds on |A*h + B| (NormFwd.ub), with which
     the consuming wide GEMM multiplies in two range-safe fp16 parts instead of the exact bf16 split (pw_gemm).
     defer: the caller's next kernel can finalise a train-mode BatchNorm itself (csrc/bn_inline.h): where that applies nothing is
-    launched here and NormFwd.fin carries what that kernel needs (the caller MUST then run such a kernel); otherwise as usual."""
+    launched here and NormFwd.fin carries what that kernel needs (the caller MUST then run such a kernel); otherwise as usual.
+    src: the tensor the statistics are of.  InstanceNorm2d only: planes far from zero in units of their own spread (|mean| > 8 sigma:
+    an un-normalised tensor, e.g. the decoder's first PreNorm behind an eval-mode BatchNorm encoder) get their statistics recomputed
+    from it about the mean (uncr_instance_repair); every other plane costs its block two loads."""
     kind = spec.code(training)
     groups = C if spec.kind == "instance" else spec.groups
     if gamma is None:                      # norm without affine parameters (InstanceNorm2d): gamma = 1, beta = 0
@@ -395,6 +398,9 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
                        fin=(part.buf, part.slots, gamma, beta, running_mean, running_var, float(momentum), float(eps)))
     hb.call("uncr_norm_finalize_fwd", part.buf if part else None, part.slots if part else 0, N, C, groups, _pcount(P),
             kind, gamma, beta, running_mean, running_var, float(momentum), float(eps), A, B, mean, rstd, ub, hbt, _stream())
+    if src is not None and spec.kind == "instance" and _INSTANCE_REPAIR:
+        hb.call("uncr_instance_repair", src, N, C, _pcount(P), P, gamma, beta, float(eps), A, B, mean, rstd, ub, hbt, _dt(src),
+                _stream())
     return NormFwd(A, B, mean, rstd, kind, groups, ub=ub, hb=hbt)
 
 
@@ -428,6 +434,8 @@ _EVAL_TAIL = True
 _CENTRED_PW1 = True
 # in_conv's backward statistics centred on the norm's mean (False: raw sum du0*c0, bisecting)
 _CENTRED_INCONV = True
+# InstanceNorm PreNorm: statistics of planes with |mean| > 8 sigma recomputed about the mean (False: raw moments only, bisecting)
+_INSTANCE_REPAIR = True
 
 # development (tools/ablate_ltae_stage.py): "record" keeps the L-TAE stage's results of the next forward / backward, "replay" hands
 # them back without launching anything -- the stage's cost inside the captured step = step time with it minus step time without it
@@ -437,7 +445,8 @@ _LTAE_STORE: Dict[str, tuple] = {}
 _DEV_OPTIONS = {"ltae_replay": "_LTAE_REPLAY", "side_stream": "_USE_SIDE", "centred_normbwd": "_CENTRED_NORMBWD", "h2_bwd": "_H2_BWD", "h2_wgrad": "_H2_WGRAD",
                 "h2_dx": "_H2_DX", "h2_fwd": "_H2_FWD", "prepack": "_PREPACK", "fused_dx": "_FUSED_DX", "fused_ltae": "_FUSED_LTAE",
                 "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER", "inconv_moments": "_INCONV_MOMENTS", "se_pool4": "_SE_POOL4", "eval_tail": "_EVAL_TAIL", "agg_two_pass": "_AGG_TWO_PASS",
-                "centred_pw1": "_CENTRED_PW1", "centred_inconv": "_CENTRED_INCONV"}
+                "centred_pw1": "_CENTRED_PW1", "centred_inconv": "_CENTRED_INCONV",
+                "instance_repair": "_INSTANCE_REPAIR"}
 
 
 class dev_options:
@@ -519,7 +528,7 @@ def norm_apply_forward(x: Tensor, spec: NormSpec, training: bool, gamma: Optiona
     P = H * W
     x = x.contiguous()
     part = stats_sq(x, N * C, P) if spec.needs_stats(training) else None
-    nf = norm_fwd(part, N, C, P, spec, training, gamma, beta, running_mean, running_var, momentum, eps)
+    nf = norm_fwd(part, N, C, P, spec, training, gamma, beta, running_mean, running_var, momentum, eps, src=x)
     out = _act((N, C, H, W), x.device, _dt(x))
     ew(EW_AFFINE, x, out=out, k=(nf.A, nf.B, None, None), planes=N * C, P=P)
     return out, dict(x=x, nf=nf, dims=(N, C, H, W))
@@ -787,7 +796,7 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     # inputs' magnitude; where a producer left none (eval-mode BatchNorm behind a foreign tensor) the GEMM takes the exact split
     h2ok = dt == F32 and _H2_FWD and Ch > 64 and C > 64
     n0 = norm_fwd(x_part if need else None, N, C, P, spec, training, p["n0w"], p["n0b"], *rm(0),
-                  bound_part=x_part if h2ok else None)
+                  bound_part=x_part if h2ok else None, src=x)
     W1t = pack_wt(p["w1"].reshape(Ch, C), transpose=True)
     geom = _geom_for(P)      # padded planes of an any-size image (csrc/anysize.hip)
     if geom is not None and dt != F32:
@@ -908,7 +917,7 @@ def _mbconv_forward_wide(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, traini
 
     if need and x_part is None:
         x_part = stats_sq(x, N * C, P)
-    n0 = norm_fwd(x_part if need else None, N, C, P, spec, training, p["n0w"], p["n0b"], *rm(0))
+    n0 = norm_fwd(x_part if need else None, N, C, P, spec, training, p["n0w"], p["n0b"], *rm(0), src=x)
     w1, wdw, w2 = p["w1"].reshape(Ch, C), p["wdw"].reshape(Ch, 9), p["w2"].reshape(C, Ch)
     slots = hb.query("uncr_dw_slots_fwd", H)
     h1s, h2s, n1s, n2s, pools = [], [], [], [], []

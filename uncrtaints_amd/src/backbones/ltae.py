@@ -272,6 +272,8 @@ class _LTAE2dFn(torch.autograd.Function):
             for _, bn in layers:
                 if bn.num_batches_tracked is not None:
                     bn.num_batches_tracked += 1
+        if getattr(te, "keep_relu_branch", False):       # parity tools: the branch the last ReLU took (see _StageFn in uncrtaints.py)
+            te._last_relu = (sv_val["m1"], sv_val["nf"].A, sv_val["nf"].B)
         ctx.sv = (sv_att, sv_val, p, vp, nh, dk, pa, seed)
         ctx.vkeys = vkeys
         return v.view(B, -1, h, w), att_d
