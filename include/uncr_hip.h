@@ -80,7 +80,11 @@ int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, int groups, 
                            float momentum, float eps, float* coefA, float* coefB, float* save_mean,
                            float* save_rstd, float* ub,
                            float* hb /* nullable (needs ub) [N*C]: the bound on |h| itself, for consumers that apply another map to h */,
-                           hipStream_t stream);
+                           const void* src /* nullable: the normalised tensor itself ([N*C] planes of P valid elements, src_stride elements
+                                              apart, storage src_act).  Train-mode statistics sets with var <= 2^-6 mean^2 (|mean| >= 8
+                                              sigma, where raw moments of fp32 slot sums lose digits) are then re-read once and
+                                              take their second moment about the mean (csrc/bn_inline.h) */,
+                           long long src_stride, int src_act, hipStream_t stream);
 int uncr_norm_finalize_bwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                            const float* gamma, const float* save_mean, const float* save_rstd, float* c1,
                            float* c2, float* c3,

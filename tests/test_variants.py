@@ -294,7 +294,7 @@ def test_hip_instance_decoder_behind_an_eval_batchnorm_encoder():
     taps = {}
     with torch.no_grad():
         out = m(dev(x), batch_positions=dev(dates)).cpu()
-        with E.dev_options(instance_repair=False):
+        with E.dev_options(instance_repair=False, stats_repair=False):
             out_raw = m(dev(x), batch_positions=dev(dates)).cpu()
         r64 = orc.forward({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in state.items()}, x.double(), dates.double(),
                           cfg, training=False, taps=taps)

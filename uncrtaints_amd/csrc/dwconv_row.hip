@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void dw_fwd_row_kernel(const T* __restrict__ i
     float A, B;
     if (fin.part) {      // the input's BatchNorm is finalised here, by every wave for its own channel (bn_inline.h)
         const int n = plane / C;
-        bn_fin_wave(fin, n, c, C, H * W, tile == 0, tile == 0 && n == 0, A, B);
+        bn_fin_wave<T>(fin, in, n, c, C, H * W, tile == 0, tile == 0 && n == 0, A, B);
     } else {
         A = cA[plane];
         B = cB[plane];

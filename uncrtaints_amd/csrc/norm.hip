@@ -6,14 +6,17 @@
 // backward coefficients  dh = C1*du + C2*h + C3  (+ d gamma, d beta).  Final combines run in fp64 in a
 // fixed order, so results are deterministic.
 #include "common.h"
+#include "bn_inline.h"
 
 // ---------------------------------------------------------------------------------------------
 // forward: GroupNorm.  grid = N*G blocks; block reduces the contiguous range of Cg*NP partials.
 // ---------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(
     const float2* __restrict__ part, int NP, int C, int G, int P, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float* __restrict__ coefA, float* __restrict__ coefB,
-    float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ ub, float* __restrict__ hb) {
+    float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ ub, float* __restrict__ hb,
+    const T* __restrict__ xsrc /* nullable: the tensor itself, for statistics sets far from zero (bn_inline.h) */, size_t pstride) {
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int Cg = C / G;
     const float2* src = part + ((size_t)n * C + (size_t)g * Cg) * NP;
@@ -41,13 +44,42 @@ __global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) { red[2 * w] = s; red[2 * w + 1] = ss; }
     __syncthreads();
+    __shared__ double sh_md, sh_vd;
+    __shared__ int sh_need;
+    const double M = (double)Cg * (double)P;
     if (threadIdx.x == 0) {
         double S = 0, SS = 0;
         for (int i = 0; i < 4; ++i) { S += red[2 * i]; SS += red[2 * i + 1]; }
-        const double M = (double)Cg * (double)P;
         const double mean = S / M;
         double var = SS / M - mean * mean;
         if (var < 0) var = 0;
+        sh_md = mean;
+        sh_vd = var;
+        sh_need = (xsrc && mean != 0.0 && var <= ldexp(mean * mean, UNCR_REPAIR_SHIFT)) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool repaired = sh_need != 0;          // block-uniform
+    if (repaired) {                              // a set >= 32 sigma from zero: second moment about the mean, from the tensor itself
+        const float m0 = (float)sh_md;
+        double S1, S2;
+        centred_partials<T>(xsrc + ((size_t)n * C + (size_t)g * Cg) * pstride, Cg, pstride, P, m0, threadIdx.x, 256, S1, S2);
+        S1 = wave_sum_d(S1);
+        S2 = wave_sum_d(S2);
+        __syncthreads();
+        if (lane == 0) { red[2 * w] = S1; red[2 * w + 1] = S2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            S1 = S2 = 0.0;
+            for (int i = 0; i < 4; ++i) { S1 += red[2 * i]; S2 += red[2 * i + 1]; }
+            const double e1 = S1 / M;
+            sh_md = (double)m0 + e1;
+            sh_vd = fmax(S2 / M - e1 * e1, 0.0);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = sh_md;
+        double var = sh_vd;
         // InstanceNorm (one plane per statistics set) over a CONSTANT plane -- a zero-padded date behind in_conv: every plane of that
         // frame holds its channel's bias, and every later plane of the frame a constant again: exact arithmetic (and the reference,
         // whose Welford mean of a constant is that constant, uncrtaints.py:16-22) gives (h - mean) * rstd = 0 there, so the frame's
@@ -56,7 +88,8 @@ __global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(
         // gradient (amplified by rstd = 1/sqrt(eps) = 316 per norm) turns into O(1) errors of the encoder's weight gradients.  A plane
         // whose variance is below the resolution of its statistics (2^-17 mean^2) is therefore TREATED as constant: var = 0 and the
         // coefficients of the exact result, A = 0, B = beta.
-        const bool flat = Cg == 1 && var <= ldexp(mean * mean, -17);
+        // (a recomputed variance resolves 2^-34 mean^2: a constant plane gives exactly 0 there)
+        const bool flat = Cg == 1 && var <= ldexp(mean * mean, repaired ? -34 : -17);
         if (flat) var = 0;
         sh_flat = flat ? 1 : 0;
         sh_mean = (float)mean;
@@ -77,11 +110,13 @@ __global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(
 }
 
 // forward: BatchNorm (train: batch statistics + running update; eval: running statistics). grid = C.
+template <typename T>
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(
     const float2* __restrict__ part, int NP, int N, int C, int P, int train, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
     float momentum, float eps, float* __restrict__ coefA, float* __restrict__ coefB,
-    float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ ub, float* __restrict__ hb) {
+    float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ ub, float* __restrict__ hb,
+    const T* __restrict__ src /* nullable, as in gn_finalize_fwd_kernel */, size_t pstride) {
     const int c = blockIdx.x;
     __shared__ double red[8];
     __shared__ float sh_mean, sh_rstd;
@@ -112,13 +147,37 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         if (lane == 0) { red[2 * w] = s; red[2 * w + 1] = ss; }
         __syncthreads();
+        __shared__ double sh_md, sh_vd;
+        __shared__ int sh_need;
+        const double M = (double)N * (double)P;
         if (threadIdx.x == 0) {
             double S = 0, SS = 0;
             for (int i = 0; i < 4; ++i) { S += red[2 * i]; SS += red[2 * i + 1]; }
-            const double M = (double)N * (double)P;
             const double mean = S / M;
-            double var = SS / M - mean * mean;
-            if (var < 0) var = 0;
+            sh_md = mean;
+            sh_vd = fmax(SS / M - mean * mean, 0.0);
+            sh_need = (src && mean != 0.0 && sh_vd <= ldexp(mean * mean, UNCR_REPAIR_SHIFT)) ? 1 : 0;
+        }
+        __syncthreads();
+        if (sh_need) {                               // block-uniform: a channel >= 32 sigma from zero (bn_inline.h)
+            const float m0 = (float)sh_md;
+            double S1, S2;
+            centred_partials<T>(src + (size_t)c * pstride, N, (size_t)C * pstride, P, m0, threadIdx.x, 256, S1, S2);
+            S1 = wave_sum_d(S1);
+            S2 = wave_sum_d(S2);
+            __syncthreads();
+            if (lane == 0) { red[2 * w] = S1; red[2 * w + 1] = S2; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                S1 = S2 = 0.0;
+                for (int i = 0; i < 4; ++i) { S1 += red[2 * i]; S2 += red[2 * i + 1]; }
+                const double e1 = S1 / M;
+                sh_md = (double)m0 + e1;
+                sh_vd = fmax(S2 / M - e1 * e1, 0.0);
+            }
+        }
+        if (threadIdx.x == 0) {
+            const double mean = sh_md, var = sh_vd;
             sh_mean = (float)mean;
             sh_rstd = (float)(1.0 / sqrt(var + (double)eps));
             if (running_mean) {
@@ -501,22 +560,27 @@ extern "C" int uncr_bn_finalize_bwd_sums(const double* sums_local, const double*
 extern "C" int uncr_norm_finalize_fwd(const float* part, int NP, int N, int C, int groups, int P, int kind,
                                       const float* gamma, const float* beta, float* running_mean,
                                       float* running_var, float momentum, float eps, float* coefA, float* coefB,
-                                      float* save_mean, float* save_rstd, float* ub, float* hb, hipStream_t stream) {
+                                      float* save_mean, float* save_rstd, float* ub, float* hb, const void* src,
+                                      long long src_stride, int src_act, hipStream_t stream) {
     if (N <= 0 || C <= 0 || P <= 0) return UNCR_ESHAPE;
+    if (src && (src_stride < P || (src_act != UNCR_F32 && src_act != UNCR_BF16))) return UNCR_EINVAL;
+    if (!src) src_act = UNCR_F32;
     if (ub && (!part || NP <= 0)) return UNCR_EINVAL;      // the bound is taken from the partial sums of squares
     if (hb && !ub) return UNCR_EINVAL;
     if (kind == NORM_GROUP) {
         if (groups <= 0 || C % groups || !part) return UNCR_EINVAL;
         if (ub && C / groups > 256) return UNCR_ESHAPE;
-        hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(N * groups), dim3(256), 0, stream, (const float2*)part, NP, C,
-                           groups, P, gamma, beta, eps, coefA, coefB, save_mean, save_rstd, ub, hb);
+        UNCR_DISPATCH_ACT(src_act, T, hipLaunchKernelGGL(gn_finalize_fwd_kernel<T>, dim3(N * groups), dim3(256), 0, stream,
+                                                          (const float2*)part, NP, C, groups, P, gamma, beta, eps, coefA, coefB,
+                                                          save_mean, save_rstd, ub, hb, (const T*)src, (size_t)src_stride));
     } else if (kind == NORM_BATCH_TRAIN || kind == NORM_BATCH_EVAL) {
         const int train = kind == NORM_BATCH_TRAIN;
         if (train && !part) return UNCR_EINVAL;
         if (!train && (!running_mean || !running_var)) return UNCR_EINVAL;
-        hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(256), 0, stream, (const float2*)part, NP, N, C, P,
-                           train, gamma, beta, running_mean, running_var, momentum, eps, coefA, coefB, save_mean,
-                           save_rstd, ub, hb);
+        UNCR_DISPATCH_ACT(src_act, T, hipLaunchKernelGGL(bn_finalize_fwd_kernel<T>, dim3(C), dim3(256), 0, stream,
+                                                          (const float2*)part, NP, N, C, P, train, gamma, beta, running_mean,
+                                                          running_var, momentum, eps, coefA, coefB, save_mean, save_rstd, ub, hb,
+                                                          (const T*)src, (size_t)src_stride));
     } else {
         return UNCR_EINVAL;
     }

@@ -365,7 +365,9 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
     the consuming wide GEMM multiplies in two range-safe fp16 parts instead of the exact bf16 split (pw_gemm).
     defer: the caller's next kernel can finalise a train-mode BatchNorm itself (csrc/bn_inline.h): where that applies nothing is
     launched here and NormFwd.fin carries what that kernel needs (the caller MUST then run such a kernel); otherwise as usual.
-    src: the tensor the statistics are of.  InstanceNorm2d only: planes far from zero in units of their own spread (|mean| > 8 sigma:
+    src: the tensor the statistics are of: train-mode statistics sets 8 sigma or more from zero are re-read once and take their second
+    moment about the mean (uncr_norm_finalize_fwd's src; the consumer-side finalisation does the same with its own input from 32 sigma).
+    InstanceNorm2d PreNorm in addition: planes far from zero in units of their own spread (|mean| > 8 sigma:
     an un-normalised tensor, e.g. the decoder's first PreNorm behind an eval-mode BatchNorm encoder) get their statistics recomputed
     from it about the mean (uncr_instance_repair); every other plane costs its block two loads."""
     kind = spec.code(training)
@@ -397,7 +399,8 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
         return NormFwd(A, B, mean, rstd, kind, groups, ub=ub, hb=hbt,
                        fin=(part.buf, part.slots, gamma, beta, running_mean, running_var, float(momentum), float(eps)))
     hb.call("uncr_norm_finalize_fwd", part.buf if part else None, part.slots if part else 0, N, C, groups, _pcount(P),
-            kind, gamma, beta, running_mean, running_var, float(momentum), float(eps), A, B, mean, rstd, ub, hbt, _stream())
+            kind, gamma, beta, running_mean, running_var, float(momentum), float(eps), A, B, mean, rstd, ub, hbt,
+            src if (_STATS_REPAIR and part is not None) else None, P, _dt(src) if src is not None else F32, _stream())
     if src is not None and spec.kind == "instance" and _INSTANCE_REPAIR:
         hb.call("uncr_instance_repair", src, N, C, _pcount(P), P, gamma, beta, float(eps), A, B, mean, rstd, ub, hbt, _dt(src),
                 _stream())
@@ -436,6 +439,9 @@ _CENTRED_PW1 = True
 _CENTRED_INCONV = True
 # InstanceNorm PreNorm: statistics of planes with |mean| > 8 sigma recomputed about the mean (False: raw moments only, bisecting)
 _INSTANCE_REPAIR = True
+# statistics sets with |mean| >= 8 sigma re-read by the finalisation kernels (False: raw moments only; the consumer-side finalisation
+# of uncr_dw_fwd_bn keeps its own re-read: switch bn_consumer off as well to bisect)
+_STATS_REPAIR = True
 
 # development (tools/ablate_ltae_stage.py): "record" keeps the L-TAE stage's results of the next forward / backward, "replay" hands
 # them back without launching anything -- the stage's cost inside the captured step = step time with it minus step time without it
@@ -446,7 +452,7 @@ _DEV_OPTIONS = {"ltae_replay": "_LTAE_REPLAY", "side_stream": "_USE_SIDE", "cent
                 "h2_dx": "_H2_DX", "h2_fwd": "_H2_FWD", "prepack": "_PREPACK", "fused_dx": "_FUSED_DX", "fused_ltae": "_FUSED_LTAE",
                 "dw_variant": "_DW_VARIANT", "bn_consumer": "_BN_CONSUMER", "inconv_moments": "_INCONV_MOMENTS", "se_pool4": "_SE_POOL4", "eval_tail": "_EVAL_TAIL", "agg_two_pass": "_AGG_TWO_PASS",
                 "centred_pw1": "_CENTRED_PW1", "centred_inconv": "_CENTRED_INCONV",
-                "instance_repair": "_INSTANCE_REPAIR"}
+                "instance_repair": "_INSTANCE_REPAIR", "stats_repair": "_STATS_REPAIR"}
 
 
 class dev_options:
@@ -805,7 +811,7 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
     # (hb: the bound on |h1| itself, for the backward's dx GEMM, which reads h1 through the norm-1 backward)
     n1 = norm_fwd(part1, N, Ch, P, spec, training, p["n1w"], p["n1b"], *rm(1),
                   bound_part=part1 if (h2ok and _H2_BWD and part1 is not None) else None, want_hb=True,
-                  defer=_DW_VARIANT == 0 and hb.query("uncr_dw_fwd_bn_supported", H, W) == 1)
+                  defer=_DW_VARIANT == 0 and hb.query("uncr_dw_fwd_bn_supported", H, W) == 1, src=h1)
 
     h2 = _act((N, Ch, H, W), x.device, dt)
     slots = hb.query("uncr_dw_slots_fwd", H) if geom is None else _dw_any_slots(geom, False)
@@ -820,7 +826,7 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
         hb.call("uncr_dw_fwd", h1, n1.A, n1.B, p["wdw"].reshape(Ch, 9).contiguous(), h2,
                 part2.buf if part2 is not None else None, N, Ch, H, W, dt, _DW_VARIANT, _stream())
     n2 = norm_fwd(part2 if need else None, N, Ch, P, spec, training, p["n2w"], p["n2b"], *rm(2),
-                  bound_part=part2 if h2ok else None)
+                  bound_part=part2 if h2ok else None, src=h2)
 
     ppool = se_pool(h2, n2.A, n2.B, N * Ch, P)
     pooled, hid_pre, s = _f32((N, Ch), x.device), _f32((N, R), x.device), _f32((N * Ch,), x.device)
@@ -838,7 +844,7 @@ def mbconv_forward(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, training: bo
         return y.view(N, C, H, W), dict(ypool=None, h3=None, dims=(N, C, Ch, R, H, W)), (party if want_out_stats else None)
     h3, part3 = pw_gemm(h2, W2t, N, Ch, C, P, pro=PRO_AFFINE_GELU, k=(n2.A, n2.B, s), epi=1 if need else 0, want_amax=True,
                         in_amax=n2.ub)
-    n3 = norm_fwd(part3, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))
+    n3 = norm_fwd(part3, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3), src=h3)
 
     y = _act((N, C, H, W), x.device, dt)
     ypool = None
@@ -944,7 +950,7 @@ def _mbconv_forward_wide(x: Tensor, p: Dict[str, Tensor], spec: NormSpec, traini
         pw_gemm(h2s[i], pack_wt(w2[:, o:o + n].contiguous(), transpose=True), N, n, C, P, pro=PRO_AFFINE_GELU,
                 k=(n2s[i].A, n2s[i].B, sg[i]), epi=0 if i == 0 else 4, out=h3.view(N, C, P))
     part3 = stats_sq(h3, N * C, P) if need else None
-    n3 = norm_fwd(part3, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3))
+    n3 = norm_fwd(part3, N, C, P, spec, training, p["n3w"], p["n3b"], *rm(3), src=h3)
 
     y = _act((N, C, H, W), dev, dt)
     _, party = ew(EW_RESIDUAL, x, b=h3, out=y, k=(n3.A, n3.B, None, None), want_part=want_out_stats, planes=N * C, P=P)
@@ -1380,7 +1386,7 @@ def inconv_forward(x: Tensor, w: Tensor, b: Tensor, gw: Tensor, gb: Tensor, spec
         return a0, dict(x=x, c0=None, a0=a0, nf=nf, mom=mom, b=bc, dims=(N, Cin, Cout, H, W), geom=_geom_for(P)), parta
     geom = _geom_for(P)
     c0, part = pw_gemm(x, Wt, N, Cin, Cout, P, bias=b.contiguous(), epi=1 if need else 0)
-    nf = norm_fwd(part, N, Cout, P, spec, training, gw, gb, buffers.get("rm"), buffers.get("rv"))
+    nf = norm_fwd(part, N, Cout, P, spec, training, gw, gb, buffers.get("rm"), buffers.get("rv"), src=c0)
     a0 = _act((N, Cout, H, W), x.device, _dt(x))
     _, parta = ew(EW_AFFINE_RELU, c0, out=a0, k=(nf.A, nf.B, None, None), want_part=True, planes=N * Cout, P=P)
     # per-plane means of the norm: pivots of the backward's second statistic, sum du0*(c0 - mean) -- c0 = W x + b of non-negative
@@ -1817,7 +1823,7 @@ def ltae_values_forward(sv_att: dict, pad: Optional[Tensor], p: Dict[str, Tensor
         C = w.shape[0]
         m1, part = pw_gemm(src, pack_wt(w, transpose=True), B, Cprev, C, S, bias=b.contiguous(), epi=1)
         rm, rv = bn_buffers[li] if (li < len(bn_buffers) and bn_buffers[li] is not None) else (None, None)
-        nf = norm_fwd(part, B, C, S, spec, training, bw, bb, rm, rv)
+        nf = norm_fwd(part, B, C, S, spec, training, bw, bb, rm, rv, src=m1)
         r = _f32((B, C, S), dev)
         ew(EW_AFFINE_RELU, m1, out=r, k=(nf.A, nf.B, None, None), want_part=False, planes=B * C, P=S)
         layers.append(dict(x=src, m1=m1, nf=nf, r=r, dims=(Cprev, C)))
