@@ -102,7 +102,13 @@ int uncr_bn_finalize_fwd_sums(const double* sums, double count, int N, int C, co
                               float* running_mean, float* running_var, float momentum, float eps, float* coefA,
                               float* coefB, float* save_mean, float* save_rstd,
                               const float* part, int NP, float* ub /* nullable: as in uncr_norm_finalize_fwd, from the LOCAL partials */,
-                              float* hb /* nullable, needs ub */, hipStream_t stream);
+                              float* hb /* nullable, needs ub */, const double* csums /* nullable: the all-reduced output of uncr_bn_centred_sums */,
+                              hipStream_t stream);
+/* LOCAL centred sums [C][2] doubles = (sum (h - m0), sum (h - m0)^2) of every channel the GLOBAL raw sums put 8 sigma or more from zero
+ * (m0 = the global raw mean in fp32; zeros for every other channel): the host all-reduces them too, and uncr_bn_finalize_fwd_sums takes
+ * those channels' statistics from them (csrc/bn_inline.h: raw moments of fp32 slot sums lose such a set).  src: the normalised tensor */
+int uncr_bn_centred_sums(const double* sums, double count, const void* src, int N, int C, int P, long long stride, int act,
+                         double* out, hipStream_t stream);
 int uncr_bn_finalize_bwd_sums(const double* sums_local, const double* sums_global, double count, int N, int C,
                               const float* gamma, const float* save_mean, const float* save_rstd, float* c1, float* c2,
                               float* c3, float* cmu, float* dgamma, float* dbeta, int centered, hipStream_t stream);

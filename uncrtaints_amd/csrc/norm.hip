@@ -476,16 +476,51 @@ __global__ __launch_bounds__(256) void bn_channel_sums_kernel(const float2* __re
 }
 
 // grid = ceil(C/256): one thread per channel (the work is a handful of flops; N coefficient copies per channel)
+// synchronised BatchNorm: the LOCAL centred sums (S1, S2) = (sum (h - m0), sum (h - m0)^2) of every channel whose GLOBAL raw moments put
+// it 8 sigma or more from zero (m0 = the global raw mean rounded to fp32: every rank decides and pivots alike); zeros for the others.
+// The host all-reduces them like the raw sums; bn_finalize_fwd_sums_kernel then takes the statistics of those channels from them.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_centred_sums_kernel(const double* __restrict__ sums, double M, const T* __restrict__ src,
+                                                              int N, int C, int P, size_t pstride, double* __restrict__ out) {
+    const int c = blockIdx.x;
+    const double mean = sums[2 * c] / M;
+    const double var = fmax(sums[2 * c + 1] / M - mean * mean, 0.0);
+    if (!(mean != 0.0 && var <= ldexp(mean * mean, UNCR_REPAIR_SHIFT))) {       // block-uniform
+        if (threadIdx.x == 0) { out[2 * c] = 0.0; out[2 * c + 1] = 0.0; }
+        return;
+    }
+    double S1, S2;
+    centred_partials<T>(src + (size_t)c * pstride, N, (size_t)C * pstride, P, (float)mean, threadIdx.x, 256, S1, S2);
+    S1 = wave_sum_d(S1);
+    S2 = wave_sum_d(S2);
+    __shared__ double red[8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[2 * w] = S1; red[2 * w + 1] = S2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S1 = S2 = 0.0;
+        for (int i = 0; i < 4; ++i) { S1 += red[2 * i]; S2 += red[2 * i + 1]; }
+        out[2 * c] = S1;
+        out[2 * c + 1] = S2;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_fwd_sums_kernel(
     const double* __restrict__ sums, double M, int N, int C, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
     float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ save_mean,
-    float* __restrict__ save_rstd, const float2* __restrict__ part, int NP, float* __restrict__ ub, float* __restrict__ hb) {
+    float* __restrict__ save_rstd, const float2* __restrict__ part, int NP, float* __restrict__ ub, float* __restrict__ hb,
+    const double* __restrict__ csums /* nullable: the all-reduced bn_centred_sums_kernel output */) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    const double mean = sums[2 * c] / M;
+    double mean = sums[2 * c] / M;
     double var = sums[2 * c + 1] / M - mean * mean;
     if (var < 0) var = 0;
+    if (csums && mean != 0.0 && var <= ldexp(mean * mean, UNCR_REPAIR_SHIFT)) {     // the condition of bn_centred_sums_kernel
+        const double e1 = csums[2 * c] / M;
+        var = fmax(csums[2 * c + 1] / M - e1 * e1, 0.0);
+        mean = (double)(float)mean + e1;
+    }
     const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
     save_mean[c] = mf;
     save_rstd[c] = rf;
@@ -535,14 +570,26 @@ extern "C" int uncr_bn_channel_sums(const float* part, int NP, int N, int C, dou
 extern "C" int uncr_bn_finalize_fwd_sums(const double* sums, double count, int N, int C, const float* gamma,
                                          const float* beta, float* running_mean, float* running_var, float momentum,
                                          float eps, float* coefA, float* coefB, float* save_mean, float* save_rstd,
-                                         const float* part, int NP, float* ub, float* hb, hipStream_t stream) {
+                                         const float* part, int NP, float* ub, float* hb, const double* csums,
+                                         hipStream_t stream) {
     if (!sums || count <= 0 || N <= 0 || C <= 0 || !gamma || !beta || !coefA || !coefB || !save_mean || !save_rstd)
         return UNCR_EINVAL;
     if (ub && (!part || NP <= 0)) return UNCR_EINVAL;
     if (hb && !ub) return UNCR_EINVAL;
     hipLaunchKernelGGL(bn_finalize_fwd_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, count, N, C,
                        gamma, beta, running_mean, running_var, momentum, eps, coefA, coefB, save_mean, save_rstd,
-                       (const float2*)part, NP, ub, hb);
+                       (const float2*)part, NP, ub, hb, csums);
+    UNCR_LAUNCH_CHECK();
+    return UNCR_OK;
+}
+
+extern "C" int uncr_bn_centred_sums(const double* sums, double count, const void* src, int N, int C, int P, long long stride,
+                                    int act, double* out, hipStream_t stream) {
+    if (!sums || !src || !out || count <= 0) return UNCR_EINVAL;
+    if (N <= 0 || C <= 0 || P <= 0 || stride < P) return UNCR_ESHAPE;
+    if (act != UNCR_F32 && act != UNCR_BF16) return UNCR_EINVAL;
+    UNCR_DISPATCH_ACT(act, T, hipLaunchKernelGGL(bn_centred_sums_kernel<T>, dim3(C), dim3(256), 0, stream, sums, count, (const T*)src, N,
+                                                  C, P, (size_t)stride, out));
     UNCR_LAUNCH_CHECK();
     return UNCR_OK;
 }

@@ -384,9 +384,15 @@ def norm_fwd(part: Optional[Part], N: int, C: int, P: int, spec: NormSpec, train
         count = _all_reduce_sums(sums) * N * _pcount(P)
         ub = _f32((N * C,), dev) if (bound_part is part and _H2_FWD) else None
         hbt = _f32((N * C,), dev) if (ub is not None and want_hb) else None
+        csums = None
+        if src is not None and _STATS_REPAIR:
+            # channels the GLOBAL raw sums put 8 sigma or more from zero: local sums about the global mean, a second (small) all-reduce
+            csums = torch.empty((C, 2), device=dev, dtype=torch.float64)
+            hb.call("uncr_bn_centred_sums", sums, count, src, N, C, _pcount(P), P, _dt(src), csums, _stream())
+            _all_reduce_sums(csums)
         hb.call("uncr_bn_finalize_fwd_sums", sums, count, N, C, gamma, beta, running_mean, running_var, float(momentum),
                 float(eps), A, B, mean, rstd, part.buf if ub is not None else None, part.slots if ub is not None else 0, ub, hbt,
-                _stream())
+                csums, _stream())
         return NormFwd(A, B, mean, rstd, kind, groups, sync_count=count, ub=ub, hb=hbt)
     ub = None
     if bound_part is not None and _H2_FWD and (kind != NORM_GROUP or C // groups <= 256):
